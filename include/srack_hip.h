@@ -1,0 +1,202 @@
+/*
+ * srack_hip.h — C ABI of the MI355X batch-render path for s-rack's module-graph evaluator.
+ *
+ * The reference (s-rack v0.3.1, Rust) has no FFI; its operator API for this path is the trait
+ * `SynthModule` (src/synth.rs:222-263) plus the free functions `plan_execution`
+ * (src/synth.rs:128-212) and `execute` (src/synth.rs:97-101).  This header is the flat,
+ * value-typed mirror of exactly that surface: what a Rust host would bind with `extern "C"`
+ * in place of `execute(&plan)` (the binding is shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - every function returns `int`: 0 = ok, < 0 = error (the reference's `Err(())` / panic);
+ *     `srack_last_error()` gives a thread-local message for the last failure.
+ *   - the caller owns every host/device buffer it passes in; the library owns the handle and
+ *     the device-side voice state hanging off it.
+ *   - a handle is not thread-safe: one render at a time per handle (the reference holds the plan
+ *     `Mutex` during `execute`, src/main.rs:60).
+ *   - no callbacks into the host during a render; no torch / C++ types in any signature.
+ *   - module indices are positions in the workspace's `all_modules` list (src/ui.rs:54): the
+ *     planner's result depends on that order (src/synth.rs:193-211), so modules must be added
+ *     in list order.
+ */
+#ifndef SRACK_HIP_H
+#define SRACK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRACK_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------ */
+enum {
+    SRACK_OK              = 0,
+    SRACK_ERR_INVALID     = -1, /* bad handle / argument (reference: panic or Err(())) */
+    SRACK_ERR_PORT        = -2, /* port index out of range: `Err(())` of get_input/set_input/get_output */
+    SRACK_ERR_NO_OUTPUT   = -3, /* no OutputModule in the list: find_output() Err, src/ui.rs:84-96 */
+    SRACK_ERR_SELF_LOOP   = -4, /* module wired to itself: RwLock self-deadlock in the reference (src/synth.rs:99,251) */
+    SRACK_ERR_STATE       = -5, /* call order violated (render before voices are configured, ...) */
+    SRACK_ERR_UNSUPPORTED = -6, /* module type outside the hot-path scope */
+    SRACK_ERR_DEVICE      = -7, /* HIP runtime error; text in srack_last_error() */
+    SRACK_ERR_NOMEM       = -8
+};
+
+/* ---- module types: the ★ rows of the scope table ------------------------------------------ */
+enum {
+    SRACK_MOD_OUTPUT      = 0, /* output::OutputModule        src/synth/output.rs:7-60      */
+    SRACK_MOD_OSCILLATOR  = 1, /* oscillator::OscillatorModule src/synth/oscillator.rs:9-158 */
+    SRACK_MOD_MOOG_FILTER = 2, /* filter::MoogFilterModule    src/synth/filter.rs:11-221    */
+    SRACK_MOD_ADSR        = 3, /* adsr::ADSRModule            src/synth/adsr.rs:7-217       */
+    SRACK_MOD_VCA         = 4, /* vca::VCAModule              src/synth/vca.rs:6-148        */
+    SRACK_MOD_MONO_MIXER  = 5, /* mixer::MonoMixerModule      src/synth/mixer.rs:6-122      */
+    SRACK_MOD_MATH        = 6, /* math::MathModule            src/synth/math.rs:13-160      */
+    SRACK_MOD__COUNT      = 7
+};
+
+/* ---- ports (u8 in the reference) --------------------------------------------------------- */
+enum { SRACK_OSC_IN_CV = 0, SRACK_OSC_IN_SYNC = 1 };                        /* oscillator.rs:164-170 */
+enum { SRACK_OSC_OUT_SINE = 0, SRACK_OSC_OUT_SQUARE = 1, SRACK_OSC_OUT_SAW = 2 }; /* oscillator.rs:90-97 */
+enum { SRACK_VCF_IN_AUDIO = 0, SRACK_VCF_IN_CV = 1 };                       /* filter.rs:113-119 */
+enum { SRACK_VCF_OUT_LOWPASS = 0, SRACK_VCF_OUT_BANDPASS = 1, SRACK_VCF_OUT_HIGHPASS = 2 }; /* filter.rs:166-172 */
+enum { SRACK_ADSR_IN_GATE = 0 };                                            /* adsr.rs:77-82 */
+enum { SRACK_VCA_IN_AUDIO = 0, SRACK_VCA_IN_CV = 1 };                       /* vca.rs:50-56 */
+
+/* ---- fields: the serialisable struct members of each module (params AND runtime state) ---- */
+/* Values travel as double (exact for f32, f64, bool, small ints). `mode`: see SRACK_ADSR_MODE_*. */
+enum { /* OscillatorModule, oscillator.rs:10-24 */
+    SRACK_OSC_VAL = 0,          /* f32, 1 V/oct offset; 0 => 440 Hz */
+    SRACK_OSC_ANTIALIASING = 1, /* bool */
+    SRACK_OSC_POS = 2,          /* f64 phase in [0,1) (state) */
+    SRACK_OSC_SYNC_LAST = 3,    /* bool, TransitionDetector.last (state; starts true, synth.rs:283) */
+    SRACK_OSC__NFIELDS = 4
+};
+enum { /* MoogFilterModule + InternalMoogFilterState, filter.rs:12-56 */
+    SRACK_VCF_FREQ = 0, SRACK_VCF_RES = 1, SRACK_VCF_EXP_AMT = 2,
+    SRACK_VCF_ST_F = 3, SRACK_VCF_ST_P = 4, SRACK_VCF_ST_Q = 5,
+    SRACK_VCF_ST_B0 = 6, SRACK_VCF_ST_B1 = 7, SRACK_VCF_ST_B2 = 8, SRACK_VCF_ST_B3 = 9, SRACK_VCF_ST_B4 = 10,
+    SRACK_VCF_ST_FREQ = 11, SRACK_VCF_ST_RES = 12,
+    SRACK_VCF__NFIELDS = 13
+};
+enum { /* ADSRModule, adsr.rs:8-24 */
+    SRACK_ADSR_A_SEC = 0, SRACK_ADSR_D_SEC = 1, SRACK_ADSR_S_VAL = 2, SRACK_ADSR_R_SEC = 3,
+    SRACK_ADSR_PHASE = 4, SRACK_ADSR_MODE = 5, SRACK_ADSR_R_VAL = 6, SRACK_ADSR_FROM_A_VAL = 7,
+    SRACK_ADSR_SAMPLE_RATE = 8, /* f32 copy taken at new(); NOT refreshed by set_audio_config (adsr.rs:69-71) */
+    SRACK_ADSR_GATE_LAST = 9,   /* TransitionDetector.last */
+    SRACK_ADSR__NFIELDS = 10
+};
+enum { SRACK_ADSR_MODE_ATTACK = 0, SRACK_ADSR_MODE_DECAY = 1, SRACK_ADSR_MODE_SUSTAIN = 2,
+       SRACK_ADSR_MODE_RELEASE = 3, SRACK_ADSR_MODE_NONE = 4 };             /* adsr.rs:27-33 */
+enum { SRACK_VCA_NEGATIVE = 0, SRACK_VCA__NFIELDS = 1 };                    /* vca.rs:14 */
+enum { SRACK_MIX_GAIN0 = 0, SRACK_MIX_GAIN1 = 1, SRACK_MIX_GAIN2 = 2, SRACK_MIX_GAIN3 = 3,
+       SRACK_MIX__NFIELDS = 4 };                                            /* mixer.rs:11 */
+enum { SRACK_MATH_CONSTANT = 0, SRACK_MATH_OPERATION = 1, SRACK_MATH__NFIELDS = 2 }; /* math.rs:21-22 */
+enum { SRACK_MATH_ADD = 0, SRACK_MATH_SUBTRACT = 1, SRACK_MATH_MULTIPLY = 2 };       /* math.rs:7-11 */
+
+/* ---- render flags ------------------------------------------------------------------------- */
+enum {
+    SRACK_RENDER_DEFAULT    = 0,
+    /* oscillator PolyBLEP in f64 with true division and f64 sin/pow, as the reference spells it
+     * (oscillator.rs:43-67,132-152): saw/square bit-identical to the CPU tick, at ~2x VALU cost. */
+    SRACK_RENDER_EXACT_OSC  = 1u << 0,
+    /* never pick a fused chain kernel; run every op through the generic tile interpreter */
+    SRACK_RENDER_NO_FUSION  = 1u << 1,
+    /* do not hoist voice-invariant sub-graphs into the control track; evaluate them per lane */
+    SRACK_RENDER_NO_UNIFORM_HOIST = 1u << 2
+};
+
+typedef struct srack_patch srack_patch; /* opaque: the workspace's module list + plan + device voice state */
+
+/* ---- library ------------------------------------------------------------------------------ */
+int         srack_abi_version(void);
+const char* srack_last_error(void);
+
+/* ---- patch graph (host only; no GPU needed) ----------------------------------------------- */
+/* AudioConfig{sample_rate:u16, buffer_size:usize, channels:u8}, synth.rs:20-25.
+ * sample_rate must fit the reference's u16 (1..65535); buffer_size >= 1 is also the length of a
+ * broken feedback edge's delay; channels = number of OutputModule inputs. */
+int srack_patch_create(uint32_t sample_rate, uint32_t buffer_size, uint32_t channels, srack_patch** out);
+int srack_patch_destroy(srack_patch* p);
+
+/* `Module::new(&audio_config)` with the reference defaults, appended to all_modules.
+ * Returns the module index (>= 0) or an error (< 0). */
+int srack_patch_add_module(srack_patch* p, int module_type);
+int srack_patch_num_modules(const srack_patch* p);
+int srack_patch_module_type(const srack_patch* p, int module);
+int srack_module_num_inputs(const srack_patch* p, int module);  /* SynthModule::get_num_inputs  */
+int srack_module_num_outputs(const srack_patch* p, int module); /* SynthModule::get_num_outputs */
+
+/* field access = the struct members egui sliders / serde touch.  Uniform across voices. */
+int srack_patch_set_field(srack_patch* p, int module, int field, double value);
+int srack_patch_get_field(const srack_patch* p, int module, int field, double* value);
+
+/* SynthModule::set_input / disconnect_input / get_input. */
+int srack_patch_connect(srack_patch* p, int src_module, int src_port, int sink_module, int sink_port);
+int srack_patch_disconnect(srack_patch* p, int sink_module, int sink_port);
+int srack_patch_get_input(const srack_patch* p, int sink_module, int sink_port, int* src_module /* -1 = None */, int* src_port);
+
+/* plan_execution (synth.rs:128-212) driven as the workspace does (ui.rs:63-82): output = first
+ * OutputModule in list order.  Writes the execution order (module indices) to `order` (capacity
+ * `cap`, may be NULL) and returns its length.  Re-run automatically by render when the graph changed. */
+int srack_patch_plan(srack_patch* p, int* order, int cap);
+/* The wires the planner turned into block delays (the removed scheduler edges, synth.rs:176-191):
+ * up to `cap` quadruples (src_module, src_port, sink_module, sink_port); returns the count. */
+int srack_patch_delayed_edges(srack_patch* p, int* quads, int cap);
+
+/* ---- voices: N independent instances of the patch ----------------------------------------- */
+/* Fix the number of voices (lanes) and drop any earlier per-voice data and device state. */
+int srack_voices_configure(srack_patch* p, uint32_t n_voices);
+/* Per-voice override of one field (the only concept with no reference counterpart: the reference
+ * has one instance of each parameter).  `values` has n_voices entries, host memory. */
+int srack_voices_set_field_f32(srack_patch* p, int module, int field, const float* values);
+int srack_voices_set_field_f64(srack_patch* p, int module, int field, const double* values);
+
+/* ---- render (needs the GPU) ---------------------------------------------------------------- */
+/* Number of distinct wires feeding the OutputModule's channels and, per channel, which plane of
+ * `d_frames` it is (-1 = unconnected => silence).  P1/P2 wire both channels to one source => 1 plane. */
+int srack_render_planes(srack_patch* p, int* channel_plane, int cap);
+
+/* Offline render of `n_samples` ticks for every voice, continuing from the current voice state
+ * (first call: the modules' initial state), like calling execute() ceil(n/B) times and keeping
+ * the first n frames (main.rs:59-90).
+ *   d_frames : device, f32 [planes][n_samples][n_voices]  (voice-minor: one wave store = 256 B)
+ *              may be NULL (mix only).
+ *   d_mix    : device, f32 [channels][n_samples] = sum over voices of the channel's frames
+ *              (the N-voice generalisation of MonoMixerModule's gain-1 sum, mixer.rs:109-118);
+ *              may be NULL.
+ *   stream   : hipStream_t (NULL = default stream).  The call is asynchronous w.r.t. the host.
+ */
+int srack_render(srack_patch* p, uint32_t n_samples, float* d_frames, float* d_mix,
+                 uint32_t flags, void* stream);
+
+/* Scratch the render needs for the mix-down partials etc. is owned by the handle; this reports it. */
+int srack_render_info(srack_patch* p, char* buf, size_t cap); /* human-readable: kernel picked, ops, rows */
+
+/* Average duration in ms of the dominant render kernel over the renders since the last call with
+ * reset != 0, measured with HIP events on the render's own stream.  Returns the number of launches
+ * in *n_launches. */
+int srack_render_kernel_ms(srack_patch* p, double* avg_ms, int* n_launches, int reset);
+
+/* Read back one field of every voice's state after a render (host buffer, n_voices doubles). */
+int srack_voices_get_field(srack_patch* p, int module, int field, double* values);
+
+/* ---- device helpers for hosts without a HIP binding ---------------------------------------- */
+int srack_device_count(int* n);
+int srack_device_set(int device);
+int srack_device_alloc(void** d_ptr, size_t bytes);
+int srack_device_free(void* d_ptr);
+int srack_device_to_host(void* h_dst, const void* d_src, size_t bytes, void* stream);
+int srack_device_sync(void* stream);
+
+/* ---- multi-GPU mix-down --------------------------------------------------------------------- */
+/* Voices shard across ranks with no exchange during the render; the only collective is the sum of
+ * the per-rank partial mixes.  `comm` is an RCCL `ncclComm_t` the host created (one rank per GPU);
+ * the call is ncclReduce(sum, f32, root) on `stream`.  In-place on `d_mix`. */
+int srack_dist_reduce_mix(void* comm, float* d_mix, size_t count, int root, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRACK_HIP_H */

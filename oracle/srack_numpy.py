@@ -1,0 +1,358 @@
+"""Second, independent CPU restatement of the s-rack tick (NumPy float32 scalars + Python float64).
+
+TEST INFRASTRUCTURE ONLY — same rule as oracle/srack_oracle.c: never imported by the product.
+
+Why it exists: the reference's own tests pin only the oscillator's sine port and the planner
+order.  Everything else is "parity unpinned" by the reference, so fidelity is argued
+by two restatements written separately (C, and this file) agreeing bit for bit on the same
+patches (tests/test_oracle.py, tests/golden/make_golden.py).  NumPy float32 scalar arithmetic is
+IEEE-exact with no contraction; math.pow / math.sin / math.fmod call the same glibc that Rust's
+f64::powf / sin / % reach on x86_64-linux-gnu.
+
+Written object-style like the reference (one class per module, calc() fills block buffers);
+citations are to /root/reference/src.
+"""
+import math
+
+import numpy as np
+
+f32 = np.float32
+ZERO, ONE, TWO = f32(0.0), f32(1.0), f32(2.0)
+
+
+class TransitionDetector:  # synth.rs:276-298
+    def __init__(self):
+        self.last = True
+
+    def is_transition(self, val):
+        above = bool(val > ZERO)
+        t = above and not self.last
+        self.last = above
+        return t
+
+
+class Module:
+    n_in = 0
+    n_out = 0
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.inputs = [None] * self.n_in  # (module, port) or None
+        self.outs = [np.zeros(cfg["buffer_size"], dtype=f32) for _ in range(self.n_out)]
+
+    def resolve(self, k):  # synth.rs:249-254
+        if self.inputs[k] is None:
+            return None
+        m, port = self.inputs[k]
+        return m.outs[port]
+
+
+class Oscillator(Module):  # oscillator.rs
+    n_in, n_out = 2, 3
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.val = f32(0.0)
+        self.sample_rate = cfg["sample_rate"]
+        self.pos = 0.0
+        self.antialiasing = True
+        self.sync = TransitionDetector()
+
+    @staticmethod
+    def poly_blep(t, dt):  # oscillator.rs:50-67
+        if dt == 0.0:
+            return 0.0
+        if t < dt:
+            t /= dt
+            return t + t - t * t - 1.0
+        elif t > 1.0 - dt:
+            t = (t - 1.0) / dt
+            return t * t + t + t + 1.0
+        return 0.0
+
+    def calc(self):  # oscillator.rs:108-158
+        cv, sync_in = self.resolve(0), self.resolve(1)
+        sine, square, saw = self.outs
+        for i in range(len(sine)):
+            sync_val = sync_in[i] if sync_in is not None else ZERO
+            if self.sync.is_transition(sync_val):
+                self.pos = 0.0
+            if cv is not None:
+                hz = 440.0 * math.pow(2.0, float(cv[i]) + float(self.val))
+            else:
+                hz = 440.0 * math.pow(2.0, float(self.val))
+            delta = hz / float(self.sample_rate)
+            sine[i] = f32(math.sin(self.pos * math.pi * 2.0))
+            lvl = f32(-1.0) if self.pos < 0.5 else f32(1.0)
+            if self.antialiasing:
+                square[i] = lvl - f32(self.poly_blep(self.pos, delta) - self.poly_blep(math.fmod(self.pos + 0.5, 1.0), delta))
+                saw[i] = (f32(self.pos) * TWO - ONE) - f32(self.poly_blep(self.pos, delta))
+            else:
+                square[i] = lvl - ZERO
+                saw[i] = (f32(self.pos) * TWO - ONE) - ZERO
+            self.pos += delta
+            self.pos = math.fmod(self.pos, 1.0)
+
+
+class MoogFilter(Module):  # filter.rs
+    n_in, n_out = 2, 3
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.freq, self.res, self.exp_amt = f32(0.2), f32(0.5), f32(0.5)
+        self.f = self.p = self.q = ZERO
+        self.b = [ZERO] * 5
+        self.sfreq = self.sres = ZERO
+
+    def state_calc(self, x, frequency, res):  # filter.rs:58-92
+        if frequency != self.sfreq or res != self.sres:
+            self.sfreq, self.sres = frequency, res
+            self.q = ONE - self.sfreq
+            self.p = self.sfreq + f32(0.8) * self.sfreq * self.q
+            self.f = self.p * TWO - ONE
+            self.q = self.sres * (ONE + f32(0.5) * self.q * (ONE - self.q + f32(5.6) * self.q * self.q))
+        b = self.b
+        x = x - (self.q * b[4])
+        t1 = b[1]
+        b[1] = (x + b[0]) * self.p - b[1] * self.f
+        t2 = b[2]
+        b[2] = (b[1] + t1) * self.p - b[2] * self.f
+        t1 = b[3]
+        b[3] = (b[2] + t2) * self.p - b[3] * self.f
+        b[4] = (b[3] + t1) * self.p - b[4] * self.f
+        b[4] = b[4] - (b[4] * b[4] * b[4]) * f32(0.166667)
+        b[0] = x
+        for k in range(5):
+            b[k] = max(min(b[k], ONE), f32(-1.0))
+        return b[4], x - b[4], f32(3.0) * (b[3] - b[4])
+
+    def calc(self):  # filter.rs:182-221
+        audio_in, cv_in = self.resolve(0), self.resolve(1)
+        lowpass, bandpass, highpass = self.outs
+        res = min(max(self.res, ZERO), ONE)
+        for idx in range(len(lowpass)):
+            audio = audio_in[idx] if audio_in is not None else ZERO
+            cv = cv_in[idx] if cv_in is not None else ZERO
+            frequency = min(max(self.freq + cv * self.exp_amt, ZERO), f32(0.9))
+            lowpass[idx], highpass[idx], bandpass[idx] = self.state_calc(audio, frequency, res)
+
+
+ATTACK, DECAY, SUSTAIN, RELEASE, NONE = range(5)  # adsr.rs:27-33
+
+
+class ADSR(Module):  # adsr.rs
+    n_in, n_out = 1, 1
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.a_sec, self.d_sec, self.s_val, self.r_sec = f32(0.0), f32(0.5), f32(0.25), f32(0.5)
+        self.phase = ZERO
+        self.mode = NONE
+        self.r_val = self.from_a_val = ZERO
+        self.sample_rate = f32(cfg["sample_rate"])
+        self.td = TransitionDetector()
+
+    def calc(self):  # adsr.rs:134-217
+        gate = self.resolve(0)
+        out = self.outs[0]
+        with np.errstate(divide="ignore"):
+            for idx in range(len(out)):
+                is_transition = self.td.is_transition(gate[idx] if gate is not None else ZERO)
+                high = gate is not None and bool(gate[idx] > ZERO)
+                if self.mode == NONE:
+                    if high:
+                        self.phase, self.mode = ZERO, ATTACK
+                elif self.mode == ATTACK:
+                    self.phase = self.phase + ONE / (self.sample_rate * self.a_sec)
+                    if self.phase >= ONE:
+                        self.phase, self.mode = ZERO, DECAY
+                    elif is_transition:
+                        self.phase = ZERO
+                        self.r_val = self.from_a_val
+                elif self.mode == DECAY:
+                    self.phase = self.phase + ONE / (self.sample_rate * self.d_sec)
+                    if self.phase >= ONE:
+                        self.phase, self.mode = ZERO, SUSTAIN
+                    if is_transition:
+                        self.phase, self.mode = ZERO, ATTACK
+                elif self.mode == SUSTAIN:
+                    if not high:
+                        self.phase, self.mode = ZERO, RELEASE
+                    if is_transition:
+                        self.phase, self.mode = ZERO, ATTACK
+                elif self.mode == RELEASE:
+                    if high:
+                        self.phase, self.mode = ZERO, ATTACK
+                    self.phase = self.phase + ONE / (self.sample_rate * self.r_sec)
+                    if self.phase >= ONE:
+                        self.phase, self.r_val, self.mode = ZERO, ZERO, NONE
+                if self.mode == NONE:
+                    o = ZERO
+                elif self.mode == ATTACK:
+                    o = self.r_val + (ONE - self.r_val) * self.phase
+                elif self.mode == DECAY:
+                    o = self.s_val + (ONE - self.s_val) * (ONE - self.phase)
+                elif self.mode == SUSTAIN:
+                    o = self.s_val
+                else:
+                    o = self.s_val * (ONE - self.phase)
+                out[idx] = o
+                if self.mode != ATTACK:
+                    self.r_val = out[idx]
+                else:
+                    self.from_a_val = out[idx]
+
+
+class VCA(Module):  # vca.rs:117-148
+    n_in, n_out = 2, 1
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.negative = False
+
+    def calc(self):
+        audio, cv = self.resolve(0), self.resolve(1)
+        out = self.outs[0]
+        if audio is not None and cv is not None:
+            for i in range(len(out)):
+                out[i] = audio[i] * cv[i] if (self.negative or cv[i] > ZERO) else ZERO
+        else:
+            out[:] = ZERO
+
+
+class MonoMixer(Module):  # mixer.rs:101-122
+    n_in, n_out = 4, 1
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.gain = [ONE] * 4
+
+    def calc(self):
+        out = self.outs[0]
+        out[:] = ZERO
+        for k in range(4):
+            buf = self.resolve(k)
+            if buf is None:
+                continue
+            for i in range(len(out)):
+                out[i] = out[i] + buf[i] * self.gain[k]
+
+
+ADD, SUBTRACT, MULTIPLY = range(3)
+
+
+class Math(Module):  # math.rs:139-160
+    n_in, n_out = 2, 1
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.constant = ZERO
+        self.operation = ADD
+
+    def calc(self):
+        i1, i2 = self.resolve(0), self.resolve(1)
+        out = self.outs[0]
+        for i in range(len(out)):
+            a = i1[i] if i1 is not None else ZERO
+            b = i2[i] if i2 is not None else self.constant
+            out[i] = a + b if self.operation == ADD else (a - b if self.operation == SUBTRACT else a * b)
+
+
+class Output(Module):  # output.rs:46-60
+    def __init__(self, cfg):
+        self.n_in = cfg["channels"]
+        super().__init__(cfg)
+        self.outs = [np.zeros(cfg["buffer_size"], dtype=f32) for _ in range(cfg["channels"])]  # bufs
+
+    def calc(self):
+        for c in range(self.n_in):
+            buf = self.resolve(c)
+            if buf is not None:
+                self.outs[c][:] = buf
+            else:
+                self.outs[c][:] = ZERO
+
+
+CLASSES = [Output, Oscillator, MoogFilter, ADSR, VCA, MonoMixer, Math]  # index = SRACK_MOD_*
+
+
+def get_inputs(m):  # synth.rs:214-218
+    return [m.inputs[k] for k in range(m.n_in)]
+
+
+def is_loop(module, edges):  # synth.rs:107-126
+    to_search, visited = [module], set()
+    while True:
+        current = next((m for m in to_search if id(m) not in visited), None)
+        if current is None:
+            return None
+        visited.add(id(current))
+        to_add = []
+        for dep in edges[id(current)]:
+            if dep is module:
+                return current
+            to_add.append(dep)
+        to_search.extend(to_add)
+
+
+def plan_execution(output, all_modules):  # synth.rs:128-212
+    edges, visited = {}, set()
+    to_search = list(all_modules) + [output]
+    while to_search:
+        module = to_search.pop()
+        if id(module) in visited:
+            continue
+        visited.add(id(module))
+        srcs = []
+        for inp in get_inputs(module):
+            if inp is not None:
+                to_search.append(inp[0])
+                srcs.append(inp[0])
+        edges[id(module)] = srcs
+    to_search = list(all_modules) + [output]
+    visited = set()
+    removed = []
+    while to_search:
+        module = to_search.pop()
+        if id(module) in visited:
+            continue
+        visited.add(id(module))
+        to_search.extend(edges[id(module)])
+        while True:
+            frm = is_loop(module, edges)
+            if frm is None:
+                break
+            edges[id(frm)] = [m for m in edges[id(frm)] if m is not module]
+            removed.append((frm, module))
+    visited = set()
+    plan = []
+    while True:
+        node = next((m for m in all_modules if id(m) not in visited and all(id(d) in visited for d in edges[id(m)])), None)
+        if node is None:
+            break
+        visited.add(id(node))
+        plan.append(node)
+    return plan, removed
+
+
+def execute(plan):  # synth.rs:97-101
+    for m in plan:
+        m.calc()
+
+
+def render(modules, n_samples, cfg, tap=None):
+    """Offline counterpart of the audio callback (main.rs:59-90). -> [channels][n_samples]."""
+    output = next((m for m in modules if isinstance(m, Output)), None)  # ui.rs:84-96
+    plan, _ = plan_execution(output, modules) if output is not None else ([], [])
+    B = cfg["buffer_size"]
+    out = np.zeros((cfg["channels"], n_samples), dtype=f32)
+    tapped = np.zeros(n_samples, dtype=f32) if tap is not None else None
+    for base in range(0, n_samples, B):
+        execute(plan)
+        n = min(B, n_samples - base)
+        if output is not None:
+            for c in range(cfg["channels"]):
+                out[c, base:base + n] = output.outs[c][:n]
+        if tap is not None:
+            tapped[base:base + n] = tap[0].outs[tap[1]][:n]
+    return (out, tapped) if tap is not None else out

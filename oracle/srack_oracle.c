@@ -1,0 +1,903 @@
+/*
+ * srack_oracle.c — CPU restatement of s-rack's tick loop.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (s-rack_amd/) never links, imports or calls it.
+ *
+ * The reference (s-rack v0.3.1) is Rust and cannot be built in this image (no rustc/cargo,
+ * 478 crates.io dependencies, no network), so this is a restatement, not the reference binary.
+ * PARITY PINNING: the reference's own tests pin only (1) the oscillator's sine port at
+ * sr=1760/B=17 (src/synth/oscillator.rs:284-305) and (2) planner ordering incl. one 2-cycle
+ * (src/synth.rs:537-613); both are replayed against this file in tests/test_oracle.py.  For
+ * saw/square/PolyBLEP, the ladder filter, ADSR, VCA, mixer, math and output the reference holds
+ * no known-answer vector, so for those "parity unpinned" by the reference: fidelity rests on
+ * this file and the independent NumPy restatement (oracle/srack_numpy.py) agreeing bit for bit.
+ *
+ * Structure follows the reference, not the GPU path: one object graph, per-port block buffers of
+ * `buffer_size` f32 (zero-initialised, synth.rs:31-33), module-major execute() (synth.rs:97-101),
+ * inputs resolved by reading the source module's buffer at calc() time (synth.rs:249-254) — so a
+ * feedback edge the planner broke is a buffer_size-sample delay with no extra code, exactly as in
+ * the reference.
+ *
+ * Rust -> C mapping that keeps bits equal on x86_64-linux-gnu: f64::powf -> pow,
+ * f64::sin -> sin, f64 % -> fmod, f32::powi(3) -> x*x*x, f32::min/max -> fminf/fmaxf,
+ * `as f32` -> (float).  Build with -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/srack_hip.h" /* enum vocabulary only (module types, fields, ports) */
+
+#define OR_MAX_IN 8
+#define OR_MAX_OUT 8
+
+typedef struct {
+    int src; /* module index, -1 = None */
+    int port;
+} or_input;
+
+/* synth.rs:276-298 */
+typedef struct {
+    int last;
+} or_transition_detector;
+
+static int or_is_transition(or_transition_detector* d, float val)
+{
+    int above = val > 0.0f;              /* synth.rs:286-288 */
+    int is_transition = above && !d->last; /* synth.rs:294 */
+    d->last = above;
+    return is_transition;
+}
+
+typedef struct {
+    /* oscillator.rs:10-24 */
+    float val;
+    uint16_t sample_rate;
+    double pos;
+    int antialiasing;
+    or_transition_detector sync_detector;
+} or_osc;
+
+typedef struct {
+    /* filter.rs:21-24, 49-56 */
+    float freq, res, exp_amt;
+    float f, p, q, b[5], sfreq, sres;
+} or_vcf;
+
+typedef struct {
+    /* adsr.rs:8-24 */
+    float a_sec, d_sec, s_val, r_sec, phase;
+    int mode;
+    float r_val, from_a_val, sample_rate;
+    or_transition_detector td;
+} or_adsr;
+
+typedef struct {
+    int type;
+    int n_in, n_out;
+    or_input in[OR_MAX_IN];
+    float* out[OR_MAX_OUT]; /* n_out buffers of B floats; OutputModule keeps its `bufs` here too */
+    union {
+        or_osc osc;
+        or_vcf vcf;
+        or_adsr adsr;
+        struct { int negative; } vca;
+        struct { float gain[4]; } mix;
+        struct { float constant; int operation; } math;
+    } u;
+} or_module;
+
+typedef struct or_patch {
+    uint32_t sample_rate, buffer_size, channels;
+    int n_modules, cap_modules;
+    or_module* modules;
+    int* plan;
+    int n_plan;
+    int plan_valid;
+    int output; /* index of the OutputModule used by the last plan, -1 if none */
+    /* removed scheduler edges recorded by the planner: (from, module) pairs */
+    int* removed;
+    int n_removed;
+} or_patch;
+
+/* ------------------------------------------------------------------------------------------ */
+
+or_patch* or_patch_new(uint32_t sample_rate, uint32_t buffer_size, uint32_t channels)
+{
+    or_patch* p = (or_patch*)calloc(1, sizeof(or_patch));
+    p->sample_rate = sample_rate;
+    p->buffer_size = buffer_size;
+    p->channels = channels;
+    p->output = -1;
+    return p;
+}
+
+void or_patch_free(or_patch* p)
+{
+    if (!p) return;
+    for (int i = 0; i < p->n_modules; i++)
+        for (int k = 0; k < OR_MAX_OUT; k++) free(p->modules[i].out[k]);
+    free(p->modules);
+    free(p->plan);
+    free(p->removed);
+    free(p);
+}
+
+static float* or_new_buffer(const or_patch* p)
+{
+    return (float*)calloc(p->buffer_size, sizeof(float)); /* AudioBuffer::new, synth.rs:31-33 */
+}
+
+/* Module::new(&audio_config) with the reference defaults. */
+int or_add_module(or_patch* p, int type)
+{
+    if (p->n_modules == p->cap_modules) {
+        p->cap_modules = p->cap_modules ? p->cap_modules * 2 : 16;
+        p->modules = (or_module*)realloc(p->modules, sizeof(or_module) * (size_t)p->cap_modules);
+    }
+    or_module* m = &p->modules[p->n_modules];
+    memset(m, 0, sizeof(*m));
+    m->type = type;
+    for (int k = 0; k < OR_MAX_IN; k++) m->in[k].src = -1;
+    switch (type) {
+    case SRACK_MOD_OUTPUT: /* output.rs:15-23 */
+        if (p->channels > OR_MAX_IN) return -1;
+        m->n_in = (int)p->channels;
+        m->n_out = 0;
+        for (uint32_t c = 0; c < p->channels; c++) m->out[c] = or_new_buffer(p); /* bufs */
+        break;
+    case SRACK_MOD_OSCILLATOR: /* oscillator.rs:27-41 */
+        m->n_in = 2;
+        m->n_out = 3;
+        m->u.osc.val = 0.0f;
+        m->u.osc.sample_rate = (uint16_t)p->sample_rate;
+        m->u.osc.pos = 0.0;
+        m->u.osc.antialiasing = 1;
+        m->u.osc.sync_detector.last = 1; /* synth.rs:283 */
+        break;
+    case SRACK_MOD_MOOG_FILTER: /* filter.rs:28-41, state Default => zeros */
+        m->n_in = 2;
+        m->n_out = 3;
+        m->u.vcf.freq = 0.2f;
+        m->u.vcf.res = 0.5f;
+        m->u.vcf.exp_amt = 0.5f;
+        break;
+    case SRACK_MOD_ADSR: /* adsr.rs:36-53 */
+        m->n_in = 1;
+        m->n_out = 1;
+        m->u.adsr.a_sec = 0.0f;
+        m->u.adsr.d_sec = 0.5f;
+        m->u.adsr.s_val = 0.25f;
+        m->u.adsr.r_sec = 0.5f;
+        m->u.adsr.phase = 0.0f;
+        m->u.adsr.mode = SRACK_ADSR_MODE_NONE;
+        m->u.adsr.r_val = 0.0f;
+        m->u.adsr.from_a_val = 0.0f;
+        m->u.adsr.sample_rate = (float)(uint16_t)p->sample_rate;
+        m->u.adsr.td.last = 1;
+        break;
+    case SRACK_MOD_VCA: /* vca.rs:18-26 */
+        m->n_in = 2;
+        m->n_out = 1;
+        m->u.vca.negative = 0;
+        break;
+    case SRACK_MOD_MONO_MIXER: /* mixer.rs:16-23 */
+        m->n_in = 4;
+        m->n_out = 1;
+        for (int k = 0; k < 4; k++) m->u.mix.gain[k] = 1.0f;
+        break;
+    case SRACK_MOD_MATH: /* math.rs:26-35 */
+        m->n_in = 2;
+        m->n_out = 1;
+        m->u.math.constant = 0.0f;
+        m->u.math.operation = SRACK_MATH_ADD;
+        break;
+    default:
+        return -1;
+    }
+    if (type != SRACK_MOD_OUTPUT)
+        for (int k = 0; k < m->n_out; k++) m->out[k] = or_new_buffer(p);
+    p->plan_valid = 0;
+    return p->n_modules++;
+}
+
+int or_num_modules(const or_patch* p) { return p->n_modules; }
+
+/* SynthModule::set_input: Err(()) on a bad port index. */
+int or_connect(or_patch* p, int src, int src_port, int sink, int sink_port)
+{
+    if (src < 0 || src >= p->n_modules || sink < 0 || sink >= p->n_modules) return -1;
+    or_module* m = &p->modules[sink];
+    if (sink_port < 0 || sink_port >= m->n_in) return -2;
+    /* the reference stores any src_port and only fails later in get_output (panic); reject early */
+    if (src_port < 0 || src_port >= p->modules[src].n_out) return -2;
+    m->in[sink_port].src = src;
+    m->in[sink_port].port = src_port;
+    p->plan_valid = 0;
+    return 0;
+}
+
+int or_disconnect(or_patch* p, int sink, int sink_port)
+{
+    if (sink < 0 || sink >= p->n_modules) return -1;
+    or_module* m = &p->modules[sink];
+    if (sink_port < 0 || sink_port >= m->n_in) return -2;
+    m->in[sink_port].src = -1;
+    p->plan_valid = 0;
+    return 0;
+}
+
+static double* or_field_f64(or_module* m, int field) { return (m->type == SRACK_MOD_OSCILLATOR && field == SRACK_OSC_POS) ? &m->u.osc.pos : NULL; }
+
+static float* or_field_f32(or_module* m, int field)
+{
+    switch (m->type) {
+    case SRACK_MOD_OSCILLATOR:
+        if (field == SRACK_OSC_VAL) return &m->u.osc.val;
+        break;
+    case SRACK_MOD_MOOG_FILTER: {
+        or_vcf* v = &m->u.vcf;
+        switch (field) {
+        case SRACK_VCF_FREQ: return &v->freq;
+        case SRACK_VCF_RES: return &v->res;
+        case SRACK_VCF_EXP_AMT: return &v->exp_amt;
+        case SRACK_VCF_ST_F: return &v->f;
+        case SRACK_VCF_ST_P: return &v->p;
+        case SRACK_VCF_ST_Q: return &v->q;
+        case SRACK_VCF_ST_B0: case SRACK_VCF_ST_B1: case SRACK_VCF_ST_B2: case SRACK_VCF_ST_B3: case SRACK_VCF_ST_B4:
+            return &v->b[field - SRACK_VCF_ST_B0];
+        case SRACK_VCF_ST_FREQ: return &v->sfreq;
+        case SRACK_VCF_ST_RES: return &v->sres;
+        }
+        break;
+    }
+    case SRACK_MOD_ADSR: {
+        or_adsr* a = &m->u.adsr;
+        switch (field) {
+        case SRACK_ADSR_A_SEC: return &a->a_sec;
+        case SRACK_ADSR_D_SEC: return &a->d_sec;
+        case SRACK_ADSR_S_VAL: return &a->s_val;
+        case SRACK_ADSR_R_SEC: return &a->r_sec;
+        case SRACK_ADSR_PHASE: return &a->phase;
+        case SRACK_ADSR_R_VAL: return &a->r_val;
+        case SRACK_ADSR_FROM_A_VAL: return &a->from_a_val;
+        case SRACK_ADSR_SAMPLE_RATE: return &a->sample_rate;
+        }
+        break;
+    }
+    case SRACK_MOD_MONO_MIXER:
+        if (field >= SRACK_MIX_GAIN0 && field <= SRACK_MIX_GAIN3) return &m->u.mix.gain[field];
+        break;
+    case SRACK_MOD_MATH:
+        if (field == SRACK_MATH_CONSTANT) return &m->u.math.constant;
+        break;
+    }
+    return NULL;
+}
+
+static int* or_field_int(or_module* m, int field)
+{
+    switch (m->type) {
+    case SRACK_MOD_OSCILLATOR:
+        if (field == SRACK_OSC_ANTIALIASING) return &m->u.osc.antialiasing;
+        if (field == SRACK_OSC_SYNC_LAST) return &m->u.osc.sync_detector.last;
+        break;
+    case SRACK_MOD_ADSR:
+        if (field == SRACK_ADSR_MODE) return &m->u.adsr.mode;
+        if (field == SRACK_ADSR_GATE_LAST) return &m->u.adsr.td.last;
+        break;
+    case SRACK_MOD_VCA:
+        if (field == SRACK_VCA_NEGATIVE) return &m->u.vca.negative;
+        break;
+    case SRACK_MOD_MATH:
+        if (field == SRACK_MATH_OPERATION) return &m->u.math.operation;
+        break;
+    }
+    return NULL;
+}
+
+int or_set_field(or_patch* p, int module, int field, double value)
+{
+    if (module < 0 || module >= p->n_modules) return -1;
+    or_module* m = &p->modules[module];
+    double* d = or_field_f64(m, field);
+    if (d) { *d = value; return 0; }
+    float* f = or_field_f32(m, field);
+    if (f) { *f = (float)value; return 0; }
+    int* i = or_field_int(m, field);
+    if (i) { *i = (int)value; return 0; }
+    return -1;
+}
+
+int or_get_field(or_patch* p, int module, int field, double* value)
+{
+    if (module < 0 || module >= p->n_modules) return -1;
+    or_module* m = &p->modules[module];
+    double* d = or_field_f64(m, field);
+    if (d) { *value = *d; return 0; }
+    float* f = or_field_f32(m, field);
+    if (f) { *value = (double)*f; return 0; }
+    int* i = or_field_int(m, field);
+    if (i) { *value = (double)*i; return 0; }
+    return -1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* plan_execution, synth.rs:107-212.  Modules are identified by index instead of Arc address.   */
+
+typedef struct {
+    int* v;
+    int n, cap;
+} ivec;
+
+static void iv_push(ivec* a, int x)
+{
+    if (a->n == a->cap) {
+        a->cap = a->cap ? a->cap * 2 : 8;
+        a->v = (int*)realloc(a->v, sizeof(int) * (size_t)a->cap);
+    }
+    a->v[a->n++] = x;
+}
+
+static void iv_remove(ivec* a, int idx)
+{
+    memmove(a->v + idx, a->v + idx + 1, sizeof(int) * (size_t)(a->n - idx - 1));
+    a->n--;
+}
+
+/* synth.rs:107-126.  Returns the module `from` that lists `module` as a dependency, or -1. */
+static int or_is_loop(int module, const ivec* edges, int n_modules)
+{
+    ivec to_search = {0}, to_add = {0};
+    char* visited = (char*)calloc((size_t)n_modules, 1);
+    int result = -1;
+    iv_push(&to_search, module);
+    for (;;) {
+        /* to_search.iter().find(|m| visited.get(m).is_none()) : first unvisited in list order */
+        int current = -1;
+        for (int i = 0; i < to_search.n; i++)
+            if (!visited[to_search.v[i]]) { current = to_search.v[i]; break; }
+        if (current < 0) break;
+        visited[current] = 1;
+        for (int k = 0; k < edges[current].n; k++) {
+            int dependency = edges[current].v[k];
+            if (dependency == module) { result = current; goto done; }
+            iv_push(&to_add, dependency);
+        }
+        for (int k = 0; k < to_add.n; k++) iv_push(&to_search, to_add.v[k]); /* append(&mut to_add) */
+        to_add.n = 0;
+    }
+done:
+    free(to_search.v);
+    free(to_add.v);
+    free(visited);
+    return result;
+}
+
+/* `all_modules` is an explicit list of module indices (the test shuffles it, synth.rs:567). */
+int or_plan_list(or_patch* p, int output, const int* all_modules, int n_all)
+{
+    int n = p->n_modules;
+    ivec* edges = (ivec*)calloc((size_t)n, sizeof(ivec)); /* K: sink, V: sources */
+    char* visited = (char*)calloc((size_t)n, 1);
+    ivec to_search = {0};
+    /* phase 1: create all edges (synth.rs:134-163) */
+    for (int i = 0; i < n_all; i++) iv_push(&to_search, all_modules[i]);
+    iv_push(&to_search, output);
+    while (to_search.n) {
+        int module = to_search.v[--to_search.n];
+        if (visited[module]) continue;
+        visited[module] = 1;
+        const or_module* m = &p->modules[module];
+        for (int k = 0; k < m->n_in; k++) { /* get_inputs: input-index order, None filtered */
+            if (m->in[k].src < 0) continue;
+            iv_push(&to_search, m->in[k].src);
+            iv_push(&edges[module], m->in[k].src);
+        }
+    }
+    /* phase 2: remove cycles (synth.rs:164-192) */
+    free(p->removed);
+    p->removed = NULL;
+    p->n_removed = 0;
+    ivec removed = {0};
+    memset(visited, 0, (size_t)n);
+    for (int i = 0; i < n_all; i++) iv_push(&to_search, all_modules[i]);
+    iv_push(&to_search, output);
+    while (to_search.n) {
+        int module = to_search.v[--to_search.n];
+        if (visited[module]) continue;
+        visited[module] = 1;
+        for (int k = 0; k < edges[module].n; k++) iv_push(&to_search, edges[module].v[k]);
+        int from;
+        while ((from = or_is_loop(module, edges, n)) >= 0) {
+            for (;;) { /* remove every `module` entry from edges[from] (synth.rs:179-190) */
+                int idx = -1;
+                for (int k = 0; k < edges[from].n; k++)
+                    if (edges[from].v[k] == module) { idx = k; break; }
+                if (idx < 0) break;
+                iv_remove(&edges[from], idx);
+            }
+            iv_push(&removed, from);
+            iv_push(&removed, module);
+        }
+    }
+    /* phase 3: repeatedly take the first unvisited list entry whose dependencies are all
+     * visited (synth.rs:193-211) */
+    memset(visited, 0, (size_t)n);
+    free(p->plan);
+    p->plan = (int*)malloc(sizeof(int) * (size_t)(n_all > 0 ? n_all : 1));
+    p->n_plan = 0;
+    for (;;) {
+        int node = -1;
+        for (int i = 0; i < n_all && node < 0; i++) {
+            int m = all_modules[i];
+            if (visited[m]) continue;
+            int ready = 1;
+            for (int k = 0; k < edges[m].n; k++)
+                if (!visited[edges[m].v[k]]) { ready = 0; break; }
+            if (ready) node = m;
+        }
+        if (node < 0) break;
+        visited[node] = 1;
+        p->plan[p->n_plan++] = node;
+    }
+    p->removed = removed.v;
+    p->n_removed = removed.n / 2;
+    p->output = output;
+    p->plan_valid = 1;
+    for (int i = 0; i < n; i++) free(edges[i].v);
+    free(edges);
+    free(visited);
+    free(to_search.v);
+    return p->n_plan;
+}
+
+/* The workspace's plan(): output = first OutputModule in list order (ui.rs:63-96). */
+int or_plan(or_patch* p)
+{
+    int output = -1;
+    for (int i = 0; i < p->n_modules; i++)
+        if (p->modules[i].type == SRACK_MOD_OUTPUT) { output = i; break; }
+    if (output < 0) { /* ui.rs:75-79: plan cleared */
+        p->n_plan = 0;
+        p->output = -1;
+        p->plan_valid = 1;
+        return 0;
+    }
+    int* all = (int*)malloc(sizeof(int) * (size_t)p->n_modules);
+    for (int i = 0; i < p->n_modules; i++) all[i] = i;
+    int r = or_plan_list(p, output, all, p->n_modules);
+    free(all);
+    return r;
+}
+
+int or_get_plan(const or_patch* p, int* order, int cap)
+{
+    for (int i = 0; i < p->n_plan && i < cap; i++) order[i] = p->plan[i];
+    return p->n_plan;
+}
+
+/* (from, module) pairs: every wire module.out -> from.in became a block delay. */
+int or_get_removed_edges(const or_patch* p, int* pairs, int cap)
+{
+    for (int i = 0; i < p->n_removed && i < cap; i++) {
+        pairs[2 * i] = p->removed[2 * i];
+        pairs[2 * i + 1] = p->removed[2 * i + 1];
+    }
+    return p->n_removed;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* calc() bodies                                                                                */
+
+/* resolve_input (synth.rs:249-254): the source's output buffer as it is *now*, or None. */
+static const float* or_resolve(const or_patch* p, const or_module* m, int k)
+{
+    if (m->in[k].src < 0) return NULL;
+    return p->modules[m->in[k].src].out[m->in[k].port];
+}
+
+/* oscillator.rs:50-67 */
+static double or_poly_blep(double t, double dt)
+{
+    if (dt == 0.0) return 0.0;
+    if (t < dt) {
+        t /= dt;
+        return t + t - t * t - 1.0;
+    } else if (t > 1.0 - dt) {
+        t = (t - 1.0) / dt;
+        return t * t + t + t + 1.0;
+    }
+    return 0.0;
+}
+
+/* oscillator.rs:108-158 */
+static void or_calc_osc(or_patch* p, or_module* m)
+{
+    static const double PI = 3.14159265358979323846264338327950288; /* std::f64::consts::PI */
+    or_osc* o = &m->u.osc;
+    const float* cv = or_resolve(p, m, 0);
+    const float* sync_in = or_resolve(p, m, 1);
+    float* sine = m->out[0];
+    float* square = m->out[1];
+    float* saw = m->out[2];
+    for (uint32_t i = 0; i < p->buffer_size; i++) {
+        float sync_val = sync_in ? sync_in[i] : 0.0f;
+        if (or_is_transition(&o->sync_detector, sync_val)) o->pos = 0.0;
+        /* get_freq_in_hz, oscillator.rs:43-48 */
+        double hz = cv ? 440.0 * pow(2.0, (double)cv[i] + (double)o->val) : 440.0 * pow(2.0, (double)o->val);
+        double delta = hz / (double)o->sample_rate;
+        sine[i] = (float)sin(o->pos * PI * 2.0);
+        square[i] = (o->pos < 0.5 ? -1.0f : 1.0f) -
+                    (o->antialiasing ? (float)(or_poly_blep(o->pos, delta) - or_poly_blep(fmod(o->pos + 0.5, 1.0), delta)) : 0.0f);
+        saw[i] = ((float)o->pos * 2.0f - 1.0f) - (o->antialiasing ? (float)or_poly_blep(o->pos, delta) : 0.0f);
+        o->pos += delta;
+        o->pos = fmod(o->pos, 1.0);
+    }
+}
+
+/* filter.rs:58-92 */
+static void or_vcf_state_calc(or_vcf* s, float input, float frequency, float res, float* lowpass, float* highpass, float* bandpass)
+{
+    if (frequency != s->sfreq || res != s->sres) {
+        s->sfreq = frequency;
+        s->sres = res;
+        s->q = 1.0f - s->sfreq;
+        s->p = s->sfreq + 0.8f * s->sfreq * s->q;
+        s->f = s->p * 2.0f - 1.0f;
+        s->q = s->sres * (1.0f + 0.5f * s->q * (1.0f - s->q + 5.6f * s->q * s->q));
+    }
+    input = input - (s->q * s->b[4]);
+    float t1, t2;
+    t1 = s->b[1];
+    s->b[1] = (input + s->b[0]) * s->p - s->b[1] * s->f;
+    t2 = s->b[2];
+    s->b[2] = (s->b[1] + t1) * s->p - s->b[2] * s->f;
+    t1 = s->b[3];
+    s->b[3] = (s->b[2] + t2) * s->p - s->b[3] * s->f;
+    s->b[4] = (s->b[3] + t1) * s->p - s->b[4] * s->f;
+    s->b[4] = s->b[4] - (s->b[4] * s->b[4] * s->b[4]) * 0.166667f; /* powi(3) */
+    s->b[0] = input;
+    for (int k = 0; k < 5; k++) s->b[k] = fmaxf(fminf(s->b[k], 1.0f), -1.0f); /* clamp_buffers */
+    *lowpass = s->b[4];
+    *highpass = input - s->b[4];
+    *bandpass = 3.0f * (s->b[3] - s->b[4]);
+}
+
+/* filter.rs:182-221.  Port 0 lowpass, 1 bandpass, 2 highpass (filter.rs:166-172); the tuple
+ * (b4, in-b4, 3(b3-b4)) is assigned to (lowpass, highpass, bandpass) (filter.rs:211). */
+static void or_calc_vcf(or_patch* p, or_module* m)
+{
+    or_vcf* v = &m->u.vcf;
+    const float* audio_in = or_resolve(p, m, 0);
+    const float* cv_in = or_resolve(p, m, 1);
+    float* lowpass = m->out[0];
+    float* bandpass = m->out[1];
+    float* highpass = m->out[2];
+    for (uint32_t idx = 0; idx < p->buffer_size; idx++) {
+        float audio = audio_in ? audio_in[idx] : 0.0f;
+        float cv = cv_in ? cv_in[idx] : 0.0f;
+        or_vcf_state_calc(v, audio, fminf(fmaxf(v->freq + cv * v->exp_amt, 0.0f), 0.9f), fminf(fmaxf(v->res, 0.0f), 1.0f),
+                          &lowpass[idx], &highpass[idx], &bandpass[idx]);
+    }
+}
+
+/* adsr.rs:134-217 */
+static void or_calc_adsr(or_patch* p, or_module* m)
+{
+    or_adsr* a = &m->u.adsr;
+    const float* gate = or_resolve(p, m, 0);
+    float* out = m->out[0];
+    for (uint32_t idx = 0; idx < p->buffer_size; idx++) {
+        int is_transition = or_is_transition(&a->td, gate ? gate[idx] : 0.0f);
+        switch (a->mode) {
+        case SRACK_ADSR_MODE_NONE:
+            if (gate && gate[idx] > 0.0f) {
+                a->phase = 0.0f;
+                a->mode = SRACK_ADSR_MODE_ATTACK;
+            }
+            break;
+        case SRACK_ADSR_MODE_ATTACK:
+            a->phase += 1.0f / (a->sample_rate * a->a_sec);
+            if (a->phase >= 1.0f) {
+                a->phase = 0.0f;
+                a->mode = SRACK_ADSR_MODE_DECAY;
+            } else if (is_transition) {
+                a->phase = 0.0f;
+                a->r_val = a->from_a_val;
+            }
+            break;
+        case SRACK_ADSR_MODE_DECAY:
+            a->phase += 1.0f / (a->sample_rate * a->d_sec);
+            if (a->phase >= 1.0f) {
+                a->phase = 0.0f;
+                a->mode = SRACK_ADSR_MODE_SUSTAIN;
+            }
+            if (is_transition) {
+                a->phase = 0.0f;
+                a->mode = SRACK_ADSR_MODE_ATTACK;
+            }
+            break;
+        case SRACK_ADSR_MODE_SUSTAIN:
+            if (!gate || gate[idx] <= 0.0f) {
+                a->phase = 0.0f;
+                a->mode = SRACK_ADSR_MODE_RELEASE;
+            }
+            if (is_transition) {
+                a->phase = 0.0f;
+                a->mode = SRACK_ADSR_MODE_ATTACK;
+            }
+            break;
+        case SRACK_ADSR_MODE_RELEASE:
+            if (gate && gate[idx] > 0.0f) {
+                a->phase = 0.0f;
+                a->mode = SRACK_ADSR_MODE_ATTACK;
+            }
+            a->phase += 1.0f / (a->sample_rate * a->r_sec);
+            if (a->phase >= 1.0f) {
+                a->phase = 0.0f;
+                a->r_val = 0.0f;
+                a->mode = SRACK_ADSR_MODE_NONE;
+            }
+            break;
+        }
+        switch (a->mode) {
+        case SRACK_ADSR_MODE_NONE: out[idx] = 0.0f; break;
+        case SRACK_ADSR_MODE_ATTACK: out[idx] = a->r_val + (1.0f - a->r_val) * a->phase; break;
+        case SRACK_ADSR_MODE_DECAY: out[idx] = a->s_val + (1.0f - a->s_val) * (1.0f - a->phase); break;
+        case SRACK_ADSR_MODE_SUSTAIN: out[idx] = a->s_val; break;
+        case SRACK_ADSR_MODE_RELEASE: out[idx] = a->s_val * (1.0f - a->phase); break;
+        }
+        if (a->mode != SRACK_ADSR_MODE_ATTACK)
+            a->r_val = out[idx];
+        else
+            a->from_a_val = out[idx];
+    }
+}
+
+/* vca.rs:117-148 */
+static void or_calc_vca(or_patch* p, or_module* m)
+{
+    const float* audio = or_resolve(p, m, 0);
+    const float* cv = or_resolve(p, m, 1);
+    float* out = m->out[0];
+    if (audio && cv) {
+        for (uint32_t i = 0; i < p->buffer_size; i++) out[i] = (m->u.vca.negative || cv[i] > 0.0f) ? audio[i] * cv[i] : 0.0f;
+    } else {
+        for (uint32_t i = 0; i < p->buffer_size; i++) out[i] = 0.0f;
+    }
+}
+
+/* mixer.rs:101-122 */
+static void or_calc_mixer(or_patch* p, or_module* m)
+{
+    float* out = m->out[0];
+    for (uint32_t i = 0; i < p->buffer_size; i++) out[i] = 0.0f;
+    for (int k = 0; k < 4; k++) {
+        const float* buf = or_resolve(p, m, k);
+        if (!buf) continue;
+        float gain = m->u.mix.gain[k];
+        for (uint32_t i = 0; i < p->buffer_size; i++) out[i] += buf[i] * gain;
+    }
+}
+
+/* math.rs:46-52, 139-160 */
+static float or_math_op(int op, float a, float b)
+{
+    switch (op) {
+    case SRACK_MATH_ADD: return a + b;
+    case SRACK_MATH_SUBTRACT: return a - b;
+    default: return a * b;
+    }
+}
+
+static void or_calc_math(or_patch* p, or_module* m)
+{
+    const float* i1 = or_resolve(p, m, 0);
+    const float* i2 = or_resolve(p, m, 1);
+    float* out = m->out[0];
+    for (uint32_t i = 0; i < p->buffer_size; i++)
+        out[i] = or_math_op(m->u.math.operation, i1 ? i1[i] : 0.0f, i2 ? i2[i] : m->u.math.constant);
+}
+
+/* output.rs:46-60 */
+static void or_calc_output(or_patch* p, or_module* m)
+{
+    for (int c = 0; c < m->n_in; c++) {
+        const float* buf = or_resolve(p, m, c);
+        if (buf)
+            memcpy(m->out[c], buf, sizeof(float) * p->buffer_size);
+        else
+            memset(m->out[c], 0, sizeof(float) * p->buffer_size);
+    }
+}
+
+static void or_calc(or_patch* p, or_module* m)
+{
+    switch (m->type) {
+    case SRACK_MOD_OUTPUT: or_calc_output(p, m); break;
+    case SRACK_MOD_OSCILLATOR: or_calc_osc(p, m); break;
+    case SRACK_MOD_MOOG_FILTER: or_calc_vcf(p, m); break;
+    case SRACK_MOD_ADSR: or_calc_adsr(p, m); break;
+    case SRACK_MOD_VCA: or_calc_vca(p, m); break;
+    case SRACK_MOD_MONO_MIXER: or_calc_mixer(p, m); break;
+    case SRACK_MOD_MATH: or_calc_math(p, m); break;
+    }
+}
+
+/* One module's calc() on its own (the oscillator unit test drives calc() directly). */
+int or_module_calc(or_patch* p, int module)
+{
+    if (module < 0 || module >= p->n_modules) return -1;
+    or_calc(p, &p->modules[module]);
+    return 0;
+}
+
+/* synth::execute, synth.rs:97-101 */
+int or_execute(or_patch* p)
+{
+    if (!p->plan_valid) or_plan(p);
+    for (int i = 0; i < p->n_plan; i++) or_calc(p, &p->modules[p->plan[i]]);
+    return 0;
+}
+
+/* Copy a module's output buffer (for OutputModule: bufs[port]). */
+int or_get_output(const or_patch* p, int module, int port, float* dst)
+{
+    if (module < 0 || module >= p->n_modules) return -1;
+    const or_module* m = &p->modules[module];
+    int n = m->type == SRACK_MOD_OUTPUT ? m->n_in : m->n_out;
+    if (port < 0 || port >= n) return -2;
+    memcpy(dst, m->out[port], sizeof(float) * p->buffer_size);
+    return 0;
+}
+
+/* The offline counterpart of the audio callback (main.rs:59-90): execute once per buffer_size
+ * frames, copy OutputModule.bufs[c], keep the first n_samples frames.
+ * out: [channels][n_samples].  Optional tap: (tap_module, tap_port) copied to tap_out[n_samples]. */
+int or_render(or_patch* p, uint32_t n_samples, float* out, int tap_module, int tap_port, float* tap_out)
+{
+    if (!p->plan_valid) or_plan(p);
+    uint32_t B = p->buffer_size;
+    for (uint32_t base = 0; base < n_samples; base += B) {
+        or_execute(p);
+        uint32_t n = n_samples - base < B ? n_samples - base : B;
+        if (out) {
+            for (uint32_t c = 0; c < p->channels; c++) {
+                if (p->output >= 0)
+                    memcpy(out + (size_t)c * n_samples + base, p->modules[p->output].out[c], sizeof(float) * n);
+                else
+                    memset(out + (size_t)c * n_samples + base, 0, sizeof(float) * n); /* main.rs:65: no output => src_buf stays 0 */
+            }
+        }
+        if (tap_out) memcpy(tap_out + base, p->modules[tap_module].out[tap_port], sizeof(float) * n);
+    }
+    return 0;
+}
+
+/* Deep copy: one module-object graph per voice for the batch baseline. */
+or_patch* or_patch_clone(const or_patch* src)
+{
+    or_patch* p = (or_patch*)calloc(1, sizeof(or_patch));
+    *p = *src;
+    p->modules = (or_module*)malloc(sizeof(or_module) * (size_t)(src->cap_modules ? src->cap_modules : 1));
+    memcpy(p->modules, src->modules, sizeof(or_module) * (size_t)src->n_modules);
+    for (int i = 0; i < p->n_modules; i++)
+        for (int k = 0; k < OR_MAX_OUT; k++)
+            if (src->modules[i].out[k]) {
+                p->modules[i].out[k] = (float*)malloc(sizeof(float) * src->buffer_size);
+                memcpy(p->modules[i].out[k], src->modules[i].out[k], sizeof(float) * src->buffer_size);
+            }
+    p->plan = NULL;
+    p->removed = NULL;
+    if (src->plan) {
+        p->plan = (int*)malloc(sizeof(int) * (size_t)(src->n_plan ? src->n_plan : 1));
+        memcpy(p->plan, src->plan, sizeof(int) * (size_t)src->n_plan);
+    }
+    if (src->removed) {
+        p->removed = (int*)malloc(sizeof(int) * 2 * (size_t)(src->n_removed ? src->n_removed : 1));
+        memcpy(p->removed, src->removed, sizeof(int) * 2 * (size_t)src->n_removed);
+    }
+    return p;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Batch render = the CPU baseline in the reference's structure: one object graph per voice,
+ * block-major execute, all three oscillator outputs computed; voices split over threads.      */
+
+typedef struct {
+    int module, field;
+    const double* values; /* [n_voices] */
+} or_override;
+
+typedef struct {
+    const or_patch* proto;
+    uint32_t v0, v1, n_voices, n_samples;
+    const or_override* ov;
+    int n_ov;
+    float* frames;       /* [channels][n_samples][n_voices] or NULL */
+    double* mix;         /* per-thread [channels][n_samples] f64 partial, or NULL */
+} or_batch_job;
+
+static void* or_batch_worker(void* arg)
+{
+    or_batch_job* j = (or_batch_job*)arg;
+    uint32_t C = j->proto->channels, T = j->n_samples;
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)C * T);
+    for (uint32_t v = j->v0; v < j->v1; v++) {
+        or_patch* p = or_patch_clone(j->proto);
+        for (int k = 0; k < j->n_ov; k++) or_set_field(p, j->ov[k].module, j->ov[k].field, j->ov[k].values[v]);
+        or_render(p, T, tmp, -1, 0, NULL);
+        if (j->frames)
+            for (uint32_t c = 0; c < C; c++)
+                for (uint32_t i = 0; i < T; i++) j->frames[((size_t)c * T + i) * j->n_voices + v] = tmp[(size_t)c * T + i];
+        if (j->mix)
+            for (size_t i = 0; i < (size_t)C * T; i++) j->mix[i] += (double)tmp[i];
+        or_patch_free(p);
+    }
+    free(tmp);
+    return NULL;
+}
+
+/* frames: [channels][n_samples][n_voices] f32 (may be NULL); mix: [channels][n_samples] f64 sum
+ * over voices (may be NULL).  ov_*: per-voice field overrides.  Returns 0. */
+int or_render_batch(const or_patch* proto, uint32_t n_voices, uint32_t n_samples, int n_ov, const int* ov_module, const int* ov_field,
+                    const double* const* ov_values, float* frames, double* mix, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if ((uint32_t)n_threads > n_voices) n_threads = (int)n_voices;
+    or_override* ov = (or_override*)calloc((size_t)(n_ov ? n_ov : 1), sizeof(or_override));
+    for (int k = 0; k < n_ov; k++) {
+        ov[k].module = ov_module[k];
+        ov[k].field = ov_field[k];
+        ov[k].values = ov_values[k];
+    }
+    or_patch* planned = or_patch_clone(proto);
+    if (!planned->plan_valid) or_plan(planned);
+    size_t mixn = (size_t)proto->channels * n_samples;
+    or_batch_job* jobs = (or_batch_job*)calloc((size_t)n_threads, sizeof(or_batch_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].proto = planned;
+        jobs[t].v0 = (uint32_t)((uint64_t)n_voices * (uint64_t)t / (uint64_t)n_threads);
+        jobs[t].v1 = (uint32_t)((uint64_t)n_voices * (uint64_t)(t + 1) / (uint64_t)n_threads);
+        jobs[t].n_voices = n_voices;
+        jobs[t].n_samples = n_samples;
+        jobs[t].ov = ov;
+        jobs[t].n_ov = n_ov;
+        jobs[t].frames = frames;
+        jobs[t].mix = mix ? (double*)calloc(mixn, sizeof(double)) : NULL;
+        pthread_create(&th[t], NULL, or_batch_worker, &jobs[t]);
+    }
+    if (mix) memset(mix, 0, sizeof(double) * mixn);
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        if (mix) {
+            for (size_t i = 0; i < mixn; i++) mix[i] += jobs[t].mix[i];
+            free(jobs[t].mix);
+        }
+    }
+    free(jobs);
+    free(th);
+    free(ov);
+    or_patch_free(planned);
+    return 0;
+}
+
+/* splitmix64-based per-voice uniform in [0,1): top 24 bits -> f32.
+ * u(seed, voice, k) = (splitmix64(seed ^ (voice*2+k)) >> 40) * 2^-24 */
+static uint64_t or_splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+float or_voice_uniform(uint64_t seed, uint64_t voice, uint32_t k)
+{
+    return (float)(or_splitmix64(seed ^ (voice * 2u + k)) >> 40) * (1.0f / 16777216.0f);
+}

@@ -1,0 +1,117 @@
+"""The BASELINE.json patches and per-voice parameter sets, written against the graph API only.
+
+`build_p1` / `build_p2` take any object with add_module / connect / set_field (the product's
+`Patch`, or the test oracle's `OraclePatch`) and wire the patch of SURVEY §8(d) in the same
+`all_modules` order, so the planner sees identical lists on both sides.
+"""
+import numpy as np
+
+# numeric vocabulary of include/srack_hip.h
+MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH = range(7)
+OSC_VAL, OSC_ANTIALIASING, OSC_POS, OSC_SYNC_LAST = range(4)
+(VCF_FREQ, VCF_RES, VCF_EXP_AMT, VCF_ST_F, VCF_ST_P, VCF_ST_Q, VCF_ST_B0, VCF_ST_B1, VCF_ST_B2, VCF_ST_B3,
+ VCF_ST_B4, VCF_ST_FREQ, VCF_ST_RES) = range(13)
+(ADSR_A_SEC, ADSR_D_SEC, ADSR_S_VAL, ADSR_R_SEC, ADSR_PHASE, ADSR_MODE, ADSR_R_VAL, ADSR_FROM_A_VAL,
+ ADSR_SAMPLE_RATE, ADSR_GATE_LAST) = range(10)
+VCA_NEGATIVE = 0
+MIX_GAIN0, MIX_GAIN1, MIX_GAIN2, MIX_GAIN3 = range(4)
+MATH_CONSTANT, MATH_OPERATION = range(2)
+MATH_ADD, MATH_SUBTRACT, MATH_MULTIPLY = range(3)
+OSC_OUT_SINE, OSC_OUT_SQUARE, OSC_OUT_SAW = range(3)
+VCF_OUT_LOWPASS, VCF_OUT_BANDPASS, VCF_OUT_HIGHPASS = range(3)
+
+SEED = 0x5EED5EED
+
+
+def build_p1(g, adsr="default", lfo_val=-8.0):
+    """Patch P1 (configs 1/2/3/5): saw VCO -> ladder VCF -> VCA, ADSR gated by an LFO square.
+
+    List order: [0] OSC_A, [1] OSC_LFO, [2] VCF, [3] ADSR, [4] VCA, [5] OUTPUT.
+    adsr="default": a 0.0 / d 0.5 / s 0.25 / r 0.5 (adsr.rs:39-42; a_sec = 0 => inf increment);
+    adsr="finite":  a 0.01 / d 0.1 / s 0.5 / r 0.2.
+    """
+    osc_a = g.add_module(MOD_OSCILLATOR)
+    osc_lfo = g.add_module(MOD_OSCILLATOR)
+    vcf = g.add_module(MOD_MOOG_FILTER)
+    adsr_m = g.add_module(MOD_ADSR)
+    vca = g.add_module(MOD_VCA)
+    out = g.add_module(MOD_OUTPUT)
+    g.set_field(osc_a, OSC_VAL, 0.0)
+    g.set_field(osc_lfo, OSC_VAL, lfo_val)
+    g.set_field(vcf, VCF_FREQ, 0.2)
+    g.set_field(vcf, VCF_RES, 0.5)
+    g.set_field(vcf, VCF_EXP_AMT, 0.5)
+    if adsr == "finite":
+        g.set_field(adsr_m, ADSR_A_SEC, 0.01)
+        g.set_field(adsr_m, ADSR_D_SEC, 0.1)
+        g.set_field(adsr_m, ADSR_S_VAL, 0.5)
+        g.set_field(adsr_m, ADSR_R_SEC, 0.2)
+    g.connect(osc_a, OSC_OUT_SAW, vcf, 0)
+    g.connect(osc_lfo, OSC_OUT_SQUARE, adsr_m, 0)
+    g.connect(vcf, VCF_OUT_LOWPASS, vca, 0)
+    g.connect(adsr_m, 0, vca, 1)
+    g.connect(vca, 0, out, 0)
+    g.connect(vca, 0, out, 1)
+    return dict(osc_a=osc_a, osc_lfo=osc_lfo, vcf=vcf, adsr=adsr_m, vca=vca, out=out)
+
+
+def build_p2(g, beta=0.3, index=1.0):
+    """Patch P2 (config 4): 2-op FM with a feedback edge.
+
+    List order: [0] OSC_M, [1] MUL_FB (x beta), [2] MUL_IDX (x index), [3] OSC_C, [4] OUTPUT.
+    OSC_M.sine -> MUL_FB -> OSC_M.cv is a cycle; the planner delays OSC_M.sine -> MUL_FB by
+    buffer_size samples (MUL_FB runs first on the previous block's sine).
+    """
+    osc_m = g.add_module(MOD_OSCILLATOR)
+    mul_fb = g.add_module(MOD_MATH)
+    mul_idx = g.add_module(MOD_MATH)
+    osc_c = g.add_module(MOD_OSCILLATOR)
+    out = g.add_module(MOD_OUTPUT)
+    for m, c in ((mul_fb, beta), (mul_idx, index)):
+        g.set_field(m, MATH_OPERATION, MATH_MULTIPLY)
+        g.set_field(m, MATH_CONSTANT, c)
+    g.connect(osc_m, OSC_OUT_SINE, mul_fb, 0)
+    g.connect(mul_fb, 0, osc_m, 0)
+    g.connect(osc_m, OSC_OUT_SINE, mul_idx, 0)
+    g.connect(mul_idx, 0, osc_c, 0)
+    g.connect(osc_c, OSC_OUT_SINE, out, 0)
+    g.connect(osc_c, OSC_OUT_SINE, out, 1)
+    return dict(osc_m=osc_m, mul_fb=mul_fb, mul_idx=mul_idx, osc_c=osc_c, out=out)
+
+
+def splitmix64(x):
+    x = (np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15))
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def voice_uniform(n_voices, k, seed=SEED, first_voice=0):
+    """Counter-based U[0,1) f32 per voice: top 24 bits of splitmix64(seed ^ (voice*2+k)).
+
+    Depends only on the GLOBAL voice index, so a rank that owns voices [v0, v1) draws the same
+    numbers the single-GPU run draws for them.
+    """
+    with np.errstate(over="ignore"):
+        v = np.arange(first_voice, first_voice + n_voices, dtype=np.uint64)
+        bits = splitmix64(np.uint64(seed) ^ (v * np.uint64(2) + np.uint64(k)))
+    return ((bits >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+
+
+def p1_voice_params(n_voices, seed=SEED, first_voice=0):
+    """cfg3/cfg5 per-voice randomisation: OSC_A.val = U(-1/24, +1/24) octaves, VCF.freq = U(0.05, 0.6).
+
+    Returned as f32, computed in f32 so host, oracle and device hold identical bits.
+    """
+    u0 = voice_uniform(n_voices, 0, seed, first_voice)
+    u1 = voice_uniform(n_voices, 1, seed, first_voice)
+    detune = (u0 * np.float32(2.0) - np.float32(1.0)) * np.float32(1.0 / 24.0)
+    cutoff = np.float32(0.05) + u1 * np.float32(0.55)
+    return detune.astype(np.float32), cutoff.astype(np.float32)
+
+
+def p2_voice_params(n_voices, seed=SEED, first_voice=0):
+    """cfg4 per-voice randomisation: feedback beta = U(0.1, 0.4), index = U(0.5, 1.5)."""
+    u0 = voice_uniform(n_voices, 0, seed, first_voice)
+    u1 = voice_uniform(n_voices, 1, seed, first_voice)
+    return (np.float32(0.1) + u0 * np.float32(0.3)).astype(np.float32), (np.float32(0.5) + u1).astype(np.float32)

@@ -1,0 +1,63 @@
+"""Adapter giving oracle/srack_numpy.py the add_module / connect / set_field graph API."""
+import numpy as np
+
+from oracle import srack_numpy as N
+
+_OSC = {0: "val", 1: "antialiasing", 2: "pos"}
+_VCF = {0: "freq", 1: "res", 2: "exp_amt"}
+_ADSR = {0: "a_sec", 1: "d_sec", 2: "s_val", 3: "r_sec", 4: "phase", 5: "mode", 6: "r_val", 7: "from_a_val", 8: "sample_rate"}
+
+
+class NumpyGraph:
+    def __init__(self, sample_rate=48000, buffer_size=1024, channels=2):
+        self.cfg = dict(sample_rate=sample_rate, buffer_size=buffer_size, channels=channels)
+        self.modules = []
+
+    def add_module(self, mtype):
+        self.modules.append(N.CLASSES[mtype](self.cfg))
+        return len(self.modules) - 1
+
+    def connect(self, src, src_port, sink, sink_port):
+        self.modules[sink].inputs[sink_port] = (self.modules[src], src_port)
+
+    def set_field(self, module, field, value):
+        m = self.modules[module]
+        if isinstance(m, N.Oscillator):
+            if field == 2:
+                m.pos = float(value)
+            elif field == 1:
+                m.antialiasing = bool(value)
+            elif field == 3:
+                m.sync.last = bool(value)
+            else:
+                m.val = np.float32(value)
+        elif isinstance(m, N.MoogFilter):
+            setattr(m, _VCF[field], np.float32(value))
+        elif isinstance(m, N.ADSR):
+            if field == 5:
+                m.mode = int(value)
+            elif field == 9:
+                m.td.last = bool(value)
+            else:
+                setattr(m, _ADSR[field], np.float32(value))
+        elif isinstance(m, N.VCA):
+            m.negative = bool(value)
+        elif isinstance(m, N.MonoMixer):
+            m.gain[field] = np.float32(value)
+        elif isinstance(m, N.Math):
+            if field == 0:
+                m.constant = np.float32(value)
+            else:
+                m.operation = int(value)
+        else:
+            raise ValueError("no fields")
+
+    def plan(self):
+        output = next(m for m in self.modules if isinstance(m, N.Output))
+        plan, removed = N.plan_execution(output, self.modules)
+        idx = {id(m): i for i, m in enumerate(self.modules)}
+        return [idx[id(m)] for m in plan], [(idx[id(a)], idx[id(b)]) for a, b in removed]
+
+    def render(self, n_samples, tap=None):
+        t = (self.modules[tap[0]], tap[1]) if tap is not None else None
+        return N.render(self.modules, n_samples, self.cfg, tap=t)

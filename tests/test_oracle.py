@@ -1,0 +1,335 @@
+"""The oracle against everything the reference's own tests pin, and against its independent twin.
+
+Reference tests replayed here (the only two that exist):
+  * oscillator::dco_tests::produces_440   src/synth/oscillator.rs:284-305
+  * synth::tests::topological_sort        src/synth.rs:537-613
+Everything else is pinned by the C oracle and the NumPy restatement agreeing bit for bit.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from tests.npgraph import NumpyGraph
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ---- reference test 1: produces_440 ------------------------------------------------------------
+def _produces_440(make):
+    g = make(440 * 4, 17, 2)  # notice odd sized buffer
+    m = g.add_module(1)
+    g.module_calc(m)
+    buf = g.get_output(m, 0)
+    assert buf[0] == 0.0
+    assert abs(buf[1] - 1.0) < 0.00001
+    assert abs(buf[2]) < 0.00001
+    assert abs(buf[3] + 1.0) < 0.00001
+    assert abs(buf[4]) < 0.00001
+    g.module_calc(m)
+    buf = g.get_output(m, 0)
+    assert abs(buf[0] - 1.0) < 0.00001  # should continue smoothly into next buffer
+
+
+def test_produces_440_oracle(oracle):
+    _produces_440(lambda sr, b, c: oracle.OraclePatch(sr, b, c))
+
+
+def test_produces_440_numpy():
+    class G(NumpyGraph):
+        def module_calc(self, m):
+            self.modules[m].calc()
+
+        def get_output(self, m, port):
+            return self.modules[m].outs[port]
+
+    _produces_440(lambda sr, b, c: G(sr, b, c))
+
+
+# ---- reference test 2: topological_sort --------------------------------------------------------
+def _topo_graph(g):
+    #     0 -> 1 -> 2 -> 3 -> o
+    #      \----> 4 -----^
+    #        5<->6^
+    mods = [g.add_module(5) for _ in range(7)]
+    out = g.add_module(0)
+    free = {m: 0 for m in mods + [out]}
+
+    def connect(src, sink):  # first unconnected input, synth.rs:523-535
+        g.connect(src, 0, sink, free[sink])
+        free[sink] += 1
+
+    connect(mods[0], mods[1])
+    connect(mods[1], mods[2])
+    connect(mods[2], mods[3])
+    connect(mods[3], out)
+    connect(mods[0], mods[4])
+    connect(mods[4], mods[3])
+    connect(mods[6], mods[4])
+    connect(mods[5], mods[6])
+    connect(mods[6], mods[5])
+    return mods, out
+
+
+def _assert_topo(plan, mods, out):
+    idx = {m: i for i, m in enumerate(plan)}
+    assert len(plan) == 8
+    assert idx[mods[0]] < idx[mods[1]] < idx[mods[2]] < idx[mods[3]] < idx[out]
+    assert idx[mods[0]] < idx[mods[4]] < idx[mods[3]]
+    assert idx[mods[6]] < idx[mods[4]]
+    assert idx[mods[5]] < idx[mods[6]]
+
+
+def test_topological_sort_oracle(oracle):
+    g = oracle.OraclePatch(44100, 64, 2)
+    mods, out = _topo_graph(g)
+    rng = random.Random(1)
+    for _ in range(1000):
+        lst = mods + [out]
+        rng.shuffle(lst)
+        plan = g.plan(output=out, all_modules=lst)
+        _assert_topo(plan, mods, out)
+        # 6 is reached first from the output side, so the 6 -> 5 wire is the delayed one
+        assert g.removed_edges() == [(mods[5], mods[6])]
+
+
+def test_topological_sort_numpy_matches_oracle(oracle):
+    from oracle import srack_numpy as N
+    g = oracle.OraclePatch(44100, 64, 2)
+    mods, out = _topo_graph(g)
+    ng = NumpyGraph(44100, 64, 2)
+    nmods, nout = _topo_graph(ng)
+    rng = random.Random(2)
+    for _ in range(200):
+        lst = mods + [out]
+        rng.shuffle(lst)
+        plan = g.plan(output=out, all_modules=lst)
+        nplan, nremoved = N.plan_execution(ng.modules[nout], [ng.modules[i] for i in lst])
+        idx = {id(m): i for i, m in enumerate(ng.modules)}
+        assert [idx[id(m)] for m in nplan] == plan
+        assert [(idx[id(a)], idx[id(b)]) for a, b in nremoved] == g.removed_edges()
+
+
+def test_planner_random_graphs_oracle_vs_numpy(oracle):
+    """Random cyclic graphs: both planners give the same order and break the same wires."""
+    from oracle import srack_numpy as N
+    rng = random.Random(7)
+    for trial in range(150):
+        n = rng.randint(2, 9)
+        g = oracle.OraclePatch(48000, 8, 2)
+        ng = NumpyGraph(48000, 8, 2)
+        types = [rng.choice([1, 2, 3, 4, 5, 6]) for _ in range(n)]
+        pos_out = rng.randint(0, n)
+        types.insert(pos_out, 0)
+        for t in types:
+            g.add_module(t)
+            ng.add_module(t)
+        n_in = {0: 2, 1: 2, 2: 2, 3: 1, 4: 2, 5: 4, 6: 2}
+        n_out = {0: 0, 1: 3, 2: 3, 3: 1, 4: 1, 5: 1, 6: 1}
+        for sink, t in enumerate(types):
+            for port in range(n_in[t]):
+                if rng.random() < 0.6:
+                    src = rng.randrange(len(types))
+                    if src == sink or n_out[types[src]] == 0:
+                        continue
+                    sp = rng.randrange(n_out[types[src]])
+                    g.connect(src, sp, sink, port)
+                    ng.connect(src, sp, sink, port)
+        plan = g.plan()
+        nplan, nremoved = ng.plan()
+        assert plan == nplan, trial
+        assert g.removed_edges() == nremoved, trial
+        assert sorted(plan) == list(range(len(types)))  # every module scheduled exactly once
+
+
+# ---- facts derived in SURVEY §8(c) -------------------------------------------------------------
+def test_oscillator_known_values(oracle):
+    g = oracle.OraclePatch(48000, 1024, 2)
+    m = g.add_module(1)
+    g.module_calc(m)
+    saw, square = g.get_output(m, 2), g.get_output(m, 1)
+    np.testing.assert_array_equal(saw[:4], np.array([0.0, -0.9816667, -0.9633333, -0.945], dtype=np.float32))
+    assert square[0] == 0.0 and square[1] == -1.0
+    # val = -8 => 1.71875 Hz; the square first goes > 0 at sample 13964
+    g = oracle.OraclePatch(48000, 1024, 2)
+    m = g.add_module(1)
+    g.set_field(m, 0, -8.0)
+    sq = []
+    for _ in range(14):
+        g.module_calc(m)
+        sq.append(g.get_output(m, 1))
+    sq = np.concatenate(sq)
+    assert int(np.argmax(sq > 0)) == 13964
+
+
+# ---- C oracle == NumPy restatement, bit for bit ------------------------------------------------
+def _both(W, oracle, build, n, sr=48000, B=64, **kw):
+    g = oracle.OraclePatch(sr, B, 2)
+    ids = build(g, **kw)
+    ng = NumpyGraph(sr, B, 2)
+    build(ng, **kw)
+    return g, ng, ids
+
+
+@pytest.mark.parametrize("adsr", ["default", "finite"])
+def test_p1_c_equals_numpy(W, oracle, adsr):
+    # LFO at val=-2 (110 Hz) so several gate cycles fit in 4000 samples
+    g, ng, ids = _both(W, oracle, W.build_p1, 4000, adsr=adsr, lfo_val=-2.0)
+    for tap in [(ids["osc_a"], 2), (ids["osc_lfo"], 1), (ids["vcf"], 0), (ids["adsr"], 0)]:
+        gg, nn, _ = _both(W, oracle, W.build_p1, 4000, adsr=adsr, lfo_val=-2.0)
+        a, ta = gg.render(4000, tap=tap)
+        b, tb = nn.render(4000, tap=tap)
+        np.testing.assert_array_equal(bits(ta), bits(tb))
+        np.testing.assert_array_equal(bits(a), bits(b))
+    assert np.abs(g.render(4000)).max() > 0.05  # the patch actually sounds
+
+
+@pytest.mark.parametrize("B", [1, 7, 64])
+def test_p2_fm_feedback_c_equals_numpy(W, oracle, B):
+    g, ng, ids = _both(W, oracle, W.build_p2, 1500, B=B, beta=0.3, index=1.0)
+    assert g.plan() == ng.plan()[0]
+    # the planner breaks OSC_M.sine -> MUL_FB: MUL_FB runs before OSC_M
+    assert g.removed_edges() == [(ids["mul_fb"], ids["osc_m"])]
+    a = g.render(1500)
+    b = ng.render(1500)
+    np.testing.assert_array_equal(bits(a), bits(b))
+    assert np.abs(a).max() > 0.5
+
+
+def test_all_module_types_c_equals_numpy(W, oracle):
+    """A patch touching every port of every ★ module type, incl. sync, filter CV, HP/BP, mixer, math."""
+    def build(g):
+        lfo = g.add_module(1)      # 0: sync + CV source
+        osc = g.add_module(1)      # 1: synced, CV-modulated, non-antialiased
+        osc2 = g.add_module(1)     # 2
+        vcf = g.add_module(2)      # 3
+        adsr = g.add_module(3)     # 4
+        vca = g.add_module(4)      # 5
+        mix = g.add_module(5)      # 6
+        sub = g.add_module(6)      # 7
+        add = g.add_module(6)      # 8
+        vca_neg = g.add_module(4)  # 9
+        out = g.add_module(0)      # 10
+        g.set_field(lfo, 0, -1.5)
+        g.set_field(osc, 0, 0.25)
+        g.set_field(osc, 1, 0)  # antialiasing off
+        g.set_field(osc2, 0, 1.0 / 12.0)
+        g.set_field(vcf, 0, 0.35)
+        g.set_field(vcf, 1, 0.8)
+        g.set_field(vcf, 2, 0.25)
+        g.set_field(adsr, 0, 0.002)
+        g.set_field(adsr, 1, 0.004)
+        g.set_field(adsr, 2, 0.6)
+        g.set_field(adsr, 3, 0.003)
+        g.set_field(mix, 0, 0.5)
+        g.set_field(mix, 2, 1.5)
+        g.set_field(sub, 1, 1)  # Subtract
+        g.set_field(sub, 0, 0.125)
+        g.set_field(add, 0, -0.75)
+        g.set_field(vca_neg, 0, 1)
+        g.connect(lfo, 0, osc, 0)       # sine -> CV (vibrato)
+        g.connect(lfo, 1, osc, 1)       # square -> sync
+        g.connect(osc, 2, vcf, 0)       # saw -> filter
+        g.connect(lfo, 2, vcf, 1)       # saw -> cutoff CV
+        g.connect(lfo, 1, adsr, 0)      # gate
+        g.connect(vcf, 1, vca, 0)       # bandpass -> VCA
+        g.connect(adsr, 0, vca, 1)
+        g.connect(vca, 0, mix, 0)
+        g.connect(vcf, 2, mix, 2)       # highpass
+        g.connect(osc2, 1, mix, 3)      # square
+        g.connect(mix, 0, sub, 0)       # mix - constant
+        g.connect(osc2, 0, add, 1)      # 0.0 + sine (in1 unconnected)
+        g.connect(add, 0, vca_neg, 0)
+        g.connect(lfo, 0, vca_neg, 1)   # negative CV passes when negative=true
+        g.connect(sub, 0, out, 0)
+        g.connect(vca_neg, 0, out, 1)
+        return out
+
+    g = oracle.OraclePatch(48000, 32, 2)
+    build(g)
+    ng = NumpyGraph(48000, 32, 2)
+    build(ng)
+    a, b = g.render(3000), ng.render(3000)
+    np.testing.assert_array_equal(bits(a), bits(b))
+    assert np.abs(a[0]).max() > 0.1 and np.abs(a[1]).max() > 0.1
+    assert not np.array_equal(a[0], a[1])
+
+
+def test_block_size_invariance_acyclic(W, oracle):
+    """Acyclic graph: block-major evaluation is independent of buffer_size."""
+    ref = None
+    for B in (1, 17, 1024):
+        g = oracle.OraclePatch(48000, B, 2)
+        W.build_p1(g, lfo_val=-2.0)
+        a = g.render(2500)
+        if ref is None:
+            ref = a
+        np.testing.assert_array_equal(bits(a), bits(ref))
+
+
+def test_feedback_delay_is_buffer_size(W, oracle):
+    """Cyclic graph: the broken edge is a buffer_size-sample delay, so B is audible."""
+    outs = {}
+    for B in (1, 64):
+        g = oracle.OraclePatch(48000, B, 2)
+        W.build_p2(g)
+        outs[B] = g.render(2000)
+    assert not np.array_equal(outs[1], outs[64])
+    # first B samples see zero feedback either way -> identical prefix of length 1
+    assert outs[1][0, 0] == outs[64][0, 0]
+
+
+def test_quirks(W, oracle):
+    # VCA outputs zeros if either input is unconnected (vca.rs:127,142-144)
+    g = oracle.OraclePatch(48000, 16, 2)
+    osc, vca, out = g.add_module(1), g.add_module(4), g.add_module(0)
+    g.connect(osc, 0, vca, 0)
+    g.connect(vca, 0, out, 0)
+    assert not g.render(64).any()
+    # a gate already high at sample 0 is not an edge, but None->Attack is level-triggered
+    g = oracle.OraclePatch(48000, 16, 2)
+    const, adsr, out = g.add_module(6), g.add_module(3), g.add_module(0)
+    g.set_field(const, 0, 1.0)  # 0.0 + 1.0
+    g.connect(const, 0, adsr, 0)
+    g.connect(adsr, 0, out, 0)
+    a = g.render(8)[0]
+    # default a_sec = 0: sample 0 enters Attack at phase 0 -> out = r_val = 0; sample 1: inf >= 1 -> Decay
+    assert a[0] == 0.0 and a[1] == 1.0 and a[2] < 1.0
+    # filter with freq = 0, res = 0 from the start never computes its coefficients (f stays 0)
+    g = oracle.OraclePatch(48000, 16, 2)
+    osc, vcf, out = g.add_module(1), g.add_module(2), g.add_module(0)
+    g.set_field(vcf, 0, 0.0)
+    g.set_field(vcf, 1, 0.0)
+    g.connect(osc, 2, vcf, 0)
+    g.connect(vcf, 0, out, 0)
+    g.render(64)
+    assert g.get_field(vcf, 3) == 0.0  # SRACK_VCF_ST_F
+    # no OutputModule => empty plan, silence
+    g = oracle.OraclePatch(48000, 16, 2)
+    g.add_module(1)
+    assert g.plan() == [] and not g.render(32).any()
+
+
+def test_voice_uniform_matches_numpy_generator(W, oracle):
+    for k in (0, 1):
+        a = oracle.voice_uniform(W.SEED, 257, k, first_voice=1000)
+        b = W.voice_uniform(257, k, W.SEED, first_voice=1000)
+        np.testing.assert_array_equal(bits(a), bits(b))
+        assert 0.0 <= a.min() and a.max() < 1.0
+
+
+def test_render_batch_matches_single_renders(W, oracle):
+    g = oracle.OraclePatch(48000, 64, 2)
+    ids = W.build_p1(g, lfo_val=-2.0)
+    det, cut = W.p1_voice_params(5)
+    frames, mix = g.render_batch(5, 700, [(ids["osc_a"], W.OSC_VAL, det), (ids["vcf"], W.VCF_FREQ, cut)],
+                                 frames=True, mix=True, threads=3)
+    for v in range(5):
+        s = oracle.OraclePatch(48000, 64, 2)
+        W.build_p1(s, lfo_val=-2.0)
+        s.set_field(ids["osc_a"], W.OSC_VAL, det[v])
+        s.set_field(ids["vcf"], W.VCF_FREQ, cut[v])
+        np.testing.assert_array_equal(bits(s.render(700)), bits(frames[:, :, v]))
+    np.testing.assert_allclose(mix, frames.astype(np.float64).sum(axis=2), rtol=0, atol=1e-12)
