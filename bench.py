@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py — voice-samples/sec of the batch render on N MI355X (one process per GPU).
+
+Workload (BASELINE.json config 3 per GPU; config 5 = 8 ranks of it):
+    patch P1 (saw VCO -> ladder VCF -> VCA, ADSR gated by an LFO square), 262 144 voices per GPU with
+    per-voice randomised detune / cutoff, 1 s @ 48 kHz per step, f32 frames [T][V] + stereo mix-down.
+A step = one srack_render() of all voices for T samples (frames resident in HBM) + the mix-down
+(+ for N > 1 the RCCL sum of the [2][T] partial mixes to rank 0).  Voices are sharded by global
+voice index, no exchange during the render => weak scaling.
+
+Prints ONE JSON line (rank 0): metric/value/unit per the driver's contract, plus
+  roofline     — achieved = 4 B x V x T / avg duration of the render kernel (HIP events on the
+                 kernel's own stream, read back through srack_render_kernel_ms), peak 8 TB/s HBM
+  cpu_baseline — the C oracle in the reference's structure (block-major execute, one object graph
+                 per voice, all oscillator ports computed) on the host cores, bounded sample (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured streaming ceiling ~6290
+HBM_STREAM_GBS = 6290.0
+BYTES_PER_VOICE_SAMPLE = 4   # one f32 frame per voice per sample
+
+
+def cpu_baseline(S, voices_per_core=6, n_samples=48000):
+    """The oracle timed on this host: `cores` threads x voices_per_core voices x 1 s of P1 (about 10-30 s of CPU work
+    in total across cores; wall time a few seconds)."""
+    from oracle import oracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    V = cores * voices_per_core
+    g = O.OraclePatch(48000, 1024, 2)
+    ids = S.build_p1(g)
+    det, cut = S.p1_voice_params(V)
+    ov = [(ids["osc_a"], S.OSC_VAL, det), (ids["vcf"], S.VCF_FREQ, cut)]
+    g.render_batch(min(V, cores), 4800, ov[:0], frames=False, mix=True, threads=cores)  # warm the threads
+    best = None
+    for _ in range(3):
+        t = time.perf_counter()
+        g.render_batch(V, n_samples, ov, frames=False, mix=True, threads=cores)
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    t = time.perf_counter()
+    g.render_batch(voices_per_core, n_samples, [(m, f, v[:voices_per_core]) for m, f, v in ov], frames=False, mix=True, threads=1)
+    dt1 = time.perf_counter() - t
+    return {
+        "value": V * n_samples / best, "unit": "voice-samples/s", "cores": cores, "kind": "port",
+        "sample": f"{V} voices x {n_samples} samples of patch P1 (cfg3 draw), buffer_size 1024, {cores} threads, best of 3",
+        "single_thread_value": voices_per_core * n_samples / dt1,
+        "note": "C restatement of the reference tick (oracle/srack_oracle.c); the Rust reference cannot be built here. "
+                "Omits the reference's per-block RwLock/Arc/Vec overhead, so it is a slightly optimistic stand-in.",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--voices", type=int, default=262144, help="voices per GPU")
+    ap.add_argument("--samples", type=int, default=48000, help="samples per step (1 s @ 48 kHz)")
+    ap.add_argument("--flags", type=int, default=0, help="SRACK_RENDER_* flags (1 exact osc, 2 no fusion, 4 no uniform hoist)")
+    ap.add_argument("--no-frames", action="store_true", help="mix only (diagnostic; not the metric)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import srack_pkg
+    S = srack_pkg.load()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    V, T, C = args.voices, args.samples, 2
+    p = S.Patch(48000, 1024, C)
+    ids = S.build_p1(p)
+    p.configure_voices(V)
+    det, cut = S.p1_voice_params(V, first_voice=rank * V)  # global voice index => same draw as the 1-GPU run
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    n_planes, _ = p.planes()
+
+    frames = None if args.no_frames else torch.empty((n_planes, T, V), dtype=torch.float32, device=dev)
+    mix = torch.empty((C, T), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        p.render_raw(T, frames.data_ptr() if frames is not None else None, mix.data_ptr(), args.flags, stream.cuda_stream)
+        if world > 1:
+            dist.reduce(mix, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: [2][T] f32 partial mixes
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    p.kernel_ms(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms, n_launch = p.kernel_ms(reset=True)
+
+    if rank == 0:
+        voice_samples = float(world) * V * T * args.steps
+        achieved = BYTES_PER_VOICE_SAMPLE * V * T / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "voice-samples/sec @48 kHz offline render",
+            "value": voice_samples / elapsed,
+            "unit": "voice-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (oscillator phase f64)", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE config 3 per GPU (config 5 at 8 GPUs): patch P1 saw VCO->ladder VCF->ADSR->VCA, "
+                            f"{V} voices/GPU with per-voice randomised detune/cutoff, {T} samples/step @48 kHz, "
+                            "f32 frames [T][V] in HBM + stereo mix-down" + (" + RCCL reduce" if world > 1 else ""),
+                "voices_per_gpu": V, "samples_per_step": T, "buffer_size": 1024, "render_flags": args.flags,
+                "frames_written": frames is not None, "program": p.info(),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "frac_of_measured_stream_ceiling": achieved / HBM_STREAM_GBS,
+                "kernel_ms": kernel_ms, "kernel_launches": n_launch,
+                "algorithmic_bytes_per_launch": BYTES_PER_VOICE_SAMPLE * V * T,
+                "voice_samples_per_s_kernel": V * T / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

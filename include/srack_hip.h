@@ -141,8 +141,15 @@ int srack_patch_get_input(const srack_patch* p, int sink_module, int sink_port, 
  * OutputModule in list order.  Writes the execution order (module indices) to `order` (capacity
  * `cap`, may be NULL) and returns its length.  Re-run automatically by render when the graph changed. */
 int srack_patch_plan(srack_patch* p, int* order, int cap);
-/* The wires the planner turned into block delays (the removed scheduler edges, synth.rs:176-191):
- * up to `cap` quadruples (src_module, src_port, sink_module, sink_port); returns the count. */
+/* plan_execution(output, &all_modules, &mut plan) with an explicit, possibly shuffled module list —
+ * what the reference's own test drives (synth.rs:561-568).  Does not affect later renders. */
+int srack_patch_plan_list(srack_patch* p, int output, const int* all_modules, int n_all, int* order, int cap);
+/* The scheduler edges phase 2 of the last plan removed (synth.rs:176-191): up to `cap` pairs
+ * (from, module) meaning "`from` no longer waits for `module`"; returns the count. */
+int srack_patch_removed_edges(srack_patch* p, int* pairs, int cap);
+/* The wires that end up as block delays: every wire whose source runs after its sink in the plan, so
+ * the sink reads the previous block's buffer.  Up to `cap` quadruples
+ * (src_module, src_port, sink_module, sink_port); returns the count. */
 int srack_patch_delayed_edges(srack_patch* p, int* quads, int cap);
 
 /* ---- voices: N independent instances of the patch ----------------------------------------- */

@@ -1,0 +1,252 @@
+"""srack_amd — host-side binding of the MI355X batch-render path (libsrack_hip.so, C ABI in include/srack_hip.h).
+
+This module is only a ctypes binding plus a thin `Patch` class whose methods carry the reference's
+names (`add_module`, `set_input`/`connect`, `plan_execution` -> `plan`, `execute` -> `render`).
+All computation happens in the HIP library; there is NO CPU fallback: if the shared library is
+missing the import fails, and a render on a host without a GPU returns SRACK_ERR_DEVICE.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import workloads  # noqa: F401  (patch builders; pure Python)
+from .workloads import *  # noqa: F401,F403  (module / field / port enums)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrack_hip.so")
+
+OK, ERR_INVALID, ERR_PORT, ERR_NO_OUTPUT, ERR_SELF_LOOP, ERR_STATE, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7, -8
+RENDER_DEFAULT, RENDER_EXACT_OSC, RENDER_NO_FUSION, RENDER_NO_UNIFORM_HOIST = 0, 1, 2, 4
+
+# every symbol include/srack_hip.h declares (tests check the library exports exactly these)
+ABI_SYMBOLS = [
+    "srack_abi_version", "srack_last_error", "srack_patch_create", "srack_patch_destroy", "srack_patch_add_module",
+    "srack_patch_num_modules", "srack_patch_module_type", "srack_module_num_inputs", "srack_module_num_outputs",
+    "srack_patch_set_field", "srack_patch_get_field", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
+    "srack_patch_plan", "srack_patch_plan_list", "srack_patch_removed_edges", "srack_patch_delayed_edges",
+    "srack_voices_configure", "srack_voices_set_field_f32", "srack_voices_set_field_f64", "srack_render_planes", "srack_render",
+    "srack_render_info", "srack_render_kernel_ms", "srack_voices_get_field", "srack_device_count", "srack_device_set",
+    "srack_device_alloc", "srack_device_free", "srack_device_to_host", "srack_device_sync", "srack_dist_reduce_mix",
+]
+
+
+class SrackError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"srack error {code}: {msg}")
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the render path.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, dbl, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_double, C.c_size_t
+    ip, dp, fp = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_float)
+    L.srack_last_error.restype = C.c_char_p
+    L.srack_patch_create.argtypes = [u32, u32, u32, C.POINTER(vp)]
+    L.srack_patch_destroy.argtypes = [vp]
+    L.srack_patch_add_module.argtypes = [vp, i32]
+    L.srack_patch_num_modules.argtypes = [vp]
+    L.srack_patch_module_type.argtypes = [vp, i32]
+    L.srack_module_num_inputs.argtypes = [vp, i32]
+    L.srack_module_num_outputs.argtypes = [vp, i32]
+    L.srack_patch_set_field.argtypes = [vp, i32, i32, dbl]
+    L.srack_patch_get_field.argtypes = [vp, i32, i32, dp]
+    L.srack_patch_connect.argtypes = [vp, i32, i32, i32, i32]
+    L.srack_patch_disconnect.argtypes = [vp, i32, i32]
+    L.srack_patch_get_input.argtypes = [vp, i32, i32, ip, ip]
+    L.srack_patch_plan.argtypes = [vp, ip, i32]
+    L.srack_patch_plan_list.argtypes = [vp, i32, ip, i32, ip, i32]
+    L.srack_patch_removed_edges.argtypes = [vp, ip, i32]
+    L.srack_patch_delayed_edges.argtypes = [vp, ip, i32]
+    L.srack_voices_configure.argtypes = [vp, u32]
+    L.srack_voices_set_field_f32.argtypes = [vp, i32, i32, fp]
+    L.srack_voices_set_field_f64.argtypes = [vp, i32, i32, dp]
+    L.srack_render_planes.argtypes = [vp, ip, i32]
+    L.srack_render.argtypes = [vp, u32, vp, vp, u32, vp]
+    L.srack_render_info.argtypes = [vp, C.c_char_p, sz]
+    L.srack_render_kernel_ms.argtypes = [vp, dp, ip, i32]
+    L.srack_voices_get_field.argtypes = [vp, i32, i32, dp]
+    L.srack_device_count.argtypes = [ip]
+    L.srack_device_set.argtypes = [i32]
+    L.srack_device_alloc.argtypes = [C.POINTER(vp), sz]
+    L.srack_device_free.argtypes = [vp]
+    L.srack_device_to_host.argtypes = [vp, vp, sz, vp]
+    L.srack_device_sync.argtypes = [vp]
+    L.srack_dist_reduce_mix.argtypes = [vp, vp, sz, i32, vp]
+    return L
+
+
+lib = _load()
+
+
+def _check(rc):
+    if rc < 0:
+        raise SrackError(rc, lib.srack_last_error().decode())
+    return rc
+
+
+def device_count():
+    n = C.c_int(0)
+    lib.srack_device_count(C.byref(n))
+    return n.value
+
+
+class Patch:
+    """The workspace's module list + plan + N voices, behind the C ABI.
+
+    Reference API mirrored: `SynthModule::set_input` -> connect, `disconnect_input` -> disconnect,
+    `get_input`, `get_num_inputs/outputs`, `plan_execution` -> plan, `execute` (x ceil(T/B) blocks)
+    -> render.  Errors the reference reports as `Err(())` / panics raise SrackError(code).
+    """
+
+    def __init__(self, sample_rate=48000, buffer_size=1024, channels=2):
+        self.sample_rate, self.buffer_size, self.channels = sample_rate, buffer_size, channels
+        h = C.c_void_p()
+        _check(lib.srack_patch_create(sample_rate, buffer_size, channels, C.byref(h)))
+        self.h = h
+        self.n_voices = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.srack_patch_destroy(self.h)
+            self.h = None
+
+    # ---- graph ------------------------------------------------------------------------------
+    def add_module(self, module_type):
+        return _check(lib.srack_patch_add_module(self.h, module_type))
+
+    def num_modules(self):
+        return _check(lib.srack_patch_num_modules(self.h))
+
+    def module_type(self, module):
+        return _check(lib.srack_patch_module_type(self.h, module))
+
+    def get_num_inputs(self, module):
+        return _check(lib.srack_module_num_inputs(self.h, module))
+
+    def get_num_outputs(self, module):
+        return _check(lib.srack_module_num_outputs(self.h, module))
+
+    def set_field(self, module, field, value):
+        _check(lib.srack_patch_set_field(self.h, module, field, float(value)))
+
+    def get_field(self, module, field):
+        v = C.c_double()
+        _check(lib.srack_patch_get_field(self.h, module, field, C.byref(v)))
+        return v.value
+
+    def connect(self, src, src_port, sink, sink_port):
+        _check(lib.srack_patch_connect(self.h, src, src_port, sink, sink_port))
+
+    def disconnect(self, sink, sink_port):
+        _check(lib.srack_patch_disconnect(self.h, sink, sink_port))
+
+    def get_input(self, sink, sink_port):
+        m, p = C.c_int(), C.c_int()
+        _check(lib.srack_patch_get_input(self.h, sink, sink_port, C.byref(m), C.byref(p)))
+        return None if m.value < 0 else (m.value, p.value)
+
+    def plan(self, output=None, all_modules=None):
+        buf = (C.c_int * 1024)()
+        if output is None and all_modules is None:
+            n = _check(lib.srack_patch_plan(self.h, buf, 1024))
+        else:
+            if all_modules is None:
+                all_modules = list(range(self.num_modules()))
+            arr = (C.c_int * len(all_modules))(*all_modules)
+            n = _check(lib.srack_patch_plan_list(self.h, output, arr, len(all_modules), buf, 1024))
+        return list(buf[:n])
+
+    def removed_edges(self):
+        buf = (C.c_int * 512)()
+        n = _check(lib.srack_patch_removed_edges(self.h, buf, 256))
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
+
+    def delayed_edges(self):
+        buf = (C.c_int * 1024)()
+        n = _check(lib.srack_patch_delayed_edges(self.h, buf, 256))
+        return [tuple(buf[4 * i:4 * i + 4]) for i in range(n)]
+
+    # ---- voices -----------------------------------------------------------------------------
+    def configure_voices(self, n_voices):
+        _check(lib.srack_voices_configure(self.h, n_voices))
+        self.n_voices = n_voices
+
+    def set_voice_field(self, module, field, values):
+        values = np.asarray(values)
+        assert values.shape == (self.n_voices,)
+        if values.dtype == np.float64:
+            a = np.ascontiguousarray(values)
+            _check(lib.srack_voices_set_field_f64(self.h, module, field, a.ctypes.data_as(C.POINTER(C.c_double))))
+        else:
+            a = np.ascontiguousarray(values, dtype=np.float32)
+            _check(lib.srack_voices_set_field_f32(self.h, module, field, a.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def get_voice_field(self, module, field):
+        out = np.empty(self.n_voices, dtype=np.float64)
+        _check(lib.srack_voices_get_field(self.h, module, field, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    # ---- render -----------------------------------------------------------------------------
+    def planes(self):
+        buf = (C.c_int * 8)()
+        n = _check(lib.srack_render_planes(self.h, buf, 8))
+        return n, list(buf[:self.channels])
+
+    def render_raw(self, n_samples, d_frames=None, d_mix=None, flags=0, stream=None):
+        """Device pointers (ints) in; asynchronous on `stream`."""
+        _check(lib.srack_render(self.h, n_samples, d_frames, d_mix, flags, stream))
+
+    def info(self):
+        buf = C.create_string_buffer(512)
+        _check(lib.srack_render_info(self.h, buf, 512))
+        return buf.value.decode()
+
+    def kernel_ms(self, reset=True):
+        ms, n = C.c_double(), C.c_int()
+        _check(lib.srack_render_kernel_ms(self.h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+    def render(self, n_samples, frames=True, mix=True, flags=0):
+        """Convenience for tests: allocates device buffers through the C ABI's device helpers,
+        renders, copies back.  -> (frames [planes][T][V] f32 or None, mix [C][T] f32 or None)."""
+        if self.n_voices == 0:
+            self.configure_voices(1)
+        n_planes, _ = self.planes()
+        V, T, Cn = self.n_voices, n_samples, self.channels
+        d_fr, d_mx = C.c_void_p(), C.c_void_p()
+        try:
+            if frames and n_planes > 0:
+                _check(lib.srack_device_alloc(C.byref(d_fr), max(1, n_planes * T * V * 4)))
+            if mix:
+                _check(lib.srack_device_alloc(C.byref(d_mx), max(1, Cn * T * 4)))
+            self.render_raw(T, d_fr if d_fr.value else None, d_mx if d_mx.value else None, flags, None)
+            fr = mx = None
+            if frames:
+                fr = np.zeros((n_planes, T, V), dtype=np.float32)
+                if d_fr.value:
+                    _check(lib.srack_device_to_host(fr.ctypes.data_as(C.c_void_p), d_fr, fr.nbytes, None))
+            if mix:
+                mx = np.empty((Cn, T), dtype=np.float32)
+                _check(lib.srack_device_to_host(mx.ctypes.data_as(C.c_void_p), d_mx, mx.nbytes, None))
+            _check(lib.srack_device_sync(None))
+            return fr, mx
+        finally:
+            if d_fr.value:
+                lib.srack_device_free(d_fr)
+            if d_mx.value:
+                lib.srack_device_free(d_mx)
+
+    def render_channels(self, n_samples, flags=0):
+        """-> [channels][T][V] f32 (planes expanded to channels, silence for unconnected ones)."""
+        fr, _ = self.render(n_samples, frames=True, mix=False, flags=flags)
+        _, cp = self.planes()
+        out = np.zeros((self.channels, n_samples, self.n_voices), dtype=np.float32)
+        for c, p in enumerate(cp):
+            if p >= 0:
+                out[c] = fr[p]
+        return out

@@ -1,0 +1,375 @@
+// capi.cpp — the extern "C" boundary declared in include/srack_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "runtime.hpp"
+
+using namespace srack;
+
+struct srack_patch {
+    PatchHandle h;
+};
+
+#define CHECK_HANDLE(p)                       \
+    do {                                      \
+        if (!(p)) {                           \
+            set_error("null patch handle");   \
+            return SRACK_ERR_INVALID;         \
+        }                                     \
+    } while (0)
+
+#define HIP_TRY_C(expr)                                                     \
+    do {                                                                    \
+        hipError_t e_ = (expr);                                             \
+        if (e_ != hipSuccess) {                                             \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));   \
+            return SRACK_ERR_DEVICE;                                        \
+        }                                                                   \
+    } while (0)
+
+template <typename T>
+static int set_voice_field(srack_patch* p, int module, int field, const T* values)
+{
+    CHECK_HANDLE(p);
+    PatchHandle& h = p->h;
+    if (h.n_voices == 0) {
+        set_error("voices_set_field: call srack_voices_configure first");
+        return SRACK_ERR_STATE;
+    }
+    int nf = h.graph.num_fields(module);
+    if (nf < 0 || field < 0 || field >= nf || !values) {
+        set_error("voices_set_field: no such module/field");
+        return SRACK_ERR_INVALID;
+    }
+    VoiceOverride o;
+    o.module = module;
+    o.field = field;
+    o.values.resize(h.n_voices);
+    const int type = h.graph.modules[(size_t)module].type;
+    const bool f64 = Graph::field_is_f64(type, field), flag = Graph::field_is_flag(type, field);
+    for (uint32_t v = 0; v < h.n_voices; v++) {
+        double x = (double)values[v];
+        o.values[v] = f64 ? x : (flag ? (double)(int)x : (double)(float)x);
+    }
+    for (auto it = h.overrides.begin(); it != h.overrides.end();)
+        it = (it->module == module && it->field == field) ? h.overrides.erase(it) : it + 1;
+    h.overrides.push_back(std::move(o));
+    h.voices_revision++;
+    return SRACK_OK;
+}
+
+extern "C" {
+
+int srack_abi_version(void) { return SRACK_ABI_VERSION; }
+const char* srack_last_error(void) { return last_error(); }
+
+int srack_patch_create(uint32_t sample_rate, uint32_t buffer_size, uint32_t channels, srack_patch** out)
+{
+    if (!out) {
+        set_error("srack_patch_create: out is null");
+        return SRACK_ERR_INVALID;
+    }
+    *out = nullptr;
+    if (sample_rate == 0 || sample_rate > 65535u) {  // AudioConfig.sample_rate is a u16 (synth.rs:22)
+        set_error("srack_patch_create: sample_rate must fit the reference's u16 (1..65535)");
+        return SRACK_ERR_INVALID;
+    }
+    if (buffer_size == 0) {
+        set_error("srack_patch_create: buffer_size must be >= 1");
+        return SRACK_ERR_INVALID;
+    }
+    if (channels == 0 || channels > 8) {
+        set_error("srack_patch_create: channels must be 1..8");
+        return SRACK_ERR_INVALID;
+    }
+    auto* p = new (std::nothrow) srack_patch();
+    if (!p) return SRACK_ERR_NOMEM;
+    p->h.graph.cfg = AudioConfig{sample_rate, buffer_size, channels};
+    *out = p;
+    return SRACK_OK;
+}
+
+int srack_patch_destroy(srack_patch* p)
+{
+    delete p;
+    return SRACK_OK;
+}
+
+int srack_patch_add_module(srack_patch* p, int module_type)
+{
+    CHECK_HANDLE(p);
+    return p->h.graph.add_module(module_type);
+}
+
+int srack_patch_num_modules(const srack_patch* p)
+{
+    CHECK_HANDLE(p);
+    return (int)p->h.graph.modules.size();
+}
+
+static const Module* get_module(const srack_patch* p, int module)
+{
+    if (!p || module < 0 || module >= (int)p->h.graph.modules.size()) {
+        set_error("no such module");
+        return nullptr;
+    }
+    return &p->h.graph.modules[(size_t)module];
+}
+
+int srack_patch_module_type(const srack_patch* p, int module)
+{
+    const Module* m = get_module(p, module);
+    return m ? m->type : SRACK_ERR_INVALID;
+}
+
+int srack_module_num_inputs(const srack_patch* p, int module)
+{
+    const Module* m = get_module(p, module);
+    return m ? m->n_in : SRACK_ERR_INVALID;
+}
+
+int srack_module_num_outputs(const srack_patch* p, int module)
+{
+    const Module* m = get_module(p, module);
+    return m ? m->n_out : SRACK_ERR_INVALID;
+}
+
+int srack_patch_set_field(srack_patch* p, int module, int field, double value)
+{
+    CHECK_HANDLE(p);
+    return p->h.graph.set_field(module, field, value);
+}
+
+int srack_patch_get_field(const srack_patch* p, int module, int field, double* value)
+{
+    CHECK_HANDLE(p);
+    return p->h.graph.get_field(module, field, value);
+}
+
+int srack_patch_connect(srack_patch* p, int src_module, int src_port, int sink_module, int sink_port)
+{
+    CHECK_HANDLE(p);
+    return p->h.graph.connect(src_module, src_port, sink_module, sink_port);
+}
+
+int srack_patch_disconnect(srack_patch* p, int sink_module, int sink_port)
+{
+    CHECK_HANDLE(p);
+    return p->h.graph.disconnect(sink_module, sink_port);
+}
+
+int srack_patch_get_input(const srack_patch* p, int sink_module, int sink_port, int* src_module, int* src_port)
+{
+    const Module* m = get_module(p, sink_module);
+    if (!m) return SRACK_ERR_INVALID;
+    if (sink_port < 0 || sink_port >= m->n_in) {
+        set_error("get_input: port index out of range");
+        return SRACK_ERR_PORT;
+    }
+    if (src_module) *src_module = m->in[(size_t)sink_port].src;
+    if (src_port) *src_port = m->in[(size_t)sink_port].port;
+    return SRACK_OK;
+}
+
+int srack_patch_plan(srack_patch* p, int* order, int cap)
+{
+    CHECK_HANDLE(p);
+    Graph& g = p->h.graph;
+    int n = g.make_plan();
+    if (g.plan.output < 0) {
+        set_error("plan: no OutputModule in the module list (plan is empty)");
+        return SRACK_ERR_NO_OUTPUT;
+    }
+    for (int i = 0; i < n && i < cap && order; i++) order[i] = g.plan.order[(size_t)i];
+    return n;
+}
+
+int srack_patch_plan_list(srack_patch* p, int output, const int* all_modules, int n_all, int* order, int cap)
+{
+    CHECK_HANDLE(p);
+    Graph& g = p->h.graph;
+    const int n_mod = (int)g.modules.size();
+    if (output < 0 || output >= n_mod || !all_modules) {
+        set_error("plan_list: bad output / list");
+        return SRACK_ERR_INVALID;
+    }
+    std::vector<int> all(all_modules, all_modules + n_all);
+    for (int m : all)
+        if (m < 0 || m >= n_mod) {
+            set_error("plan_list: module index out of range");
+            return SRACK_ERR_INVALID;
+        }
+    int n = g.make_plan(output, all);
+    for (int i = 0; i < n && i < cap && order; i++) order[i] = g.plan.order[(size_t)i];
+    g.plan.valid = false;  // a shuffled list is a test device; renders always plan in list order
+    return n;
+}
+
+int srack_patch_removed_edges(srack_patch* p, int* pairs, int cap)
+{
+    CHECK_HANDLE(p);
+    const auto& r = p->h.graph.plan.removed;
+    for (size_t i = 0; i < r.size() && (int)i < cap && pairs; i++) {
+        pairs[2 * i] = r[i].first;
+        pairs[2 * i + 1] = r[i].second;
+    }
+    return (int)r.size();
+}
+
+int srack_patch_delayed_edges(srack_patch* p, int* quads, int cap)
+{
+    CHECK_HANDLE(p);
+    Graph& g = p->h.graph;
+    if (!g.plan.valid) g.make_plan();
+    auto edges = g.delayed_edges();
+    for (size_t i = 0; i < edges.size() && (int)i < cap && quads; i++) {
+        quads[4 * i + 0] = edges[i].src;
+        quads[4 * i + 1] = edges[i].src_port;
+        quads[4 * i + 2] = edges[i].sink;
+        quads[4 * i + 3] = edges[i].sink_port;
+    }
+    return (int)edges.size();
+}
+
+int srack_voices_configure(srack_patch* p, uint32_t n_voices)
+{
+    CHECK_HANDLE(p);
+    if (n_voices == 0) {
+        set_error("voices_configure: n_voices must be >= 1");
+        return SRACK_ERR_INVALID;
+    }
+    p->h.n_voices = n_voices;
+    p->h.overrides.clear();
+    p->h.voices_revision++;
+    return SRACK_OK;
+}
+
+int srack_voices_set_field_f32(srack_patch* p, int module, int field, const float* values) { return set_voice_field(p, module, field, values); }
+int srack_voices_set_field_f64(srack_patch* p, int module, int field, const double* values) { return set_voice_field(p, module, field, values); }
+
+int srack_render_planes(srack_patch* p, int* channel_plane, int cap)
+{
+    CHECK_HANDLE(p);
+    int rc = ensure_program(p->h, p->h.prog_valid ? p->h.prog_flags : 0u);
+    if (rc != SRACK_OK) return rc;
+    for (int c = 0; c < p->h.prog.hdr.n_channels && c < cap && channel_plane; c++) channel_plane[c] = p->h.prog.hdr.channel_plane[c];
+    return p->h.prog.hdr.n_planes;
+}
+
+int srack_render(srack_patch* p, uint32_t n_samples, float* d_frames, float* d_mix, uint32_t flags, void* stream)
+{
+    CHECK_HANDLE(p);
+    if (p->h.n_voices == 0) {
+        set_error("render: call srack_voices_configure first");
+        return SRACK_ERR_STATE;
+    }
+    return device_render(p->h, n_samples, d_frames, d_mix, flags, stream);
+}
+
+int srack_render_info(srack_patch* p, char* buf, size_t cap)
+{
+    CHECK_HANDLE(p);
+    int rc = ensure_program(p->h, p->h.prog_valid ? p->h.prog_flags : 0u);
+    if (rc != SRACK_OK) return rc;
+    std::string s = p->h.prog.description;
+    const char* k = device_kernel_name(p->h);
+    if (k && *k) s += std::string(" kernel=") + k;
+    if (buf && cap) {
+        std::strncpy(buf, s.c_str(), cap - 1);
+        buf[cap - 1] = 0;
+    }
+    return (int)s.size();
+}
+
+int srack_render_kernel_ms(srack_patch* p, double* avg_ms, int* n_launches, int reset)
+{
+    CHECK_HANDLE(p);
+    return device_kernel_ms(p->h, avg_ms, n_launches, reset);
+}
+
+int srack_voices_get_field(srack_patch* p, int module, int field, double* values)
+{
+    CHECK_HANDLE(p);
+    PatchHandle& h = p->h;
+    if (!values || h.n_voices == 0) {
+        set_error("voices_get_field: bad arguments / voices not configured");
+        return SRACK_ERR_INVALID;
+    }
+    int rc = ensure_program(h, h.prog_valid ? h.prog_flags : 0u);
+    if (rc != SRACK_OK) return rc;
+    StateLoc loc = h.prog.locate(h.graph, module, field);
+    if (loc.row < 0) {  // a parameter, or a module that is not evaluated: the field value itself
+        double x;
+        rc = h.graph.get_field(module, field, &x);
+        if (rc != SRACK_OK) return rc;
+        for (uint32_t v = 0; v < h.n_voices; v++) values[v] = x;
+        for (const auto& o : h.overrides)
+            if (o.module == module && o.field == field)
+                for (uint32_t v = 0; v < h.n_voices; v++) values[v] = o.values[v];
+        return SRACK_OK;
+    }
+    const uint32_t V = h.n_voices;
+    std::vector<uint32_t> rows((size_t)V * (loc.f64 ? 2 : 1));
+    rc = device_read_rows(h, loc.row, loc.f64 ? 2 : 1, rows.data());
+    if (rc != SRACK_OK) return rc;
+    for (uint32_t v = 0; v < V; v++) {
+        if (loc.f64) {
+            uint64_t u = (uint64_t)rows[v] | ((uint64_t)rows[(size_t)V + v] << 32);
+            std::memcpy(&values[v], &u, 8);
+        } else if (loc.flag) {
+            values[v] = (double)(int32_t)rows[v];
+        } else {
+            float f;
+            std::memcpy(&f, &rows[v], 4);
+            values[v] = (double)f;
+        }
+    }
+    return SRACK_OK;
+}
+
+// ---- device helpers -------------------------------------------------------------------------------
+int srack_device_count(int* n)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) c = 0;
+    if (n) *n = c;
+    return SRACK_OK;
+}
+
+int srack_device_set(int device)
+{
+    HIP_TRY_C(hipSetDevice(device));
+    return SRACK_OK;
+}
+
+int srack_device_alloc(void** d_ptr, size_t bytes)
+{
+    if (!d_ptr) return SRACK_ERR_INVALID;
+    HIP_TRY_C(hipMalloc(d_ptr, bytes));
+    return SRACK_OK;
+}
+
+int srack_device_free(void* d_ptr)
+{
+    HIP_TRY_C(hipFree(d_ptr));
+    return SRACK_OK;
+}
+
+int srack_device_to_host(void* h_dst, const void* d_src, size_t bytes, void* stream)
+{
+    HIP_TRY_C(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));
+    return SRACK_OK;
+}
+
+int srack_device_sync(void* stream)
+{
+    HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));
+    return SRACK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,570 @@
+// flatten.cpp — plan -> DevOp list + initial voice table.
+//
+// What happens here, in order:
+//   1. plan (graph.cpp, = plan_execution) and find the modules that can reach the OutputModule;
+//      modules that cannot are not evaluated (their buffers are unobservable offline).
+//   2. dead-port elimination: an oscillator / filter port nobody reads is not computed
+//      (the reference always computes all three, oscillator.rs:133-149; results on the read
+//      ports are unaffected).
+//   3. wires whose source runs after its sink (broken feedback edges) become a ring of
+//      buffer_size samples per voice: OP_DELAY_RD before the sink, OP_DELAY_WR after the source.
+//   4. constant hoisting: an oscillator without CV has a constant increment
+//      delta = 440 * 2^f64(val) / f64(sample_rate); it is computed here with glibc pow — the very
+//      value the reference recomputes every sample (oscillator.rs:43-48,132) — per voice.
+//   5. wire slots by linear scan over the op sequence; voice-table rows for state and per-voice
+//      parameters; tile size from the LDS budget.
+//   6. pattern match for the fused chain kernels.
+#include "flatten.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <sstream>
+
+namespace srack {
+
+namespace {
+
+constexpr int kRingLdsMax = 16;         // rings up to this many samples live in LDS rows (persisted as state)
+constexpr int kTileMax = 32;            // samples per interpreter tile
+constexpr int kLdsBudget = 40 * 1024;   // bytes of LDS per wave the interpreter may use (=> >= 4 waves / CU)
+
+struct Wire {
+    int def_op = -1;
+    int last_use = -1;
+    int slot = -1;
+};
+
+uint32_t f32_bits(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+struct Builder {
+    Graph& g;
+    uint32_t V;
+    const std::vector<VoiceOverride>& ov;
+    FlatProgram& out;
+    std::vector<Wire> wires;
+    std::vector<std::vector<uint32_t>> rows;  // row-major voice table under construction
+
+    const VoiceOverride* find_override(int module, int field) const
+    {
+        const VoiceOverride* hit = nullptr;
+        for (const auto& o : ov)
+            if (o.module == module && o.field == field) hit = &o;  // last one wins
+        return hit;
+    }
+
+    double field(int module, int f) const { return g.modules[(size_t)module].fields[(size_t)f]; }
+
+    int new_row() {
+        rows.emplace_back();
+        return (int)rows.size() - 1;
+    }
+
+    // a 32-bit state row initialised from a module field (uniform or per-voice override)
+    int state_row_f32(int module, int f)
+    {
+        int r = new_row();
+        auto& row = rows[(size_t)r];
+        row.resize(V);
+        if (const VoiceOverride* o = find_override(module, f))
+            for (uint32_t v = 0; v < V; v++) row[v] = f32_bits((float)o->values[v]);
+        else
+            std::fill(row.begin(), row.end(), f32_bits((float)field(module, f)));
+        return r;
+    }
+
+    int state_row_flag(int module, int f)
+    {
+        int r = new_row();
+        auto& row = rows[(size_t)r];
+        row.resize(V);
+        if (const VoiceOverride* o = find_override(module, f))
+            for (uint32_t v = 0; v < V; v++) row[v] = (uint32_t)(int)o->values[v];
+        else
+            std::fill(row.begin(), row.end(), (uint32_t)(int)field(module, f));
+        return r;
+    }
+
+    // two rows (lo, hi) holding an f64
+    int rows_f64(const std::vector<double>* per_voice, double uniform)
+    {
+        int lo = new_row(), hi = new_row();
+        rows[(size_t)lo].resize(V);
+        rows[(size_t)hi].resize(V);
+        for (uint32_t v = 0; v < V; v++) {
+            double d = per_voice ? (*per_voice)[v] : uniform;
+            uint64_t u;
+            std::memcpy(&u, &d, 8);
+            rows[(size_t)lo][v] = (uint32_t)u;
+            rows[(size_t)hi][v] = (uint32_t)(u >> 32);
+        }
+        return lo;
+    }
+
+    // parameter k of `op`: per-voice row if overridden, uniform scalar otherwise
+    void param(DevOp& op, int k, int module, int f, std::vector<std::pair<int, const VoiceOverride*>>& deferred)
+    {
+        op.par_val[k] = (float)field(module, f);
+        op.par_row[k] = -1;
+        if (const VoiceOverride* o = find_override(module, f)) {
+            op.par_row[k] = -2;  // patched to a real row after all state rows are allocated
+            deferred.emplace_back((int)out.ops.size() * kMaxPar + k, o);
+        }
+    }
+};
+
+}  // namespace
+
+StateLoc FlatProgram::locate(const Graph& g, int module, int field) const
+{
+    StateLoc loc;
+    if (module < 0 || module >= (int)op_of_module.size()) return loc;
+    int oi = op_of_module[(size_t)module];
+    if (oi < 0) return loc;
+    const DevOp& op = ops[(size_t)oi];
+    int type = g.modules[(size_t)module].type;
+    if (!Graph::field_is_state(type, field) || op.state_row < 0) return loc;
+    switch (type) {
+    case SRACK_MOD_OSCILLATOR:
+        if (field == SRACK_OSC_POS) {
+            loc.row = op.state_row + OSC_S_POS_LO;
+            loc.f64 = true;
+        } else {
+            loc.row = op.state_row + OSC_S_SYNC_LAST;
+            loc.flag = true;
+        }
+        break;
+    case SRACK_MOD_MOOG_FILTER:
+        if (field <= SRACK_VCF_ST_Q)
+            loc.row = op.state_row + VCF_S_F + (field - SRACK_VCF_ST_F);
+        else if (field <= SRACK_VCF_ST_B4)
+            loc.row = op.state_row + VCF_S_B0 + (field - SRACK_VCF_ST_B0);
+        else
+            loc.row = op.state_row + VCF_S_FREQ + (field - SRACK_VCF_ST_FREQ);
+        break;
+    case SRACK_MOD_ADSR:
+        switch (field) {
+        case SRACK_ADSR_PHASE: loc.row = op.state_row + ADSR_S_PHASE; break;
+        case SRACK_ADSR_MODE: loc.row = op.state_row + ADSR_S_MODE; loc.flag = true; break;
+        case SRACK_ADSR_R_VAL: loc.row = op.state_row + ADSR_S_R_VAL; break;
+        case SRACK_ADSR_FROM_A_VAL: loc.row = op.state_row + ADSR_S_FROM_A; break;
+        case SRACK_ADSR_GATE_LAST: loc.row = op.state_row + ADSR_S_GATE_LAST; loc.flag = true; break;
+        }
+        break;
+    }
+    return loc;
+}
+
+int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overrides, uint32_t render_flags, FlatProgram& out)
+{
+    out = FlatProgram{};
+    out.n_voices = n_voices;
+    out.render_flags = render_flags;
+    if (n_voices == 0) {
+        set_error("flatten: n_voices = 0 (call srack_voices_configure first)");
+        return SRACK_ERR_STATE;
+    }
+    if (!g.plan.valid) g.make_plan();
+    const int n_mod = (int)g.modules.size();
+    out.op_of_module.assign((size_t)n_mod, -1);
+    DevProgram& H = out.hdr;
+    H.n_channels = (int)g.cfg.channels;
+    H.buffer_size = (int)g.cfg.buffer_size;
+    for (int c = 0; c < 8; c++) H.channel_plane[c] = -1;
+
+    for (const auto& o : overrides) {
+        if (o.module < 0 || o.module >= n_mod || o.field < 0 || o.field >= g.num_fields(o.module) || o.values.size() != n_voices) {
+            set_error("flatten: bad per-voice override");
+            return SRACK_ERR_INVALID;
+        }
+        int type = g.modules[(size_t)o.module].type;
+        if ((type == SRACK_MOD_OSCILLATOR && o.field == SRACK_OSC_ANTIALIASING) || (type == SRACK_MOD_MATH && o.field == SRACK_MATH_OPERATION)) {
+            set_error("flatten: antialiasing / operation select code paths and cannot differ per voice");
+            return SRACK_ERR_UNSUPPORTED;
+        }
+    }
+
+    const int output = g.plan.output;
+    Builder b{g, n_voices, overrides, out, {}, {}};
+    if (output < 0) {  // no OutputModule: empty plan (ui.rs:75-79) => silence
+        out.description = "no OutputModule: empty plan";
+        H.tile = kTileMax;
+        return SRACK_OK;
+    }
+
+    // ---- 1. reachability from the output, 2. live ports -------------------------------------
+    std::vector<char> live((size_t)n_mod, 0);
+    std::vector<uint32_t> port_live((size_t)n_mod, 0);  // bit per output port
+    {
+        std::vector<int> stack{output};
+        while (!stack.empty()) {
+            int m = stack.back();
+            stack.pop_back();
+            if (live[(size_t)m]) continue;
+            live[(size_t)m] = 1;
+            for (const InputRef& in : g.modules[(size_t)m].in)
+                if (in.src >= 0) {
+                    if (in.src == m) {
+                        set_error("module " + std::to_string(m) + " is wired to itself: the reference deadlocks on this (synth.rs:99,251)");
+                        return SRACK_ERR_SELF_LOOP;
+                    }
+                    port_live[(size_t)in.src] |= 1u << in.port;
+                    stack.push_back(in.src);
+                }
+        }
+    }
+    const auto& pos = g.plan.position;
+    auto is_delayed = [&](int src, int sink) { return pos[(size_t)src] > pos[(size_t)sink]; };
+
+    // rings: one per (src, port) that has a delayed reader
+    std::map<std::pair<int, int>, int> ring_of;  // -> ring index
+    struct Ring { int src, port, first_row, global_id, wire; };
+    std::vector<Ring> rings;
+    for (int m : g.plan.order) {
+        if (!live[(size_t)m]) continue;
+        for (const InputRef& in : g.modules[(size_t)m].in)
+            if (in.src >= 0 && is_delayed(in.src, m) && !ring_of.count({in.src, in.port})) {
+                ring_of[{in.src, in.port}] = (int)rings.size();
+                rings.push_back(Ring{in.src, in.port, -1, -1, -1});
+            }
+    }
+    const int B = (int)g.cfg.buffer_size;
+    const bool rings_in_lds = B <= kRingLdsMax;
+
+    // ---- 3.-4. emit ops in plan order ---------------------------------------------------------
+    std::map<std::pair<int, int>, int> wire_of;  // (module, port) -> wire id
+    std::vector<std::pair<int, const VoiceOverride*>> deferred;  // per-voice parameter rows to allocate
+    std::vector<std::pair<int, const VoiceOverride*>> deferred_delta;  // op index, OSC val override
+    auto new_wire = [&](int def_op) {
+        b.wires.push_back(Wire{def_op, def_op, -1});
+        return (int)b.wires.size() - 1;
+    };
+    auto use_wire = [&](int w, int op_index) { b.wires[(size_t)w].last_use = std::max(b.wires[(size_t)w].last_use, op_index); };
+    // in_slot / out_slot temporarily hold WIRE ids; mapped to slots after the scan
+    int n_planes = 0;
+
+    for (int m : g.plan.order) {
+        if (!live[(size_t)m]) continue;
+        const Module& mod = g.modules[(size_t)m];
+        int in_wire[kMaxIn];
+        for (int k = 0; k < kMaxIn; k++) in_wire[k] = -1;
+        for (int k = 0; k < mod.n_in; k++) {
+            const InputRef& in = mod.in[(size_t)k];
+            if (in.src < 0) continue;
+            if (is_delayed(in.src, m)) {
+                int r = ring_of[{in.src, in.port}];
+                DevOp rd{};
+                rd.kind = OP_DELAY_RD;
+                rd.module = in.src;
+                rd.aux = r;  // ring index for now
+                rd.state_row = -1;
+                for (int j = 0; j < kMaxIn; j++) rd.in_slot[j] = -1;
+                for (int j = 0; j < kMaxOut; j++) rd.out_slot[j] = -1;
+                for (int j = 0; j < kMaxPar; j++) rd.par_row[j] = -1;
+                int w = new_wire((int)out.ops.size());
+                rd.out_slot[0] = w;
+                out.ops.push_back(rd);
+                in_wire[k] = w;
+            } else {
+                auto it = wire_of.find({in.src, in.port});
+                if (it == wire_of.end()) {
+                    set_error("flatten: internal error, source wire not defined before its reader");
+                    return SRACK_ERR_INVALID;
+                }
+                in_wire[k] = it->second;
+            }
+        }
+        const int oi = (int)out.ops.size();
+        DevOp op{};
+        op.module = m;
+        op.state_row = -1;
+        op.delta_row = -1;
+        op.aux = 0;
+        for (int j = 0; j < kMaxIn; j++) op.in_slot[j] = in_wire[j];
+        for (int j = 0; j < kMaxOut; j++) op.out_slot[j] = -1;
+        for (int j = 0; j < kMaxPar; j++) op.par_row[j] = -1;
+        for (int k = 0; k < kMaxIn; k++)
+            if (in_wire[k] >= 0) use_wire(in_wire[k], oi);
+        auto connected = [&](int k) { return in_wire[k] >= 0; };
+        const uint32_t pl = port_live[(size_t)m];
+
+        switch (mod.type) {
+        case SRACK_MOD_OSCILLATOR: {
+            op.kind = OP_OSC;
+            if (connected(0)) op.flags |= OSC_HAS_CV;
+            if (connected(1)) op.flags |= OSC_HAS_SYNC;
+            if (b.field(m, SRACK_OSC_ANTIALIASING) != 0.0) op.flags |= OSC_AA;
+            if (pl & 1u) op.flags |= OSC_OUT_SINE;
+            if (pl & 2u) op.flags |= OSC_OUT_SQUARE;
+            if (pl & 4u) op.flags |= OSC_OUT_SAW;
+            if (render_flags & SRACK_RENDER_EXACT_OSC) op.flags |= OSC_EXACT;
+            op.sample_rate = (double)g.cfg.sample_rate;  // `self.sample_rate as f64`, u16 in the reference
+            {   // pos: f64 state, two rows (lo, hi)
+                const VoiceOverride* o = b.find_override(m, SRACK_OSC_POS);
+                op.state_row = b.rows_f64(o ? &o->values : nullptr, b.field(m, SRACK_OSC_POS));
+            }
+            b.state_row_flag(m, SRACK_OSC_SYNC_LAST);
+            b.param(op, OSC_P_VAL, m, SRACK_OSC_VAL, deferred);
+            if (!(op.flags & OSC_HAS_CV)) {
+                // get_freq_in_hz(None, i) / sample_rate — loop-invariant, same bits as the reference
+                op.delta = 440.0 * std::pow(2.0, (double)(float)b.field(m, SRACK_OSC_VAL)) / op.sample_rate;
+                if (const VoiceOverride* o = b.find_override(m, SRACK_OSC_VAL)) {
+                    op.delta_row = -2;
+                    deferred_delta.emplace_back(oi, o);
+                }
+            }
+            break;
+        }
+        case SRACK_MOD_MOOG_FILTER:
+            op.kind = OP_VCF;
+            if (connected(0)) op.flags |= VCF_HAS_AUDIO;
+            if (connected(1)) op.flags |= VCF_HAS_CV;
+            if (pl & 1u) op.flags |= VCF_OUT_LP;
+            if (pl & 2u) op.flags |= VCF_OUT_BP;
+            if (pl & 4u) op.flags |= VCF_OUT_HP;
+            op.state_row = b.state_row_f32(m, SRACK_VCF_ST_F);
+            b.state_row_f32(m, SRACK_VCF_ST_P);
+            b.state_row_f32(m, SRACK_VCF_ST_Q);
+            for (int k = 0; k < 5; k++) b.state_row_f32(m, SRACK_VCF_ST_B0 + k);
+            b.state_row_f32(m, SRACK_VCF_ST_FREQ);
+            b.state_row_f32(m, SRACK_VCF_ST_RES);
+            b.param(op, VCF_P_FREQ, m, SRACK_VCF_FREQ, deferred);
+            b.param(op, VCF_P_RES, m, SRACK_VCF_RES, deferred);
+            b.param(op, VCF_P_EXP, m, SRACK_VCF_EXP_AMT, deferred);
+            break;
+        case SRACK_MOD_ADSR:
+            op.kind = OP_ADSR;
+            if (connected(0)) op.flags |= ADSR_HAS_GATE;
+            op.state_row = b.state_row_f32(m, SRACK_ADSR_PHASE);
+            b.state_row_flag(m, SRACK_ADSR_MODE);
+            b.state_row_f32(m, SRACK_ADSR_R_VAL);
+            b.state_row_f32(m, SRACK_ADSR_FROM_A_VAL);
+            b.state_row_flag(m, SRACK_ADSR_GATE_LAST);
+            b.param(op, ADSR_P_A, m, SRACK_ADSR_A_SEC, deferred);
+            b.param(op, ADSR_P_D, m, SRACK_ADSR_D_SEC, deferred);
+            b.param(op, ADSR_P_S, m, SRACK_ADSR_S_VAL, deferred);
+            b.param(op, ADSR_P_R, m, SRACK_ADSR_R_SEC, deferred);
+            b.param(op, ADSR_P_SR, m, SRACK_ADSR_SAMPLE_RATE, deferred);
+            break;
+        case SRACK_MOD_VCA:
+            op.kind = OP_VCA;
+            if (connected(0)) op.flags |= VCA_HAS_AUDIO;
+            if (connected(1)) op.flags |= VCA_HAS_CV;
+            b.param(op, VCA_P_NEG, m, SRACK_VCA_NEGATIVE, deferred);
+            break;
+        case SRACK_MOD_MONO_MIXER:
+            op.kind = OP_MIX;
+            for (int k = 0; k < 4; k++) {
+                if (connected(k)) op.flags |= 1u << k;
+                b.param(op, MIX_P_GAIN0 + k, m, SRACK_MIX_GAIN0 + k, deferred);
+            }
+            break;
+        case SRACK_MOD_MATH:
+            op.kind = OP_MATH;
+            if (connected(0)) op.flags |= MATH_HAS_IN1;
+            if (connected(1)) op.flags |= MATH_HAS_IN2;
+            op.flags |= ((uint32_t)(int)b.field(m, SRACK_MATH_OPERATION) & 3u) << MATH_OP_SHIFT;
+            b.param(op, MATH_P_CONST, m, SRACK_MATH_CONSTANT, deferred);
+            break;
+        case SRACK_MOD_OUTPUT:
+            op.kind = OP_OUT;
+            break;
+        default:
+            set_error("flatten: unsupported module type");
+            return SRACK_ERR_UNSUPPORTED;
+        }
+
+        if (mod.type == SRACK_MOD_OUTPUT) {
+            if (m != output) continue;  // a second OutputModule is never the plan's sink; it has no readers
+            // one OP_OUT per distinct source wire (plane); channels map onto planes
+            std::map<int, int> plane_of_wire;
+            for (int c = 0; c < mod.n_in && c < 8; c++) {
+                if (in_wire[c] < 0) continue;
+                auto it = plane_of_wire.find(in_wire[c]);
+                if (it == plane_of_wire.end()) {
+                    DevOp o2 = op;
+                    for (int j = 0; j < kMaxIn; j++) o2.in_slot[j] = -1;
+                    o2.in_slot[0] = in_wire[c];
+                    o2.aux = n_planes;
+                    use_wire(in_wire[c], (int)out.ops.size());
+                    out.ops.push_back(o2);
+                    it = plane_of_wire.emplace(in_wire[c], n_planes++).first;
+                }
+                H.channel_plane[c] = it->second;
+            }
+            out.op_of_module[(size_t)m] = oi;
+            continue;
+        }
+
+        for (int p = 0; p < mod.n_out; p++)
+            if (pl & (1u << p)) {
+                int w = new_wire(oi);
+                op.out_slot[p] = w;
+                wire_of[{m, p}] = w;
+            }
+        out.op_of_module[(size_t)m] = oi;
+        out.ops.push_back(op);
+        // source side of every ring fed by this module
+        for (int p = 0; p < mod.n_out; p++) {
+            auto it = ring_of.find({m, p});
+            if (it == ring_of.end()) continue;
+            DevOp wr{};
+            wr.kind = OP_DELAY_WR;
+            wr.module = m;
+            wr.aux = it->second;
+            wr.state_row = -1;
+            for (int j = 0; j < kMaxIn; j++) wr.in_slot[j] = -1;
+            for (int j = 0; j < kMaxOut; j++) wr.out_slot[j] = -1;
+            for (int j = 0; j < kMaxPar; j++) wr.par_row[j] = -1;
+            wr.in_slot[0] = wire_of[{m, p}];
+            use_wire(wr.in_slot[0], (int)out.ops.size());
+            out.ops.push_back(wr);
+        }
+    }
+    if ((int)out.ops.size() > kMaxOps) {
+        set_error("flatten: patch needs more than " + std::to_string(kMaxOps) + " ops");
+        return SRACK_ERR_UNSUPPORTED;
+    }
+
+    // ---- rings: storage ---------------------------------------------------------------------
+    int n_global = 0;
+    for (Ring& r : rings) {
+        if (rings_in_lds) {
+            r.first_row = (int)b.rows.size();
+            for (int k = 0; k < B; k++) {  // zero-initialised buffer (synth.rs:31-33)
+                int row = b.new_row();
+                b.rows[(size_t)row].assign(n_voices, 0u);
+            }
+        } else {
+            r.global_id = n_global++;
+        }
+    }
+    for (DevOp& op : out.ops)
+        if (op.kind == OP_DELAY_RD || op.kind == OP_DELAY_WR) {
+            const Ring& r = rings[(size_t)op.aux];
+            if (rings_in_lds) {
+                op.aux = r.first_row;
+            } else {
+                op.aux = r.global_id;
+                op.flags |= DELAY_RING_GLOBAL;
+            }
+        }
+    H.n_rings = n_global;
+    H.n_state_rows = (int)b.rows.size();
+
+    // ---- per-voice parameter rows (read-only) -------------------------------------------------
+    for (auto& d : deferred) {
+        DevOp& op = out.ops[(size_t)(d.first / kMaxPar)];
+        int k = d.first % kMaxPar;
+        int r = b.new_row();
+        auto& row = b.rows[(size_t)r];
+        row.resize(n_voices);
+        for (uint32_t v = 0; v < n_voices; v++) row[v] = f32_bits((float)d.second->values[v]);
+        op.par_row[k] = r;
+    }
+    for (auto& d : deferred_delta) {
+        DevOp& op = out.ops[(size_t)d.first];
+        std::vector<double> delta(n_voices);
+        for (uint32_t v = 0; v < n_voices; v++) delta[v] = 440.0 * std::pow(2.0, (double)(float)d.second->values[v]) / op.sample_rate;
+        op.delta_row = b.rows_f64(&delta, 0.0);
+    }
+    H.n_rows = (int)b.rows.size();
+
+    // ---- 5. wire slots: linear scan -----------------------------------------------------------
+    {
+        std::vector<int> free_slots;
+        int n_slots = 0;
+        std::vector<std::vector<int>> expire(out.ops.size() + 1);
+        for (size_t w = 0; w < b.wires.size(); w++) expire[(size_t)b.wires[w].last_use].push_back((int)w);
+        std::vector<std::vector<int>> defs(out.ops.size());
+        for (size_t w = 0; w < b.wires.size(); w++) defs[(size_t)b.wires[w].def_op].push_back((int)w);
+        for (size_t i = 0; i < out.ops.size(); i++) {
+            for (int w : defs[i]) {  // outputs may not reuse this op's input slots: inputs stay live through the op
+                if (free_slots.empty()) {
+                    b.wires[(size_t)w].slot = n_slots++;
+                } else {
+                    b.wires[(size_t)w].slot = free_slots.back();
+                    free_slots.pop_back();
+                }
+            }
+            for (int w : expire[i]) free_slots.push_back(b.wires[(size_t)w].slot);
+        }
+        H.n_slots = n_slots;
+        for (DevOp& op : out.ops) {
+            for (int k = 0; k < kMaxIn; k++)
+                if (op.in_slot[k] >= 0) op.in_slot[k] = b.wires[(size_t)op.in_slot[k]].slot;
+            for (int k = 0; k < kMaxOut; k++)
+                if (op.out_slot[k] >= 0) op.out_slot[k] = b.wires[(size_t)op.out_slot[k]].slot;
+        }
+    }
+    H.n_ops = (int)out.ops.size();
+    H.n_planes = n_planes;
+
+    // ---- tile size from the LDS budget --------------------------------------------------------
+    {
+        int tile = kTileMax;
+        if (!rings.empty())
+            while (tile > B) tile >>= 1;  // a tile may not span more than one ring period
+        while (tile > 1 && (H.n_rows + H.n_slots * tile) * 256 > kLdsBudget) tile >>= 1;
+        if ((H.n_rows + H.n_slots * tile) * 256 > 64 * 1024) {
+            set_error("flatten: patch state does not fit the LDS budget of the tile interpreter");
+            return SRACK_ERR_UNSUPPORTED;
+        }
+        H.tile = tile;
+    }
+
+    // ---- voice table ----------------------------------------------------------------------------
+    out.table.resize((size_t)H.n_rows * n_voices);
+    for (int r = 0; r < H.n_rows; r++) std::memcpy(&out.table[(size_t)r * n_voices], b.rows[(size_t)r].data(), sizeof(uint32_t) * n_voices);
+
+    // ---- 6. fused-kernel pattern match ----------------------------------------------------------
+    if (!(render_flags & SRACK_RENDER_NO_FUSION)) {
+        // voice chain: {OSC_A, OSC_L, VCF, ADSR, VCA, OUT}, no CV/sync on the oscillators, no filter CV,
+        // VCF <- OSC_A, ADSR <- OSC_L, VCA <- (VCF, ADSR), one plane <- VCA, no rings
+        int n_kind[16] = {0};
+        for (const DevOp& op : out.ops) n_kind[op.kind]++;
+        if (rings.empty() && H.n_ops == 6 && n_kind[OP_OSC] == 2 && n_kind[OP_VCF] == 1 && n_kind[OP_ADSR] == 1 && n_kind[OP_VCA] == 1 &&
+            n_kind[OP_OUT] == 1) {
+            const DevOp *vcf = nullptr, *adsr = nullptr, *vca = nullptr, *outp = nullptr;
+            for (const DevOp& op : out.ops) {
+                if (op.kind == OP_VCF) vcf = &op;
+                if (op.kind == OP_ADSR) adsr = &op;
+                if (op.kind == OP_VCA) vca = &op;
+                if (op.kind == OP_OUT) outp = &op;
+            }
+            auto src_of = [&](int sink_module, int k) { return g.modules[(size_t)sink_module].in[(size_t)k]; };
+            const Module& mv = g.modules[(size_t)vca->module];
+            bool ok = vca->flags == (VCA_HAS_AUDIO | VCA_HAS_CV) && mv.in[0].src == vcf->module && mv.in[1].src == adsr->module &&
+                      src_of(outp->module, 0).src >= 0 && g.modules[(size_t)outp->module].in[0].src == vca->module &&
+                      (vcf->flags & (VCF_HAS_AUDIO | VCF_HAS_CV)) == VCF_HAS_AUDIO && (adsr->flags & ADSR_HAS_GATE);
+            if (ok) {
+                int osc_a = src_of(vcf->module, 0).src, osc_l = src_of(adsr->module, 0).src;
+                ok = osc_a != osc_l && g.modules[(size_t)osc_a].type == SRACK_MOD_OSCILLATOR && g.modules[(size_t)osc_l].type == SRACK_MOD_OSCILLATOR;
+                if (ok) {
+                    const DevOp& oa = out.ops[(size_t)out.op_of_module[(size_t)osc_a]];
+                    const DevOp& ol = out.ops[(size_t)out.op_of_module[(size_t)osc_l]];
+                    auto one_port = [](uint32_t f) { uint32_t m = f & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW); return m && !(m & (m - 1)); };
+                    auto one_vcf = [](uint32_t f) { uint32_t m = f & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP); return m && !(m & (m - 1)); };
+                    ok = !(oa.flags & (OSC_HAS_CV | OSC_HAS_SYNC)) && !(ol.flags & (OSC_HAS_CV | OSC_HAS_SYNC)) && one_port(oa.flags) && one_port(ol.flags) &&
+                         one_vcf(vcf->flags) && (oa.flags & OSC_AA) && (ol.flags & OSC_AA);
+                }
+            }
+            if (ok) out.fused = FUSED_VOICE_CHAIN;
+        }
+    }
+
+    std::ostringstream d;
+    d << "ops=" << H.n_ops << " slots=" << H.n_slots << " rows=" << H.n_rows << " (state " << H.n_state_rows << ") planes=" << H.n_planes
+      << " rings=" << rings.size() << (rings.empty() ? "" : (rings_in_lds ? "(lds)" : "(hbm)")) << " tile=" << H.tile << " B=" << B
+      << " fused=" << out.fused;
+    out.description = d.str();
+    return SRACK_OK;
+}
+
+}  // namespace srack

@@ -1,0 +1,46 @@
+// flatten.hpp — plan -> op list.  The host half of "the host flattens the graph into a
+// topologically-ordered op list and calls the HIP kernels".
+#pragma once
+#include <string>
+#include <vector>
+
+#include "graph.hpp"
+#include "program.hpp"
+
+namespace srack {
+
+struct VoiceOverride {  // per-voice values of one module field (srack_voices_set_field_*)
+    int module, field;
+    std::vector<double> values;  // n_voices entries
+};
+
+enum FusedKind : int {
+    FUSED_NONE = 0,
+    FUSED_VOICE_CHAIN = 1,  // OSC -> VCF -> VCA, envelope = ADSR gated by an LFO OSC (patch P1's shape)
+    FUSED_FM_PAIR = 2       // OSC_M (z^-1 feedback through a Multiply) -> Multiply -> OSC_C (patch P2, B = 1)
+};
+
+struct StateLoc {  // where a module's state field lives in the voice table
+    int row = -1;   // first row (-1: field is not device state)
+    bool f64 = false;
+    bool flag = false;
+};
+
+struct FlatProgram {
+    DevProgram hdr{};
+    std::vector<DevOp> ops;
+    std::vector<uint32_t> table;      // [n_rows][n_voices] initial voice table (state rows, then parameter rows)
+    std::vector<int> op_of_module;    // module index -> op index, -1 if the module cannot reach the output
+    int fused = FUSED_NONE;
+    int fused_variant = 0;            // kernel-specific (which oscillator port / filter port the chain uses)
+    uint32_t n_voices = 0;
+    uint32_t render_flags = 0;
+    std::string description;
+
+    StateLoc locate(const Graph& g, int module, int field) const;
+};
+
+// Returns SRACK_OK or an error; on success `out` is complete.
+int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overrides, uint32_t render_flags, FlatProgram& out);
+
+}  // namespace srack

@@ -1,0 +1,332 @@
+// modules.hip.h — one per-sample step function per module type, for one voice (= one lane).
+//
+// These are the arithmetic bodies of the reference's calc() loops (file:line cited per function),
+// written once and inlined both into the tile interpreter (wires in LDS tiles) and into the fused
+// chain kernels (wires in VGPRs).  `flags` is wave-uniform; in the fused kernels it is a
+// compile-time constant and every `if (flags & ...)` folds away.
+//
+// Numerics contract (build: -ffp-contract=off, f32 denormals on, correctly rounded f32 divide):
+//   * VCF / ADSR / VCA / mixer / math: the same IEEE f32 operations in the same order as the
+//     reference => bit-identical to the CPU tick given identical inputs.
+//   * oscillator phase: f64 accumulate + exact wrap => bit-identical `pos` whenever delta is
+//     (constant pitch: delta is computed on the host with glibc pow, like the reference).
+//   * oscillator outputs, default mode: PolyBLEP and sine evaluated in f32 from f64-exact phase
+//     differences (abs error ~1e-7, inside the 1e-5 contract); OSC_EXACT mode: f64 with true
+//     division / ocml sin / pow exactly as oscillator.rs spells them (saw and square bit-identical).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/srack_hip.h"
+#include "program.hpp"
+
+namespace srack {
+namespace dev {
+
+#define SRK_DEV __device__ __forceinline__
+
+// TransitionDetector::is_transition, synth.rs:292-297
+SRK_DEV bool rising_edge(bool& last, float val)
+{
+    bool above = val > 0.0f;
+    bool t = above && !last;
+    last = above;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Oscillator — oscillator.rs:43-67 (get_freq_in_hz, poly_blep), :124-153 (per-sample body)
+// ---------------------------------------------------------------------------------------------
+struct OscRegs {
+    double pos;      // phase in [0,1)
+    bool sync_last;  // sync TransitionDetector.last
+};
+
+struct OscConst {    // per-voice constants, set up once per kernel (or tile)
+    double delta;    // phase increment when CV is unconnected
+    double val;      // f64(val) when CV is connected
+    double sr;       // f64(sample_rate)
+    float inv_dt;    // 1 / f32(delta) for the f32 PolyBLEP (constant pitch)
+};
+
+// poly_blep, f64, literally (oscillator.rs:50-67)
+SRK_DEV double poly_blep_exact(double t, double dt)
+{
+    if (dt == 0.0) return 0.0;
+    if (t < dt) {
+        t /= dt;
+        return t + t - t * t - 1.0;
+    } else if (t > 1.0 - dt) {
+        t = (t - 1.0) / dt;
+        return t * t + t + t + 1.0;
+    }
+    return 0.0;
+}
+
+// poly_blep in f32 from the f64-exact pair (t, t - 1).  `t < dt` <=> t/dt < 1 and
+// `t > 1 - dt` <=> (t-1)/dt > -1; the polynomial is continuous (= 0) at both borders, so a
+// border decided differently from the f64 compare costs nothing.  dt == 0 => inv_dt = inf =>
+// ta = inf or NaN, tb = -inf: both tests false => 0, as the reference's early return.
+SRK_DEV float poly_blep_fast(float t, float tm1, float inv_dt)
+{
+    float ta = t * inv_dt;
+    float tb = tm1 * inv_dt;
+    float fa = __builtin_fmaf(ta, 2.0f - ta, -1.0f);  // 2t - t^2 - 1
+    float fb = __builtin_fmaf(tb, tb + 2.0f, 1.0f);   // t^2 + 2t + 1
+    return ta < 1.0f ? fa : (tb > -1.0f ? fb : 0.0f);
+}
+
+// sin(2*pi*x) for x in [-0.25, 0.25], odd minimax-style polynomial evaluated in f32 (abs err < 6e-8)
+SRK_DEV float sin2pi_quarter(float x)
+{
+    const float c1 = 6.28318530717958647692f, c3 = -41.3417022403997602f, c5 = 81.6052492760750e+0f, c7 = -76.7058597530613f,
+                c9 = 42.0586939448620f, c11 = -15.0946425768229f, c13 = 3.81995258484692f;
+    float x2 = x * x;
+    float p = __builtin_fmaf(c13, x2, c11);
+    p = __builtin_fmaf(p, x2, c9);
+    p = __builtin_fmaf(p, x2, c7);
+    p = __builtin_fmaf(p, x2, c5);
+    p = __builtin_fmaf(p, x2, c3);
+    p = __builtin_fmaf(p, x2, c1);
+    return p * x;
+}
+
+// sin(2*pi*pos), pos in [0,1): reduce around 0.5 in f64 (exact), fold to a quarter wave in f32.
+SRK_DEV float sine_fast(double pos)
+{
+    float q = (float)(pos - 0.5);                 // [-0.5, 0.5); sin(2 pi pos) = -sin(2 pi q)
+    float r = __builtin_copysignf(0.5f, q) - q;   // reflection: sin(2 pi q) = sin(2 pi r) for |q| > 1/4
+    float x = __builtin_fabsf(q) > 0.25f ? r : q;
+    return -sin2pi_quarter(x);
+}
+
+SRK_DEV double wrap01(double x)
+{
+    // `pos %= 1.0` (fmod) for x >= 0: x - floor(x) is exact in f64; NaN/inf propagate as fmod's do
+    return x - __builtin_floor(x);
+}
+
+SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, float sync, float& sine, float& square, float& saw)
+{
+    if (flags & OSC_HAS_SYNC) {
+        if (rising_edge(s.sync_last, sync)) s.pos = 0.0;
+    } else {
+        // sync_val = 0.0 (oscillator.rs:125-128): never above threshold; `last` still updates
+        s.sync_last = false;
+    }
+    const double pos = s.pos;
+    double delta;
+    if (flags & OSC_HAS_CV) {
+        // 440 * 2^(f64(cv) + f64(val)) / f64(sample_rate), per sample (oscillator.rs:45,132)
+        double e = (double)cv + c.val;
+        double hz = (flags & OSC_EXACT) ? 440.0 * pow(2.0, e) : 440.0 * exp2(e);
+        delta = hz / c.sr;
+    } else {
+        delta = c.delta;
+    }
+    if (flags & OSC_EXACT) {
+        const bool aa = flags & OSC_AA;
+        if (flags & OSC_OUT_SINE) sine = (float)sin(pos * 3.14159265358979323846 * 2.0);
+        if (flags & OSC_OUT_SQUARE)
+            square = (pos < 0.5 ? -1.0f : 1.0f) - (aa ? (float)(poly_blep_exact(pos, delta) - poly_blep_exact(fmod(pos + 0.5, 1.0), delta)) : 0.0f);
+        if (flags & OSC_OUT_SAW) saw = ((float)pos * 2.0f - 1.0f) - (aa ? (float)poly_blep_exact(pos, delta) : 0.0f);
+        s.pos = fmod(pos + delta, 1.0);
+        return;
+    }
+    float inv_dt = c.inv_dt;
+    if (flags & OSC_HAS_CV) inv_dt = 1.0f / (float)delta;
+    if (flags & OSC_OUT_SINE) sine = sine_fast(pos);
+    if (flags & (OSC_OUT_SQUARE | OSC_OUT_SAW)) {
+        const float p32 = (float)pos;            // `self.pos as f32`
+        float blep0 = 0.0f;
+        if (flags & OSC_AA) blep0 = poly_blep_fast(p32, (float)(pos - 1.0), inv_dt);
+        if (flags & OSC_OUT_SAW) saw = __builtin_fmaf(p32, 2.0f, -1.0f) - blep0;  // p32*2 is exact => fma == mul,sub
+        if (flags & OSC_OUT_SQUARE) {
+            float blep1 = 0.0f;
+            if (flags & OSC_AA) {
+                double p2 = pos + 0.5;               // (pos + 0.5) % 1.0
+                p2 = p2 >= 1.0 ? p2 - 1.0 : p2;
+                blep1 = poly_blep_fast((float)p2, (float)(p2 - 1.0), inv_dt);
+            }
+            square = (pos < 0.5 ? -1.0f : 1.0f) - (blep0 - blep1);
+        }
+    }
+    s.pos = wrap01(pos + delta);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Moog ladder — InternalMoogFilterState::calc + clamp_buffers, filter.rs:58-92
+// ---------------------------------------------------------------------------------------------
+struct VcfRegs {
+    float f, p, q;
+    float b0, b1, b2, b3, b4;
+    float freq, res;  // the (frequency, res) the coefficients were computed for
+};
+
+SRK_DEV float clamp1(float x) { return fmaxf(fminf(x, 1.0f), -1.0f); }  // x.min(1.0).max(-1.0)
+
+// filter.rs:61-68 — recompute only when (frequency, res) changed
+SRK_DEV void vcf_coeffs(VcfRegs& s, float frequency, float res)
+{
+    if (frequency != s.freq || res != s.res) {
+        s.freq = frequency;
+        s.res = res;
+        float q = 1.0f - frequency;
+        s.p = frequency + 0.8f * frequency * q;
+        s.f = s.p * 2.0f - 1.0f;
+        s.q = res * (1.0f + 0.5f * q * (1.0f - q + 5.6f * q * q));
+    }
+}
+
+// filter.rs:69-82 — returns lowpass; band/highpass through references (caller stores only live ports)
+SRK_DEV void vcf_step(VcfRegs& s, float input, float& lowpass, float& bandpass, float& highpass)
+{
+    input = input - (s.q * s.b4);
+    float t1 = s.b1;
+    s.b1 = (input + s.b0) * s.p - s.b1 * s.f;
+    float t2 = s.b2;
+    s.b2 = (s.b1 + t1) * s.p - s.b2 * s.f;
+    t1 = s.b3;
+    s.b3 = (s.b2 + t2) * s.p - s.b3 * s.f;
+    s.b4 = (s.b3 + t1) * s.p - s.b4 * s.f;
+    s.b4 = s.b4 - (s.b4 * s.b4 * s.b4) * 0.166667f;
+    s.b0 = clamp1(input);
+    s.b1 = clamp1(s.b1);
+    s.b2 = clamp1(s.b2);
+    s.b3 = clamp1(s.b3);
+    s.b4 = clamp1(s.b4);
+    lowpass = s.b4;
+    highpass = input - s.b4;
+    bandpass = 3.0f * (s.b3 - s.b4);
+}
+
+// (self.freq + cv * self.exp_amt).max(0.0).min(0.9), filter.rs:213
+SRK_DEV float vcf_frequency(float freq, float cv, float exp_amt) { return fminf(fmaxf(freq + cv * exp_amt, 0.0f), 0.9f); }
+SRK_DEV float vcf_resonance(float res) { return fminf(fmaxf(res, 0.0f), 1.0f); }  // filter.rs:214
+
+// ---------------------------------------------------------------------------------------------
+// ADSR — adsr.rs:138-214
+// ---------------------------------------------------------------------------------------------
+struct AdsrRegs {
+    float phase, r_val, from_a_val;
+    int mode;
+    bool gate_last;
+};
+
+struct AdsrConst {
+    float inc_a, inc_d, inc_r;  // 1.0 / (sample_rate * X_sec): loop-invariant, hoisted (same bits)
+    float s_val;
+};
+
+SRK_DEV AdsrConst adsr_consts(float a_sec, float d_sec, float s_val, float r_sec, float sample_rate)
+{
+    AdsrConst c;
+    c.inc_a = 1.0f / (sample_rate * a_sec);  // a_sec = 0 => +inf: Attack lasts one sample (adsr.rs:39,152-156)
+    c.inc_d = 1.0f / (sample_rate * d_sec);
+    c.inc_r = 1.0f / (sample_rate * r_sec);
+    c.s_val = s_val;
+    return c;
+}
+
+SRK_DEV float adsr_step(uint32_t flags, AdsrRegs& s, const AdsrConst& c, float gate)
+{
+    const bool has_gate = flags & ADSR_HAS_GATE;
+    const float g = has_gate ? gate : 0.0f;
+    const bool is_transition = rising_edge(s.gate_last, g);
+    const bool high = has_gate && gate > 0.0f;
+    switch (s.mode) {
+    case SRACK_ADSR_MODE_NONE:
+        if (high) {
+            s.phase = 0.0f;
+            s.mode = SRACK_ADSR_MODE_ATTACK;
+        }
+        break;
+    case SRACK_ADSR_MODE_ATTACK:
+        s.phase += c.inc_a;
+        if (s.phase >= 1.0f) {
+            s.phase = 0.0f;
+            s.mode = SRACK_ADSR_MODE_DECAY;
+        } else if (is_transition) {
+            s.phase = 0.0f;
+            s.r_val = s.from_a_val;
+        }
+        break;
+    case SRACK_ADSR_MODE_DECAY:
+        s.phase += c.inc_d;
+        if (s.phase >= 1.0f) {
+            s.phase = 0.0f;
+            s.mode = SRACK_ADSR_MODE_SUSTAIN;
+        }
+        if (is_transition) {
+            s.phase = 0.0f;
+            s.mode = SRACK_ADSR_MODE_ATTACK;
+        }
+        break;
+    case SRACK_ADSR_MODE_SUSTAIN:
+        if (!high) {  // gate_in_buf.is_none() || gate <= 0.0
+            s.phase = 0.0f;
+            s.mode = SRACK_ADSR_MODE_RELEASE;
+        }
+        if (is_transition) {
+            s.phase = 0.0f;
+            s.mode = SRACK_ADSR_MODE_ATTACK;
+        }
+        break;
+    default:  // SRACK_ADSR_MODE_RELEASE
+        if (high) {
+            s.phase = 0.0f;
+            s.mode = SRACK_ADSR_MODE_ATTACK;
+        }
+        s.phase += c.inc_r;  // yes, also right after switching to Attack (adsr.rs:187-199)
+        if (s.phase >= 1.0f) {
+            s.phase = 0.0f;
+            s.r_val = 0.0f;
+            s.mode = SRACK_ADSR_MODE_NONE;
+        }
+        break;
+    }
+    float out;
+    switch (s.mode) {
+    case SRACK_ADSR_MODE_NONE: out = 0.0f; break;
+    case SRACK_ADSR_MODE_ATTACK: out = s.r_val + (1.0f - s.r_val) * s.phase; break;
+    case SRACK_ADSR_MODE_DECAY: out = c.s_val + (1.0f - c.s_val) * (1.0f - s.phase); break;
+    case SRACK_ADSR_MODE_SUSTAIN: out = c.s_val; break;
+    default: out = c.s_val * (1.0f - s.phase); break;
+    }
+    if (s.mode != SRACK_ADSR_MODE_ATTACK)
+        s.r_val = out;
+    else
+        s.from_a_val = out;
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VCA vca.rs:127-144, mixer mixer.rs:109-118, math math.rs:46-52,149-156
+// ---------------------------------------------------------------------------------------------
+SRK_DEV float vca_step(uint32_t flags, bool negative, float audio, float cv)
+{
+    if ((flags & (VCA_HAS_AUDIO | VCA_HAS_CV)) != (VCA_HAS_AUDIO | VCA_HAS_CV)) return 0.0f;  // output.fill(0.0)
+    return (negative || cv > 0.0f) ? audio * cv : 0.0f;
+}
+
+SRK_DEV float mixer_step(uint32_t connected, const float in[4], const float gain[4])
+{
+    float out = 0.0f;  // output.fill(0.0), then one `*dst += src * gain` pass per connected input
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (connected & (1u << k)) out = out + in[k] * gain[k];
+    return out;
+}
+
+SRK_DEV float math_step(uint32_t flags, float in1, float in2, float constant)
+{
+    float a = (flags & MATH_HAS_IN1) ? in1 : 0.0f;
+    float b = (flags & MATH_HAS_IN2) ? in2 : constant;
+    switch ((flags >> MATH_OP_SHIFT) & 3u) {
+    case SRACK_MATH_ADD: return a + b;
+    case SRACK_MATH_SUBTRACT: return a - b;
+    default: return a * b;
+    }
+}
+
+}  // namespace dev
+}  // namespace srack

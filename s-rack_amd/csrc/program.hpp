@@ -1,0 +1,106 @@
+// program.hpp — the flattened op list: what the host planner hands to the HIP kernels.
+//
+// One DevOp per planned module (reference: one `calc()` call per plan entry, synth.rs:97-101).
+// Wires are numbered slots (an f32 per voice per sample); a slot lives in an LDS tile in the
+// tile interpreter and in a VGPR in the fused kernels.  Plain C structs: shared by host C++ and
+// device code, copied to the device verbatim.
+#pragma once
+#include <cstdint>
+
+namespace srack {
+
+enum OpKind : int32_t {
+    OP_NONE = 0,
+    OP_OSC = 1,        // OscillatorModule::calc      oscillator.rs:108-158
+    OP_VCF = 2,        // MoogFilterModule::calc      filter.rs:182-221
+    OP_ADSR = 3,       // ADSRModule::calc            adsr.rs:134-217
+    OP_VCA = 4,        // VCAModule::calc             vca.rs:117-148
+    OP_MIX = 5,        // MonoMixerModule::calc       mixer.rs:101-122
+    OP_MATH = 6,       // MathModule::calc            math.rs:139-160
+    OP_OUT = 7,        // OutputModule::calc          output.rs:46-60 (+ frame store and mix-down)
+    OP_DELAY_RD = 8,   // broken feedback edge: ring[(n - B) mod B] -> slot   (sink side)
+    OP_DELAY_WR = 9,   // slot -> ring[n mod B]                               (source side)
+    OP_TRACK_RD = 10   // control track (voice-invariant sub-graph, evaluated once) -> slot
+};
+
+// per-kind flag bits -----------------------------------------------------------------------------
+enum : uint32_t {
+    // OP_OSC
+    OSC_HAS_CV = 1u << 0,
+    OSC_HAS_SYNC = 1u << 1,
+    OSC_AA = 1u << 2,         // antialiasing (PolyBLEP) on
+    OSC_OUT_SINE = 1u << 3,   // which ports anything reads; dead ports are not computed
+    OSC_OUT_SQUARE = 1u << 4,
+    OSC_OUT_SAW = 1u << 5,
+    OSC_EXACT = 1u << 6,      // f64 PolyBLEP / sin / pow exactly as the reference spells them
+    // OP_VCF
+    VCF_HAS_AUDIO = 1u << 0,
+    VCF_HAS_CV = 1u << 1,
+    VCF_OUT_LP = 1u << 3,
+    VCF_OUT_BP = 1u << 4,
+    VCF_OUT_HP = 1u << 5,
+    // OP_ADSR
+    ADSR_HAS_GATE = 1u << 0,
+    // OP_VCA
+    VCA_HAS_AUDIO = 1u << 0,
+    VCA_HAS_CV = 1u << 1,
+    // OP_MIX: bit k = input k connected
+    // OP_MATH
+    MATH_HAS_IN1 = 1u << 0,
+    MATH_HAS_IN2 = 1u << 1,
+    MATH_OP_SHIFT = 4,        // bits 4..5 = SRACK_MATH_ADD / SUBTRACT / MULTIPLY
+    // OP_DELAY_*
+    DELAY_RING_GLOBAL = 1u << 0  // ring in HBM ([B][V] f32); otherwise B consecutive LDS rows
+};
+
+constexpr int kMaxIn = 8;  // OutputModule: one input per channel (u8 in the reference; capped at 8 here)
+constexpr int kMaxOut = 3;
+constexpr int kMaxPar = 8;
+
+// parameter indices into DevOp::par_row / par_val, per kind
+enum { OSC_P_VAL = 0 };                                            // f32 `val` (used when CV is wired)
+enum { VCF_P_FREQ = 0, VCF_P_RES = 1, VCF_P_EXP = 2 };
+enum { ADSR_P_A = 0, ADSR_P_D = 1, ADSR_P_S = 2, ADSR_P_R = 3, ADSR_P_SR = 4 };
+enum { VCA_P_NEG = 0 };
+enum { MIX_P_GAIN0 = 0 };
+enum { MATH_P_CONST = 0 };
+
+// state rows per kind (row offsets from DevOp::state_row), all 32-bit rows of the voice table
+enum { OSC_S_POS_LO = 0, OSC_S_POS_HI = 1, OSC_S_SYNC_LAST = 2, OSC_S__N = 3 };
+enum { VCF_S_F = 0, VCF_S_P = 1, VCF_S_Q = 2, VCF_S_B0 = 3, VCF_S_FREQ = 8, VCF_S_RES = 9, VCF_S__N = 10 };
+enum { ADSR_S_PHASE = 0, ADSR_S_MODE = 1, ADSR_S_R_VAL = 2, ADSR_S_FROM_A = 3, ADSR_S_GATE_LAST = 4, ADSR_S__N = 5 };
+
+struct DevOp {
+    int32_t kind;
+    uint32_t flags;
+    int32_t module;             // index in all_modules (diagnostics, state read-back)
+    int32_t in_slot[kMaxIn];    // wire slot per input port, -1 = None (unconnected)
+    int32_t out_slot[kMaxOut];  // wire slot per output port, -1 = nobody reads it
+    int32_t state_row;          // first state row in the voice table (-1: stateless)
+    int32_t par_row[kMaxPar];   // >= 0: per-voice row in the voice table; -1: uniform => par_val
+    float par_val[kMaxPar];
+    // OP_OSC without CV: delta = 440 * 2^val / sample_rate, hoisted to the host in f64
+    // (bit-equal to the reference's per-sample value, oscillator.rs:43-48,132)
+    int32_t delta_row;          // >= 0: two per-voice rows (lo, hi); -1: uniform => delta
+    int32_t aux;                // OP_OUT: plane; OP_DELAY_*: ring id / first LDS row; OP_TRACK_RD: track index
+    double delta;
+    double sample_rate;         // OP_OSC: f64(sample_rate), the divisor of oscillator.rs:132
+};
+
+struct DevProgram {
+    int32_t n_ops;
+    int32_t n_slots;        // wire slots (tile interpreter: LDS tiles)
+    int32_t n_rows;         // rows of the voice table: state rows, then per-voice parameter rows
+    int32_t n_state_rows;   // rows [0, n_state_rows) are written back at the end of a render
+    int32_t n_planes;       // distinct wires feeding the OutputModule
+    int32_t n_channels;
+    int32_t channel_plane[8];  // per output channel: plane index or -1
+    int32_t buffer_size;    // B: length of a broken edge's delay
+    int32_t n_rings;        // global rings ([B][V] f32 each)
+    int32_t tile;           // samples per tile the interpreter uses (<= B when rings exist)
+    int32_t pad_;
+};
+
+constexpr int kMaxOps = 96;
+
+}  // namespace srack

@@ -1,0 +1,41 @@
+// runtime.hpp — the object behind `srack_patch*`: graph + voices + flattened program + device state.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "flatten.hpp"
+#include "graph.hpp"
+
+namespace srack {
+
+struct DeviceState;  // HIP side, render.hip
+
+struct PatchHandle {
+    Graph graph;
+    uint32_t n_voices = 0;
+    std::vector<VoiceOverride> overrides;
+    uint64_t voices_revision = 0;  // bumped by configure / per-voice set_field
+
+    FlatProgram prog;
+    bool prog_valid = false;
+    uint64_t prog_graph_revision = 0, prog_voices_revision = 0;
+    uint32_t prog_flags = 0;
+
+    DeviceState* dev = nullptr;
+    uint64_t samples_rendered = 0;  // absolute tick count: phase of the feedback rings
+
+    ~PatchHandle();
+};
+
+// (Re)flatten when the graph, the voices or the flags changed since the last render; a re-flatten
+// resets the device voice state to the modules' fields (like re-loading the patch).
+int ensure_program(PatchHandle& h, uint32_t flags);
+
+int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_mix, uint32_t flags, void* stream);
+int device_kernel_ms(PatchHandle& h, double* avg_ms, int* n_launches, int reset);
+int device_read_rows(PatchHandle& h, int first_row, int n_rows, uint32_t* host_dst);
+void device_release(DeviceState* d);
+const char* device_kernel_name(const PatchHandle& h);
+
+}  // namespace srack

@@ -1,0 +1,327 @@
+"""Parity of the HIP path with the CPU oracle, through the C ABI.  Needs a real MI355X (-m gpu).
+
+Tolerance (BASELINE.json north_star: 1e-5 relative fp32; SURVEY §7 gives it a denominator):
+    |gpu - ref| <= 1e-5 * max(|ref|, 1)      per sample.
+The f32 modules are bit-exact by construction; with SRACK_RENDER_EXACT_OSC the oscillator's saw and
+square are too, so chains that use only those ports are compared bit for bit in that mode.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import srack_pkg
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def S():
+    S = srack_pkg.load()
+    assert S.device_count() > 0, "no GPU visible: the render path has no CPU fallback"
+    return S
+
+
+def assert_close(gpu, ref, tol=TOL):
+    gpu, ref = np.asarray(gpu, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert gpu.shape == ref.shape
+    err = np.abs(gpu - ref) / np.maximum(np.abs(ref), 1.0)
+    assert np.isfinite(gpu).all()
+    assert err.max() <= tol, f"max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    return err.max()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+MODES = [pytest.param(0, id="fused"), pytest.param(2, id="interp"), pytest.param(1, id="fused-exact"), pytest.param(3, id="interp-exact")]
+
+
+# ---- the reference's oscillator test, through the whole GPU path --------------------------------
+@pytest.mark.parametrize("flags", [0, 1])
+def test_produces_440(S, flags):
+    """oscillator::dco_tests::produces_440 (oscillator.rs:284-305): sr 1760, B 17, two calc() calls."""
+    p = S.Patch(440 * 4, 17, 2)
+    osc, out = p.add_module(S.MOD_OSCILLATOR), p.add_module(S.MOD_OUTPUT)
+    p.connect(osc, S.OSC_OUT_SINE, out, 0)
+    p.configure_voices(1)
+    buf = p.render_channels(17, flags)[0, :, 0]
+    assert buf[0] == 0.0
+    assert abs(buf[1] - 1.0) < 0.00001
+    assert abs(buf[2]) < 0.00001
+    assert abs(buf[3] + 1.0) < 0.00001
+    assert abs(buf[4]) < 0.00001
+    buf = p.render_channels(17, flags)[0, :, 0]  # second block continues from the carried phase
+    assert abs(buf[0] - 1.0) < 0.00001
+
+
+# ---- cfg1 golden: 1 voice, P1, 1 s -----------------------------------------------------------------
+@pytest.mark.parametrize("flags", MODES)
+@pytest.mark.parametrize("adsr", ["default", "finite"])
+def test_cfg1_golden(S, adsr, flags):
+    gold = np.load(os.path.join(GOLD, f"cfg1_p1_{adsr}.npz"))["audio"]
+    p = S.Patch(48000, 1024, 2)
+    S.build_p1(p, adsr=adsr)
+    p.configure_voices(1)
+    assert ("fused=1" in p.info()) == (not flags & 2)
+    out = p.render_channels(48000, flags)
+    if flags & 1:  # exact oscillator: saw and square are pure f64 arithmetic => the whole chain is bit-identical
+        np.testing.assert_array_equal(bits(out[0, :, 0]), bits(gold))
+    else:
+        assert_close(out[0, :, 0], gold)
+    np.testing.assert_array_equal(out[0], out[1])
+    assert not out[0, :13964].any() and np.abs(out[0, 13964:]).max() > 0.1
+
+
+# ---- cfg3 golden + fresh oracle draw: per-voice detune / cutoff -----------------------------------------
+@pytest.mark.parametrize("flags", MODES)
+def test_cfg3_golden_voices(S, flags):
+    z = np.load(os.path.join(GOLD, "cfg3_p1_voices8.npz"))
+    gold = z["audio"]
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p1(p, lfo_val=float(z["lfo_val"]))
+    p.configure_voices(8)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, z["detune"])
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, z["cutoff"])
+    out = p.render_channels(gold.shape[0], flags)[0]
+    if flags & 1:
+        np.testing.assert_array_equal(bits(out), bits(gold))
+    else:
+        assert_close(out, gold)
+
+
+@pytest.mark.parametrize("flags", [pytest.param(0, id="fused"), pytest.param(2, id="interp")])
+@pytest.mark.parametrize("V", [1, 63, 64, 65, 300])
+def test_p1_voices_vs_oracle_and_mix(S, oracle, V, flags):
+    T = 6000
+    det, cut = S.p1_voice_params(V, first_voice=12345)
+    o = oracle.OraclePatch(48000, 1024, 2)
+    ids = S.build_p1(o, adsr="finite", lfo_val=-3.0)
+    ref, ref_mix = o.render_batch(V, T, [(ids["osc_a"], S.OSC_VAL, det), (ids["vcf"], S.VCF_FREQ, cut)], mix=True, threads=8)
+    p = S.Patch(48000, 1024, 2)
+    S.build_p1(p, adsr="finite", lfo_val=-3.0)
+    p.configure_voices(V)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    fr, mix = p.render(T, frames=True, mix=True, flags=flags)
+    assert fr.shape == (1, T, V)
+    assert_close(fr[0], ref[0])
+    # mix-down: sum over voices, checked against the f64 sum of the GPU's own frames and of the oracle's
+    own = fr[0].astype(np.float64).sum(axis=1)
+    scale = np.abs(fr[0].astype(np.float64)).sum(axis=1)
+    assert (np.abs(mix[0] - own) <= 1e-5 * np.maximum(scale, 1.0)).all()
+    assert (np.abs(mix[0] - ref_mix[0]) <= 2e-5 * np.maximum(scale, 1.0)).all()
+    np.testing.assert_array_equal(mix[0], mix[1])
+
+
+def test_cfg2_identical_voices(S, oracle):
+    """config 2: 4096 identical voices, same patch — every column equals the 1-voice oracle render."""
+    T, V = 4096, 4096
+    o = oracle.OraclePatch(48000, 1024, 2)
+    S.build_p1(o, lfo_val=-2.0)
+    ref = o.render(T)[0]
+    p = S.Patch(48000, 1024, 2)
+    S.build_p1(p, lfo_val=-2.0)
+    p.configure_voices(V)
+    fr, mix = p.render(T)
+    assert (fr[0] == fr[0][:, :1]).all()
+    assert_close(fr[0][:, 0], ref)
+    assert_close(mix[0] / V, ref, tol=2e-5)
+
+
+# ---- FM patch with a feedback edge (config 4) ---------------------------------------------------------
+@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("B", [1, 7, 16, 64, 1024])
+def test_p2_feedback_vs_oracle(S, oracle, B, flags):
+    T, V = 3000, 70
+    beta, index = S.p2_voice_params(V)
+    o = oracle.OraclePatch(48000, B, 2)
+    ids = S.build_p2(o)
+    ref, _ = o.render_batch(V, T, [(ids["mul_fb"], S.MATH_CONSTANT, beta), (ids["mul_idx"], S.MATH_CONSTANT, index)], threads=8)
+    p = S.Patch(48000, B, 2)
+    S.build_p2(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, beta)
+    p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
+    assert p.delayed_edges() == [(ids["osc_m"], 0, ids["mul_fb"], 0)]
+    out = p.render_channels(T, flags)
+    assert_close(out[0], ref[0])
+    assert np.abs(out[0]).max() > 0.9
+
+
+@pytest.mark.parametrize("B", [1, 1024])
+def test_cfg4_golden(S, B):
+    z = np.load(os.path.join(GOLD, f"cfg4_p2_b{B}.npz"))
+    p = S.Patch(48000, B, 2)
+    S.build_p2(p, beta=float(z["beta"]), index=float(z["index"]))
+    p.configure_voices(3)
+    out = p.render_channels(len(z["audio"]))
+    for v in range(3):
+        assert_close(out[0, :, v], z["audio"])
+
+
+# ---- every port of every module type, through the interpreter ---------------------------------------------
+def _everything(g):
+    lfo, osc, osc2, vcf, adsr, vca, mix, sub, add, vca_neg, out = [g.add_module(t) for t in (1, 1, 1, 2, 3, 4, 5, 6, 6, 4, 0)]
+    for m, f, v in ((lfo, 0, -1.5), (osc, 0, 0.25), (osc, 1, 0), (osc2, 0, 1.0 / 12.0), (vcf, 0, 0.35), (vcf, 1, 0.8), (vcf, 2, 0.25),
+                    (adsr, 0, 0.002), (adsr, 1, 0.004), (adsr, 2, 0.6), (adsr, 3, 0.003), (mix, 0, 0.5), (mix, 2, 1.5),
+                    (sub, 1, 1), (sub, 0, 0.125), (add, 0, -0.75), (vca_neg, 0, 1)):
+        g.set_field(m, f, v)
+    for s, sp, d, dp in ((lfo, 0, osc, 0), (lfo, 1, osc, 1), (osc, 2, vcf, 0), (lfo, 2, vcf, 1), (lfo, 1, adsr, 0), (vcf, 1, vca, 0),
+                         (adsr, 0, vca, 1), (vca, 0, mix, 0), (vcf, 2, mix, 2), (osc2, 1, mix, 3), (mix, 0, sub, 0), (osc2, 0, add, 1),
+                         (add, 0, vca_neg, 0), (lfo, 0, vca_neg, 1), (sub, 0, out, 0), (vca_neg, 0, out, 1)):
+        g.connect(s, sp, d, dp)
+    return dict(lfo=lfo, osc=osc, osc2=osc2, vcf=vcf, adsr=adsr)
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_all_module_types_vs_oracle(S, oracle, flags):
+    T, V = 3000, 130
+    rng = np.random.default_rng(5)
+    val = rng.uniform(-0.5, 0.5, V).astype(np.float32)
+    cut = rng.uniform(0.1, 0.6, V).astype(np.float32)
+    o = oracle.OraclePatch(48000, 32, 2)
+    ids = _everything(o)
+    ref, ref_mix = o.render_batch(V, T, [(ids["osc"], S.OSC_VAL, val), (ids["vcf"], S.VCF_FREQ, cut)], mix=True, threads=8)
+    p = S.Patch(48000, 32, 2)
+    _everything(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["osc"], S.OSC_VAL, val)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    assert p.planes() == (2, [0, 1])
+    fr, mix = p.render(T, flags=flags)
+    assert_close(fr[0], ref[0])
+    assert_close(fr[1], ref[1])
+    scale = np.abs(ref.astype(np.float64)).sum(axis=2)
+    assert (np.abs(mix - ref_mix) <= 2e-5 * np.maximum(scale, 1.0)).all()
+    assert not np.array_equal(fr[0], fr[1])
+
+
+def test_quirks_on_gpu(S, oracle):
+    def both(build, T=64, B=16):
+        o, p = oracle.OraclePatch(48000, B, 2), S.Patch(48000, B, 2)
+        build(o)
+        build(p)
+        p.configure_voices(2)
+        return o.render(T), p.render_channels(T)[:, :, 0], p
+
+    def vca_open(g):  # VCA with one input unconnected => zeros (vca.rs:142-144)
+        osc, vca, out = g.add_module(1), g.add_module(4), g.add_module(0)
+        g.connect(osc, 0, vca, 0)
+        g.connect(vca, 0, out, 0)
+    ref, gpu, _ = both(vca_open)
+    assert not gpu.any() and not ref.any()
+
+    def gate_high(g):  # gate high at sample 0: not an edge, but None -> Attack is level triggered; a_sec = 0 => one-sample attack
+        c, adsr, out = g.add_module(6), g.add_module(3), g.add_module(0)
+        g.set_field(c, 0, 1.0)
+        g.connect(c, 0, adsr, 0)
+        g.connect(adsr, 0, out, 1)
+    ref, gpu, _ = both(gate_high, T=30000)
+    np.testing.assert_array_equal(bits(gpu), bits(ref))  # pure f32 path: bit-exact
+    assert gpu[1][0] == 0.0 and gpu[1][1] == 1.0 and not gpu[0].any()
+
+    def f0r0(g):  # freq = res = 0 from the start: coefficients never computed, f stays 0 (filter.rs:61)
+        osc, vcf, out = g.add_module(1), g.add_module(2), g.add_module(0)
+        g.set_field(vcf, 0, 0.0)
+        g.set_field(vcf, 1, 0.0)
+        g.connect(osc, 2, vcf, 0)
+        g.connect(vcf, 0, out, 0)
+        return vcf
+    ref, gpu, p = both(f0r0)
+    assert_close(gpu, ref)
+    assert (p.get_voice_field(1, S.VCF_ST_F) == 0.0).all()
+
+    def no_output(g):
+        g.add_module(1)
+    o, p = oracle.OraclePatch(48000, 16, 2), S.Patch(48000, 16, 2)
+    no_output(o)
+    no_output(p)
+    p.configure_voices(2)
+    fr, mix = p.render(32)
+    assert fr.shape == (0, 32, 2) and not mix.any() and not o.render(32).any()
+
+
+# ---- properties that do not need the oracle -----------------------------------------------------------------
+@pytest.mark.parametrize("flags", [pytest.param(0, id="fused"), pytest.param(2, id="interp")])
+def test_render_continues_from_state(S, flags):
+    """execute() carries state between calls: render(T) == render(a) ++ render(T - a), bit for bit."""
+    V, T = 200, 5000
+    det, cut = S.p1_voice_params(V)
+
+    def make():
+        p = S.Patch(48000, 1024, 2)
+        ids = S.build_p1(p, adsr="finite", lfo_val=-3.0)
+        p.configure_voices(V)
+        p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+        p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+        return p, ids
+    p, ids = make()
+    whole, mix_whole = p.render(T, flags=flags)
+    end_pos = p.get_voice_field(ids["osc_a"], S.OSC_POS)
+    q, _ = make()
+    parts = [q.render(n, flags=flags) for n in (1, 999, 33, T - 1033)]
+    np.testing.assert_array_equal(bits(np.concatenate([f[0] for f, _ in parts], axis=0)), bits(whole[0]))
+    np.testing.assert_array_equal(bits(np.concatenate([m for _, m in parts], axis=1)), bits(mix_whole))
+    np.testing.assert_array_equal(q.get_voice_field(ids["osc_a"], S.OSC_POS), end_pos)
+    assert ((end_pos >= 0) & (end_pos < 1)).all()
+
+
+def test_feedback_ring_continues_across_renders(S, oracle):
+    T, V = 2500, 66
+    for B in (1, 16, 100):
+        o = oracle.OraclePatch(48000, B, 2)
+        S.build_p2(o)
+        ref = o.render(T)[0]
+        p = S.Patch(48000, B, 2)
+        S.build_p2(p)
+        p.configure_voices(V)
+        parts = [p.render_channels(n)[0] for n in (7, 1000, T - 1007)]
+        out = np.concatenate(parts, axis=0)
+        assert_close(out[:, 0], ref)
+        assert (out == out[:, :1]).all()
+
+
+def test_mix_is_additive_over_voice_shards(S):
+    """The multi-GPU contract: voices shard with no exchange; mix(all) == sum of the shards' mixes."""
+    V, T = 1024, 3000
+    det, cut = S.p1_voice_params(V)
+
+    def shard(v0, v1):
+        p = S.Patch(48000, 1024, 2)
+        ids = S.build_p1(p, adsr="finite", lfo_val=-3.0)
+        p.configure_voices(v1 - v0)
+        d, c = S.p1_voice_params(v1 - v0, first_voice=v0)
+        np.testing.assert_array_equal(d, det[v0:v1])
+        p.set_voice_field(ids["osc_a"], S.OSC_VAL, d)
+        p.set_voice_field(ids["vcf"], S.VCF_FREQ, c)
+        return p.render(T)
+    fr, mix = shard(0, V)
+    parts = [shard(a, b) for a, b in ((0, 256), (256, 512), (512, 1024))]
+    np.testing.assert_array_equal(bits(np.concatenate([f[0] for f, _ in parts], axis=1)), bits(fr[0]))
+    total = sum(m.astype(np.float64) for _, m in parts)
+    scale = np.abs(fr[0].astype(np.float64)).sum(axis=1)
+    assert (np.abs(mix[0] - total[0]) <= 1e-5 * np.maximum(scale, 1.0)).all()
+
+
+def test_full_size_voices_short_render(S, oracle):
+    """cfg3's voice count (262 144) for 512 samples: sampled voices vs the oracle, and the mix vs an f64 sum."""
+    V, T = 262144, 512
+    det, cut = S.p1_voice_params(V)
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p1(p, adsr="finite", lfo_val=2.0)
+    p.configure_voices(V)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    fr, mix = p.render(T)
+    pick = np.unique(np.concatenate([np.arange(0, V, 4099), [0, 63, 64, V - 65, V - 64, V - 1]]))
+    o = oracle.OraclePatch(48000, 1024, 2)
+    S.build_p1(o, adsr="finite", lfo_val=2.0)
+    ref, _ = o.render_batch(len(pick), T, [(ids["osc_a"], S.OSC_VAL, det[pick]), (ids["vcf"], S.VCF_FREQ, cut[pick])], threads=8)
+    assert_close(fr[0][:, pick], ref[0])
+    own = fr[0].astype(np.float64).sum(axis=1)
+    scale = np.abs(fr[0].astype(np.float64)).sum(axis=1)
+    assert (np.abs(mix[0] - own) <= 1e-5 * np.maximum(scale, 1.0)).all()

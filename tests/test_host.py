@@ -1,0 +1,190 @@
+"""Host-side logic of the product (no GPU): C-ABI surface, graph API, planner parity with the oracle, flattening."""
+import ctypes
+import random
+import re
+import os
+
+import numpy as np
+import pytest
+
+import srack_pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def S():
+    return srack_pkg.load()
+
+
+def test_library_exports_every_declared_symbol(S):
+    hdr = open(os.path.join(ROOT, "include", "srack_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(srack_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(S.ABI_SYMBOLS)
+    L = ctypes.CDLL(S.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.srack_abi_version() == 1
+
+
+def test_module_defaults_match_reference_new(S):
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p1(p)
+    q = S.Patch(44100, 64, 2)
+    osc, vcf, adsr, vca, mix, math, out = [q.add_module(t) for t in (1, 2, 3, 4, 5, 6, 0)]
+    assert [q.get_num_inputs(m) for m in (osc, vcf, adsr, vca, mix, math, out)] == [2, 2, 1, 2, 4, 2, 2]
+    assert [q.get_num_outputs(m) for m in (osc, vcf, adsr, vca, mix, math, out)] == [3, 3, 1, 1, 1, 1, 0]
+    assert q.get_field(osc, S.OSC_VAL) == 0.0 and q.get_field(osc, S.OSC_ANTIALIASING) == 1 and q.get_field(osc, S.OSC_SYNC_LAST) == 1
+    assert q.get_field(vcf, S.VCF_FREQ) == float(np.float32(0.2)) and q.get_field(vcf, S.VCF_RES) == 0.5 and q.get_field(vcf, S.VCF_EXP_AMT) == 0.5
+    assert [q.get_field(adsr, f) for f in (S.ADSR_A_SEC, S.ADSR_D_SEC, S.ADSR_S_VAL, S.ADSR_R_SEC)] == [0.0, 0.5, 0.25, 0.5]
+    assert q.get_field(adsr, S.ADSR_MODE) == 4 and q.get_field(adsr, S.ADSR_SAMPLE_RATE) == 44100.0 and q.get_field(adsr, S.ADSR_GATE_LAST) == 1
+    assert [q.get_field(mix, k) for k in range(4)] == [1.0] * 4
+    assert q.get_field(math, S.MATH_CONSTANT) == 0.0 and q.get_field(math, S.MATH_OPERATION) == 0
+    assert p.get_input(ids["vca"], 1) == (ids["adsr"], 0) and p.get_input(ids["osc_a"], 0) is None
+
+
+def test_error_behaviour(S):
+    p = S.Patch(48000, 64, 2)
+    osc, out = p.add_module(1), p.add_module(0)
+    with pytest.raises(S.SrackError) as e:  # Err(()) of set_input on a bad port
+        p.connect(osc, 0, out, 2)
+    assert e.value.code == S.ERR_PORT
+    with pytest.raises(S.SrackError) as e:  # get_output(3) is Err(())
+        p.connect(osc, 3, out, 0)
+    assert e.value.code == S.ERR_PORT
+    with pytest.raises(S.SrackError) as e:
+        p.connect(7, 0, out, 0)
+    assert e.value.code == S.ERR_INVALID
+    with pytest.raises(S.SrackError) as e:  # NoiseModule etc. are out of scope
+        p.add_module(9)
+    assert e.value.code == S.ERR_UNSUPPORTED
+    for bad in ((0, 64, 2), (70000, 64, 2), (48000, 0, 2), (48000, 64, 0), (48000, 64, 9)):
+        with pytest.raises(S.SrackError):
+            S.Patch(*bad)
+    q = S.Patch(48000, 64, 2)
+    q.add_module(1)
+    with pytest.raises(S.SrackError) as e:  # find_output() fails: no OutputModule
+        q.plan()
+    assert e.value.code == S.ERR_NO_OUTPUT
+    # a module wired to itself deadlocks the reference; rejected at flatten time
+    r = S.Patch(48000, 64, 2)
+    mix, out = r.add_module(5), r.add_module(0)
+    r.connect(mix, 0, mix, 0)
+    r.connect(mix, 0, out, 0)
+    r.configure_voices(4)
+    with pytest.raises(S.SrackError) as e:
+        r.info()
+    assert e.value.code == S.ERR_SELF_LOOP
+    # render before voices are configured
+    s = S.Patch(48000, 64, 2)
+    S.build_p1(s)
+    with pytest.raises(S.SrackError) as e:
+        s.render_raw(16)
+    assert e.value.code == S.ERR_STATE
+
+
+def _topo_graph(g):
+    mods = [g.add_module(5) for _ in range(7)]
+    out = g.add_module(0)
+    free = {m: 0 for m in mods + [out]}
+
+    def connect(src, sink):
+        g.connect(src, 0, sink, free[sink])
+        free[sink] += 1
+
+    for a, b in ((0, 1), (1, 2), (2, 3)):
+        connect(mods[a], mods[b])
+    connect(mods[3], out)
+    connect(mods[0], mods[4])
+    connect(mods[4], mods[3])
+    connect(mods[6], mods[4])
+    connect(mods[5], mods[6])
+    connect(mods[6], mods[5])
+    return mods, out
+
+
+def test_reference_topological_sort_on_the_product_planner(S, oracle):
+    """synth::tests::topological_sort (synth.rs:537-613) against the product, and vs the oracle's order."""
+    g = S.Patch(44100, 64, 2)
+    mods, out = _topo_graph(g)
+    o = oracle.OraclePatch(44100, 64, 2)
+    _topo_graph(o)
+    rng = random.Random(3)
+    for _ in range(1000):
+        lst = mods + [out]
+        rng.shuffle(lst)
+        plan = g.plan(output=out, all_modules=lst)
+        idx = {m: i for i, m in enumerate(plan)}
+        assert idx[mods[0]] < idx[mods[1]] < idx[mods[2]] < idx[mods[3]] < idx[out]
+        assert idx[mods[0]] < idx[mods[4]] < idx[mods[3]]
+        assert idx[mods[6]] < idx[mods[4]]
+        assert idx[mods[5]] < idx[mods[6]]
+        assert plan == o.plan(output=out, all_modules=lst)
+        assert g.removed_edges() == o.removed_edges()
+
+
+def test_planner_random_graphs_product_vs_oracle(S, oracle):
+    rng = random.Random(11)
+    n_in = {0: 2, 1: 2, 2: 2, 3: 1, 4: 2, 5: 4, 6: 2}
+    n_out = {0: 0, 1: 3, 2: 3, 3: 1, 4: 1, 5: 1, 6: 1}
+    for trial in range(300):
+        n = rng.randint(2, 12)
+        types = [rng.choice([1, 2, 3, 4, 5, 6]) for _ in range(n)]
+        types.insert(rng.randint(0, n), 0)
+        g, o = S.Patch(48000, 8, 2), oracle.OraclePatch(48000, 8, 2)
+        for t in types:
+            g.add_module(t)
+            o.add_module(t)
+        for sink, t in enumerate(types):
+            for port in range(n_in[t]):
+                if rng.random() < 0.6:
+                    src = rng.randrange(len(types))
+                    if src == sink or n_out[types[src]] == 0:
+                        continue
+                    sp = rng.randrange(n_out[types[src]])
+                    g.connect(src, sp, sink, port)
+                    o.connect(src, sp, sink, port)
+        plan = g.plan()
+        assert plan == o.plan(), trial
+        assert g.removed_edges() == o.removed_edges(), trial
+        pos = {m: i for i, m in enumerate(plan)}
+        for (src, sp, sink, k) in g.delayed_edges():  # delayed <=> source scheduled after its sink
+            assert pos[src] > pos[sink]
+            assert g.get_input(sink, k) == (src, sp)
+
+
+def test_flatten_descriptions(S):
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p1(p)
+    p.configure_voices(100)
+    det, cut = S.p1_voice_params(100)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    info = p.info()
+    assert "ops=6" in info and "planes=1" in info and "fused=1" in info and "rings=0" in info
+    assert p.planes() == (1, [0, 0])
+    # dead-port elimination: only saw / square / lowpass are live
+    q = S.Patch(48000, 1, 2)
+    S.build_p2(q)
+    q.configure_voices(64)
+    assert "rings=1(lds)" in q.info() and "tile=1" in q.info()
+    assert q.delayed_edges() == [(0, 0, 1, 0)]  # OSC_M.sine -> MUL_FB.in1
+    q = S.Patch(48000, 1024, 2)
+    S.build_p2(q)
+    q.configure_voices(64)
+    assert "rings=1(hbm)" in q.info() and "tile=32" in q.info()
+    # per-voice values of a state field are returned before any render
+    p.set_voice_field(ids["osc_a"], S.OSC_POS, np.linspace(0, 0.5, 100))
+    np.testing.assert_array_equal(p.get_voice_field(ids["osc_a"], S.OSC_POS), np.linspace(0, 0.5, 100))
+    np.testing.assert_array_equal(p.get_voice_field(ids["vcf"], S.VCF_FREQ), cut.astype(np.float64))
+
+
+def test_no_gpu_render_fails_loudly(S):
+    if S.device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = S.Patch(48000, 64, 2)
+    S.build_p1(p)
+    p.configure_voices(64)
+    with pytest.raises(S.SrackError) as e:
+        p.render(16)
+    assert e.value.code == S.ERR_DEVICE
