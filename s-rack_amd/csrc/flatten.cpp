@@ -555,6 +555,23 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                          one_vcf(vcf->flags) && (oa.flags & OSC_AA) && (ol.flags & OSC_AA);
                 }
             }
+            if (ok) {
+                // the fused kernel's constant-pitch oscillator needs delta < 0.25 (PolyBLEP windows must not overlap)
+                for (int role = 0; role < 2 && ok; role++) {
+                    const InputRef& in = role == 0 ? src_of(vcf->module, 0) : src_of(adsr->module, 0);
+                    const DevOp& o = out.ops[(size_t)out.op_of_module[(size_t)in.src]];
+                    if (o.delta_row >= 0) {
+                        for (uint32_t v = 0; v < n_voices && ok; v++) {
+                            uint64_t u = (uint64_t)out.table[(size_t)o.delta_row * n_voices + v] | ((uint64_t)out.table[(size_t)(o.delta_row + 1) * n_voices + v] << 32);
+                            double dlt;
+                            std::memcpy(&dlt, &u, 8);
+                            ok = dlt < 0.25;
+                        }
+                    } else {
+                        ok = o.delta < 0.25;
+                    }
+                }
+            }
             if (ok) out.fused = FUSED_VOICE_CHAIN;
         }
     }

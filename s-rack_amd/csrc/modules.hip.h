@@ -24,6 +24,14 @@ namespace dev {
 
 #define SRK_DEV __device__ __forceinline__
 
+// Makes x opaque to the optimiser at this point: both arms of a following select are then already
+// computed, so it stays a v_cndmask instead of being turned into an exec-masked branch.
+SRK_DEV float keep(float x)
+{
+    asm("" : "+v"(x));
+    return x;
+}
+
 // TransitionDetector::is_transition, synth.rs:292-297
 SRK_DEV bool rising_edge(bool& last, float val)
 {
@@ -70,9 +78,10 @@ SRK_DEV float poly_blep_fast(float t, float tm1, float inv_dt)
 {
     float ta = t * inv_dt;
     float tb = tm1 * inv_dt;
-    float fa = __builtin_fmaf(ta, 2.0f - ta, -1.0f);  // 2t - t^2 - 1
-    float fb = __builtin_fmaf(tb, tb + 2.0f, 1.0f);   // t^2 + 2t + 1
-    return ta < 1.0f ? fa : (tb > -1.0f ? fb : 0.0f);
+    float fa = keep(__builtin_fmaf(ta, 2.0f - ta, -1.0f));  // 2t - t^2 - 1
+    float fb = keep(__builtin_fmaf(tb, tb + 2.0f, 1.0f));   // t^2 + 2t + 1
+    const float hi = tb > -1.0f ? fb : 0.0f;
+    return ta < 1.0f ? fa : hi;
 }
 
 // sin(2*pi*x) for x in [-0.25, 0.25], odd minimax-style polynomial evaluated in f32 (abs err < 6e-8)
@@ -154,6 +163,105 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
 }
 
 // ---------------------------------------------------------------------------------------------
+// Constant-pitch, unsynced oscillator — the hot special case (no CV, no sync, delta < 0.25).
+// Same phase recurrence as osc_step (bit-identical pos); the per-sample work is cut down by
+//   * carrying f32(pos) and t = pos/dt from one sample to the next: the wrapped next phase w
+//     gives both next sample's `t < dt` term (w/dt) and this sample's `t > 1-dt` term
+//     ((pos-1)/dt = w/dt - 1 when the phase wrapped), so one f64->f32 convert per sample;
+//   * testing "is any lane of the wave inside a PolyBLEP window" on the high dword of pos with
+//     integer compares; an LFO-rate oscillator is outside its windows for >99% of the samples
+//     and then square == -1/+1 exactly, as in the reference (blep terms are exactly 0).
+// ---------------------------------------------------------------------------------------------
+struct COsc {
+    double pos, delta;
+    float p32;     // f32(pos)
+    float ta;      // p32 * inv_dt  ( = t/dt of poly_blep's first branch)
+    float inv_dt;
+    // "near an edge" guards on hi32(pos): pos < dt | pos > 1-dt | |pos-0.5| < dt (with margin)
+    int hA, hB, hQ0;
+    uint32_t hQspan;
+};
+
+SRK_DEV void cosc_init(COsc& o, double pos, double delta)
+{
+    o.pos = pos;
+    o.delta = delta;
+    o.inv_dt = 1.0f / (float)delta;
+    o.p32 = (float)pos;
+    o.ta = o.p32 * o.inv_dt;
+    // margin 2^-20 over every f64 rounding in the reference's compares; g = 0.25 makes the three
+    // windows cover [0,1) (overlapping windows or a NaN delta: always take the full path)
+    const double g = __builtin_fmin(delta * (1.0 + 9.5367431640625e-07) + 1e-300, 0.25);
+    o.hA = __double2hiint(g);
+    o.hB = __double2hiint(1.0 - g);
+    o.hQ0 = __double2hiint(0.5 - g);
+    o.hQspan = (uint32_t)(__double2hiint(0.5 + g) - o.hQ0);
+}
+
+SRK_DEV double cosc_advance(COsc& o, bool& wrapped)
+{
+    const double np = o.pos + o.delta;              // pos += delta
+    wrapped = __double2hiint(np) >= 0x3ff00000;     // np >= 1.0 (np is non-negative)
+    return __builtin_amdgcn_fract(np);              // pos %= 1.0: exact for 0 <= np < 2
+}
+
+// saw port only
+SRK_DEV float cosc_saw(COsc& o)
+{
+    bool wrapped;
+    const double w = cosc_advance(o, wrapped);
+    const float w32 = (float)w;
+    const float ta_next = w32 * o.inv_dt;
+    const float tb = ta_next - 1.0f;                                // (pos - 1) / dt when the phase wraps at this step
+    const float fa = keep(__builtin_fmaf(o.ta, 2.0f - o.ta, -1.0f));  // 2t - t^2 - 1
+    const float fb = keep(__builtin_fmaf(tb, tb + 2.0f, 1.0f));       // t^2 + 2t + 1
+    const float hi = wrapped ? fb : 0.0f;
+    const float blep = o.ta < 1.0f ? fa : hi;
+    const float saw = __builtin_fmaf(o.p32, 2.0f, -1.0f) - blep;
+    o.pos = w;
+    o.p32 = w32;
+    o.ta = ta_next;
+    return saw;
+}
+
+// square port only
+SRK_DEV float cosc_square(COsc& o)
+{
+    const int h = __double2hiint(o.pos);
+    const uint64_t near = __builtin_amdgcn_ballot_w64(h <= o.hA) | __builtin_amdgcn_ballot_w64(h >= o.hB) |
+                          __builtin_amdgcn_ballot_w64((uint32_t)(h - o.hQ0) <= o.hQspan);
+    float sq = h < 0x3fe00000 ? -1.0f : 1.0f;  // pos < 0.5
+    if (near != 0) {
+        const double pos = o.pos;
+        const float blep0 = poly_blep_fast((float)pos, (float)(pos - 1.0), o.inv_dt);
+        double p2 = pos + 0.5;
+        p2 = p2 >= 1.0 ? p2 - 1.0 : p2;
+        const float blep1 = poly_blep_fast((float)p2, (float)(p2 - 1.0), o.inv_dt);
+        sq = sq - (blep0 - blep1);
+    }
+    bool wrapped;
+    o.pos = cosc_advance(o, wrapped);
+    return sq;
+}
+
+// sine port only
+SRK_DEV float cosc_sine(COsc& o)
+{
+    const float s = sine_fast(o.pos);
+    bool wrapped;
+    o.pos = cosc_advance(o, wrapped);
+    return s;
+}
+
+template <uint32_t kPort>
+SRK_DEV float cosc_step(COsc& o)
+{
+    if (kPort == OSC_OUT_SAW) return cosc_saw(o);
+    if (kPort == OSC_OUT_SQUARE) return cosc_square(o);
+    return cosc_sine(o);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Moog ladder — InternalMoogFilterState::calc + clamp_buffers, filter.rs:58-92
 // ---------------------------------------------------------------------------------------------
 struct VcfRegs {
@@ -162,7 +270,15 @@ struct VcfRegs {
     float freq, res;  // the (frequency, res) the coefficients were computed for
 };
 
-SRK_DEV float clamp1(float x) { return fmaxf(fminf(x, 1.0f), -1.0f); }  // x.min(1.0).max(-1.0)
+// clamp_buffers: x.min(1.0).max(-1.0) (filter.rs:89).  kMed3: one v_med3_f32 instead of min+max —
+// identical for every non-NaN x; a NaN (only reachable when an inf/NaN is fed into the filter)
+// becomes -1.0 instead of the reference's +1.0.  The exact render mode uses the literal form.
+template <bool kMed3>
+SRK_DEV float clamp1(float x)
+{
+    if (kMed3) return __builtin_amdgcn_fmed3f(x, -1.0f, 1.0f);
+    return fmaxf(fminf(x, 1.0f), -1.0f);
+}
 
 // filter.rs:61-68 — recompute only when (frequency, res) changed
 SRK_DEV void vcf_coeffs(VcfRegs& s, float frequency, float res)
@@ -178,6 +294,7 @@ SRK_DEV void vcf_coeffs(VcfRegs& s, float frequency, float res)
 }
 
 // filter.rs:69-82 — returns lowpass; band/highpass through references (caller stores only live ports)
+template <bool kMed3 = false>
 SRK_DEV void vcf_step(VcfRegs& s, float input, float& lowpass, float& bandpass, float& highpass)
 {
     input = input - (s.q * s.b4);
@@ -189,11 +306,11 @@ SRK_DEV void vcf_step(VcfRegs& s, float input, float& lowpass, float& bandpass, 
     s.b3 = (s.b2 + t2) * s.p - s.b3 * s.f;
     s.b4 = (s.b3 + t1) * s.p - s.b4 * s.f;
     s.b4 = s.b4 - (s.b4 * s.b4 * s.b4) * 0.166667f;
-    s.b0 = clamp1(input);
-    s.b1 = clamp1(s.b1);
-    s.b2 = clamp1(s.b2);
-    s.b3 = clamp1(s.b3);
-    s.b4 = clamp1(s.b4);
+    s.b0 = clamp1<kMed3>(input);
+    s.b1 = clamp1<kMed3>(s.b1);
+    s.b2 = clamp1<kMed3>(s.b2);
+    s.b3 = clamp1<kMed3>(s.b3);
+    s.b4 = clamp1<kMed3>(s.b4);
     lowpass = s.b4;
     highpass = input - s.b4;
     bandpass = 3.0f * (s.b3 - s.b4);
@@ -296,6 +413,67 @@ SRK_DEV float adsr_step(uint32_t flags, AdsrRegs& s, const AdsrConst& c, float g
         s.r_val = out;
     else
         s.from_a_val = out;
+    return out;
+}
+
+// Segmented ADSR: between mode changes the envelope is  phase += inc; out = c0 + c1 * u  with
+// u = phase (Attack) or 1 - phase, and (inc, c0, c1) fixed — the same f32 operations adsr_step
+// performs for that mode, so the bits are identical.  A sample that may change the mode
+// (phase >= 1, gate level or edge, depending on the mode) sends the whole wave through adsr_step.
+struct AdsrSeg {
+    float inc, c0, c1;
+    float k0, k1;    // u = k0 + k1 * phase: (0, 1) in Attack (u = phase), (1, -1) otherwise (u = 1 - phase); both exact
+    float held;      // previous sample's output: r_val / from_a_val are materialised from it on demand
+    // lane masks (SGPR pairs): the per-sample "does any lane leave its segment" test is scalar-unit work
+    uint64_t attack, on_high, on_low, on_edge, last;
+};
+
+SRK_DEV bool lane_bit(uint64_t mask) { return (mask >> (threadIdx.x & 63)) & 1u; }
+
+SRK_DEV void adsr_seg_enter(const AdsrRegs& s, const AdsrConst& c, AdsrSeg& g)
+{
+    const int m = s.mode;
+    const bool a = m == SRACK_ADSR_MODE_ATTACK, d = m == SRACK_ADSR_MODE_DECAY, su = m == SRACK_ADSR_MODE_SUSTAIN, r = m == SRACK_ADSR_MODE_RELEASE;
+    g.k0 = a ? 0.0f : 1.0f;
+    g.k1 = a ? 1.0f : -1.0f;
+    g.inc = a ? c.inc_a : (d ? c.inc_d : (r ? c.inc_r : 0.0f));
+    g.c0 = a ? s.r_val : ((d || su) ? c.s_val : 0.0f);
+    g.c1 = a ? 1.0f - s.r_val : (d ? 1.0f - c.s_val : (r ? c.s_val : 0.0f));
+    g.attack = __builtin_amdgcn_ballot_w64(a);
+    g.on_high = __builtin_amdgcn_ballot_w64(!(a || d || su));  // None, Release: a high gate starts an attack
+    g.on_low = __builtin_amdgcn_ballot_w64(su);                // Sustain: gate low starts the release
+    g.on_edge = __builtin_amdgcn_ballot_w64(a || d || su);     // Attack, Decay, Sustain: a rising edge retriggers
+    g.last = __builtin_amdgcn_ballot_w64(s.gate_last);
+    g.held = a ? s.from_a_val : s.r_val;
+}
+
+SRK_DEV void adsr_seg_flush(AdsrRegs& s, const AdsrSeg& g)
+{
+    if (lane_bit(g.attack))
+        s.from_a_val = g.held;
+    else
+        s.r_val = g.held;
+    s.gate_last = lane_bit(g.last);
+}
+
+SRK_DEV float adsr_seg_step(AdsrRegs& s, const AdsrConst& c, AdsrSeg& g, float gate)
+{
+    const float ph = s.phase + g.inc;
+    const uint64_t m_over = __builtin_amdgcn_ballot_w64(ph >= 1.0f);
+    const uint64_t m_high = __builtin_amdgcn_ballot_w64(gate > 0.0f);
+    const uint64_t m_leave = m_over | (m_high & g.on_high) | (~m_high & g.on_low) | (m_high & ~g.last & g.on_edge);
+    float out;
+    if (m_leave != 0) {
+        adsr_seg_flush(s, g);
+        out = adsr_step(ADSR_HAS_GATE, s, c, gate);
+        adsr_seg_enter(s, c, g);
+    } else {
+        s.phase = ph;
+        g.last = m_high;
+        const float u = g.k0 + g.k1 * ph;
+        out = g.c0 + g.c1 * u;
+    }
+    g.held = out;
     return out;
 }
 

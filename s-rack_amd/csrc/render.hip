@@ -378,35 +378,60 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
     const AdsrConst kd = adsr_consts(parv(od, ADSR_P_A), parv(od, ADSR_P_D), parv(od, ADSR_P_S), parv(od, ADSR_P_R), parv(od, ADSR_P_SR));
     const bool negative = parv(oc, VCA_P_NEG) != 0.0f;
 
-    float* fp = a.frames ? a.frames + (size_t)plane * a.T * V + voice : nullptr;
+    // frames: uniform base pointer advanced by V per sample + a constant per-lane offset => SGPR base, 0 VALU
+    float* frame_row = a.frames ? a.frames + (size_t)plane * a.T * V + (size_t)blockIdx.x * 64 : nullptr;
     float* mp = a.mixpart ? a.mixpart + ((size_t)plane * a.n_waves + blockIdx.x) * a.T : nullptr;
+    const bool has_frames = frame_row != nullptr, has_mix = mp != nullptr;
+
+    COsc ca, cl;
+    AdsrSeg seg;
+    if (!kExact) {
+        cosc_init(ca, sa.pos, ka.delta);
+        cosc_init(cl, sl.pos, kl.delta);
+        adsr_seg_enter(sd, kd, seg);
+    }
 
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
         for (int i = 0; i < n; i++) {
-            float sine = 0.0f, square = 0.0f, saw = 0.0f;
-            osc_step(fa, sa, ka, 0.0f, 0.0f, sine, square, saw);
-            const float x = kOscAPort == OSC_OUT_SINE ? sine : (kOscAPort == OSC_OUT_SQUARE ? square : saw);
-            float gs = 0.0f, gq = 0.0f, gw = 0.0f;
-            osc_step(fl, sl, kl, 0.0f, 0.0f, gs, gq, gw);
-            const float gate = kOscLPort == OSC_OUT_SINE ? gs : (kOscLPort == OSC_OUT_SQUARE ? gq : gw);
-            float lp, bp, hp;
-            vcf_step(sv, x, lp, bp, hp);
-            const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
-            const float env = adsr_step(ADSR_HAS_GATE, sd, kd, gate);
-            const float o = vca_step(VCA_HAS_AUDIO | VCA_HAS_CV, negative, y, env);
-            if (fp) {
-                if (active) *fp = o;
-                fp += V;
+            float x, gate, env;
+            if (kExact) {
+                float sine = 0.0f, square = 0.0f, saw = 0.0f;
+                osc_step(fa, sa, ka, 0.0f, 0.0f, sine, square, saw);
+                x = kOscAPort == OSC_OUT_SINE ? sine : (kOscAPort == OSC_OUT_SQUARE ? square : saw);
+                float gs = 0.0f, gq = 0.0f, gw = 0.0f;
+                osc_step(fl, sl, kl, 0.0f, 0.0f, gs, gq, gw);
+                gate = kOscLPort == OSC_OUT_SINE ? gs : (kOscLPort == OSC_OUT_SQUARE ? gq : gw);
+            } else {
+                x = cosc_step<kOscAPort>(ca);
+                gate = cosc_step<kOscLPort>(cl);
             }
-            if (mp) mix_tile[i * 64 + lane] = active ? o : 0.0f;
+            float lp, bp, hp;
+            vcf_step<!kExact>(sv, x, lp, bp, hp);
+            const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
+            if (kExact)
+                env = adsr_step(ADSR_HAS_GATE, sd, kd, gate);
+            else
+                env = adsr_seg_step(sd, kd, seg, gate);
+            const float o = vca_step(VCA_HAS_AUDIO | VCA_HAS_CV, negative, y, env);
+            if (has_frames) {
+                if (active) frame_row[lane] = o;
+                frame_row += V;
+            }
+            if (has_mix) mix_tile[i * 64 + lane] = active ? o : 0.0f;
         }
-        if (mp) {
+        if (has_mix) {
             __syncthreads();
             float sum = tile_row_sum(mix_tile, kMixRows, lane);
             if (lane < n) mp[t0 + lane] = sum;
             __syncthreads();
         }
+    }
+    if (!kExact) {
+        sa.pos = ca.pos;
+        sl.pos = cl.pos;
+        sa.sync_last = sl.sync_last = false;  // sync unconnected: `last` follows the constant 0.0 input
+        adsr_seg_flush(sd, seg);
     }
 
     if (active) {

@@ -66,8 +66,9 @@ def test_cfg1_golden(S, adsr, flags):
     p = S.Patch(48000, 1024, 2)
     S.build_p1(p, adsr=adsr)
     p.configure_voices(1)
-    assert ("fused=1" in p.info()) == (not flags & 2)
     out = p.render_channels(48000, flags)
+    assert ("fused=1" in p.info()) == (not flags & 2)
+    assert ("kernel=render_interp" in p.info()) == bool(flags & 2)
     if flags & 1:  # exact oscillator: saw and square are pure f64 arithmetic => the whole chain is bit-identical
         np.testing.assert_array_equal(bits(out[0, :, 0]), bits(gold))
     else:
@@ -265,7 +266,10 @@ def test_render_continues_from_state(S, flags):
     q, _ = make()
     parts = [q.render(n, flags=flags) for n in (1, 999, 33, T - 1033)]
     np.testing.assert_array_equal(bits(np.concatenate([f[0] for f, _ in parts], axis=0)), bits(whole[0]))
-    np.testing.assert_array_equal(bits(np.concatenate([m for _, m in parts], axis=1)), bits(mix_whole))
+    # the mix's summation order depends on where a sample falls in its 32-row tile, so chunked mixes agree to rounding only
+    mix_parts = np.concatenate([m for _, m in parts], axis=1)
+    scale = np.abs(whole[0].astype(np.float64)).sum(axis=1)
+    assert (np.abs(mix_parts.astype(np.float64) - mix_whole) <= 1e-5 * np.maximum(scale, 1.0)).all()
     np.testing.assert_array_equal(q.get_voice_field(ids["osc_a"], S.OSC_POS), end_pos)
     assert ((end_pos >= 0) & (end_pos < 1)).all()
 
