@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--samples", type=int, default=48000, help="samples per step (1 s @ 48 kHz)")
     ap.add_argument("--flags", type=int, default=0, help="SRACK_RENDER_* flags (1 exact osc, 2 no fusion, 4 no uniform hoist)")
     ap.add_argument("--no-frames", action="store_true", help="mix only (diagnostic; not the metric)")
+    ap.add_argument("--no-mix", action="store_true", help="frames only (diagnostic; not the metric)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -103,8 +104,8 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     def step():
-        p.render_raw(T, frames.data_ptr() if frames is not None else None, mix.data_ptr(), args.flags, stream.cuda_stream)
-        if world > 1:
+        p.render_raw(T, frames.data_ptr() if frames is not None else None, None if args.no_mix else mix.data_ptr(), args.flags, stream.cuda_stream)
+        if world > 1 and not args.no_mix:
             dist.reduce(mix, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: [2][T] f32 partial mixes
 
     def fence():
@@ -129,7 +130,11 @@ def main():
 
     if rank == 0:
         voice_samples = float(world) * V * T * args.steps
-        achieved = BYTES_PER_VOICE_SAMPLE * V * T / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # a step may be several launches of the render kernel (chunks that pipeline against the control program):
+        # roofline figures are per launch, like rocprofv3's per-kernel average
+        launches_per_step = max(1, n_launch // max(1, args.steps))
+        bytes_per_launch = BYTES_PER_VOICE_SAMPLE * V * T / launches_per_step
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
             "metric": "voice-samples/sec @48 kHz offline render",
             "value": voice_samples / elapsed,
@@ -143,15 +148,15 @@ def main():
                             f"{V} voices/GPU with per-voice randomised detune/cutoff, {T} samples/step @48 kHz, "
                             "f32 frames [T][V] in HBM + stereo mix-down" + (" + RCCL reduce" if world > 1 else ""),
                 "voices_per_gpu": V, "samples_per_step": T, "buffer_size": 1024, "render_flags": args.flags,
-                "frames_written": frames is not None, "program": p.info(),
+                "frames_written": frames is not None, "mix_down": not args.no_mix, "program": p.info(),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "frac_of_measured_stream_ceiling": achieved / HBM_STREAM_GBS,
-                "kernel_ms": kernel_ms, "kernel_launches": n_launch,
-                "algorithmic_bytes_per_launch": BYTES_PER_VOICE_SAMPLE * V * T,
-                "voice_samples_per_s_kernel": V * T / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
+                "kernel_ms": kernel_ms, "kernel_launches": n_launch, "launches_per_step": launches_per_step,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "voice_samples_per_s_kernel": V * T / launches_per_step / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
             },
         }
         if world == 1 and not args.no_cpu:

@@ -255,8 +255,9 @@ int srack_render_planes(srack_patch* p, int* channel_plane, int cap)
     CHECK_HANDLE(p);
     int rc = ensure_program(p->h, p->h.prog_valid ? p->h.prog_flags : 0u);
     if (rc != SRACK_OK) return rc;
-    for (int c = 0; c < p->h.prog.hdr.n_channels && c < cap && channel_plane; c++) channel_plane[c] = p->h.prog.hdr.channel_plane[c];
-    return p->h.prog.hdr.n_planes;
+    const DevProgram& H = p->h.prog.voice.hdr;
+    for (int c = 0; c < H.n_channels && c < cap && channel_plane; c++) channel_plane[c] = H.channel_plane[c];
+    return H.n_planes;
 }
 
 int srack_render(srack_patch* p, uint32_t n_samples, float* d_frames, float* d_mix, uint32_t flags, void* stream)
@@ -300,7 +301,10 @@ int srack_voices_get_field(srack_patch* p, int module, int field, double* values
     }
     int rc = ensure_program(h, h.prog_valid ? h.prog_flags : 0u);
     if (rc != SRACK_OK) return rc;
-    StateLoc loc = h.prog.locate(h.graph, module, field);
+    // a module evaluated by the control program has ONE state, shared by every voice
+    const bool ctl = h.prog.n_tracks > 0 && module >= 0 && module < (int)h.prog.in_ctl.size() && h.prog.in_ctl[(size_t)module];
+    const FlatProgram& P = ctl ? h.prog.ctl : h.prog.voice;
+    StateLoc loc = P.locate(h.graph, module, field);
     if (loc.row < 0) {  // a parameter, or a module that is not evaluated: the field value itself
         double x;
         rc = h.graph.get_field(module, field, &x);
@@ -311,19 +315,20 @@ int srack_voices_get_field(srack_patch* p, int module, int field, double* values
                 for (uint32_t v = 0; v < h.n_voices; v++) values[v] = o.values[v];
         return SRACK_OK;
     }
-    const uint32_t V = h.n_voices;
+    const uint32_t V = P.n_voices;
     std::vector<uint32_t> rows((size_t)V * (loc.f64 ? 2 : 1));
-    rc = device_read_rows(h, loc.row, loc.f64 ? 2 : 1, rows.data());
+    rc = device_read_rows(h, ctl, loc.row, loc.f64 ? 2 : 1, rows.data());
     if (rc != SRACK_OK) return rc;
-    for (uint32_t v = 0; v < V; v++) {
+    for (uint32_t v = 0; v < h.n_voices; v++) {
+        const uint32_t sv = ctl ? 0u : v;
         if (loc.f64) {
-            uint64_t u = (uint64_t)rows[v] | ((uint64_t)rows[(size_t)V + v] << 32);
+            uint64_t u = (uint64_t)rows[sv] | ((uint64_t)rows[(size_t)V + sv] << 32);
             std::memcpy(&values[v], &u, 8);
         } else if (loc.flag) {
-            values[v] = (double)(int32_t)rows[v];
+            values[v] = (double)(int32_t)rows[sv];
         } else {
             float f;
-            std::memcpy(&f, &rows[v], 4);
+            std::memcpy(&f, &rows[sv], 4);
             values[v] = (double)f;
         }
     }

@@ -1,4 +1,4 @@
-// flatten.cpp — plan -> DevOp list + initial voice table.
+// flatten.cpp — plan -> DevOp lists + initial voice tables.
 //
 // What happens here, in order:
 //   1. plan (graph.cpp, = plan_execution) and find the modules that can reach the OutputModule;
@@ -6,14 +6,19 @@
 //   2. dead-port elimination: an oscillator / filter port nobody reads is not computed
 //      (the reference always computes all three, oscillator.rs:133-149; results on the read
 //      ports are unaffected).
-//   3. wires whose source runs after its sink (broken feedback edges) become a ring of
+//   3. uniform hoisting: a module whose fields carry no per-voice override and whose inputs all
+//      come from such modules produces the same samples for every voice.  That sub-graph becomes
+//      the CONTROL program, evaluated once (one voice) into control tracks; the VOICE program reads
+//      the tracks with OP_TRACK_RD.  (The reference has one instance of everything; "N voices" is
+//      this build's axis, so sharing voice-invariant work changes no sample.)
+//   4. wires whose source runs after its sink (broken feedback edges) become a ring of
 //      buffer_size samples per voice: OP_DELAY_RD before the sink, OP_DELAY_WR after the source.
-//   4. constant hoisting: an oscillator without CV has a constant increment
+//   5. constant hoisting: an oscillator without CV has a constant increment
 //      delta = 440 * 2^f64(val) / f64(sample_rate); it is computed here with glibc pow — the very
 //      value the reference recomputes every sample (oscillator.rs:43-48,132) — per voice.
-//   5. wire slots by linear scan over the op sequence; voice-table rows for state and per-voice
+//   6. wire slots by linear scan over the op sequence; voice-table rows for state and per-voice
 //      parameters; tile size from the LDS budget.
-//   6. pattern match for the fused chain kernels.
+//   7. pattern match for the fused chain kernels.
 #include "flatten.hpp"
 
 #include <algorithm>
@@ -43,10 +48,34 @@ uint32_t f32_bits(float f)
     return u;
 }
 
+DevOp blank_op(int kind, int module)
+{
+    DevOp op{};
+    op.kind = kind;
+    op.module = module;
+    op.state_row = -1;
+    op.delta_row = -1;
+    for (int j = 0; j < kMaxIn; j++) op.in_slot[j] = -1;
+    for (int j = 0; j < kMaxOut; j++) op.out_slot[j] = -1;
+    for (int j = 0; j < kMaxPar; j++) op.par_row[j] = -1;
+    return op;
+}
+
+struct Analysis {  // whole-graph facts shared by both programs
+    std::vector<char> live;
+    std::vector<uint32_t> port_live;
+    std::vector<char> in_ctl;
+    std::vector<std::pair<int, int>> tracks;         // (module, port) exported by the control program
+    std::map<std::pair<int, int>, int> track_of;
+};
+
 struct Builder {
     Graph& g;
     uint32_t V;
     const std::vector<VoiceOverride>& ov;
+    uint32_t render_flags;
+    const Analysis& A;
+    bool is_ctl;
     FlatProgram& out;
     std::vector<Wire> wires;
     std::vector<std::vector<uint32_t>> rows;  // row-major voice table under construction
@@ -61,12 +90,12 @@ struct Builder {
 
     double field(int module, int f) const { return g.modules[(size_t)module].fields[(size_t)f]; }
 
-    int new_row() {
+    int new_row()
+    {
         rows.emplace_back();
         return (int)rows.size() - 1;
     }
 
-    // a 32-bit state row initialised from a module field (uniform or per-voice override)
     int state_row_f32(int module, int f)
     {
         int r = new_row();
@@ -91,7 +120,6 @@ struct Builder {
         return r;
     }
 
-    // two rows (lo, hi) holding an f64
     int rows_f64(const std::vector<double>* per_voice, double uniform)
     {
         int lo = new_row(), hi = new_row();
@@ -107,7 +135,6 @@ struct Builder {
         return lo;
     }
 
-    // parameter k of `op`: per-voice row if overridden, uniform scalar otherwise
     void param(DevOp& op, int k, int module, int f, std::vector<std::pair<int, const VoiceOverride*>>& deferred)
     {
         op.par_val[k] = (float)field(module, f);
@@ -117,7 +144,401 @@ struct Builder {
             deferred.emplace_back((int)out.ops.size() * kMaxPar + k, o);
         }
     }
+
+    int build();
+    void match_fused(bool has_rings);
 };
+
+int Builder::build()
+{
+    const int n_mod = (int)g.modules.size();
+    DevProgram& H = out.hdr;
+    H.n_channels = (int)g.cfg.channels;
+    H.buffer_size = (int)g.cfg.buffer_size;
+    for (int c = 0; c < 8; c++) H.channel_plane[c] = -1;
+    out.op_of_module.assign((size_t)n_mod, -1);
+    out.n_voices = V;
+    out.render_flags = render_flags;
+    const int output = g.plan.output;
+    const auto& pos = g.plan.position;
+    auto mine = [&](int m) { return A.live[(size_t)m] && (bool)A.in_ctl[(size_t)m] == is_ctl; };
+    auto is_delayed = [&](int src, int sink) { return pos[(size_t)src] > pos[(size_t)sink]; };
+
+    // rings: one per (src, port) in this program that has a delayed reader in this program
+    std::map<std::pair<int, int>, int> ring_of;
+    struct Ring { int first_row, global_id; };
+    std::vector<Ring> rings;
+    for (int m : g.plan.order) {
+        if (!mine(m)) continue;
+        for (const InputRef& in : g.modules[(size_t)m].in)
+            if (in.src >= 0 && mine(in.src) && is_delayed(in.src, m) && !ring_of.count({in.src, in.port})) {
+                ring_of[{in.src, in.port}] = (int)rings.size();
+                rings.push_back(Ring{-1, -1});
+            }
+    }
+    const int B = (int)g.cfg.buffer_size;
+    const bool rings_in_lds = B <= kRingLdsMax;
+
+    std::map<std::pair<int, int>, int> wire_of;  // (module, port) -> wire id; in_slot / out_slot hold WIRE ids until the scan
+    std::vector<std::pair<int, const VoiceOverride*>> deferred, deferred_delta;
+    auto new_wire = [&](int def_op) {
+        wires.push_back(Wire{def_op, def_op, -1});
+        return (int)wires.size() - 1;
+    };
+    auto use_wire = [&](int w, int op_index) { wires[(size_t)w].last_use = std::max(wires[(size_t)w].last_use, op_index); };
+    int n_planes = 0;
+
+    // voice program: one OP_TRACK_RD per control track some module of this program reads
+    std::map<int, int> wire_of_track;
+    if (!is_ctl) {
+        for (int m : g.plan.order) {
+            if (!mine(m)) continue;
+            for (const InputRef& in : g.modules[(size_t)m].in) {
+                if (in.src < 0 || !A.in_ctl[(size_t)in.src]) continue;
+                int k = A.track_of.at({in.src, in.port});
+                if (wire_of_track.count(k)) continue;
+                DevOp rd = blank_op(OP_TRACK_RD, in.src);
+                rd.aux = k;
+                int w = new_wire((int)out.ops.size());
+                rd.out_slot[0] = w;
+                out.ops.push_back(rd);
+                wire_of_track[k] = w;
+            }
+        }
+    }
+
+    for (int m : g.plan.order) {
+        if (!mine(m)) continue;
+        const Module& mod = g.modules[(size_t)m];
+        int in_wire[kMaxIn];
+        for (int k = 0; k < kMaxIn; k++) in_wire[k] = -1;
+        for (int k = 0; k < mod.n_in; k++) {
+            const InputRef& in = mod.in[(size_t)k];
+            if (in.src < 0) continue;
+            if (!is_ctl && A.in_ctl[(size_t)in.src]) {  // a control track (never a delayed edge: see the uniform analysis)
+                in_wire[k] = wire_of_track.at(A.track_of.at({in.src, in.port}));
+            } else if (is_delayed(in.src, m)) {
+                DevOp rd = blank_op(OP_DELAY_RD, in.src);
+                rd.aux = ring_of.at({in.src, in.port});
+                int w = new_wire((int)out.ops.size());
+                rd.out_slot[0] = w;
+                out.ops.push_back(rd);
+                in_wire[k] = w;
+            } else {
+                auto it = wire_of.find({in.src, in.port});
+                if (it == wire_of.end()) {
+                    set_error("flatten: internal error, source wire not defined before its reader");
+                    return SRACK_ERR_INVALID;
+                }
+                in_wire[k] = it->second;
+            }
+        }
+        const int oi = (int)out.ops.size();
+        DevOp op = blank_op(OP_NONE, m);
+        for (int j = 0; j < kMaxIn; j++) op.in_slot[j] = in_wire[j];
+        for (int k = 0; k < kMaxIn; k++)
+            if (in_wire[k] >= 0) use_wire(in_wire[k], oi);
+        auto connected = [&](int k) { return in_wire[k] >= 0; };
+        const uint32_t pl = A.port_live[(size_t)m];
+
+        switch (mod.type) {
+        case SRACK_MOD_OSCILLATOR: {
+            op.kind = OP_OSC;
+            if (connected(0)) op.flags |= OSC_HAS_CV;
+            if (connected(1)) op.flags |= OSC_HAS_SYNC;
+            if (field(m, SRACK_OSC_ANTIALIASING) != 0.0) op.flags |= OSC_AA;
+            if (pl & 1u) op.flags |= OSC_OUT_SINE;
+            if (pl & 2u) op.flags |= OSC_OUT_SQUARE;
+            if (pl & 4u) op.flags |= OSC_OUT_SAW;
+            if (render_flags & SRACK_RENDER_EXACT_OSC) op.flags |= OSC_EXACT;
+            op.sample_rate = (double)g.cfg.sample_rate;  // `self.sample_rate as f64`, u16 in the reference
+            {   // pos: f64 state, two rows (lo, hi)
+                const VoiceOverride* o = find_override(m, SRACK_OSC_POS);
+                op.state_row = rows_f64(o ? &o->values : nullptr, field(m, SRACK_OSC_POS));
+            }
+            state_row_flag(m, SRACK_OSC_SYNC_LAST);
+            param(op, OSC_P_VAL, m, SRACK_OSC_VAL, deferred);
+            if (!(op.flags & OSC_HAS_CV)) {
+                // get_freq_in_hz(None, i) / sample_rate — loop-invariant, same bits as the reference
+                op.delta = 440.0 * std::pow(2.0, (double)(float)field(m, SRACK_OSC_VAL)) / op.sample_rate;
+                bool small = op.delta < 0.25;
+                if (const VoiceOverride* o = find_override(m, SRACK_OSC_VAL)) {
+                    op.delta_row = -2;
+                    deferred_delta.emplace_back(oi, o);
+                    for (uint32_t v = 0; v < V && small; v++)
+                        small = 440.0 * std::pow(2.0, (double)(float)o->values[v]) / op.sample_rate < 0.25;
+                }
+                const uint32_t ports = op.flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
+                if (small && !(op.flags & (OSC_HAS_SYNC | OSC_EXACT)) && (op.flags & OSC_AA) && ports && !(ports & (ports - 1)))
+                    op.flags |= OSC_CONST_FAST;
+            }
+            break;
+        }
+        case SRACK_MOD_MOOG_FILTER:
+            op.kind = OP_VCF;
+            if (connected(0)) op.flags |= VCF_HAS_AUDIO;
+            if (connected(1)) op.flags |= VCF_HAS_CV;
+            if (pl & 1u) op.flags |= VCF_OUT_LP;
+            if (pl & 2u) op.flags |= VCF_OUT_BP;
+            if (pl & 4u) op.flags |= VCF_OUT_HP;
+            op.state_row = state_row_f32(m, SRACK_VCF_ST_F);
+            state_row_f32(m, SRACK_VCF_ST_P);
+            state_row_f32(m, SRACK_VCF_ST_Q);
+            for (int k = 0; k < 5; k++) state_row_f32(m, SRACK_VCF_ST_B0 + k);
+            state_row_f32(m, SRACK_VCF_ST_FREQ);
+            state_row_f32(m, SRACK_VCF_ST_RES);
+            param(op, VCF_P_FREQ, m, SRACK_VCF_FREQ, deferred);
+            param(op, VCF_P_RES, m, SRACK_VCF_RES, deferred);
+            param(op, VCF_P_EXP, m, SRACK_VCF_EXP_AMT, deferred);
+            break;
+        case SRACK_MOD_ADSR:
+            op.kind = OP_ADSR;
+            if (connected(0)) op.flags |= ADSR_HAS_GATE;
+            op.state_row = state_row_f32(m, SRACK_ADSR_PHASE);
+            state_row_flag(m, SRACK_ADSR_MODE);
+            state_row_f32(m, SRACK_ADSR_R_VAL);
+            state_row_f32(m, SRACK_ADSR_FROM_A_VAL);
+            state_row_flag(m, SRACK_ADSR_GATE_LAST);
+            param(op, ADSR_P_A, m, SRACK_ADSR_A_SEC, deferred);
+            param(op, ADSR_P_D, m, SRACK_ADSR_D_SEC, deferred);
+            param(op, ADSR_P_S, m, SRACK_ADSR_S_VAL, deferred);
+            param(op, ADSR_P_R, m, SRACK_ADSR_R_SEC, deferred);
+            param(op, ADSR_P_SR, m, SRACK_ADSR_SAMPLE_RATE, deferred);
+            break;
+        case SRACK_MOD_VCA:
+            op.kind = OP_VCA;
+            if (connected(0)) op.flags |= VCA_HAS_AUDIO;
+            if (connected(1)) op.flags |= VCA_HAS_CV;
+            param(op, VCA_P_NEG, m, SRACK_VCA_NEGATIVE, deferred);
+            break;
+        case SRACK_MOD_MONO_MIXER:
+            op.kind = OP_MIX;
+            for (int k = 0; k < 4; k++) {
+                if (connected(k)) op.flags |= 1u << k;
+                param(op, MIX_P_GAIN0 + k, m, SRACK_MIX_GAIN0 + k, deferred);
+            }
+            break;
+        case SRACK_MOD_MATH:
+            op.kind = OP_MATH;
+            if (connected(0)) op.flags |= MATH_HAS_IN1;
+            if (connected(1)) op.flags |= MATH_HAS_IN2;
+            op.flags |= ((uint32_t)(int)field(m, SRACK_MATH_OPERATION) & 3u) << MATH_OP_SHIFT;
+            param(op, MATH_P_CONST, m, SRACK_MATH_CONSTANT, deferred);
+            break;
+        case SRACK_MOD_OUTPUT:
+            op.kind = OP_OUT;
+            break;
+        default:
+            set_error("flatten: unsupported module type");
+            return SRACK_ERR_UNSUPPORTED;
+        }
+
+        if (mod.type == SRACK_MOD_OUTPUT) {
+            if (m != output) continue;  // only the plan's sink is observable
+            // one OP_OUT per distinct source wire (plane); channels map onto planes
+            std::map<int, int> plane_of_wire;
+            for (int c = 0; c < mod.n_in && c < 8; c++) {
+                if (in_wire[c] < 0) continue;
+                auto it = plane_of_wire.find(in_wire[c]);
+                if (it == plane_of_wire.end()) {
+                    DevOp o2 = blank_op(OP_OUT, m);
+                    o2.in_slot[0] = in_wire[c];
+                    o2.aux = n_planes;
+                    use_wire(in_wire[c], (int)out.ops.size());
+                    out.ops.push_back(o2);
+                    it = plane_of_wire.emplace(in_wire[c], n_planes++).first;
+                }
+                H.channel_plane[c] = it->second;
+            }
+            out.op_of_module[(size_t)m] = oi;
+            continue;
+        }
+
+        for (int p = 0; p < mod.n_out; p++)
+            if (pl & (1u << p)) {
+                int w = new_wire(oi);
+                op.out_slot[p] = w;
+                wire_of[{m, p}] = w;
+            }
+        out.op_of_module[(size_t)m] = oi;
+        out.ops.push_back(op);
+        for (int p = 0; p < mod.n_out; p++) {
+            auto it = ring_of.find({m, p});  // source side of a ring fed by this module
+            if (it != ring_of.end()) {
+                DevOp wr = blank_op(OP_DELAY_WR, m);
+                wr.aux = it->second;
+                wr.in_slot[0] = wire_of.at({m, p});
+                use_wire(wr.in_slot[0], (int)out.ops.size());
+                out.ops.push_back(wr);
+            }
+            if (is_ctl) {  // control program: exported wires are written out as track planes
+                auto tk = A.track_of.find({m, p});
+                if (tk != A.track_of.end()) {
+                    DevOp o2 = blank_op(OP_OUT, m);
+                    o2.in_slot[0] = wire_of.at({m, p});
+                    o2.aux = tk->second;
+                    use_wire(o2.in_slot[0], (int)out.ops.size());
+                    out.ops.push_back(o2);
+                    n_planes = std::max(n_planes, tk->second + 1);
+                }
+            }
+        }
+    }
+    if ((int)out.ops.size() > kMaxOps) {
+        set_error("flatten: patch needs more than " + std::to_string(kMaxOps) + " ops");
+        return SRACK_ERR_UNSUPPORTED;
+    }
+
+    // ---- rings: storage ---------------------------------------------------------------------
+    int n_global = 0;
+    for (Ring& r : rings) {
+        if (rings_in_lds) {
+            r.first_row = (int)rows.size();
+            for (int k = 0; k < B; k++) rows[(size_t)new_row()].assign(V, 0u);  // zero-initialised buffer (synth.rs:31-33)
+        } else {
+            r.global_id = n_global++;
+        }
+    }
+    for (DevOp& op : out.ops)
+        if (op.kind == OP_DELAY_RD || op.kind == OP_DELAY_WR) {
+            const Ring& r = rings[(size_t)op.aux];
+            if (rings_in_lds) {
+                op.aux = r.first_row;
+            } else {
+                op.aux = r.global_id;
+                op.flags |= DELAY_RING_GLOBAL;
+            }
+        }
+    H.n_rings = n_global;
+    H.n_state_rows = (int)rows.size();
+
+    // ---- per-voice parameter rows (read-only) -------------------------------------------------
+    for (auto& d : deferred) {
+        DevOp& op = out.ops[(size_t)(d.first / kMaxPar)];
+        int r = new_row();
+        auto& row = rows[(size_t)r];
+        row.resize(V);
+        for (uint32_t v = 0; v < V; v++) row[v] = f32_bits((float)d.second->values[v]);
+        op.par_row[d.first % kMaxPar] = r;
+    }
+    for (auto& d : deferred_delta) {
+        DevOp& op = out.ops[(size_t)d.first];
+        std::vector<double> delta(V);
+        for (uint32_t v = 0; v < V; v++) delta[v] = 440.0 * std::pow(2.0, (double)(float)d.second->values[v]) / op.sample_rate;
+        op.delta_row = rows_f64(&delta, 0.0);
+    }
+    H.n_rows = (int)rows.size();
+
+    // ---- wire slots: linear scan ----------------------------------------------------------------
+    {
+        std::vector<int> free_slots;
+        int n_slots = 0;
+        std::vector<std::vector<int>> expire(out.ops.size() + 1), defs(out.ops.size() + 1);
+        for (size_t w = 0; w < wires.size(); w++) {
+            expire[(size_t)wires[w].last_use].push_back((int)w);
+            defs[(size_t)wires[w].def_op].push_back((int)w);
+        }
+        for (size_t i = 0; i < out.ops.size(); i++) {
+            for (int w : defs[i]) {  // outputs never reuse this op's input slots: inputs stay live through the op
+                if (free_slots.empty()) {
+                    wires[(size_t)w].slot = n_slots++;
+                } else {
+                    wires[(size_t)w].slot = free_slots.back();
+                    free_slots.pop_back();
+                }
+            }
+            for (int w : expire[i]) free_slots.push_back(wires[(size_t)w].slot);
+        }
+        H.n_slots = n_slots;
+        for (DevOp& op : out.ops) {
+            for (int k = 0; k < kMaxIn; k++)
+                if (op.in_slot[k] >= 0) op.in_slot[k] = wires[(size_t)op.in_slot[k]].slot;
+            for (int k = 0; k < kMaxOut; k++)
+                if (op.out_slot[k] >= 0) op.out_slot[k] = wires[(size_t)op.out_slot[k]].slot;
+        }
+    }
+    H.n_ops = (int)out.ops.size();
+    H.n_planes = n_planes;
+
+    // ---- tile size from the LDS budget ------------------------------------------------------------
+    {
+        int tile = kTileMax;
+        if (!rings.empty())
+            while (tile > B) tile >>= 1;  // a tile may not span more than one ring period
+        while (tile > 1 && (H.n_rows + H.n_slots * tile) * 256 > kLdsBudget) tile >>= 1;
+        if ((H.n_rows + H.n_slots * tile) * 256 > 64 * 1024) {
+            set_error("flatten: patch state does not fit the LDS budget of the tile interpreter");
+            return SRACK_ERR_UNSUPPORTED;
+        }
+        H.tile = tile;
+    }
+
+    out.table.resize((size_t)H.n_rows * V);
+    for (int r = 0; r < H.n_rows; r++) std::memcpy(&out.table[(size_t)r * V], rows[(size_t)r].data(), sizeof(uint32_t) * V);
+
+    if (!is_ctl && !(render_flags & SRACK_RENDER_NO_FUSION)) match_fused(!rings.empty());
+    if (is_ctl && !(render_flags & SRACK_RENDER_NO_FUSION) && rings.empty() && H.n_ops == 3 && out.ops[0].kind == OP_OSC &&
+        out.ops[1].kind == OP_ADSR && out.ops[2].kind == OP_OUT && (out.ops[0].flags & OSC_CONST_FAST) && (out.ops[1].flags & ADSR_HAS_GATE) &&
+        g.modules[(size_t)out.ops[1].module].in[0].src == out.ops[0].module && out.ops[2].module == out.ops[1].module)
+        out.fused = FUSED_CTL_GATE_ENV;  // uniform parameters only (V == 1, no overrides): par_val / delta are used directly
+
+    std::ostringstream d;
+    d << (is_ctl ? "ctl[" : "voice[") << "ops=" << H.n_ops << " slots=" << H.n_slots << " rows=" << H.n_rows << " (state " << H.n_state_rows
+      << ") planes=" << H.n_planes << " rings=" << rings.size() << (rings.empty() ? "" : (rings_in_lds ? "(lds)" : "(hbm)")) << " tile=" << H.tile
+      << " fused=" << out.fused << "]";
+    out.description = d.str();
+    return SRACK_OK;
+}
+
+// Fused kernels (render.hip) for patch P1's shape.  All-per-voice form:
+//   {OSC_A, OSC_L, VCF, ADSR, VCA, OUT}: VCF <- OSC_A, ADSR <- OSC_L, VCA <- (VCF, ADSR), one plane <- VCA.
+// After uniform hoisting the LFO/ADSR pair lives in the control program and the voice program is
+//   {TRACK_RD, OSC_A, VCF, VCA, OUT}: VCA <- (VCF, track).
+// Oscillators must be OSC_CONST_FAST (or the exact flavour of the same shape), filters have no CV.
+void Builder::match_fused(bool has_rings)
+{
+    if (has_rings) return;
+    int n_kind[16] = {0};
+    for (const DevOp& op : out.ops) n_kind[op.kind]++;
+    const DevProgram& H = out.hdr;
+    const bool full = H.n_ops == 6 && n_kind[OP_OSC] == 2 && n_kind[OP_VCF] == 1 && n_kind[OP_ADSR] == 1 && n_kind[OP_VCA] == 1 && n_kind[OP_OUT] == 1;
+    const bool tracked = H.n_ops == 5 && n_kind[OP_TRACK_RD] == 1 && n_kind[OP_OSC] == 1 && n_kind[OP_VCF] == 1 && n_kind[OP_VCA] == 1 && n_kind[OP_OUT] == 1;
+    if (!full && !tracked) return;
+    const DevOp *vcf = nullptr, *adsr = nullptr, *vca = nullptr, *outp = nullptr, *trk = nullptr;
+    for (const DevOp& op : out.ops) {
+        if (op.kind == OP_VCF) vcf = &op;
+        if (op.kind == OP_ADSR) adsr = &op;
+        if (op.kind == OP_VCA) vca = &op;
+        if (op.kind == OP_OUT) outp = &op;
+        if (op.kind == OP_TRACK_RD) trk = &op;
+    }
+    auto src_of = [&](int sink_module, int k) { return g.modules[(size_t)sink_module].in[(size_t)k]; };
+    auto osc_ok = [&](int module) {
+        if (g.modules[(size_t)module].type != SRACK_MOD_OSCILLATOR || out.op_of_module[(size_t)module] < 0) return false;
+        const DevOp& o = out.ops[(size_t)out.op_of_module[(size_t)module]];
+        if (o.flags & (OSC_HAS_CV | OSC_HAS_SYNC)) return false;
+        const uint32_t ports = o.flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
+        if (!ports || (ports & (ports - 1)) || !(o.flags & OSC_AA)) return false;
+        return (o.flags & OSC_CONST_FAST) || (o.flags & OSC_EXACT);
+    };
+    const uint32_t vcf_ports = vcf->flags & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP);
+    bool ok = vca->flags == (VCA_HAS_AUDIO | VCA_HAS_CV) && src_of(vca->module, 0).src == vcf->module && src_of(outp->module, 0).src >= 0 &&
+              (vcf->flags & (VCF_HAS_AUDIO | VCF_HAS_CV)) == VCF_HAS_AUDIO && vcf_ports && !(vcf_ports & (vcf_ports - 1)) &&
+              osc_ok(src_of(vcf->module, 0).src);
+    for (int c = 0; c < H.n_channels && ok; c++) {
+        const InputRef& in = src_of(outp->module, c);
+        ok = in.src < 0 || in.src == vca->module;
+    }
+    if (!ok) return;
+    if (full) {
+        ok = src_of(vca->module, 1).src == adsr->module && (adsr->flags & ADSR_HAS_GATE) && osc_ok(src_of(adsr->module, 0).src) &&
+             src_of(adsr->module, 0).src != src_of(vcf->module, 0).src && src_of(adsr->module, 0).port == SRACK_OSC_OUT_SQUARE;
+        if (ok) out.fused = FUSED_VOICE_CHAIN;
+    } else {
+        ok = A.in_ctl[(size_t)src_of(vca->module, 1).src] && trk != nullptr;
+        if (ok) out.fused = FUSED_VOICE_CHAIN_TRACK;
+    }
+}
 
 }  // namespace
 
@@ -161,23 +582,15 @@ StateLoc FlatProgram::locate(const Graph& g, int module, int field) const
     return loc;
 }
 
-int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overrides, uint32_t render_flags, FlatProgram& out)
+int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overrides, uint32_t render_flags, FlatPair& out)
 {
-    out = FlatProgram{};
-    out.n_voices = n_voices;
-    out.render_flags = render_flags;
+    out = FlatPair{};
     if (n_voices == 0) {
         set_error("flatten: n_voices = 0 (call srack_voices_configure first)");
         return SRACK_ERR_STATE;
     }
     if (!g.plan.valid) g.make_plan();
     const int n_mod = (int)g.modules.size();
-    out.op_of_module.assign((size_t)n_mod, -1);
-    DevProgram& H = out.hdr;
-    H.n_channels = (int)g.cfg.channels;
-    H.buffer_size = (int)g.cfg.buffer_size;
-    for (int c = 0; c < 8; c++) H.channel_plane[c] = -1;
-
     for (const auto& o : overrides) {
         if (o.module < 0 || o.module >= n_mod || o.field < 0 || o.field >= g.num_fields(o.module) || o.values.size() != n_voices) {
             set_error("flatten: bad per-voice override");
@@ -189,397 +602,94 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             return SRACK_ERR_UNSUPPORTED;
         }
     }
-
+    Analysis A;
+    A.live.assign((size_t)n_mod, 0);
+    A.port_live.assign((size_t)n_mod, 0);
+    A.in_ctl.assign((size_t)n_mod, 0);
+    out.in_ctl = A.in_ctl;
     const int output = g.plan.output;
-    Builder b{g, n_voices, overrides, out, {}, {}};
+    static const std::vector<VoiceOverride> kNoOverrides;
     if (output < 0) {  // no OutputModule: empty plan (ui.rs:75-79) => silence
-        out.description = "no OutputModule: empty plan";
-        H.tile = kTileMax;
+        out.voice.hdr.n_channels = (int)g.cfg.channels;
+        out.voice.hdr.buffer_size = (int)g.cfg.buffer_size;
+        for (int c = 0; c < 8; c++) out.voice.hdr.channel_plane[c] = -1;
+        out.voice.hdr.tile = kTileMax;
+        out.voice.n_voices = n_voices;
+        out.voice.op_of_module.assign((size_t)n_mod, -1);
+        out.description = out.voice.description = "no OutputModule: empty plan";
         return SRACK_OK;
     }
 
-    // ---- 1. reachability from the output, 2. live ports -------------------------------------
-    std::vector<char> live((size_t)n_mod, 0);
-    std::vector<uint32_t> port_live((size_t)n_mod, 0);  // bit per output port
+    // ---- 1. reachability from the output, 2. live ports -------------------------------------------
     {
         std::vector<int> stack{output};
         while (!stack.empty()) {
             int m = stack.back();
             stack.pop_back();
-            if (live[(size_t)m]) continue;
-            live[(size_t)m] = 1;
+            if (A.live[(size_t)m]) continue;
+            A.live[(size_t)m] = 1;
             for (const InputRef& in : g.modules[(size_t)m].in)
                 if (in.src >= 0) {
                     if (in.src == m) {
                         set_error("module " + std::to_string(m) + " is wired to itself: the reference deadlocks on this (synth.rs:99,251)");
                         return SRACK_ERR_SELF_LOOP;
                     }
-                    port_live[(size_t)in.src] |= 1u << in.port;
+                    A.port_live[(size_t)in.src] |= 1u << in.port;
                     stack.push_back(in.src);
                 }
         }
     }
-    const auto& pos = g.plan.position;
-    auto is_delayed = [&](int src, int sink) { return pos[(size_t)src] > pos[(size_t)sink]; };
 
-    // rings: one per (src, port) that has a delayed reader
-    std::map<std::pair<int, int>, int> ring_of;  // -> ring index
-    struct Ring { int src, port, first_row, global_id, wire; };
-    std::vector<Ring> rings;
-    for (int m : g.plan.order) {
-        if (!live[(size_t)m]) continue;
-        for (const InputRef& in : g.modules[(size_t)m].in)
-            if (in.src >= 0 && is_delayed(in.src, m) && !ring_of.count({in.src, in.port})) {
-                ring_of[{in.src, in.port}] = (int)rings.size();
-                rings.push_back(Ring{in.src, in.port, -1, -1, -1});
-            }
-    }
-    const int B = (int)g.cfg.buffer_size;
-    const bool rings_in_lds = B <= kRingLdsMax;
-
-    // ---- 3.-4. emit ops in plan order ---------------------------------------------------------
-    std::map<std::pair<int, int>, int> wire_of;  // (module, port) -> wire id
-    std::vector<std::pair<int, const VoiceOverride*>> deferred;  // per-voice parameter rows to allocate
-    std::vector<std::pair<int, const VoiceOverride*>> deferred_delta;  // op index, OSC val override
-    auto new_wire = [&](int def_op) {
-        b.wires.push_back(Wire{def_op, def_op, -1});
-        return (int)b.wires.size() - 1;
-    };
-    auto use_wire = [&](int w, int op_index) { b.wires[(size_t)w].last_use = std::max(b.wires[(size_t)w].last_use, op_index); };
-    // in_slot / out_slot temporarily hold WIRE ids; mapped to slots after the scan
-    int n_planes = 0;
-
-    for (int m : g.plan.order) {
-        if (!live[(size_t)m]) continue;
-        const Module& mod = g.modules[(size_t)m];
-        int in_wire[kMaxIn];
-        for (int k = 0; k < kMaxIn; k++) in_wire[k] = -1;
-        for (int k = 0; k < mod.n_in; k++) {
-            const InputRef& in = mod.in[(size_t)k];
-            if (in.src < 0) continue;
-            if (is_delayed(in.src, m)) {
-                int r = ring_of[{in.src, in.port}];
-                DevOp rd{};
-                rd.kind = OP_DELAY_RD;
-                rd.module = in.src;
-                rd.aux = r;  // ring index for now
-                rd.state_row = -1;
-                for (int j = 0; j < kMaxIn; j++) rd.in_slot[j] = -1;
-                for (int j = 0; j < kMaxOut; j++) rd.out_slot[j] = -1;
-                for (int j = 0; j < kMaxPar; j++) rd.par_row[j] = -1;
-                int w = new_wire((int)out.ops.size());
-                rd.out_slot[0] = w;
-                out.ops.push_back(rd);
-                in_wire[k] = w;
-            } else {
-                auto it = wire_of.find({in.src, in.port});
-                if (it == wire_of.end()) {
-                    set_error("flatten: internal error, source wire not defined before its reader");
-                    return SRACK_ERR_INVALID;
-                }
-                in_wire[k] = it->second;
-            }
-        }
-        const int oi = (int)out.ops.size();
-        DevOp op{};
-        op.module = m;
-        op.state_row = -1;
-        op.delta_row = -1;
-        op.aux = 0;
-        for (int j = 0; j < kMaxIn; j++) op.in_slot[j] = in_wire[j];
-        for (int j = 0; j < kMaxOut; j++) op.out_slot[j] = -1;
-        for (int j = 0; j < kMaxPar; j++) op.par_row[j] = -1;
-        for (int k = 0; k < kMaxIn; k++)
-            if (in_wire[k] >= 0) use_wire(in_wire[k], oi);
-        auto connected = [&](int k) { return in_wire[k] >= 0; };
-        const uint32_t pl = port_live[(size_t)m];
-
-        switch (mod.type) {
-        case SRACK_MOD_OSCILLATOR: {
-            op.kind = OP_OSC;
-            if (connected(0)) op.flags |= OSC_HAS_CV;
-            if (connected(1)) op.flags |= OSC_HAS_SYNC;
-            if (b.field(m, SRACK_OSC_ANTIALIASING) != 0.0) op.flags |= OSC_AA;
-            if (pl & 1u) op.flags |= OSC_OUT_SINE;
-            if (pl & 2u) op.flags |= OSC_OUT_SQUARE;
-            if (pl & 4u) op.flags |= OSC_OUT_SAW;
-            if (render_flags & SRACK_RENDER_EXACT_OSC) op.flags |= OSC_EXACT;
-            op.sample_rate = (double)g.cfg.sample_rate;  // `self.sample_rate as f64`, u16 in the reference
-            {   // pos: f64 state, two rows (lo, hi)
-                const VoiceOverride* o = b.find_override(m, SRACK_OSC_POS);
-                op.state_row = b.rows_f64(o ? &o->values : nullptr, b.field(m, SRACK_OSC_POS));
-            }
-            b.state_row_flag(m, SRACK_OSC_SYNC_LAST);
-            b.param(op, OSC_P_VAL, m, SRACK_OSC_VAL, deferred);
-            if (!(op.flags & OSC_HAS_CV)) {
-                // get_freq_in_hz(None, i) / sample_rate — loop-invariant, same bits as the reference
-                op.delta = 440.0 * std::pow(2.0, (double)(float)b.field(m, SRACK_OSC_VAL)) / op.sample_rate;
-                if (const VoiceOverride* o = b.find_override(m, SRACK_OSC_VAL)) {
-                    op.delta_row = -2;
-                    deferred_delta.emplace_back(oi, o);
-                }
-            }
-            break;
-        }
-        case SRACK_MOD_MOOG_FILTER:
-            op.kind = OP_VCF;
-            if (connected(0)) op.flags |= VCF_HAS_AUDIO;
-            if (connected(1)) op.flags |= VCF_HAS_CV;
-            if (pl & 1u) op.flags |= VCF_OUT_LP;
-            if (pl & 2u) op.flags |= VCF_OUT_BP;
-            if (pl & 4u) op.flags |= VCF_OUT_HP;
-            op.state_row = b.state_row_f32(m, SRACK_VCF_ST_F);
-            b.state_row_f32(m, SRACK_VCF_ST_P);
-            b.state_row_f32(m, SRACK_VCF_ST_Q);
-            for (int k = 0; k < 5; k++) b.state_row_f32(m, SRACK_VCF_ST_B0 + k);
-            b.state_row_f32(m, SRACK_VCF_ST_FREQ);
-            b.state_row_f32(m, SRACK_VCF_ST_RES);
-            b.param(op, VCF_P_FREQ, m, SRACK_VCF_FREQ, deferred);
-            b.param(op, VCF_P_RES, m, SRACK_VCF_RES, deferred);
-            b.param(op, VCF_P_EXP, m, SRACK_VCF_EXP_AMT, deferred);
-            break;
-        case SRACK_MOD_ADSR:
-            op.kind = OP_ADSR;
-            if (connected(0)) op.flags |= ADSR_HAS_GATE;
-            op.state_row = b.state_row_f32(m, SRACK_ADSR_PHASE);
-            b.state_row_flag(m, SRACK_ADSR_MODE);
-            b.state_row_f32(m, SRACK_ADSR_R_VAL);
-            b.state_row_f32(m, SRACK_ADSR_FROM_A_VAL);
-            b.state_row_flag(m, SRACK_ADSR_GATE_LAST);
-            b.param(op, ADSR_P_A, m, SRACK_ADSR_A_SEC, deferred);
-            b.param(op, ADSR_P_D, m, SRACK_ADSR_D_SEC, deferred);
-            b.param(op, ADSR_P_S, m, SRACK_ADSR_S_VAL, deferred);
-            b.param(op, ADSR_P_R, m, SRACK_ADSR_R_SEC, deferred);
-            b.param(op, ADSR_P_SR, m, SRACK_ADSR_SAMPLE_RATE, deferred);
-            break;
-        case SRACK_MOD_VCA:
-            op.kind = OP_VCA;
-            if (connected(0)) op.flags |= VCA_HAS_AUDIO;
-            if (connected(1)) op.flags |= VCA_HAS_CV;
-            b.param(op, VCA_P_NEG, m, SRACK_VCA_NEGATIVE, deferred);
-            break;
-        case SRACK_MOD_MONO_MIXER:
-            op.kind = OP_MIX;
-            for (int k = 0; k < 4; k++) {
-                if (connected(k)) op.flags |= 1u << k;
-                b.param(op, MIX_P_GAIN0 + k, m, SRACK_MIX_GAIN0 + k, deferred);
-            }
-            break;
-        case SRACK_MOD_MATH:
-            op.kind = OP_MATH;
-            if (connected(0)) op.flags |= MATH_HAS_IN1;
-            if (connected(1)) op.flags |= MATH_HAS_IN2;
-            op.flags |= ((uint32_t)(int)b.field(m, SRACK_MATH_OPERATION) & 3u) << MATH_OP_SHIFT;
-            b.param(op, MATH_P_CONST, m, SRACK_MATH_CONSTANT, deferred);
-            break;
-        case SRACK_MOD_OUTPUT:
-            op.kind = OP_OUT;
-            break;
-        default:
-            set_error("flatten: unsupported module type");
-            return SRACK_ERR_UNSUPPORTED;
-        }
-
-        if (mod.type == SRACK_MOD_OUTPUT) {
-            if (m != output) continue;  // a second OutputModule is never the plan's sink; it has no readers
-            // one OP_OUT per distinct source wire (plane); channels map onto planes
-            std::map<int, int> plane_of_wire;
-            for (int c = 0; c < mod.n_in && c < 8; c++) {
-                if (in_wire[c] < 0) continue;
-                auto it = plane_of_wire.find(in_wire[c]);
-                if (it == plane_of_wire.end()) {
-                    DevOp o2 = op;
-                    for (int j = 0; j < kMaxIn; j++) o2.in_slot[j] = -1;
-                    o2.in_slot[0] = in_wire[c];
-                    o2.aux = n_planes;
-                    use_wire(in_wire[c], (int)out.ops.size());
-                    out.ops.push_back(o2);
-                    it = plane_of_wire.emplace(in_wire[c], n_planes++).first;
-                }
-                H.channel_plane[c] = it->second;
-            }
-            out.op_of_module[(size_t)m] = oi;
-            continue;
-        }
-
-        for (int p = 0; p < mod.n_out; p++)
-            if (pl & (1u << p)) {
-                int w = new_wire(oi);
-                op.out_slot[p] = w;
-                wire_of[{m, p}] = w;
-            }
-        out.op_of_module[(size_t)m] = oi;
-        out.ops.push_back(op);
-        // source side of every ring fed by this module
-        for (int p = 0; p < mod.n_out; p++) {
-            auto it = ring_of.find({m, p});
-            if (it == ring_of.end()) continue;
-            DevOp wr{};
-            wr.kind = OP_DELAY_WR;
-            wr.module = m;
-            wr.aux = it->second;
-            wr.state_row = -1;
-            for (int j = 0; j < kMaxIn; j++) wr.in_slot[j] = -1;
-            for (int j = 0; j < kMaxOut; j++) wr.out_slot[j] = -1;
-            for (int j = 0; j < kMaxPar; j++) wr.par_row[j] = -1;
-            wr.in_slot[0] = wire_of[{m, p}];
-            use_wire(wr.in_slot[0], (int)out.ops.size());
-            out.ops.push_back(wr);
-        }
-    }
-    if ((int)out.ops.size() > kMaxOps) {
-        set_error("flatten: patch needs more than " + std::to_string(kMaxOps) + " ops");
-        return SRACK_ERR_UNSUPPORTED;
-    }
-
-    // ---- rings: storage ---------------------------------------------------------------------
-    int n_global = 0;
-    for (Ring& r : rings) {
-        if (rings_in_lds) {
-            r.first_row = (int)b.rows.size();
-            for (int k = 0; k < B; k++) {  // zero-initialised buffer (synth.rs:31-33)
-                int row = b.new_row();
-                b.rows[(size_t)row].assign(n_voices, 0u);
-            }
-        } else {
-            r.global_id = n_global++;
-        }
-    }
-    for (DevOp& op : out.ops)
-        if (op.kind == OP_DELAY_RD || op.kind == OP_DELAY_WR) {
-            const Ring& r = rings[(size_t)op.aux];
-            if (rings_in_lds) {
-                op.aux = r.first_row;
-            } else {
-                op.aux = r.global_id;
-                op.flags |= DELAY_RING_GLOBAL;
-            }
-        }
-    H.n_rings = n_global;
-    H.n_state_rows = (int)b.rows.size();
-
-    // ---- per-voice parameter rows (read-only) -------------------------------------------------
-    for (auto& d : deferred) {
-        DevOp& op = out.ops[(size_t)(d.first / kMaxPar)];
-        int k = d.first % kMaxPar;
-        int r = b.new_row();
-        auto& row = b.rows[(size_t)r];
-        row.resize(n_voices);
-        for (uint32_t v = 0; v < n_voices; v++) row[v] = f32_bits((float)d.second->values[v]);
-        op.par_row[k] = r;
-    }
-    for (auto& d : deferred_delta) {
-        DevOp& op = out.ops[(size_t)d.first];
-        std::vector<double> delta(n_voices);
-        for (uint32_t v = 0; v < n_voices; v++) delta[v] = 440.0 * std::pow(2.0, (double)(float)d.second->values[v]) / op.sample_rate;
-        op.delta_row = b.rows_f64(&delta, 0.0);
-    }
-    H.n_rows = (int)b.rows.size();
-
-    // ---- 5. wire slots: linear scan -----------------------------------------------------------
-    {
-        std::vector<int> free_slots;
-        int n_slots = 0;
-        std::vector<std::vector<int>> expire(out.ops.size() + 1);
-        for (size_t w = 0; w < b.wires.size(); w++) expire[(size_t)b.wires[w].last_use].push_back((int)w);
-        std::vector<std::vector<int>> defs(out.ops.size());
-        for (size_t w = 0; w < b.wires.size(); w++) defs[(size_t)b.wires[w].def_op].push_back((int)w);
-        for (size_t i = 0; i < out.ops.size(); i++) {
-            for (int w : defs[i]) {  // outputs may not reuse this op's input slots: inputs stay live through the op
-                if (free_slots.empty()) {
-                    b.wires[(size_t)w].slot = n_slots++;
-                } else {
-                    b.wires[(size_t)w].slot = free_slots.back();
-                    free_slots.pop_back();
-                }
-            }
-            for (int w : expire[i]) free_slots.push_back(b.wires[(size_t)w].slot);
-        }
-        H.n_slots = n_slots;
-        for (DevOp& op : out.ops) {
-            for (int k = 0; k < kMaxIn; k++)
-                if (op.in_slot[k] >= 0) op.in_slot[k] = b.wires[(size_t)op.in_slot[k]].slot;
-            for (int k = 0; k < kMaxOut; k++)
-                if (op.out_slot[k] >= 0) op.out_slot[k] = b.wires[(size_t)op.out_slot[k]].slot;
-        }
-    }
-    H.n_ops = (int)out.ops.size();
-    H.n_planes = n_planes;
-
-    // ---- tile size from the LDS budget --------------------------------------------------------
-    {
-        int tile = kTileMax;
-        if (!rings.empty())
-            while (tile > B) tile >>= 1;  // a tile may not span more than one ring period
-        while (tile > 1 && (H.n_rows + H.n_slots * tile) * 256 > kLdsBudget) tile >>= 1;
-        if ((H.n_rows + H.n_slots * tile) * 256 > 64 * 1024) {
-            set_error("flatten: patch state does not fit the LDS budget of the tile interpreter");
-            return SRACK_ERR_UNSUPPORTED;
-        }
-        H.tile = tile;
-    }
-
-    // ---- voice table ----------------------------------------------------------------------------
-    out.table.resize((size_t)H.n_rows * n_voices);
-    for (int r = 0; r < H.n_rows; r++) std::memcpy(&out.table[(size_t)r * n_voices], b.rows[(size_t)r].data(), sizeof(uint32_t) * n_voices);
-
-    // ---- 6. fused-kernel pattern match ----------------------------------------------------------
-    if (!(render_flags & SRACK_RENDER_NO_FUSION)) {
-        // voice chain: {OSC_A, OSC_L, VCF, ADSR, VCA, OUT}, no CV/sync on the oscillators, no filter CV,
-        // VCF <- OSC_A, ADSR <- OSC_L, VCA <- (VCF, ADSR), one plane <- VCA, no rings
-        int n_kind[16] = {0};
-        for (const DevOp& op : out.ops) n_kind[op.kind]++;
-        if (rings.empty() && H.n_ops == 6 && n_kind[OP_OSC] == 2 && n_kind[OP_VCF] == 1 && n_kind[OP_ADSR] == 1 && n_kind[OP_VCA] == 1 &&
-            n_kind[OP_OUT] == 1) {
-            const DevOp *vcf = nullptr, *adsr = nullptr, *vca = nullptr, *outp = nullptr;
-            for (const DevOp& op : out.ops) {
-                if (op.kind == OP_VCF) vcf = &op;
-                if (op.kind == OP_ADSR) adsr = &op;
-                if (op.kind == OP_VCA) vca = &op;
-                if (op.kind == OP_OUT) outp = &op;
-            }
-            auto src_of = [&](int sink_module, int k) { return g.modules[(size_t)sink_module].in[(size_t)k]; };
-            const Module& mv = g.modules[(size_t)vca->module];
-            bool ok = vca->flags == (VCA_HAS_AUDIO | VCA_HAS_CV) && mv.in[0].src == vcf->module && mv.in[1].src == adsr->module &&
-                      src_of(outp->module, 0).src >= 0 && g.modules[(size_t)outp->module].in[0].src == vca->module &&
-                      (vcf->flags & (VCF_HAS_AUDIO | VCF_HAS_CV)) == VCF_HAS_AUDIO && (adsr->flags & ADSR_HAS_GATE);
-            if (ok) {
-                int osc_a = src_of(vcf->module, 0).src, osc_l = src_of(adsr->module, 0).src;
-                ok = osc_a != osc_l && g.modules[(size_t)osc_a].type == SRACK_MOD_OSCILLATOR && g.modules[(size_t)osc_l].type == SRACK_MOD_OSCILLATOR;
-                if (ok) {
-                    const DevOp& oa = out.ops[(size_t)out.op_of_module[(size_t)osc_a]];
-                    const DevOp& ol = out.ops[(size_t)out.op_of_module[(size_t)osc_l]];
-                    auto one_port = [](uint32_t f) { uint32_t m = f & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW); return m && !(m & (m - 1)); };
-                    auto one_vcf = [](uint32_t f) { uint32_t m = f & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP); return m && !(m & (m - 1)); };
-                    ok = !(oa.flags & (OSC_HAS_CV | OSC_HAS_SYNC)) && !(ol.flags & (OSC_HAS_CV | OSC_HAS_SYNC)) && one_port(oa.flags) && one_port(ol.flags) &&
-                         one_vcf(vcf->flags) && (oa.flags & OSC_AA) && (ol.flags & OSC_AA);
-                }
-            }
-            if (ok) {
-                // the fused kernel's constant-pitch oscillator needs delta < 0.25 (PolyBLEP windows must not overlap)
-                for (int role = 0; role < 2 && ok; role++) {
-                    const InputRef& in = role == 0 ? src_of(vcf->module, 0) : src_of(adsr->module, 0);
-                    const DevOp& o = out.ops[(size_t)out.op_of_module[(size_t)in.src]];
-                    if (o.delta_row >= 0) {
-                        for (uint32_t v = 0; v < n_voices && ok; v++) {
-                            uint64_t u = (uint64_t)out.table[(size_t)o.delta_row * n_voices + v] | ((uint64_t)out.table[(size_t)(o.delta_row + 1) * n_voices + v] << 32);
-                            double dlt;
-                            std::memcpy(&dlt, &u, 8);
-                            ok = dlt < 0.25;
-                        }
-                    } else {
-                        ok = o.delta < 0.25;
+    // ---- 3. voice-invariant sub-graph ----------------------------------------------------------------
+    if (n_voices > 1 && !(render_flags & SRACK_RENDER_NO_UNIFORM_HOIST)) {
+        std::vector<char>& u = A.in_ctl;
+        for (int m = 0; m < n_mod; m++) u[(size_t)m] = A.live[(size_t)m] && m != output;
+        for (const auto& o : overrides) u[(size_t)o.module] = 0;
+        const auto& pos = g.plan.position;
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (int m = 0; m < n_mod; m++) {
+                if (!A.live[(size_t)m]) continue;
+                for (const InputRef& in : g.modules[(size_t)m].in) {
+                    if (in.src < 0) continue;
+                    if (u[(size_t)m] && !u[(size_t)in.src]) {  // fed by something per-voice
+                        u[(size_t)m] = 0;
+                        changed = true;
+                    }
+                    // a per-voice module reading a uniform source through a broken (delayed) edge would need the
+                    // track's history across renders: keep such a source per-voice instead
+                    if (!u[(size_t)m] && u[(size_t)in.src] && pos[(size_t)in.src] > pos[(size_t)m]) {
+                        u[(size_t)in.src] = 0;
+                        changed = true;
                     }
                 }
             }
-            if (ok) out.fused = FUSED_VOICE_CHAIN;
         }
+        for (int m : g.plan.order) {
+            if (!A.live[(size_t)m] || u[(size_t)m]) continue;
+            for (const InputRef& in : g.modules[(size_t)m].in)
+                if (in.src >= 0 && u[(size_t)in.src] && !A.track_of.count({in.src, in.port})) {
+                    A.track_of[{in.src, in.port}] = (int)A.tracks.size();
+                    A.tracks.emplace_back(in.src, in.port);
+                }
+        }
+        if (A.tracks.empty()) std::fill(u.begin(), u.end(), 0);
     }
+    out.in_ctl = A.in_ctl;
+    out.n_tracks = (int)A.tracks.size();
 
+    if (out.n_tracks > 0) {
+        Builder bc{g, 1, kNoOverrides, render_flags, A, true, out.ctl, {}, {}};
+        int rc = bc.build();
+        if (rc != SRACK_OK) return rc;
+    }
+    Builder bv{g, n_voices, overrides, render_flags, A, false, out.voice, {}, {}};
+    int rc = bv.build();
+    if (rc != SRACK_OK) return rc;
     std::ostringstream d;
-    d << "ops=" << H.n_ops << " slots=" << H.n_slots << " rows=" << H.n_rows << " (state " << H.n_state_rows << ") planes=" << H.n_planes
-      << " rings=" << rings.size() << (rings.empty() ? "" : (rings_in_lds ? "(lds)" : "(hbm)")) << " tile=" << H.tile << " B=" << B
-      << " fused=" << out.fused;
+    d << out.voice.description;
+    if (out.n_tracks > 0) d << " + " << out.ctl.description << " tracks=" << out.n_tracks;
+    d << " B=" << g.cfg.buffer_size;
     out.description = d.str();
     return SRACK_OK;
 }

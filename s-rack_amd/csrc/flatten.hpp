@@ -16,8 +16,10 @@ struct VoiceOverride {  // per-voice values of one module field (srack_voices_se
 
 enum FusedKind : int {
     FUSED_NONE = 0,
-    FUSED_VOICE_CHAIN = 1,  // OSC -> VCF -> VCA, envelope = ADSR gated by an LFO OSC (patch P1's shape)
-    FUSED_FM_PAIR = 2       // OSC_M (z^-1 feedback through a Multiply) -> Multiply -> OSC_C (patch P2, B = 1)
+    FUSED_VOICE_CHAIN = 1,        // OSC -> VCF -> VCA, envelope = ADSR gated by an LFO OSC (patch P1's shape), all per voice
+    FUSED_VOICE_CHAIN_TRACK = 2,  // OSC -> VCF -> VCA, envelope read from a control track (P1 after uniform hoisting)
+    FUSED_FM_PAIR = 3,            // OSC_M (z^-1 feedback through a Multiply) -> Multiply -> OSC_C (patch P2, B = 1)
+    FUSED_CTL_GATE_ENV = 4        // control program {OSC -> ADSR -> track}: the voice-invariant half of P1
 };
 
 struct StateLoc {  // where a module's state field lives in the voice table
@@ -40,7 +42,18 @@ struct FlatProgram {
     StateLoc locate(const Graph& g, int module, int field) const;
 };
 
+// The flattened patch: the per-voice program and, when part of the graph is voice-invariant (no
+// per-voice override anywhere upstream), a control program that evaluates that part ONCE (one
+// voice) into control tracks [n_tracks][T] which the voice program reads with OP_TRACK_RD.
+struct FlatPair {
+    FlatProgram voice;
+    FlatProgram ctl;      // valid iff n_tracks > 0; its "planes" are the tracks
+    int n_tracks = 0;
+    std::vector<char> in_ctl;  // per module: evaluated by the control program
+    std::string description;
+};
+
 // Returns SRACK_OK or an error; on success `out` is complete.
-int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overrides, uint32_t render_flags, FlatProgram& out);
+int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overrides, uint32_t render_flags, FlatPair& out);
 
 }  // namespace srack

@@ -33,6 +33,8 @@ enum : uint32_t {
     OSC_OUT_SQUARE = 1u << 4,
     OSC_OUT_SAW = 1u << 5,
     OSC_EXACT = 1u << 6,      // f64 PolyBLEP / sin / pow exactly as the reference spells them
+    OSC_CONST_FAST = 1u << 7, // host-proved: no CV, no sync, one live port, PolyBLEP on, every voice's delta < 0.25
+                              // => the carried-phase oscillator (modules.hip.h, COsc) may be used
     // OP_VCF
     VCF_HAS_AUDIO = 1u << 0,
     VCF_HAS_CV = 1u << 1,

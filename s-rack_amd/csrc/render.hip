@@ -23,6 +23,7 @@
 //   mixpart f32 [planes][n_waves][T]  per-wave partial sums, T contiguous
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -39,12 +40,17 @@ struct KernelArgs {
     float* rings;
     float* frames;
     float* mixpart;
+    const float* tracks;  // control tracks [n_tracks][t_stride] written by the control program (may be null)
     uint32_t V, T, n_waves, pad_;
-    uint64_t n0;  // absolute index of this render's first sample
+    // A launch covers T samples of a render of t_stride samples; frames / mixpart / tracks arrive pre-offset to
+    // the launch's first sample and keep the whole render's strides.
+    uint64_t plane_stride;  // frames: elements between planes (= t_stride * V)
+    uint32_t t_stride, pad2_;
+    uint64_t n0;  // absolute index of this launch's first sample (phase of the feedback rings)
 };
 
-struct ChainRoles {  // op indices of the fused voice chain
-    int osc_a, osc_l, vcf, adsr, vca, out;
+struct ChainRoles {  // op indices of the fused voice chain (osc_l / adsr unused in the track variant)
+    int osc_a, osc_l, vcf, adsr, vca, out, track;
 };
 
 namespace dev {
@@ -80,6 +86,20 @@ __device__ __noinline__ void tile_osc(const Ctx& c, const DevOp& op)
     k.inv_dt = 1.0f / (float)k.delta;
     const int i_cv = op.in_slot[0], i_sync = op.in_slot[1];
     const int o_sine = op.out_slot[0], o_square = op.out_slot[1], o_saw = op.out_slot[2];
+    if (fl & OSC_CONST_FAST) {  // no CV, no sync, one live port, delta < 0.25 for every voice (host-checked)
+        COsc o;
+        cosc_init(o, s.pos, k.delta);
+        if (fl & OSC_OUT_SAW)
+            for (int i = 0; i < c.n; i++) WIRE(o_saw, i) = cosc_saw(o);
+        else if (fl & OSC_OUT_SQUARE)
+            for (int i = 0; i < c.n; i++) WIRE(o_square, i) = cosc_square(o);
+        else
+            for (int i = 0; i < c.n; i++) WIRE(o_sine, i) = cosc_sine(o);
+        ROW(sr + OSC_S_POS_LO) = f64_lo(o.pos);
+        ROW(sr + OSC_S_POS_HI) = f64_hi(o.pos);
+        ROW(sr + OSC_S_SYNC_LAST) = 0u;  // sync unconnected: `last` follows the constant 0.0 input
+        return;
+    }
     for (int i = 0; i < c.n; i++) {
         float cv = (fl & OSC_HAS_CV) ? WIRE(i_cv, i) : 0.0f;
         float sync = (fl & OSC_HAS_SYNC) ? WIRE(i_sync, i) : 0.0f;
@@ -155,9 +175,13 @@ __device__ __noinline__ void tile_adsr(const Ctx& c, const DevOp& op)
     s.gate_last = ROW(sr + ADSR_S_GATE_LAST) != 0;
     const AdsrConst k = adsr_consts(par(c, op, ADSR_P_A), par(c, op, ADSR_P_D), par(c, op, ADSR_P_S), par(c, op, ADSR_P_R), par(c, op, ADSR_P_SR));
     const int i_gate = op.in_slot[0], o = op.out_slot[0];
-    for (int i = 0; i < c.n; i++) {
-        float gate = (op.flags & ADSR_HAS_GATE) ? WIRE(i_gate, i) : 0.0f;
-        WIRE(o, i) = adsr_step(op.flags, s, k, gate);
+    if (op.flags & ADSR_HAS_GATE) {
+        AdsrSeg g;
+        adsr_seg_enter(s, k, g);
+        for (int i = 0; i < c.n; i++) WIRE(o, i) = adsr_seg_step(s, k, g, WIRE(i_gate, i));
+        adsr_seg_flush(s, g);
+    } else {
+        for (int i = 0; i < c.n; i++) WIRE(o, i) = adsr_step(op.flags, s, k, 0.0f);
     }
     ROW(sr + ADSR_S_PHASE) = __float_as_uint(s.phase);
     ROW(sr + ADSR_S_MODE) = (uint32_t)s.mode;
@@ -216,7 +240,7 @@ __device__ __noinline__ void tile_out(const Ctx& c, const DevOp& op, const Kerne
 {
     const int slot = op.in_slot[0], plane = op.aux;
     if (a.frames) {
-        float* f = a.frames + ((size_t)plane * a.T + t0) * a.V + voice;
+        float* f = a.frames + (size_t)plane * a.plane_stride + (size_t)t0 * a.V + voice;
         if (active)
             for (int i = 0; i < c.n; i++) f[(size_t)i * a.V] = WIRE(slot, i);
     }
@@ -225,9 +249,16 @@ __device__ __noinline__ void tile_out(const Ctx& c, const DevOp& op, const Kerne
             for (int i = 0; i < c.n; i++) WIRE(slot, i) = 0.0f;  // lanes past V contribute nothing
         __syncthreads();
         float sum = tile_row_sum(c.wires + (size_t)slot * c.tile * 64, c.tile, c.lane);
-        if (c.lane < c.n) a.mixpart[((size_t)plane * a.n_waves + blockIdx.x) * a.T + t0 + c.lane] = sum;
+        if (c.lane < c.n) a.mixpart[((size_t)plane * a.n_waves + blockIdx.x) * a.t_stride + t0 + c.lane] = sum;
         __syncthreads();
     }
+}
+
+__device__ __noinline__ void tile_track_rd(const Ctx& c, const DevOp& op, const KernelArgs& a, uint32_t t0)
+{
+    const float* trk = a.tracks + (size_t)op.aux * a.t_stride + t0;  // wave-uniform addresses: every lane gets the same sample
+    const int o = op.out_slot[0];
+    for (int i = 0; i < c.n; i++) WIRE(o, i) = trk[i];
 }
 
 __device__ __noinline__ void tile_delay_rd(const Ctx& c, const DevOp& op, const KernelArgs& a, uint64_t n_abs, uint32_t voice_c)
@@ -300,6 +331,7 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
             case OP_MIX: dev::tile_mix(c, op); break;
             case OP_MATH: dev::tile_math(c, op); break;
             case OP_OUT: dev::tile_out(c, op, a, t0, voice, active); break;
+            case OP_TRACK_RD: dev::tile_track_rd(c, op, a, t0); break;
             case OP_DELAY_RD: dev::tile_delay_rd(c, op, a, a.n0 + t0, voice_c); break;
             case OP_DELAY_WR: dev::tile_delay_wr(c, op, a, a.n0 + t0, voice, active); break;
             default: break;
@@ -310,11 +342,67 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
         for (int r = 0; r < a.prog.n_state_rows; r++) a.table[(size_t)r * a.V + voice] = c.rows[r * 64 + lane];
 }
 
-// ---- fused voice chain (patch P1's shape) -------------------------------------------------------------
-// OSC_A.<port> -> VCF.<port> -> VCA <- ADSR <- OSC_L.<port>; all wires and all state in VGPRs.
 constexpr int kMixRows = 32;
 
-template <uint32_t kOscAPort, uint32_t kOscLPort, uint32_t kVcfPort, bool kExact>
+// ---- per-sample output of the fused kernels ---------------------------------------------------------------
+// kOut: 0 = decide at run time (exact-mode kernels), 1 = frames only, 2 = mix only, 3 = frames + mix.
+// Frames: SGPR row base advanced by V per sample + a constant per-lane offset; lanes past V (only in the
+// last wave) shadow voice V-1, compute the identical sample and store it to the identical address, so the
+// store needs no exec mask.  Mix: the sample goes into a 32-row LDS tile; every 32 samples (and at the end)
+// the rows are summed over the 64 lanes (tile_row_sum) and one lane per row writes the wave's partial.
+struct Emit {
+    float* frame_row;   // wave-uniform
+    float* mp;          // wave-uniform: mixpart row of this wave
+    bool has_frames, has_mix, full_wave;
+    int lane, lane_c;
+    uint32_t n_active;  // lanes of this wave that are real voices
+};
+
+template <int kOut>
+SRK_DEV void emit_put(Emit& e, float* mix_tile, float o, int i, uint32_t V)  // i = row of the current 32-sample tile
+{
+    const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
+    const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
+    if (frames) {
+        e.frame_row[e.lane_c] = o;
+        e.frame_row += V;
+    }
+    if (mix) mix_tile[i * 64 + e.lane] = o;
+}
+
+template <int kOut>
+SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n)  // the tile holds samples t0 .. t0+n-1
+{
+    using dev::tile_row_sum;
+    const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
+    if (!mix) return;
+    if (!e.full_wave && (uint32_t)e.lane >= e.n_active)  // shadow lanes contribute nothing to the mix
+        for (int r = 0; r < kMixRows; r++) mix_tile[r * 64 + e.lane] = 0.0f;
+    __syncthreads();
+    const float sum = tile_row_sum(mix_tile, kMixRows, e.lane);
+    if (e.lane < n) e.mp[t0 + e.lane] = sum;
+    __syncthreads();
+}
+
+SRK_DEV Emit make_emit(const KernelArgs& a, int plane, int lane)
+{
+    Emit e;
+    const uint32_t wave0 = blockIdx.x * 64u;
+    e.n_active = min(64u, a.V - wave0);
+    e.full_wave = e.n_active == 64u;
+    e.lane = lane;
+    e.lane_c = min(lane, (int)e.n_active - 1);
+    e.frame_row = a.frames ? a.frames + (size_t)plane * a.plane_stride + wave0 : nullptr;
+    e.mp = a.mixpart ? a.mixpart + ((size_t)plane * a.n_waves + blockIdx.x) * a.t_stride : nullptr;
+    e.has_frames = e.frame_row != nullptr;
+    e.has_mix = e.mp != nullptr;
+    return e;
+}
+
+// ---- fused voice chain (patch P1's shape) -------------------------------------------------------------
+// OSC_A.<port> -> VCF.<port> -> VCA <- ADSR <- OSC_L.<port>; all wires and all state in VGPRs.
+
+template <uint32_t kOscAPort, uint32_t kOscLPort, uint32_t kVcfPort, bool kExact, int kOut>
 __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRoles r)
 {
     using namespace dev;
@@ -378,23 +466,26 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
     const AdsrConst kd = adsr_consts(parv(od, ADSR_P_A), parv(od, ADSR_P_D), parv(od, ADSR_P_S), parv(od, ADSR_P_R), parv(od, ADSR_P_SR));
     const bool negative = parv(oc, VCA_P_NEG) != 0.0f;
 
-    // frames: uniform base pointer advanced by V per sample + a constant per-lane offset => SGPR base, 0 VALU
-    float* frame_row = a.frames ? a.frames + (size_t)plane * a.T * V + (size_t)blockIdx.x * 64 : nullptr;
-    float* mp = a.mixpart ? a.mixpart + ((size_t)plane * a.n_waves + blockIdx.x) * a.T : nullptr;
-    const bool has_frames = frame_row != nullptr, has_mix = mp != nullptr;
+    Emit em = make_emit(a, plane, lane);
 
     COsc ca, cl;
     AdsrSeg seg;
+    float x = 0.0f, gate = 0.0f;
+    double pos_a = sa.pos, pos_l = sl.pos;  // oscillator phases after exactly t samples (the loop runs one sample ahead)
     if (!kExact) {
         cosc_init(ca, sa.pos, ka.delta);
         cosc_init(cl, sl.pos, kl.delta);
         adsr_seg_enter(sd, kd, seg);
+        if (a.T > 0) {  // software pipeline: the oscillators of sample t+1 are evaluated beside the filter of sample t
+            x = cosc_step<kOscAPort>(ca);
+            gate = cosc_step<kOscLPort>(cl);
+        }
     }
 
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
         for (int i = 0; i < n; i++) {
-            float x, gate, env;
+            float env, x_next = 0.0f, gate_next = 0.0f;
             if (kExact) {
                 float sine = 0.0f, square = 0.0f, saw = 0.0f;
                 osc_step(fa, sa, ka, 0.0f, 0.0f, sine, square, saw);
@@ -402,34 +493,32 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
                 float gs = 0.0f, gq = 0.0f, gw = 0.0f;
                 osc_step(fl, sl, kl, 0.0f, 0.0f, gs, gq, gw);
                 gate = kOscLPort == OSC_OUT_SINE ? gs : (kOscLPort == OSC_OUT_SQUARE ? gq : gw);
-            } else {
-                x = cosc_step<kOscAPort>(ca);
-                gate = cosc_step<kOscLPort>(cl);
             }
             float lp, bp, hp;
             vcf_step<!kExact>(sv, x, lp, bp, hp);
             const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
+            if (!kExact) {  // next sample's oscillators: same basic block as the filter chain above => they interleave
+                pos_a = ca.pos;
+                pos_l = cl.pos;
+                x_next = cosc_step<kOscAPort>(ca);
+                gate_next = cosc_step<kOscLPort>(cl);
+            }
             if (kExact)
                 env = adsr_step(ADSR_HAS_GATE, sd, kd, gate);
             else
                 env = adsr_seg_step(sd, kd, seg, gate);
             const float o = vca_step(VCA_HAS_AUDIO | VCA_HAS_CV, negative, y, env);
-            if (has_frames) {
-                if (active) frame_row[lane] = o;
-                frame_row += V;
+            emit_put<kOut>(em, mix_tile, o, i, V);
+            if (!kExact) {
+                x = x_next;
+                gate = gate_next;
             }
-            if (has_mix) mix_tile[i * 64 + lane] = active ? o : 0.0f;
         }
-        if (has_mix) {
-            __syncthreads();
-            float sum = tile_row_sum(mix_tile, kMixRows, lane);
-            if (lane < n) mp[t0 + lane] = sum;
-            __syncthreads();
-        }
+        emit_flush<kOut>(em, mix_tile, t0, n);
     }
     if (!kExact) {
-        sa.pos = ca.pos;
-        sl.pos = cl.pos;
+        sa.pos = pos_a;
+        sl.pos = pos_l;
         sa.sync_last = sl.sync_last = false;  // sync unconnected: `last` follows the constant 0.0 input
         adsr_seg_flush(sd, seg);
     }
@@ -458,6 +547,159 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
         put(od.state_row + ADSR_S_R_VAL, __float_as_uint(sd.r_val));
         put(od.state_row + ADSR_S_FROM_A, __float_as_uint(sd.from_a_val));
         put(od.state_row + ADSR_S_GATE_LAST, sd.gate_last ? 1u : 0u);
+    }
+}
+
+// ---- fused voice chain, envelope from a control track (P1 after uniform hoisting) ---------------------
+// OSC_A.<port> -> VCF.<port> -> VCA <- track[t]; the track sample is wave-uniform (scalar load, SGPR operand).
+// The loop body is one basic block: the filter chain of sample t interleaves with the oscillator of t+1.
+template <uint32_t kOscAPort, uint32_t kVcfPort, bool kExact, int kOut>
+__global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, ChainRoles r)
+{
+    using namespace dev;
+    __shared__ float mix_tile[kMixRows * 64];
+    const int lane = threadIdx.x;
+    const uint32_t voice = blockIdx.x * 64u + lane;
+    const bool active = voice < a.V;
+    const uint32_t vc = active ? voice : a.V - 1;
+    const uint32_t V = a.V;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+
+    const DevOp& oa = a.ops[r.osc_a];
+    const DevOp& ov = a.ops[r.vcf];
+    const DevOp& oc = a.ops[r.vca];
+    const int plane = a.ops[r.out].aux;
+    const float* __restrict__ env_track = a.tracks + (size_t)r.track * a.t_stride;
+
+    constexpr uint32_t fa = OSC_AA | kOscAPort | (kExact ? OSC_EXACT : 0u);
+    OscRegs sa;
+    OscConst ka;
+    sa.pos = make_f64(row(oa.state_row + OSC_S_POS_LO), row(oa.state_row + OSC_S_POS_HI));
+    sa.sync_last = row(oa.state_row + OSC_S_SYNC_LAST) != 0;
+    ka.sr = oa.sample_rate;
+    ka.val = 0.0;
+    ka.delta = oa.delta_row >= 0 ? make_f64(row(oa.delta_row), row(oa.delta_row + 1)) : oa.delta;
+    ka.inv_dt = 1.0f / (float)ka.delta;
+
+    VcfRegs sv;
+    const int s0 = ov.state_row;
+    sv.f = __uint_as_float(row(s0 + VCF_S_F));
+    sv.p = __uint_as_float(row(s0 + VCF_S_P));
+    sv.q = __uint_as_float(row(s0 + VCF_S_Q));
+    sv.b0 = __uint_as_float(row(s0 + VCF_S_B0 + 0));
+    sv.b1 = __uint_as_float(row(s0 + VCF_S_B0 + 1));
+    sv.b2 = __uint_as_float(row(s0 + VCF_S_B0 + 2));
+    sv.b3 = __uint_as_float(row(s0 + VCF_S_B0 + 3));
+    sv.b4 = __uint_as_float(row(s0 + VCF_S_B0 + 4));
+    sv.freq = __uint_as_float(row(s0 + VCF_S_FREQ));
+    sv.res = __uint_as_float(row(s0 + VCF_S_RES));
+    if (a.T > 0) vcf_coeffs(sv, vcf_frequency(parv(ov, VCF_P_FREQ), 0.0f, parv(ov, VCF_P_EXP)), vcf_resonance(parv(ov, VCF_P_RES)));
+    const bool negative = parv(oc, VCA_P_NEG) != 0.0f;
+
+    Emit em = make_emit(a, plane, lane);
+
+    COsc ca;
+    float x = 0.0f;
+    double pos_a = sa.pos;
+    if (!kExact) {
+        cosc_init(ca, sa.pos, ka.delta);
+        if (a.T > 0) x = cosc_step<kOscAPort>(ca);
+    }
+    // The envelope track is wave-uniform.  Lane l prefetches sample t0 + l of the NEXT 64-sample tile with one
+    // coalesced load while the current tile is consumed through v_readlane (SGPR operand): no per-sample memory wait.
+    float env_tile = env_track[min((uint32_t)(lane & (kMixRows - 1)), a.T - 1)];
+    for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
+        const float env_next = env_track[min(t0 + kMixRows + (uint32_t)(lane & (kMixRows - 1)), a.T - 1)];
+        const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+        for (int i = 0; i < n; i++) {
+            const float env = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(env_tile), i));
+            if (kExact) {
+                float sine = 0.0f, square = 0.0f, saw = 0.0f;
+                osc_step(fa, sa, ka, 0.0f, 0.0f, sine, square, saw);
+                x = kOscAPort == OSC_OUT_SINE ? sine : (kOscAPort == OSC_OUT_SQUARE ? square : saw);
+            }
+            float lp, bp, hp;
+            vcf_step<!kExact>(sv, x, lp, bp, hp);
+            const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
+            if (!kExact) {
+                pos_a = ca.pos;
+                x = cosc_step<kOscAPort>(ca);  // sample t+1
+            }
+            const float o = vca_step(VCA_HAS_AUDIO | VCA_HAS_CV, negative, y, env);
+            emit_put<kOut>(em, mix_tile, o, i, V);
+        }
+        emit_flush<kOut>(em, mix_tile, t0, n);
+        env_tile = env_next;
+    }
+    if (!kExact) {
+        sa.pos = pos_a;
+        sa.sync_last = false;
+    }
+    if (active) {
+        auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+        put(oa.state_row + OSC_S_POS_LO, f64_lo(sa.pos));
+        put(oa.state_row + OSC_S_POS_HI, f64_hi(sa.pos));
+        put(oa.state_row + OSC_S_SYNC_LAST, sa.sync_last ? 1u : 0u);
+        put(s0 + VCF_S_F, __float_as_uint(sv.f));
+        put(s0 + VCF_S_P, __float_as_uint(sv.p));
+        put(s0 + VCF_S_Q, __float_as_uint(sv.q));
+        put(s0 + VCF_S_B0 + 0, __float_as_uint(sv.b0));
+        put(s0 + VCF_S_B0 + 1, __float_as_uint(sv.b1));
+        put(s0 + VCF_S_B0 + 2, __float_as_uint(sv.b2));
+        put(s0 + VCF_S_B0 + 3, __float_as_uint(sv.b3));
+        put(s0 + VCF_S_B0 + 4, __float_as_uint(sv.b4));
+        put(s0 + VCF_S_FREQ, __float_as_uint(sv.freq));
+        put(s0 + VCF_S_RES, __float_as_uint(sv.res));
+    }
+}
+
+// ---- fused control chain: OSC (constant pitch) -> ADSR -> track ---------------------------------------------
+// The voice-invariant half of patch P1's shape: one voice, one wave, every lane computes the same numbers.
+// It is a pure latency chain (phase accumulate -> gate -> envelope state machine), so it is kept short: state
+// in VGPRs, the carried-phase oscillator and the segmented ADSR, 64 samples gathered across lanes per store.
+template <uint32_t kOscPort>
+__global__ __launch_bounds__(64) void render_ctl_gate_env(KernelArgs a, ChainRoles r)
+{
+    using namespace dev;
+    const int lane = threadIdx.x;
+    auto row = [&](int rr) { return a.table[rr]; };  // V == 1
+    const DevOp& ol = a.ops[r.osc_l];
+    const DevOp& od = a.ops[r.adsr];
+    float* __restrict__ track = a.frames + (size_t)a.ops[r.out].aux * a.plane_stride;
+
+    COsc cl;
+    cosc_init(cl, make_f64(row(ol.state_row + OSC_S_POS_LO), row(ol.state_row + OSC_S_POS_HI)), ol.delta);
+    AdsrRegs sd;
+    sd.phase = __uint_as_float(row(od.state_row + ADSR_S_PHASE));
+    sd.mode = (int)row(od.state_row + ADSR_S_MODE);
+    sd.r_val = __uint_as_float(row(od.state_row + ADSR_S_R_VAL));
+    sd.from_a_val = __uint_as_float(row(od.state_row + ADSR_S_FROM_A));
+    sd.gate_last = row(od.state_row + ADSR_S_GATE_LAST) != 0;
+    const AdsrConst kd = adsr_consts(od.par_val[ADSR_P_A], od.par_val[ADSR_P_D], od.par_val[ADSR_P_S], od.par_val[ADSR_P_R], od.par_val[ADSR_P_SR]);
+    AdsrSeg seg;
+    adsr_seg_enter(sd, kd, seg);
+
+    for (uint32_t t0 = 0; t0 < a.T; t0 += 64) {
+        const int n = (int)min(64u, a.T - t0);
+        float keep_v = 0.0f;  // lane j keeps sample t0 + j
+        for (int j = 0; j < n; j++) {
+            const float gate = cosc_step<kOscPort>(cl);
+            const float env = adsr_seg_step(sd, kd, seg, gate);
+            keep_v = lane == j ? env : keep_v;
+        }
+        if (lane < n) track[t0 + lane] = keep_v;
+    }
+    adsr_seg_flush(sd, seg);
+    if (lane == 0) {
+        a.table[ol.state_row + OSC_S_POS_LO] = f64_lo(cl.pos);
+        a.table[ol.state_row + OSC_S_POS_HI] = f64_hi(cl.pos);
+        a.table[ol.state_row + OSC_S_SYNC_LAST] = 0u;
+        a.table[od.state_row + ADSR_S_PHASE] = __float_as_uint(sd.phase);
+        a.table[od.state_row + ADSR_S_MODE] = (uint32_t)sd.mode;
+        a.table[od.state_row + ADSR_S_R_VAL] = __float_as_uint(sd.r_val);
+        a.table[od.state_row + ADSR_S_FROM_A] = __float_as_uint(sd.from_a_val);
+        a.table[od.state_row + ADSR_S_GATE_LAST] = sd.gate_last ? 1u : 0u;
     }
 }
 
@@ -512,30 +754,50 @@ __global__ void fill_zero(float* p, size_t n)
         }                                                                                               \
     } while (0)
 
-struct DeviceState {
+struct DevProg {  // device copy of one FlatProgram
     DevOp* d_ops = nullptr;
     uint32_t* d_table = nullptr;
     float* d_rings = nullptr;
+    void release()
+    {
+        (void)hipFree(d_ops);
+        (void)hipFree(d_table);
+        (void)hipFree(d_rings);
+        d_ops = nullptr;
+        d_table = nullptr;
+        d_rings = nullptr;
+    }
+};
+
+struct DeviceState {
+    DevProg voice, ctl;
     float* d_mixpart = nullptr;
     size_t mixpart_bytes = 0;
-    size_t rings_bytes = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timings;  // (start, stop) pairs not yet read
+    float* d_tracks = nullptr;
+    size_t tracks_bytes = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timings;  // (start, stop) pairs of the dominant kernel, not yet read
     std::vector<hipEvent_t> pool;
     const char* kernel_name = "";
+    hipStream_t ctl_stream = nullptr;      // the control program runs ahead of the voice kernels on its own stream
+    hipEvent_t ev_begin = nullptr;         // render start on the caller's stream
+    std::vector<hipEvent_t> ev_chunk;      // control chunk k finished
 };
 
 void device_release(DeviceState* d)
 {
     if (!d) return;
-    (void)hipFree(d->d_ops);
-    (void)hipFree(d->d_table);
-    (void)hipFree(d->d_rings);
+    d->voice.release();
+    d->ctl.release();
     (void)hipFree(d->d_mixpart);
+    (void)hipFree(d->d_tracks);
     for (auto& p : d->timings) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
     }
     for (auto e : d->pool) (void)hipEventDestroy(e);
+    for (auto e : d->ev_chunk) (void)hipEventDestroy(e);
+    if (d->ev_begin) (void)hipEventDestroy(d->ev_begin);
+    if (d->ctl_stream) (void)hipStreamDestroy(d->ctl_stream);
     delete d;
 }
 
@@ -552,74 +814,133 @@ int ensure_program(PatchHandle& h, uint32_t flags)
     h.prog_voices_revision = h.voices_revision;
     h.prog_flags = flags;
     h.samples_rendered = 0;
-    // device copies are refreshed lazily by device_render
-    if (h.dev) {
+    if (h.dev) {  // device copies are rebuilt lazily by device_render
         device_release(h.dev);
         h.dev = nullptr;
     }
     return SRACK_OK;
 }
 
-static int upload_program(PatchHandle& h)
+static int upload_one(const FlatProgram& P, DevProg& d)
 {
-    auto* d = new DeviceState();
-    h.dev = d;
-    const FlatProgram& P = h.prog;
     if (!P.ops.empty()) {
-        HIP_TRY(hipMalloc(&d->d_ops, sizeof(DevOp) * P.ops.size()));
-        HIP_TRY(hipMemcpy(d->d_ops, P.ops.data(), sizeof(DevOp) * P.ops.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&d.d_ops, sizeof(DevOp) * P.ops.size()));
+        HIP_TRY(hipMemcpy(d.d_ops, P.ops.data(), sizeof(DevOp) * P.ops.size(), hipMemcpyHostToDevice));
     }
     if (!P.table.empty()) {
-        HIP_TRY(hipMalloc(&d->d_table, sizeof(uint32_t) * P.table.size()));
-        HIP_TRY(hipMemcpy(d->d_table, P.table.data(), sizeof(uint32_t) * P.table.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&d.d_table, sizeof(uint32_t) * P.table.size()));
+        HIP_TRY(hipMemcpy(d.d_table, P.table.data(), sizeof(uint32_t) * P.table.size(), hipMemcpyHostToDevice));
     }
     if (P.hdr.n_rings > 0) {
-        d->rings_bytes = sizeof(float) * (size_t)P.hdr.n_rings * (size_t)P.hdr.buffer_size * P.n_voices;
-        HIP_TRY(hipMalloc(&d->d_rings, d->rings_bytes));
-        HIP_TRY(hipMemset(d->d_rings, 0, d->rings_bytes));  // AudioBuffer::new fills 0.0 (synth.rs:31-33)
+        size_t bytes = sizeof(float) * (size_t)P.hdr.n_rings * (size_t)P.hdr.buffer_size * P.n_voices;
+        HIP_TRY(hipMalloc(&d.d_rings, bytes));
+        HIP_TRY(hipMemset(d.d_rings, 0, bytes));  // AudioBuffer::new fills 0.0 (synth.rs:31-33)
     }
     return SRACK_OK;
 }
 
-template <uint32_t A, uint32_t F, bool E>
-static void launch_chain(uint32_t lfo_port, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
+static int upload_program(PatchHandle& h)
 {
-    if (lfo_port == OSC_OUT_SQUARE)
-        hipLaunchKernelGGL((render_voice_chain<A, OSC_OUT_SQUARE, F, E>), grid, dim3(64), 0, st, ka, roles);
-    else if (lfo_port == OSC_OUT_SAW)
-        hipLaunchKernelGGL((render_voice_chain<A, OSC_OUT_SAW, F, E>), grid, dim3(64), 0, st, ka, roles);
-    else
-        hipLaunchKernelGGL((render_voice_chain<A, OSC_OUT_SINE, F, E>), grid, dim3(64), 0, st, ka, roles);
+    h.dev = new DeviceState();
+    int rc = upload_one(h.prog.voice, h.dev->voice);
+    if (rc == SRACK_OK && h.prog.n_tracks > 0) rc = upload_one(h.prog.ctl, h.dev->ctl);
+    return rc;
 }
 
-template <uint32_t A, bool E>
-static void launch_chain_f(uint32_t vcf_port, uint32_t lfo_port, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
+static int grow(float*& p, size_t& have, size_t need)
+{
+    if (need <= have) return SRACK_OK;
+    (void)hipFree(p);
+    p = nullptr;
+    have = 0;
+    HIP_TRY(hipMalloc(&p, need));
+    have = need;
+    return SRACK_OK;
+}
+
+// ---- fused-kernel dispatch (template parameters from runtime port flags) ---------------------------
+template <uint32_t A, uint32_t F, bool E, int O>
+static void launch_fused4(bool track, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
+{
+    // 8 KiB static mix tile + kLdsPad dynamic = 10 KiB per single-wave workgroup: at most 16 workgroups fit a CU's
+    // 160 KiB, i.e. exactly 4 waves per SIMD.  Without the pad the dispatcher packs up to 20 waves on some CUs and
+    // leaves others short; the over-full CUs then finish last (measured: waves alive only 63 % of the kernel).
+    constexpr size_t kLdsPad = 2048;
+    if (track)
+        hipLaunchKernelGGL((render_voice_chain_track<A, F, E, O>), grid, dim3(64), kLdsPad, st, ka, roles);
+    else
+        hipLaunchKernelGGL((render_voice_chain<A, OSC_OUT_SQUARE, F, E, O>), grid, dim3(64), kLdsPad, st, ka, roles);
+}
+
+template <uint32_t A, uint32_t F>
+static void launch_fused3(bool exact, int out_mode, bool track, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
+{
+    if (exact)  // exact mode is the validation flavour: one instantiation, output mode decided at run time
+        launch_fused4<A, F, true, 0>(track, ka, roles, grid, st);
+    else if (out_mode == 3)
+        launch_fused4<A, F, false, 3>(track, ka, roles, grid, st);
+    else if (out_mode == 1)
+        launch_fused4<A, F, false, 1>(track, ka, roles, grid, st);
+    else
+        launch_fused4<A, F, false, 2>(track, ka, roles, grid, st);
+}
+
+template <uint32_t A>
+static void launch_fused2(uint32_t vcf_port, bool exact, int out_mode, bool track, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
 {
     if (vcf_port == VCF_OUT_LP)
-        launch_chain<A, VCF_OUT_LP, E>(lfo_port, ka, roles, grid, st);
+        launch_fused3<A, VCF_OUT_LP>(exact, out_mode, track, ka, roles, grid, st);
     else if (vcf_port == VCF_OUT_BP)
-        launch_chain<A, VCF_OUT_BP, E>(lfo_port, ka, roles, grid, st);
+        launch_fused3<A, VCF_OUT_BP>(exact, out_mode, track, ka, roles, grid, st);
     else
-        launch_chain<A, VCF_OUT_HP, E>(lfo_port, ka, roles, grid, st);
+        launch_fused3<A, VCF_OUT_HP>(exact, out_mode, track, ka, roles, grid, st);
 }
 
-template <bool E>
-static void launch_chain_a(uint32_t osc_port, uint32_t vcf_port, uint32_t lfo_port, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
+static void launch_fused(uint32_t osc_port, uint32_t vcf_port, bool exact, int out_mode, bool track, const KernelArgs& ka, const ChainRoles& roles, dim3 grid,
+                         hipStream_t st)
 {
     if (osc_port == OSC_OUT_SAW)
-        launch_chain_f<OSC_OUT_SAW, E>(vcf_port, lfo_port, ka, roles, grid, st);
+        launch_fused2<OSC_OUT_SAW>(vcf_port, exact, out_mode, track, ka, roles, grid, st);
     else if (osc_port == OSC_OUT_SQUARE)
-        launch_chain_f<OSC_OUT_SQUARE, E>(vcf_port, lfo_port, ka, roles, grid, st);
+        launch_fused2<OSC_OUT_SQUARE>(vcf_port, exact, out_mode, track, ka, roles, grid, st);
     else
-        launch_chain_f<OSC_OUT_SINE, E>(vcf_port, lfo_port, ka, roles, grid, st);
+        launch_fused2<OSC_OUT_SINE>(vcf_port, exact, out_mode, track, ka, roles, grid, st);
 }
 
+static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_t st)
+{
+    size_t lds = ((size_t)P.hdr.n_rows + (size_t)P.hdr.n_slots * P.hdr.tile) * 256;
+    hipLaunchKernelGGL(render_interp, dim3(ka.n_waves), dim3(64), lds, st, ka);
+}
+
+static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t st)
+{
+    if (Cp.fused == FUSED_CTL_GATE_ENV) {
+        ChainRoles roles{};
+        roles.osc_l = 0;
+        roles.adsr = 1;
+        roles.out = 2;
+        const uint32_t port = Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
+        if (port == OSC_OUT_SQUARE)
+            hipLaunchKernelGGL((render_ctl_gate_env<OSC_OUT_SQUARE>), dim3(1), dim3(64), 0, st, kc, roles);
+        else if (port == OSC_OUT_SAW)
+            hipLaunchKernelGGL((render_ctl_gate_env<OSC_OUT_SAW>), dim3(1), dim3(64), 0, st, kc, roles);
+        else
+            hipLaunchKernelGGL((render_ctl_gate_env<OSC_OUT_SINE>), dim3(1), dim3(64), 0, st, kc, roles);
+    } else {
+        launch_interp(Cp, kc, st);
+    }
+}
+
+// How a render is scheduled.  Without a control program: one launch of the voice kernel.  With one: the
+// render is cut into chunks; control chunk k (one wave, a latency chain) runs on its own stream and voice
+// chunk k waits only for it, so all but the first control chunk hide behind voice kernels of earlier chunks.
 int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_mix, uint32_t flags, void* stream)
 {
     int rc = ensure_program(h, flags);
     if (rc != SRACK_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const FlatProgram& P = h.prog;
+    const FlatProgram& P = h.prog.voice;
     const uint32_t V = P.n_voices, T = n_samples, C = (uint32_t)P.hdr.n_channels;
     if (T == 0) return SRACK_OK;
     if (!h.dev) {
@@ -637,29 +958,12 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         h.samples_rendered += T;
         return SRACK_OK;
     }
-    if (d_mix) {
-        size_t need = sizeof(float) * (size_t)P.hdr.n_planes * n_waves * T;
-        if (need > d->mixpart_bytes) {
-            (void)hipFree(d->d_mixpart);
-            d->d_mixpart = nullptr;
-            d->mixpart_bytes = 0;
-            HIP_TRY(hipMalloc(&d->d_mixpart, need));
-            d->mixpart_bytes = need;
-        }
-    }
-    KernelArgs ka{};
-    ka.ops = d->d_ops;
-    ka.prog = P.hdr;
-    ka.table = d->d_table;
-    ka.rings = d->d_rings;
-    ka.frames = d_frames;
-    ka.mixpart = d_mix ? d->d_mixpart : nullptr;
-    ka.V = V;
-    ka.T = T;
-    ka.n_waves = n_waves;
-    ka.n0 = h.samples_rendered;
+    if (d_mix && (rc = grow(d->d_mixpart, d->mixpart_bytes, sizeof(float) * (size_t)P.hdr.n_planes * n_waves * T)) != SRACK_OK) return rc;
 
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool has_ctl = h.prog.n_tracks > 0;
+    constexpr uint32_t kChunk = 6144;  // samples per chunk (a multiple of every tile size): ~0.1 s of audio
+    const uint32_t n_chunks = has_ctl ? (T + kChunk - 1) / kChunk : 1;
+    const uint32_t chunk_len = has_ctl ? kChunk : T;
     auto get_event = [&](hipEvent_t& e) -> int {
         if (!d->pool.empty()) {
             e = d->pool.back();
@@ -669,41 +973,96 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         HIP_TRY(hipEventCreate(&e));
         return SRACK_OK;
     };
-    if ((rc = get_event(e0)) != SRACK_OK || (rc = get_event(e1)) != SRACK_OK) return rc;
-    HIP_TRY(hipEventRecord(e0, st));
 
-    if (P.fused == FUSED_VOICE_CHAIN) {
-        ChainRoles roles{};
-        uint32_t osc_port = 0, lfo_port = 0, vcf_port = 0;
+    if (has_ctl) {
+        if ((rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
+        if (!d->ctl_stream) HIP_TRY(hipStreamCreateWithFlags(&d->ctl_stream, hipStreamNonBlocking));
+        if (!d->ev_begin) HIP_TRY(hipEventCreateWithFlags(&d->ev_begin, hipEventDisableTiming));
+        while (d->ev_chunk.size() < n_chunks) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            d->ev_chunk.push_back(e);
+        }
+        // the track buffer may still be read by the previous render on `st`: start after it
+        HIP_TRY(hipEventRecord(d->ev_begin, st));
+        HIP_TRY(hipStreamWaitEvent(d->ctl_stream, d->ev_begin, 0));
+        const FlatProgram& Cp = h.prog.ctl;
+        for (uint32_t k = 0; k < n_chunks; k++) {
+            const uint32_t t_off = k * chunk_len, len = std::min(chunk_len, T - t_off);
+            KernelArgs kc{};
+            kc.ops = d->ctl.d_ops;
+            kc.prog = Cp.hdr;
+            kc.table = d->ctl.d_table;
+            kc.rings = d->ctl.d_rings;
+            kc.frames = d->d_tracks + t_off;  // the control program's planes are the tracks: [n_tracks][T][1]
+            kc.plane_stride = T;
+            kc.t_stride = T;
+            kc.V = 1;
+            kc.T = len;
+            kc.n_waves = 1;
+            kc.n0 = h.samples_rendered + t_off;
+            launch_ctl(Cp, kc, d->ctl_stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(d->ev_chunk[k], d->ctl_stream));
+        }
+    }
+
+    ChainRoles roles{};
+    uint32_t osc_port = 0, vcf_port = 0;
+    const bool fused = P.fused == FUSED_VOICE_CHAIN || P.fused == FUSED_VOICE_CHAIN_TRACK;
+    const bool track = P.fused == FUSED_VOICE_CHAIN_TRACK;
+    if (fused) {
         for (int i = 0; i < (int)P.ops.size(); i++) {
             const DevOp& op = P.ops[(size_t)i];
             if (op.kind == OP_VCF) { roles.vcf = i; vcf_port = op.flags & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP); }
             if (op.kind == OP_ADSR) roles.adsr = i;
             if (op.kind == OP_VCA) roles.vca = i;
             if (op.kind == OP_OUT) roles.out = i;
+            if (op.kind == OP_TRACK_RD) roles.track = op.aux;
         }
         const Graph& g = h.graph;
         roles.osc_a = P.op_of_module[(size_t)g.modules[(size_t)P.ops[(size_t)roles.vcf].module].in[0].src];
-        roles.osc_l = P.op_of_module[(size_t)g.modules[(size_t)P.ops[(size_t)roles.adsr].module].in[0].src];
+        if (!track) roles.osc_l = P.op_of_module[(size_t)g.modules[(size_t)P.ops[(size_t)roles.adsr].module].in[0].src];
         osc_port = P.ops[(size_t)roles.osc_a].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
-        lfo_port = P.ops[(size_t)roles.osc_l].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
-        if (flags & SRACK_RENDER_EXACT_OSC)
-            launch_chain_a<true>(osc_port, vcf_port, lfo_port, ka, roles, dim3(n_waves), st);
-        else
-            launch_chain_a<false>(osc_port, vcf_port, lfo_port, ka, roles, dim3(n_waves), st);
-        d->kernel_name = "render_voice_chain";
+        d->kernel_name = track ? "render_voice_chain_track" : "render_voice_chain";
     } else {
-        size_t lds = ((size_t)P.hdr.n_rows + (size_t)P.hdr.n_slots * P.hdr.tile) * 256;
-        hipLaunchKernelGGL(render_interp, dim3(n_waves), dim3(64), lds, st, ka);
         d->kernel_name = "render_interp";
     }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, st));
-    d->timings.emplace_back(e0, e1);
-    if (d->timings.size() > 4096) {  // nobody is reading them: recycle the oldest
-        d->pool.push_back(d->timings.front().first);
-        d->pool.push_back(d->timings.front().second);
-        d->timings.erase(d->timings.begin());
+
+    for (uint32_t k = 0; k < n_chunks; k++) {
+        const uint32_t t_off = k * chunk_len, len = std::min(chunk_len, T - t_off);
+        KernelArgs ka{};
+        ka.ops = d->voice.d_ops;
+        ka.prog = P.hdr;
+        ka.table = d->voice.d_table;
+        ka.rings = d->voice.d_rings;
+        ka.frames = d_frames ? d_frames + (size_t)t_off * V : nullptr;
+        ka.mixpart = d_mix ? d->d_mixpart + t_off : nullptr;
+        ka.tracks = has_ctl ? d->d_tracks + t_off : nullptr;
+        ka.plane_stride = (uint64_t)T * V;
+        ka.t_stride = T;
+        ka.V = V;
+        ka.T = len;
+        ka.n_waves = n_waves;
+        ka.n0 = h.samples_rendered + t_off;
+        if (has_ctl) HIP_TRY(hipStreamWaitEvent(st, d->ev_chunk[k], 0));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if ((rc = get_event(e0)) != SRACK_OK || (rc = get_event(e1)) != SRACK_OK) return rc;
+        HIP_TRY(hipEventRecord(e0, st));
+        if (fused) {
+            const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
+            if (out_mode != 0) launch_fused(osc_port, vcf_port, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, track, ka, roles, dim3(n_waves), st);
+        } else {
+            launch_interp(P, ka, st);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e1, st));
+        d->timings.emplace_back(e0, e1);
+        if (d->timings.size() > 4096) {  // nobody is reading them: recycle the oldest
+            d->pool.push_back(d->timings.front().first);
+            d->pool.push_back(d->timings.front().second);
+            d->timings.erase(d->timings.begin());
+        }
     }
 
     if (d_mix) {
@@ -746,14 +1105,17 @@ int device_kernel_ms(PatchHandle& h, double* avg_ms, int* n_launches, int reset)
     return SRACK_OK;
 }
 
-int device_read_rows(PatchHandle& h, int first_row, int n_rows, uint32_t* host_dst)
+// rows of the voice program's table (ctl = false) or of the control program's one-voice table
+int device_read_rows(PatchHandle& h, bool ctl, int first_row, int n_rows, uint32_t* host_dst)
 {
-    const size_t V = h.prog.n_voices;
-    if (h.dev && h.dev->d_table) {
+    const FlatProgram& P = ctl ? h.prog.ctl : h.prog.voice;
+    const size_t V = P.n_voices;
+    const uint32_t* d_table = h.dev ? (ctl ? h.dev->ctl.d_table : h.dev->voice.d_table) : nullptr;
+    if (d_table) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(host_dst, h.dev->d_table + (size_t)first_row * V, sizeof(uint32_t) * V * (size_t)n_rows, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(host_dst, d_table + (size_t)first_row * V, sizeof(uint32_t) * V * (size_t)n_rows, hipMemcpyDeviceToHost));
     } else {  // nothing rendered yet: the initial table
-        std::memcpy(host_dst, h.prog.table.data() + (size_t)first_row * V, sizeof(uint32_t) * V * (size_t)n_rows);
+        std::memcpy(host_dst, P.table.data() + (size_t)first_row * V, sizeof(uint32_t) * V * (size_t)n_rows);
     }
     return SRACK_OK;
 }

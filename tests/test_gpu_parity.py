@@ -37,7 +37,10 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-MODES = [pytest.param(0, id="fused"), pytest.param(2, id="interp"), pytest.param(1, id="fused-exact"), pytest.param(3, id="interp-exact")]
+# render flags: 1 exact oscillator, 2 no fused kernels (tile interpreter), 4 no uniform hoisting (everything per voice)
+MODES = [pytest.param(0, id="fused"), pytest.param(2, id="interp"), pytest.param(1, id="fused-exact"), pytest.param(3, id="interp-exact"),
+         pytest.param(4, id="fused-nohoist"), pytest.param(6, id="interp-nohoist"), pytest.param(5, id="fused-exact-nohoist")]
+FAST_MODES = [pytest.param(0, id="fused"), pytest.param(2, id="interp"), pytest.param(4, id="fused-nohoist"), pytest.param(6, id="interp-nohoist")]
 
 
 # ---- the reference's oscillator test, through the whole GPU path --------------------------------
@@ -67,7 +70,7 @@ def test_cfg1_golden(S, adsr, flags):
     S.build_p1(p, adsr=adsr)
     p.configure_voices(1)
     out = p.render_channels(48000, flags)
-    assert ("fused=1" in p.info()) == (not flags & 2)
+    assert ("fused=1" in p.info()) == (not flags & 2)  # one voice: nothing is hoisted
     assert ("kernel=render_interp" in p.info()) == bool(flags & 2)
     if flags & 1:  # exact oscillator: saw and square are pure f64 arithmetic => the whole chain is bit-identical
         np.testing.assert_array_equal(bits(out[0, :, 0]), bits(gold))
@@ -94,7 +97,7 @@ def test_cfg3_golden_voices(S, flags):
         assert_close(out, gold)
 
 
-@pytest.mark.parametrize("flags", [pytest.param(0, id="fused"), pytest.param(2, id="interp")])
+@pytest.mark.parametrize("flags", FAST_MODES)
 @pytest.mark.parametrize("V", [1, 63, 64, 65, 300])
 def test_p1_voices_vs_oracle_and_mix(S, oracle, V, flags):
     T = 6000
@@ -109,6 +112,8 @@ def test_p1_voices_vs_oracle_and_mix(S, oracle, V, flags):
     p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
     fr, mix = p.render(T, frames=True, mix=True, flags=flags)
     assert fr.shape == (1, T, V)
+    want = "render_interp" if flags & 2 else ("render_voice_chain" if (flags & 4 or V == 1) else "render_voice_chain_track")
+    assert p.info().endswith("kernel=" + want), p.info()
     assert_close(fr[0], ref[0])
     # mix-down: sum over voices, checked against the f64 sum of the GPU's own frames and of the oracle's
     own = fr[0].astype(np.float64).sum(axis=1)
@@ -247,7 +252,7 @@ def test_quirks_on_gpu(S, oracle):
 
 
 # ---- properties that do not need the oracle -----------------------------------------------------------------
-@pytest.mark.parametrize("flags", [pytest.param(0, id="fused"), pytest.param(2, id="interp")])
+@pytest.mark.parametrize("flags", FAST_MODES)
 def test_render_continues_from_state(S, flags):
     """execute() carries state between calls: render(T) == render(a) ++ render(T - a), bit for bit."""
     V, T = 200, 5000

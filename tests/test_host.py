@@ -161,22 +161,38 @@ def test_flatten_descriptions(S):
     p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
     p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
     info = p.info()
-    assert "ops=6" in info and "planes=1" in info and "fused=1" in info and "rings=0" in info
+    # uniform hoisting: LFO + ADSR carry no per-voice value => control program (3 ops: OSC, ADSR, track out);
+    # the voice program keeps TRACK_RD, OSC_A, VCF, VCA, OUT and matches the fused track kernel
+    assert "voice[ops=5" in info and "fused=2" in info and "ctl[ops=3" in info and "tracks=1" in info
     assert p.planes() == (1, [0, 0])
-    # dead-port elimination: only saw / square / lowpass are live
+    # one voice: nothing to share, the all-per-voice fused kernel
+    q = S.Patch(48000, 1024, 2)
+    S.build_p1(q)
+    q.configure_voices(1)
+    assert "voice[ops=6" in q.info() and "fused=1" in q.info() and "ctl[" not in q.info()
+    # identical voices: everything is voice-invariant; the voice program only broadcasts the track
+    q = S.Patch(48000, 1024, 2)
+    S.build_p1(q)
+    q.configure_voices(4096)
+    assert "voice[ops=2" in q.info() and "ctl[ops=6" in q.info()
+    # feedback patch, per-voice beta: the whole loop is per voice; B = 1 => ring in LDS rows, tile of 1
     q = S.Patch(48000, 1, 2)
-    S.build_p2(q)
+    ids2 = S.build_p2(q)
     q.configure_voices(64)
-    assert "rings=1(lds)" in q.info() and "tile=1" in q.info()
+    q.set_voice_field(ids2["mul_fb"], S.MATH_CONSTANT, np.linspace(0.1, 0.4, 64))
+    assert "rings=1(lds)" in q.info() and "tile=1" in q.info() and "ctl[" not in q.info()
     assert q.delayed_edges() == [(0, 0, 1, 0)]  # OSC_M.sine -> MUL_FB.in1
     q = S.Patch(48000, 1024, 2)
-    S.build_p2(q)
+    ids2 = S.build_p2(q)
     q.configure_voices(64)
+    q.set_voice_field(ids2["mul_fb"], S.MATH_CONSTANT, np.linspace(0.1, 0.4, 64))
     assert "rings=1(hbm)" in q.info() and "tile=32" in q.info()
     # per-voice values of a state field are returned before any render
     p.set_voice_field(ids["osc_a"], S.OSC_POS, np.linspace(0, 0.5, 100))
     np.testing.assert_array_equal(p.get_voice_field(ids["osc_a"], S.OSC_POS), np.linspace(0, 0.5, 100))
     np.testing.assert_array_equal(p.get_voice_field(ids["vcf"], S.VCF_FREQ), cut.astype(np.float64))
+    # a module of the control program has one state shared by all voices
+    np.testing.assert_array_equal(p.get_voice_field(ids["adsr"], S.ADSR_MODE), np.full(100, 4.0))
 
 
 def test_no_gpu_render_fails_loudly(S):
