@@ -205,22 +205,23 @@ SRK_DEV double cosc_advance(COsc& o, bool& wrapped)
     return __builtin_amdgcn_fract(np);              // pos %= 1.0: exact for 0 <= np < 2
 }
 
-// saw port only
+// saw port only.  With t = pos/dt the two PolyBLEP branches are -(1 - t)^2 (first dt after the wrap) and
+// (t' + 1)^2 = (w/dt)^2 (last dt before it, w = next phase).  max(1 - t, 0) is zero outside the first
+// window, so that branch needs no compare; the second one is gated by the wrap bit of the f64 add.
 SRK_DEV float cosc_saw(COsc& o)
 {
     bool wrapped;
     const double w = cosc_advance(o, wrapped);
     const float w32 = (float)w;
-    const float ta_next = w32 * o.inv_dt;
-    const float tb = ta_next - 1.0f;                                // (pos - 1) / dt when the phase wraps at this step
-    const float fa = keep(__builtin_fmaf(o.ta, 2.0f - o.ta, -1.0f));  // 2t - t^2 - 1
-    const float fb = keep(__builtin_fmaf(tb, tb + 2.0f, 1.0f));       // t^2 + 2t + 1
-    const float hi = wrapped ? fb : 0.0f;
-    const float blep = o.ta < 1.0f ? fa : hi;
-    const float saw = __builtin_fmaf(o.p32, 2.0f, -1.0f) - blep;
+    const float tn = w32 * o.inv_dt;
+    const float base = __builtin_fmaf(o.p32, 2.0f, -1.0f);     // (pos as f32) * 2.0 - 1.0, exact as an fma
+    const float u = fmaxf(1.0f - o.ta, 0.0f);
+    const float s1 = __builtin_fmaf(u, u, base);               // base - (2t - t^2 - 1)
+    const float s2 = keep(__builtin_fmaf(-tn, tn, s1));        // base - (t'^2 + 2t' + 1)
+    const float saw = wrapped ? s2 : s1;
     o.pos = w;
     o.p32 = w32;
-    o.ta = ta_next;
+    o.ta = tn;
     return saw;
 }
 

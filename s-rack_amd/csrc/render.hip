@@ -612,7 +612,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
         const float env_next = env_track[min(t0 + kMixRows + (uint32_t)(lane & (kMixRows - 1)), a.T - 1)];
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
-        for (int i = 0; i < n; i++) {
+        auto sample = [&](int i) {
             const float env = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(env_tile), i));
             if (kExact) {
                 float sine = 0.0f, square = 0.0f, saw = 0.0f;
@@ -626,8 +626,17 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
                 pos_a = ca.pos;
                 x = cosc_step<kOscAPort>(ca);  // sample t+1
             }
-            const float o = vca_step(VCA_HAS_AUDIO | VCA_HAS_CV, negative, y, env);
+            // vca.rs:132: (negative || cv > 0.0) ? audio * cv : 0.0 — cv is wave-uniform here, so `cv > 0.0` is decided
+            // on the scalar unit from the bit pattern: positive, non-zero, not NaN  <=>  0 < bits <= 0x7f800000
+            const bool cv_pos = (uint32_t)(__float_as_int(env) - 1) < 0x7f800000u;
+            const float o = (negative || cv_pos) ? y * env : 0.0f;
             emit_put<kOut>(em, mix_tile, o, i, V);
+        };
+        if (n == kMixRows) {  // constant trip count: unrollable (readlane is convergent, so a runtime count is not)
+#pragma unroll 8
+            for (int i = 0; i < kMixRows; i++) sample(i);
+        } else {
+            for (int i = 0; i < n; i++) sample(i);
         }
         emit_flush<kOut>(em, mix_tile, t0, n);
         env_tile = env_next;
@@ -680,13 +689,51 @@ __global__ __launch_bounds__(64) void render_ctl_gate_env(KernelArgs a, ChainRol
     AdsrSeg seg;
     adsr_seg_enter(sd, kd, seg);
 
+    // Four samples at a time on the assumption that nothing happens in them: the square stays outside its PolyBLEP
+    // windows (so it is exactly -1/+1) and the envelope stays in its segment.  One scalar test per group instead
+    // of two per sample; when the assumption fails the group is redone one sample at a time (cosc / adsr_seg).
+    float out[4];
+    auto try_group = [&]() -> bool {
+        double pos = cl.pos;
+        float ph = sd.phase;
+        uint64_t last = seg.last, bad = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int hw = __double2hiint(pos);
+            bad |= __builtin_amdgcn_ballot_w64(hw <= cl.hA) | __builtin_amdgcn_ballot_w64(hw >= cl.hB) |
+                   __builtin_amdgcn_ballot_w64((uint32_t)(hw - cl.hQ0) <= cl.hQspan);
+            const uint64_t high = __builtin_amdgcn_ballot_w64(hw >= 0x3fe00000);  // square = +1 > 0  <=>  pos >= 0.5
+            pos = __builtin_amdgcn_fract(pos + cl.delta);
+            ph = ph + seg.inc;
+            bad |= __builtin_amdgcn_ballot_w64(ph >= 1.0f) | (high & seg.on_high) | (~high & seg.on_low) | (high & ~last & seg.on_edge);
+            last = high;
+            out[q] = seg.c0 + seg.c1 * (seg.k0 + seg.k1 * ph);
+        }
+        if (bad != 0) return false;
+        cl.pos = pos;
+        sd.phase = ph;
+        seg.last = last;
+        seg.held = out[3];
+        return true;
+    };
+
     for (uint32_t t0 = 0; t0 < a.T; t0 += 64) {
         const int n = (int)min(64u, a.T - t0);
         float keep_v = 0.0f;  // lane j keeps sample t0 + j
-        for (int j = 0; j < n; j++) {
-            const float gate = cosc_step<kOscPort>(cl);
-            const float env = adsr_seg_step(sd, kd, seg, gate);
-            keep_v = lane == j ? env : keep_v;
+        int j = 0;
+        while (j < n) {
+            if (kOscPort == OSC_OUT_SQUARE && j + 4 <= n && try_group()) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) keep_v = lane == j + q ? out[q] : keep_v;
+                j += 4;
+                continue;
+            }
+            const int stop = min(n, j + 4);
+            for (; j < stop; j++) {
+                const float gate = cosc_step<kOscPort>(cl);
+                const float env = adsr_seg_step(sd, kd, seg, gate);
+                keep_v = lane == j ? env : keep_v;
+            }
         }
         if (lane < n) track[t0 + lane] = keep_v;
     }
@@ -703,34 +750,48 @@ __global__ __launch_bounds__(64) void render_ctl_gate_env(KernelArgs a, ChainRol
     }
 }
 
-// ---- mix-down, pass 2: mix[c][i] = sum over waves of mixpart[plane(c)][w][i] --------------------------
+// ---- mix-down, passes 2 and 3: mix[c][i] = sum over waves of mixpart[plane(c)][w][i] ---------------------------
+// Deterministic (fixed order, no atomics).  Pass 2 splits the waves into kMixSplit groups so that enough loads
+// are in flight to stream the partials at HBM rate: block (x, y) sums group y for 256 consecutive samples into
+// mixgroup[plane][y][i].  Pass 3 adds the kMixSplit group sums and fans planes out to channels.
+constexpr uint32_t kMixSplit = 16;
+
 struct MixArgs {
-    const float* mixpart;
-    float* mix;
-    uint32_t T, n_waves, n_channels;
+    const float* mixpart;   // [planes][n_waves][T]
+    float* mixgroup;        // [planes][kMixSplit][T]
+    float* mix;             // [channels][T]
+    uint32_t T, n_waves, n_channels, n_planes;
     int32_t channel_plane[8];
 };
 
-__global__ __launch_bounds__(256) void mix_reduce(MixArgs m)
+__global__ __launch_bounds__(256) void mix_reduce_groups(MixArgs m)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m.T) return;
+    const uint32_t per = (m.n_waves + kMixSplit - 1) / kMixSplit;
+    const uint32_t w0 = blockIdx.y * per, w1 = min(m.n_waves, w0 + per);
+    for (uint32_t plane = 0; plane < m.n_planes; plane++) {
+        const float* p = m.mixpart + (size_t)plane * m.n_waves * m.T + i;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // fixed 8-way split: deterministic, 8 loads in flight per thread
+        uint32_t w = w0;
+        for (; w + 8 <= w1; w += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] += p[(size_t)(w + k) * m.T];
+        }
+        for (; w < w1; w++) s[0] += p[(size_t)w * m.T];
+        m.mixgroup[((size_t)plane * kMixSplit + blockIdx.y) * m.T + i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    }
+}
+
+__global__ __launch_bounds__(256) void mix_reduce_final(MixArgs m)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= m.T) return;
     for (uint32_t c = 0; c < m.n_channels; c++) {
         const int plane = m.channel_plane[c];
         float s = 0.0f;
-        if (plane >= 0) {
-            const float* p = m.mixpart + (size_t)plane * m.n_waves * m.T + i;
-            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // fixed 4-way split: deterministic, 4 loads in flight
-            uint32_t w = 0;
-            for (; w + 4 <= m.n_waves; w += 4) {
-                s0 += p[(size_t)(w + 0) * m.T];
-                s1 += p[(size_t)(w + 1) * m.T];
-                s2 += p[(size_t)(w + 2) * m.T];
-                s3 += p[(size_t)(w + 3) * m.T];
-            }
-            for (; w < m.n_waves; w++) s0 += p[(size_t)w * m.T];
-            s = (s0 + s1) + (s2 + s3);
-        }
+        if (plane >= 0)
+            for (uint32_t y = 0; y < kMixSplit; y++) s += m.mixgroup[((size_t)plane * kMixSplit + y) * m.T + i];
         m.mix[(size_t)c * m.T + i] = s;
     }
 }
@@ -773,6 +834,8 @@ struct DeviceState {
     DevProg voice, ctl;
     float* d_mixpart = nullptr;
     size_t mixpart_bytes = 0;
+    float* d_mixgroup = nullptr;
+    size_t mixgroup_bytes = 0;
     float* d_tracks = nullptr;
     size_t tracks_bytes = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timings;  // (start, stop) pairs of the dominant kernel, not yet read
@@ -789,6 +852,7 @@ void device_release(DeviceState* d)
     d->voice.release();
     d->ctl.release();
     (void)hipFree(d->d_mixpart);
+    (void)hipFree(d->d_mixgroup);
     (void)hipFree(d->d_tracks);
     for (auto& p : d->timings) {
         (void)hipEventDestroy(p.first);
@@ -959,11 +1023,21 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         return SRACK_OK;
     }
     if (d_mix && (rc = grow(d->d_mixpart, d->mixpart_bytes, sizeof(float) * (size_t)P.hdr.n_planes * n_waves * T)) != SRACK_OK) return rc;
+    if (d_mix && (rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * T)) != SRACK_OK) return rc;
 
     const bool has_ctl = h.prog.n_tracks > 0;
-    constexpr uint32_t kChunk = 6144;  // samples per chunk (a multiple of every tile size): ~0.1 s of audio
-    const uint32_t n_chunks = has_ctl ? (T + kChunk - 1) / kChunk : 1;
-    const uint32_t chunk_len = has_ctl ? kChunk : T;
+    // chunk schedule: short first chunks (only control chunk 0 is exposed), doubling up to kChunkMax
+    constexpr uint32_t kChunkFirst = 1024, kChunkMax = 8192;  // multiples of every tile size
+    std::vector<std::pair<uint32_t, uint32_t>> chunks;       // (t_off, len)
+    if (has_ctl) {
+        for (uint32_t t_off = 0, len = kChunkFirst; t_off < T; t_off += len, len = std::min(len * 2, kChunkMax)) {
+            len = std::min(len, T - t_off);
+            chunks.emplace_back(t_off, len);
+        }
+    } else {
+        chunks.emplace_back(0u, T);
+    }
+    const uint32_t n_chunks = (uint32_t)chunks.size();
     auto get_event = [&](hipEvent_t& e) -> int {
         if (!d->pool.empty()) {
             e = d->pool.back();
@@ -988,7 +1062,7 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         HIP_TRY(hipStreamWaitEvent(d->ctl_stream, d->ev_begin, 0));
         const FlatProgram& Cp = h.prog.ctl;
         for (uint32_t k = 0; k < n_chunks; k++) {
-            const uint32_t t_off = k * chunk_len, len = std::min(chunk_len, T - t_off);
+            const uint32_t t_off = chunks[k].first, len = chunks[k].second;
             KernelArgs kc{};
             kc.ops = d->ctl.d_ops;
             kc.prog = Cp.hdr;
@@ -1030,7 +1104,7 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
     }
 
     for (uint32_t k = 0; k < n_chunks; k++) {
-        const uint32_t t_off = k * chunk_len, len = std::min(chunk_len, T - t_off);
+        const uint32_t t_off = chunks[k].first, len = chunks[k].second;
         KernelArgs ka{};
         ka.ops = d->voice.d_ops;
         ka.prog = P.hdr;
@@ -1068,12 +1142,15 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
     if (d_mix) {
         MixArgs m{};
         m.mixpart = d->d_mixpart;
+        m.mixgroup = d->d_mixgroup;
         m.mix = d_mix;
         m.T = T;
         m.n_waves = n_waves;
         m.n_channels = C;
+        m.n_planes = (uint32_t)P.hdr.n_planes;
         for (int c = 0; c < 8; c++) m.channel_plane[c] = P.hdr.channel_plane[c];
-        hipLaunchKernelGGL(mix_reduce, dim3((T + 255) / 256), dim3(256), 0, st, m);
+        hipLaunchKernelGGL(mix_reduce_groups, dim3((T + 255) / 256, kMixSplit), dim3(256), 0, st, m);
+        hipLaunchKernelGGL(mix_reduce_final, dim3((T + 255) / 256), dim3(256), 0, st, m);
         HIP_TRY(hipGetLastError());
     }
     h.samples_rendered += T;
