@@ -111,7 +111,7 @@ class Patch:
         self.n_voices = 0
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:  # `lib` is already gone at interpreter shutdown
             lib.srack_patch_destroy(self.h)
             self.h = None
 

@@ -476,7 +476,7 @@ int Builder::build()
     out.table.resize((size_t)H.n_rows * V);
     for (int r = 0; r < H.n_rows; r++) std::memcpy(&out.table[(size_t)r * V], rows[(size_t)r].data(), sizeof(uint32_t) * V);
 
-    if (!is_ctl && !(render_flags & SRACK_RENDER_NO_FUSION)) match_fused(!rings.empty());
+    if (!(render_flags & SRACK_RENDER_NO_FUSION)) match_fused(!rings.empty());
     if (is_ctl && !(render_flags & SRACK_RENDER_NO_FUSION) && rings.empty() && H.n_ops == 3 && out.ops[0].kind == OP_OSC &&
         out.ops[1].kind == OP_ADSR && out.ops[2].kind == OP_OUT && (out.ops[0].flags & OSC_CONST_FAST) && (out.ops[1].flags & ADSR_HAS_GATE) &&
         g.modules[(size_t)out.ops[1].module].in[0].src == out.ops[0].module && out.ops[2].module == out.ops[1].module)
@@ -497,7 +497,23 @@ int Builder::build()
 // Oscillators must be OSC_CONST_FAST (or the exact flavour of the same shape), filters have no CV.
 void Builder::match_fused(bool has_rings)
 {
-    if (has_rings) return;
+    if (has_rings) {
+        // 2-operator FM with a one-sample feedback edge (patch P2 at buffer_size 1):
+        //   DELAY_RD -> MATH_FB -> OSC_M -> DELAY_WR ; OSC_M -> MATH_IDX -> OSC_C -> OUT ; only sine ports, no sync
+        const auto& o = out.ops;
+        const DevProgram& H = out.hdr;
+        auto is_scale = [](const DevOp& op) { return op.kind == OP_MATH && (op.flags & (MATH_HAS_IN1 | MATH_HAS_IN2)) == MATH_HAS_IN1; };
+        auto is_fm_osc = [](const DevOp& op) {
+            return op.kind == OP_OSC && (op.flags & (OSC_HAS_CV | OSC_HAS_SYNC | OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW)) == (OSC_HAS_CV | OSC_OUT_SINE);
+        };
+        if (H.buffer_size == 1 && H.n_ops == 7 && H.n_planes == 1 && o[0].kind == OP_DELAY_RD && !(o[0].flags & DELAY_RING_GLOBAL) && is_scale(o[1]) &&
+            is_fm_osc(o[2]) && o[3].kind == OP_DELAY_WR && is_scale(o[4]) && is_fm_osc(o[5]) && o[6].kind == OP_OUT && o[0].module == o[2].module &&
+            o[1].in_slot[0] == o[0].out_slot[0] && o[2].in_slot[0] == o[1].out_slot[0] && o[3].in_slot[0] == o[2].out_slot[0] &&
+            o[4].in_slot[0] == o[2].out_slot[0] && o[5].in_slot[0] == o[4].out_slot[0] && o[6].in_slot[0] == o[5].out_slot[0] && o[0].aux == o[3].aux)
+            out.fused = FUSED_FM_PAIR;
+        return;
+    }
+    if (is_ctl) return;  // the voice-chain shapes below are per-voice programs
     int n_kind[16] = {0};
     for (const DevOp& op : out.ops) n_kind[op.kind]++;
     const DevProgram& H = out.hdr;

@@ -663,6 +663,79 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
     }
 }
 
+// ---- fused 2-operator FM with a z^-1 feedback edge (patch P2's shape, buffer_size == 1) --------------------
+//   MATH_FB(in1 = OSC_M.sine delayed by one sample) -> OSC_M.cv ; OSC_M.sine -> MATH_IDX -> OSC_C.cv ; OSC_C.sine -> out
+// The broken edge is a one-sample delay, so the fed-back sine lives in a VGPR ("in-register recurrence").
+// Both oscillators have CV: 2^x and sin per sample per operator (oscillator.rs:45,132-133).  The modulator of
+// sample t+1 depends only on its own sine of sample t, so it runs one sample ahead of the carrier.
+template <bool kExact, int kOut>
+__global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
+{
+    using namespace dev;
+    __shared__ float mix_tile[kMixRows * 64];
+    const int lane = threadIdx.x;
+    const uint32_t voice = blockIdx.x * 64u + lane;
+    const bool active = voice < a.V;
+    const uint32_t vc = active ? voice : a.V - 1;
+    const uint32_t V = a.V;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+
+    const DevOp& ofb = a.ops[r.adsr];    // MATH on the feedback path   (roles reuse the ChainRoles slots)
+    const DevOp& om = a.ops[r.osc_l];    // modulator
+    const DevOp& oix = a.ops[r.vca];     // MATH scaling the modulation index
+    const DevOp& ocr = a.ops[r.osc_a];   // carrier
+    const int plane = a.ops[r.out].aux;
+    const int ring_row = r.track;        // the z^-1 ring: one state row
+
+    constexpr uint32_t fo = OSC_HAS_CV | OSC_AA | OSC_OUT_SINE | (kExact ? OSC_EXACT : 0u);
+    OscRegs sm, sc;
+    OscConst km, kc;
+    sm.pos = make_f64(row(om.state_row + OSC_S_POS_LO), row(om.state_row + OSC_S_POS_HI));
+    sm.sync_last = row(om.state_row + OSC_S_SYNC_LAST) != 0;
+    sc.pos = make_f64(row(ocr.state_row + OSC_S_POS_LO), row(ocr.state_row + OSC_S_POS_HI));
+    sc.sync_last = row(ocr.state_row + OSC_S_SYNC_LAST) != 0;
+    km.sr = om.sample_rate;
+    km.val = (double)parv(om, OSC_P_VAL);
+    km.delta = 0.0;
+    km.inv_dt = 0.0f;
+    kc = km;
+    kc.sr = ocr.sample_rate;
+    kc.val = (double)parv(ocr, OSC_P_VAL);
+    const float c_fb = parv(ofb, MATH_P_CONST), c_ix = parv(oix, MATH_P_CONST);
+    const uint32_t f_fb = ofb.flags, f_ix = oix.flags;
+    float fed = __uint_as_float(row(ring_row));  // OSC_M.sine of the previous tick (0.0 before the first)
+
+    Emit em = make_emit(a, plane, lane);
+    float sq = 0.0f, sw = 0.0f;
+    // prologue: modulator of sample 0
+    float sine_m = 0.0f;
+    if (a.T > 0) osc_step(fo, sm, km, math_step(f_fb, fed, 0.0f, c_fb), 0.0f, sine_m, sq, sw);
+    for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
+        const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+        for (int i = 0; i < n; i++) {
+            const float cur = sine_m;  // OSC_M.sine[t]
+            fed = cur;                 // what the ring holds after tick t
+            float out = 0.0f;
+            osc_step(fo, sc, kc, math_step(f_ix, cur, 0.0f, c_ix), 0.0f, out, sq, sw);   // carrier of sample t
+            if (t0 + (uint32_t)i + 1 < a.T)                                               // modulator of sample t+1
+                osc_step(fo, sm, km, math_step(f_fb, cur, 0.0f, c_fb), 0.0f, sine_m, sq, sw);
+            emit_put<kOut>(em, mix_tile, out, i, V);
+        }
+        emit_flush<kOut>(em, mix_tile, t0, n);
+    }
+    if (active) {
+        auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+        put(om.state_row + OSC_S_POS_LO, f64_lo(sm.pos));
+        put(om.state_row + OSC_S_POS_HI, f64_hi(sm.pos));
+        put(om.state_row + OSC_S_SYNC_LAST, 0u);
+        put(ocr.state_row + OSC_S_POS_LO, f64_lo(sc.pos));
+        put(ocr.state_row + OSC_S_POS_HI, f64_hi(sc.pos));
+        put(ocr.state_row + OSC_S_SYNC_LAST, 0u);
+        put(ring_row, __float_as_uint(fed));
+    }
+}
+
 // ---- fused control chain: OSC (constant pitch) -> ADSR -> track ---------------------------------------------
 // The voice-invariant half of patch P1's shape: one voice, one wave, every lane computes the same numbers.
 // It is a pure latency chain (phase accumulate -> gate -> envelope state machine), so it is kept short: state
@@ -991,6 +1064,18 @@ static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t 
             hipLaunchKernelGGL((render_ctl_gate_env<OSC_OUT_SAW>), dim3(1), dim3(64), 0, st, kc, roles);
         else
             hipLaunchKernelGGL((render_ctl_gate_env<OSC_OUT_SINE>), dim3(1), dim3(64), 0, st, kc, roles);
+    } else if (Cp.fused == FUSED_FM_PAIR) {
+        ChainRoles roles{};
+        roles.adsr = 1;
+        roles.osc_l = 2;
+        roles.vca = 4;
+        roles.osc_a = 5;
+        roles.out = 6;
+        roles.track = Cp.ops[0].aux;
+        if (Cp.render_flags & SRACK_RENDER_EXACT_OSC)
+            hipLaunchKernelGGL((render_fm_pair<true, 0>), dim3(1), dim3(64), 0, st, kc, roles);
+        else
+            hipLaunchKernelGGL((render_fm_pair<false, 0>), dim3(1), dim3(64), 0, st, kc, roles);
     } else {
         launch_interp(Cp, kc, st);
     }
@@ -1103,6 +1188,16 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         d->kernel_name = "render_interp";
     }
 
+    const bool fm_pair = P.fused == FUSED_FM_PAIR;
+    if (fm_pair) {  // op order fixed by the matcher: DELAY_RD, MATH_FB, OSC_M, DELAY_WR, MATH_IDX, OSC_C, OUT
+        roles.adsr = 1;
+        roles.osc_l = 2;
+        roles.vca = 4;
+        roles.osc_a = 5;
+        roles.out = 6;
+        roles.track = P.ops[0].aux;  // the ring's state row
+        d->kernel_name = "render_fm_pair";
+    }
     for (uint32_t k = 0; k < n_chunks; k++) {
         const uint32_t t_off = chunks[k].first, len = chunks[k].second;
         KernelArgs ka{};
@@ -1126,6 +1221,11 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         if (fused) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             if (out_mode != 0) launch_fused(osc_port, vcf_port, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, track, ka, roles, dim3(n_waves), st);
+        } else if (fm_pair) {
+            if (flags & SRACK_RENDER_EXACT_OSC)
+                hipLaunchKernelGGL((render_fm_pair<true, 0>), dim3(n_waves), dim3(64), 0, st, ka, roles);
+            else
+                hipLaunchKernelGGL((render_fm_pair<false, 0>), dim3(n_waves), dim3(64), 0, st, ka, roles);
         } else {
             launch_interp(P, ka, st);
         }
