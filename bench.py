@@ -60,6 +60,26 @@ def cpu_baseline(S, voices_per_core=6, n_samples=48000):
     }
 
 
+def measured_traffic(kernel_name, V, T):
+    """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC summary (profiles/*_summary.json,
+    written by profiles/summarize.py from separate WRITE_SIZE / FETCH_SIZE passes of this very command), or None.
+    Only valid for the default workload the profile was taken on."""
+    import glob
+    if (V, T) != (262144, 48000):
+        return None
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for name, v in d.get("derived", {}).items():
+            if kernel_name and kernel_name in name and "hbm_traffic_bytes" in v:
+                best = {"bytes_per_launch": v["hbm_traffic_bytes"], "write": v.get("hbm_write_bytes"),
+                        "read_corrected": v.get("hbm_read_bytes_gfx950_corrected"), "source": os.path.basename(path)}
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,12 +173,18 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
+                "traffic_detail": None,
                 "frac_of_measured_stream_ceiling": achieved / HBM_STREAM_GBS,
                 "kernel_ms": kernel_ms, "kernel_launches": n_launch, "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "voice_samples_per_s_kernel": V * T / launches_per_step / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
             },
         }
+        kname = p.info().split("kernel=")[-1] if "kernel=" in p.info() else ""
+        tr = measured_traffic(kname, V, T) if args.flags == 0 and frames is not None and not args.no_mix else None
+        if tr:
+            out["roofline"]["traffic"] = tr["bytes_per_launch"]
+            out["roofline"]["traffic_detail"] = tr
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(out), flush=True)

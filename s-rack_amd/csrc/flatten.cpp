@@ -33,7 +33,7 @@ namespace {
 
 constexpr int kRingLdsMax = 16;         // rings up to this many samples live in LDS rows (persisted as state)
 constexpr int kTileMax = 32;            // samples per interpreter tile
-constexpr int kLdsBudget = 40 * 1024;   // bytes of LDS per wave the interpreter may use (=> >= 4 waves / CU)
+constexpr int kLdsBudget = 20 * 1024;   // bytes of LDS per wave the interpreter may use (=> 8 waves / CU, 2 per SIMD)
 
 struct Wire {
     int def_op = -1;

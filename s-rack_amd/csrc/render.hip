@@ -72,6 +72,7 @@ SRK_DEV float par(const Ctx& c, const DevOp& op, int k) { return op.par_row[k] >
 
 // ---- one tile of one module type -----------------------------------------------------------------
 
+template <bool kExact>
 __device__ __noinline__ void tile_osc(const Ctx& c, const DevOp& op)
 {
     const uint32_t fl = op.flags;
@@ -104,7 +105,7 @@ __device__ __noinline__ void tile_osc(const Ctx& c, const DevOp& op)
         float cv = (fl & OSC_HAS_CV) ? WIRE(i_cv, i) : 0.0f;
         float sync = (fl & OSC_HAS_SYNC) ? WIRE(i_sync, i) : 0.0f;
         float sine = 0.0f, square = 0.0f, saw = 0.0f;
-        osc_step(fl, s, k, cv, sync, sine, square, saw);
+        osc_step(kExact ? (fl | OSC_EXACT) : (fl & ~OSC_EXACT), s, k, cv, sync, sine, square, saw);
         if (fl & OSC_OUT_SINE) WIRE(o_sine, i) = sine;
         if (fl & OSC_OUT_SQUARE) WIRE(o_square, i) = square;
         if (fl & OSC_OUT_SAW) WIRE(o_saw, i) = saw;
@@ -303,6 +304,7 @@ __device__ __noinline__ void tile_delay_wr(const Ctx& c, const DevOp& op, const 
 }  // namespace dev
 
 // ---- generic tile interpreter ----------------------------------------------------------------------
+template <bool kExact>
 __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
         for (int i = 0; i < a.prog.n_ops; i++) {
             const DevOp& op = a.ops[i];
             switch (op.kind) {
-            case OP_OSC: dev::tile_osc(c, op); break;
+            case OP_OSC: dev::tile_osc<kExact>(c, op); break;
             case OP_VCF: dev::tile_vcf(c, op); break;
             case OP_ADSR: dev::tile_adsr(c, op); break;
             case OP_VCA: dev::tile_vca(c, op); break;
@@ -1047,7 +1049,10 @@ static void launch_fused(uint32_t osc_port, uint32_t vcf_port, bool exact, int o
 static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_t st)
 {
     size_t lds = ((size_t)P.hdr.n_rows + (size_t)P.hdr.n_slots * P.hdr.tile) * 256;
-    hipLaunchKernelGGL(render_interp, dim3(ka.n_waves), dim3(64), lds, st, ka);
+    if (P.render_flags & SRACK_RENDER_EXACT_OSC)
+        hipLaunchKernelGGL(render_interp<true>, dim3(ka.n_waves), dim3(64), lds, st, ka);
+    else
+        hipLaunchKernelGGL(render_interp<false>, dim3(ka.n_waves), dim3(64), lds, st, ka);
 }
 
 static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t st)
