@@ -502,7 +502,9 @@ void Builder::match_fused(bool has_rings)
         //   DELAY_RD -> MATH_FB -> OSC_M -> DELAY_WR ; OSC_M -> MATH_IDX -> OSC_C -> OUT ; only sine ports, no sync
         const auto& o = out.ops;
         const DevProgram& H = out.hdr;
-        auto is_scale = [](const DevOp& op) { return op.kind == OP_MATH && (op.flags & (MATH_HAS_IN1 | MATH_HAS_IN2)) == MATH_HAS_IN1; };
+        auto is_scale = [](const DevOp& op) {  // Multiply by the module's constant: in1 connected, in2 not
+            return op.kind == OP_MATH && (op.flags & (MATH_HAS_IN1 | MATH_HAS_IN2)) == MATH_HAS_IN1 && ((op.flags >> MATH_OP_SHIFT) & 3u) == SRACK_MATH_MULTIPLY;
+        };
         auto is_fm_osc = [](const DevOp& op) {
             return op.kind == OP_OSC && (op.flags & (OSC_HAS_CV | OSC_HAS_SYNC | OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW)) == (OSC_HAS_CV | OSC_OUT_SINE);
         };

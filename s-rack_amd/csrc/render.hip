@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -41,7 +42,8 @@ struct KernelArgs {
     float* frames;
     float* mixpart;
     const float* tracks;  // control tracks [n_tracks][t_stride] written by the control program (may be null)
-    uint32_t V, T, n_waves, pad_;
+    uint32_t V, T, n_waves;
+    uint32_t lanes;  // voices per wave: 64, or 32 / 16 when there are too few voices to fill the SIMDs (idle lanes shadow the wave's last voice)
     // A launch covers T samples of a render of t_stride samples; frames / mixpart / tracks arrive pre-offset to
     // the launch's first sample and keep the whole render's strides.
     uint64_t plane_stride;  // frames: elements between planes (= t_stride * V)
@@ -58,6 +60,25 @@ namespace dev {
 SRK_DEV double make_f64(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 SRK_DEV uint32_t f64_lo(double d) { return (uint32_t)__double2loint(d); }
 SRK_DEV uint32_t f64_hi(double d) { return (uint32_t)__double2hiint(d); }
+
+struct WaveMap {   // which voices a wave owns
+    uint32_t wave0;     // first voice of the wave
+    uint32_t n_active;  // real voices in it (lanes >= n_active shadow voice wave0 + n_active - 1: same work, same stores)
+    uint32_t voice;     // this lane's voice (meaningful when active)
+    uint32_t vc;        // this lane's voice clamped to a real one (safe to load from)
+    bool active;
+};
+
+SRK_DEV WaveMap wave_map(const KernelArgs& a, int lane)
+{
+    WaveMap m;
+    m.wave0 = blockIdx.x * a.lanes;
+    m.n_active = min(a.lanes, a.V - m.wave0);
+    m.active = (uint32_t)lane < m.n_active;
+    m.voice = m.wave0 + (uint32_t)lane;
+    m.vc = m.active ? m.voice : m.wave0 + m.n_active - 1;
+    return m;
+}
 
 struct Ctx {            // what every tile function sees
     uint32_t* rows;     // LDS [n_rows][64]
@@ -309,9 +330,9 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
-    const uint32_t voice = blockIdx.x * 64u + lane;
-    const bool active = voice < a.V;
-    const uint32_t voice_c = active ? voice : a.V - 1;  // idle lanes shadow the last voice; they never store
+    const dev::WaveMap wm = dev::wave_map(a, lane);
+    const uint32_t voice = wm.voice, voice_c = wm.vc;  // idle lanes shadow the wave's last voice; they never store
+    const bool active = wm.active;
     const int n_rows = a.prog.n_rows, tile = a.prog.tile;
     dev::Ctx c;
     c.rows = lds;
@@ -388,9 +409,12 @@ SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n)  // the ti
 
 SRK_DEV Emit make_emit(const KernelArgs& a, int plane, int lane)
 {
+    using dev::WaveMap;
+    using dev::wave_map;
     Emit e;
-    const uint32_t wave0 = blockIdx.x * 64u;
-    e.n_active = min(64u, a.V - wave0);
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t wave0 = wm.wave0;
+    e.n_active = wm.n_active;
     e.full_wave = e.n_active == 64u;
     e.lane = lane;
     e.lane_c = min(lane, (int)e.n_active - 1);
@@ -410,10 +434,9 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
     using namespace dev;
     __shared__ float mix_tile[kMixRows * 64];
     const int lane = threadIdx.x;
-    const uint32_t voice = blockIdx.x * 64u + lane;
-    const bool active = voice < a.V;
-    const uint32_t vc = active ? voice : a.V - 1;
-    const uint32_t V = a.V;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
+    const bool active = wm.active;
     auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
     auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
 
@@ -561,10 +584,9 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
     using namespace dev;
     __shared__ float mix_tile[kMixRows * 64];
     const int lane = threadIdx.x;
-    const uint32_t voice = blockIdx.x * 64u + lane;
-    const bool active = voice < a.V;
-    const uint32_t vc = active ? voice : a.V - 1;
-    const uint32_t V = a.V;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
+    const bool active = wm.active;
     auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
     auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
 
@@ -676,10 +698,9 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
     using namespace dev;
     __shared__ float mix_tile[kMixRows * 64];
     const int lane = threadIdx.x;
-    const uint32_t voice = blockIdx.x * 64u + lane;
-    const bool active = voice < a.V;
-    const uint32_t vc = active ? voice : a.V - 1;
-    const uint32_t V = a.V;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
+    const bool active = wm.active;
     auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
     auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
 
@@ -704,28 +725,29 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
     kc = km;
     kc.sr = ocr.sample_rate;
     kc.val = (double)parv(ocr, OSC_P_VAL);
+    // both MATH modules are Multiply by a constant (host-checked): in1 * constant (math.rs:152)
     const float c_fb = parv(ofb, MATH_P_CONST), c_ix = parv(oix, MATH_P_CONST);
-    const uint32_t f_fb = ofb.flags, f_ix = oix.flags;
     float fed = __uint_as_float(row(ring_row));  // OSC_M.sine of the previous tick (0.0 before the first)
 
     Emit em = make_emit(a, plane, lane);
     float sq = 0.0f, sw = 0.0f;
-    // prologue: modulator of sample 0
     float sine_m = 0.0f;
-    if (a.T > 0) osc_step(fo, sm, km, math_step(f_fb, fed, 0.0f, c_fb), 0.0f, sine_m, sq, sw);
+    double pos_m = sm.pos;  // modulator phase after exactly t samples (the loop runs it one sample ahead)
+    if (a.T > 0) osc_step(fo, sm, km, fed * c_fb, 0.0f, sine_m, sq, sw);  // modulator of sample 0
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
         for (int i = 0; i < n; i++) {
-            const float cur = sine_m;  // OSC_M.sine[t]
-            fed = cur;                 // what the ring holds after tick t
+            const float cur = sine_m;  // OSC_M.sine[t]: feeds the carrier now and, through the z^-1 ring, the modulator of t+1
             float out = 0.0f;
-            osc_step(fo, sc, kc, math_step(f_ix, cur, 0.0f, c_ix), 0.0f, out, sq, sw);   // carrier of sample t
-            if (t0 + (uint32_t)i + 1 < a.T)                                               // modulator of sample t+1
-                osc_step(fo, sm, km, math_step(f_fb, cur, 0.0f, c_fb), 0.0f, sine_m, sq, sw);
+            osc_step(fo, sc, kc, cur * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
+            pos_m = sm.pos;
+            osc_step(fo, sm, km, cur * c_fb, 0.0f, sine_m, sq, sw);   // modulator of sample t+1 (independent of the carrier)
+            fed = cur;
             emit_put<kOut>(em, mix_tile, out, i, V);
         }
         emit_flush<kOut>(em, mix_tile, t0, n);
     }
+    sm.pos = pos_m;  // drop the look-ahead step
     if (active) {
         auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
         put(om.state_row + OSC_S_POS_LO, f64_lo(sm.pos));
@@ -1080,7 +1102,7 @@ static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t 
         if (Cp.render_flags & SRACK_RENDER_EXACT_OSC)
             hipLaunchKernelGGL((render_fm_pair<true, 0>), dim3(1), dim3(64), 0, st, kc, roles);
         else
-            hipLaunchKernelGGL((render_fm_pair<false, 0>), dim3(1), dim3(64), 0, st, kc, roles);
+            hipLaunchKernelGGL((render_fm_pair<false, 1>), dim3(1), dim3(64), 0, st, kc, roles);
     } else {
         launch_interp(Cp, kc, st);
     }
@@ -1102,7 +1124,16 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         if (rc != SRACK_OK) return rc;
     }
     DeviceState* d = h.dev;
-    const uint32_t n_waves = (V + 63) / 64;
+    // Voices per wave.  A full wave (64) is right whenever there are enough voices to give every SIMD work.
+    // With few voices, half- or quarter-filled waves double / quadruple the number of waves: a VALU instruction
+    // costs the same for 16 lanes as for 64, so this only pays while SIMDs would otherwise sit idle (VALU-bound
+    // kernels: up to one wave per SIMD) or while waves are latency-bound (FM pair, interpreter: up to four).
+    const uint32_t kSimds = 1024;
+    uint32_t want_waves = kSimds;
+    if (const char* e = getenv("SRACK_WANT_WAVES")) want_waves = (uint32_t)atoi(e);  // tuning knob (tools/): waves to aim for
+    uint32_t lanes = 64;
+    while (lanes > 16 && (V + lanes - 1) / lanes * 2 <= want_waves) lanes >>= 1;
+    const uint32_t n_waves = (V + lanes - 1) / lanes;
 
     if (P.hdr.n_planes == 0) {  // nothing reaches the output: silence (output.rs:55)
         if (d_mix) {
@@ -1164,6 +1195,7 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
             kc.V = 1;
             kc.T = len;
             kc.n_waves = 1;
+            kc.lanes = 64;
             kc.n0 = h.samples_rendered + t_off;
             launch_ctl(Cp, kc, d->ctl_stream);
             HIP_TRY(hipGetLastError());
@@ -1218,6 +1250,7 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         ka.V = V;
         ka.T = len;
         ka.n_waves = n_waves;
+        ka.lanes = lanes;
         ka.n0 = h.samples_rendered + t_off;
         if (has_ctl) HIP_TRY(hipStreamWaitEvent(st, d->ev_chunk[k], 0));
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1227,10 +1260,15 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             if (out_mode != 0) launch_fused(osc_port, vcf_port, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, track, ka, roles, dim3(n_waves), st);
         } else if (fm_pair) {
+            const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             if (flags & SRACK_RENDER_EXACT_OSC)
                 hipLaunchKernelGGL((render_fm_pair<true, 0>), dim3(n_waves), dim3(64), 0, st, ka, roles);
-            else
-                hipLaunchKernelGGL((render_fm_pair<false, 0>), dim3(n_waves), dim3(64), 0, st, ka, roles);
+            else if (out_mode == 3)
+                hipLaunchKernelGGL((render_fm_pair<false, 3>), dim3(n_waves), dim3(64), 0, st, ka, roles);
+            else if (out_mode == 1)
+                hipLaunchKernelGGL((render_fm_pair<false, 1>), dim3(n_waves), dim3(64), 0, st, ka, roles);
+            else if (out_mode == 2)
+                hipLaunchKernelGGL((render_fm_pair<false, 2>), dim3(n_waves), dim3(64), 0, st, ka, roles);
         } else {
             launch_interp(P, ka, st);
         }
