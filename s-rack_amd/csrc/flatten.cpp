@@ -465,8 +465,8 @@ int Builder::build()
         int tile = kTileMax;
         if (!rings.empty())
             while (tile > B) tile >>= 1;  // a tile may not span more than one ring period
-        while (tile > 1 && (H.n_rows + H.n_slots * tile) * 256 > kLdsBudget) tile >>= 1;
-        if ((H.n_rows + H.n_slots * tile) * 256 > 64 * 1024) {
+        while (tile > 1 && (H.n_rows + 2 + H.n_slots * tile) * 256 > kLdsBudget) tile >>= 1;  // + zero and trash rows
+        if ((H.n_rows + 2 + H.n_slots * tile) * 256 > 64 * 1024) {
             set_error("flatten: patch state does not fit the LDS budget of the tile interpreter");
             return SRACK_ERR_UNSUPPORTED;
         }

@@ -83,6 +83,8 @@ SRK_DEV WaveMap wave_map(const KernelArgs& a, int lane)
 struct Ctx {            // what every tile function sees
     uint32_t* rows;     // LDS [n_rows][64]
     float* wires;       // LDS [n_slots][tile][64]
+    float* zero;        // LDS row of zeros: what an unconnected input reads (stride 0)
+    float* trash;       // LDS row nobody reads: where an unread output goes (stride 0)
     int tile, n, lane;  // tile capacity, samples in this tile, lane
 };
 
@@ -90,6 +92,46 @@ struct Ctx {            // what every tile function sees
 #define WIRE(slot, i) c.wires[((slot) * c.tile + (i)) * 64 + c.lane]
 
 SRK_DEV float par(const Ctx& c, const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(ROW(op.par_row[k])) : op.par_val[k]; }
+
+// A port as (lane pointer, stride in floats per sample).  Unconnected inputs read the zero row, unread outputs
+// write the trash row, both with stride 0 — so tile loops carry no per-sample "is it wired" branches.
+struct Port {
+    float* p;
+    int stride;
+};
+SRK_DEV Port in_port(const Ctx& c, int slot) { return slot >= 0 ? Port{c.wires + (size_t)slot * c.tile * 64 + c.lane, 64} : Port{c.zero + c.lane, 0}; }
+SRK_DEV Port out_port(const Ctx& c, int slot) { return slot >= 0 ? Port{c.wires + (size_t)slot * c.tile * 64 + c.lane, 64} : Port{c.trash + c.lane, 0}; }
+
+// Runs step(x[NI], y[NO]) for every sample of the tile, kU samples at a time: the kU x NI input reads are issued
+// together, then the kU steps, then the kU x NO writes — one LDS round trip per kU samples instead of per sample.
+// (Output slots never alias an op's own input slots: flatten.cpp keeps inputs live through the op.)
+template <int NI, int NO, class Step>
+SRK_DEV void tile_run(const Ctx& c, const Port (&in)[NI], const Port (&out)[NO], Step step)
+{
+    constexpr int kU = 4;
+    int i = 0;
+    for (; i + kU <= c.n; i += kU) {
+        float x[kU][NI], y[kU][NO];
+#pragma unroll
+        for (int u = 0; u < kU; u++)
+#pragma unroll
+            for (int k = 0; k < NI; k++) x[u][k] = in[k].p[(i + u) * in[k].stride];
+#pragma unroll
+        for (int u = 0; u < kU; u++) step(x[u], y[u]);
+#pragma unroll
+        for (int u = 0; u < kU; u++)
+#pragma unroll
+            for (int k = 0; k < NO; k++) out[k].p[(i + u) * out[k].stride] = y[u][k];
+    }
+    for (; i < c.n; i++) {
+        float x[NI], y[NO];
+#pragma unroll
+        for (int k = 0; k < NI; k++) x[k] = in[k].p[i * in[k].stride];
+        step(x, y);
+#pragma unroll
+        for (int k = 0; k < NO; k++) out[k].p[i * out[k].stride] = y[k];
+    }
+}
 
 // ---- one tile of one module type -----------------------------------------------------------------
 
@@ -106,31 +148,32 @@ __device__ __noinline__ void tile_osc(const Ctx& c, const DevOp& op)
     k.val = (double)par(c, op, OSC_P_VAL);
     k.delta = op.delta_row >= 0 ? make_f64(ROW(op.delta_row), ROW(op.delta_row + 1)) : op.delta;
     k.inv_dt = 1.0f / (float)k.delta;
-    const int i_cv = op.in_slot[0], i_sync = op.in_slot[1];
-    const int o_sine = op.out_slot[0], o_square = op.out_slot[1], o_saw = op.out_slot[2];
+    const Port out[3] = {out_port(c, op.out_slot[0]), out_port(c, op.out_slot[1]), out_port(c, op.out_slot[2])};
     if (fl & OSC_CONST_FAST) {  // no CV, no sync, one live port, delta < 0.25 for every voice (host-checked)
         COsc o;
         cosc_init(o, s.pos, k.delta);
-        if (fl & OSC_OUT_SAW)
-            for (int i = 0; i < c.n; i++) WIRE(o_saw, i) = cosc_saw(o);
-        else if (fl & OSC_OUT_SQUARE)
-            for (int i = 0; i < c.n; i++) WIRE(o_square, i) = cosc_square(o);
-        else
-            for (int i = 0; i < c.n; i++) WIRE(o_sine, i) = cosc_sine(o);
+        const Port none[1] = {in_port(c, -1)};
+        if (fl & OSC_OUT_SAW) {
+            const Port w[1] = {out[2]};
+            tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_saw(o); });
+        } else if (fl & OSC_OUT_SQUARE) {
+            const Port w[1] = {out[1]};
+            tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_square(o); });
+        } else {
+            const Port w[1] = {out[0]};
+            tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_sine(o); });
+        }
         ROW(sr + OSC_S_POS_LO) = f64_lo(o.pos);
         ROW(sr + OSC_S_POS_HI) = f64_hi(o.pos);
         ROW(sr + OSC_S_SYNC_LAST) = 0u;  // sync unconnected: `last` follows the constant 0.0 input
         return;
     }
-    for (int i = 0; i < c.n; i++) {
-        float cv = (fl & OSC_HAS_CV) ? WIRE(i_cv, i) : 0.0f;
-        float sync = (fl & OSC_HAS_SYNC) ? WIRE(i_sync, i) : 0.0f;
-        float sine = 0.0f, square = 0.0f, saw = 0.0f;
-        osc_step(kExact ? (fl | OSC_EXACT) : (fl & ~OSC_EXACT), s, k, cv, sync, sine, square, saw);
-        if (fl & OSC_OUT_SINE) WIRE(o_sine, i) = sine;
-        if (fl & OSC_OUT_SQUARE) WIRE(o_square, i) = square;
-        if (fl & OSC_OUT_SAW) WIRE(o_saw, i) = saw;
-    }
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const uint32_t f = kExact ? (fl | OSC_EXACT) : (fl & ~OSC_EXACT);
+    tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
+        y[0] = y[1] = y[2] = 0.0f;
+        osc_step(f, s, k, x[0], x[1], y[0], y[1], y[2]);
+    });
     ROW(sr + OSC_S_POS_LO) = f64_lo(s.pos);
     ROW(sr + OSC_S_POS_HI) = f64_hi(s.pos);
     ROW(sr + OSC_S_SYNC_LAST) = s.sync_last ? 1u : 0u;
@@ -164,6 +207,7 @@ SRK_DEV void vcf_store(const Ctx& c, int sr, const VcfRegs& s)
     ROW(sr + VCF_S_RES) = __float_as_uint(s.res);
 }
 
+template <bool kExact>
 __device__ __noinline__ void tile_vcf(const Ctx& c, const DevOp& op)
 {
     const uint32_t fl = op.flags;
@@ -171,17 +215,17 @@ __device__ __noinline__ void tile_vcf(const Ctx& c, const DevOp& op)
     vcf_load(c, op.state_row, s);
     const float freq = par(c, op, VCF_P_FREQ), exp_amt = par(c, op, VCF_P_EXP);
     const float res = vcf_resonance(par(c, op, VCF_P_RES));
-    const int i_audio = op.in_slot[0], i_cv = op.in_slot[1];
-    const int o_lp = op.out_slot[0], o_bp = op.out_slot[1], o_hp = op.out_slot[2];
-    if (!(fl & VCF_HAS_CV)) vcf_coeffs(s, vcf_frequency(freq, 0.0f, exp_amt), res);  // constant cutoff: the check can only fire on the first sample
-    for (int i = 0; i < c.n; i++) {
-        float audio = (fl & VCF_HAS_AUDIO) ? WIRE(i_audio, i) : 0.0f;
-        if (fl & VCF_HAS_CV) vcf_coeffs(s, vcf_frequency(freq, WIRE(i_cv, i), exp_amt), res);
-        float lp, bp, hp;
-        vcf_step(s, audio, lp, bp, hp);
-        if (fl & VCF_OUT_LP) WIRE(o_lp, i) = lp;
-        if (fl & VCF_OUT_BP) WIRE(o_bp, i) = bp;
-        if (fl & VCF_OUT_HP) WIRE(o_hp, i) = hp;
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const Port out[3] = {out_port(c, op.out_slot[0]), out_port(c, op.out_slot[1]), out_port(c, op.out_slot[2])};
+    if (fl & VCF_HAS_CV) {
+        tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
+            vcf_coeffs(s, vcf_frequency(freq, x[1], exp_amt), res);
+            vcf_step<!kExact>(s, x[0], y[0], y[1], y[2]);
+        });
+    } else {
+        // constant cutoff: the "did (frequency, res) change" check can only fire on the first sample
+        vcf_coeffs(s, vcf_frequency(freq, 0.0f, exp_amt), res);
+        tile_run<2, 3>(c, in, out, [&](const float* x, float* y) { vcf_step<!kExact>(s, x[0], y[0], y[1], y[2]); });
     }
     vcf_store(c, op.state_row, s);
 }
@@ -196,14 +240,15 @@ __device__ __noinline__ void tile_adsr(const Ctx& c, const DevOp& op)
     s.from_a_val = __uint_as_float(ROW(sr + ADSR_S_FROM_A));
     s.gate_last = ROW(sr + ADSR_S_GATE_LAST) != 0;
     const AdsrConst k = adsr_consts(par(c, op, ADSR_P_A), par(c, op, ADSR_P_D), par(c, op, ADSR_P_S), par(c, op, ADSR_P_R), par(c, op, ADSR_P_SR));
-    const int i_gate = op.in_slot[0], o = op.out_slot[0];
+    const Port in[1] = {in_port(c, op.in_slot[0])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
     if (op.flags & ADSR_HAS_GATE) {
         AdsrSeg g;
         adsr_seg_enter(s, k, g);
-        for (int i = 0; i < c.n; i++) WIRE(o, i) = adsr_seg_step(s, k, g, WIRE(i_gate, i));
+        tile_run<1, 1>(c, in, out, [&](const float* x, float* y) { y[0] = adsr_seg_step(s, k, g, x[0]); });
         adsr_seg_flush(s, g);
     } else {
-        for (int i = 0; i < c.n; i++) WIRE(o, i) = adsr_step(op.flags, s, k, 0.0f);
+        tile_run<1, 1>(c, in, out, [&](const float*, float* y) { y[0] = adsr_step(op.flags, s, k, 0.0f); });
     }
     ROW(sr + ADSR_S_PHASE) = __float_as_uint(s.phase);
     ROW(sr + ADSR_S_MODE) = (uint32_t)s.mode;
@@ -215,33 +260,29 @@ __device__ __noinline__ void tile_adsr(const Ctx& c, const DevOp& op)
 __device__ __noinline__ void tile_vca(const Ctx& c, const DevOp& op)
 {
     const bool negative = par(c, op, VCA_P_NEG) != 0.0f;
-    const int i_audio = op.in_slot[0], i_cv = op.in_slot[1], o = op.out_slot[0];
-    const bool both = (op.flags & (VCA_HAS_AUDIO | VCA_HAS_CV)) == (VCA_HAS_AUDIO | VCA_HAS_CV);
-    for (int i = 0; i < c.n; i++) WIRE(o, i) = both ? vca_step(op.flags, negative, WIRE(i_audio, i), WIRE(i_cv, i)) : 0.0f;
+    const uint32_t fl = op.flags;
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
+    tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = vca_step(fl, negative, x[0], x[1]); });
 }
 
 __device__ __noinline__ void tile_mix(const Ctx& c, const DevOp& op)
 {
     float gain[4];
     for (int k = 0; k < 4; k++) gain[k] = par(c, op, MIX_P_GAIN0 + k);
-    const int o = op.out_slot[0];
-    for (int i = 0; i < c.n; i++) {
-        float in[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) in[k] = (op.flags & (1u << k)) ? WIRE(op.in_slot[k], i) : 0.0f;
-        WIRE(o, i) = mixer_step(op.flags, in, gain);
-    }
+    const uint32_t fl = op.flags;
+    const Port in[4] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1]), in_port(c, op.in_slot[2]), in_port(c, op.in_slot[3])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
+    tile_run<4, 1>(c, in, out, [&](const float* x, float* y) { y[0] = mixer_step(fl, x, gain); });
 }
 
 __device__ __noinline__ void tile_math(const Ctx& c, const DevOp& op)
 {
     const float constant = par(c, op, MATH_P_CONST);
-    const int o = op.out_slot[0];
-    for (int i = 0; i < c.n; i++) {
-        float a = (op.flags & MATH_HAS_IN1) ? WIRE(op.in_slot[0], i) : 0.0f;
-        float b = (op.flags & MATH_HAS_IN2) ? WIRE(op.in_slot[1], i) : 0.0f;
-        WIRE(o, i) = math_step(op.flags, a, b, constant);
-    }
+    const uint32_t fl = op.flags;
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
+    tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = math_step(fl, x[0], x[1], constant); });
 }
 
 // Sum an LDS tile [rows_in_tile][64] over the 64 lanes: lane l owns row l % R and the column
@@ -263,8 +304,17 @@ __device__ __noinline__ void tile_out(const Ctx& c, const DevOp& op, const Kerne
     const int slot = op.in_slot[0], plane = op.aux;
     if (a.frames) {
         float* f = a.frames + (size_t)plane * a.plane_stride + (size_t)t0 * a.V + voice;
-        if (active)
-            for (int i = 0; i < c.n; i++) f[(size_t)i * a.V] = WIRE(slot, i);
+        if (active) {
+            int i = 0;
+            for (; i + 8 <= c.n; i += 8) {  // 8 LDS reads in flight, then 8 coalesced 256-B row stores
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = WIRE(slot, i + u);
+#pragma unroll
+                for (int u = 0; u < 8; u++) f[(size_t)(i + u) * a.V] = v[u];
+            }
+            for (; i < c.n; i++) f[(size_t)i * a.V] = WIRE(slot, i);
+        }
     }
     if (a.mixpart) {
         if (!active)
@@ -280,7 +330,15 @@ __device__ __noinline__ void tile_track_rd(const Ctx& c, const DevOp& op, const 
 {
     const float* trk = a.tracks + (size_t)op.aux * a.t_stride + t0;  // wave-uniform addresses: every lane gets the same sample
     const int o = op.out_slot[0];
-    for (int i = 0; i < c.n; i++) WIRE(o, i) = trk[i];
+    int i = 0;
+    for (; i + 8 <= c.n; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = trk[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) WIRE(o, i + u) = v[u];
+    }
+    for (; i < c.n; i++) WIRE(o, i) = trk[i];
 }
 
 __device__ __noinline__ void tile_delay_rd(const Ctx& c, const DevOp& op, const KernelArgs& a, uint64_t n_abs, uint32_t voice_c)
@@ -290,7 +348,18 @@ __device__ __noinline__ void tile_delay_rd(const Ctx& c, const DevOp& op, const 
     if (op.flags & DELAY_RING_GLOBAL) {
         const float* ring = a.rings + (size_t)op.aux * B * a.V + voice_c;
         uint32_t p = (uint32_t)(n_abs % B);
-        for (int i = 0; i < c.n; i++) {
+        int i = 0;
+        for (; i + 8 <= c.n; i += 8) {  // 8 ring rows in flight per round trip to HBM / L2
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                v[u] = ring[(size_t)p * a.V];
+                p = p + 1 == B ? 0 : p + 1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) WIRE(o, i + u) = v[u];
+        }
+        for (; i < c.n; i++) {
             WIRE(o, i) = ring[(size_t)p * a.V];
             p = p + 1 == B ? 0 : p + 1;
         }
@@ -336,7 +405,10 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
     const int n_rows = a.prog.n_rows, tile = a.prog.tile;
     dev::Ctx c;
     c.rows = lds;
-    c.wires = reinterpret_cast<float*>(lds + (size_t)n_rows * 64);
+    c.zero = reinterpret_cast<float*>(lds + (size_t)n_rows * 64);
+    c.trash = c.zero + 64;
+    c.wires = c.trash + 64;
+    c.zero[lane] = 0.0f;
     c.tile = tile;
     c.lane = lane;
     c.n = 0;
@@ -348,7 +420,7 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
             const DevOp& op = a.ops[i];
             switch (op.kind) {
             case OP_OSC: dev::tile_osc<kExact>(c, op); break;
-            case OP_VCF: dev::tile_vcf(c, op); break;
+            case OP_VCF: dev::tile_vcf<kExact>(c, op); break;
             case OP_ADSR: dev::tile_adsr(c, op); break;
             case OP_VCA: dev::tile_vca(c, op); break;
             case OP_MIX: dev::tile_mix(c, op); break;
@@ -1070,7 +1142,7 @@ static void launch_fused(uint32_t osc_port, uint32_t vcf_port, bool exact, int o
 
 static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_t st)
 {
-    size_t lds = ((size_t)P.hdr.n_rows + (size_t)P.hdr.n_slots * P.hdr.tile) * 256;
+    size_t lds = ((size_t)P.hdr.n_rows + 2 + (size_t)P.hdr.n_slots * P.hdr.tile) * 256;  // + the zero and trash rows
     if (P.render_flags & SRACK_RENDER_EXACT_OSC)
         hipLaunchKernelGGL(render_interp<true>, dim3(ka.n_waves), dim3(64), lds, st, ka);
     else
