@@ -1,0 +1,124 @@
+// The reference's own two tests, written against the C++ mirror of its API (include/srack.hpp).
+//   test_mirror topo   — synth::tests::topological_sort (src/synth.rs:537-613), CPU only
+//   test_mirror dco    — oscillator::dco_tests::produces_440 (src/synth/oscillator.rs:284-305), needs the GPU
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <random>
+
+#include "../../include/srack.hpp"
+
+using namespace srack;
+
+#define REQUIRE(cond)                                                      \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);  \
+            return 1;                                                      \
+        }                                                                  \
+    } while (0)
+
+static void connect(const SharedSynthModule& src, SharedSynthModule sink)
+{
+    auto inputs = get_inputs(sink);  // first unconnected input (synth.rs:523-535)
+    size_t idx = 0;
+    while (inputs[idx].has_value()) idx++;
+    if (!sink.set_input((uint8_t)idx, src, 0)) throw Error(SRACK_ERR_PORT, "set_input");
+}
+
+static int topological_sort()
+{
+    //     0 -> 1 -> 2 -> 3 -> o
+    //      \----> 4 -----^
+    //        5<->6^
+    AudioConfig ac;
+    ac.buffer_size = 64;
+    ac.sample_rate = 44100;
+    ac.channels = 2;
+    Workspace ws(ac);
+    std::vector<SharedSynthModule> modules;
+    for (int i = 0; i < 7; i++) modules.push_back(ws.add(ModuleType::MonoMixer));
+    SharedSynthModule out = ws.add(ModuleType::Output);
+    connect(modules[0], modules[1]);
+    connect(modules[1], modules[2]);
+    connect(modules[2], modules[3]);
+    connect(modules[3], out);
+    connect(modules[0], modules[4]);
+    connect(modules[4], modules[3]);
+    connect(modules[6], modules[4]);
+    connect(modules[5], modules[6]);
+    connect(modules[6], modules[5]);
+    std::mt19937 rng(12345);
+    for (int iter = 0; iter < 1000; iter++) {
+        std::vector<SharedSynthModule> list(modules), plan;
+        list.push_back(out);
+        std::shuffle(list.begin(), list.end(), rng);
+        plan_execution(ws, out, list, plan);
+        std::map<int, size_t> indexes;
+        for (size_t i = 0; i < plan.size(); i++) indexes[plan[i].index()] = i;
+        auto at = [&](const SharedSynthModule& m) { return indexes.at(m.index()); };
+        REQUIRE(plan.size() == 8);
+        REQUIRE(at(modules[0]) < at(modules[1]));
+        REQUIRE(at(modules[1]) < at(modules[2]));
+        REQUIRE(at(modules[2]) < at(modules[3]));
+        REQUIRE(at(modules[3]) < at(out));
+        REQUIRE(at(modules[0]) < at(modules[4]));
+        REQUIRE(at(modules[4]) < at(modules[3]));
+        REQUIRE(at(modules[6]) < at(modules[4]));
+        REQUIRE(at(modules[5]) < at(modules[6]));
+    }
+    // error behaviour of the trait: Err(()) on a bad port, None for an unconnected input
+    REQUIRE(!modules[0].set_input(9, modules[1], 0));
+    REQUIRE(!modules[0].get_input(9).has_value());
+    REQUIRE(modules[2].get_input(3).has_value() && !modules[2].get_input(3)->has_value());
+    REQUIRE(modules[1].get_input(0)->value().first == modules[0]);
+    REQUIRE(out.get_num_inputs() == 2 && out.get_num_outputs() == 0 && modules[0].get_name() == "Mono Mixer");
+    std::printf("topological_sort ok\n");
+    return 0;
+}
+
+static int produces_440()
+{
+    AudioConfig ac;
+    ac.sample_rate = 440 * 4;
+    ac.buffer_size = 17;  // notice odd sized buffer
+    ac.channels = 2;
+    Workspace ws(ac);
+    SharedSynthModule module = ws.add(ModuleType::Oscillator);
+    SharedSynthModule out = ws.add(ModuleType::Output);
+    REQUIRE(out.set_input(0, module, SRACK_OSC_OUT_SINE));
+    ws.configure_voices(1);
+    REQUIRE(ws.planes() == 1);
+    void* d = nullptr;
+    REQUIRE(srack_device_alloc(&d, 17 * sizeof(float)) == SRACK_OK);
+    float buf[17];
+    ws.execute_batch(17, (float*)d, nullptr);  // module.calc()
+    REQUIRE(srack_device_to_host(buf, d, sizeof(buf), nullptr) == SRACK_OK);
+    REQUIRE(buf[0] == 0.0f);
+    REQUIRE(std::fabs(buf[1] - 1.0f) < 0.00001f);
+    REQUIRE(std::fabs(buf[2]) < 0.00001f);
+    REQUIRE(std::fabs(buf[3] + 1.0f) < 0.00001f);
+    REQUIRE(std::fabs(buf[4]) < 0.00001f);
+    ws.execute_batch(17, (float*)d, nullptr);  // module.calc() again
+    REQUIRE(srack_device_to_host(buf, d, sizeof(buf), nullptr) == SRACK_OK);
+    REQUIRE(std::fabs(buf[0] - 1.0f) < 0.00001f);  // should continue smoothly into next buffer
+    srack_device_free(d);
+    std::printf("produces_440 ok\n");
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    try {
+        if (argc > 1 && !std::strcmp(argv[1], "topo")) return topological_sort();
+        if (argc > 1 && !std::strcmp(argv[1], "dco")) return produces_440();
+    } catch (const Error& e) {
+        std::printf("srack::Error %d: %s\n", e.code, e.what());
+        return 2;
+    }
+    std::printf("usage: test_mirror topo|dco\n");
+    return 3;
+}

@@ -334,3 +334,71 @@ def test_full_size_voices_short_render(S, oracle):
     own = fr[0].astype(np.float64).sum(axis=1)
     scale = np.abs(fr[0].astype(np.float64)).sum(axis=1)
     assert (np.abs(mix[0] - own) <= 1e-5 * np.maximum(scale, 1.0)).all()
+
+
+# ---- edge cases: channel counts, ragged lengths, chunk boundaries, empty renders ----------------------------------
+def test_channel_layouts(S, oracle):
+    """1 and 4 output channels; distinct wires, a shared wire and an unconnected channel."""
+    def build(g, channels):
+        osc, osc2, vcf, out = g.add_module(1), g.add_module(1), g.add_module(2), g.add_module(0)
+        g.set_field(osc2, 0, 0.5)
+        g.connect(osc, 2, vcf, 0)
+        g.connect(vcf, 0, out, 0)
+        if channels == 4:
+            g.connect(osc2, 0, out, 1)   # a second plane
+            g.connect(vcf, 0, out, 3)    # shares channel 0's plane; channel 2 stays unconnected
+    for channels in (1, 4):
+        o, p = oracle.OraclePatch(48000, 256, channels), S.Patch(48000, 256, channels)
+        build(o, channels)
+        build(p, channels)
+        V, T = 70, 900
+        val = np.linspace(-0.3, 0.3, V).astype(np.float32)
+        ref, ref_mix = o.render_batch(V, T, [(0, S.OSC_VAL, val)], mix=True, threads=4)
+        p.configure_voices(V)
+        p.set_voice_field(0, S.OSC_VAL, val)
+        n_planes, cp = p.planes()
+        assert (n_planes, cp) == ((1, [0]) if channels == 1 else (2, [0, 1, -1, 0]))
+        got = p.render_channels(T)
+        assert_close(got, ref)
+        _, mix = p.render(T, frames=False, mix=True)  # continues from the state: compare against the oracle's next T samples
+        ref2, ref_mix2 = o.render_batch(V, 2 * T, [(0, S.OSC_VAL, val)], mix=True, threads=4)
+        scale = np.abs(ref2[:, T:, :].astype(np.float64)).sum(axis=2)
+        assert (np.abs(mix - ref_mix2[:, T:]) <= 2e-5 * np.maximum(scale, 1.0)).all()
+        if channels == 4:
+            assert not got[2].any() and not mix[2].any()
+
+
+@pytest.mark.parametrize("T", [1, 31, 33, 1023, 1025, 3073, 7169])
+def test_ragged_lengths_across_tiles_and_chunks(S, oracle, T):
+    """Lengths around the 32-sample tile and the 1024/2048/4096-sample chunk borders of the pipelined render."""
+    V = 96
+    det, cut = S.p1_voice_params(V, first_voice=99)
+    o = oracle.OraclePatch(48000, 1024, 2)
+    ids = S.build_p1(o, adsr="finite", lfo_val=1.0)
+    ref, _ = o.render_batch(V, T, [(ids["osc_a"], S.OSC_VAL, det), (ids["vcf"], S.VCF_FREQ, cut)], threads=8)
+    for flags in (0, 2):
+        p = S.Patch(48000, 1024, 2)
+        S.build_p1(p, adsr="finite", lfo_val=1.0)
+        p.configure_voices(V)
+        p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+        p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+        assert_close(p.render_channels(T, flags)[0], ref[0])
+
+
+def test_empty_render_and_output_selection(S):
+    p = S.Patch(48000, 64, 2)
+    ids = S.build_p1(p, lfo_val=2.0)
+    p.configure_voices(130)
+    p.render_raw(0)  # zero samples: nothing to do, no device buffers needed
+    fr, mix = p.render(500)
+    fr2, _ = S_render_again(S, frames=True, mix=False)
+    _, mix2 = S_render_again(S, frames=False, mix=True)
+    np.testing.assert_array_equal(fr2, fr)     # frames do not depend on whether the mix is requested
+    np.testing.assert_array_equal(mix2, mix)   # and vice versa
+
+
+def S_render_again(S, frames, mix):
+    p = S.Patch(48000, 64, 2)
+    S.build_p1(p, lfo_val=2.0)
+    p.configure_voices(130)
+    return p.render(500, frames=frames, mix=mix)
