@@ -47,7 +47,8 @@ struct KernelArgs {
     // A launch covers T samples of a render of t_stride samples; frames / mixpart / tracks arrive pre-offset to
     // the launch's first sample and keep the whole render's strides.
     uint64_t plane_stride;  // frames: elements between planes (= t_stride * V)
-    uint32_t t_stride, pad2_;
+    uint32_t t_stride;
+    uint32_t block0;  // blocks [0, block0) of the grid are not voice waves (a co-scheduled control block); wave = blockIdx.x - block0
     uint64_t n0;  // absolute index of this launch's first sample (phase of the feedback rings)
 };
 
@@ -72,7 +73,7 @@ struct WaveMap {   // which voices a wave owns
 SRK_DEV WaveMap wave_map(const KernelArgs& a, int lane)
 {
     WaveMap m;
-    m.wave0 = blockIdx.x * a.lanes;
+    m.wave0 = (blockIdx.x - a.block0) * a.lanes;
     m.n_active = min(a.lanes, a.V - m.wave0);
     m.active = (uint32_t)lane < m.n_active;
     m.voice = m.wave0 + (uint32_t)lane;
@@ -321,7 +322,7 @@ __device__ __noinline__ void tile_out(const Ctx& c, const DevOp& op, const Kerne
             for (int i = 0; i < c.n; i++) WIRE(slot, i) = 0.0f;  // lanes past V contribute nothing
         __syncthreads();
         float sum = tile_row_sum(c.wires + (size_t)slot * c.tile * 64, c.tile, c.lane);
-        if (c.lane < c.n) a.mixpart[((size_t)plane * a.n_waves + blockIdx.x) * a.t_stride + t0 + c.lane] = sum;
+        if (c.lane < c.n) a.mixpart[((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride + t0 + c.lane] = sum;
         __syncthreads();
     }
 }
@@ -491,11 +492,121 @@ SRK_DEV Emit make_emit(const KernelArgs& a, int plane, int lane)
     e.lane = lane;
     e.lane_c = min(lane, (int)e.n_active - 1);
     e.frame_row = a.frames ? a.frames + (size_t)plane * a.plane_stride + wave0 : nullptr;
-    e.mp = a.mixpart ? a.mixpart + ((size_t)plane * a.n_waves + blockIdx.x) * a.t_stride : nullptr;
+    e.mp = a.mixpart ? a.mixpart + ((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride : nullptr;
     e.has_frames = e.frame_row != nullptr;
     e.has_mix = e.mp != nullptr;
     return e;
 }
+
+// ---- fused control chain: OSC (constant pitch) -> ADSR -> track ---------------------------------------------
+// The voice-invariant half of patch P1's shape: one voice, one wave, every lane computes the same numbers.
+// It is a pure latency chain (phase accumulate -> gate -> envelope state machine), so it is kept short: state
+// in VGPRs, the carried-phase oscillator and the segmented ADSR, 64 samples gathered across lanes per store.
+// What the control block needs: a slice of KernelArgs small enough to ride along with a voice kernel's arguments.
+struct CtlWork {
+    const DevOp* ops;
+    uint32_t* table;   // the control program's one-voice table
+    float* track;      // this chunk's first sample of the envelope track
+    uint32_t T;        // samples to produce (0: nothing to do)
+    uint32_t port;     // OSC_OUT_* of the gate oscillator
+};
+
+template <uint32_t kOscPort>
+SRK_DEV void ctl_gate_env_body(const CtlWork& a)
+{
+    using namespace dev;
+    const ChainRoles r{0, 0, 0, 1, 0, 2, 0};  // op order of the matched control program: OSC, ADSR, OUT
+    const int lane = threadIdx.x;
+    auto row = [&](int rr) { return a.table[rr]; };  // V == 1
+    const DevOp& ol = a.ops[r.osc_l];
+    const DevOp& od = a.ops[r.adsr];
+    float* __restrict__ track = a.track;
+
+    COsc cl;
+    cosc_init(cl, make_f64(row(ol.state_row + OSC_S_POS_LO), row(ol.state_row + OSC_S_POS_HI)), ol.delta);
+    AdsrRegs sd;
+    sd.phase = __uint_as_float(row(od.state_row + ADSR_S_PHASE));
+    sd.mode = (int)row(od.state_row + ADSR_S_MODE);
+    sd.r_val = __uint_as_float(row(od.state_row + ADSR_S_R_VAL));
+    sd.from_a_val = __uint_as_float(row(od.state_row + ADSR_S_FROM_A));
+    sd.gate_last = row(od.state_row + ADSR_S_GATE_LAST) != 0;
+    const AdsrConst kd = adsr_consts(od.par_val[ADSR_P_A], od.par_val[ADSR_P_D], od.par_val[ADSR_P_S], od.par_val[ADSR_P_R], od.par_val[ADSR_P_SR]);
+    AdsrSeg seg;
+    adsr_seg_enter(sd, kd, seg);
+
+    // Four samples at a time on the assumption that nothing happens in them: the square stays outside its PolyBLEP
+    // windows (so it is exactly -1/+1) and the envelope stays in its segment.  One scalar test per group instead
+    // of two per sample; when the assumption fails the group is redone one sample at a time (cosc / adsr_seg).
+    float out[4];
+    auto try_group = [&]() -> bool {
+        double pos = cl.pos;
+        float ph = sd.phase;
+        uint64_t last = seg.last, bad = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int hw = __double2hiint(pos);
+            bad |= __builtin_amdgcn_ballot_w64(hw <= cl.hA) | __builtin_amdgcn_ballot_w64(hw >= cl.hB) |
+                   __builtin_amdgcn_ballot_w64((uint32_t)(hw - cl.hQ0) <= cl.hQspan);
+            const uint64_t high = __builtin_amdgcn_ballot_w64(hw >= 0x3fe00000);  // square = +1 > 0  <=>  pos >= 0.5
+            pos = __builtin_amdgcn_fract(pos + cl.delta);
+            ph = ph + seg.inc;
+            bad |= __builtin_amdgcn_ballot_w64(ph >= 1.0f) | (high & seg.on_high) | (~high & seg.on_low) | (high & ~last & seg.on_edge);
+            last = high;
+            out[q] = seg.c0 + seg.c1 * (seg.k0 + seg.k1 * ph);
+        }
+        if (bad != 0) return false;
+        cl.pos = pos;
+        sd.phase = ph;
+        seg.last = last;
+        seg.held = out[3];
+        return true;
+    };
+
+    for (uint32_t t0 = 0; t0 < a.T; t0 += 64) {
+        const int n = (int)min(64u, a.T - t0);
+        float keep_v = 0.0f;  // lane j keeps sample t0 + j
+        int j = 0;
+        while (j < n) {
+            if (kOscPort == OSC_OUT_SQUARE && j + 4 <= n && try_group()) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) keep_v = lane == j + q ? out[q] : keep_v;
+                j += 4;
+                continue;
+            }
+            const int stop = min(n, j + 4);
+            for (; j < stop; j++) {
+                const float gate = cosc_step<kOscPort>(cl);
+                const float env = adsr_seg_step(sd, kd, seg, gate);
+                keep_v = lane == j ? env : keep_v;
+            }
+        }
+        if (lane < n) track[t0 + lane] = keep_v;
+    }
+    adsr_seg_flush(sd, seg);
+    if (lane == 0) {
+        a.table[ol.state_row + OSC_S_POS_LO] = f64_lo(cl.pos);
+        a.table[ol.state_row + OSC_S_POS_HI] = f64_hi(cl.pos);
+        a.table[ol.state_row + OSC_S_SYNC_LAST] = 0u;
+        a.table[od.state_row + ADSR_S_PHASE] = __float_as_uint(sd.phase);
+        a.table[od.state_row + ADSR_S_MODE] = (uint32_t)sd.mode;
+        a.table[od.state_row + ADSR_S_R_VAL] = __float_as_uint(sd.r_val);
+        a.table[od.state_row + ADSR_S_FROM_A] = __float_as_uint(sd.from_a_val);
+        a.table[od.state_row + ADSR_S_GATE_LAST] = sd.gate_last ? 1u : 0u;
+    }
+}
+
+
+SRK_DEV void ctl_gate_env(const CtlWork& w)
+{
+    if (w.port == OSC_OUT_SQUARE)
+        ctl_gate_env_body<OSC_OUT_SQUARE>(w);
+    else if (w.port == OSC_OUT_SAW)
+        ctl_gate_env_body<OSC_OUT_SAW>(w);
+    else
+        ctl_gate_env_body<OSC_OUT_SINE>(w);
+}
+
+__global__ __launch_bounds__(64) void render_ctl_gate_env(CtlWork w) { ctl_gate_env(w); }
 
 // ---- fused voice chain (patch P1's shape) -------------------------------------------------------------
 // OSC_A.<port> -> VCF.<port> -> VCA <- ADSR <- OSC_L.<port>; all wires and all state in VGPRs.
@@ -651,10 +762,16 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
 // OSC_A.<port> -> VCF.<port> -> VCA <- track[t]; the track sample is wave-uniform (scalar load, SGPR operand).
 // The loop body is one basic block: the filter chain of sample t interleaves with the oscillator of t+1.
 template <uint32_t kOscAPort, uint32_t kVcfPort, bool kExact, int kOut>
-__global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, ChainRoles r)
+__global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, ChainRoles r, CtlWork co)
 {
     using namespace dev;
     __shared__ float mix_tile[kMixRows * 64];
+    // Block 0 of a co-scheduled launch is not a voice wave: it computes the NEXT chunk's envelope track while the
+    // voice blocks consume this chunk's (written by the previous launch).  Same stream, no events, no second queue.
+    if (blockIdx.x < a.block0) {
+        ctl_gate_env(co);
+        return;
+    }
     const int lane = threadIdx.x;
     const WaveMap wm = wave_map(a, lane);
     const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
@@ -832,93 +949,6 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
     }
 }
 
-// ---- fused control chain: OSC (constant pitch) -> ADSR -> track ---------------------------------------------
-// The voice-invariant half of patch P1's shape: one voice, one wave, every lane computes the same numbers.
-// It is a pure latency chain (phase accumulate -> gate -> envelope state machine), so it is kept short: state
-// in VGPRs, the carried-phase oscillator and the segmented ADSR, 64 samples gathered across lanes per store.
-template <uint32_t kOscPort>
-__global__ __launch_bounds__(64) void render_ctl_gate_env(KernelArgs a, ChainRoles r)
-{
-    using namespace dev;
-    const int lane = threadIdx.x;
-    auto row = [&](int rr) { return a.table[rr]; };  // V == 1
-    const DevOp& ol = a.ops[r.osc_l];
-    const DevOp& od = a.ops[r.adsr];
-    float* __restrict__ track = a.frames + (size_t)a.ops[r.out].aux * a.plane_stride;
-
-    COsc cl;
-    cosc_init(cl, make_f64(row(ol.state_row + OSC_S_POS_LO), row(ol.state_row + OSC_S_POS_HI)), ol.delta);
-    AdsrRegs sd;
-    sd.phase = __uint_as_float(row(od.state_row + ADSR_S_PHASE));
-    sd.mode = (int)row(od.state_row + ADSR_S_MODE);
-    sd.r_val = __uint_as_float(row(od.state_row + ADSR_S_R_VAL));
-    sd.from_a_val = __uint_as_float(row(od.state_row + ADSR_S_FROM_A));
-    sd.gate_last = row(od.state_row + ADSR_S_GATE_LAST) != 0;
-    const AdsrConst kd = adsr_consts(od.par_val[ADSR_P_A], od.par_val[ADSR_P_D], od.par_val[ADSR_P_S], od.par_val[ADSR_P_R], od.par_val[ADSR_P_SR]);
-    AdsrSeg seg;
-    adsr_seg_enter(sd, kd, seg);
-
-    // Four samples at a time on the assumption that nothing happens in them: the square stays outside its PolyBLEP
-    // windows (so it is exactly -1/+1) and the envelope stays in its segment.  One scalar test per group instead
-    // of two per sample; when the assumption fails the group is redone one sample at a time (cosc / adsr_seg).
-    float out[4];
-    auto try_group = [&]() -> bool {
-        double pos = cl.pos;
-        float ph = sd.phase;
-        uint64_t last = seg.last, bad = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int hw = __double2hiint(pos);
-            bad |= __builtin_amdgcn_ballot_w64(hw <= cl.hA) | __builtin_amdgcn_ballot_w64(hw >= cl.hB) |
-                   __builtin_amdgcn_ballot_w64((uint32_t)(hw - cl.hQ0) <= cl.hQspan);
-            const uint64_t high = __builtin_amdgcn_ballot_w64(hw >= 0x3fe00000);  // square = +1 > 0  <=>  pos >= 0.5
-            pos = __builtin_amdgcn_fract(pos + cl.delta);
-            ph = ph + seg.inc;
-            bad |= __builtin_amdgcn_ballot_w64(ph >= 1.0f) | (high & seg.on_high) | (~high & seg.on_low) | (high & ~last & seg.on_edge);
-            last = high;
-            out[q] = seg.c0 + seg.c1 * (seg.k0 + seg.k1 * ph);
-        }
-        if (bad != 0) return false;
-        cl.pos = pos;
-        sd.phase = ph;
-        seg.last = last;
-        seg.held = out[3];
-        return true;
-    };
-
-    for (uint32_t t0 = 0; t0 < a.T; t0 += 64) {
-        const int n = (int)min(64u, a.T - t0);
-        float keep_v = 0.0f;  // lane j keeps sample t0 + j
-        int j = 0;
-        while (j < n) {
-            if (kOscPort == OSC_OUT_SQUARE && j + 4 <= n && try_group()) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) keep_v = lane == j + q ? out[q] : keep_v;
-                j += 4;
-                continue;
-            }
-            const int stop = min(n, j + 4);
-            for (; j < stop; j++) {
-                const float gate = cosc_step<kOscPort>(cl);
-                const float env = adsr_seg_step(sd, kd, seg, gate);
-                keep_v = lane == j ? env : keep_v;
-            }
-        }
-        if (lane < n) track[t0 + lane] = keep_v;
-    }
-    adsr_seg_flush(sd, seg);
-    if (lane == 0) {
-        a.table[ol.state_row + OSC_S_POS_LO] = f64_lo(cl.pos);
-        a.table[ol.state_row + OSC_S_POS_HI] = f64_hi(cl.pos);
-        a.table[ol.state_row + OSC_S_SYNC_LAST] = 0u;
-        a.table[od.state_row + ADSR_S_PHASE] = __float_as_uint(sd.phase);
-        a.table[od.state_row + ADSR_S_MODE] = (uint32_t)sd.mode;
-        a.table[od.state_row + ADSR_S_R_VAL] = __float_as_uint(sd.r_val);
-        a.table[od.state_row + ADSR_S_FROM_A] = __float_as_uint(sd.from_a_val);
-        a.table[od.state_row + ADSR_S_GATE_LAST] = sd.gate_last ? 1u : 0u;
-    }
-}
-
 // ---- mix-down, passes 2 and 3: mix[c][i] = sum over waves of mixpart[plane(c)][w][i] ---------------------------
 // Deterministic (fixed order, no atomics).  Pass 2 splits the waves into kMixSplit groups so that enough loads
 // are in flight to stream the partials at HBM rate: block (x, y) sums group y for 256 consecutive samples into
@@ -1093,51 +1123,50 @@ static int grow(float*& p, size_t& have, size_t need)
 
 // ---- fused-kernel dispatch (template parameters from runtime port flags) ---------------------------
 template <uint32_t A, uint32_t F, bool E, int O>
-static void launch_fused4(bool track, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
+static void launch_fused4(bool track, const KernelArgs& ka, const ChainRoles& roles, const CtlWork& co, dim3 grid, hipStream_t st)
 {
-    // 8 KiB static mix tile + kLdsPad dynamic = 10 KiB per single-wave workgroup: at most 16 workgroups fit a CU's
-    // 160 KiB, i.e. exactly 4 waves per SIMD.  Without the pad the dispatcher packs up to 20 waves on some CUs and
-    // leaves others short; the over-full CUs then finish last (measured: waves alive only 63 % of the kernel).
-    constexpr size_t kLdsPad = 2048;
     if (track)
-        hipLaunchKernelGGL((render_voice_chain_track<A, F, E, O>), grid, dim3(64), kLdsPad, st, ka, roles);
+        hipLaunchKernelGGL((render_voice_chain_track<A, F, E, O>), grid, dim3(64), 0, st, ka, roles, co);
     else
-        hipLaunchKernelGGL((render_voice_chain<A, OSC_OUT_SQUARE, F, E, O>), grid, dim3(64), kLdsPad, st, ka, roles);
+        hipLaunchKernelGGL((render_voice_chain<A, OSC_OUT_SQUARE, F, E, O>), grid, dim3(64), 0, st, ka, roles);
 }
 
 template <uint32_t A, uint32_t F>
-static void launch_fused3(bool exact, int out_mode, bool track, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
+static void launch_fused3(bool exact, int out_mode, bool track, const KernelArgs& ka, const ChainRoles& roles, const CtlWork& co, dim3 grid, hipStream_t st)
 {
     if (exact)  // exact mode is the validation flavour: one instantiation, output mode decided at run time
-        launch_fused4<A, F, true, 0>(track, ka, roles, grid, st);
+        launch_fused4<A, F, true, 0>(track, ka, roles, co, grid, st);
     else if (out_mode == 3)
-        launch_fused4<A, F, false, 3>(track, ka, roles, grid, st);
+        launch_fused4<A, F, false, 3>(track, ka, roles, co, grid, st);
     else if (out_mode == 1)
-        launch_fused4<A, F, false, 1>(track, ka, roles, grid, st);
-    else
-        launch_fused4<A, F, false, 2>(track, ka, roles, grid, st);
+        launch_fused4<A, F, false, 1>(track, ka, roles, co, grid, st);
+    else if (out_mode == 2)
+        launch_fused4<A, F, false, 2>(track, ka, roles, co, grid, st);
+    else  // neither frames nor mix requested: the render only advances the voice state
+        launch_fused4<A, F, false, 0>(track, ka, roles, co, grid, st);
 }
 
 template <uint32_t A>
-static void launch_fused2(uint32_t vcf_port, bool exact, int out_mode, bool track, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
+static void launch_fused2(uint32_t vcf_port, bool exact, int out_mode, bool track, const KernelArgs& ka, const ChainRoles& roles, const CtlWork& co, dim3 grid,
+                          hipStream_t st)
 {
     if (vcf_port == VCF_OUT_LP)
-        launch_fused3<A, VCF_OUT_LP>(exact, out_mode, track, ka, roles, grid, st);
+        launch_fused3<A, VCF_OUT_LP>(exact, out_mode, track, ka, roles, co, grid, st);
     else if (vcf_port == VCF_OUT_BP)
-        launch_fused3<A, VCF_OUT_BP>(exact, out_mode, track, ka, roles, grid, st);
+        launch_fused3<A, VCF_OUT_BP>(exact, out_mode, track, ka, roles, co, grid, st);
     else
-        launch_fused3<A, VCF_OUT_HP>(exact, out_mode, track, ka, roles, grid, st);
+        launch_fused3<A, VCF_OUT_HP>(exact, out_mode, track, ka, roles, co, grid, st);
 }
 
-static void launch_fused(uint32_t osc_port, uint32_t vcf_port, bool exact, int out_mode, bool track, const KernelArgs& ka, const ChainRoles& roles, dim3 grid,
-                         hipStream_t st)
+static void launch_fused(uint32_t osc_port, uint32_t vcf_port, bool exact, int out_mode, bool track, const KernelArgs& ka, const ChainRoles& roles,
+                         const CtlWork& co, dim3 grid, hipStream_t st)
 {
     if (osc_port == OSC_OUT_SAW)
-        launch_fused2<OSC_OUT_SAW>(vcf_port, exact, out_mode, track, ka, roles, grid, st);
+        launch_fused2<OSC_OUT_SAW>(vcf_port, exact, out_mode, track, ka, roles, co, grid, st);
     else if (osc_port == OSC_OUT_SQUARE)
-        launch_fused2<OSC_OUT_SQUARE>(vcf_port, exact, out_mode, track, ka, roles, grid, st);
+        launch_fused2<OSC_OUT_SQUARE>(vcf_port, exact, out_mode, track, ka, roles, co, grid, st);
     else
-        launch_fused2<OSC_OUT_SINE>(vcf_port, exact, out_mode, track, ka, roles, grid, st);
+        launch_fused2<OSC_OUT_SINE>(vcf_port, exact, out_mode, track, ka, roles, co, grid, st);
 }
 
 static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_t st)
@@ -1152,17 +1181,9 @@ static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_
 static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t st)
 {
     if (Cp.fused == FUSED_CTL_GATE_ENV) {
-        ChainRoles roles{};
-        roles.osc_l = 0;
-        roles.adsr = 1;
-        roles.out = 2;
-        const uint32_t port = Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
-        if (port == OSC_OUT_SQUARE)
-            hipLaunchKernelGGL((render_ctl_gate_env<OSC_OUT_SQUARE>), dim3(1), dim3(64), 0, st, kc, roles);
-        else if (port == OSC_OUT_SAW)
-            hipLaunchKernelGGL((render_ctl_gate_env<OSC_OUT_SAW>), dim3(1), dim3(64), 0, st, kc, roles);
-        else
-            hipLaunchKernelGGL((render_ctl_gate_env<OSC_OUT_SINE>), dim3(1), dim3(64), 0, st, kc, roles);
+        CtlWork w{kc.ops, kc.table, kc.frames + (size_t)Cp.ops[2].aux * kc.plane_stride, kc.T,
+                  Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW)};
+        hipLaunchKernelGGL(render_ctl_gate_env, dim3(1), dim3(64), 0, st, w);
     } else if (Cp.fused == FUSED_FM_PAIR) {
         ChainRoles roles{};
         roles.adsr = 1;
@@ -1219,6 +1240,18 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
     if (d_mix && (rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * T)) != SRACK_OK) return rc;
 
     const bool has_ctl = h.prog.n_tracks > 0;
+    // Two ways to overlap the control program with the voice kernels:
+    //  co-scheduled (fused track kernel + fused gate-envelope control program): voice launch k carries one extra
+    //    block that computes the track of chunk k+1; everything stays on the caller's stream.
+    //  two streams (any other combination): control chunks run on a private stream, voice chunk k waits on event k.
+    //    This overlaps only while the two streams map to different hardware queues (GPU_MAX_HW_QUEUES, default 4,
+    //    shared with the host's other streams): measured 15 ms -> 20 ms per step once RCCL's streams are alive.
+    const bool co_ctl = has_ctl && P.fused == FUSED_VOICE_CHAIN_TRACK && h.prog.ctl.fused == FUSED_CTL_GATE_ENV && h.prog.n_tracks == 1;
+    auto ctl_work = [&](uint32_t t_off, uint32_t len) {
+        const FlatProgram& Cp = h.prog.ctl;
+        return CtlWork{d->ctl.d_ops, d->ctl.d_table, d->d_tracks + (size_t)Cp.ops[2].aux * T + t_off, len,
+                       Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW)};
+    };
     // chunk schedule: short first chunks (only control chunk 0 is exposed), doubling up to kChunkMax
     constexpr uint32_t kChunkFirst = 1024, kChunkMax = 8192;  // multiples of every tile size
     std::vector<std::pair<uint32_t, uint32_t>> chunks;       // (t_off, len)
@@ -1241,8 +1274,11 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         return SRACK_OK;
     };
 
-    if (has_ctl) {
-        if ((rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
+    if (has_ctl && (rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
+    if (co_ctl) {  // chunk 0's track: the only control work that is not hidden (1024 samples, ~0.15 ms)
+        hipLaunchKernelGGL(render_ctl_gate_env, dim3(1), dim3(64), 0, st, ctl_work(chunks[0].first, chunks[0].second));
+        HIP_TRY(hipGetLastError());
+    } else if (has_ctl) {
         if (!d->ctl_stream) HIP_TRY(hipStreamCreateWithFlags(&d->ctl_stream, hipStreamNonBlocking));
         if (!d->ev_begin) HIP_TRY(hipEventCreateWithFlags(&d->ev_begin, hipEventDisableTiming));
         while (d->ev_chunk.size() < n_chunks) {
@@ -1324,13 +1360,18 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         ka.n_waves = n_waves;
         ka.lanes = lanes;
         ka.n0 = h.samples_rendered + t_off;
-        if (has_ctl) HIP_TRY(hipStreamWaitEvent(st, d->ev_chunk[k], 0));
+        CtlWork co{};
+        if (co_ctl && k + 1 < n_chunks) {  // this launch's block 0 prepares the next chunk's track
+            co = ctl_work(chunks[k + 1].first, chunks[k + 1].second);
+            ka.block0 = 1;
+        }
+        if (has_ctl && !co_ctl) HIP_TRY(hipStreamWaitEvent(st, d->ev_chunk[k], 0));
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if ((rc = get_event(e0)) != SRACK_OK || (rc = get_event(e1)) != SRACK_OK) return rc;
         HIP_TRY(hipEventRecord(e0, st));
         if (fused) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
-            if (out_mode != 0) launch_fused(osc_port, vcf_port, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, track, ka, roles, dim3(n_waves), st);
+            launch_fused(osc_port, vcf_port, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, track, ka, roles, co, dim3(n_waves + ka.block0), st);
         } else if (fm_pair) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             if (flags & SRACK_RENDER_EXACT_OSC)
@@ -1341,6 +1382,8 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
                 hipLaunchKernelGGL((render_fm_pair<false, 1>), dim3(n_waves), dim3(64), 0, st, ka, roles);
             else if (out_mode == 2)
                 hipLaunchKernelGGL((render_fm_pair<false, 2>), dim3(n_waves), dim3(64), 0, st, ka, roles);
+            else
+                hipLaunchKernelGGL((render_fm_pair<false, 0>), dim3(n_waves), dim3(64), 0, st, ka, roles);
         } else {
             launch_interp(P, ka, st);
         }

@@ -402,3 +402,21 @@ def S_render_again(S, frames, mix):
     S.build_p1(p, lfo_val=2.0)
     p.configure_voices(130)
     return p.render(500, frames=frames, mix=mix)
+
+
+def test_render_without_outputs_still_advances_state(S):
+    """d_frames = d_mix = NULL is a skip-ahead: state moves exactly as if the frames had been written."""
+    def make():
+        p = S.Patch(48000, 1024, 2)
+        ids = S.build_p1(p, adsr="finite", lfo_val=1.0)
+        p.configure_voices(100)
+        det, cut = S.p1_voice_params(100)
+        p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+        p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+        return p
+    a, b = make(), make()
+    a.render(3000)
+    b.render_raw(3000)  # no outputs
+    fa, _ = a.render(500)
+    fb, _ = b.render(500)
+    np.testing.assert_array_equal(bits(fa), bits(fb))
