@@ -460,7 +460,7 @@ SRK_DEV void emit_put(Emit& e, float* mix_tile, float o, int i, uint32_t V)  // 
     const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
     const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
     if (frames) {
-        e.frame_row[e.lane_c] = o;
+        __builtin_nontemporal_store(o, &e.frame_row[e.lane_c]);  // write-once stream: keep it out of the L2's way
         e.frame_row += V;
     }
     if (mix) mix_tile[i * 64 + e.lane] = o;
