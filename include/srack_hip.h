@@ -53,7 +53,10 @@ enum {
     SRACK_MOD_VCA         = 4, /* vca::VCAModule              src/synth/vca.rs:6-148        */
     SRACK_MOD_MONO_MIXER  = 5, /* mixer::MonoMixerModule      src/synth/mixer.rs:6-122      */
     SRACK_MOD_MATH        = 6, /* math::MathModule            src/synth/math.rs:13-160      */
-    SRACK_MOD__COUNT      = 7
+    /* scope table (f) rank 1: the clocked note sources that sit in front of the path in real patches */
+    SRACK_MOD_GRID_SEQUENCER    = 7, /* sequencer::GridSequencerModule    src/synth/sequencer.rs:12-246   */
+    SRACK_MOD_PATTERN_SEQUENCER = 8, /* sequencer::PatternSequencerModule src/synth/sequencer.rs:336-533 */
+    SRACK_MOD__COUNT      = 9
 };
 
 /* ---- ports (u8 in the reference) --------------------------------------------------------- */
@@ -63,6 +66,9 @@ enum { SRACK_VCF_IN_AUDIO = 0, SRACK_VCF_IN_CV = 1 };                       /* f
 enum { SRACK_VCF_OUT_LOWPASS = 0, SRACK_VCF_OUT_BANDPASS = 1, SRACK_VCF_OUT_HIGHPASS = 2 }; /* filter.rs:166-172 */
 enum { SRACK_ADSR_IN_GATE = 0 };                                            /* adsr.rs:77-82 */
 enum { SRACK_VCA_IN_AUDIO = 0, SRACK_VCA_IN_CV = 1 };                       /* vca.rs:50-56 */
+enum { SRACK_SEQ_IN_STEP = 0, SRACK_SEQ_IN_SYNC = 1 };                      /* sequencer.rs:253-259, 543-549 */
+enum { SRACK_GRIDSEQ_OUT_CV = 0, SRACK_GRIDSEQ_OUT_GATE = 1, SRACK_GRIDSEQ_OUT_SYNC = 2 }; /* sequencer.rs:291-298 */
+enum { SRACK_PATSEQ_OUT_GATE0 = 0, SRACK_PATSEQ_OUT_SYNC = 8 };             /* gates 0..7, then sync (sequencer.rs:578-586) */
 
 /* ---- fields: the serialisable struct members of each module (params AND runtime state) ---- */
 /* Values travel as double (exact for f32, f64, bool, small ints). `mode`: see SRACK_ADSR_MODE_*. */
@@ -94,6 +100,25 @@ enum { SRACK_MIX_GAIN0 = 0, SRACK_MIX_GAIN1 = 1, SRACK_MIX_GAIN2 = 2, SRACK_MIX_
        SRACK_MIX__NFIELDS = 4 };                                            /* mixer.rs:11 */
 enum { SRACK_MATH_CONSTANT = 0, SRACK_MATH_OPERATION = 1, SRACK_MATH__NFIELDS = 2 }; /* math.rs:21-22 */
 enum { SRACK_MATH_ADD = 0, SRACK_MATH_SUBTRACT = 1, SRACK_MATH_MULTIPLY = 2 };       /* math.rs:7-11 */
+enum { /* GridSequencerModule, sequencer.rs:13-30 (the sequence itself: srack_patch_set_step) */
+    SRACK_GRIDSEQ_STEPS_PER_OCTAVE = 0, /* u16, default 12 */
+    SRACK_GRIDSEQ_OCTAVES = 1,          /* u8, UI only */
+    SRACK_GRIDSEQ_LENGTH = 2,           /* sequence.len(), 1..64, default 64 */
+    SRACK_GRIDSEQ_CURRENT_STEP = 3,     /* u16 (state) */
+    SRACK_GRIDSEQ_STEP_LAST = 4,        /* transition_detector.last (state) */
+    SRACK_GRIDSEQ_SYNC_LAST = 5,        /* sync_transition_detector.last (state) */
+    SRACK_GRIDSEQ_LAST = 6,             /* f32: the CV held over empty steps (state) */
+    SRACK_GRIDSEQ__NFIELDS = 7
+};
+enum { /* PatternSequencerModule, sequencer.rs:337-349 */
+    SRACK_PATSEQ_LENGTH = 0,            /* sequence[0].len(), 1..64, default 64 */
+    SRACK_PATSEQ_CURRENT_STEP = 1, SRACK_PATSEQ_STEP_LAST = 2, SRACK_PATSEQ_SYNC_LAST = 3,
+    SRACK_PATSEQ__NFIELDS = 4
+};
+/* step contents for srack_patch_set_step.
+ * Grid: sequence[step] = None | Some((value, hold)) (sequencer.rs:19);  Pattern: sequence[channel][step] = None | Some(false) | Some(true). */
+enum { SRACK_STEP_NONE = 0, SRACK_STEP_ON = 1 /* Some((v,false)) / Some(false): gate follows the clock */,
+       SRACK_STEP_HOLD = 2 /* Some((v,true)) / Some(true): gate held at 1.0 */ };
 
 /* ---- render flags ------------------------------------------------------------------------- */
 enum {
@@ -131,6 +156,11 @@ int srack_module_num_outputs(const srack_patch* p, int module); /* SynthModule::
 /* field access = the struct members egui sliders / serde touch.  Uniform across voices. */
 int srack_patch_set_field(srack_patch* p, int module, int field, double value);
 int srack_patch_get_field(const srack_patch* p, int module, int field, double* value);
+
+/* Sequencer grid cells (the egui grid editors write these, sequencer.rs:137-184, 437-478).
+ * Grid sequencer: channel must be 0, `value` is the note index (u16); pattern sequencer: channel 0..7, value ignored. */
+int srack_patch_set_step(srack_patch* p, int module, int channel, int step, int state, int value);
+int srack_patch_get_step(const srack_patch* p, int module, int channel, int step, int* state, int* value);
 
 /* SynthModule::set_input / disconnect_input / get_input. */
 int srack_patch_connect(srack_patch* p, int src_module, int src_port, int sink_module, int sink_port);

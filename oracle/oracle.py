@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsrack_oracle.so")
 
 # module types / fields: numeric vocabulary of include/srack_hip.h
-MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH = range(7)
+MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH, MOD_GRID_SEQUENCER, MOD_PATTERN_SEQUENCER = range(9)
 
 
 def build(force=False):
@@ -51,6 +51,7 @@ def lib():
         L.or_disconnect.argtypes = [vp, i32, i32]
         L.or_set_field.argtypes = [vp, i32, i32, dbl]
         L.or_get_field.argtypes = [vp, i32, i32, dp]
+        L.or_set_step.argtypes = [vp, i32, i32, i32, i32, i32]
         L.or_plan.argtypes = [vp]
         L.or_plan_list.argtypes = [vp, i32, ip, i32]
         L.or_get_plan.argtypes = [vp, ip, i32]
@@ -107,6 +108,10 @@ class OraclePatch:
     def set_field(self, module, field, value):
         if self.L.or_set_field(self.h, module, field, float(value)) < 0:
             raise ValueError("or_set_field failed")
+
+    def set_step(self, module, channel, step, state, value=0):
+        if self.L.or_set_step(self.h, module, channel, step, state, value) < 0:
+            raise ValueError("or_set_step failed")
 
     def get_field(self, module, field):
         v = C.c_double()

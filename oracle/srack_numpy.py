@@ -273,7 +273,76 @@ class Output(Module):  # output.rs:46-60
                 self.outs[c][:] = ZERO
 
 
-CLASSES = [Output, Oscillator, MoogFilter, ADSR, VCA, MonoMixer, Math]  # index = SRACK_MOD_*
+class _Sequencer(Module):  # the stepping shared by both sequencers: sequencer.rs:219-231, 504-516
+    n_in = 2
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.current_step = 0
+        self.td = TransitionDetector()
+        self.sync_td = TransitionDetector()
+
+    def advance(self, step_in, sync_in, length):
+        if self.td.is_transition(step_in):
+            self.current_step += 1
+        if self.sync_td.is_transition(sync_in):
+            self.current_step = 0
+        cs = self.current_step
+        if cs >= length:
+            self.current_step = 0
+            cs = 0
+        return cs
+
+
+class GridSequencer(_Sequencer):  # sequencer.rs:12-246
+    n_out = 3
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.sequence = [None] * 64  # None | (val, hold)
+        self.steps_per_octave = 12
+        self.octaves = 2
+        self.last = ZERO
+
+    def calc(self):  # sequencer.rs:190-246
+        step_buf, sync_buf = self.resolve(0), self.resolve(1)
+        cv_out, gate_out, sync_out = self.outs
+        for idx in range(len(cv_out)):
+            step_in = step_buf[idx] if step_buf is not None else ZERO
+            sync_in = sync_buf[idx] if sync_buf is not None else ZERO
+            cs = self.advance(step_in, sync_in, len(self.sequence))
+            cell = self.sequence[cs]
+            if cell is not None:
+                val, hold = cell
+                cv_out[idx] = f32(val) * (ONE / f32(self.steps_per_octave))
+                gate_out[idx] = ONE if hold else step_in
+            else:
+                cv_out[idx] = self.last
+                gate_out[idx] = ZERO
+            sync_out[idx] = ONE if cs == 0 else ZERO
+            self.last = cv_out[idx]
+
+
+class PatternSequencer(_Sequencer):  # sequencer.rs:336-533
+    n_out = 9
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.sequence = [[None] * 64 for _ in range(8)]  # None | False | True
+
+    def calc(self):  # sequencer.rs:482-533
+        step_buf, sync_buf = self.resolve(0), self.resolve(1)
+        for idx in range(len(self.outs[0])):
+            step_in = step_buf[idx] if step_buf is not None else ZERO
+            sync_in = sync_buf[idx] if sync_buf is not None else ZERO
+            cs = self.advance(step_in, sync_in, len(self.sequence[0]))
+            for c in range(8):
+                v = self.sequence[c][cs]
+                self.outs[c][idx] = ZERO if v is None else (ONE if v else step_in)
+            self.outs[8][idx] = ONE if cs == 0 else ZERO
+
+
+CLASSES = [Output, Oscillator, MoogFilter, ADSR, VCA, MonoMixer, Math, GridSequencer, PatternSequencer]  # index = SRACK_MOD_*
 
 
 def get_inputs(m):  # synth.rs:214-218

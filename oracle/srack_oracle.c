@@ -12,6 +12,8 @@
  * saw/square/PolyBLEP, the ladder filter, ADSR, VCA, mixer, math and output the reference holds
  * no known-answer vector, so for those "parity unpinned" by the reference: fidelity rests on
  * this file and the independent NumPy restatement (oracle/srack_numpy.py) agreeing bit for bit.
+ * The same holds for the two sequencers (src/synth/sequencer.rs:190-246, 482-533), added as the
+ * scope table's "next" row.
  *
  * Structure follows the reference, not the GPU path: one object graph, per-port block buffers of
  * `buffer_size` f32 (zero-initialised, synth.rs:31-33), module-major execute() (synth.rs:97-101),
@@ -32,7 +34,7 @@
 #include "../include/srack_hip.h" /* enum vocabulary only (module types, fields, ports) */
 
 #define OR_MAX_IN 8
-#define OR_MAX_OUT 8
+#define OR_MAX_OUT 9  /* PatternSequencerModule: 8 gates + sync */
 
 typedef struct {
     int src; /* module index, -1 = None */
@@ -75,6 +77,18 @@ typedef struct {
     or_transition_detector td;
 } or_adsr;
 
+/* sequencer.rs:13-30 (grid) and 337-349 (pattern); grid uses channel 0 of `present/hold` plus `val` */
+typedef struct {
+    int length;            /* sequence.len() / sequence[0].len() */
+    int steps_per_octave, octaves;
+    uint16_t val[64];      /* grid: Some((val, _)) */
+    uint8_t present[8][64];/* != None */
+    uint8_t hold[8][64];   /* grid: Some((_, hold)); pattern: Some(true) */
+    uint16_t current_step;
+    or_transition_detector td, sync_td;
+    float last;
+} or_seq;
+
 typedef struct {
     int type;
     int n_in, n_out;
@@ -87,6 +101,7 @@ typedef struct {
         struct { int negative; } vca;
         struct { float gain[4]; } mix;
         struct { float constant; int operation; } math;
+        or_seq seq;
     } u;
 } or_module;
 
@@ -195,6 +210,22 @@ int or_add_module(or_patch* p, int type)
         m->u.math.constant = 0.0f;
         m->u.math.operation = SRACK_MATH_ADD;
         break;
+    case SRACK_MOD_GRID_SEQUENCER: /* sequencer.rs:33-50 */
+        m->n_in = 2;
+        m->n_out = 3;
+        m->u.seq.length = 64;
+        m->u.seq.octaves = 2;
+        m->u.seq.steps_per_octave = 12;
+        m->u.seq.td.last = 1;
+        m->u.seq.sync_td.last = 1;
+        break;
+    case SRACK_MOD_PATTERN_SEQUENCER: /* sequencer.rs:352-368 */
+        m->n_in = 2;
+        m->n_out = 9;
+        m->u.seq.length = 64;
+        m->u.seq.td.last = 1;
+        m->u.seq.sync_td.last = 1;
+        break;
     default:
         return -1;
     }
@@ -274,6 +305,9 @@ static float* or_field_f32(or_module* m, int field)
     case SRACK_MOD_MATH:
         if (field == SRACK_MATH_CONSTANT) return &m->u.math.constant;
         break;
+    case SRACK_MOD_GRID_SEQUENCER:
+        if (field == SRACK_GRIDSEQ_LAST) return &m->u.seq.last;
+        break;
     }
     return NULL;
 }
@@ -295,8 +329,40 @@ static int* or_field_int(or_module* m, int field)
     case SRACK_MOD_MATH:
         if (field == SRACK_MATH_OPERATION) return &m->u.math.operation;
         break;
+    case SRACK_MOD_GRID_SEQUENCER:
+        if (field == SRACK_GRIDSEQ_STEPS_PER_OCTAVE) return &m->u.seq.steps_per_octave;
+        if (field == SRACK_GRIDSEQ_OCTAVES) return &m->u.seq.octaves;
+        if (field == SRACK_GRIDSEQ_LENGTH) return &m->u.seq.length;
+        if (field == SRACK_GRIDSEQ_STEP_LAST) return &m->u.seq.td.last;
+        if (field == SRACK_GRIDSEQ_SYNC_LAST) return &m->u.seq.sync_td.last;
+        break;
+    case SRACK_MOD_PATTERN_SEQUENCER:
+        if (field == SRACK_PATSEQ_LENGTH) return &m->u.seq.length;
+        if (field == SRACK_PATSEQ_STEP_LAST) return &m->u.seq.td.last;
+        if (field == SRACK_PATSEQ_SYNC_LAST) return &m->u.seq.sync_td.last;
+        break;
     }
     return NULL;
+}
+
+static int or_is_current_step_field(const or_module* m, int field)
+{
+    return (m->type == SRACK_MOD_GRID_SEQUENCER && field == SRACK_GRIDSEQ_CURRENT_STEP) ||
+           (m->type == SRACK_MOD_PATTERN_SEQUENCER && field == SRACK_PATSEQ_CURRENT_STEP);
+}
+
+/* a grid cell: state 0 = None, 1 = Some((value,false)) / Some(false), 2 = Some((value,true)) / Some(true) */
+int or_set_step(or_patch* p, int module, int channel, int step, int state, int value)
+{
+    if (module < 0 || module >= p->n_modules) return -1;
+    or_module* m = &p->modules[module];
+    int grid = m->type == SRACK_MOD_GRID_SEQUENCER;
+    if (!grid && m->type != SRACK_MOD_PATTERN_SEQUENCER) return -1;
+    if (step < 0 || step >= 64 || channel < 0 || channel >= (grid ? 1 : 8) || state < 0 || state > 2) return -1;
+    m->u.seq.present[channel][step] = state != 0;
+    m->u.seq.hold[channel][step] = state == 2;
+    if (grid) m->u.seq.val[step] = (uint16_t)value;
+    return 0;
 }
 
 int or_set_field(or_patch* p, int module, int field, double value)
@@ -309,6 +375,7 @@ int or_set_field(or_patch* p, int module, int field, double value)
     if (f) { *f = (float)value; return 0; }
     int* i = or_field_int(m, field);
     if (i) { *i = (int)value; return 0; }
+    if (or_is_current_step_field(m, field)) { m->u.seq.current_step = (uint16_t)value; return 0; }
     return -1;
 }
 
@@ -322,6 +389,7 @@ int or_get_field(or_patch* p, int module, int field, double* value)
     if (f) { *value = (double)*f; return 0; }
     int* i = or_field_int(m, field);
     if (i) { *value = (double)*i; return 0; }
+    if (or_is_current_step_field(m, field)) { *value = (double)m->u.seq.current_step; return 0; }
     return -1;
 }
 
@@ -703,6 +771,57 @@ static void or_calc_math(or_patch* p, or_module* m)
         out[i] = or_math_op(m->u.math.operation, i1 ? i1[i] : 0.0f, i2 ? i2[i] : m->u.math.constant);
 }
 
+/* the stepping both sequencers share: sequencer.rs:219-231 and 504-516 */
+static int or_seq_advance(or_seq* q, float step_in, float sync_in)
+{
+    if (or_is_transition(&q->td, step_in)) q->current_step += 1;
+    if (or_is_transition(&q->sync_td, sync_in)) q->current_step = 0;
+    int current_step = (int)q->current_step;
+    if (current_step >= q->length) {
+        q->current_step = 0;
+        current_step = 0;
+    }
+    return current_step;
+}
+
+/* GridSequencerModule::calc, sequencer.rs:190-246 */
+static void or_calc_gridseq(or_patch* p, or_module* m)
+{
+    or_seq* q = &m->u.seq;
+    const float* step_buf = or_resolve(p, m, 0);
+    const float* sync_buf = or_resolve(p, m, 1);
+    float *cv_out = m->out[0], *gate_out = m->out[1], *sync_out = m->out[2];
+    for (uint32_t idx = 0; idx < p->buffer_size; idx++) {
+        float step_in = step_buf ? step_buf[idx] : 0.0f;
+        float sync_in = sync_buf ? sync_buf[idx] : 0.0f;
+        int cs = or_seq_advance(q, step_in, sync_in);
+        if (q->present[0][cs]) {
+            cv_out[idx] = (float)q->val[cs] * (1.0f / (float)(uint16_t)q->steps_per_octave);
+            gate_out[idx] = q->hold[0][cs] ? 1.0f : step_in;
+        } else {
+            cv_out[idx] = q->last;
+            gate_out[idx] = 0.0f;
+        }
+        sync_out[idx] = cs == 0 ? 1.0f : 0.0f;
+        q->last = cv_out[idx];
+    }
+}
+
+/* PatternSequencerModule::calc, sequencer.rs:482-533 */
+static void or_calc_patseq(or_patch* p, or_module* m)
+{
+    or_seq* q = &m->u.seq;
+    const float* step_buf = or_resolve(p, m, 0);
+    const float* sync_buf = or_resolve(p, m, 1);
+    for (uint32_t idx = 0; idx < p->buffer_size; idx++) {
+        float step_in = step_buf ? step_buf[idx] : 0.0f;
+        float sync_in = sync_buf ? sync_buf[idx] : 0.0f;
+        int cs = or_seq_advance(q, step_in, sync_in);
+        for (int c = 0; c < 8; c++) m->out[c][idx] = q->present[c][cs] ? (q->hold[c][cs] ? 1.0f : step_in) : 0.0f;
+        m->out[8][idx] = cs == 0 ? 1.0f : 0.0f;
+    }
+}
+
 /* output.rs:46-60 */
 static void or_calc_output(or_patch* p, or_module* m)
 {
@@ -725,6 +844,8 @@ static void or_calc(or_patch* p, or_module* m)
     case SRACK_MOD_VCA: or_calc_vca(p, m); break;
     case SRACK_MOD_MONO_MIXER: or_calc_mixer(p, m); break;
     case SRACK_MOD_MATH: or_calc_math(p, m); break;
+    case SRACK_MOD_GRID_SEQUENCER: or_calc_gridseq(p, m); break;
+    case SRACK_MOD_PATTERN_SEQUENCER: or_calc_patseq(p, m); break;
     }
 }
 

@@ -23,7 +23,7 @@ RENDER_DEFAULT, RENDER_EXACT_OSC, RENDER_NO_FUSION, RENDER_NO_UNIFORM_HOIST = 0,
 ABI_SYMBOLS = [
     "srack_abi_version", "srack_last_error", "srack_patch_create", "srack_patch_destroy", "srack_patch_add_module",
     "srack_patch_num_modules", "srack_patch_module_type", "srack_module_num_inputs", "srack_module_num_outputs",
-    "srack_patch_set_field", "srack_patch_get_field", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
+    "srack_patch_set_field", "srack_patch_get_field", "srack_patch_set_step", "srack_patch_get_step", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
     "srack_patch_plan", "srack_patch_plan_list", "srack_patch_removed_edges", "srack_patch_delayed_edges",
     "srack_voices_configure", "srack_voices_set_field_f32", "srack_voices_set_field_f64", "srack_render_planes", "srack_render",
     "srack_render_info", "srack_render_kernel_ms", "srack_voices_get_field", "srack_device_count", "srack_device_set",
@@ -55,6 +55,8 @@ def _load():
     L.srack_module_num_outputs.argtypes = [vp, i32]
     L.srack_patch_set_field.argtypes = [vp, i32, i32, dbl]
     L.srack_patch_get_field.argtypes = [vp, i32, i32, dp]
+    L.srack_patch_set_step.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.srack_patch_get_step.argtypes = [vp, i32, i32, i32, ip, ip]
     L.srack_patch_connect.argtypes = [vp, i32, i32, i32, i32]
     L.srack_patch_disconnect.argtypes = [vp, i32, i32]
     L.srack_patch_get_input.argtypes = [vp, i32, i32, ip, ip]
@@ -138,6 +140,14 @@ class Patch:
         v = C.c_double()
         _check(lib.srack_patch_get_field(self.h, module, field, C.byref(v)))
         return v.value
+
+    def set_step(self, module, channel, step, state, value=0):
+        _check(lib.srack_patch_set_step(self.h, module, channel, step, state, value))
+
+    def get_step(self, module, channel, step):
+        st, v = C.c_int(), C.c_int()
+        _check(lib.srack_patch_get_step(self.h, module, channel, step, C.byref(st), C.byref(v)))
+        return st.value, v.value
 
     def connect(self, src, src_port, sink, sink_port):
         _check(lib.srack_patch_connect(self.h, src, src_port, sink, sink_port))

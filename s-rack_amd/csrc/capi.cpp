@@ -149,6 +149,18 @@ int srack_patch_get_field(const srack_patch* p, int module, int field, double* v
     return p->h.graph.get_field(module, field, value);
 }
 
+int srack_patch_set_step(srack_patch* p, int module, int channel, int step, int state, int value)
+{
+    CHECK_HANDLE(p);
+    return p->h.graph.set_step(module, channel, step, state, value);
+}
+
+int srack_patch_get_step(const srack_patch* p, int module, int channel, int step, int* state, int* value)
+{
+    CHECK_HANDLE(p);
+    return p->h.graph.get_step(module, channel, step, state, value);
+}
+
 int srack_patch_connect(srack_patch* p, int src_module, int src_port, int sink_module, int sink_port)
 {
     CHECK_HANDLE(p);

@@ -55,6 +55,7 @@ DevOp blank_op(int kind, int module)
     op.module = module;
     op.state_row = -1;
     op.delta_row = -1;
+    op.seq_row = -1;
     for (int j = 0; j < kMaxIn; j++) op.in_slot[j] = -1;
     for (int j = 0; j < kMaxOut; j++) op.out_slot[j] = -1;
     for (int j = 0; j < kMaxPar; j++) op.par_row[j] = -1;
@@ -181,6 +182,7 @@ int Builder::build()
 
     std::map<std::pair<int, int>, int> wire_of;  // (module, port) -> wire id; in_slot / out_slot hold WIRE ids until the scan
     std::vector<std::pair<int, const VoiceOverride*>> deferred, deferred_delta;
+    std::vector<int> seq_ops;  // sequencer ops: each gets one read-only row to stage its 64 cells in
     auto new_wire = [&](int def_op) {
         wires.push_back(Wire{def_op, def_op, -1});
         return (int)wires.size() - 1;
@@ -325,6 +327,26 @@ int Builder::build()
             op.flags |= ((uint32_t)(int)field(m, SRACK_MATH_OPERATION) & 3u) << MATH_OP_SHIFT;
             param(op, MATH_P_CONST, m, SRACK_MATH_CONSTANT, deferred);
             break;
+        case SRACK_MOD_GRID_SEQUENCER:
+        case SRACK_MOD_PATTERN_SEQUENCER: {
+            const bool grid = mod.type == SRACK_MOD_GRID_SEQUENCER;
+            op.kind = grid ? OP_GRIDSEQ : OP_PATSEQ;
+            op.flags = pl & 0x1ffu;  // which output ports are read
+            if (connected(0)) op.flags |= SEQ_HAS_STEP;
+            if (connected(1)) op.flags |= SEQ_HAS_SYNC;
+            op.state_row = state_row_flag(m, grid ? SRACK_GRIDSEQ_CURRENT_STEP : SRACK_PATSEQ_CURRENT_STEP);
+            state_row_flag(m, grid ? SRACK_GRIDSEQ_STEP_LAST : SRACK_PATSEQ_STEP_LAST);
+            state_row_flag(m, grid ? SRACK_GRIDSEQ_SYNC_LAST : SRACK_PATSEQ_SYNC_LAST);
+            if (grid) {
+                state_row_f32(m, SRACK_GRIDSEQ_LAST);
+                param(op, GRIDSEQ_P_SPO, m, SRACK_GRIDSEQ_STEPS_PER_OCTAVE, deferred);
+            }
+            op.seq_len = (int)field(m, grid ? SRACK_GRIDSEQ_LENGTH : SRACK_PATSEQ_LENGTH);
+            op.aux = (int)out.seqtab.size();
+            out.seqtab.insert(out.seqtab.end(), mod.cells.begin(), mod.cells.end());
+            seq_ops.push_back(oi);
+            break;
+        }
         case SRACK_MOD_OUTPUT:
             op.kind = OP_OUT;
             break;
@@ -426,6 +448,11 @@ int Builder::build()
         std::vector<double> delta(V);
         for (uint32_t v = 0; v < V; v++) delta[v] = 440.0 * std::pow(2.0, (double)(float)d.second->values[v]) / op.sample_rate;
         op.delta_row = rows_f64(&delta, 0.0);
+    }
+    for (int oi : seq_ops) {  // contents are written by the tile function; the row only reserves LDS
+        int r = new_row();
+        rows[(size_t)r].assign(V, 0u);
+        out.ops[(size_t)oi].seq_row = r;
     }
     H.n_rows = (int)rows.size();
 
@@ -587,6 +614,14 @@ StateLoc FlatProgram::locate(const Graph& g, int module, int field) const
         else
             loc.row = op.state_row + VCF_S_FREQ + (field - SRACK_VCF_ST_FREQ);
         break;
+    case SRACK_MOD_GRID_SEQUENCER:
+        loc.row = op.state_row + (field - SRACK_GRIDSEQ_CURRENT_STEP);
+        loc.flag = field != SRACK_GRIDSEQ_LAST;
+        break;
+    case SRACK_MOD_PATTERN_SEQUENCER:
+        loc.row = op.state_row + (field - SRACK_PATSEQ_CURRENT_STEP);
+        loc.flag = true;
+        break;
     case SRACK_MOD_ADSR:
         switch (field) {
         case SRACK_ADSR_PHASE: loc.row = op.state_row + ADSR_S_PHASE; break;
@@ -615,8 +650,10 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             return SRACK_ERR_INVALID;
         }
         int type = g.modules[(size_t)o.module].type;
-        if ((type == SRACK_MOD_OSCILLATOR && o.field == SRACK_OSC_ANTIALIASING) || (type == SRACK_MOD_MATH && o.field == SRACK_MATH_OPERATION)) {
-            set_error("flatten: antialiasing / operation select code paths and cannot differ per voice");
+        if ((type == SRACK_MOD_OSCILLATOR && o.field == SRACK_OSC_ANTIALIASING) || (type == SRACK_MOD_MATH && o.field == SRACK_MATH_OPERATION) ||
+            (type == SRACK_MOD_GRID_SEQUENCER && (o.field == SRACK_GRIDSEQ_LENGTH || o.field == SRACK_GRIDSEQ_OCTAVES)) ||
+            (type == SRACK_MOD_PATTERN_SEQUENCER && o.field == SRACK_PATSEQ_LENGTH)) {
+            set_error("flatten: antialiasing / operation / sequence length are structural and cannot differ per voice");
             return SRACK_ERR_UNSUPPORTED;
         }
     }

@@ -19,6 +19,8 @@ int Graph::fields_of_type(int type)
     case SRACK_MOD_VCA: return SRACK_VCA__NFIELDS;
     case SRACK_MOD_MONO_MIXER: return SRACK_MIX__NFIELDS;
     case SRACK_MOD_MATH: return SRACK_MATH__NFIELDS;
+    case SRACK_MOD_GRID_SEQUENCER: return SRACK_GRIDSEQ__NFIELDS;
+    case SRACK_MOD_PATTERN_SEQUENCER: return SRACK_PATSEQ__NFIELDS;
     default: return -1;
     }
 }
@@ -31,6 +33,8 @@ bool Graph::field_is_state(int type, int field)
     case SRACK_MOD_ADSR:
         return field == SRACK_ADSR_PHASE || field == SRACK_ADSR_MODE || field == SRACK_ADSR_R_VAL || field == SRACK_ADSR_FROM_A_VAL ||
                field == SRACK_ADSR_GATE_LAST;
+    case SRACK_MOD_GRID_SEQUENCER: return field >= SRACK_GRIDSEQ_CURRENT_STEP;
+    case SRACK_MOD_PATTERN_SEQUENCER: return field >= SRACK_PATSEQ_CURRENT_STEP;
     default: return false;
     }
 }
@@ -44,6 +48,8 @@ bool Graph::field_is_flag(int type, int field)
     case SRACK_MOD_ADSR: return field == SRACK_ADSR_MODE || field == SRACK_ADSR_GATE_LAST;
     case SRACK_MOD_VCA: return field == SRACK_VCA_NEGATIVE;
     case SRACK_MOD_MATH: return field == SRACK_MATH_OPERATION;
+    case SRACK_MOD_GRID_SEQUENCER: return field != SRACK_GRIDSEQ_LAST;  // integers and detector bits; `last` is an f32
+    case SRACK_MOD_PATTERN_SEQUENCER: return true;
     default: return false;
     }
 }
@@ -104,6 +110,24 @@ int Graph::add_module(int type)
         m.n_out = 1;
         m.fields[SRACK_MATH_OPERATION] = SRACK_MATH_ADD;
         break;
+    case SRACK_MOD_GRID_SEQUENCER:  // sequencer.rs:33-50: sequence = vec![None; 64], octaves 2, steps_per_octave 12
+        m.n_in = 2;
+        m.n_out = 3;
+        m.fields[SRACK_GRIDSEQ_STEPS_PER_OCTAVE] = 12;
+        m.fields[SRACK_GRIDSEQ_OCTAVES] = 2;
+        m.fields[SRACK_GRIDSEQ_LENGTH] = 64;
+        m.fields[SRACK_GRIDSEQ_STEP_LAST] = 1.0;  // both TransitionDetectors start at `true`
+        m.fields[SRACK_GRIDSEQ_SYNC_LAST] = 1.0;
+        m.cells.assign(64, 0u);
+        break;
+    case SRACK_MOD_PATTERN_SEQUENCER:  // sequencer.rs:352-368: 8 gate outputs + sync, sequence = vec![vec![None; 64]; 8]
+        m.n_in = 2;
+        m.n_out = 9;
+        m.fields[SRACK_PATSEQ_LENGTH] = 64;
+        m.fields[SRACK_PATSEQ_STEP_LAST] = 1.0;
+        m.fields[SRACK_PATSEQ_SYNC_LAST] = 1.0;
+        m.cells.assign(64, 0u);
+        break;
     }
     m.in.assign((size_t)m.n_in, InputRef{});
     modules.push_back(std::move(m));
@@ -126,6 +150,12 @@ int Graph::set_field(int module, int field, double value)
         return SRACK_ERR_INVALID;
     }
     Module& m = modules[(size_t)module];
+    if ((m.type == SRACK_MOD_GRID_SEQUENCER && field == SRACK_GRIDSEQ_LENGTH) || (m.type == SRACK_MOD_PATTERN_SEQUENCER && field == SRACK_PATSEQ_LENGTH)) {
+        if (!(value >= 1.0 && value <= 64.0)) {  // the UI keeps 2..64 (sequencer.rs:101-131); an empty sequence would index out of bounds
+            set_error("set_field: sequence length must be 1..64");
+            return SRACK_ERR_INVALID;
+        }
+    }
     if (field_is_f64(m.type, field))
         m.fields[(size_t)field] = value;
     else if (field_is_flag(m.type, field))
@@ -144,6 +174,57 @@ int Graph::get_field(int module, int field, double* value) const
         return SRACK_ERR_INVALID;
     }
     *value = modules[(size_t)module].fields[(size_t)field];
+    return SRACK_OK;
+}
+
+// A grid cell of a sequencer (what the egui editors toggle, sequencer.rs:137-184, 437-478).
+int Graph::set_step(int module, int channel, int step, int state, int value)
+{
+    if (module < 0 || module >= (int)modules.size()) {
+        set_error("set_step: no such module");
+        return SRACK_ERR_INVALID;
+    }
+    Module& m = modules[(size_t)module];
+    const bool grid = m.type == SRACK_MOD_GRID_SEQUENCER;
+    if ((!grid && m.type != SRACK_MOD_PATTERN_SEQUENCER) || step < 0 || step >= 64 || channel < 0 || channel >= (grid ? 1 : 8) || state < 0 ||
+        state > SRACK_STEP_HOLD || value < 0 || value > 65535) {
+        set_error("set_step: not a sequencer, or channel / step / state / value out of range");
+        return SRACK_ERR_INVALID;
+    }
+    uint32_t& cell = m.cells[(size_t)step];
+    if (grid) {
+        cell = state == SRACK_STEP_NONE ? 0u : (0x80000000u | (state == SRACK_STEP_HOLD ? 0x40000000u : 0u) | (uint32_t)value);
+    } else {
+        cell &= ~(3u << (2 * channel));
+        if (state != SRACK_STEP_NONE) cell |= (1u | (state == SRACK_STEP_HOLD ? 2u : 0u)) << (2 * channel);
+    }
+    revision++;
+    return SRACK_OK;
+}
+
+int Graph::get_step(int module, int channel, int step, int* state, int* value) const
+{
+    if (module < 0 || module >= (int)modules.size()) {
+        set_error("get_step: no such module");
+        return SRACK_ERR_INVALID;
+    }
+    const Module& m = modules[(size_t)module];
+    const bool grid = m.type == SRACK_MOD_GRID_SEQUENCER;
+    if ((!grid && m.type != SRACK_MOD_PATTERN_SEQUENCER) || step < 0 || step >= 64 || channel < 0 || channel >= (grid ? 1 : 8)) {
+        set_error("get_step: not a sequencer, or channel / step out of range");
+        return SRACK_ERR_INVALID;
+    }
+    const uint32_t cell = m.cells[(size_t)step];
+    int st, v = 0;
+    if (grid) {
+        st = !(cell & 0x80000000u) ? SRACK_STEP_NONE : ((cell & 0x40000000u) ? SRACK_STEP_HOLD : SRACK_STEP_ON);
+        v = (int)(cell & 0xffffu);
+    } else {
+        const uint32_t b = (cell >> (2 * channel)) & 3u;
+        st = !(b & 1u) ? SRACK_STEP_NONE : ((b & 2u) ? SRACK_STEP_HOLD : SRACK_STEP_ON);
+    }
+    if (state) *state = st;
+    if (value) *value = v;
     return SRACK_OK;
 }
 

@@ -29,6 +29,9 @@ struct Module {
     int n_in = 0, n_out = 0;
     std::vector<InputRef> in;
     std::vector<double> fields;  // indexed by the SRACK_<TYPE>_* field enums
+    // sequencers: 64 grid cells in device format.  Grid: bit 31 present, bit 30 hold, bits 0..15 note value;
+    // pattern: bits 2c / 2c+1 = present / hold of channel c.
+    std::vector<uint32_t> cells;
 };
 
 struct AudioConfig {  // synth.rs:20-25
@@ -60,6 +63,8 @@ public:
     int num_fields(int module) const;
     int set_field(int module, int field, double value);
     int get_field(int module, int field, double* value) const;
+    int set_step(int module, int channel, int step, int state, int value);
+    int get_step(int module, int channel, int step, int* state, int* value) const;
     int connect(int src, int src_port, int sink, int sink_port);
     int disconnect(int sink, int sink_port);
 

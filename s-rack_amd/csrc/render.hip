@@ -42,6 +42,7 @@ struct KernelArgs {
     float* frames;
     float* mixpart;
     const float* tracks;  // control tracks [n_tracks][t_stride] written by the control program (may be null)
+    const uint32_t* seqtab;  // sequencer grids, 64 cells per sequencer op
     uint32_t V, T, n_waves;
     uint32_t lanes;  // voices per wave: 64, or 32 / 16 when there are too few voices to fill the SIMDs (idle lanes shadow the wave's last voice)
     // A launch covers T samples of a render of t_stride samples; frames / mixpart / tracks arrive pre-offset to
@@ -286,6 +287,72 @@ __device__ __noinline__ void tile_math(const Ctx& c, const DevOp& op)
     tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = math_step(fl, x[0], x[1], constant); });
 }
 
+// Sequencers (sequencer.rs:190-246, 482-533).  The 64 grid cells are wave-shared data: staged once per tile in an LDS
+// row indexed by STEP (not by lane); every lane then gathers the cell of its own current_step.
+struct SeqRegs {
+    uint32_t current_step;
+    bool step_last, sync_last;
+};
+
+SRK_DEV uint32_t seq_advance(SeqRegs& s, float step_in, float sync_in, uint32_t length)
+{
+    if (rising_edge(s.step_last, step_in)) s.current_step = (s.current_step + 1u) & 0xffffu;  // u16 in the reference
+    if (rising_edge(s.sync_last, sync_in)) s.current_step = 0u;
+    uint32_t cs = s.current_step;
+    if (cs >= length) {
+        s.current_step = 0u;
+        cs = 0u;
+    }
+    return cs;
+}
+
+__device__ __noinline__ void tile_seq(const Ctx& c, const DevOp& op, const KernelArgs& a)
+{
+    const int sr = op.state_row;
+    SeqRegs s;
+    s.current_step = ROW(sr + SEQ_S_CURRENT);
+    s.step_last = ROW(sr + SEQ_S_STEP_LAST) != 0;
+    s.sync_last = ROW(sr + SEQ_S_SYNC_LAST) != 0;
+    __syncthreads();
+    c.rows[op.seq_row * 64 + c.lane] = a.seqtab[op.aux + c.lane];
+    __syncthreads();
+    const uint32_t* cells = c.rows + op.seq_row * 64;
+    const uint32_t length = (uint32_t)op.seq_len;
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    if (op.kind == OP_GRIDSEQ) {
+        float last = __uint_as_float(ROW(sr + GRIDSEQ_S_LAST));
+        const float inv_spo = 1.0f / par(c, op, GRIDSEQ_P_SPO);  // 1.0 / steps_per_octave as f32 (sequencer.rs:236)
+        const Port out[3] = {out_port(c, op.out_slot[0]), out_port(c, op.out_slot[1]), out_port(c, op.out_slot[2])};
+        tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
+            const uint32_t cs = seq_advance(s, x[0], x[1], length);
+            const uint32_t cell = cells[cs];
+            const bool present = cell & 0x80000000u, hold = cell & 0x40000000u;
+            y[0] = present ? (float)(cell & 0xffffu) * inv_spo : last;
+            y[1] = present ? (hold ? 1.0f : x[0]) : 0.0f;
+            y[2] = cs == 0u ? 1.0f : 0.0f;
+            last = y[0];
+        });
+        ROW(sr + GRIDSEQ_S_LAST) = __float_as_uint(last);
+    } else {
+        Port out[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = out_port(c, op.out_slot[k]);
+        tile_run<2, 9>(c, in, out, [&](const float* x, float* y) {
+            const uint32_t cs = seq_advance(s, x[0], x[1], length);
+            const uint32_t cell = cells[cs];
+#pragma unroll
+            for (int ch = 0; ch < 8; ch++) {
+                const uint32_t b = (cell >> (2 * ch)) & 3u;
+                y[ch] = (b & 1u) ? ((b & 2u) ? 1.0f : x[0]) : 0.0f;
+            }
+            y[8] = cs == 0u ? 1.0f : 0.0f;
+        });
+    }
+    ROW(sr + SEQ_S_CURRENT) = s.current_step;
+    ROW(sr + SEQ_S_STEP_LAST) = s.step_last ? 1u : 0u;
+    ROW(sr + SEQ_S_SYNC_LAST) = s.sync_last ? 1u : 0u;
+}
+
 // Sum an LDS tile [rows_in_tile][64] over the 64 lanes: lane l owns row l % R and the column
 // segment l / R (R = tile capacity, a power of two <= 64); columns are visited skewed by the row
 // so the 32 lanes of a half-wave hit 32 different banks.  Result valid in lanes < R.
@@ -428,6 +495,8 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
             case OP_MATH: dev::tile_math(c, op); break;
             case OP_OUT: dev::tile_out(c, op, a, t0, voice, active); break;
             case OP_TRACK_RD: dev::tile_track_rd(c, op, a, t0); break;
+            case OP_GRIDSEQ:
+            case OP_PATSEQ: dev::tile_seq(c, op, a); break;
             case OP_DELAY_RD: dev::tile_delay_rd(c, op, a, a.n0 + t0, voice_c); break;
             case OP_DELAY_WR: dev::tile_delay_wr(c, op, a, a.n0 + t0, voice, active); break;
             default: break;
@@ -1021,11 +1090,14 @@ struct DevProg {  // device copy of one FlatProgram
     DevOp* d_ops = nullptr;
     uint32_t* d_table = nullptr;
     float* d_rings = nullptr;
+    uint32_t* d_seqtab = nullptr;
     void release()
     {
         (void)hipFree(d_ops);
         (void)hipFree(d_table);
         (void)hipFree(d_rings);
+        (void)hipFree(d_seqtab);
+        d_seqtab = nullptr;
         d_ops = nullptr;
         d_table = nullptr;
         d_rings = nullptr;
@@ -1096,6 +1168,10 @@ static int upload_one(const FlatProgram& P, DevProg& d)
     if (!P.table.empty()) {
         HIP_TRY(hipMalloc(&d.d_table, sizeof(uint32_t) * P.table.size()));
         HIP_TRY(hipMemcpy(d.d_table, P.table.data(), sizeof(uint32_t) * P.table.size(), hipMemcpyHostToDevice));
+    }
+    if (!P.seqtab.empty()) {
+        HIP_TRY(hipMalloc(&d.d_seqtab, sizeof(uint32_t) * P.seqtab.size()));
+        HIP_TRY(hipMemcpy(d.d_seqtab, P.seqtab.data(), sizeof(uint32_t) * P.seqtab.size(), hipMemcpyHostToDevice));
     }
     if (P.hdr.n_rings > 0) {
         size_t bytes = sizeof(float) * (size_t)P.hdr.n_rings * (size_t)P.hdr.buffer_size * P.n_voices;
@@ -1300,6 +1376,7 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
             kc.prog = Cp.hdr;
             kc.table = d->ctl.d_table;
             kc.rings = d->ctl.d_rings;
+            kc.seqtab = d->ctl.d_seqtab;
             kc.frames = d->d_tracks + t_off;  // the control program's planes are the tracks: [n_tracks][T][1]
             kc.plane_stride = T;
             kc.t_stride = T;
@@ -1353,6 +1430,7 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         ka.prog = P.hdr;
         ka.table = d->voice.d_table;
         ka.rings = d->voice.d_rings;
+        ka.seqtab = d->voice.d_seqtab;
         ka.frames = d_frames ? d_frames + (size_t)t_off * V : nullptr;
         ka.mixpart = d_mix ? d->d_mixpart + t_off : nullptr;
         ka.tracks = has_ctl ? d->d_tracks + t_off : nullptr;

@@ -7,7 +7,8 @@
 import numpy as np
 
 # numeric vocabulary of include/srack_hip.h
-MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH = range(7)
+(MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH, MOD_GRID_SEQUENCER,
+ MOD_PATTERN_SEQUENCER) = range(9)
 OSC_VAL, OSC_ANTIALIASING, OSC_POS, OSC_SYNC_LAST = range(4)
 (VCF_FREQ, VCF_RES, VCF_EXP_AMT, VCF_ST_F, VCF_ST_P, VCF_ST_Q, VCF_ST_B0, VCF_ST_B1, VCF_ST_B2, VCF_ST_B3,
  VCF_ST_B4, VCF_ST_FREQ, VCF_ST_RES) = range(13)
@@ -17,6 +18,12 @@ VCA_NEGATIVE = 0
 MIX_GAIN0, MIX_GAIN1, MIX_GAIN2, MIX_GAIN3 = range(4)
 MATH_CONSTANT, MATH_OPERATION = range(2)
 MATH_ADD, MATH_SUBTRACT, MATH_MULTIPLY = range(3)
+(GRIDSEQ_STEPS_PER_OCTAVE, GRIDSEQ_OCTAVES, GRIDSEQ_LENGTH, GRIDSEQ_CURRENT_STEP, GRIDSEQ_STEP_LAST, GRIDSEQ_SYNC_LAST,
+ GRIDSEQ_LAST) = range(7)
+PATSEQ_LENGTH, PATSEQ_CURRENT_STEP, PATSEQ_STEP_LAST, PATSEQ_SYNC_LAST = range(4)
+STEP_NONE, STEP_ON, STEP_HOLD = range(3)
+GRIDSEQ_OUT_CV, GRIDSEQ_OUT_GATE, GRIDSEQ_OUT_SYNC = range(3)
+PATSEQ_OUT_SYNC = 8
 OSC_OUT_SINE, OSC_OUT_SQUARE, OSC_OUT_SAW = range(3)
 VCF_OUT_LOWPASS, VCF_OUT_BANDPASS, VCF_OUT_HIGHPASS = range(3)
 
@@ -77,6 +84,59 @@ def build_p2(g, beta=0.3, index=1.0):
     g.connect(osc_c, OSC_OUT_SINE, out, 0)
     g.connect(osc_c, OSC_OUT_SINE, out, 1)
     return dict(osc_m=osc_m, mul_fb=mul_fb, mul_idx=mul_idx, osc_c=osc_c, out=out)
+
+
+def build_p3(g, clock_val=-4.0, length=8):
+    """Patch P3 (scope table (f) rank 1): the screenshot's shape — an LFO clocks a grid sequencer whose CV plays the
+    VCO and whose gate fires the amplitude ADSR; a pattern sequencer on the same clock gates a second ADSR that
+    sweeps the filter.  A per-voice transpose is a Math(Add) after the sequencer CV.
+
+    List order: [0] CLOCK (LFO), [1] GRID, [2] PATTERN, [3] TRANSPOSE (Add), [4] OSC, [5] ADSR_AMP, [6] ADSR_FLT,
+    [7] VCF, [8] VCA, [9] OUTPUT.
+    """
+    clock = g.add_module(MOD_OSCILLATOR)
+    grid = g.add_module(MOD_GRID_SEQUENCER)
+    pat = g.add_module(MOD_PATTERN_SEQUENCER)
+    transpose = g.add_module(MOD_MATH)
+    osc = g.add_module(MOD_OSCILLATOR)
+    adsr_amp = g.add_module(MOD_ADSR)
+    adsr_flt = g.add_module(MOD_ADSR)
+    vcf = g.add_module(MOD_MOOG_FILTER)
+    vca = g.add_module(MOD_VCA)
+    out = g.add_module(MOD_OUTPUT)
+    g.set_field(clock, OSC_VAL, clock_val)
+    g.set_field(grid, GRIDSEQ_LENGTH, length)
+    g.set_field(pat, PATSEQ_LENGTH, length)
+    notes = [0, 3, 7, 12, 10, 7, 3, 5]
+    for i in range(length):
+        if i % 4 == 3:
+            continue  # a rest: the CV holds the previous note, the gate stays low
+        g.set_step(grid, 0, i, STEP_HOLD if i % 4 == 1 else STEP_ON, notes[i % len(notes)])
+        g.set_step(pat, 1, i, STEP_ON if i % 2 == 0 else STEP_NONE)
+        g.set_step(pat, 5, i, STEP_HOLD if i == 2 else STEP_NONE)
+    for m, vals in ((adsr_amp, (0.002, 0.02, 0.6, 0.01)), (adsr_flt, (0.001, 0.03, 0.3, 0.02))):
+        for f, v in zip((ADSR_A_SEC, ADSR_D_SEC, ADSR_S_VAL, ADSR_R_SEC), vals):
+            g.set_field(m, f, v)
+    g.set_field(transpose, MATH_OPERATION, MATH_ADD)
+    g.set_field(transpose, MATH_CONSTANT, -1.0)
+    g.set_field(vcf, VCF_FREQ, 0.15)
+    g.set_field(vcf, VCF_RES, 0.6)
+    g.set_field(vcf, VCF_EXP_AMT, 0.4)
+    g.connect(clock, OSC_OUT_SQUARE, grid, 0)
+    g.connect(clock, OSC_OUT_SQUARE, pat, 0)
+    g.connect(grid, GRIDSEQ_OUT_SYNC, pat, 1)         # the grid's sync output re-syncs the pattern
+    g.connect(grid, GRIDSEQ_OUT_CV, transpose, 0)
+    g.connect(transpose, 0, osc, 0)
+    g.connect(grid, GRIDSEQ_OUT_GATE, adsr_amp, 0)
+    g.connect(pat, 1, adsr_flt, 0)
+    g.connect(osc, OSC_OUT_SAW, vcf, 0)
+    g.connect(adsr_flt, 0, vcf, 1)
+    g.connect(vcf, VCF_OUT_LOWPASS, vca, 0)
+    g.connect(adsr_amp, 0, vca, 1)
+    g.connect(vca, 0, out, 0)
+    g.connect(pat, 5, out, 1)                         # a raw gate on the second channel
+    return dict(clock=clock, grid=grid, pat=pat, transpose=transpose, osc=osc, adsr_amp=adsr_amp, adsr_flt=adsr_flt, vcf=vcf,
+                vca=vca, out=out)
 
 
 def splitmix64(x):

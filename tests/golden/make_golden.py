@@ -46,6 +46,14 @@ if __name__ == "__main__":
     # cfg4 shape: P2 FM with feedback, z^-1 (B=1) and the app-default delay line (B=1024); 0.25 s
     save("cfg4_p2_b1.npz", both(W.build_p2, 12000, 1, beta=0.3, index=1.0), buffer_size=1, beta=0.3, index=1.0)
     save("cfg4_p2_b1024.npz", both(W.build_p2, 12000, 1024, beta=0.3, index=1.0), buffer_size=1024, beta=0.3, index=1.0)
+    # scope table (f) rank 1: sequencer-driven patch P3, both channels (audio, raw pattern gate), 0.25 s
+    g = O.OraclePatch(48000, 1024, 2)
+    W.build_p3(g)
+    ng = NumpyGraph(48000, 1024, 2)
+    W.build_p3(ng)
+    a, b = g.render(12000), ng.render(12000)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "C oracle != NumPy restatement (P3)"
+    save("p3_sequencers.npz", np.ascontiguousarray(a.T), buffer_size=1024)
     # cfg3 shape: 8 voices of P1 with the per-voice detune/cutoff draw, 0.5 s
     det, cut = W.p1_voice_params(8)
     voices = []

@@ -49,8 +49,41 @@ class NumpyGraph:
                 m.constant = np.float32(value)
             else:
                 m.operation = int(value)
+        elif isinstance(m, N.GridSequencer):
+            if field == 0:
+                m.steps_per_octave = int(value)
+            elif field == 1:
+                m.octaves = int(value)
+            elif field == 2:
+                m.sequence = (m.sequence + [None] * 64)[:int(value)]
+            elif field == 3:
+                m.current_step = int(value)
+            elif field == 4:
+                m.td.last = bool(value)
+            elif field == 5:
+                m.sync_td.last = bool(value)
+            else:
+                m.last = np.float32(value)
+        elif isinstance(m, N.PatternSequencer):
+            if field == 0:
+                m.sequence = [(ch + [None] * 64)[:int(value)] for ch in m.sequence]
+            elif field == 1:
+                m.current_step = int(value)
+            elif field == 2:
+                m.td.last = bool(value)
+            else:
+                m.sync_td.last = bool(value)
         else:
             raise ValueError("no fields")
+
+    def set_step(self, module, channel, step, state, value=0):
+        m = self.modules[module]
+        if isinstance(m, N.GridSequencer):
+            if step < len(m.sequence):
+                m.sequence[step] = None if state == 0 else (int(value), state == 2)
+        else:
+            if step < len(m.sequence[channel]):
+                m.sequence[channel][step] = None if state == 0 else (state == 2)
 
     def plan(self):
         output = next(m for m in self.modules if isinstance(m, N.Output))

@@ -44,3 +44,10 @@ def test_cfg3_voices(W, oracle):
     ids = W.build_p1(g, lfo_val=float(z["lfo_val"]))
     frames, _ = g.render_batch(8, audio.shape[0], [(ids["osc_a"], W.OSC_VAL, det), (ids["vcf"], W.VCF_FREQ, cut)], threads=4)
     np.testing.assert_array_equal(frames[0].view(np.uint32), audio.view(np.uint32))
+
+
+def test_p3_sequencers(W, oracle):
+    z, audio = load("p3_sequencers.npz")
+    g = oracle.OraclePatch(48000, int(z["buffer_size"]), 2)
+    W.build_p3(g)
+    np.testing.assert_array_equal(g.render(audio.shape[0]).T.view(np.uint32), audio.view(np.uint32))

@@ -420,3 +420,61 @@ def test_render_without_outputs_still_advances_state(S):
     fa, _ = a.render(500)
     fb, _ = b.render(500)
     np.testing.assert_array_equal(bits(fa), bits(fb))
+
+
+# ---- scope table (f) rank 1: sequencer-driven patch ---------------------------------------------------------------
+@pytest.mark.parametrize("flags", [pytest.param(0, id="hoist"), pytest.param(4, id="nohoist"), pytest.param(1, id="exact")])
+def test_p3_sequencers_vs_oracle(S, oracle, flags):
+    V, T = 150, 12000
+    transpose = np.linspace(-2.0, 0.5, V).astype(np.float32)
+    cut = np.linspace(0.05, 0.4, V).astype(np.float32)
+    o = oracle.OraclePatch(48000, 1024, 2)
+    ids = S.build_p3(o)
+    ref, ref_mix = o.render_batch(V, T, [(ids["transpose"], S.MATH_CONSTANT, transpose), (ids["vcf"], S.VCF_FREQ, cut)], mix=True, threads=8)
+    p = S.Patch(48000, 1024, 2)
+    S.build_p3(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, transpose)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    assert p.planes() == (2, [0, 1])
+    fr, mix = p.render(T, flags=flags)
+    assert ("ctl[" in p.info()) == (not flags & 4)
+    assert_close(fr[0], ref[0])
+    np.testing.assert_array_equal(fr[1], ref[1])  # a raw pattern gate: exactly 0.0 / 1.0 / the clock's square
+    scale = np.abs(ref.astype(np.float64)).sum(axis=2)
+    assert (np.abs(mix - ref_mix) <= 2e-5 * np.maximum(scale, 1.0)).all()
+    assert np.abs(fr[0]).max() > 0.1
+    # sequencer state is readable per voice (one shared state when it lives in the control program)
+    steps = p.get_voice_field(ids["grid"], S.GRIDSEQ_CURRENT_STEP)
+    assert (steps == steps[0]).all() and 0 <= steps[0] < 8
+
+
+def test_p3_per_voice_clocks(S, oracle):
+    """Per-voice clock rates: the sequencers step at different times in different lanes."""
+    V, T = 96, 9000
+    rate = np.linspace(-5.0, -3.0, V).astype(np.float32)
+    o = oracle.OraclePatch(48000, 64, 2)
+    ids = S.build_p3(o)
+    ref, _ = o.render_batch(V, T, [(ids["clock"], S.OSC_VAL, rate)], threads=8)
+    p = S.Patch(48000, 64, 2)
+    S.build_p3(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["clock"], S.OSC_VAL, rate)
+    fr, _ = p.render(T)
+    assert "ctl[" not in p.info()
+    assert_close(fr[0], ref[0])
+    assert_close(fr[1], ref[1])
+    steps = p.get_voice_field(ids["grid"], S.GRIDSEQ_CURRENT_STEP)
+    assert len(np.unique(steps)) > 1
+
+
+def test_p3_golden(S):
+    z = np.load(os.path.join(GOLD, "p3_sequencers.npz"))
+    gold = z["audio"]  # [T][2]
+    p = S.Patch(48000, int(z["buffer_size"]), 2)
+    S.build_p3(p)
+    p.configure_voices(2)
+    out = p.render_channels(gold.shape[0])
+    for v in range(2):
+        assert_close(out[0, :, v], gold[:, 0])
+        np.testing.assert_array_equal(out[1, :, v], gold[:, 1])

@@ -204,3 +204,26 @@ def test_no_gpu_render_fails_loudly(S):
     with pytest.raises(S.SrackError) as e:
         p.render(16)
     assert e.value.code == S.ERR_DEVICE
+
+
+def test_sequencer_graph_api(S):
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p3(p)
+    assert p.get_num_inputs(ids["grid"]) == 2 and p.get_num_outputs(ids["grid"]) == 3 and p.get_num_outputs(ids["pat"]) == 9
+    assert p.get_field(ids["grid"], S.GRIDSEQ_STEPS_PER_OCTAVE) == 12 and p.get_field(ids["grid"], S.GRIDSEQ_STEP_LAST) == 1
+    assert p.get_step(ids["grid"], 0, 1) == (S.STEP_HOLD, 3) and p.get_step(ids["grid"], 0, 3) == (S.STEP_NONE, 0)
+    assert p.get_step(ids["pat"], 5, 2) == (S.STEP_HOLD, 0) and p.get_step(ids["pat"], 1, 0) == (S.STEP_ON, 0)
+    with pytest.raises(S.SrackError):
+        p.set_step(ids["grid"], 1, 0, 1, 0)      # a grid sequencer has one channel
+    with pytest.raises(S.SrackError):
+        p.set_step(ids["osc"], 0, 0, 1, 0)       # not a sequencer
+    with pytest.raises(S.SrackError):
+        p.set_field(ids["pat"], S.PATSEQ_LENGTH, 0)
+    with pytest.raises(S.SrackError) as e:       # Err(()) of get_output(9)
+        p.connect(ids["pat"], 9, ids["out"], 0)
+    assert e.value.code == S.ERR_PORT
+    # per-voice transpose only: clock, both sequencers and both envelopes are voice-invariant => control program
+    p.configure_voices(128)
+    p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, np.linspace(-2, 0, 128))
+    info = p.info()
+    assert "ctl[ops=" in info and "tracks=4" in info, info

@@ -333,3 +333,46 @@ def test_render_batch_matches_single_renders(W, oracle):
         s.set_field(ids["vcf"], W.VCF_FREQ, cut[v])
         np.testing.assert_array_equal(bits(s.render(700)), bits(frames[:, :, v]))
     np.testing.assert_allclose(mix, frames.astype(np.float64).sum(axis=2), rtol=0, atol=1e-12)
+
+
+# ---- scope table (f) rank 1: the sequencers (no reference test pins them: double restatement only) ----------------
+@pytest.mark.parametrize("B", [1, 64, 1024])
+def test_p3_sequencers_c_equals_numpy(W, oracle, B):
+    g, ng, ids = _both(W, oracle, W.build_p3, 9000, B=B)
+    assert g.plan() == ng.plan()[0]
+    for tap in [(ids["grid"], 0), (ids["grid"], 1), (ids["grid"], 2), (ids["pat"], 1), (ids["pat"], 8)]:
+        gg, nn, _ = _both(W, oracle, W.build_p3, 9000, B=B)
+        a, ta = gg.render(9000, tap=tap)
+        b, tb = nn.render(9000, tap=tap)
+        np.testing.assert_array_equal(bits(ta), bits(tb))
+        np.testing.assert_array_equal(bits(a), bits(b))
+    a = g.render(9000)
+    assert np.abs(a[0]).max() > 0.1 and a[1].max() == 1.0 and a[1].min() == 0.0
+
+
+def test_sequencer_semantics(oracle):
+    """Stepping, wrap, sync reset, held CV over rests, gate = clock vs held (sequencer.rs:219-243)."""
+    g = oracle.OraclePatch(48000, 8, 2)
+    clock, grid, out = g.add_module(1), g.add_module(7), g.add_module(0)
+    g.set_field(clock, 0, 3.0)           # 3520 Hz: a rising edge every ~13.6 samples
+    g.set_field(grid, 2, 3)              # length 3
+    g.set_step(grid, 0, 0, 1, 12)        # step 0: note 12 -> 1.0 V, gate follows the clock
+    g.set_step(grid, 0, 2, 2, 6)         # step 2: note 6 -> 0.5 V, gate held
+    g.connect(clock, 1, grid, 0)
+    g.connect(grid, 0, out, 0)
+    g.connect(grid, 1, out, 1)
+    a = g.render(120)
+    cv, gate = a[0], a[1]
+    assert cv[0] == 1.0                                   # starts on step 0
+    assert set(np.unique(cv)) == {np.float32(0.5), np.float32(1.0)}   # step 1 is a rest: holds 1.0, never 0
+    assert gate.max() == 1.0 and (gate[cv == 0.5] == 1.0).all()       # held gate on step 2
+    # default sequence (all None): CV stays at `last` = 0, gate 0, sync 1 only on step 0
+    g = oracle.OraclePatch(48000, 8, 2)
+    clock, pat, out = g.add_module(1), g.add_module(8), g.add_module(0)
+    g.set_field(clock, 0, 3.0)
+    g.set_field(pat, 0, 4)
+    g.connect(clock, 1, pat, 0)
+    g.connect(pat, 8, out, 0)
+    g.connect(pat, 3, out, 1)
+    a = g.render(200)
+    assert a[0][0] == 1.0 and 0.2 < a[0].mean() < 0.3 and not a[1].any()
