@@ -190,25 +190,6 @@ int Builder::build()
     auto use_wire = [&](int w, int op_index) { wires[(size_t)w].last_use = std::max(wires[(size_t)w].last_use, op_index); };
     int n_planes = 0;
 
-    // voice program: one OP_TRACK_RD per control track some module of this program reads
-    std::map<int, int> wire_of_track;
-    if (!is_ctl) {
-        for (int m : g.plan.order) {
-            if (!mine(m)) continue;
-            for (const InputRef& in : g.modules[(size_t)m].in) {
-                if (in.src < 0 || !A.in_ctl[(size_t)in.src]) continue;
-                int k = A.track_of.at({in.src, in.port});
-                if (wire_of_track.count(k)) continue;
-                DevOp rd = blank_op(OP_TRACK_RD, in.src);
-                rd.aux = k;
-                int w = new_wire((int)out.ops.size());
-                rd.out_slot[0] = w;
-                out.ops.push_back(rd);
-                wire_of_track[k] = w;
-            }
-        }
-    }
-
     for (int m : g.plan.order) {
         if (!mine(m)) continue;
         const Module& mod = g.modules[(size_t)m];
@@ -217,8 +198,8 @@ int Builder::build()
         for (int k = 0; k < mod.n_in; k++) {
             const InputRef& in = mod.in[(size_t)k];
             if (in.src < 0) continue;
-            if (!is_ctl && A.in_ctl[(size_t)in.src]) {  // a control track (never a delayed edge: see the uniform analysis)
-                in_wire[k] = wire_of_track.at(A.track_of.at({in.src, in.port}));
+            if (!is_ctl && A.in_ctl[(size_t)in.src]) {  // a control track (never a delayed edge: see the uniform analysis),
+                in_wire[k] = -2 - A.track_of.at({in.src, in.port});  // read in place from HBM: no wire, no slot
             } else if (is_delayed(in.src, m)) {
                 DevOp rd = blank_op(OP_DELAY_RD, in.src);
                 rd.aux = ring_of.at({in.src, in.port});
@@ -240,7 +221,7 @@ int Builder::build()
         for (int j = 0; j < kMaxIn; j++) op.in_slot[j] = in_wire[j];
         for (int k = 0; k < kMaxIn; k++)
             if (in_wire[k] >= 0) use_wire(in_wire[k], oi);
-        auto connected = [&](int k) { return in_wire[k] >= 0; };
+        auto connected = [&](int k) { return in_wire[k] != -1; };
         const uint32_t pl = A.port_live[(size_t)m];
 
         switch (mod.type) {
@@ -360,13 +341,13 @@ int Builder::build()
             // one OP_OUT per distinct source wire (plane); channels map onto planes
             std::map<int, int> plane_of_wire;
             for (int c = 0; c < mod.n_in && c < 8; c++) {
-                if (in_wire[c] < 0) continue;
+                if (in_wire[c] == -1) continue;
                 auto it = plane_of_wire.find(in_wire[c]);
                 if (it == plane_of_wire.end()) {
                     DevOp o2 = blank_op(OP_OUT, m);
                     o2.in_slot[0] = in_wire[c];
                     o2.aux = n_planes;
-                    use_wire(in_wire[c], (int)out.ops.size());
+                    if (in_wire[c] >= 0) use_wire(in_wire[c], (int)out.ops.size());
                     out.ops.push_back(o2);
                     it = plane_of_wire.emplace(in_wire[c], n_planes++).first;
                 }
@@ -478,8 +459,12 @@ int Builder::build()
         }
         H.n_slots = n_slots;
         for (DevOp& op : out.ops) {
-            for (int k = 0; k < kMaxIn; k++)
-                if (op.in_slot[k] >= 0) op.in_slot[k] = wires[(size_t)op.in_slot[k]].slot;
+            for (int k = 0; k < kMaxIn; k++) {
+                if (op.in_slot[k] >= 0)
+                    op.in_slot[k] = wires[(size_t)op.in_slot[k]].slot;
+                else if (op.in_slot[k] <= -2)
+                    op.in_slot[k] = kTrackSlot + (-2 - op.in_slot[k]);
+            }
             for (int k = 0; k < kMaxOut; k++)
                 if (op.out_slot[k] >= 0) op.out_slot[k] = wires[(size_t)op.out_slot[k]].slot;
         }
@@ -520,7 +505,7 @@ int Builder::build()
 // Fused kernels (render.hip) for patch P1's shape.  All-per-voice form:
 //   {OSC_A, OSC_L, VCF, ADSR, VCA, OUT}: VCF <- OSC_A, ADSR <- OSC_L, VCA <- (VCF, ADSR), one plane <- VCA.
 // After uniform hoisting the LFO/ADSR pair lives in the control program and the voice program is
-//   {TRACK_RD, OSC_A, VCF, VCA, OUT}: VCA <- (VCF, track).
+//   {OSC_A, VCF, VCA, OUT}: VCA <- (VCF, control track).
 // Oscillators must be OSC_CONST_FAST (or the exact flavour of the same shape), filters have no CV.
 void Builder::match_fused(bool has_rings)
 {
@@ -547,15 +532,14 @@ void Builder::match_fused(bool has_rings)
     for (const DevOp& op : out.ops) n_kind[op.kind]++;
     const DevProgram& H = out.hdr;
     const bool full = H.n_ops == 6 && n_kind[OP_OSC] == 2 && n_kind[OP_VCF] == 1 && n_kind[OP_ADSR] == 1 && n_kind[OP_VCA] == 1 && n_kind[OP_OUT] == 1;
-    const bool tracked = H.n_ops == 5 && n_kind[OP_TRACK_RD] == 1 && n_kind[OP_OSC] == 1 && n_kind[OP_VCF] == 1 && n_kind[OP_VCA] == 1 && n_kind[OP_OUT] == 1;
+    const bool tracked = H.n_ops == 4 && n_kind[OP_OSC] == 1 && n_kind[OP_VCF] == 1 && n_kind[OP_VCA] == 1 && n_kind[OP_OUT] == 1;
     if (!full && !tracked) return;
-    const DevOp *vcf = nullptr, *adsr = nullptr, *vca = nullptr, *outp = nullptr, *trk = nullptr;
+    const DevOp *vcf = nullptr, *adsr = nullptr, *vca = nullptr, *outp = nullptr;
     for (const DevOp& op : out.ops) {
         if (op.kind == OP_VCF) vcf = &op;
         if (op.kind == OP_ADSR) adsr = &op;
         if (op.kind == OP_VCA) vca = &op;
         if (op.kind == OP_OUT) outp = &op;
-        if (op.kind == OP_TRACK_RD) trk = &op;
     }
     auto src_of = [&](int sink_module, int k) { return g.modules[(size_t)sink_module].in[(size_t)k]; };
     auto osc_ok = [&](int module) {
@@ -580,7 +564,7 @@ void Builder::match_fused(bool has_rings)
              src_of(adsr->module, 0).src != src_of(vcf->module, 0).src && src_of(adsr->module, 0).port == SRACK_OSC_OUT_SQUARE;
         if (ok) out.fused = FUSED_VOICE_CHAIN;
     } else {
-        ok = A.in_ctl[(size_t)src_of(vca->module, 1).src] && trk != nullptr;
+        ok = A.in_ctl[(size_t)src_of(vca->module, 1).src] && vca->in_slot[1] >= kTrackSlot;
         if (ok) out.fused = FUSED_VOICE_CHAIN_TRACK;
     }
 }

@@ -47,6 +47,11 @@ SRK_DEV bool rising_edge(bool& last, float val)
 struct OscRegs {
     double pos;      // phase in [0,1)
     bool sync_last;  // sync TransitionDetector.last
+    // CV path only, not module state: the last CV seen and the increment computed for it.  2^x is a pure function
+    // of (cv, val), and sequencer-driven CVs are constant for thousands of samples, so it is re-evaluated only
+    // when some lane's CV changed (NaN != NaN: the first sample always evaluates).
+    float seen_cv = __builtin_nanf("");
+    double seen_delta = 0.0;
 };
 
 struct OscConst {    // per-voice constants, set up once per kernel (or tile)
@@ -148,9 +153,13 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
     double delta;
     if (flags & OSC_HAS_CV) {
         // 440 * 2^(f64(cv) + f64(val)) / f64(sample_rate), per sample (oscillator.rs:45,132)
-        double e = (double)cv + c.val;
-        // exact mode: 440 * 2^e / sr as written; default mode: (440 / sr) * 2^e with the series above
-        delta = (flags & OSC_EXACT) ? 440.0 * pow(2.0, e) / c.sr : (440.0 / c.sr) * exp2_fast(e);
+        if ((flags & OSC_CV_AUDIO_RATE) || __builtin_amdgcn_ballot_w64(cv != s.seen_cv) != 0) {
+            const double e = (double)cv + c.val;
+            // exact mode: 440 * 2^e / sr as written; default mode: (440 / sr) * 2^e with the series above
+            s.seen_delta = (flags & OSC_EXACT) ? 440.0 * pow(2.0, e) / c.sr : (440.0 / c.sr) * exp2_fast(e);
+            s.seen_cv = cv;
+        }
+        delta = s.seen_delta;
     } else {
         delta = c.delta;
     }
@@ -306,13 +315,17 @@ SRK_DEV float clamp1(float x)
 // filter.rs:61-68 — recompute only when (frequency, res) changed
 SRK_DEV void vcf_coeffs(VcfRegs& s, float frequency, float res)
 {
-    if (frequency != s.freq || res != s.res) {
-        s.freq = frequency;
-        s.res = res;
-        float q = 1.0f - frequency;
-        s.p = frequency + 0.8f * frequency * q;
-        s.f = s.p * 2.0f - 1.0f;
-        s.q = res * (1.0f + 0.5f * q * (1.0f - q + 5.6f * q * q));
+    const bool changed = frequency != s.freq || res != s.res;
+    if (__builtin_amdgcn_ballot_w64(changed) != 0) {  // wave-uniform skip; lanes whose pair is unchanged keep their coefficients
+        const float q = 1.0f - frequency;
+        const float p = frequency + 0.8f * frequency * q;
+        const float f = p * 2.0f - 1.0f;
+        const float qq = res * (1.0f + 0.5f * q * (1.0f - q + 5.6f * q * q));
+        s.freq = changed ? frequency : s.freq;
+        s.res = changed ? res : s.res;
+        s.p = changed ? p : s.p;
+        s.f = changed ? f : s.f;
+        s.q = changed ? qq : s.q;
     }
 }
 

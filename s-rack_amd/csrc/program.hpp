@@ -37,6 +37,7 @@ enum : uint32_t {
     OSC_EXACT = 1u << 6,      // f64 PolyBLEP / sin / pow exactly as the reference spells them
     OSC_CONST_FAST = 1u << 7, // host-proved: no CV, no sync, one live port, PolyBLEP on, every voice's delta < 0.25
                               // => the carried-phase oscillator (modules.hip.h, COsc) may be used
+    OSC_CV_AUDIO_RATE = 1u << 8,  // the CV changes every sample (FM): do not bother caching 2^cv per CV value
     // OP_VCF
     VCF_HAS_AUDIO = 1u << 0,
     VCF_HAS_CV = 1u << 1,
@@ -113,5 +114,9 @@ struct DevProgram {
 };
 
 constexpr int kMaxOps = 96;
+
+// An input slot >= kTrackSlot is not an LDS wire but control track (slot - kTrackSlot): a wave-uniform stream in HBM
+// written by the control program, read in place (stride 1 per sample, no lane offset).
+constexpr int kTrackSlot = 0x4000;
 
 }  // namespace srack

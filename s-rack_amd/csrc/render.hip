@@ -87,6 +87,8 @@ struct Ctx {            // what every tile function sees
     float* wires;       // LDS [n_slots][tile][64]
     float* zero;        // LDS row of zeros: what an unconnected input reads (stride 0)
     float* trash;       // LDS row nobody reads: where an unread output goes (stride 0)
+    const float* tracks_t0;  // control tracks at this tile's first sample ([n_tracks][t_stride], wave-uniform)
+    uint32_t t_stride;
     int tile, n, lane;  // tile capacity, samples in this tile, lane
 };
 
@@ -101,7 +103,11 @@ struct Port {
     float* p;
     int stride;
 };
-SRK_DEV Port in_port(const Ctx& c, int slot) { return slot >= 0 ? Port{c.wires + (size_t)slot * c.tile * 64 + c.lane, 64} : Port{c.zero + c.lane, 0}; }
+SRK_DEV Port in_port(const Ctx& c, int slot)
+{
+    if (slot >= kTrackSlot) return Port{const_cast<float*>(c.tracks_t0) + (size_t)(slot - kTrackSlot) * c.t_stride, 1};  // same address in every lane
+    return slot >= 0 ? Port{c.wires + (size_t)slot * c.tile * 64 + c.lane, 64} : Port{c.zero + c.lane, 0};
+}
 SRK_DEV Port out_port(const Ctx& c, int slot) { return slot >= 0 ? Port{c.wires + (size_t)slot * c.tile * 64 + c.lane, 64} : Port{c.trash + c.lane, 0}; }
 
 // Runs step(x[NI], y[NO]) for every sample of the tile, kU samples at a time: the kU x NI input reads are issued
@@ -370,43 +376,34 @@ SRK_DEV float tile_row_sum(const float* t, int R, int lane)
 __device__ __noinline__ void tile_out(const Ctx& c, const DevOp& op, const KernelArgs& a, uint32_t t0, uint32_t voice, bool active)
 {
     const int slot = op.in_slot[0], plane = op.aux;
+    const Port in = in_port(c, slot);  // an LDS wire, or a control track when every voice plays the same thing
     if (a.frames) {
         float* f = a.frames + (size_t)plane * a.plane_stride + (size_t)t0 * a.V + voice;
         if (active) {
             int i = 0;
-            for (; i + 8 <= c.n; i += 8) {  // 8 LDS reads in flight, then 8 coalesced 256-B row stores
+            for (; i + 8 <= c.n; i += 8) {  // 8 reads in flight, then 8 coalesced 256-B row stores
                 float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = WIRE(slot, i + u);
+                for (int u = 0; u < 8; u++) v[u] = in.p[(i + u) * in.stride];
 #pragma unroll
                 for (int u = 0; u < 8; u++) f[(size_t)(i + u) * a.V] = v[u];
             }
-            for (; i < c.n; i++) f[(size_t)i * a.V] = WIRE(slot, i);
+            for (; i < c.n; i++) f[(size_t)i * a.V] = in.p[i * in.stride];
         }
     }
     if (a.mixpart) {
+        float* mp = a.mixpart + ((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride + t0;
+        if (slot >= kTrackSlot) {  // identical voices: the wave's partial is (number of real voices) x sample
+            if (c.lane < c.n) mp[c.lane] = (float)min(a.lanes, a.V - (blockIdx.x - a.block0) * a.lanes) * in.p[c.lane];
+            return;
+        }
         if (!active)
             for (int i = 0; i < c.n; i++) WIRE(slot, i) = 0.0f;  // lanes past V contribute nothing
         __syncthreads();
         float sum = tile_row_sum(c.wires + (size_t)slot * c.tile * 64, c.tile, c.lane);
-        if (c.lane < c.n) a.mixpart[((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride + t0 + c.lane] = sum;
+        if (c.lane < c.n) mp[c.lane] = sum;
         __syncthreads();
     }
-}
-
-__device__ __noinline__ void tile_track_rd(const Ctx& c, const DevOp& op, const KernelArgs& a, uint32_t t0)
-{
-    const float* trk = a.tracks + (size_t)op.aux * a.t_stride + t0;  // wave-uniform addresses: every lane gets the same sample
-    const int o = op.out_slot[0];
-    int i = 0;
-    for (; i + 8 <= c.n; i += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = trk[i + u];
-#pragma unroll
-        for (int u = 0; u < 8; u++) WIRE(o, i + u) = v[u];
-    }
-    for (; i < c.n; i++) WIRE(o, i) = trk[i];
 }
 
 __device__ __noinline__ void tile_delay_rd(const Ctx& c, const DevOp& op, const KernelArgs& a, uint64_t n_abs, uint32_t voice_c)
@@ -480,10 +477,13 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
     c.tile = tile;
     c.lane = lane;
     c.n = 0;
+    c.t_stride = a.t_stride;
+    c.tracks_t0 = a.tracks;
     for (int r = 0; r < n_rows; r++) c.rows[r * 64 + lane] = a.table[(size_t)r * a.V + voice_c];
 
     for (uint32_t t0 = 0; t0 < a.T; t0 += (uint32_t)tile) {
         c.n = (int)min((uint32_t)tile, a.T - t0);
+        c.tracks_t0 = a.tracks + t0;
         for (int i = 0; i < a.prog.n_ops; i++) {
             const DevOp& op = a.ops[i];
             switch (op.kind) {
@@ -494,7 +494,6 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
             case OP_MIX: dev::tile_mix(c, op); break;
             case OP_MATH: dev::tile_math(c, op); break;
             case OP_OUT: dev::tile_out(c, op, a, t0, voice, active); break;
-            case OP_TRACK_RD: dev::tile_track_rd(c, op, a, t0); break;
             case OP_GRIDSEQ:
             case OP_PATSEQ: dev::tile_seq(c, op, a); break;
             case OP_DELAY_RD: dev::tile_delay_rd(c, op, a, a.n0 + t0, voice_c); break;
@@ -972,7 +971,7 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
     const int plane = a.ops[r.out].aux;
     const int ring_row = r.track;        // the z^-1 ring: one state row
 
-    constexpr uint32_t fo = OSC_HAS_CV | OSC_AA | OSC_OUT_SINE | (kExact ? OSC_EXACT : 0u);
+    constexpr uint32_t fo = OSC_HAS_CV | OSC_CV_AUDIO_RATE | OSC_AA | OSC_OUT_SINE | (kExact ? OSC_EXACT : 0u);
     OscRegs sm, sc;
     OscConst km, kc;
     sm.pos = make_f64(row(om.state_row + OSC_S_POS_LO), row(om.state_row + OSC_S_POS_HI));
@@ -1402,7 +1401,7 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
             if (op.kind == OP_ADSR) roles.adsr = i;
             if (op.kind == OP_VCA) roles.vca = i;
             if (op.kind == OP_OUT) roles.out = i;
-            if (op.kind == OP_TRACK_RD) roles.track = op.aux;
+            if (op.kind == OP_VCA && track) roles.track = op.in_slot[1] - kTrackSlot;
         }
         const Graph& g = h.graph;
         roles.osc_a = P.op_of_module[(size_t)g.modules[(size_t)P.ops[(size_t)roles.vcf].module].in[0].src];

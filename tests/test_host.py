@@ -162,8 +162,8 @@ def test_flatten_descriptions(S):
     p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
     info = p.info()
     # uniform hoisting: LFO + ADSR carry no per-voice value => control program (3 ops: OSC, ADSR, track out);
-    # the voice program keeps TRACK_RD, OSC_A, VCF, VCA, OUT and matches the fused track kernel
-    assert "voice[ops=5" in info and "fused=2" in info and "ctl[ops=3" in info and "tracks=1" in info
+    # the voice program keeps OSC_A, VCF, VCA, OUT (the VCA's CV is the control track, read in place) and matches the fused track kernel
+    assert "voice[ops=4" in info and "fused=2" in info and "ctl[ops=3" in info and "tracks=1" in info
     assert p.planes() == (1, [0, 0])
     # one voice: nothing to share, the all-per-voice fused kernel
     q = S.Patch(48000, 1024, 2)
@@ -174,7 +174,7 @@ def test_flatten_descriptions(S):
     q = S.Patch(48000, 1024, 2)
     S.build_p1(q)
     q.configure_voices(4096)
-    assert "voice[ops=2" in q.info() and "ctl[ops=6" in q.info()
+    assert "voice[ops=1" in q.info() and "ctl[ops=6" in q.info()
     # feedback patch, per-voice beta: the whole loop is per voice; B = 1 => ring in LDS rows, tile of 1
     q = S.Patch(48000, 1, 2)
     ids2 = S.build_p2(q)

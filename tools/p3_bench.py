@@ -1,0 +1,22 @@
+"""Sequencer-driven patch P3 at scale (diagnostic): per-voice transpose + cutoff, everything else voice-invariant."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, srack_pkg
+S = srack_pkg.load()
+V, T = int(sys.argv[1]) if len(sys.argv) > 1 else 262144, 48000
+for flags in (0, 4):
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p3(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, np.linspace(-2, 0.5, V).astype(np.float32))
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, np.linspace(0.05, 0.4, V).astype(np.float32))
+    n_planes, _ = p.planes()
+    frames = torch.empty((n_planes, T, V), dtype=torch.float32, device="cuda")
+    mix = torch.empty((2, T), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    p.render_raw(T, frames.data_ptr(), mix.data_ptr(), flags, st); torch.cuda.synchronize()
+    t = time.perf_counter()
+    p.render_raw(T, frames.data_ptr(), mix.data_ptr(), flags, st); torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    ms, n = p.kernel_ms()
+    print(f"flags={flags}: {dt*1e3:.1f} ms/step  {V*T/dt/1e9:.1f} G voice-samples/s  voice kernels {ms*n/2:.1f} ms/step  {p.info()}")
