@@ -40,6 +40,22 @@ __global__ __launch_bounds__(256) void probe(float* out, float seed)
             if (OP == 13) f[k] = 1.0f / f[k];
             if (OP == 14) { f[k] = __builtin_amdgcn_rcpf(f[k]); }
             if (OP == 15) { d[k] = d[k] >= 1.0 ? d[k] - 1.0 : d[k]; }
+            if (OP == 16) {  // packed f32: two independent values per lane in one instruction
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 v = {f[k], f[(k + 4) & 7]};
+                f2 av = {a, a}, bv = {b, b};
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(v) : "v"(v), "v"(av), "v"(bv));
+                f[k] = v.x;
+                f[(k + 4) & 7] = v.y;
+            }
+            if (OP == 17) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 v = {f[k], f[(k + 4) & 7]};
+                f2 av = {a, a};
+                asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(av));
+                f[k] = v.x;
+                f[(k + 4) & 7] = v.y;
+            }
         }
     }
     float acc = 0.f;
@@ -110,6 +126,8 @@ int main()
     run<7, 8>("v_min+v_max f32", d_out, 2);
     run<8, 8>("v_cmp+v_cndmask f32", d_out, 2);
     run<9, 8>("v_ashr+v_add i32", d_out, 2);
+    run<16, 4>("v_pk_fma_f32 (2 values)", d_out, 1);
+    run<17, 4>("v_pk_mul_f32 (2 values)", d_out, 1);
     run<13, 8>("f32 divide (IEEE)", d_out, 1);
     run<14, 8>("v_rcp_f32", d_out, 1);
     for (int w : {1, 2, 4, 8}) run_occ<0, 1>("v_fma_f32 dep", d_out, w);
