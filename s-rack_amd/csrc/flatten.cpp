@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <sstream>
@@ -475,9 +476,12 @@ int Builder::build()
     // ---- tile size from the LDS budget ------------------------------------------------------------
     {
         int tile = kTileMax;
+        int lds_budget = is_ctl ? 56 * 1024 : kLdsBudget;  // the control program is one wave: occupancy is irrelevant, long tiles are not
+        if (const char* e = getenv("SRACK_TILE_MAX")) tile = atoi(e);        // tuning knobs (tools/)
+        if (const char* e = getenv("SRACK_LDS_BUDGET")) lds_budget = atoi(e);
         if (!rings.empty())
             while (tile > B) tile >>= 1;  // a tile may not span more than one ring period
-        while (tile > 1 && (H.n_rows + 2 + H.n_slots * tile) * 256 > kLdsBudget) tile >>= 1;  // + zero and trash rows
+        while (tile > 1 && (H.n_rows + 2 + H.n_slots * tile) * 256 > lds_budget) tile >>= 1;  // + zero and trash rows
         if ((H.n_rows + 2 + H.n_slots * tile) * 256 > 64 * 1024) {
             set_error("flatten: patch state does not fit the LDS budget of the tile interpreter");
             return SRACK_ERR_UNSUPPORTED;
