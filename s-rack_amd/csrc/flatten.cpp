@@ -472,6 +472,7 @@ int Builder::build()
     }
     H.n_ops = (int)out.ops.size();
     H.n_planes = n_planes;
+    H.n_tracks = is_ctl ? 0 : (int)A.tracks.size();
 
     // ---- tile size from the LDS budget ------------------------------------------------------------
     {
@@ -481,8 +482,9 @@ int Builder::build()
         if (const char* e = getenv("SRACK_LDS_BUDGET")) lds_budget = atoi(e);
         if (!rings.empty())
             while (tile > B) tile >>= 1;  // a tile may not span more than one ring period
-        while (tile > 1 && (H.n_rows + 2 + H.n_slots * tile) * 256 > lds_budget) tile >>= 1;  // + zero and trash rows
-        if ((H.n_rows + 2 + H.n_slots * tile) * 256 > 64 * 1024) {
+        const int fixed_rows = H.n_rows + 2 + H.n_tracks;  // voice table + zero and trash rows + one row per control track
+        while (tile > 1 && (fixed_rows + H.n_slots * tile) * 256 > lds_budget) tile >>= 1;
+        if ((fixed_rows + H.n_slots * tile) * 256 > 64 * 1024) {
             set_error("flatten: patch state does not fit the LDS budget of the tile interpreter");
             return SRACK_ERR_UNSUPPORTED;
         }

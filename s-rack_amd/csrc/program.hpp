@@ -110,7 +110,7 @@ struct DevProgram {
     int32_t buffer_size;    // B: length of a broken edge's delay
     int32_t n_rings;        // global rings ([B][V] f32 each)
     int32_t tile;           // samples per tile the interpreter uses (<= B when rings exist)
-    int32_t pad_;
+    int32_t n_tracks;       // control tracks this program reads (each gets one LDS row per tile)
 };
 
 constexpr int kMaxOps = 96;

@@ -82,33 +82,55 @@ SRK_DEV WaveMap wave_map(const KernelArgs& a, int lane)
     return m;
 }
 
+// LDS pointers carry their address space: a plain float* inside a struct handed to a noinline function degrades every
+// access to flat_load / flat_store (measured: 25 VMEM instructions and 54 % wait cycles per voice-sample).
+// The op list is read-only, wave-uniform data: seen through the constant address space its fields arrive by scalar
+// loads (s_load_dword*) instead of flat loads on the vector memory path.
+typedef const __attribute__((address_space(4))) DevOp COp;
+typedef const __attribute__((address_space(4))) KernelArgs CArgs;  // the kernel's own argument block, read in place (kernarg segment)
+// Arguments of a non-kernel function travel in VGPRs, so the compiler no longer knows the op pointer is the same in
+// every lane and would fetch each field with a vector load.  readfirstlane makes the uniformity explicit again.
+SRK_DEV COp& uniform_op(COp& op)
+{
+    const uint64_t p = (uint64_t)&op;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return *(COp*)(((uint64_t)hi << 32) | lo);
+}
+SRK_DEV CArgs& uniform_args(CArgs& a)
+{
+    const uint64_t p = (uint64_t)&a;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return *(CArgs*)(((uint64_t)hi << 32) | lo);
+}
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
 struct Ctx {            // what every tile function sees
-    uint32_t* rows;     // LDS [n_rows][64]
-    float* wires;       // LDS [n_slots][tile][64]
-    float* zero;        // LDS row of zeros: what an unconnected input reads (stride 0)
-    float* trash;       // LDS row nobody reads: where an unread output goes (stride 0)
-    const float* tracks_t0;  // control tracks at this tile's first sample ([n_tracks][t_stride], wave-uniform)
-    uint32_t t_stride;
+    lds_u32* rows;      // LDS [n_rows][64]
+    lds_f32* wires;     // LDS [n_slots][tile][64]
+    lds_f32* zero;      // LDS row of zeros: what an unconnected input reads (stride 0)
+    lds_f32* trash;     // LDS row nobody reads: where an unread output goes (stride 0)
+    lds_f32* trk;       // LDS [n_tracks][64]: this tile's samples of every control track (same for all lanes)
     int tile, n, lane;  // tile capacity, samples in this tile, lane
 };
 
 #define ROW(r) c.rows[(r) * 64 + c.lane]
 #define WIRE(slot, i) c.wires[((slot) * c.tile + (i)) * 64 + c.lane]
 
-SRK_DEV float par(const Ctx& c, const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(ROW(op.par_row[k])) : op.par_val[k]; }
+SRK_DEV float par(const Ctx& c, COp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(ROW(op.par_row[k])) : op.par_val[k]; }
 
 // A port as (lane pointer, stride in floats per sample).  Unconnected inputs read the zero row, unread outputs
 // write the trash row, both with stride 0 — so tile loops carry no per-sample "is it wired" branches.
 struct Port {
-    float* p;
+    lds_f32* p;
     int stride;
 };
 SRK_DEV Port in_port(const Ctx& c, int slot)
 {
-    if (slot >= kTrackSlot) return Port{const_cast<float*>(c.tracks_t0) + (size_t)(slot - kTrackSlot) * c.t_stride, 1};  // same address in every lane
-    return slot >= 0 ? Port{c.wires + (size_t)slot * c.tile * 64 + c.lane, 64} : Port{c.zero + c.lane, 0};
+    if (slot >= kTrackSlot) return Port{c.trk + (slot - kTrackSlot) * 64, 1};  // a control track: same address in every lane (LDS broadcast)
+    return slot >= 0 ? Port{c.wires + slot * c.tile * 64 + c.lane, 64} : Port{c.zero + c.lane, 0};
 }
-SRK_DEV Port out_port(const Ctx& c, int slot) { return slot >= 0 ? Port{c.wires + (size_t)slot * c.tile * 64 + c.lane, 64} : Port{c.trash + c.lane, 0}; }
+SRK_DEV Port out_port(const Ctx& c, int slot) { return slot >= 0 ? Port{c.wires + slot * c.tile * 64 + c.lane, 64} : Port{c.trash + c.lane, 0}; }
 
 // Runs step(x[NI], y[NO]) for every sample of the tile, kU samples at a time: the kU x NI input reads are issued
 // together, then the kU steps, then the kU x NO writes — one LDS round trip per kU samples instead of per sample.
@@ -144,8 +166,9 @@ SRK_DEV void tile_run(const Ctx& c, const Port (&in)[NI], const Port (&out)[NO],
 // ---- one tile of one module type -----------------------------------------------------------------
 
 template <bool kExact>
-__device__ __noinline__ void tile_osc(const Ctx& c, const DevOp& op)
+__device__ __noinline__ void tile_osc(const Ctx c, COp& op_v)
 {
+    COp& op = uniform_op(op_v);
     const uint32_t fl = op.flags;
     const int sr = op.state_row;
     OscRegs s;
@@ -216,8 +239,9 @@ SRK_DEV void vcf_store(const Ctx& c, int sr, const VcfRegs& s)
 }
 
 template <bool kExact>
-__device__ __noinline__ void tile_vcf(const Ctx& c, const DevOp& op)
+__device__ __noinline__ void tile_vcf(const Ctx c, COp& op_v)
 {
+    COp& op = uniform_op(op_v);
     const uint32_t fl = op.flags;
     VcfRegs s;
     vcf_load(c, op.state_row, s);
@@ -238,8 +262,9 @@ __device__ __noinline__ void tile_vcf(const Ctx& c, const DevOp& op)
     vcf_store(c, op.state_row, s);
 }
 
-__device__ __noinline__ void tile_adsr(const Ctx& c, const DevOp& op)
+__device__ __noinline__ void tile_adsr(const Ctx c, COp& op_v)
 {
+    COp& op = uniform_op(op_v);
     const int sr = op.state_row;
     AdsrRegs s;
     s.phase = __uint_as_float(ROW(sr + ADSR_S_PHASE));
@@ -265,8 +290,9 @@ __device__ __noinline__ void tile_adsr(const Ctx& c, const DevOp& op)
     ROW(sr + ADSR_S_GATE_LAST) = s.gate_last ? 1u : 0u;
 }
 
-__device__ __noinline__ void tile_vca(const Ctx& c, const DevOp& op)
+__device__ __noinline__ void tile_vca(const Ctx c, COp& op_v)
 {
+    COp& op = uniform_op(op_v);
     const bool negative = par(c, op, VCA_P_NEG) != 0.0f;
     const uint32_t fl = op.flags;
     const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
@@ -274,8 +300,9 @@ __device__ __noinline__ void tile_vca(const Ctx& c, const DevOp& op)
     tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = vca_step(fl, negative, x[0], x[1]); });
 }
 
-__device__ __noinline__ void tile_mix(const Ctx& c, const DevOp& op)
+__device__ __noinline__ void tile_mix(const Ctx c, COp& op_v)
 {
+    COp& op = uniform_op(op_v);
     float gain[4];
     for (int k = 0; k < 4; k++) gain[k] = par(c, op, MIX_P_GAIN0 + k);
     const uint32_t fl = op.flags;
@@ -284,8 +311,9 @@ __device__ __noinline__ void tile_mix(const Ctx& c, const DevOp& op)
     tile_run<4, 1>(c, in, out, [&](const float* x, float* y) { y[0] = mixer_step(fl, x, gain); });
 }
 
-__device__ __noinline__ void tile_math(const Ctx& c, const DevOp& op)
+__device__ __noinline__ void tile_math(const Ctx c, COp& op_v)
 {
+    COp& op = uniform_op(op_v);
     const float constant = par(c, op, MATH_P_CONST);
     const uint32_t fl = op.flags;
     const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
@@ -312,8 +340,10 @@ SRK_DEV uint32_t seq_advance(SeqRegs& s, float step_in, float sync_in, uint32_t 
     return cs;
 }
 
-__device__ __noinline__ void tile_seq(const Ctx& c, const DevOp& op, const KernelArgs& a)
+__device__ __noinline__ void tile_seq(const Ctx c, COp& op_v, CArgs& a_v)
 {
+    COp& op = uniform_op(op_v);
+    CArgs& a = uniform_args(a_v);
     const int sr = op.state_row;
     SeqRegs s;
     s.current_step = ROW(sr + SEQ_S_CURRENT);
@@ -322,7 +352,7 @@ __device__ __noinline__ void tile_seq(const Ctx& c, const DevOp& op, const Kerne
     __syncthreads();
     c.rows[op.seq_row * 64 + c.lane] = a.seqtab[op.aux + c.lane];
     __syncthreads();
-    const uint32_t* cells = c.rows + op.seq_row * 64;
+    const lds_u32* cells = c.rows + op.seq_row * 64;
     const uint32_t length = (uint32_t)op.seq_len;
     const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
     if (op.kind == OP_GRIDSEQ) {
@@ -362,19 +392,22 @@ __device__ __noinline__ void tile_seq(const Ctx& c, const DevOp& op, const Kerne
 // Sum an LDS tile [rows_in_tile][64] over the 64 lanes: lane l owns row l % R and the column
 // segment l / R (R = tile capacity, a power of two <= 64); columns are visited skewed by the row
 // so the 32 lanes of a half-wave hit 32 different banks.  Result valid in lanes < R.
-SRK_DEV float tile_row_sum(const float* t, int R, int lane)
+template <class Ptr>
+SRK_DEV float tile_row_sum(Ptr t, int R, int lane)
 {
     const int row = lane & (R - 1);
     const int seg = lane / R;          // 64 / R segments of R columns each
-    const float* p = t + row * 64 + seg * R;
+    const Ptr p = t + row * 64 + seg * R;
     float sum = 0.0f;
     for (int j = 0; j < R; j++) sum += p[(j + row) & (R - 1)];
     for (int m = R; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
     return sum;
 }
 
-__device__ __noinline__ void tile_out(const Ctx& c, const DevOp& op, const KernelArgs& a, uint32_t t0, uint32_t voice, bool active)
+__device__ __noinline__ void tile_out(const Ctx c, COp& op_v, CArgs& a_v, uint32_t t0, uint32_t voice, bool active)
 {
+    COp& op = uniform_op(op_v);
+    CArgs& a = uniform_args(a_v);
     const int slot = op.in_slot[0], plane = op.aux;
     const Port in = in_port(c, slot);  // an LDS wire, or a control track when every voice plays the same thing
     if (a.frames) {
@@ -400,14 +433,16 @@ __device__ __noinline__ void tile_out(const Ctx& c, const DevOp& op, const Kerne
         if (!active)
             for (int i = 0; i < c.n; i++) WIRE(slot, i) = 0.0f;  // lanes past V contribute nothing
         __syncthreads();
-        float sum = tile_row_sum(c.wires + (size_t)slot * c.tile * 64, c.tile, c.lane);
+        float sum = tile_row_sum(c.wires + slot * c.tile * 64, c.tile, c.lane);
         if (c.lane < c.n) mp[c.lane] = sum;
         __syncthreads();
     }
 }
 
-__device__ __noinline__ void tile_delay_rd(const Ctx& c, const DevOp& op, const KernelArgs& a, uint64_t n_abs, uint32_t voice_c)
+__device__ __noinline__ void tile_delay_rd(const Ctx c, COp& op_v, CArgs& a_v, uint64_t n_abs, uint32_t voice_c)
 {
+    COp& op = uniform_op(op_v);
+    CArgs& a = uniform_args(a_v);
     const int o = op.out_slot[0];
     const uint32_t B = (uint32_t)a.prog.buffer_size;
     if (op.flags & DELAY_RING_GLOBAL) {
@@ -437,8 +472,10 @@ __device__ __noinline__ void tile_delay_rd(const Ctx& c, const DevOp& op, const 
     }
 }
 
-__device__ __noinline__ void tile_delay_wr(const Ctx& c, const DevOp& op, const KernelArgs& a, uint64_t n_abs, uint32_t voice, bool active)
+__device__ __noinline__ void tile_delay_wr(const Ctx c, COp& op_v, CArgs& a_v, uint64_t n_abs, uint32_t voice, bool active)
 {
+    COp& op = uniform_op(op_v);
+    CArgs& a = uniform_args(a_v);
     const int s = op.in_slot[0];
     const uint32_t B = (uint32_t)a.prog.buffer_size;
     uint32_t p = (uint32_t)(n_abs % B);
@@ -464,28 +501,33 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
+    dev::CArgs& ca = *(dev::CArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // `a` itself, addressable without a private copy
     const dev::WaveMap wm = dev::wave_map(a, lane);
     const uint32_t voice = wm.voice, voice_c = wm.vc;  // idle lanes shadow the wave's last voice; they never store
     const bool active = wm.active;
     const int n_rows = a.prog.n_rows, tile = a.prog.tile;
     dev::Ctx c;
-    c.rows = lds;
-    c.zero = reinterpret_cast<float*>(lds + (size_t)n_rows * 64);
+    c.rows = (dev::lds_u32*)lds;
+    c.zero = (dev::lds_f32*)(lds + (size_t)n_rows * 64);
     c.trash = c.zero + 64;
-    c.wires = c.trash + 64;
+    c.trk = c.trash + 64;
+    c.wires = c.trk + a.prog.n_tracks * 64;
     c.zero[lane] = 0.0f;
     c.tile = tile;
     c.lane = lane;
     c.n = 0;
-    c.t_stride = a.t_stride;
-    c.tracks_t0 = a.tracks;
     for (int r = 0; r < n_rows; r++) c.rows[r * 64 + lane] = a.table[(size_t)r * a.V + voice_c];
 
     for (uint32_t t0 = 0; t0 < a.T; t0 += (uint32_t)tile) {
         c.n = (int)min((uint32_t)tile, a.T - t0);
-        c.tracks_t0 = a.tracks + t0;
+        if (a.prog.n_tracks > 0) {  // this tile's slice of every control track: one coalesced load per track
+            __syncthreads();
+            for (int k = 0; k < a.prog.n_tracks; k++)
+                if (lane < c.n) c.trk[k * 64 + lane] = a.tracks[(size_t)k * a.t_stride + t0 + lane];
+            __syncthreads();
+        }
         for (int i = 0; i < a.prog.n_ops; i++) {
-            const DevOp& op = a.ops[i];
+            dev::COp& op = ((dev::COp*)a.ops)[i];
             switch (op.kind) {
             case OP_OSC: dev::tile_osc<kExact>(c, op); break;
             case OP_VCF: dev::tile_vcf<kExact>(c, op); break;
@@ -493,11 +535,11 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
             case OP_VCA: dev::tile_vca(c, op); break;
             case OP_MIX: dev::tile_mix(c, op); break;
             case OP_MATH: dev::tile_math(c, op); break;
-            case OP_OUT: dev::tile_out(c, op, a, t0, voice, active); break;
+            case OP_OUT: dev::tile_out(c, op, ca, t0, voice, active); break;
             case OP_GRIDSEQ:
-            case OP_PATSEQ: dev::tile_seq(c, op, a); break;
-            case OP_DELAY_RD: dev::tile_delay_rd(c, op, a, a.n0 + t0, voice_c); break;
-            case OP_DELAY_WR: dev::tile_delay_wr(c, op, a, a.n0 + t0, voice, active); break;
+            case OP_PATSEQ: dev::tile_seq(c, op, ca); break;
+            case OP_DELAY_RD: dev::tile_delay_rd(c, op, ca, a.n0 + t0, voice_c); break;
+            case OP_DELAY_WR: dev::tile_delay_wr(c, op, ca, a.n0 + t0, voice, active); break;
             default: break;
             }
         }
@@ -1249,7 +1291,7 @@ static void launch_fused(uint32_t osc_port, uint32_t vcf_port, bool exact, int o
 
 static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_t st)
 {
-    size_t lds = ((size_t)P.hdr.n_rows + 2 + (size_t)P.hdr.n_slots * P.hdr.tile) * 256;  // + the zero and trash rows
+    size_t lds = ((size_t)P.hdr.n_rows + 2 + (size_t)P.hdr.n_tracks + (size_t)P.hdr.n_slots * P.hdr.tile) * 256;  // + zero, trash and track rows
     if (P.render_flags & SRACK_RENDER_EXACT_OSC)
         hipLaunchKernelGGL(render_interp<true>, dim3(ka.n_waves), dim3(64), lds, st, ka);
     else
