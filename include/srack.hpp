@@ -43,7 +43,11 @@ enum class ModuleType : int {  // the hot-path subset of SynthModuleType (synth.
     ADSR = SRACK_MOD_ADSR,
     VCA = SRACK_MOD_VCA,
     MonoMixer = SRACK_MOD_MONO_MIXER,
-    Math = SRACK_MOD_MATH
+    Math = SRACK_MOD_MATH,
+    GridSequencer = SRACK_MOD_GRID_SEQUENCER,
+    PatternSequencer = SRACK_MOD_PATTERN_SEQUENCER,
+    NonLinear = SRACK_MOD_NONLINEAR,
+    Sample = SRACK_MOD_SAMPLE
 };
 
 class Error : public std::runtime_error {  // what the reference would panic with
@@ -77,6 +81,9 @@ public:
     // struct fields (what the egui sliders and serde touch), by the SRACK_<TYPE>_<FIELD> enums
     void set(int field, double value);
     double get(int field) const;
+    // sequencer grid cells (sequencer.rs:137-184, 437-478) and the sample player's WaveBox (sample.rs:31-69)
+    void set_step(int channel, int step, int state, int value = 0);
+    void set_wave(const std::vector<float>& samples, float sample_rate);
 
 private:
     friend class Workspace;
@@ -155,13 +162,14 @@ private:
 
 inline std::string SharedSynthModule::get_name() const
 {
-    static const char* names[] = {"Output", "Oscillator", "Moog Filter", "ADSR", "VCA", "Mono Mixer", "Math"};  // each module's get_name()
+    static const char* names[] = {"Output", "Oscillator", "Moog Filter", "ADSR", "VCA", "Mono Mixer", "Math",
+                                  "Grid Sequencer", "Pattern Sequencer", "Non-Linear", "Sample"};  // each module's get_name()
     int t = srack_patch_module_type(ws_->p_, index_);
     if (t == SRACK_MOD_MATH) {
         static const char* ops[] = {"Add", "Subtract", "Multiply"};  // math.rs:37-43
         return ops[(int)get(SRACK_MATH_OPERATION) % 3];
     }
-    return t >= 0 && t < 7 ? names[t] : "?";
+    return t >= 0 && t < SRACK_MOD__COUNT ? names[t] : "?";
 }
 inline uint8_t SharedSynthModule::get_num_inputs() const { return (uint8_t)ws_->check(srack_module_num_inputs(ws_->p_, index_)); }
 inline uint8_t SharedSynthModule::get_num_outputs() const { return (uint8_t)ws_->check(srack_module_num_outputs(ws_->p_, index_)); }
@@ -178,6 +186,11 @@ inline std::optional<std::optional<std::pair<SharedSynthModule, uint8_t>>> Share
     return std::optional<std::pair<SharedSynthModule, uint8_t>>{std::make_pair(SharedSynthModule(ws_, m), (uint8_t)port)};
 }
 inline void SharedSynthModule::set(int field, double value) { ws_->check(srack_patch_set_field(ws_->p_, index_, field, value)); }
+inline void SharedSynthModule::set_step(int channel, int step, int state, int value) { ws_->check(srack_patch_set_step(ws_->p_, index_, channel, step, state, value)); }
+inline void SharedSynthModule::set_wave(const std::vector<float>& samples, float sample_rate)
+{
+    ws_->check(srack_patch_set_wave(ws_->p_, index_, samples.data(), (uint32_t)samples.size(), sample_rate));
+}
 inline double SharedSynthModule::get(int field) const
 {
     double v = 0;

@@ -56,7 +56,10 @@ enum {
     /* scope table (f) rank 1: the clocked note sources that sit in front of the path in real patches */
     SRACK_MOD_GRID_SEQUENCER    = 7, /* sequencer::GridSequencerModule    src/synth/sequencer.rs:12-246   */
     SRACK_MOD_PATTERN_SEQUENCER = 8, /* sequencer::PatternSequencerModule src/synth/sequencer.rs:336-533 */
-    SRACK_MOD__COUNT      = 9
+    /* scope table (f) rank 4: the remaining per-voice modules */
+    SRACK_MOD_NONLINEAR   = 9,  /* math::NonLinearModule       src/synth/math.rs:176-311     */
+    SRACK_MOD_SAMPLE      = 10, /* sample::SampleModule        src/synth/sample.rs:72-240    */
+    SRACK_MOD__COUNT      = 11
 };
 
 /* ---- ports (u8 in the reference) --------------------------------------------------------- */
@@ -66,6 +69,7 @@ enum { SRACK_VCF_IN_AUDIO = 0, SRACK_VCF_IN_CV = 1 };                       /* f
 enum { SRACK_VCF_OUT_LOWPASS = 0, SRACK_VCF_OUT_BANDPASS = 1, SRACK_VCF_OUT_HIGHPASS = 2 }; /* filter.rs:166-172 */
 enum { SRACK_ADSR_IN_GATE = 0 };                                            /* adsr.rs:77-82 */
 enum { SRACK_VCA_IN_AUDIO = 0, SRACK_VCA_IN_CV = 1 };                       /* vca.rs:50-56 */
+enum { SRACK_SAMPLE_IN_GATE = 0, SRACK_SAMPLE_IN_CV = 1 };                  /* sample.rs:166-172 */
 enum { SRACK_SEQ_IN_STEP = 0, SRACK_SEQ_IN_SYNC = 1 };                      /* sequencer.rs:253-259, 543-549 */
 enum { SRACK_GRIDSEQ_OUT_CV = 0, SRACK_GRIDSEQ_OUT_GATE = 1, SRACK_GRIDSEQ_OUT_SYNC = 2 }; /* sequencer.rs:291-298 */
 enum { SRACK_PATSEQ_OUT_GATE0 = 0, SRACK_PATSEQ_OUT_SYNC = 8 };             /* gates 0..7, then sync (sequencer.rs:578-586) */
@@ -115,6 +119,17 @@ enum { /* PatternSequencerModule, sequencer.rs:337-349 */
     SRACK_PATSEQ_CURRENT_STEP = 1, SRACK_PATSEQ_STEP_LAST = 2, SRACK_PATSEQ_SYNC_LAST = 3,
     SRACK_PATSEQ__NFIELDS = 4
 };
+enum { SRACK_NONLIN_CONSTANT = 0 /* f32 exponent used when In2 is unconnected, default 1.0 */,
+       SRACK_NONLIN__NFIELDS = 1 };                                         /* math.rs:177-185 */
+enum { /* SampleModule + WaveBox, sample.rs:15-20, 72-85 (the samples themselves: srack_patch_set_wave) */
+    SRACK_SAMPLE_SAMPLE_RATE = 0,      /* f32 copy of the audio sample rate */
+    SRACK_SAMPLE_WAVE_SAMPLE_RATE = 1, /* f32 wavebox.sample_rate; 0.0 until a wave is set */
+    SRACK_SAMPLE_WAVE_NEW = 2,         /* wavebox.new: the next render starts with pos = 0, playing = false */
+    SRACK_SAMPLE_POS = 3,              /* f32 read position in wave samples (state) */
+    SRACK_SAMPLE_PLAYING = 4,          /* bool (state) */
+    SRACK_SAMPLE_GATE_LAST = 5,        /* transition_detector.last (state) */
+    SRACK_SAMPLE__NFIELDS = 6
+};
 /* step contents for srack_patch_set_step.
  * Grid: sequence[step] = None | Some((value, hold)) (sequencer.rs:19);  Pattern: sequence[channel][step] = None | Some(false) | Some(true). */
 enum { SRACK_STEP_NONE = 0, SRACK_STEP_ON = 1 /* Some((v,false)) / Some(false): gate follows the clock */,
@@ -161,6 +176,12 @@ int srack_patch_get_field(const srack_patch* p, int module, int field, double* v
  * Grid sequencer: channel must be 0, `value` is the note index (u16); pattern sequencer: channel 0..7, value ignored. */
 int srack_patch_set_step(srack_patch* p, int module, int channel, int step, int state, int value);
 int srack_patch_get_step(const srack_patch* p, int module, int channel, int step, int* state, int* value);
+
+/* SampleModule's WaveBox as WaveBox::load leaves it (sample.rs:31-69): the first channel of the file as
+ * f32 samples (copied), the file's sample rate, and new = true.  Shared by every voice.
+ * get_wave copies up to `cap` samples and returns the wave's length. */
+int srack_patch_set_wave(srack_patch* p, int module, const float* samples, uint32_t n_samples, float sample_rate);
+int srack_patch_get_wave(const srack_patch* p, int module, float* samples, uint32_t cap, float* sample_rate);
 
 /* SynthModule::set_input / disconnect_input / get_input. */
 int srack_patch_connect(srack_patch* p, int src_module, int src_port, int sink_module, int sink_port);

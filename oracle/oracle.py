@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsrack_oracle.so")
 
 # module types / fields: numeric vocabulary of include/srack_hip.h
-MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH, MOD_GRID_SEQUENCER, MOD_PATTERN_SEQUENCER = range(9)
+MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH, MOD_GRID_SEQUENCER, MOD_PATTERN_SEQUENCER, MOD_NONLINEAR, MOD_SAMPLE = range(11)
 
 
 def build(force=False):
@@ -52,6 +52,7 @@ def lib():
         L.or_set_field.argtypes = [vp, i32, i32, dbl]
         L.or_get_field.argtypes = [vp, i32, i32, dp]
         L.or_set_step.argtypes = [vp, i32, i32, i32, i32, i32]
+        L.or_set_wave.argtypes = [vp, i32, fp, u32, C.c_float]
         L.or_plan.argtypes = [vp]
         L.or_plan_list.argtypes = [vp, i32, ip, i32]
         L.or_get_plan.argtypes = [vp, ip, i32]
@@ -112,6 +113,11 @@ class OraclePatch:
     def set_step(self, module, channel, step, state, value=0):
         if self.L.or_set_step(self.h, module, channel, step, state, value) < 0:
             raise ValueError("or_set_step failed")
+
+    def set_wave(self, module, samples, sample_rate):
+        a = np.ascontiguousarray(samples, dtype=np.float32)
+        if self.L.or_set_wave(self.h, module, _fp(a), a.size, float(sample_rate)) < 0:
+            raise ValueError("or_set_wave failed")
 
     def get_field(self, module, field):
         v = C.c_double()

@@ -12,9 +12,20 @@ f64::powf / sin / % reach on x86_64-linux-gnu.
 Written object-style like the reference (one class per module, calc() fills block buffers);
 citations are to /root/reference/src.
 """
+import ctypes
 import math
 
 import numpy as np
+
+# f32::powf is libm's powf (math.rs:204, sample.rs:236); Python has no f32 pow of its own, and NumPy's float32 power is
+# NumPy's own SIMD routine, so call the same glibc symbol Rust reaches
+_libm = ctypes.CDLL("libm.so.6")
+_libm.powf.restype = ctypes.c_float
+_libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+
+
+def powf(a, b):
+    return np.float32(_libm.powf(float(a), float(b)))
 
 f32 = np.float32
 ZERO, ONE, TWO = f32(0.0), f32(1.0), f32(2.0)
@@ -342,7 +353,66 @@ class PatternSequencer(_Sequencer):  # sequencer.rs:336-533
             self.outs[8][idx] = ONE if cs == 0 else ZERO
 
 
-CLASSES = [Output, Oscillator, MoogFilter, ADSR, VCA, MonoMixer, Math, GridSequencer, PatternSequencer]  # index = SRACK_MOD_*
+class NonLinear(Module):  # math.rs:176-311
+    n_in, n_out = 2, 1
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.constant = ONE
+
+    @staticmethod
+    def operation(a, b):  # math.rs:203-205
+        return powf(a, b) if a > ZERO else -powf(-a, b)
+
+    def calc(self):  # math.rs:291-311
+        i1, i2 = self.resolve(0), self.resolve(1)
+        out = self.outs[0]
+        for i in range(len(out)):
+            out[i] = self.operation(i1[i] if i1 is not None else ZERO, i2[i] if i2 is not None else self.constant)
+
+
+def as_usize(x):  # Rust `f32 as usize`: saturating, NaN -> 0
+    x = float(x)
+    if not x > 0.0:
+        return 0
+    return min(int(x), 2**64 - 1)
+
+
+class Sample(Module):  # sample.rs:72-240
+    n_in, n_out = 2, 1
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.td = TransitionDetector()
+        self.pos = ZERO
+        self.playing = False
+        self.sample_rate = f32(cfg["sample_rate"])
+        self.samples = np.zeros(0, dtype=f32)  # WaveBox::default()
+        self.wave_sample_rate = ZERO
+        self.wave_new = False
+
+    def load(self, samples, sample_rate):  # what WaveBox::load leaves behind, sample.rs:31-69
+        self.samples = np.array(samples, dtype=f32)
+        self.wave_sample_rate = f32(sample_rate)
+        self.wave_new = True
+
+    def calc(self):  # sample.rs:192-240
+        gate_in, cv_in = self.resolve(0), self.resolve(1)
+        out = self.outs[0]
+        if self.wave_new:
+            self.pos, self.playing, self.wave_new = ZERO, False, False
+        with np.errstate(all="ignore"):
+            for idx in range(len(out)):
+                if self.td.is_transition(gate_in[idx] if gate_in is not None else ZERO):
+                    self.pos, self.playing = ZERO, True
+                if as_usize(self.pos) >= len(self.samples):
+                    self.pos, self.playing = ZERO, False
+                out[idx] = self.samples[as_usize(self.pos)] if len(self.samples) else ZERO
+                if self.playing:
+                    self.pos = self.pos + self.wave_sample_rate / self.sample_rate * powf(TWO, cv_in[idx] if cv_in is not None else ZERO)
+
+
+CLASSES = [Output, Oscillator, MoogFilter, ADSR, VCA, MonoMixer, Math, GridSequencer, PatternSequencer, NonLinear, Sample]  # index = SRACK_MOD_*
 
 
 def get_inputs(m):  # synth.rs:214-218

@@ -12,8 +12,9 @@
  * saw/square/PolyBLEP, the ladder filter, ADSR, VCA, mixer, math and output the reference holds
  * no known-answer vector, so for those "parity unpinned" by the reference: fidelity rests on
  * this file and the independent NumPy restatement (oracle/srack_numpy.py) agreeing bit for bit.
- * The same holds for the two sequencers (src/synth/sequencer.rs:190-246, 482-533), added as the
- * scope table's "next" row.
+ * The same holds for the two sequencers (src/synth/sequencer.rs:190-246, 482-533), the non-linear
+ * waveshaper (src/synth/math.rs:176-205, 291-311) and the sample player (src/synth/sample.rs:192-240),
+ * added as the scope table's "next" rows.
  *
  * Structure follows the reference, not the GPU path: one object graph, per-port block buffers of
  * `buffer_size` f32 (zero-initialised, synth.rs:31-33), module-major execute() (synth.rs:97-101),
@@ -89,6 +90,19 @@ typedef struct {
     float last;
 } or_seq;
 
+/* sample.rs:72-85 + WaveBox (sample.rs:15-20).  The reference shares one WaveBox between clones of a
+ * module (Arc); here every clone owns a copy, including the `new` flag, so each voice sees the load. */
+typedef struct {
+    or_transition_detector td;
+    float pos;
+    int playing;
+    float sample_rate;   /* audio_config.sample_rate as f32 */
+    float* samples;      /* wavebox.samples */
+    uint32_t n_samples;
+    float wave_sample_rate;
+    int wave_new;
+} or_sample;
+
 typedef struct {
     int type;
     int n_in, n_out;
@@ -101,6 +115,8 @@ typedef struct {
         struct { int negative; } vca;
         struct { float gain[4]; } mix;
         struct { float constant; int operation; } math;
+        struct { float constant; } nonlin;
+        or_sample smp;
         or_seq seq;
     } u;
 } or_module;
@@ -133,8 +149,10 @@ or_patch* or_patch_new(uint32_t sample_rate, uint32_t buffer_size, uint32_t chan
 void or_patch_free(or_patch* p)
 {
     if (!p) return;
-    for (int i = 0; i < p->n_modules; i++)
+    for (int i = 0; i < p->n_modules; i++) {
         for (int k = 0; k < OR_MAX_OUT; k++) free(p->modules[i].out[k]);
+        if (p->modules[i].type == SRACK_MOD_SAMPLE) free(p->modules[i].u.smp.samples);
+    }
     free(p->modules);
     free(p->plan);
     free(p->removed);
@@ -209,6 +227,17 @@ int or_add_module(or_patch* p, int type)
         m->n_out = 1;
         m->u.math.constant = 0.0f;
         m->u.math.operation = SRACK_MATH_ADD;
+        break;
+    case SRACK_MOD_NONLINEAR: /* math.rs:186-196 */
+        m->n_in = 2;
+        m->n_out = 1;
+        m->u.nonlin.constant = 1.0f;
+        break;
+    case SRACK_MOD_SAMPLE: /* sample.rs:88-101; WaveBox::default() => no samples, sample_rate 0.0, new false */
+        m->n_in = 2;
+        m->n_out = 1;
+        m->u.smp.td.last = 1;
+        m->u.smp.sample_rate = (float)(uint16_t)p->sample_rate;
         break;
     case SRACK_MOD_GRID_SEQUENCER: /* sequencer.rs:33-50 */
         m->n_in = 2;
@@ -308,6 +337,14 @@ static float* or_field_f32(or_module* m, int field)
     case SRACK_MOD_GRID_SEQUENCER:
         if (field == SRACK_GRIDSEQ_LAST) return &m->u.seq.last;
         break;
+    case SRACK_MOD_NONLINEAR:
+        if (field == SRACK_NONLIN_CONSTANT) return &m->u.nonlin.constant;
+        break;
+    case SRACK_MOD_SAMPLE:
+        if (field == SRACK_SAMPLE_POS) return &m->u.smp.pos;
+        if (field == SRACK_SAMPLE_SAMPLE_RATE) return &m->u.smp.sample_rate;
+        if (field == SRACK_SAMPLE_WAVE_SAMPLE_RATE) return &m->u.smp.wave_sample_rate;
+        break;
     }
     return NULL;
 }
@@ -336,6 +373,11 @@ static int* or_field_int(or_module* m, int field)
         if (field == SRACK_GRIDSEQ_STEP_LAST) return &m->u.seq.td.last;
         if (field == SRACK_GRIDSEQ_SYNC_LAST) return &m->u.seq.sync_td.last;
         break;
+    case SRACK_MOD_SAMPLE:
+        if (field == SRACK_SAMPLE_PLAYING) return &m->u.smp.playing;
+        if (field == SRACK_SAMPLE_GATE_LAST) return &m->u.smp.td.last;
+        if (field == SRACK_SAMPLE_WAVE_NEW) return &m->u.smp.wave_new;
+        break;
     case SRACK_MOD_PATTERN_SEQUENCER:
         if (field == SRACK_PATSEQ_LENGTH) return &m->u.seq.length;
         if (field == SRACK_PATSEQ_STEP_LAST) return &m->u.seq.td.last;
@@ -362,6 +404,21 @@ int or_set_step(or_patch* p, int module, int channel, int step, int state, int v
     m->u.seq.present[channel][step] = state != 0;
     m->u.seq.hold[channel][step] = state == 2;
     if (grid) m->u.seq.val[step] = (uint16_t)value;
+    return 0;
+}
+
+/* What WaveBox::load leaves behind (sample.rs:31-69): the first channel's samples as f32, the file's
+ * sample rate, new = true.  (Decoding the .wav itself is the host's job and off the path.) */
+int or_set_wave(or_patch* p, int module, const float* samples, uint32_t n, float wave_sample_rate)
+{
+    if (module < 0 || module >= p->n_modules || p->modules[module].type != SRACK_MOD_SAMPLE) return -1;
+    or_sample* s = &p->modules[module].u.smp;
+    free(s->samples);
+    s->samples = n ? (float*)malloc(sizeof(float) * n) : NULL;
+    if (n) memcpy(s->samples, samples, sizeof(float) * n);
+    s->n_samples = n;
+    s->wave_sample_rate = wave_sample_rate;
+    s->wave_new = 1;
     return 0;
 }
 
@@ -771,6 +828,61 @@ static void or_calc_math(or_patch* p, or_module* m)
         out[i] = or_math_op(m->u.math.operation, i1 ? i1[i] : 0.0f, i2 ? i2[i] : m->u.math.constant);
 }
 
+/* NonLinearModule::operation, math.rs:203-205: sign-preserving power (f32::powf = libm powf) */
+static float or_nonlin_op(float a, float b)
+{
+    if (a > 0.0f) return powf(a, b);
+    return -powf(-a, b);
+}
+
+/* NonLinearModule::calc, math.rs:291-311 */
+static void or_calc_nonlin(or_patch* p, or_module* m)
+{
+    const float* i1 = or_resolve(p, m, 0);
+    const float* i2 = or_resolve(p, m, 1);
+    float* out = m->out[0];
+    for (uint32_t i = 0; i < p->buffer_size; i++) out[i] = or_nonlin_op(i1 ? i1[i] : 0.0f, i2 ? i2[i] : m->u.nonlin.constant);
+}
+
+/* Rust's `f32 as usize`: saturating, NaN -> 0 */
+static size_t or_f32_as_usize(float x)
+{
+    if (!(x > 0.0f)) return 0; /* negative, -0, NaN */
+    if (x >= 18446744073709551616.0f) return SIZE_MAX;
+    return (size_t)x;
+}
+
+/* SampleModule::calc, sample.rs:192-240 (the try_lock failure branch needs a second thread holding
+ * the WaveBox; there is none in an offline render) */
+static void or_calc_sample(or_patch* p, or_module* m)
+{
+    or_sample* s = &m->u.smp;
+    const float* gate_in = or_resolve(p, m, 0);
+    const float* cv_in = or_resolve(p, m, 1);
+    float* out = m->out[0];
+    if (s->wave_new) {
+        s->pos = 0.0f;
+        s->playing = 0;
+        s->wave_new = 0;
+    }
+    for (uint32_t idx = 0; idx < p->buffer_size; idx++) {
+        int trigger = or_is_transition(&s->td, gate_in ? gate_in[idx] : 0.0f);
+        if (trigger) {
+            s->pos = 0.0f;
+            s->playing = 1;
+        }
+        if (or_f32_as_usize(s->pos) >= (size_t)s->n_samples) {
+            s->pos = 0.0f;
+            s->playing = 0;
+        }
+        if (s->n_samples != 0)
+            out[idx] = s->samples[or_f32_as_usize(s->pos)];
+        else
+            out[idx] = 0.0f;
+        if (s->playing) s->pos += s->wave_sample_rate / s->sample_rate * powf(2.0f, cv_in ? cv_in[idx] : 0.0f);
+    }
+}
+
 /* the stepping both sequencers share: sequencer.rs:219-231 and 504-516 */
 static int or_seq_advance(or_seq* q, float step_in, float sync_in)
 {
@@ -844,6 +956,8 @@ static void or_calc(or_patch* p, or_module* m)
     case SRACK_MOD_VCA: or_calc_vca(p, m); break;
     case SRACK_MOD_MONO_MIXER: or_calc_mixer(p, m); break;
     case SRACK_MOD_MATH: or_calc_math(p, m); break;
+    case SRACK_MOD_NONLINEAR: or_calc_nonlin(p, m); break;
+    case SRACK_MOD_SAMPLE: or_calc_sample(p, m); break;
     case SRACK_MOD_GRID_SEQUENCER: or_calc_gridseq(p, m); break;
     case SRACK_MOD_PATTERN_SEQUENCER: or_calc_patseq(p, m); break;
     }
@@ -906,12 +1020,18 @@ or_patch* or_patch_clone(const or_patch* src)
     *p = *src;
     p->modules = (or_module*)malloc(sizeof(or_module) * (size_t)(src->cap_modules ? src->cap_modules : 1));
     memcpy(p->modules, src->modules, sizeof(or_module) * (size_t)src->n_modules);
-    for (int i = 0; i < p->n_modules; i++)
+    for (int i = 0; i < p->n_modules; i++) {
         for (int k = 0; k < OR_MAX_OUT; k++)
             if (src->modules[i].out[k]) {
                 p->modules[i].out[k] = (float*)malloc(sizeof(float) * src->buffer_size);
                 memcpy(p->modules[i].out[k], src->modules[i].out[k], sizeof(float) * src->buffer_size);
             }
+        if (src->modules[i].type == SRACK_MOD_SAMPLE && src->modules[i].u.smp.samples) {
+            const or_sample* ss = &src->modules[i].u.smp;
+            p->modules[i].u.smp.samples = (float*)malloc(sizeof(float) * ss->n_samples);
+            memcpy(p->modules[i].u.smp.samples, ss->samples, sizeof(float) * ss->n_samples);
+        }
+    }
     p->plan = NULL;
     p->removed = NULL;
     if (src->plan) {

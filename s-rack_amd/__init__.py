@@ -23,7 +23,7 @@ RENDER_DEFAULT, RENDER_EXACT_OSC, RENDER_NO_FUSION, RENDER_NO_UNIFORM_HOIST = 0,
 ABI_SYMBOLS = [
     "srack_abi_version", "srack_last_error", "srack_patch_create", "srack_patch_destroy", "srack_patch_add_module",
     "srack_patch_num_modules", "srack_patch_module_type", "srack_module_num_inputs", "srack_module_num_outputs",
-    "srack_patch_set_field", "srack_patch_get_field", "srack_patch_set_step", "srack_patch_get_step", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
+    "srack_patch_set_field", "srack_patch_get_field", "srack_patch_set_step", "srack_patch_get_step", "srack_patch_set_wave", "srack_patch_get_wave", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
     "srack_patch_plan", "srack_patch_plan_list", "srack_patch_removed_edges", "srack_patch_delayed_edges",
     "srack_voices_configure", "srack_voices_set_field_f32", "srack_voices_set_field_f64", "srack_render_planes", "srack_render",
     "srack_render_info", "srack_render_kernel_ms", "srack_voices_get_field", "srack_device_count", "srack_device_set",
@@ -57,6 +57,8 @@ def _load():
     L.srack_patch_get_field.argtypes = [vp, i32, i32, dp]
     L.srack_patch_set_step.argtypes = [vp, i32, i32, i32, i32, i32]
     L.srack_patch_get_step.argtypes = [vp, i32, i32, i32, ip, ip]
+    L.srack_patch_set_wave.argtypes = [vp, i32, fp, u32, C.c_float]
+    L.srack_patch_get_wave.argtypes = [vp, i32, fp, u32, fp]
     L.srack_patch_connect.argtypes = [vp, i32, i32, i32, i32]
     L.srack_patch_disconnect.argtypes = [vp, i32, i32]
     L.srack_patch_get_input.argtypes = [vp, i32, i32, ip, ip]
@@ -148,6 +150,18 @@ class Patch:
         st, v = C.c_int(), C.c_int()
         _check(lib.srack_patch_get_step(self.h, module, channel, step, C.byref(st), C.byref(v)))
         return st.value, v.value
+
+    def set_wave(self, module, samples, sample_rate):
+        """WaveBox::load's result for a SampleModule: first-channel f32 samples + the file's sample rate."""
+        a = np.ascontiguousarray(samples, dtype=np.float32)
+        _check(lib.srack_patch_set_wave(self.h, module, a.ctypes.data_as(C.POINTER(C.c_float)), a.size, float(sample_rate)))
+
+    def get_wave(self, module):
+        sr = C.c_float()
+        n = _check(lib.srack_patch_get_wave(self.h, module, None, 0, C.byref(sr)))
+        a = np.zeros(n, dtype=np.float32)
+        _check(lib.srack_patch_get_wave(self.h, module, a.ctypes.data_as(C.POINTER(C.c_float)), n, C.byref(sr)))
+        return a, sr.value
 
     def connect(self, src, src_port, sink, sink_port):
         _check(lib.srack_patch_connect(self.h, src, src_port, sink, sink_port))

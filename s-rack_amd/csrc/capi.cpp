@@ -161,6 +161,26 @@ int srack_patch_get_step(const srack_patch* p, int module, int channel, int step
     return p->h.graph.get_step(module, channel, step, state, value);
 }
 
+int srack_patch_set_wave(srack_patch* p, int module, const float* samples, uint32_t n_samples, float sample_rate)
+{
+    CHECK_HANDLE(p);
+    return p->h.graph.set_wave(module, samples, n_samples, sample_rate);
+}
+
+int srack_patch_get_wave(const srack_patch* p, int module, float* samples, uint32_t cap, float* sample_rate)
+{
+    CHECK_HANDLE(p);
+    const Module* m = get_module(p, module);
+    if (!m || m->type != SRACK_MOD_SAMPLE) {
+        set_error("get_wave: not a SampleModule");
+        return SRACK_ERR_INVALID;
+    }
+    if (samples)
+        for (size_t i = 0; i < m->wave.size() && i < (size_t)cap; i++) samples[i] = m->wave[i];
+    if (sample_rate) *sample_rate = (float)m->fields[SRACK_SAMPLE_WAVE_SAMPLE_RATE];
+    return (int)m->wave.size();
+}
+
 int srack_patch_connect(srack_patch* p, int src_module, int src_port, int sink_module, int sink_port)
 {
     CHECK_HANDLE(p);

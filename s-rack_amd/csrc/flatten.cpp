@@ -309,6 +309,34 @@ int Builder::build()
             op.flags |= ((uint32_t)(int)field(m, SRACK_MATH_OPERATION) & 3u) << MATH_OP_SHIFT;
             param(op, MATH_P_CONST, m, SRACK_MATH_CONSTANT, deferred);
             break;
+        case SRACK_MOD_NONLINEAR:
+            op.kind = OP_NONLIN;
+            if (connected(0)) op.flags |= MATH_HAS_IN1;
+            if (connected(1)) op.flags |= MATH_HAS_IN2;
+            param(op, NONLIN_P_CONST, m, SRACK_NONLIN_CONSTANT, deferred);
+            break;
+        case SRACK_MOD_SAMPLE: {
+            op.kind = OP_SAMPLE;
+            if (connected(0)) op.flags |= SMP_HAS_GATE;
+            if (connected(1)) op.flags |= SMP_HAS_CV;
+            op.state_row = state_row_f32(m, SRACK_SAMPLE_POS);
+            const int playing_row = state_row_flag(m, SRACK_SAMPLE_PLAYING);
+            state_row_flag(m, SRACK_SAMPLE_GATE_LAST);
+            if (field(m, SRACK_SAMPLE_WAVE_NEW) != 0.0) {  // `if wavebox.new { pos = 0.0; playing = false; }` at the first calc (sample.rs:206-210)
+                rows[(size_t)op.state_row].assign(V, 0u);
+                rows[(size_t)playing_row].assign(V, 0u);
+            }
+            param(op, SMP_P_SR, m, SRACK_SAMPLE_SAMPLE_RATE, deferred);
+            param(op, SMP_P_WAVE_SR, m, SRACK_SAMPLE_WAVE_SAMPLE_RATE, deferred);
+            if (mod.wave.size() >= (size_t)1 << 31) {
+                set_error("flatten: wave longer than 2^31 - 1 samples");
+                return SRACK_ERR_UNSUPPORTED;
+            }
+            op.seq_len = (int)mod.wave.size();
+            op.aux = (int)out.seqtab.size();
+            for (float f : mod.wave) out.seqtab.push_back(f32_bits(f));
+            break;
+        }
         case SRACK_MOD_GRID_SEQUENCER:
         case SRACK_MOD_PATTERN_SEQUENCER: {
             const bool grid = mod.type == SRACK_MOD_GRID_SEQUENCER;
@@ -612,6 +640,10 @@ StateLoc FlatProgram::locate(const Graph& g, int module, int field) const
         loc.row = op.state_row + (field - SRACK_PATSEQ_CURRENT_STEP);
         loc.flag = true;
         break;
+    case SRACK_MOD_SAMPLE:
+        loc.row = op.state_row + (field - SRACK_SAMPLE_POS);
+        loc.flag = field != SRACK_SAMPLE_POS;
+        break;
     case SRACK_MOD_ADSR:
         switch (field) {
         case SRACK_ADSR_PHASE: loc.row = op.state_row + ADSR_S_PHASE; break;
@@ -642,8 +674,8 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
         int type = g.modules[(size_t)o.module].type;
         if ((type == SRACK_MOD_OSCILLATOR && o.field == SRACK_OSC_ANTIALIASING) || (type == SRACK_MOD_MATH && o.field == SRACK_MATH_OPERATION) ||
             (type == SRACK_MOD_GRID_SEQUENCER && (o.field == SRACK_GRIDSEQ_LENGTH || o.field == SRACK_GRIDSEQ_OCTAVES)) ||
-            (type == SRACK_MOD_PATTERN_SEQUENCER && o.field == SRACK_PATSEQ_LENGTH)) {
-            set_error("flatten: antialiasing / operation / sequence length are structural and cannot differ per voice");
+            (type == SRACK_MOD_PATTERN_SEQUENCER && o.field == SRACK_PATSEQ_LENGTH) || (type == SRACK_MOD_SAMPLE && o.field == SRACK_SAMPLE_WAVE_NEW)) {
+            set_error("flatten: antialiasing / operation / sequence length / wavebox.new are structural and cannot differ per voice");
             return SRACK_ERR_UNSUPPORTED;
         }
     }

@@ -21,6 +21,8 @@ int Graph::fields_of_type(int type)
     case SRACK_MOD_MATH: return SRACK_MATH__NFIELDS;
     case SRACK_MOD_GRID_SEQUENCER: return SRACK_GRIDSEQ__NFIELDS;
     case SRACK_MOD_PATTERN_SEQUENCER: return SRACK_PATSEQ__NFIELDS;
+    case SRACK_MOD_NONLINEAR: return SRACK_NONLIN__NFIELDS;
+    case SRACK_MOD_SAMPLE: return SRACK_SAMPLE__NFIELDS;
     default: return -1;
     }
 }
@@ -35,6 +37,7 @@ bool Graph::field_is_state(int type, int field)
                field == SRACK_ADSR_GATE_LAST;
     case SRACK_MOD_GRID_SEQUENCER: return field >= SRACK_GRIDSEQ_CURRENT_STEP;
     case SRACK_MOD_PATTERN_SEQUENCER: return field >= SRACK_PATSEQ_CURRENT_STEP;
+    case SRACK_MOD_SAMPLE: return field >= SRACK_SAMPLE_POS;
     default: return false;
     }
 }
@@ -50,6 +53,7 @@ bool Graph::field_is_flag(int type, int field)
     case SRACK_MOD_MATH: return field == SRACK_MATH_OPERATION;
     case SRACK_MOD_GRID_SEQUENCER: return field != SRACK_GRIDSEQ_LAST;  // integers and detector bits; `last` is an f32
     case SRACK_MOD_PATTERN_SEQUENCER: return true;
+    case SRACK_MOD_SAMPLE: return field == SRACK_SAMPLE_WAVE_NEW || field == SRACK_SAMPLE_PLAYING || field == SRACK_SAMPLE_GATE_LAST;
     default: return false;
     }
 }
@@ -127,6 +131,17 @@ int Graph::add_module(int type)
         m.fields[SRACK_PATSEQ_STEP_LAST] = 1.0;
         m.fields[SRACK_PATSEQ_SYNC_LAST] = 1.0;
         m.cells.assign(64, 0u);
+        break;
+    case SRACK_MOD_NONLINEAR:  // math.rs:186-196
+        m.n_in = 2;
+        m.n_out = 1;
+        m.fields[SRACK_NONLIN_CONSTANT] = 1.0;
+        break;
+    case SRACK_MOD_SAMPLE:  // sample.rs:88-101; WaveBox::default(): no samples, sample_rate 0.0, new = false
+        m.n_in = 2;
+        m.n_out = 1;
+        m.fields[SRACK_SAMPLE_SAMPLE_RATE] = (double)(float)cfg.sample_rate;
+        m.fields[SRACK_SAMPLE_GATE_LAST] = 1.0;
         break;
     }
     m.in.assign((size_t)m.n_in, InputRef{});
@@ -225,6 +240,21 @@ int Graph::get_step(int module, int channel, int step, int* state, int* value) c
     }
     if (state) *state = st;
     if (value) *value = v;
+    return SRACK_OK;
+}
+
+// WaveBox::load's result (sample.rs:31-69): samples, sample_rate, new = true
+int Graph::set_wave(int module, const float* samples, uint32_t n, float sample_rate)
+{
+    if (module < 0 || module >= (int)modules.size() || modules[(size_t)module].type != SRACK_MOD_SAMPLE || (n && !samples)) {
+        set_error("set_wave: not a SampleModule");
+        return SRACK_ERR_INVALID;
+    }
+    Module& m = modules[(size_t)module];
+    m.wave.assign(samples, samples + n);
+    m.fields[SRACK_SAMPLE_WAVE_SAMPLE_RATE] = (double)sample_rate;
+    m.fields[SRACK_SAMPLE_WAVE_NEW] = 1.0;
+    revision++;
     return SRACK_OK;
 }
 

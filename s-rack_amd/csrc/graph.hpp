@@ -32,6 +32,7 @@ struct Module {
     // sequencers: 64 grid cells in device format.  Grid: bit 31 present, bit 30 hold, bits 0..15 note value;
     // pattern: bits 2c / 2c+1 = present / hold of channel c.
     std::vector<uint32_t> cells;
+    std::vector<float> wave;  // SampleModule: wavebox.samples
 };
 
 struct AudioConfig {  // synth.rs:20-25
@@ -65,6 +66,7 @@ public:
     int get_field(int module, int field, double* value) const;
     int set_step(int module, int channel, int step, int state, int value);
     int get_step(int module, int channel, int step, int* state, int* value) const;
+    int set_wave(int module, const float* samples, uint32_t n, float sample_rate);
     int connect(int src, int src_port, int sink, int sink_port);
     int disconnect(int sink, int sink_port);
 

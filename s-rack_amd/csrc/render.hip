@@ -321,6 +321,56 @@ __device__ __noinline__ void tile_math(const Ctx c, COp& op_v)
     tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = math_step(fl, x[0], x[1], constant); });
 }
 
+__device__ __noinline__ void tile_nonlin(const Ctx c, COp& op_v)
+{
+    COp& op = uniform_op(op_v);
+    const float constant = par(c, op, NONLIN_P_CONST);
+    const uint32_t fl = op.flags;
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
+    tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = nonlin_step(fl, x[0], x[1], constant); });
+}
+
+// SampleModule (sample.rs:192-240) in two passes over the tile: the position state machine does not depend on the
+// samples it reads, so pass 1 leaves each sample's read INDEX in the output wire and pass 2 turns indices into
+// samples with independent gathers from the shared wave (8 loads in flight per lane instead of one per step).
+__device__ __noinline__ void tile_sample(const Ctx c, COp& op_v, CArgs& a_v)
+{
+    COp& op = uniform_op(op_v);
+    CArgs& a = uniform_args(a_v);
+    const int sr = op.state_row;
+    const uint32_t fl = op.flags;
+    SmpRegs s;
+    s.pos = __uint_as_float(ROW(sr + SMP_S_POS));
+    s.playing = ROW(sr + SMP_S_PLAYING) != 0;
+    s.gate_last = ROW(sr + SMP_S_GATE_LAST) != 0;
+    const float ratio = par(c, op, SMP_P_WAVE_SR) / par(c, op, SMP_P_SR);
+    const uint32_t n_wave = (uint32_t)op.seq_len;
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
+    tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = __uint_as_float(sample_advance(fl, s, ratio, n_wave, x[0], x[1])); });
+    ROW(sr + SMP_S_POS) = __float_as_uint(s.pos);
+    ROW(sr + SMP_S_PLAYING) = s.playing ? 1u : 0u;
+    ROW(sr + SMP_S_GATE_LAST) = s.gate_last ? 1u : 0u;
+    if (op.out_slot[0] < 0) return;
+    const uint32_t* wave = a.seqtab + op.aux;
+    const Port w = out[0];
+    int i = 0;
+    for (; i + 8 <= c.n; i += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = __float_as_uint(w.p[(i + u) * w.stride]);
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = n_wave ? wave[v[u]] : 0u;  // empty wave: `*out = 0.0`
+#pragma unroll
+        for (int u = 0; u < 8; u++) w.p[(i + u) * w.stride] = __uint_as_float(v[u]);
+    }
+    for (; i < c.n; i++) {
+        const uint32_t idx = __float_as_uint(w.p[i * w.stride]);
+        w.p[i * w.stride] = __uint_as_float(n_wave ? wave[idx] : 0u);
+    }
+}
+
 // Sequencers (sequencer.rs:190-246, 482-533).  The 64 grid cells are wave-shared data: staged once per tile in an LDS
 // row indexed by STEP (not by lane); every lane then gathers the cell of its own current_step.
 struct SeqRegs {
@@ -538,6 +588,8 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
             case OP_OUT: dev::tile_out(c, op, ca, t0, voice, active); break;
             case OP_GRIDSEQ:
             case OP_PATSEQ: dev::tile_seq(c, op, ca); break;
+            case OP_NONLIN: dev::tile_nonlin(c, op); break;
+            case OP_SAMPLE: dev::tile_sample(c, op, ca); break;
             case OP_DELAY_RD: dev::tile_delay_rd(c, op, ca, a.n0 + t0, voice_c); break;
             case OP_DELAY_WR: dev::tile_delay_wr(c, op, ca, a.n0 + t0, voice, active); break;
             default: break;

@@ -8,7 +8,7 @@ import numpy as np
 
 # numeric vocabulary of include/srack_hip.h
 (MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH, MOD_GRID_SEQUENCER,
- MOD_PATTERN_SEQUENCER) = range(9)
+ MOD_PATTERN_SEQUENCER, MOD_NONLINEAR, MOD_SAMPLE) = range(11)
 OSC_VAL, OSC_ANTIALIASING, OSC_POS, OSC_SYNC_LAST = range(4)
 (VCF_FREQ, VCF_RES, VCF_EXP_AMT, VCF_ST_F, VCF_ST_P, VCF_ST_Q, VCF_ST_B0, VCF_ST_B1, VCF_ST_B2, VCF_ST_B3,
  VCF_ST_B4, VCF_ST_FREQ, VCF_ST_RES) = range(13)
@@ -21,6 +21,8 @@ MATH_ADD, MATH_SUBTRACT, MATH_MULTIPLY = range(3)
 (GRIDSEQ_STEPS_PER_OCTAVE, GRIDSEQ_OCTAVES, GRIDSEQ_LENGTH, GRIDSEQ_CURRENT_STEP, GRIDSEQ_STEP_LAST, GRIDSEQ_SYNC_LAST,
  GRIDSEQ_LAST) = range(7)
 PATSEQ_LENGTH, PATSEQ_CURRENT_STEP, PATSEQ_STEP_LAST, PATSEQ_SYNC_LAST = range(4)
+NONLIN_CONSTANT = 0
+SAMPLE_SAMPLE_RATE, SAMPLE_WAVE_SAMPLE_RATE, SAMPLE_WAVE_NEW, SAMPLE_POS, SAMPLE_PLAYING, SAMPLE_GATE_LAST = range(6)
 STEP_NONE, STEP_ON, STEP_HOLD = range(3)
 GRIDSEQ_OUT_CV, GRIDSEQ_OUT_GATE, GRIDSEQ_OUT_SYNC = range(3)
 PATSEQ_OUT_SYNC = 8
@@ -137,6 +139,50 @@ def build_p3(g, clock_val=-4.0, length=8):
     g.connect(pat, 5, out, 1)                         # a raw gate on the second channel
     return dict(clock=clock, grid=grid, pat=pat, transpose=transpose, osc=osc, adsr_amp=adsr_amp, adsr_flt=adsr_flt, vcf=vcf,
                 vca=vca, out=out)
+
+
+def p4_wave(n=1500):
+    """A deterministic stand-in for a loaded .wav (first channel as f32, WaveBox::load sample.rs:31-69): a decaying
+    two-partial tone with a little hash noise, so neighbouring samples differ enough for an index slip to show."""
+    i = np.arange(n, dtype=np.float64)
+    with np.errstate(over="ignore"):
+        noise = (splitmix64(np.arange(n, dtype=np.uint64) ^ np.uint64(0xABCDEF)) >> np.uint64(40)).astype(np.float64) / 16777216.0 - 0.5
+    w = np.exp(-i / (0.35 * n)) * (0.7 * np.sin(2 * np.pi * i * 0.031) + 0.25 * np.sin(2 * np.pi * i * 0.173)) + 0.05 * noise
+    return w.astype(np.float32)
+
+
+def build_p4(g, wave=None, wave_rate=44100.0, clock_val=-3.0):
+    """Patch P4 (scope table (f) rank 4): a clocked sample player with vibrato through the sign-preserving waveshaper.
+
+    List order: [0] CLOCK (square -> Sample.gate), [1] LFO (sine), [2] DEPTH (Multiply: vibrato depth), [3] SAMPLE,
+    [4] SHAPER (NonLinear, exponent = its constant), [5] OUTPUT (ch0 <- shaper, ch1 <- raw sample).
+    """
+    clock = g.add_module(MOD_OSCILLATOR)
+    lfo = g.add_module(MOD_OSCILLATOR)
+    depth = g.add_module(MOD_MATH)
+    smp = g.add_module(MOD_SAMPLE)
+    shaper = g.add_module(MOD_NONLINEAR)
+    out = g.add_module(MOD_OUTPUT)
+    g.set_field(clock, OSC_VAL, clock_val)
+    g.set_field(lfo, OSC_VAL, -5.0)
+    g.set_field(depth, MATH_OPERATION, MATH_MULTIPLY)
+    g.set_field(depth, MATH_CONSTANT, 0.5)
+    g.set_field(shaper, NONLIN_CONSTANT, 0.75)
+    g.set_wave(smp, p4_wave() if wave is None else wave, wave_rate)
+    g.connect(clock, OSC_OUT_SQUARE, smp, 0)
+    g.connect(lfo, OSC_OUT_SINE, depth, 0)
+    g.connect(depth, 0, smp, 1)
+    g.connect(smp, 0, shaper, 0)
+    g.connect(shaper, 0, out, 0)
+    g.connect(smp, 0, out, 1)
+    return dict(clock=clock, lfo=lfo, depth=depth, smp=smp, shaper=shaper, out=out)
+
+
+def p4_voice_params(n_voices, seed=SEED, first_voice=0):
+    """per-voice vibrato depth = U(0, 1) octaves and shaper exponent = U(0.5, 2.0) (the UI slider's range, math.rs:317)."""
+    u0 = voice_uniform(n_voices, 0, seed, first_voice)
+    u1 = voice_uniform(n_voices, 1, seed, first_voice)
+    return u0.astype(np.float32), (np.float32(0.5) + u1 * np.float32(1.5)).astype(np.float32)
 
 
 def splitmix64(x):

@@ -33,6 +33,8 @@ def both(build, n, B, **kw):
 
 
 def save(name, audio, **meta):
+    if len(sys.argv) > 1 and name not in sys.argv[1:]:  # `make_golden.py p4_sample_nonlinear.npz`: only that file
+        return
     sha = hashlib.sha256(audio.tobytes()).hexdigest()
     np.savez_compressed(os.path.join(HERE, name), audio=audio, sha256=np.array(sha), **{k: np.array(v) for k, v in meta.items()})
     print(name, audio.shape, sha[:16], float(np.abs(audio).max()))
@@ -54,6 +56,14 @@ if __name__ == "__main__":
     a, b = g.render(12000), ng.render(12000)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "C oracle != NumPy restatement (P3)"
     save("p3_sequencers.npz", np.ascontiguousarray(a.T), buffer_size=1024)
+    # scope table (f) rank 4: sample player + waveshaper P4, both channels (shaped, raw sample), 0.25 s
+    g = O.OraclePatch(48000, 1024, 2)
+    W.build_p4(g)
+    ng = NumpyGraph(48000, 1024, 2)
+    W.build_p4(ng)
+    a, b = g.render(12000), ng.render(12000)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "C oracle != NumPy restatement (P4)"
+    save("p4_sample_nonlinear.npz", np.ascontiguousarray(a.T), buffer_size=1024)
     # cfg3 shape: 8 voices of P1 with the per-voice detune/cutoff draw, 0.5 s
     det, cut = W.p1_voice_params(8)
     voices = []

@@ -73,6 +73,21 @@ class NumpyGraph:
                 m.td.last = bool(value)
             else:
                 m.sync_td.last = bool(value)
+        elif isinstance(m, N.NonLinear):
+            m.constant = np.float32(value)
+        elif isinstance(m, N.Sample):
+            if field == 0:
+                m.sample_rate = np.float32(value)
+            elif field == 1:
+                m.wave_sample_rate = np.float32(value)
+            elif field == 2:
+                m.wave_new = bool(value)
+            elif field == 3:
+                m.pos = np.float32(value)
+            elif field == 4:
+                m.playing = bool(value)
+            else:
+                m.td.last = bool(value)
         else:
             raise ValueError("no fields")
 
@@ -84,6 +99,9 @@ class NumpyGraph:
         else:
             if step < len(m.sequence[channel]):
                 m.sequence[channel][step] = None if state == 0 else (state == 2)
+
+    def set_wave(self, module, samples, sample_rate):
+        self.modules[module].load(samples, sample_rate)
 
     def plan(self):
         output = next(m for m in self.modules if isinstance(m, N.Output))

@@ -478,3 +478,187 @@ def test_p3_golden(S):
     for v in range(2):
         assert_close(out[0, :, v], gold[:, 0])
         np.testing.assert_array_equal(out[1, :, v], gold[:, 1])
+
+
+# ---- scope table (f) rank 4: sample player + sign-preserving waveshaper -----------------------------------------------
+def _p4_pair(S, oracle, V, T, B=1024, **kw):
+    depth, expo = S.p4_voice_params(V)
+    o = oracle.OraclePatch(48000, B, 2)
+    ids = S.build_p4(o, **kw)
+    ref, ref_mix = o.render_batch(V, T, [(ids["depth"], S.MATH_CONSTANT, depth), (ids["shaper"], S.NONLIN_CONSTANT, expo)], mix=True, threads=8)
+    p = S.Patch(48000, B, 2)
+    S.build_p4(p, **kw)
+    p.configure_voices(V)
+    p.set_voice_field(ids["depth"], S.MATH_CONSTANT, depth)
+    p.set_voice_field(ids["shaper"], S.NONLIN_CONSTANT, expo)
+    return p, ids, ref, ref_mix
+
+
+@pytest.mark.parametrize("flags", [pytest.param(1, id="exact"), pytest.param(5, id="exact-nohoist")])
+def test_p4_sample_nonlinear_vs_oracle(S, oracle, flags):
+    """With the exact oscillator the vibrato CV has the oracle's bits, so the read position — an index — must too."""
+    V, T = 130, 9000
+    p, ids, ref, ref_mix = _p4_pair(S, oracle, V, T)
+    assert p.planes() == (2, [0, 1])
+    fr, mix = p.render(T, flags=flags)
+    np.testing.assert_array_equal(bits(fr[1]), bits(ref[1]))   # the raw sample player: wave values, bit for bit
+    assert_close(fr[0], ref[0])                                # the waveshaper: powf within the f32 contract
+    assert (bits(fr[0]) == bits(ref[0])).mean() > 0.99         # ... and almost always the very same float
+    scale = np.abs(ref.astype(np.float64)).sum(axis=2)
+    assert (np.abs(mix - ref_mix) <= 2e-5 * np.maximum(scale, 1.0)).all()
+    assert np.abs(fr[1]).max() > 0.3 and len(np.unique(fr[1][:, 0])) > 100
+    pos = p.get_voice_field(ids["smp"], S.SAMPLE_POS)
+    assert len(np.unique(pos)) > 1 and (pos >= 0).all()
+
+
+def test_p4_default_mode_index_slips_are_rare(S, oracle):
+    """Default mode evaluates the LFO's sine in f32 (|err| ~1e-7): the vibrato CV, hence the read position, carries that
+    error, and a position within ~1e-4 of an integer may truncate to the neighbouring wave sample.  Everything that is
+    not such a slip is still bit-exact; slips stay below 0.1 % of the samples."""
+    V, T = 130, 9000
+    p, ids, ref, _ = _p4_pair(S, oracle, V, T)
+    fr, _ = p.render(T)
+    same = bits(fr[1]) == bits(ref[1])
+    assert same.mean() > 0.999
+    err = np.abs(fr[0].astype(np.float64) - ref[0]) / np.maximum(np.abs(ref[0]), 1.0)
+    assert (err[same] <= TOL).all()
+
+
+@pytest.mark.parametrize("B", [1, 64])
+def test_p4_constant_pitch_is_exact_in_default_mode(S, oracle, B):
+    """No oscillator in the pitch path: CV from per-voice constants only => indices exact in every mode."""
+    V, T = 70, 5000
+    cv = np.linspace(-2.0, 2.0, V).astype(np.float32)
+    def build(g):
+        clk, off, smp, out = g.add_module(S.MOD_OSCILLATOR), g.add_module(S.MOD_MATH), g.add_module(S.MOD_SAMPLE), g.add_module(S.MOD_OUTPUT)
+        g.set_field(clk, S.OSC_VAL, -2.0)
+        g.set_wave(smp, S.p4_wave(700), 32000.0)
+        g.connect(clk, S.OSC_OUT_SQUARE, smp, 0)
+        g.connect(off, 0, smp, 1)             # Add(None, constant) = 0.0 + constant
+        g.connect(smp, 0, out, 0)
+        return off
+    o = oracle.OraclePatch(48000, B, 2)
+    off = build(o)
+    ref, _ = o.render_batch(V, T, [(off, S.MATH_CONSTANT, cv)], threads=8)
+    for flags in (0, 4):
+        p = S.Patch(48000, B, 2)
+        build(p)
+        p.configure_voices(V)
+        p.set_voice_field(off, S.MATH_CONSTANT, cv)
+        fr, _ = p.render(T, flags=flags)
+        np.testing.assert_array_equal(bits(fr[0]), bits(ref[0]))
+        assert p.planes() == (1, [0, -1])          # channel 1 unconnected: no plane, silence
+
+
+def test_sample_edge_cases_on_gpu(S, oracle):
+    """Empty WaveBox, unconnected gate / CV, huge and NaN-producing pitch CVs, a one-sample wave."""
+    def run(build, T=600, V=3):
+        o = oracle.OraclePatch(48000, 32, 2)
+        build(o)
+        ref, _ = o.render_batch(V, T, [], threads=1)
+        p = S.Patch(48000, 32, 2)
+        build(p)
+        p.configure_voices(V)
+        fr = p.render_channels(T, 1)
+        np.testing.assert_array_equal(bits(fr), bits(ref))
+        return fr
+
+    def empty(g):
+        clk, smp, out = g.add_module(S.MOD_OSCILLATOR), g.add_module(S.MOD_SAMPLE), g.add_module(S.MOD_OUTPUT)
+        g.set_field(clk, S.OSC_VAL, 2.0)
+        g.connect(clk, 1, smp, 0)
+        g.connect(smp, 0, out, 0)
+    assert not run(empty).any()
+
+    def no_gate(g):
+        smp, out = g.add_module(S.MOD_SAMPLE), g.add_module(S.MOD_OUTPUT)
+        g.set_wave(smp, S.p4_wave(50), 48000.0)
+        g.set_field(smp, S.SAMPLE_WAVE_NEW, 0)     # keep the state set below
+        g.set_field(smp, S.SAMPLE_PLAYING, 1)      # a saved patch caught mid-playback
+        g.set_field(smp, S.SAMPLE_POS, 7.0)
+        g.connect(smp, 0, out, 0)
+    fr = run(no_gate)
+    np.testing.assert_array_equal(fr[0, :43, 0], S.p4_wave(50)[7:])
+
+    for cv in (200.0, -200.0, 127.5, -140.0):
+        def wild(g, cv=cv):
+            clk, k, smp, out = g.add_module(S.MOD_OSCILLATOR), g.add_module(S.MOD_MATH), g.add_module(S.MOD_SAMPLE), g.add_module(S.MOD_OUTPUT)
+            g.set_field(clk, S.OSC_VAL, 1.0)
+            g.set_field(k, S.MATH_CONSTANT, cv)
+            g.set_wave(smp, S.p4_wave(90), 44100.0)
+            g.connect(clk, 1, smp, 0)
+            g.connect(k, 0, smp, 1)
+            g.connect(smp, 0, out, 0)
+            g.connect(clk, 1, out, 1)
+        run(wild)
+
+    def one(g):
+        clk, smp, out = g.add_module(S.MOD_OSCILLATOR), g.add_module(S.MOD_SAMPLE), g.add_module(S.MOD_OUTPUT)
+        g.set_wave(smp, np.array([0.625], dtype=np.float32), 8000.0)
+        g.connect(clk, 1, smp, 0)
+        g.connect(smp, 0, out, 0)
+    assert (run(one) [0] == 0.625).all()
+
+
+def test_nonlinear_edge_cases_on_gpu(S, oracle):
+    """Negative / zero / huge bases and exponents, both inputs wired, In1 unconnected (math.rs:299-304)."""
+    V, T = 64, 400
+    expo = np.concatenate([np.linspace(0.5, 2.0, 40), [0.0, 1.0, 3.0, -1.0, -0.5, 40.0, -40.0, 0.25], np.linspace(2.0, 9.0, 16)]).astype(np.float32)
+    def build(g):
+        osc, gain, nl, nl2, nl3, out = (g.add_module(S.MOD_OSCILLATOR), g.add_module(S.MOD_MATH), g.add_module(S.MOD_NONLINEAR),
+                                        g.add_module(S.MOD_NONLINEAR), g.add_module(S.MOD_NONLINEAR), g.add_module(S.MOD_OUTPUT))
+        g.set_field(osc, S.OSC_VAL, 1.5)
+        g.set_field(gain, S.MATH_OPERATION, S.MATH_MULTIPLY)
+        g.set_field(gain, S.MATH_CONSTANT, 3.0)
+        g.connect(osc, S.OSC_OUT_SAW, gain, 0)
+        g.connect(gain, 0, nl, 0)          # base in [-3, 3], exponent = per-voice constant
+        g.connect(osc, S.OSC_OUT_SAW, nl2, 0)
+        g.connect(gain, 0, nl2, 1)         # both wired: base saw, exponent 3*saw
+        g.connect(gain, 0, nl3, 1)         # In1 unconnected: operation(0.0, b)
+        mix = g.add_module(S.MOD_MONO_MIXER)
+        g.connect(nl2, 0, mix, 0)
+        g.connect(nl3, 0, mix, 1)
+        g.connect(nl, 0, out, 0)
+        g.connect(nl2, 0, out, 1)
+        return nl, nl3
+    o = oracle.OraclePatch(48000, 64, 2)
+    nl, _ = build(o)
+    ref, _ = o.render_batch(V, T, [(nl, S.NONLIN_CONSTANT, expo)], threads=4)
+    p = S.Patch(48000, 64, 2)
+    build(p)
+    p.configure_voices(V)
+    p.set_voice_field(nl, S.NONLIN_CONSTANT, expo)
+    fr, _ = p.render(T, flags=1)           # exact oscillator: identical bases, so only powf itself is compared
+    fin = np.isfinite(ref)
+    np.testing.assert_array_equal(np.isnan(fr), np.isnan(ref))
+    np.testing.assert_array_equal(fr[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)])   # +-inf where libm overflows
+    g64, r64 = fr[fin].astype(np.float64), ref[fin].astype(np.float64)
+    assert (np.abs(g64 - r64) <= 1e-5 * np.maximum(np.abs(r64), 1e-30)).all()              # purely relative: powf spans 1e-38..1e38
+    assert (np.signbit(fr[fin]) == np.signbit(ref[fin])).all()
+
+
+def test_p4_golden(S):
+    z = np.load(os.path.join(GOLD, "p4_sample_nonlinear.npz"))
+    gold = z["audio"]  # [T][2]
+    p = S.Patch(48000, int(z["buffer_size"]), 2)
+    S.build_p4(p)
+    p.configure_voices(2)
+    out = p.render_channels(gold.shape[0], 1)
+    for v in range(2):
+        np.testing.assert_array_equal(bits(out[1, :, v]), bits(gold[:, 1]))
+        assert_close(out[0, :, v], gold[:, 0])
+
+
+def test_wave_roundtrip_and_state_readback(S):
+    p = S.Patch(48000, 64, 2)
+    smp, out = p.add_module(S.MOD_SAMPLE), p.add_module(S.MOD_OUTPUT)
+    w = S.p4_wave(33)
+    p.set_wave(smp, w, 22050.0)
+    got, sr = p.get_wave(smp)
+    np.testing.assert_array_equal(got, w)
+    assert sr == 22050.0 and p.get_field(smp, S.SAMPLE_WAVE_NEW) == 1.0
+    p.connect(smp, 0, out, 0)
+    p.configure_voices(5)
+    fr, _ = p.render(10)
+    assert (fr[0] == w[0]).all()                       # never triggered: holds samples[0]
+    assert (p.get_voice_field(smp, S.SAMPLE_PLAYING) == 0).all()

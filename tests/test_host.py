@@ -55,8 +55,8 @@ def test_error_behaviour(S):
     with pytest.raises(S.SrackError) as e:
         p.connect(7, 0, out, 0)
     assert e.value.code == S.ERR_INVALID
-    with pytest.raises(S.SrackError) as e:  # NoiseModule etc. are out of scope
-        p.add_module(9)
+    with pytest.raises(S.SrackError) as e:  # NoiseModule / Freeverb etc. are out of scope
+        p.add_module(11)
     assert e.value.code == S.ERR_UNSUPPORTED
     for bad in ((0, 64, 2), (70000, 64, 2), (48000, 0, 2), (48000, 64, 0), (48000, 64, 9)):
         with pytest.raises(S.SrackError):
@@ -227,3 +227,35 @@ def test_sequencer_graph_api(S):
     p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, np.linspace(-2, 0, 128))
     info = p.info()
     assert "ctl[ops=" in info and "tracks=4" in info, info
+
+
+def test_sample_and_nonlinear_graph_api(S):
+    p = S.Patch(44100, 256, 2)
+    ids = S.build_p4(p)
+    smp, sh = ids["smp"], ids["shaper"]
+    assert (p.get_num_inputs(smp), p.get_num_outputs(smp), p.get_num_inputs(sh), p.get_num_outputs(sh)) == (2, 1, 2, 1)
+    assert p.get_field(smp, S.SAMPLE_SAMPLE_RATE) == 44100.0 and p.get_field(smp, S.SAMPLE_WAVE_SAMPLE_RATE) == 44100.0
+    assert p.get_field(smp, S.SAMPLE_WAVE_NEW) == 1 and p.get_field(smp, S.SAMPLE_GATE_LAST) == 1 and p.get_field(smp, S.SAMPLE_PLAYING) == 0
+    w, sr = p.get_wave(smp)
+    np.testing.assert_array_equal(w, S.p4_wave())
+    q = S.Patch(48000, 64, 2)
+    nl = q.add_module(S.MOD_NONLINEAR)
+    fresh = q.add_module(S.MOD_SAMPLE)
+    assert q.get_field(nl, S.NONLIN_CONSTANT) == 1.0                   # math.rs:194
+    assert q.get_wave(fresh)[0].size == 0 and q.get_field(fresh, S.SAMPLE_WAVE_NEW) == 0   # WaveBox::default()
+    with pytest.raises(S.SrackError):
+        q.set_wave(nl, np.zeros(4, dtype=np.float32), 48000.0)         # not a SampleModule
+    with pytest.raises(S.SrackError) as e:
+        q.connect(nl, 1, fresh, 0)                                     # get_output(1) is Err(())
+    assert e.value.code == S.ERR_PORT
+    # per-voice exponent + depth: the clock and the LFO stay voice-invariant (control program), the sampler does not
+    p.configure_voices(256)
+    depth, expo = S.p4_voice_params(256)
+    p.set_voice_field(ids["depth"], S.MATH_CONSTANT, depth)
+    p.set_voice_field(sh, S.NONLIN_CONSTANT, expo)
+    info = p.info()
+    assert "ctl[ops=" in info and "tracks=2" in info, info
+    with pytest.raises(S.SrackError) as e:
+        p.set_voice_field(smp, S.SAMPLE_WAVE_NEW, np.zeros(256))
+        p.info()
+    assert e.value.code == S.ERR_UNSUPPORTED

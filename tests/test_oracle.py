@@ -376,3 +376,95 @@ def test_sequencer_semantics(oracle):
     g.connect(pat, 3, out, 1)
     a = g.render(200)
     assert a[0][0] == 1.0 and 0.2 < a[0].mean() < 0.3 and not a[1].any()
+
+
+# ---- scope table (f) rank 4: NonLinear and Sample (no reference test pins them: double restatement only) -----------
+@pytest.mark.parametrize("B", [1, 64, 1024])
+def test_p4_sample_nonlinear_c_equals_numpy(W, oracle, B):
+    g, ng, ids = _both(W, oracle, W.build_p4, 6000, B=B)
+    assert g.plan() == ng.plan()[0]
+    a, ta = g.render(6000, tap=(ids["smp"], 0))
+    b, tb = ng.render(6000, tap=(ids["smp"], 0))
+    np.testing.assert_array_equal(bits(ta), bits(tb))
+    np.testing.assert_array_equal(bits(a), bits(b))
+    assert np.abs(a[0]).max() > 0.3 and np.abs(a[1]).max() > 0.3 and not np.array_equal(a[0], a[1])
+
+
+def test_sample_semantics(W, oracle):
+    """Trigger, run-out, pitch and the empty WaveBox (sample.rs:206-238)."""
+    wave = np.arange(1, 11, dtype=np.float32) / 16        # 10 samples, all different, none zero
+    def make(rate=48000.0, clock=3.0, load=True):
+        g = oracle.OraclePatch(48000, 16, 2)
+        clk, smp, out = g.add_module(1), g.add_module(10), g.add_module(0)
+        g.set_field(clk, 0, clock)
+        if load:
+            g.set_wave(smp, wave, rate)
+        g.connect(clk, 1, smp, 0)
+        g.connect(smp, 0, out, 0)
+        g.connect(clk, 1, out, 1)
+        return g, smp
+    # same rate: one wave sample per tick after the first rising edge; when the wave runs out, sample 0 is held
+    g, smp = make(clock=-1.0)            # 220 Hz: one rising edge every ~218 samples
+    a = g.render(300)
+    gate = a[1] > 0
+    first = int(np.argmax(gate[1:] & ~gate[:-1])) + 1
+    np.testing.assert_array_equal(a[0][:first], np.full(first, wave[0]))   # not playing yet: pos stays 0 -> samples[0]
+    np.testing.assert_array_equal(a[0][first:first + 10], wave)
+    np.testing.assert_array_equal(a[0][first + 10:first + 60], np.full(50, wave[0]))
+    assert g.get_field(smp, W.SAMPLE_PLAYING) in (0.0, 1.0) and g.get_field(smp, W.SAMPLE_WAVE_NEW) == 0.0
+    # half rate: every wave sample twice
+    g, _ = make(rate=24000.0, clock=-1.0)
+    a = g.render(300)
+    np.testing.assert_array_equal(a[0][first:first + 20], np.repeat(wave, 2))
+    # retrigger before the end restarts from 0
+    g, _ = make(clock=6.0)               # 28160 Hz: edges every ~1.7 samples
+    a = g.render(64)
+    assert a[0].max() <= wave[3] and len(np.unique(a[0])) > 1
+    # no wave loaded: silence
+    g, _ = make(load=False)
+    assert not g.render(64)[0].any()
+
+
+def test_nonlinear_semantics(oracle):
+    """Sign-preserving power, the unconnected-input cases and libm's edge cases (math.rs:203-205, 299-304)."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.powf.restype = ctypes.c_float
+    libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    g = oracle.OraclePatch(48000, 64, 2)
+    osc, nl, nl0, out = g.add_module(1), g.add_module(9), g.add_module(9), g.add_module(0)
+    g.set_field(nl, 0, 0.5)
+    g.set_field(nl0, 0, 0.0)             # (None, None) with constant 0: -( (-0.0)^0 ) = -1
+    g.connect(osc, 0, nl, 0)
+    g.connect(nl, 0, out, 0)
+    g.connect(nl0, 0, out, 1)
+    a, s = g.render(64, tap=(osc, 0))
+    want = np.array([libm.powf(float(x), 0.5) if x > 0 else -libm.powf(float(-x), 0.5) for x in s], dtype=np.float32)
+    np.testing.assert_array_equal(bits(a[0]), bits(want))
+    assert (np.sign(a[0]) == np.sign(s)).all() and (a[1] == -1.0).all()
+
+
+def test_pow2_libm_formula_matches_glibc():
+    """The device computes `2.0_f32.powf(cv)` (sample.rs:236) by restating glibc's powf for base 2: exact log2 step, then
+    the exp2 kernel (32-entry table of rounded 2^(i/32), cubic, one rounding).  Same formula here, against libm itself."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.powf.restype = ctypes.c_float
+    libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    tab = (np.exp2(np.arange(32) / 32.0).view(np.uint64) - (np.arange(32, dtype=np.uint64) << np.uint64(47)))
+    rng = np.random.default_rng(5)
+    y = np.concatenate([rng.uniform(-20, 20, 200000), rng.uniform(-149.9, 127.99, 20000), [0.0, -0.0, 1.0, -126.0, -149.0, 127.0]]).astype(np.float32)
+    xd = y.astype(np.float64)
+    shift = float.fromhex("0x1.8p+52") / 32.0
+    kd = xd + shift
+    ki = kd.view(np.uint64)
+    kd = kd - shift
+    r = xd - kd
+    with np.errstate(over="ignore"):
+        s = (tab[(ki & np.uint64(31)).astype(np.int64)] + (ki << np.uint64(47))).view(np.float64)
+    z = float.fromhex("0x1.c6af84b912394p-5") * r + float.fromhex("0x1.ebfce50fac4f3p-3")
+    p = float.fromhex("0x1.62e42ff0c52d6p-1") * r + 1.0
+    p = (z * (r * r) + p) * s
+    mine = p.astype(np.float32)
+    ref = np.array([libm.powf(2.0, float(v)) for v in y], dtype=np.float32)
+    np.testing.assert_array_equal(bits(mine), bits(ref))
