@@ -203,6 +203,23 @@ int srack_patch_removed_edges(srack_patch* p, int* pairs, int cap);
  * (src_module, src_port, sink_module, sink_port); returns the count. */
 int srack_patch_delayed_edges(srack_patch* p, int* quads, int cap);
 
+/* ---- .srk rack files (scope table (f) rank 2) ------------------------------------------------- */
+/* FileFormat{modules, connections, positions} (ui.rs:578-586) in rmp-serde 1.3.0's compact MessagePack form.
+ * load = SynthModuleWorkspaceImpl::deserialize (ui.rs:116-135) against the host's AudioConfig: the module list comes
+ * out in REVERSE file order (ui.rs:654-660), V0 variants migrate, saved buffers survive only at the same buffer_size,
+ * connections with unknown ids or bad ports are dropped.  Noise / Freeverb modules => SRACK_ERR_UNSUPPORTED.
+ * save = serialize (ui.rs:98-114): writes at most `cap` bytes to `buf` (may be NULL) and the full size to *n_bytes. */
+int srack_patch_load_srk(const void* bytes, size_t n_bytes, uint32_t sample_rate, uint32_t buffer_size, uint32_t channels, srack_patch** out);
+int srack_patch_save_srk(const srack_patch* p, void* buf, size_t cap, size_t* n_bytes);
+/* SynthModule::get_id: the UUID string that keys a file's connection list.  Returns its length. */
+int srack_patch_module_id(const srack_patch* p, int module, char* buf, size_t cap);
+/* Workspace position of a module's window (FileFormat.positions); get returns 1 if the module has one, else 0. */
+int srack_patch_set_module_position(srack_patch* p, int module, float x, float y);
+int srack_patch_get_module_position(const srack_patch* p, int module, float* x, float* y);
+/* Contents of one output buffer before the first tick (what a loaded file carries): `n` = buffer_size samples, or 0
+ * for a fresh, zeroed buffer.  Only the sink of a broken feedback edge ever observes it. */
+int srack_patch_set_output_buffer(srack_patch* p, int module, int port, const float* samples, uint32_t n);
+
 /* ---- voices: N independent instances of the patch ----------------------------------------- */
 /* Fix the number of voices (lanes) and drop any earlier per-voice data and device state. */
 int srack_voices_configure(srack_patch* p, uint32_t n_voices);

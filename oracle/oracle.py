@@ -53,6 +53,7 @@ def lib():
         L.or_get_field.argtypes = [vp, i32, i32, dp]
         L.or_set_step.argtypes = [vp, i32, i32, i32, i32, i32]
         L.or_set_wave.argtypes = [vp, i32, fp, u32, C.c_float]
+        L.or_set_output_buffer.argtypes = [vp, i32, i32, fp]
         L.or_plan.argtypes = [vp]
         L.or_plan_list.argtypes = [vp, i32, ip, i32]
         L.or_get_plan.argtypes = [vp, ip, i32]
@@ -118,6 +119,12 @@ class OraclePatch:
         a = np.ascontiguousarray(samples, dtype=np.float32)
         if self.L.or_set_wave(self.h, module, _fp(a), a.size, float(sample_rate)) < 0:
             raise ValueError("or_set_wave failed")
+
+    def set_output_buffer(self, module, port, samples):
+        a = np.ascontiguousarray(samples, dtype=np.float32)
+        assert a.size == self.buffer_size
+        if self.L.or_set_output_buffer(self.h, module, port, _fp(a)) < 0:
+            raise ValueError("or_set_output_buffer failed")
 
     def get_field(self, module, field):
         v = C.c_double()

@@ -422,6 +422,17 @@ int or_set_wave(or_patch* p, int module, const float* samples, uint32_t n, float
     return 0;
 }
 
+/* The contents of an output buffer before the first tick, as a loaded .srk leaves them (AudioBuffer is serialised
+ * with its samples, synth.rs:27-28).  Only a broken feedback edge's sink observes them. */
+int or_set_output_buffer(or_patch* p, int module, int port, const float* samples)
+{
+    if (module < 0 || module >= p->n_modules) return -1;
+    or_module* m = &p->modules[module];
+    if (m->type == SRACK_MOD_OUTPUT || port < 0 || port >= m->n_out) return -2;
+    memcpy(m->out[port], samples, sizeof(float) * p->buffer_size);
+    return 0;
+}
+
 int or_set_field(or_patch* p, int module, int field, double value)
 {
     if (module < 0 || module >= p->n_modules) return -1;

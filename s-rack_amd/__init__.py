@@ -23,7 +23,8 @@ RENDER_DEFAULT, RENDER_EXACT_OSC, RENDER_NO_FUSION, RENDER_NO_UNIFORM_HOIST = 0,
 ABI_SYMBOLS = [
     "srack_abi_version", "srack_last_error", "srack_patch_create", "srack_patch_destroy", "srack_patch_add_module",
     "srack_patch_num_modules", "srack_patch_module_type", "srack_module_num_inputs", "srack_module_num_outputs",
-    "srack_patch_set_field", "srack_patch_get_field", "srack_patch_set_step", "srack_patch_get_step", "srack_patch_set_wave", "srack_patch_get_wave", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
+    "srack_patch_set_field", "srack_patch_get_field", "srack_patch_set_step", "srack_patch_get_step", "srack_patch_set_wave", "srack_patch_get_wave", "srack_patch_load_srk", "srack_patch_save_srk", "srack_patch_module_id",
+    "srack_patch_set_module_position", "srack_patch_get_module_position", "srack_patch_set_output_buffer", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
     "srack_patch_plan", "srack_patch_plan_list", "srack_patch_removed_edges", "srack_patch_delayed_edges",
     "srack_voices_configure", "srack_voices_set_field_f32", "srack_voices_set_field_f64", "srack_render_planes", "srack_render",
     "srack_render_info", "srack_render_kernel_ms", "srack_voices_get_field", "srack_device_count", "srack_device_set",
@@ -59,6 +60,12 @@ def _load():
     L.srack_patch_get_step.argtypes = [vp, i32, i32, i32, ip, ip]
     L.srack_patch_set_wave.argtypes = [vp, i32, fp, u32, C.c_float]
     L.srack_patch_get_wave.argtypes = [vp, i32, fp, u32, fp]
+    L.srack_patch_load_srk.argtypes = [C.c_char_p, sz, u32, u32, u32, C.POINTER(vp)]
+    L.srack_patch_save_srk.argtypes = [vp, C.c_char_p, sz, C.POINTER(sz)]
+    L.srack_patch_module_id.argtypes = [vp, i32, C.c_char_p, sz]
+    L.srack_patch_set_module_position.argtypes = [vp, i32, C.c_float, C.c_float]
+    L.srack_patch_get_module_position.argtypes = [vp, i32, fp, fp]
+    L.srack_patch_set_output_buffer.argtypes = [vp, i32, i32, fp, u32]
     L.srack_patch_connect.argtypes = [vp, i32, i32, i32, i32]
     L.srack_patch_disconnect.argtypes = [vp, i32, i32]
     L.srack_patch_get_input.argtypes = [vp, i32, i32, ip, ip]
@@ -107,12 +114,45 @@ class Patch:
     -> render.  Errors the reference reports as `Err(())` / panics raise SrackError(code).
     """
 
-    def __init__(self, sample_rate=48000, buffer_size=1024, channels=2):
+    def __init__(self, sample_rate=48000, buffer_size=1024, channels=2, _handle=None):
         self.sample_rate, self.buffer_size, self.channels = sample_rate, buffer_size, channels
-        h = C.c_void_p()
-        _check(lib.srack_patch_create(sample_rate, buffer_size, channels, C.byref(h)))
+        h = _handle if _handle is not None else C.c_void_p()
+        if _handle is None:
+            _check(lib.srack_patch_create(sample_rate, buffer_size, channels, C.byref(h)))
         self.h = h
         self.n_voices = 0
+
+    # ---- .srk rack files (FileFormat, ui.rs:578-586) -------------------------------------------------
+    @classmethod
+    def load_srk(cls, data, sample_rate=48000, buffer_size=1024, channels=2):
+        """SynthModuleWorkspaceImpl::deserialize (ui.rs:116-135) against this AudioConfig."""
+        h = C.c_void_p()
+        data = bytes(data)
+        _check(lib.srack_patch_load_srk(data, len(data), sample_rate, buffer_size, channels, C.byref(h)))
+        return cls(sample_rate, buffer_size, channels, _handle=h)
+
+    def save_srk(self):
+        n = C.c_size_t()
+        _check(lib.srack_patch_save_srk(self.h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        _check(lib.srack_patch_save_srk(self.h, buf, n.value, C.byref(n)))
+        return buf.raw[:n.value]
+
+    def module_id(self, module):
+        buf = C.create_string_buffer(64)
+        _check(lib.srack_patch_module_id(self.h, module, buf, 64))
+        return buf.value.decode()
+
+    def set_module_position(self, module, x, y):
+        _check(lib.srack_patch_set_module_position(self.h, module, x, y))
+
+    def get_module_position(self, module):
+        x, y = C.c_float(), C.c_float()
+        return (x.value, y.value) if _check(lib.srack_patch_get_module_position(self.h, module, C.byref(x), C.byref(y))) else None
+
+    def set_output_buffer(self, module, port, samples):
+        a = np.ascontiguousarray(samples, dtype=np.float32)
+        _check(lib.srack_patch_set_output_buffer(self.h, module, port, a.ctypes.data_as(C.POINTER(C.c_float)), a.size))
 
     def __del__(self):
         if getattr(self, "h", None) and lib is not None:  # `lib` is already gone at interpreter shutdown

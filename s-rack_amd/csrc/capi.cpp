@@ -4,10 +4,16 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "runtime.hpp"
 
 using namespace srack;
+
+namespace srack {  // srk.cpp
+int load_srk(const uint8_t* bytes, size_t n_bytes, Graph& g);
+std::vector<uint8_t> save_srk(const Graph& g);
+}
 
 struct srack_patch {
     PatchHandle h;
@@ -179,6 +185,67 @@ int srack_patch_get_wave(const srack_patch* p, int module, float* samples, uint3
         for (size_t i = 0; i < m->wave.size() && i < (size_t)cap; i++) samples[i] = m->wave[i];
     if (sample_rate) *sample_rate = (float)m->fields[SRACK_SAMPLE_WAVE_SAMPLE_RATE];
     return (int)m->wave.size();
+}
+
+int srack_patch_load_srk(const void* bytes, size_t n_bytes, uint32_t sample_rate, uint32_t buffer_size, uint32_t channels, srack_patch** out)
+{
+    if (!bytes && n_bytes) {
+        set_error("srack_patch_load_srk: bytes is null");
+        return SRACK_ERR_INVALID;
+    }
+    int rc = srack_patch_create(sample_rate, buffer_size, channels, out);
+    if (rc != SRACK_OK) return rc;
+    rc = load_srk((const uint8_t*)bytes, n_bytes, (*out)->h.graph);
+    if (rc != SRACK_OK) {
+        delete *out;
+        *out = nullptr;
+    }
+    return rc;
+}
+
+int srack_patch_save_srk(const srack_patch* p, void* buf, size_t cap, size_t* n_bytes)
+{
+    CHECK_HANDLE(p);
+    const std::vector<uint8_t> bytes = save_srk(p->h.graph);
+    if (n_bytes) *n_bytes = bytes.size();
+    if (buf && cap) std::memcpy(buf, bytes.data(), bytes.size() < cap ? bytes.size() : cap);
+    return SRACK_OK;
+}
+
+int srack_patch_module_id(const srack_patch* p, int module, char* buf, size_t cap)
+{
+    CHECK_HANDLE(p);
+    const Module* m = get_module(p, module);
+    if (!m) return SRACK_ERR_INVALID;
+    if (buf && cap) std::snprintf(buf, cap, "%s", m->id.c_str());
+    return (int)m->id.size();
+}
+
+int srack_patch_set_module_position(srack_patch* p, int module, float x, float y)
+{
+    CHECK_HANDLE(p);
+    if (!get_module(p, module)) return SRACK_ERR_INVALID;
+    Module& m = p->h.graph.modules[(size_t)module];
+    m.has_pos = true;
+    m.pos_x = x;
+    m.pos_y = y;
+    return SRACK_OK;
+}
+
+int srack_patch_get_module_position(const srack_patch* p, int module, float* x, float* y)
+{
+    CHECK_HANDLE(p);
+    const Module* m = get_module(p, module);
+    if (!m) return SRACK_ERR_INVALID;
+    if (x) *x = m->pos_x;
+    if (y) *y = m->pos_y;
+    return m->has_pos ? 1 : 0;
+}
+
+int srack_patch_set_output_buffer(srack_patch* p, int module, int port, const float* samples, uint32_t n)
+{
+    CHECK_HANDLE(p);
+    return p->h.graph.set_output_buffer(module, port, samples, n);
 }
 
 int srack_patch_connect(srack_patch* p, int src_module, int src_port, int sink_module, int sink_port)

@@ -168,14 +168,14 @@ int Builder::build()
 
     // rings: one per (src, port) in this program that has a delayed reader in this program
     std::map<std::pair<int, int>, int> ring_of;
-    struct Ring { int first_row, global_id; };
+    struct Ring { int first_row, global_id, src, port; };
     std::vector<Ring> rings;
     for (int m : g.plan.order) {
         if (!mine(m)) continue;
         for (const InputRef& in : g.modules[(size_t)m].in)
             if (in.src >= 0 && mine(in.src) && is_delayed(in.src, m) && !ring_of.count({in.src, in.port})) {
                 ring_of[{in.src, in.port}] = (int)rings.size();
-                rings.push_back(Ring{-1, -1});
+                rings.push_back(Ring{-1, -1, in.src, in.port});
             }
     }
     const int B = (int)g.cfg.buffer_size;
@@ -422,15 +422,24 @@ int Builder::build()
     }
 
     // ---- rings: storage ---------------------------------------------------------------------
+    // Initial contents: the source's output buffer as it is before the first tick — zeros for a fresh module
+    // (synth.rs:31-33), the saved block for a patch loaded from a .srk (Module::out_init).
     int n_global = 0;
     for (Ring& r : rings) {
+        const Module& src = g.modules[(size_t)r.src];
+        const std::vector<float>* init = (size_t)r.port < src.out_init.size() && src.out_init[(size_t)r.port].size() == (size_t)B ? &src.out_init[(size_t)r.port] : nullptr;
         if (rings_in_lds) {
             r.first_row = (int)rows.size();
-            for (int k = 0; k < B; k++) rows[(size_t)new_row()].assign(V, 0u);  // zero-initialised buffer (synth.rs:31-33)
+            for (int k = 0; k < B; k++) rows[(size_t)new_row()].assign(V, init ? f32_bits((*init)[(size_t)k]) : 0u);
         } else {
             r.global_id = n_global++;
+            if (init) {
+                out.ring_init.resize((size_t)n_global * B, 0.0f);
+                std::copy(init->begin(), init->end(), out.ring_init.begin() + (size_t)r.global_id * B);
+            }
         }
     }
+    if (!out.ring_init.empty()) out.ring_init.resize((size_t)n_global * B, 0.0f);
     for (DevOp& op : out.ops)
         if (op.kind == OP_DELAY_RD || op.kind == OP_DELAY_WR) {
             const Ring& r = rings[(size_t)op.aux];

@@ -2,12 +2,37 @@
 #include "graph.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 
 namespace srack {
 
 static thread_local std::string g_error;
 void set_error(const std::string& msg) { g_error = msg; }
 const char* last_error() { return g_error.c_str(); }
+
+// Module ids only have to be unique strings (they key the connection list of a .srk file, ui.rs:612-637); the layout
+// follows a version-4 UUID so files written here look like the reference's.
+std::string new_module_id()
+{
+    static std::atomic<uint64_t> counter{0};
+    static const uint64_t seed = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+    auto mix = [](uint64_t x) {
+        x += 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        return x ^ (x >> 31);
+    };
+    const uint64_t n = counter.fetch_add(1);
+    uint64_t a = mix(seed ^ (2 * n)), b = mix(seed ^ (2 * n + 1));
+    a = (a & ~0xF000ull) | 0x4000ull;                        // version 4
+    b = (b & ~(0xC0ull << 56)) | (0x80ull << 56);            // RFC 4122 variant
+    char buf[40];
+    std::snprintf(buf, sizeof buf, "%08x-%04x-%04x-%04x-%012llx", (unsigned)(a >> 32), (unsigned)((a >> 16) & 0xffff), (unsigned)(a & 0xffff),
+                  (unsigned)(b >> 48), (unsigned long long)(b & 0xffffffffffffull));
+    return buf;
+}
 
 int Graph::fields_of_type(int type)
 {
@@ -145,6 +170,7 @@ int Graph::add_module(int type)
         break;
     }
     m.in.assign((size_t)m.n_in, InputRef{});
+    m.id = new_module_id();
     modules.push_back(std::move(m));
     plan.valid = false;
     revision++;
@@ -254,6 +280,22 @@ int Graph::set_wave(int module, const float* samples, uint32_t n, float sample_r
     m.wave.assign(samples, samples + n);
     m.fields[SRACK_SAMPLE_WAVE_SAMPLE_RATE] = (double)sample_rate;
     m.fields[SRACK_SAMPLE_WAVE_NEW] = 1.0;
+    revision++;
+    return SRACK_OK;
+}
+
+// Contents of one output buffer as a loaded .srk leaves them: only observable through a broken feedback edge, whose
+// sink reads the source's buffer before the source has run.
+int Graph::set_output_buffer(int module, int port, const float* samples, uint32_t n)
+{
+    if (module < 0 || module >= (int)modules.size() || port < 0 || port >= modules[(size_t)module].n_out || (n != 0 && n != cfg.buffer_size) ||
+        (n && !samples)) {
+        set_error("set_output_buffer: no such module / port, or length != buffer_size");
+        return SRACK_ERR_INVALID;
+    }
+    Module& m = modules[(size_t)module];
+    m.out_init.resize((size_t)m.n_out);
+    m.out_init[(size_t)port].assign(samples, samples + n);
     revision++;
     return SRACK_OK;
 }

@@ -33,6 +33,13 @@ struct Module {
     // pattern: bits 2c / 2c+1 = present / hold of channel c.
     std::vector<uint32_t> cells;
     std::vector<float> wave;  // SampleModule: wavebox.samples
+    // what a .srk file carries besides the fields (ui.rs:578-586): the module's UUID string, its workspace position,
+    // and the contents of its output buffers — the latter is what the sink of a broken feedback edge reads during
+    // the first block after a load (empty = zeros, AudioBuffer::new)
+    std::string id;
+    bool has_pos = false;
+    float pos_x = 0.0f, pos_y = 0.0f;
+    std::vector<std::vector<float>> out_init;  // per output port: buffer_size samples, or empty
 };
 
 struct AudioConfig {  // synth.rs:20-25
@@ -67,6 +74,7 @@ public:
     int set_step(int module, int channel, int step, int state, int value);
     int get_step(int module, int channel, int step, int* state, int* value) const;
     int set_wave(int module, const float* samples, uint32_t n, float sample_rate);
+    int set_output_buffer(int module, int port, const float* samples, uint32_t n);  // n == buffer_size, or 0 to clear
     int connect(int src, int src_port, int sink, int sink_port);
     int disconnect(int sink, int sink_port);
 
@@ -84,6 +92,8 @@ public:
     static bool field_is_f64(int type, int field);
     static bool field_is_flag(int type, int field);  // bool / enum stored as integer
 };
+
+std::string new_module_id();  // uuid::Uuid::new_v4().to_string() stand-in (unique per process, version-4 layout)
 
 void set_error(const std::string& msg);
 const char* last_error();

@@ -1252,6 +1252,13 @@ int ensure_program(PatchHandle& h, uint32_t flags)
     return SRACK_OK;
 }
 
+// rings[row][v] = init[row] for every voice (row = ring * B + sample)
+__global__ void ring_fill(float* rings, const float* init, uint32_t V)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < V) rings[(size_t)blockIdx.y * V + v] = init[blockIdx.y];
+}
+
 static int upload_one(const FlatProgram& P, DevProg& d)
 {
     if (!P.ops.empty()) {
@@ -1269,7 +1276,18 @@ static int upload_one(const FlatProgram& P, DevProg& d)
     if (P.hdr.n_rings > 0) {
         size_t bytes = sizeof(float) * (size_t)P.hdr.n_rings * (size_t)P.hdr.buffer_size * P.n_voices;
         HIP_TRY(hipMalloc(&d.d_rings, bytes));
-        HIP_TRY(hipMemset(d.d_rings, 0, bytes));  // AudioBuffer::new fills 0.0 (synth.rs:31-33)
+        if (P.ring_init.empty()) {
+            HIP_TRY(hipMemset(d.d_rings, 0, bytes));  // AudioBuffer::new fills 0.0 (synth.rs:31-33)
+        } else {  // a loaded patch: every voice starts from the saved block
+            float* d_init = nullptr;
+            HIP_TRY(hipMalloc(&d_init, sizeof(float) * P.ring_init.size()));
+            HIP_TRY(hipMemcpy(d_init, P.ring_init.data(), sizeof(float) * P.ring_init.size(), hipMemcpyHostToDevice));
+            const uint32_t n_rows = (uint32_t)P.ring_init.size();
+            hipLaunchKernelGGL(ring_fill, dim3((P.n_voices + 255) / 256, n_rows), dim3(256), 0, 0, d.d_rings, d_init, P.n_voices);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(d_init));
+        }
     }
     return SRACK_OK;
 }
