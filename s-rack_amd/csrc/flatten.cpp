@@ -34,7 +34,6 @@ namespace {
 
 constexpr int kRingLdsMax = 16;         // rings up to this many samples live in LDS rows (persisted as state)
 constexpr int kTileMax = 32;            // samples per interpreter tile
-constexpr int kLdsBudget = 20 * 1024;   // bytes of LDS per wave the interpreter may use (=> 8 waves / CU, 2 per SIMD)
 
 struct Wire {
     int def_op = -1;
@@ -485,7 +484,13 @@ int Builder::build()
             defs[(size_t)wires[w].def_op].push_back((int)w);
         }
         for (size_t i = 0; i < out.ops.size(); i++) {
-            for (int w : defs[i]) {  // outputs never reuse this op's input slots: inputs stay live through the op
+            // An input read for the last time by this op hands its slot to one of the op's outputs: every tile function
+            // reads a group of samples from all its inputs before it writes that group's outputs (tile_run), and sample
+            // i of a wire is only ever touched at index i, so computing in place is safe — and each slot saved is a
+            // tile of LDS, i.e. longer tiles or more resident waves.
+            for (int w : expire[i])
+                if (wires[(size_t)w].def_op < (int)i) free_slots.push_back(wires[(size_t)w].slot);
+            for (int w : defs[i]) {
                 if (free_slots.empty()) {
                     wires[(size_t)w].slot = n_slots++;
                 } else {
@@ -493,7 +498,8 @@ int Builder::build()
                     free_slots.pop_back();
                 }
             }
-            for (int w : expire[i]) free_slots.push_back(wires[(size_t)w].slot);
+            for (int w : expire[i])
+                if (wires[(size_t)w].def_op == (int)i) free_slots.push_back(wires[(size_t)w].slot);
         }
         H.n_slots = n_slots;
         for (DevOp& op : out.ops) {
@@ -511,17 +517,48 @@ int Builder::build()
     H.n_planes = n_planes;
     H.n_tracks = is_ctl ? 0 : (int)A.tracks.size();
 
-    // ---- tile size from the LDS budget ------------------------------------------------------------
+    // ---- tile length: LDS per wave decides how many waves a CU holds ---------------------------------------
+    // One wave needs (fixed rows + slots x tile) x 256 B of LDS, handed out in 1280-B granules from 160 KB per CU.
+    // A wave's module chains are latency-bound, so a round of resident waves costs nearly the same whether the CU
+    // holds 4 or 15 of them; what costs is another round, and a tile's fixed work (op fields, state rows in and out,
+    // the call) paid more often when tiles are short.  The model is fitted to P1 through the interpreter on MI355X
+    // (tools/occ_probe.sh): a round with r waves per CU takes 17 + 0.7 r (ms at 48 000 samples), the last round holds
+    // the remainder, a tile's fixed work is worth ~8 samples, and a CU that would be exactly full spills a few waves
+    // into an extra, nearly empty round.  It predicts the measured times of eleven (tile, voices) pairs within 15 %
+    // after a common scale, which is all a choice between tile lengths needs.
     {
-        int tile = kTileMax;
-        int lds_budget = is_ctl ? 56 * 1024 : kLdsBudget;  // the control program is one wave: occupancy is irrelevant, long tiles are not
-        if (const char* e = getenv("SRACK_TILE_MAX")) tile = atoi(e);        // tuning knobs (tools/)
-        if (const char* e = getenv("SRACK_LDS_BUDGET")) lds_budget = atoi(e);
-        if (!rings.empty())
-            while (tile > B) tile >>= 1;  // a tile may not span more than one ring period
         const int fixed_rows = H.n_rows + 2 + H.n_tracks;  // voice table + zero and trash rows + one row per control track
-        while (tile > 1 && (fixed_rows + H.n_slots * tile) * 256 > lds_budget) tile >>= 1;
-        if ((fixed_rows + H.n_slots * tile) * 256 > 64 * 1024) {
+        auto lds_bytes = [&](int tile) { return (fixed_rows + H.n_slots * tile) * 256; };
+        int tile_max = kTileMax;
+        if (const char* e = getenv("SRACK_TILE_MAX")) tile_max = atoi(e);  // tuning knob (tools/)
+        if (!rings.empty()) tile_max = std::min(tile_max, B);              // a tile may not span more than one ring period
+        int tile = 0;
+        if (is_ctl) {  // one wave: residency is irrelevant, long tiles are not
+            int budget = 56 * 1024;
+            if (const char* e = getenv("SRACK_LDS_BUDGET")) budget = atoi(e);
+            for (tile = std::max(tile_max, 1); tile > 1 && lds_bytes(tile) > budget; tile >>= 1) {}
+        } else {
+            constexpr int kCUs = 256, kLdsPerCU = 160 * 1024, kGranule = 1280, kWaveSlots = 20;  // 5 waves per SIMD (<= 96 VGPRs)
+            const int need = (int)(((V + 63) / 64 + kCUs - 1) / kCUs);  // waves per CU this render asks for
+            double best = 0.0;
+            static const int kCandidates[] = {32, 28, 24, 20, 16, 12, 8, 4, 2, 1};
+            for (int t : kCandidates) {
+                if (t > tile_max && t != 1) continue;
+                const int bytes = lds_bytes(t);
+                if (bytes > 64 * 1024) continue;
+                const int alloc = (bytes + kGranule - 1) / kGranule * kGranule;
+                const int cap = std::min(kWaveSlots, kLdsPerCU / alloc);
+                const int full = need / cap, rem = need % cap;
+                double rounds_ms = full * (17.0 + 0.7 * cap) + (rem ? 17.0 + 0.7 * rem : 0.0);
+                if (need == cap) rounds_ms += 8.0;
+                const double cost = rounds_ms * (1.0 + 8.0 / t);
+                if (tile == 0 || cost < best) {
+                    best = cost;
+                    tile = t;
+                }
+            }
+        }
+        if (tile < 1 || lds_bytes(tile) > 64 * 1024) {
             set_error("flatten: patch state does not fit the LDS budget of the tile interpreter");
             return SRACK_ERR_UNSUPPORTED;
         }

@@ -114,6 +114,28 @@ struct Ctx {            // what every tile function sees
     int tile, n, lane;  // tile capacity, samples in this tile, lane
 };
 
+// Arguments of a non-inlined device function travel in VGPRs, so the compiler must assume they differ per lane: loops
+// over c.n become exec-masked loops and every address sum a vector add.  Everything in Ctx but `lane` IS wave-uniform;
+// saying so (v_readfirstlane) moves loop control and address arithmetic to the scalar unit.
+template <class P>
+SRK_DEV P uniform_lds(P p)
+{
+    return (P)(uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p);  // an LDS address is 32 bits
+}
+SRK_DEV Ctx uniform_ctx(const Ctx& v)
+{
+    Ctx c;
+    c.rows = uniform_lds(v.rows);
+    c.wires = uniform_lds(v.wires);
+    c.zero = uniform_lds(v.zero);
+    c.trash = uniform_lds(v.trash);
+    c.trk = uniform_lds(v.trk);
+    c.tile = __builtin_amdgcn_readfirstlane(v.tile);
+    c.n = __builtin_amdgcn_readfirstlane(v.n);
+    c.lane = v.lane;
+    return c;
+}
+
 #define ROW(r) c.rows[(r) * 64 + c.lane]
 #define WIRE(slot, i) c.wires[((slot) * c.tile + (i)) * 64 + c.lane]
 
@@ -134,7 +156,8 @@ SRK_DEV Port out_port(const Ctx& c, int slot) { return slot >= 0 ? Port{c.wires 
 
 // Runs step(x[NI], y[NO]) for every sample of the tile, kU samples at a time: the kU x NI input reads are issued
 // together, then the kU steps, then the kU x NO writes — one LDS round trip per kU samples instead of per sample.
-// (Output slots never alias an op's own input slots: flatten.cpp keeps inputs live through the op.)
+// An output may share its slot with an input of the same op (flatten.cpp reuses the slot of an input that dies here):
+// that is safe because a group's inputs are all read before any of its outputs is written, and sample i only lives at row i.
 template <int NI, int NO, class Step>
 SRK_DEV void tile_run(const Ctx& c, const Port (&in)[NI], const Port (&out)[NO], Step step)
 {
@@ -164,10 +187,13 @@ SRK_DEV void tile_run(const Ctx& c, const Port (&in)[NI], const Port (&out)[NO],
 }
 
 // ---- one tile of one module type -----------------------------------------------------------------
+// Every tile function is a template on the kernel flavour, also where the code does not depend on it: the register
+// budget a kernel asks for (amdgpu_waves_per_eu, see render_interp) only reaches callees that no other kernel shares.
 
 template <bool kExact>
-__device__ __noinline__ void tile_osc(const Ctx c, COp& op_v)
+__device__ __noinline__ void tile_osc(const Ctx c_v, COp& op_v)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     const uint32_t fl = op.flags;
     const int sr = op.state_row;
@@ -239,8 +265,9 @@ SRK_DEV void vcf_store(const Ctx& c, int sr, const VcfRegs& s)
 }
 
 template <bool kExact>
-__device__ __noinline__ void tile_vcf(const Ctx c, COp& op_v)
+__device__ __noinline__ void tile_vcf(const Ctx c_v, COp& op_v)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     const uint32_t fl = op.flags;
     VcfRegs s;
@@ -262,8 +289,10 @@ __device__ __noinline__ void tile_vcf(const Ctx c, COp& op_v)
     vcf_store(c, op.state_row, s);
 }
 
-__device__ __noinline__ void tile_adsr(const Ctx c, COp& op_v)
+template <bool kExact>
+__device__ __noinline__ void tile_adsr(const Ctx c_v, COp& op_v)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     const int sr = op.state_row;
     AdsrRegs s;
@@ -290,8 +319,10 @@ __device__ __noinline__ void tile_adsr(const Ctx c, COp& op_v)
     ROW(sr + ADSR_S_GATE_LAST) = s.gate_last ? 1u : 0u;
 }
 
-__device__ __noinline__ void tile_vca(const Ctx c, COp& op_v)
+template <bool kExact>
+__device__ __noinline__ void tile_vca(const Ctx c_v, COp& op_v)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     const bool negative = par(c, op, VCA_P_NEG) != 0.0f;
     const uint32_t fl = op.flags;
@@ -300,8 +331,10 @@ __device__ __noinline__ void tile_vca(const Ctx c, COp& op_v)
     tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = vca_step(fl, negative, x[0], x[1]); });
 }
 
-__device__ __noinline__ void tile_mix(const Ctx c, COp& op_v)
+template <bool kExact>
+__device__ __noinline__ void tile_mix(const Ctx c_v, COp& op_v)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     float gain[4];
     for (int k = 0; k < 4; k++) gain[k] = par(c, op, MIX_P_GAIN0 + k);
@@ -311,8 +344,10 @@ __device__ __noinline__ void tile_mix(const Ctx c, COp& op_v)
     tile_run<4, 1>(c, in, out, [&](const float* x, float* y) { y[0] = mixer_step(fl, x, gain); });
 }
 
-__device__ __noinline__ void tile_math(const Ctx c, COp& op_v)
+template <bool kExact>
+__device__ __noinline__ void tile_math(const Ctx c_v, COp& op_v)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     const float constant = par(c, op, MATH_P_CONST);
     const uint32_t fl = op.flags;
@@ -321,8 +356,10 @@ __device__ __noinline__ void tile_math(const Ctx c, COp& op_v)
     tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = math_step(fl, x[0], x[1], constant); });
 }
 
-__device__ __noinline__ void tile_nonlin(const Ctx c, COp& op_v)
+template <bool kExact>
+__device__ __noinline__ void tile_nonlin(const Ctx c_v, COp& op_v)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     const float constant = par(c, op, NONLIN_P_CONST);
     const uint32_t fl = op.flags;
@@ -334,8 +371,10 @@ __device__ __noinline__ void tile_nonlin(const Ctx c, COp& op_v)
 // SampleModule (sample.rs:192-240) in two passes over the tile: the position state machine does not depend on the
 // samples it reads, so pass 1 leaves each sample's read INDEX in the output wire and pass 2 turns indices into
 // samples with independent gathers from the shared wave (8 loads in flight per lane instead of one per step).
-__device__ __noinline__ void tile_sample(const Ctx c, COp& op_v, CArgs& a_v)
+template <bool kExact>
+__device__ __noinline__ void tile_sample(const Ctx c_v, COp& op_v, CArgs& a_v)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     CArgs& a = uniform_args(a_v);
     const int sr = op.state_row;
@@ -390,8 +429,10 @@ SRK_DEV uint32_t seq_advance(SeqRegs& s, float step_in, float sync_in, uint32_t 
     return cs;
 }
 
-__device__ __noinline__ void tile_seq(const Ctx c, COp& op_v, CArgs& a_v)
+template <bool kExact>
+__device__ __noinline__ void tile_seq(const Ctx c_v, COp& op_v, CArgs& a_v)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     CArgs& a = uniform_args(a_v);
     const int sr = op.state_row;
@@ -439,23 +480,27 @@ __device__ __noinline__ void tile_seq(const Ctx c, COp& op_v, CArgs& a_v)
     ROW(sr + SEQ_S_SYNC_LAST) = s.sync_last ? 1u : 0u;
 }
 
-// Sum an LDS tile [rows_in_tile][64] over the 64 lanes: lane l owns row l % R and the column
-// segment l / R (R = tile capacity, a power of two <= 64); columns are visited skewed by the row
-// so the 32 lanes of a half-wave hit 32 different banks.  Result valid in lanes < R.
+// Sum the first `rows` rows of an LDS tile [..][64] over the 64 lanes.  R = the power of two >= rows (<= 64): lane l
+// owns row l % R and the column segment l / R (64 / R segments of R columns each); columns are visited skewed by the
+// row so the 32 lanes of a half-wave hit 32 different banks.  Lanes whose row is past `rows` idle.  Valid in lanes < rows.
 template <class Ptr>
-SRK_DEV float tile_row_sum(Ptr t, int R, int lane)
+SRK_DEV float tile_row_sum(Ptr t, int rows, int lane)
 {
+    const int R = rows <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)rows - 1u));
     const int row = lane & (R - 1);
-    const int seg = lane / R;          // 64 / R segments of R columns each
+    const int seg = lane / R;
     const Ptr p = t + row * 64 + seg * R;
     float sum = 0.0f;
-    for (int j = 0; j < R; j++) sum += p[(j + row) & (R - 1)];
+    if (row < rows)
+        for (int j = 0; j < R; j++) sum += p[(j + row) & (R - 1)];
     for (int m = R; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
     return sum;
 }
 
-__device__ __noinline__ void tile_out(const Ctx c, COp& op_v, CArgs& a_v, uint32_t t0, uint32_t voice, bool active)
+template <bool kExact>
+__device__ __noinline__ void tile_out(const Ctx c_v, COp& op_v, CArgs& a_v, uint32_t t0, uint32_t voice, bool active)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     CArgs& a = uniform_args(a_v);
     const int slot = op.in_slot[0], plane = op.aux;
@@ -489,8 +534,10 @@ __device__ __noinline__ void tile_out(const Ctx c, COp& op_v, CArgs& a_v, uint32
     }
 }
 
-__device__ __noinline__ void tile_delay_rd(const Ctx c, COp& op_v, CArgs& a_v, uint64_t n_abs, uint32_t voice_c)
+template <bool kExact>
+__device__ __noinline__ void tile_delay_rd(const Ctx c_v, COp& op_v, CArgs& a_v, uint64_t n_abs, uint32_t voice_c)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     CArgs& a = uniform_args(a_v);
     const int o = op.out_slot[0];
@@ -522,8 +569,10 @@ __device__ __noinline__ void tile_delay_rd(const Ctx c, COp& op_v, CArgs& a_v, u
     }
 }
 
-__device__ __noinline__ void tile_delay_wr(const Ctx c, COp& op_v, CArgs& a_v, uint64_t n_abs, uint32_t voice, bool active)
+template <bool kExact>
+__device__ __noinline__ void tile_delay_wr(const Ctx c_v, COp& op_v, CArgs& a_v, uint64_t n_abs, uint32_t voice, bool active)
 {
+    const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     CArgs& a = uniform_args(a_v);
     const int s = op.in_slot[0];
@@ -547,7 +596,7 @@ __device__ __noinline__ void tile_delay_wr(const Ctx c, COp& op_v, CArgs& a_v, u
 
 // ---- generic tile interpreter ----------------------------------------------------------------------
 template <bool kExact>
-__global__ __launch_bounds__(64) void render_interp(KernelArgs a)
+SRK_DEV void interp_body(const KernelArgs& a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
@@ -581,23 +630,40 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a)
             switch (op.kind) {
             case OP_OSC: dev::tile_osc<kExact>(c, op); break;
             case OP_VCF: dev::tile_vcf<kExact>(c, op); break;
-            case OP_ADSR: dev::tile_adsr(c, op); break;
-            case OP_VCA: dev::tile_vca(c, op); break;
-            case OP_MIX: dev::tile_mix(c, op); break;
-            case OP_MATH: dev::tile_math(c, op); break;
-            case OP_OUT: dev::tile_out(c, op, ca, t0, voice, active); break;
+            case OP_ADSR: dev::tile_adsr<kExact>(c, op); break;
+            case OP_VCA: dev::tile_vca<kExact>(c, op); break;
+            case OP_MIX: dev::tile_mix<kExact>(c, op); break;
+            case OP_MATH: dev::tile_math<kExact>(c, op); break;
+            case OP_OUT: dev::tile_out<kExact>(c, op, ca, t0, voice, active); break;
             case OP_GRIDSEQ:
-            case OP_PATSEQ: dev::tile_seq(c, op, ca); break;
-            case OP_NONLIN: dev::tile_nonlin(c, op); break;
-            case OP_SAMPLE: dev::tile_sample(c, op, ca); break;
-            case OP_DELAY_RD: dev::tile_delay_rd(c, op, ca, a.n0 + t0, voice_c); break;
-            case OP_DELAY_WR: dev::tile_delay_wr(c, op, ca, a.n0 + t0, voice, active); break;
+            case OP_PATSEQ: dev::tile_seq<kExact>(c, op, ca); break;
+            case OP_NONLIN: dev::tile_nonlin<kExact>(c, op); break;
+            case OP_SAMPLE: dev::tile_sample<kExact>(c, op, ca); break;
+            case OP_DELAY_RD: dev::tile_delay_rd<kExact>(c, op, ca, a.n0 + t0, voice_c); break;
+            case OP_DELAY_WR: dev::tile_delay_wr<kExact>(c, op, ca, a.n0 + t0, voice, active); break;
             default: break;
             }
         }
     }
     if (active)
         for (int r = 0; r < a.prog.n_state_rows; r++) a.table[(size_t)r * a.V + voice] = c.rows[r * 64 + lane];
+}
+
+// Two entry points over one body.  The default flavour is told to fit five waves per SIMD (<= 96 VGPRs; it needs 103
+// unconstrained): resident waves are what hides the latency of the per-module dependency chains, and at the headline
+// size (16 waves per CU) four per SIMD leaves no slack for the dispatcher.  The exact flavour (f64 PolyBLEP / sin / pow,
+// 184 VGPRs) would spill heavily under that cap and is left alone.
+template <bool kExact>
+__global__ __launch_bounds__(64) void render_interp(KernelArgs a);
+template <>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void render_interp<false>(KernelArgs a)
+{
+    interp_body<false>(a);
+}
+template <>
+__global__ __launch_bounds__(64) void render_interp<true>(KernelArgs a)
+{
+    interp_body<true>(a);
 }
 
 constexpr int kMixRows = 32;
@@ -1362,6 +1428,12 @@ static void launch_fused(uint32_t osc_port, uint32_t vcf_port, bool exact, int o
 static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_t st)
 {
     size_t lds = ((size_t)P.hdr.n_rows + 2 + (size_t)P.hdr.n_tracks + (size_t)P.hdr.n_slots * P.hdr.tile) * 256;  // + zero, trash and track rows
+    if (getenv("SRACK_DEBUG_OCC")) {  // tools/: what the runtime says about resident workgroups per CU for this LDS size
+        int n = -1;
+        hipError_t e = (P.render_flags & SRACK_RENDER_EXACT_OSC) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_interp<true>, 64, lds)
+                                                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_interp<false>, 64, lds);
+        fprintf(stderr, "[srack] render_interp lds=%zu B/wave occupancy=%d workgroups/CU (%s) waves=%u\n", lds, n, hipGetErrorString(e), ka.n_waves);
+    }
     if (P.render_flags & SRACK_RENDER_EXACT_OSC)
         hipLaunchKernelGGL(render_interp<true>, dim3(ka.n_waves), dim3(64), lds, st, ka);
     else
