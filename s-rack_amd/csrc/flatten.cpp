@@ -146,6 +146,28 @@ struct Builder {
         }
     }
 
+    // Is this wire a sequencer's note CV, possibly offset / scaled / mixed with constants?  Such a CV holds one value
+    // for thousands of samples, which lets the oscillator carry its phase terms between note changes.
+    bool stepwise(int module, int port, int depth) const
+    {
+        if (module < 0 || depth > 8) return false;
+        const Module& m = g.modules[(size_t)module];
+        switch (m.type) {
+        case SRACK_MOD_GRID_SEQUENCER: return port == SRACK_GRIDSEQ_OUT_CV;
+        case SRACK_MOD_MATH:
+        case SRACK_MOD_MONO_MIXER: {
+            bool any = false;
+            for (const InputRef& in : m.in)
+                if (in.src >= 0) {
+                    if (!stepwise(in.src, in.port, depth + 1)) return false;
+                    any = true;
+                }
+            return any;
+        }
+        default: return false;
+        }
+    }
+
     int build();
     void match_fused(bool has_rings);
 };
@@ -229,6 +251,7 @@ int Builder::build()
             op.kind = OP_OSC;
             if (connected(0)) op.flags |= OSC_HAS_CV;
             if (connected(1)) op.flags |= OSC_HAS_SYNC;
+            if (connected(0) && stepwise(mod.in[0].src, mod.in[0].port, 0)) op.flags |= OSC_CV_STEPWISE;
             if (field(m, SRACK_OSC_ANTIALIASING) != 0.0) op.flags |= OSC_AA;
             if (pl & 1u) op.flags |= OSC_OUT_SINE;
             if (pl & 2u) op.flags |= OSC_OUT_SQUARE;

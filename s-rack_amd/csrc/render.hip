@@ -226,6 +226,46 @@ __device__ __noinline__ void tile_osc(const Ctx c_v, COp& op_v)
         return;
     }
     const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const uint32_t ports = fl & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
+    if (!kExact && (fl & (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_HAS_SYNC | OSC_AA)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1))) {
+        // A sequencer-driven pitch: the carried-phase oscillator between note changes.  When some lane's CV differs from
+        // the one its increment was computed for (a wave-uniform test), that increment is recomputed — 440 / sr x 2^(cv +
+        // val), as osc_step does — and the carried terms are rebuilt from the exact f64 phase.  An increment of 0.25 or
+        // more (or NaN) breaks the carried form's "one PolyBLEP window at a time": those samples take osc_step.
+        COsc o;
+        float seen_cv = __builtin_nanf("");
+        bool carried = false;
+        const uint32_t f = fl & ~OSC_EXACT;
+        const Port cvp[1] = {in[0]};
+        const Port w[1] = {out[(fl & OSC_OUT_SAW) ? 2 : (fl & OSC_OUT_SQUARE) ? 1 : 0]};
+        o.pos = s.pos;
+        tile_run<1, 1>(c, cvp, w, [&](const float* x, float* y) {
+            const float cv = x[0];
+            if (__builtin_amdgcn_ballot_w64(cv != seen_cv) != 0) {
+                const double delta = (440.0 / k.sr) * exp2_fast((double)cv + k.val);
+                seen_cv = cv;
+                carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
+                cosc_init(o, o.pos, delta);
+            }
+            if (carried) {
+                y[0] = (fl & OSC_OUT_SAW) ? cosc_saw(o) : (fl & OSC_OUT_SQUARE) ? cosc_square(o) : cosc_sine(o);
+            } else {
+                OscRegs g;
+                g.pos = o.pos;
+                g.sync_last = false;
+                g.seen_cv = seen_cv;
+                g.seen_delta = o.delta;
+                float o3[3] = {0.0f, 0.0f, 0.0f};
+                osc_step(f, g, k, cv, 0.0f, o3[0], o3[1], o3[2]);
+                y[0] = (fl & OSC_OUT_SAW) ? o3[2] : (fl & OSC_OUT_SQUARE) ? o3[1] : o3[0];
+                cosc_init(o, g.pos, o.delta);
+            }
+        });
+        ROW(sr + OSC_S_POS_LO) = f64_lo(o.pos);
+        ROW(sr + OSC_S_POS_HI) = f64_hi(o.pos);
+        ROW(sr + OSC_S_SYNC_LAST) = 0u;
+        return;
+    }
     const uint32_t f = kExact ? (fl | OSC_EXACT) : (fl & ~OSC_EXACT);
     tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
         y[0] = y[1] = y[2] = 0.0f;
