@@ -144,7 +144,9 @@ enum {
     /* never pick a fused chain kernel; run every op through the generic tile interpreter */
     SRACK_RENDER_NO_FUSION  = 1u << 1,
     /* do not hoist voice-invariant sub-graphs into the control track; evaluate them per lane */
-    SRACK_RENDER_NO_UNIFORM_HOIST = 1u << 2
+    SRACK_RENDER_NO_UNIFORM_HOIST = 1u << 2,
+    /* evaluate the control program as one stage instead of a pipeline of dependency depths */
+    SRACK_RENDER_NO_CTL_STAGES = 1u << 3
 };
 
 typedef struct srack_patch srack_patch; /* opaque: the workspace's module list + plan + device voice state */

@@ -401,8 +401,9 @@ int srack_voices_get_field(srack_patch* p, int module, int field, double* values
     int rc = ensure_program(h, h.prog_valid ? h.prog_flags : 0u);
     if (rc != SRACK_OK) return rc;
     // a module evaluated by the control program has ONE state, shared by every voice
-    const bool ctl = h.prog.n_tracks > 0 && module >= 0 && module < (int)h.prog.in_ctl.size() && h.prog.in_ctl[(size_t)module];
-    const FlatProgram& P = ctl ? h.prog.ctl : h.prog.voice;
+    const int stage = h.prog.n_tracks > 0 && module >= 0 && module < (int)h.prog.ctl_stage.size() ? h.prog.ctl_stage[(size_t)module] : -1;
+    const bool ctl = stage >= 0;
+    const FlatProgram& P = ctl ? h.prog.ctl[(size_t)stage] : h.prog.voice;
     StateLoc loc = P.locate(h.graph, module, field);
     if (loc.row < 0) {  // a parameter, or a module that is not evaluated: the field value itself
         double x;
@@ -416,7 +417,7 @@ int srack_voices_get_field(srack_patch* p, int module, int field, double* values
     }
     const uint32_t V = P.n_voices;
     std::vector<uint32_t> rows((size_t)V * (loc.f64 ? 2 : 1));
-    rc = device_read_rows(h, ctl, loc.row, loc.f64 ? 2 : 1, rows.data());
+    rc = device_read_rows(h, stage, loc.row, loc.f64 ? 2 : 1, rows.data());
     if (rc != SRACK_OK) return rc;
     for (uint32_t v = 0; v < h.n_voices; v++) {
         const uint32_t sv = ctl ? 0u : v;

@@ -66,7 +66,8 @@ struct Analysis {  // whole-graph facts shared by both programs
     std::vector<char> live;
     std::vector<uint32_t> port_live;
     std::vector<char> in_ctl;
-    std::vector<std::pair<int, int>> tracks;         // (module, port) exported by the control program
+    std::vector<int> stage;                          // per module: control stage (>= 0) or -1 = voice program
+    std::vector<std::pair<int, int>> tracks;         // (module, port) exported by a control stage
     std::map<std::pair<int, int>, int> track_of;
 };
 
@@ -76,6 +77,7 @@ struct Builder {
     const std::vector<VoiceOverride>& ov;
     uint32_t render_flags;
     const Analysis& A;
+    int stage;        // which program is being built: a control stage (>= 0) or -1 = the voice program
     bool is_ctl;
     FlatProgram& out;
     std::vector<Wire> wires;
@@ -184,7 +186,8 @@ int Builder::build()
     out.render_flags = render_flags;
     const int output = g.plan.output;
     const auto& pos = g.plan.position;
-    auto mine = [&](int m) { return A.live[(size_t)m] && (bool)A.in_ctl[(size_t)m] == is_ctl; };
+    auto mine = [&](int m) { return A.live[(size_t)m] && A.stage[(size_t)m] == stage; };
+    std::vector<int> my_tracks;  // rows of the track buffer this program reads, in order of first use
     auto is_delayed = [&](int src, int sink) { return pos[(size_t)src] > pos[(size_t)sink]; };
 
     // rings: one per (src, port) in this program that has a delayed reader in this program
@@ -220,8 +223,11 @@ int Builder::build()
         for (int k = 0; k < mod.n_in; k++) {
             const InputRef& in = mod.in[(size_t)k];
             if (in.src < 0) continue;
-            if (!is_ctl && A.in_ctl[(size_t)in.src]) {  // a control track (never a delayed edge: see the uniform analysis),
-                in_wire[k] = -2 - A.track_of.at({in.src, in.port});  // read in place from HBM: no wire, no slot
+            if (A.stage[(size_t)in.src] != stage) {  // a control track from an (earlier) control stage — never a delayed edge,
+                const int tk = A.track_of.at({in.src, in.port});  // see the uniform analysis; no wire, no slot
+                size_t local = std::find(my_tracks.begin(), my_tracks.end(), tk) - my_tracks.begin();
+                if (local == my_tracks.size()) my_tracks.push_back(tk);
+                in_wire[k] = -2 - (int)local;
             } else if (is_delayed(in.src, m)) {
                 DevOp rd = blank_op(OP_DELAY_RD, in.src);
                 rd.aux = ring_of.at({in.src, in.port});
@@ -538,7 +544,12 @@ int Builder::build()
     }
     H.n_ops = (int)out.ops.size();
     H.n_planes = n_planes;
-    H.n_tracks = is_ctl ? 0 : (int)A.tracks.size();
+    if ((int)my_tracks.size() > kMaxTracksRead) {
+        set_error("flatten: one program reads more than " + std::to_string(kMaxTracksRead) + " control tracks");
+        return SRACK_ERR_UNSUPPORTED;
+    }
+    H.n_tracks = (int)my_tracks.size();
+    for (size_t k = 0; k < my_tracks.size(); k++) H.track_id[k] = my_tracks[k];
 
     // ---- tile length: LDS per wave decides how many waves a CU holds ---------------------------------------
     // One wave needs (fixed rows + slots x tile) x 256 B of LDS, handed out in 1280-B granules from 160 KB per CU.
@@ -822,19 +833,70 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
         if (A.tracks.empty()) std::fill(u.begin(), u.end(), 0);
     }
     out.in_ctl = A.in_ctl;
+    A.stage.assign((size_t)n_mod, -1);
+    for (int m = 0; m < n_mod; m++)
+        if (A.in_ctl[(size_t)m]) A.stage[(size_t)m] = 0;
+
+    // ---- 3b. control units ---------------------------------------------------------------------------------
+    // One wave evaluating one voice is a latency chain: ~0.1-0.3 us per module per sample, and the voice kernels of
+    // a chunk cannot start before the chunk's tracks exist.  Control modules only exchange finished samples, so a
+    // module at dependency depth d can work on chunk k while its consumers work on chunk k-1: every module becomes
+    // its own unit (one block of the control launch), trailing by its depth; every wire between units is a track.
+    // The launch then lasts as long as its slowest module, not as the sum.  A feedback edge inside the control
+    // sub-graph would tie depths together, and a small control program is not worth the extra tracks (it may also be
+    // the fused gate -> envelope shape): both stay one unit.
+    constexpr int kMinModulesToSplit = 4;
+    std::vector<int> unit_lag{0};
+    if (!A.tracks.empty() && !(render_flags & SRACK_RENDER_NO_CTL_STAGES)) {
+        const auto& pos = g.plan.position;
+        int n_ctl = 0;
+        bool feedback = false;
+        for (int m = 0; m < n_mod; m++) {
+            if (!A.in_ctl[(size_t)m]) continue;
+            n_ctl++;
+            for (const InputRef& in : g.modules[(size_t)m].in)
+                if (in.src >= 0 && A.in_ctl[(size_t)in.src] && pos[(size_t)in.src] > pos[(size_t)m]) feedback = true;
+        }
+        if (n_ctl >= kMinModulesToSplit && !feedback) {
+            unit_lag.clear();
+            for (int m : g.plan.order) {  // plan order: every non-delayed source comes first
+                if (!A.in_ctl[(size_t)m]) continue;
+                int depth = 0;
+                for (const InputRef& in : g.modules[(size_t)m].in)
+                    if (in.src >= 0 && A.in_ctl[(size_t)in.src]) depth = std::max(depth, unit_lag[(size_t)A.stage[(size_t)in.src]] + 1);
+                A.stage[(size_t)m] = (int)unit_lag.size();
+                unit_lag.push_back(depth);
+            }
+            for (int m : g.plan.order) {  // wires between units travel as tracks too
+                if (!A.in_ctl[(size_t)m]) continue;
+                for (const InputRef& in : g.modules[(size_t)m].in)
+                    if (in.src >= 0 && A.stage[(size_t)in.src] != A.stage[(size_t)m] && !A.track_of.count({in.src, in.port})) {
+                        A.track_of[{in.src, in.port}] = (int)A.tracks.size();
+                        A.tracks.emplace_back(in.src, in.port);
+                    }
+            }
+        }
+    }
+    const int n_stages = (int)unit_lag.size();
+    out.ctl_stage = A.stage;
+    out.ctl_lag = unit_lag;
     out.n_tracks = (int)A.tracks.size();
 
     if (out.n_tracks > 0) {
-        Builder bc{g, 1, kNoOverrides, render_flags, A, true, out.ctl, {}, {}};
-        int rc = bc.build();
-        if (rc != SRACK_OK) return rc;
+        out.ctl.resize((size_t)n_stages);
+        for (int st = 0; st < n_stages; st++) {
+            Builder bc{g, 1, kNoOverrides, render_flags, A, st, true, out.ctl[(size_t)st], {}, {}};
+            int rc = bc.build();
+            if (rc != SRACK_OK) return rc;
+        }
     }
-    Builder bv{g, n_voices, overrides, render_flags, A, false, out.voice, {}, {}};
+    Builder bv{g, n_voices, overrides, render_flags, A, -1, false, out.voice, {}, {}};
     int rc = bv.build();
     if (rc != SRACK_OK) return rc;
     std::ostringstream d;
     d << out.voice.description;
-    if (out.n_tracks > 0) d << " + " << out.ctl.description << " tracks=" << out.n_tracks;
+    for (const FlatProgram& c : out.ctl) d << " + " << c.description;
+    if (out.n_tracks > 0) d << " tracks=" << out.n_tracks;
     d << " B=" << g.cfg.buffer_size;
     out.description = d.str();
     return SRACK_OK;

@@ -49,9 +49,15 @@ struct FlatProgram {
 // voice) into control tracks [n_tracks][T] which the voice program reads with OP_TRACK_RD.
 struct FlatPair {
     FlatProgram voice;
-    FlatProgram ctl;      // valid iff n_tracks > 0; its "planes" are the tracks
-    int n_tracks = 0;
-    std::vector<char> in_ctl;  // per module: evaluated by the control program
+    // The control program, valid iff n_tracks > 0; its "planes" are the tracks.  One wave evaluating one voice is a
+    // pure latency chain, so a large control program is cut into UNITS of one module each: a unit reads the tracks of
+    // the modules it depends on and runs `ctl_lag` chunks behind the deepest-upstream unit, all units side by side in
+    // one launch (render.hip).  A small one (or one with internal feedback) stays a single unit with lag 0.
+    std::vector<FlatProgram> ctl;
+    std::vector<int> ctl_lag;   // per unit: dependency depth = how many chunks it trails
+    int n_tracks = 0;           // rows of the track buffer
+    std::vector<char> in_ctl;   // per module: evaluated by the control program
+    std::vector<int> ctl_stage; // per module: its unit, -1 if not in the control program
     std::string description;
 };
 

@@ -71,6 +71,7 @@ enum : uint32_t {
 constexpr int kMaxIn = 8;  // OutputModule: one input per channel (u8 in the reference; capped at 8 here)
 constexpr int kMaxOut = 9;  // PatternSequencerModule: 8 gates + sync
 constexpr int kMaxPar = 8;
+constexpr int kMaxTracksRead = 16;  // control tracks one program may read
 
 // parameter indices into DevOp::par_row / par_val, per kind
 enum { OSC_P_VAL = 0 };                                            // f32 `val` (used when CV is wired)
@@ -120,7 +121,8 @@ struct DevProgram {
     int32_t buffer_size;    // B: length of a broken edge's delay
     int32_t n_rings;        // global rings ([B][V] f32 each)
     int32_t tile;           // samples per tile the interpreter uses (<= B when rings exist)
-    int32_t n_tracks;       // control tracks this program reads (each gets one LDS row per tile)
+    int32_t n_tracks;       // control tracks this program reads (each gets one LDS row per tile) ...
+    int32_t track_id[kMaxTracksRead];  // ... and which rows of the track buffer they are (input slot kTrackSlot + k reads track_id[k])
 };
 
 constexpr int kMaxOps = 96;

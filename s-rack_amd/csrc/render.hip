@@ -71,7 +71,8 @@ struct WaveMap {   // which voices a wave owns
     bool active;
 };
 
-SRK_DEV WaveMap wave_map(const KernelArgs& a, int lane)
+template <class Args>
+SRK_DEV WaveMap wave_map(const Args& a, int lane)
 {
     WaveMap m;
     m.wave0 = (blockIdx.x - a.block0) * a.lanes;
@@ -635,12 +636,15 @@ __device__ __noinline__ void tile_delay_wr(const Ctx c_v, COp& op_v, CArgs& a_v,
 }  // namespace dev
 
 // ---- generic tile interpreter ----------------------------------------------------------------------
+// `a` is the argument block seen through the constant address space (the kernarg segment itself, or one entry of the
+// stage table in global memory): every field arrives by a scalar load, and tile functions can take its address.
 template <bool kExact>
-SRK_DEV void interp_body(const KernelArgs& a)
+SRK_DEV void interp_body(dev::CArgs& a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
-    dev::CArgs& ca = *(dev::CArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // `a` itself, addressable without a private copy
+    if (a.T == 0) return;  // an idle slot of the control pipeline
+    dev::CArgs& ca = a;
     const dev::WaveMap wm = dev::wave_map(a, lane);
     const uint32_t voice = wm.voice, voice_c = wm.vc;  // idle lanes shadow the wave's last voice; they never store
     const bool active = wm.active;
@@ -659,10 +663,10 @@ SRK_DEV void interp_body(const KernelArgs& a)
 
     for (uint32_t t0 = 0; t0 < a.T; t0 += (uint32_t)tile) {
         c.n = (int)min((uint32_t)tile, a.T - t0);
-        if (a.prog.n_tracks > 0) {  // this tile's slice of every control track: one coalesced load per track
+        if (a.prog.n_tracks > 0) {  // this tile's slice of every control track the program reads: one coalesced load per track
             __syncthreads();
             for (int k = 0; k < a.prog.n_tracks; k++)
-                if (lane < c.n) c.trk[k * 64 + lane] = a.tracks[(size_t)k * a.t_stride + t0 + lane];
+                if (lane < c.n) c.trk[k * 64 + lane] = a.tracks[(size_t)a.prog.track_id[k] * a.t_stride + t0 + lane];
             __syncthreads();
         }
         for (int i = 0; i < a.prog.n_ops; i++) {
@@ -698,12 +702,31 @@ __global__ __launch_bounds__(64) void render_interp(KernelArgs a);
 template <>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void render_interp<false>(KernelArgs a)
 {
-    interp_body<false>(a);
+    interp_body<false>(*(dev::CArgs*)__builtin_amdgcn_kernarg_segment_ptr());
 }
 template <>
 __global__ __launch_bounds__(64) void render_interp<true>(KernelArgs a)
 {
-    interp_body<true>(a);
+    interp_body<true>(*(dev::CArgs*)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
+// The control pipeline: block b runs control unit b (one module) on the chunk its entry of `slots` describes (T == 0:
+// nothing to do in this launch).  A unit trails the units it reads by at least one chunk, i.e. it reads tracks written by
+// an EARLIER launch: the kernel boundary provides the ordering; within a launch the units touch disjoint state and
+// disjoint track ranges.
+// (Same register budget as render_interp<false>: the tile functions are shared, and the budget only propagates to
+// callees whose callers all agree.)
+template <bool kExact>
+__global__ __launch_bounds__(64) void render_interp_stages(const KernelArgs* slots);
+template <>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void render_interp_stages<false>(const KernelArgs* slots)
+{
+    interp_body<false>(*(dev::CArgs*)(uintptr_t)(slots + blockIdx.x));
+}
+template <>
+__global__ __launch_bounds__(64) void render_interp_stages<true>(const KernelArgs* slots)
+{
+    interp_body<true>(*(dev::CArgs*)(uintptr_t)(slots + blockIdx.x));
 }
 
 constexpr int kMixRows = 32;
@@ -1304,7 +1327,11 @@ struct DevProg {  // device copy of one FlatProgram
 };
 
 struct DeviceState {
-    DevProg voice, ctl;
+    DevProg voice;
+    std::vector<DevProg> ctl;  // one per control stage
+    KernelArgs* d_stage_slots = nullptr;  // [launches][stages] argument blocks of the staged control pipeline
+    size_t stage_slots_cap = 0;
+    std::vector<KernelArgs> h_stage_slots;
     float* d_mixpart = nullptr;
     size_t mixpart_bytes = 0;
     float* d_mixgroup = nullptr;
@@ -1323,7 +1350,8 @@ void device_release(DeviceState* d)
 {
     if (!d) return;
     d->voice.release();
-    d->ctl.release();
+    for (DevProg& c : d->ctl) c.release();
+    (void)hipFree(d->d_stage_slots);
     (void)hipFree(d->d_mixpart);
     (void)hipFree(d->d_mixgroup);
     (void)hipFree(d->d_tracks);
@@ -1402,7 +1430,8 @@ static int upload_program(PatchHandle& h)
 {
     h.dev = new DeviceState();
     int rc = upload_one(h.prog.voice, h.dev->voice);
-    if (rc == SRACK_OK && h.prog.n_tracks > 0) rc = upload_one(h.prog.ctl, h.dev->ctl);
+    h.dev->ctl.resize(h.prog.ctl.size());
+    for (size_t s = 0; s < h.prog.ctl.size() && rc == SRACK_OK; s++) rc = upload_one(h.prog.ctl[s], h.dev->ctl[s]);
     return rc;
 }
 
@@ -1548,17 +1577,23 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
     //  two streams (any other combination): control chunks run on a private stream, voice chunk k waits on event k.
     //    This overlaps only while the two streams map to different hardware queues (GPU_MAX_HW_QUEUES, default 4,
     //    shared with the host's other streams): measured 15 ms -> 20 ms per step once RCCL's streams are alive.
-    const bool co_ctl = has_ctl && P.fused == FUSED_VOICE_CHAIN_TRACK && h.prog.ctl.fused == FUSED_CTL_GATE_ENV && h.prog.n_tracks == 1;
+    const uint32_t n_stages = (uint32_t)h.prog.ctl.size();
+    const bool co_ctl = has_ctl && P.fused == FUSED_VOICE_CHAIN_TRACK && n_stages == 1 && h.prog.ctl[0].fused == FUSED_CTL_GATE_ENV && h.prog.n_tracks == 1;
     auto ctl_work = [&](uint32_t t_off, uint32_t len) {
-        const FlatProgram& Cp = h.prog.ctl;
-        return CtlWork{d->ctl.d_ops, d->ctl.d_table, d->d_tracks + (size_t)Cp.ops[2].aux * T + t_off, len,
+        const FlatProgram& Cp = h.prog.ctl[0];
+        return CtlWork{d->ctl[0].d_ops, d->ctl[0].d_table, d->d_tracks + (size_t)Cp.ops[2].aux * T + t_off, len,
                        Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW)};
     };
     // chunk schedule: short first chunks (only control chunk 0 is exposed), doubling up to kChunkMax
-    constexpr uint32_t kChunkFirst = 1024, kChunkMax = 8192;  // multiples of every tile size
+    // With a control pipeline of depth L the first voice chunk waits for L + 1 control launches: those stay short.
+    constexpr uint32_t kChunkFirst = 1024, kChunkMax = 8192;
+    uint32_t max_lag = 0;
+    for (int lag : h.prog.ctl_lag) max_lag = std::max(max_lag, (uint32_t)lag);
     std::vector<std::pair<uint32_t, uint32_t>> chunks;       // (t_off, len)
     if (has_ctl) {
-        for (uint32_t t_off = 0, len = kChunkFirst; t_off < T; t_off += len, len = std::min(len * 2, kChunkMax)) {
+        uint32_t k = 0;
+        for (uint32_t t_off = 0, len = kChunkFirst; t_off < T; t_off += len, k++) {
+            if (k > max_lag) len = std::min(len * 2, kChunkMax);
             len = std::min(len, T - t_off);
             chunks.emplace_back(t_off, len);
         }
@@ -1591,16 +1626,16 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         // the track buffer may still be read by the previous render on `st`: start after it
         HIP_TRY(hipEventRecord(d->ev_begin, st));
         HIP_TRY(hipStreamWaitEvent(d->ctl_stream, d->ev_begin, 0));
-        const FlatProgram& Cp = h.prog.ctl;
-        for (uint32_t k = 0; k < n_chunks; k++) {
+        auto stage_args = [&](uint32_t s, uint32_t k) {
             const uint32_t t_off = chunks[k].first, len = chunks[k].second;
             KernelArgs kc{};
-            kc.ops = d->ctl.d_ops;
-            kc.prog = Cp.hdr;
-            kc.table = d->ctl.d_table;
-            kc.rings = d->ctl.d_rings;
-            kc.seqtab = d->ctl.d_seqtab;
+            kc.ops = d->ctl[s].d_ops;
+            kc.prog = h.prog.ctl[s].hdr;
+            kc.table = d->ctl[s].d_table;
+            kc.rings = d->ctl[s].d_rings;
+            kc.seqtab = d->ctl[s].d_seqtab;
             kc.frames = d->d_tracks + t_off;  // the control program's planes are the tracks: [n_tracks][T][1]
+            kc.tracks = d->d_tracks + t_off;  // ... and later stages read earlier stages' tracks from the same buffer
             kc.plane_stride = T;
             kc.t_stride = T;
             kc.V = 1;
@@ -1608,9 +1643,47 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
             kc.n_waves = 1;
             kc.lanes = 64;
             kc.n0 = h.samples_rendered + t_off;
-            launch_ctl(Cp, kc, d->ctl_stream);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(d->ev_chunk[k], d->ctl_stream));
+            return kc;
+        };
+        const bool staged = h.prog.ctl[0].fused == FUSED_NONE;  // the interpreter: all stages side by side in one launch
+        if (staged) {
+            // launch j runs unit s on chunk j - lag[s]; chunk c is complete after launch c + max_lag
+            const uint32_t n_launch = n_chunks + max_lag;
+            d->h_stage_slots.assign((size_t)n_launch * n_stages, KernelArgs{});
+            size_t lds = 0;
+            for (uint32_t s = 0; s < n_stages; s++) {
+                const DevProgram& H = h.prog.ctl[s].hdr;
+                lds = std::max(lds, ((size_t)H.n_rows + 2 + (size_t)H.n_tracks + (size_t)H.n_slots * H.tile) * 256);
+                for (uint32_t k = 0; k < n_chunks; k++) {
+                    KernelArgs& slot = d->h_stage_slots[(size_t)(k + (uint32_t)h.prog.ctl_lag[s]) * n_stages + s];
+                    slot = stage_args(s, k);
+                    slot.block0 = s;  // the stage's one wave is wave 0 of its program
+                }
+            }
+            const size_t bytes = sizeof(KernelArgs) * d->h_stage_slots.size();
+            if (bytes > d->stage_slots_cap) {
+                (void)hipFree(d->d_stage_slots);
+                d->d_stage_slots = nullptr;
+                d->stage_slots_cap = 0;
+                HIP_TRY(hipMalloc(&d->d_stage_slots, bytes));
+                d->stage_slots_cap = bytes;
+            }
+            HIP_TRY(hipMemcpyAsync(d->d_stage_slots, d->h_stage_slots.data(), bytes, hipMemcpyHostToDevice, d->ctl_stream));
+            for (uint32_t j = 0; j < n_launch; j++) {
+                const KernelArgs* slots = d->d_stage_slots + (size_t)j * n_stages;
+                if (flags & SRACK_RENDER_EXACT_OSC)
+                    hipLaunchKernelGGL(render_interp_stages<true>, dim3(n_stages), dim3(64), lds, d->ctl_stream, slots);
+                else
+                    hipLaunchKernelGGL(render_interp_stages<false>, dim3(n_stages), dim3(64), lds, d->ctl_stream, slots);
+                HIP_TRY(hipGetLastError());
+                if (j >= max_lag) HIP_TRY(hipEventRecord(d->ev_chunk[j - max_lag], d->ctl_stream));
+            }
+        } else {
+            for (uint32_t k = 0; k < n_chunks; k++) {
+                launch_ctl(h.prog.ctl[0], stage_args(0, k), d->ctl_stream);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(d->ev_chunk[k], d->ctl_stream));
+            }
         }
     }
 
@@ -1625,7 +1698,7 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
             if (op.kind == OP_ADSR) roles.adsr = i;
             if (op.kind == OP_VCA) roles.vca = i;
             if (op.kind == OP_OUT) roles.out = i;
-            if (op.kind == OP_VCA && track) roles.track = op.in_slot[1] - kTrackSlot;
+            if (op.kind == OP_VCA && track) roles.track = P.hdr.track_id[op.in_slot[1] - kTrackSlot];
         }
         const Graph& g = h.graph;
         roles.osc_a = P.op_of_module[(size_t)g.modules[(size_t)P.ops[(size_t)roles.vcf].module].in[0].src];
@@ -1745,11 +1818,11 @@ int device_kernel_ms(PatchHandle& h, double* avg_ms, int* n_launches, int reset)
 }
 
 // rows of the voice program's table (ctl = false) or of the control program's one-voice table
-int device_read_rows(PatchHandle& h, bool ctl, int first_row, int n_rows, uint32_t* host_dst)
+int device_read_rows(PatchHandle& h, int ctl_stage, int first_row, int n_rows, uint32_t* host_dst)
 {
-    const FlatProgram& P = ctl ? h.prog.ctl : h.prog.voice;
+    const FlatProgram& P = ctl_stage >= 0 ? h.prog.ctl[(size_t)ctl_stage] : h.prog.voice;
     const size_t V = P.n_voices;
-    const uint32_t* d_table = h.dev ? (ctl ? h.dev->ctl.d_table : h.dev->voice.d_table) : nullptr;
+    const uint32_t* d_table = h.dev ? (ctl_stage >= 0 ? h.dev->ctl[(size_t)ctl_stage].d_table : h.dev->voice.d_table) : nullptr;
     if (d_table) {
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(host_dst, d_table + (size_t)first_row * V, sizeof(uint32_t) * V * (size_t)n_rows, hipMemcpyDeviceToHost));

@@ -174,7 +174,8 @@ def test_flatten_descriptions(S):
     q = S.Patch(48000, 1024, 2)
     S.build_p1(q)
     q.configure_voices(4096)
-    assert "voice[ops=1" in q.info() and "ctl[ops=6" in q.info()
+    # ... and a control program of five modules becomes five pipelined units, one module each
+    assert "voice[ops=1" in q.info() and q.info().count("ctl[ops=2") == 5 and "tracks=5" in q.info()
     # feedback patch, per-voice beta: the whole loop is per voice; B = 1 => ring in LDS rows, tile of 1
     q = S.Patch(48000, 1, 2)
     ids2 = S.build_p2(q)
@@ -226,7 +227,9 @@ def test_sequencer_graph_api(S):
     p.configure_voices(128)
     p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, np.linspace(-2, 0, 128))
     info = p.info()
-    assert "ctl[ops=" in info and "tracks=4" in info, info
+    # ... as five pipelined units (clock, grid, pattern, two envelopes); 4 tracks reach the voice program, 4 more carry
+    # wires between units
+    assert info.count("ctl[ops=") == 5 and "tracks=8" in info, info
 
 
 def test_sample_and_nonlinear_graph_api(S):
