@@ -645,6 +645,44 @@ void Builder::match_fused(bool has_rings)
     int n_kind[16] = {0};
     for (const DevOp& op : out.ops) n_kind[op.kind]++;
     const DevProgram& H = out.hdr;
+    // Sequencer-driven subtractive voice (patch P3 after hoisting): the note CV, the filter envelope and the amplitude
+    // envelope arrive as control tracks; per voice there is an optional transpose (Math on the note track), the
+    // oscillator, the filter and the VCA.  Further output channels may carry tracks as they are (a raw gate, ...).
+    if (n_kind[OP_OSC] == 1 && n_kind[OP_VCF] == 1 && n_kind[OP_VCA] == 1 && n_kind[OP_OUT] >= 1 && n_kind[OP_OUT] <= 5 && n_kind[OP_MATH] <= 1 &&
+        H.n_ops == 3 + n_kind[OP_OUT] + n_kind[OP_MATH] && !(render_flags & SRACK_RENDER_EXACT_OSC)) {
+        const DevOp *math = nullptr, *osc = nullptr, *vcf = nullptr, *vca = nullptr;
+        for (const DevOp& op : out.ops) {
+            if (op.kind == OP_MATH) math = &op;
+            if (op.kind == OP_OSC) osc = &op;
+            if (op.kind == OP_VCF) vcf = &op;
+            if (op.kind == OP_VCA) vca = &op;
+        }
+        auto src_of = [&](int sink_module, int k) { return g.modules[(size_t)sink_module].in[(size_t)k]; };
+        auto is_track = [](int slot) { return slot >= kTrackSlot; };
+        const uint32_t ports = osc->flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
+        const uint32_t vcf_ports = vcf->flags & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP);
+        bool ok = (osc->flags & ~(OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1));
+        if (ok && math)
+            ok = src_of(osc->module, 0).src == math->module && (math->flags & (MATH_HAS_IN1 | MATH_HAS_IN2)) == MATH_HAS_IN1 && is_track(math->in_slot[0]);
+        else if (ok)
+            ok = is_track(osc->in_slot[0]);
+        ok = ok && (vcf->flags & VCF_HAS_AUDIO) && src_of(vcf->module, 0).src == osc->module && vcf_ports && !(vcf_ports & (vcf_ports - 1)) &&
+             (!(vcf->flags & VCF_HAS_CV) || is_track(vcf->in_slot[1]));
+        ok = ok && vca->flags == (VCA_HAS_AUDIO | VCA_HAS_CV) && src_of(vca->module, 0).src == vcf->module && is_track(vca->in_slot[1]);
+        int n_main = 0;
+        for (const DevOp& op : out.ops) {
+            if (op.kind != OP_OUT || is_track(op.in_slot[0])) continue;
+            n_main++;  // a plane fed by a wire: it must be the VCA's
+            bool from_vca = false;
+            for (int c = 0; c < H.n_channels; c++)
+                if (H.channel_plane[c] == op.aux) from_vca = src_of(op.module, c).src == vca->module;
+            ok = ok && from_vca;
+        }
+        if (ok && n_main == 1) {
+            out.fused = FUSED_VOICE_CHAIN_SEQ;
+            return;
+        }
+    }
     const bool full = H.n_ops == 6 && n_kind[OP_OSC] == 2 && n_kind[OP_VCF] == 1 && n_kind[OP_ADSR] == 1 && n_kind[OP_VCA] == 1 && n_kind[OP_OUT] == 1;
     const bool tracked = H.n_ops == 4 && n_kind[OP_OSC] == 1 && n_kind[OP_VCF] == 1 && n_kind[OP_VCA] == 1 && n_kind[OP_OUT] == 1;
     if (!full && !tracked) return;

@@ -19,7 +19,8 @@ enum FusedKind : int {
     FUSED_VOICE_CHAIN = 1,        // OSC -> VCF -> VCA, envelope = ADSR gated by an LFO OSC (patch P1's shape), all per voice
     FUSED_VOICE_CHAIN_TRACK = 2,  // OSC -> VCF -> VCA, envelope read from a control track (P1 after uniform hoisting)
     FUSED_FM_PAIR = 3,            // OSC_M (z^-1 feedback through a Multiply) -> Multiply -> OSC_C (patch P2, B = 1)
-    FUSED_CTL_GATE_ENV = 4        // control program {OSC -> ADSR -> track}: the voice-invariant half of P1
+    FUSED_CTL_GATE_ENV = 4,       // control program {OSC -> ADSR -> track}: the voice-invariant half of P1
+    FUSED_VOICE_CHAIN_SEQ = 5     // [MATH(track, k)] -> OSC(cv) -> VCF([cv = track]) -> VCA(track) -> OUT (+ OUTs fed by tracks): patch P3's shape
 };
 
 struct StateLoc {  // where a module's state field lives in the voice table

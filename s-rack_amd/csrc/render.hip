@@ -57,6 +57,13 @@ struct ChainRoles {  // op indices of the fused voice chain (osc_l / adsr unused
     int osc_a, osc_l, vcf, adsr, vca, out, track;
 };
 
+struct SeqRoles {  // the fused sequencer-driven voice chain: op indices and rows of the track buffer
+    int math, osc, vcf, vca, out;        // math = -1: the oscillator's CV is the note track itself
+    int trk_pitch, trk_cutoff, trk_env;  // trk_cutoff = -1: the filter has no CV
+    int n_extra;                         // further output planes that carry a track as it is
+    int extra_plane[4], extra_trk[4];
+};
+
 namespace dev {
 
 SRK_DEV double make_f64(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
@@ -1170,6 +1177,174 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
     }
 }
 
+// ---- fused sequencer-driven voice chain (patch P3's shape after hoisting) ------------------------------------------
+//   [MATH(note track, k)] -> OSC.cv ; OSC -> VCF (cutoff CV = envelope track) -> VCA (CV = envelope track) -> OUT,
+//   plus output channels that carry a track unchanged (a raw gate).  The three tracks are wave-uniform: each is
+//   prefetched one 32-sample tile ahead (lane l holds sample l) and read per sample with v_readlane, so "did the note /
+//   the cutoff CV change" is a scalar compare.  Between note changes the oscillator is the carried-phase one; at a
+//   change every lane recomputes its increment 440 / sr * 2^(cv + val) and rebuilds the carried terms from the exact f64
+//   phase (as tile_osc's stepwise path).  The filter coefficients are recomputed only when the cutoff CV's bits changed
+//   (vcf_coeffs re-checks per lane, as filter.rs:61 does).
+template <uint32_t kOscPort, int kOut>
+__global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRoles r)
+{
+    using namespace dev;
+    __shared__ float mix_tile[kMixRows * 64];
+    const int lane = threadIdx.x;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
+    const bool active = wm.active;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+
+    const DevOp& oo = a.ops[r.osc];
+    const DevOp& ov = a.ops[r.vcf];
+    const DevOp& oc = a.ops[r.vca];
+    const int plane = a.ops[r.out].aux;
+    const bool has_math = r.math >= 0, has_cut = r.trk_cutoff >= 0;
+    const uint32_t mflags = has_math ? a.ops[r.math].flags : 0u;
+    const float mconst = has_math ? parv(a.ops[r.math], MATH_P_CONST) : 0.0f;
+    const float* __restrict__ pitch_track = a.tracks + (size_t)r.trk_pitch * a.t_stride;
+    const float* __restrict__ cut_track = a.tracks + (size_t)(has_cut ? r.trk_cutoff : r.trk_env) * a.t_stride;
+    const float* __restrict__ env_track = a.tracks + (size_t)r.trk_env * a.t_stride;
+
+    constexpr uint32_t fo = OSC_HAS_CV | OSC_AA | kOscPort;
+    OscConst ko;
+    ko.sr = oo.sample_rate;
+    ko.val = (double)parv(oo, OSC_P_VAL);
+    ko.delta = 0.0;
+    ko.inv_dt = 0.0f;
+    const double hz_scale = 440.0 / ko.sr;
+    COsc co;
+    co.pos = make_f64(row(oo.state_row + OSC_S_POS_LO), row(oo.state_row + OSC_S_POS_HI));
+    co.delta = 0.0;
+    bool carried = false, have_pitch = false, have_cut = false;
+    uint32_t seen_pitch = 0u, seen_cut = 0u;
+    float cv_lane = 0.0f;
+
+    VcfRegs sv;
+    const int s0 = ov.state_row;
+    sv.f = __uint_as_float(row(s0 + VCF_S_F));
+    sv.p = __uint_as_float(row(s0 + VCF_S_P));
+    sv.q = __uint_as_float(row(s0 + VCF_S_Q));
+    sv.b0 = __uint_as_float(row(s0 + VCF_S_B0 + 0));
+    sv.b1 = __uint_as_float(row(s0 + VCF_S_B0 + 1));
+    sv.b2 = __uint_as_float(row(s0 + VCF_S_B0 + 2));
+    sv.b3 = __uint_as_float(row(s0 + VCF_S_B0 + 3));
+    sv.b4 = __uint_as_float(row(s0 + VCF_S_B0 + 4));
+    sv.freq = __uint_as_float(row(s0 + VCF_S_FREQ));
+    sv.res = __uint_as_float(row(s0 + VCF_S_RES));
+    const float vfreq = parv(ov, VCF_P_FREQ), vexp = parv(ov, VCF_P_EXP), vres = vcf_resonance(parv(ov, VCF_P_RES));
+    const uint32_t vport = ov.flags & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP);
+    if (!has_cut && a.T > 0) vcf_coeffs(sv, vcf_frequency(vfreq, 0.0f, vexp), vres);
+    const bool negative = parv(oc, VCA_P_NEG) != 0.0f;
+
+    Emit em = make_emit(a, plane, lane);
+    float* extra_row[4] = {nullptr, nullptr, nullptr, nullptr};   // frame rows of the track-fed planes (wave-uniform)
+    float* extra_mp[4] = {nullptr, nullptr, nullptr, nullptr};    // ... and their mix partials
+    const float* extra_track[4] = {env_track, env_track, env_track, env_track};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (e >= r.n_extra) continue;
+        extra_track[e] = a.tracks + (size_t)r.extra_trk[e] * a.t_stride;
+        if (a.frames) extra_row[e] = a.frames + (size_t)r.extra_plane[e] * a.plane_stride + wm.wave0;
+        if (a.mixpart) extra_mp[e] = a.mixpart + ((size_t)r.extra_plane[e] * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride;
+    }
+
+    const uint32_t l32 = (uint32_t)(lane & (kMixRows - 1));
+    auto fetch = [&](const float* trk, uint32_t t0) { return trk[min(t0 + l32, a.T - 1)]; };
+    float pitch_tile = fetch(pitch_track, 0), cut_tile = fetch(cut_track, 0), env_tile = fetch(env_track, 0);
+    float extra_tile[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) extra_tile[e] = fetch(extra_track[e], 0);
+    for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
+        const float pitch_next = fetch(pitch_track, t0 + kMixRows), cut_next = fetch(cut_track, t0 + kMixRows), env_next = fetch(env_track, t0 + kMixRows);
+        float extra_next[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) extra_next[e] = fetch(extra_track[e], t0 + kMixRows);
+        const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+        auto sample = [&](int i) {
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(pitch_tile), i);
+            if (!have_pitch || pb != seen_pitch) {  // a new note (scalar test): new increment, carried terms rebuilt
+                have_pitch = true;
+                seen_pitch = pb;
+                const float note = __uint_as_float(pb);
+                cv_lane = has_math ? math_step(mflags, note, 0.0f, mconst) : note;
+                const double delta = hz_scale * exp2_fast((double)cv_lane + ko.val);
+                carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
+                cosc_init(co, co.pos, delta);
+            }
+            float x;
+            if (carried) {
+                x = cosc_step<kOscPort>(co);
+            } else {  // an increment of a quarter cycle or more somewhere in the wave: the literal per-sample form
+                OscRegs g;
+                g.pos = co.pos;
+                g.sync_last = false;
+                g.seen_cv = cv_lane;
+                g.seen_delta = co.delta;
+                float sine = 0.0f, square = 0.0f, saw = 0.0f;
+                osc_step(fo, g, ko, cv_lane, 0.0f, sine, square, saw);
+                x = kOscPort == OSC_OUT_SINE ? sine : (kOscPort == OSC_OUT_SQUARE ? square : saw);
+                co.pos = g.pos;
+            }
+            if (has_cut) {
+                const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cut_tile), i);
+                if (!have_cut || cb != seen_cut) {
+                    have_cut = true;
+                    seen_cut = cb;
+                    vcf_coeffs(sv, vcf_frequency(vfreq, __uint_as_float(cb), vexp), vres);
+                }
+            }
+            float lp, bp, hp;
+            vcf_step<true>(sv, x, lp, bp, hp);
+            const float y = vport == VCF_OUT_LP ? lp : (vport == VCF_OUT_BP ? bp : hp);
+            const float env = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(env_tile), i));
+            const bool cv_pos = (uint32_t)(__float_as_int(env) - 1) < 0x7f800000u;  // env > 0.0 on the scalar unit
+            const float o = (negative || cv_pos) ? y * env : 0.0f;
+            emit_put<kOut>(em, mix_tile, o, i, V);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (e < r.n_extra && extra_row[e]) {
+                    const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(extra_tile[e]), i));
+                    __builtin_nontemporal_store(v, &extra_row[e][em.lane_c]);
+                    extra_row[e] += V;
+                }
+        };
+        if (n == kMixRows) {
+#pragma unroll 4
+            for (int i = 0; i < kMixRows; i++) sample(i);
+        } else {
+            for (int i = 0; i < n; i++) sample(i);
+        }
+        emit_flush<kOut>(em, mix_tile, t0, n);
+#pragma unroll
+        for (int e = 0; e < 4; e++)  // every voice carries the same sample: the wave's partial is count x sample
+            if (e < r.n_extra && extra_mp[e] && lane < n) extra_mp[e][t0 + lane] = (float)em.n_active * extra_tile[e];
+        pitch_tile = pitch_next;
+        cut_tile = cut_next;
+        env_tile = env_next;
+#pragma unroll
+        for (int e = 0; e < 4; e++) extra_tile[e] = extra_next[e];
+    }
+    if (active) {
+        auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+        put(oo.state_row + OSC_S_POS_LO, f64_lo(co.pos));
+        put(oo.state_row + OSC_S_POS_HI, f64_hi(co.pos));
+        put(oo.state_row + OSC_S_SYNC_LAST, 0u);  // sync unconnected: `last` follows the constant 0.0 input
+        put(s0 + VCF_S_F, __float_as_uint(sv.f));
+        put(s0 + VCF_S_P, __float_as_uint(sv.p));
+        put(s0 + VCF_S_Q, __float_as_uint(sv.q));
+        put(s0 + VCF_S_B0 + 0, __float_as_uint(sv.b0));
+        put(s0 + VCF_S_B0 + 1, __float_as_uint(sv.b1));
+        put(s0 + VCF_S_B0 + 2, __float_as_uint(sv.b2));
+        put(s0 + VCF_S_B0 + 3, __float_as_uint(sv.b3));
+        put(s0 + VCF_S_B0 + 4, __float_as_uint(sv.b4));
+        put(s0 + VCF_S_FREQ, __float_as_uint(sv.freq));
+        put(s0 + VCF_S_RES, __float_as_uint(sv.res));
+    }
+}
+
 // ---- fused 2-operator FM with a z^-1 feedback edge (patch P2's shape, buffer_size == 1) --------------------
 //   MATH_FB(in1 = OSC_M.sine delayed by one sample) -> OSC_M.cv ; OSC_M.sine -> MATH_IDX -> OSC_C.cv ; OSC_C.sine -> out
 // The broken edge is a one-sample delay, so the fed-back sine lives in a VGPR ("in-register recurrence").
@@ -1494,6 +1669,27 @@ static void launch_fused(uint32_t osc_port, uint32_t vcf_port, bool exact, int o
         launch_fused2<OSC_OUT_SINE>(vcf_port, exact, out_mode, track, ka, roles, co, grid, st);
 }
 
+template <uint32_t kPort>
+static void launch_seq2(int out_mode, const KernelArgs& ka, const SeqRoles& r, dim3 grid, hipStream_t st)
+{
+    if (out_mode == 3)
+        hipLaunchKernelGGL((render_voice_chain_seq<kPort, 3>), grid, dim3(64), 0, st, ka, r);
+    else if (out_mode == 1)
+        hipLaunchKernelGGL((render_voice_chain_seq<kPort, 1>), grid, dim3(64), 0, st, ka, r);
+    else
+        hipLaunchKernelGGL((render_voice_chain_seq<kPort, 0>), grid, dim3(64), 0, st, ka, r);
+}
+
+static void launch_seq(uint32_t osc_port, int out_mode, const KernelArgs& ka, const SeqRoles& r, dim3 grid, hipStream_t st)
+{
+    if (osc_port == OSC_OUT_SAW)
+        launch_seq2<OSC_OUT_SAW>(out_mode, ka, r, grid, st);
+    else if (osc_port == OSC_OUT_SQUARE)
+        launch_seq2<OSC_OUT_SQUARE>(out_mode, ka, r, grid, st);
+    else
+        launch_seq2<OSC_OUT_SINE>(out_mode, ka, r, grid, st);
+}
+
 static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_t st)
 {
     size_t lds = ((size_t)P.hdr.n_rows + 2 + (size_t)P.hdr.n_tracks + (size_t)P.hdr.n_slots * P.hdr.tile) * 256;  // + zero, trash and track rows
@@ -1709,6 +1905,30 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         d->kernel_name = "render_interp";
     }
 
+    const bool seq_chain = P.fused == FUSED_VOICE_CHAIN_SEQ;
+    SeqRoles seq{};
+    uint32_t seq_port = 0;
+    if (seq_chain) {
+        seq.math = seq.trk_cutoff = -1;
+        auto track_row = [&](int slot) { return P.hdr.track_id[slot - kTrackSlot]; };
+        for (int i = 0; i < (int)P.ops.size(); i++) {
+            const DevOp& op = P.ops[(size_t)i];
+            if (op.kind == OP_MATH) { seq.math = i; seq.trk_pitch = track_row(op.in_slot[0]); }
+            if (op.kind == OP_OSC) { seq.osc = i; seq_port = op.flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW); }
+            if (op.kind == OP_VCF) { seq.vcf = i; if (op.flags & VCF_HAS_CV) seq.trk_cutoff = track_row(op.in_slot[1]); }
+            if (op.kind == OP_VCA) { seq.vca = i; seq.trk_env = track_row(op.in_slot[1]); }
+            if (op.kind == OP_OUT) {
+                if (op.in_slot[0] >= kTrackSlot) {
+                    seq.extra_plane[seq.n_extra] = op.aux;
+                    seq.extra_trk[seq.n_extra++] = track_row(op.in_slot[0]);
+                } else {
+                    seq.out = i;
+                }
+            }
+        }
+        if (seq.math < 0) seq.trk_pitch = track_row(P.ops[(size_t)seq.osc].in_slot[0]);
+        d->kernel_name = "render_voice_chain_seq";
+    }
     const bool fm_pair = P.fused == FUSED_FM_PAIR;
     if (fm_pair) {  // op order fixed by the matcher: DELAY_RD, MATH_FB, OSC_M, DELAY_WR, MATH_IDX, OSC_C, OUT
         roles.adsr = 1;
@@ -1749,6 +1969,9 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         if (fused) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             launch_fused(osc_port, vcf_port, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, track, ka, roles, co, dim3(n_waves + ka.block0), st);
+        } else if (seq_chain) {
+            const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
+            launch_seq(seq_port, out_mode, ka, seq, dim3(n_waves), st);
         } else if (fm_pair) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             if (flags & SRACK_RENDER_EXACT_OSC)

@@ -449,6 +449,29 @@ def test_p3_sequencers_vs_oracle(S, oracle, flags):
     assert (steps == steps[0]).all() and 0 <= steps[0] < 8
 
 
+@pytest.mark.parametrize("flags", [pytest.param(0, id="fused"), pytest.param(2, id="interp")])
+def test_p3_extreme_transpose_takes_the_literal_oscillator(S, oracle, flags):
+    """Notes whose phase increment reaches a quarter cycle (>= 12 kHz at 48 kHz) leave the carried-phase form: lanes on both
+    sides of that limit share waves here, and the filter has no CV (the second shape of the fused chain)."""
+    V, T = 100, 6000
+    transpose = np.linspace(3.0, 5.6, V).astype(np.float32)
+    def build(g):
+        ids = S.build_p3(g)
+        g.disconnect(ids["vcf"], 1)
+        return ids
+    o = oracle.OraclePatch(48000, 1024, 2)
+    ids = build(o)
+    ref, _ = o.render_batch(V, T, [(ids["transpose"], S.MATH_CONSTANT, transpose)], threads=8)
+    p = S.Patch(48000, 1024, 2)
+    build(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, transpose)
+    fr, _ = p.render(T, flags=flags)
+    assert ("fused=5" in p.info()) == (flags == 0)
+    assert_close(fr[0], ref[0])
+    np.testing.assert_array_equal(fr[1], ref[1])
+
+
 def test_p3_per_voice_clocks(S, oracle):
     """Per-voice clock rates: the sequencers step at different times in different lanes."""
     V, T = 96, 9000

@@ -230,6 +230,7 @@ def test_sequencer_graph_api(S):
     # ... as five pipelined units (clock, grid, pattern, two envelopes); 4 tracks reach the voice program, 4 more carry
     # wires between units
     assert info.count("ctl[ops=") == 5 and "tracks=8" in info, info
+    assert "fused=5" in info.split(" + ")[0]     # [transpose] -> VCO -> VCF(cv) -> VCA + a raw gate channel: the fused sequencer-driven chain
 
 
 def test_sample_and_nonlinear_graph_api(S):
