@@ -567,7 +567,8 @@ int Builder::build()
         if (const char* e = getenv("SRACK_TILE_MAX")) tile_max = atoi(e);  // tuning knob (tools/)
         if (!rings.empty()) tile_max = std::min(tile_max, B);              // a tile may not span more than one ring period
         int tile = 0;
-        if (is_ctl) {  // one wave: residency is irrelevant, long tiles are not
+        if (is_ctl) {  // one wave: residency is irrelevant, long tiles are not (a row holds 64 samples of a track: the cap)
+            if (!getenv("SRACK_TILE_MAX")) tile_max = rings.empty() ? 64 : std::min(64, B);
             int budget = 56 * 1024;
             if (const char* e = getenv("SRACK_LDS_BUDGET")) budget = atoi(e);
             for (tile = std::max(tile_max, 1); tile > 1 && lds_bytes(tile) > budget; tile >>= 1) {}
