@@ -423,7 +423,8 @@ def test_render_without_outputs_still_advances_state(S):
 
 
 # ---- scope table (f) rank 1: sequencer-driven patch ---------------------------------------------------------------
-@pytest.mark.parametrize("flags", [pytest.param(0, id="hoist"), pytest.param(4, id="nohoist"), pytest.param(1, id="exact")])
+@pytest.mark.parametrize("flags", [pytest.param(0, id="hoist"), pytest.param(4, id="nohoist"), pytest.param(1, id="exact"), pytest.param(2, id="hoist-interp"),
+                                   pytest.param(8, id="hoist-one-control-unit"), pytest.param(10, id="hoist-interp-one-control-unit")])
 def test_p3_sequencers_vs_oracle(S, oracle, flags):
     V, T = 150, 12000
     transpose = np.linspace(-2.0, 0.5, V).astype(np.float32)
@@ -439,6 +440,9 @@ def test_p3_sequencers_vs_oracle(S, oracle, flags):
     assert p.planes() == (2, [0, 1])
     fr, mix = p.render(T, flags=flags)
     assert ("ctl[" in p.info()) == (not flags & 4)
+    if not flags & 4:  # five pipelined control units, or one when staging is off
+        assert p.info().count("ctl[") == (1 if flags & 8 else 5)
+        assert ("fused=5" in p.info()) == (not flags & 3)
     assert_close(fr[0], ref[0])
     np.testing.assert_array_equal(fr[1], ref[1])  # a raw pattern gate: exactly 0.0 / 1.0 / the clock's square
     scale = np.abs(ref.astype(np.float64)).sum(axis=2)
