@@ -1,0 +1,750 @@
+// fused.hip.h — the fused kernels: whole patch shapes with every wire and all state in VGPRs (no LDS except the
+// mix-down transpose tile), and the passes that sum the per-wave mix partials.
+//   render_voice_chain        patch P1 with every module per voice
+//   render_voice_chain_track  P1 after uniform hoisting (the flagship kernel), with the co-scheduled control block
+//   render_ctl_gate_env       P1's control program: OSC -> ADSR -> track
+//   render_voice_chain_seq    patch P3's shape: sequencer-driven subtractive voice
+//   render_fm_pair            patch P2 at buffer_size 1: two-operator FM with a z^-1 feedback edge
+//   mix_reduce_groups/final   deterministic sum of the per-wave partials (no atomics)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "interp.hip.h"
+
+namespace srack {
+
+constexpr int kMixRows = 32;
+
+// ---- per-sample output of the fused kernels ---------------------------------------------------------------
+// kOut: 0 = decide at run time (exact-mode kernels), 1 = frames only, 2 = mix only, 3 = frames + mix.
+// Frames: SGPR row base advanced by V per sample + a constant per-lane offset; lanes past V (only in the
+// last wave) shadow voice V-1, compute the identical sample and store it to the identical address, so the
+// store needs no exec mask.  Mix: the sample goes into a 32-row LDS tile; every 32 samples (and at the end)
+// the rows are summed over the 64 lanes (tile_row_sum) and one lane per row writes the wave's partial.
+struct Emit {
+    float* frame_row;   // wave-uniform
+    float* mp;          // wave-uniform: mixpart row of this wave
+    bool has_frames, has_mix, full_wave;
+    int lane, lane_c;
+    uint32_t n_active;  // lanes of this wave that are real voices
+};
+
+template <int kOut>
+SRK_DEV void emit_put(Emit& e, float* mix_tile, float o, int i, uint32_t V)  // i = row of the current 32-sample tile
+{
+    const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
+    const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
+    if (frames) {
+        __builtin_nontemporal_store(o, &e.frame_row[e.lane_c]);  // write-once stream: keep it out of the L2's way
+        e.frame_row += V;
+    }
+    if (mix) mix_tile[i * 64 + e.lane] = o;
+}
+
+template <int kOut>
+SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n)  // the tile holds samples t0 .. t0+n-1
+{
+    using dev::tile_row_sum;
+    const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
+    if (!mix) return;
+    if (!e.full_wave && (uint32_t)e.lane >= e.n_active)  // shadow lanes contribute nothing to the mix
+        for (int r = 0; r < kMixRows; r++) mix_tile[r * 64 + e.lane] = 0.0f;
+    __syncthreads();
+    const float sum = tile_row_sum(mix_tile, kMixRows, e.lane);
+    if (e.lane < n) e.mp[t0 + e.lane] = sum;
+    __syncthreads();
+}
+
+SRK_DEV Emit make_emit(const KernelArgs& a, int plane, int lane)
+{
+    using dev::WaveMap;
+    using dev::wave_map;
+    Emit e;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t wave0 = wm.wave0;
+    e.n_active = wm.n_active;
+    e.full_wave = e.n_active == 64u;
+    e.lane = lane;
+    e.lane_c = min(lane, (int)e.n_active - 1);
+    e.frame_row = a.frames ? a.frames + (size_t)plane * a.plane_stride + wave0 : nullptr;
+    e.mp = a.mixpart ? a.mixpart + ((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride : nullptr;
+    e.has_frames = e.frame_row != nullptr;
+    e.has_mix = e.mp != nullptr;
+    return e;
+}
+
+// ---- fused control chain: OSC (constant pitch) -> ADSR -> track ---------------------------------------------
+// The voice-invariant half of patch P1's shape: one voice, one wave, every lane computes the same numbers.
+// It is a pure latency chain (phase accumulate -> gate -> envelope state machine), so it is kept short: state
+// in VGPRs, the carried-phase oscillator and the segmented ADSR, 64 samples gathered across lanes per store.
+// What the control block needs: a slice of KernelArgs small enough to ride along with a voice kernel's arguments.
+struct CtlWork {
+    const DevOp* ops;
+    uint32_t* table;   // the control program's one-voice table
+    float* track;      // this chunk's first sample of the envelope track
+    uint32_t T;        // samples to produce (0: nothing to do)
+    uint32_t port;     // OSC_OUT_* of the gate oscillator
+};
+
+template <uint32_t kOscPort>
+SRK_DEV void ctl_gate_env_body(const CtlWork& a)
+{
+    using namespace dev;
+    const ChainRoles r{0, 0, 0, 1, 0, 2, 0};  // op order of the matched control program: OSC, ADSR, OUT
+    const int lane = threadIdx.x;
+    auto row = [&](int rr) { return a.table[rr]; };  // V == 1
+    const DevOp& ol = a.ops[r.osc_l];
+    const DevOp& od = a.ops[r.adsr];
+    float* __restrict__ track = a.track;
+
+    COsc cl;
+    cosc_init(cl, make_f64(row(ol.state_row + OSC_S_POS_LO), row(ol.state_row + OSC_S_POS_HI)), ol.delta);
+    AdsrRegs sd;
+    sd.phase = __uint_as_float(row(od.state_row + ADSR_S_PHASE));
+    sd.mode = (int)row(od.state_row + ADSR_S_MODE);
+    sd.r_val = __uint_as_float(row(od.state_row + ADSR_S_R_VAL));
+    sd.from_a_val = __uint_as_float(row(od.state_row + ADSR_S_FROM_A));
+    sd.gate_last = row(od.state_row + ADSR_S_GATE_LAST) != 0;
+    const AdsrConst kd = adsr_consts(od.par_val[ADSR_P_A], od.par_val[ADSR_P_D], od.par_val[ADSR_P_S], od.par_val[ADSR_P_R], od.par_val[ADSR_P_SR]);
+    AdsrSeg seg;
+    adsr_seg_enter(sd, kd, seg);
+
+    // Four samples at a time on the assumption that nothing happens in them: the square stays outside its PolyBLEP
+    // windows (so it is exactly -1/+1) and the envelope stays in its segment.  One scalar test per group instead
+    // of two per sample; when the assumption fails the group is redone one sample at a time (cosc / adsr_seg).
+    float out[4];
+    auto try_group = [&]() -> bool {
+        double pos = cl.pos;
+        float ph = sd.phase;
+        uint64_t last = seg.last, bad = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int hw = __double2hiint(pos);
+            bad |= __builtin_amdgcn_ballot_w64(hw <= cl.hA) | __builtin_amdgcn_ballot_w64(hw >= cl.hB) |
+                   __builtin_amdgcn_ballot_w64((uint32_t)(hw - cl.hQ0) <= cl.hQspan);
+            const uint64_t high = __builtin_amdgcn_ballot_w64(hw >= 0x3fe00000);  // square = +1 > 0  <=>  pos >= 0.5
+            pos = __builtin_amdgcn_fract(pos + cl.delta);
+            ph = ph + seg.inc;
+            bad |= __builtin_amdgcn_ballot_w64(ph >= 1.0f) | (high & seg.on_high) | (~high & seg.on_low) | (high & ~last & seg.on_edge);
+            last = high;
+            out[q] = seg.c0 + seg.c1 * (seg.k0 + seg.k1 * ph);
+        }
+        if (bad != 0) return false;
+        cl.pos = pos;
+        sd.phase = ph;
+        seg.last = last;
+        seg.held = out[3];
+        return true;
+    };
+
+    for (uint32_t t0 = 0; t0 < a.T; t0 += 64) {
+        const int n = (int)min(64u, a.T - t0);
+        float keep_v = 0.0f;  // lane j keeps sample t0 + j
+        int j = 0;
+        while (j < n) {
+            if (kOscPort == OSC_OUT_SQUARE && j + 4 <= n && try_group()) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) keep_v = lane == j + q ? out[q] : keep_v;
+                j += 4;
+                continue;
+            }
+            const int stop = min(n, j + 4);
+            for (; j < stop; j++) {
+                const float gate = cosc_step<kOscPort>(cl);
+                const float env = adsr_seg_step(sd, kd, seg, gate);
+                keep_v = lane == j ? env : keep_v;
+            }
+        }
+        if (lane < n) track[t0 + lane] = keep_v;
+    }
+    adsr_seg_flush(sd, seg);
+    if (lane == 0) {
+        a.table[ol.state_row + OSC_S_POS_LO] = f64_lo(cl.pos);
+        a.table[ol.state_row + OSC_S_POS_HI] = f64_hi(cl.pos);
+        a.table[ol.state_row + OSC_S_SYNC_LAST] = 0u;
+        a.table[od.state_row + ADSR_S_PHASE] = __float_as_uint(sd.phase);
+        a.table[od.state_row + ADSR_S_MODE] = (uint32_t)sd.mode;
+        a.table[od.state_row + ADSR_S_R_VAL] = __float_as_uint(sd.r_val);
+        a.table[od.state_row + ADSR_S_FROM_A] = __float_as_uint(sd.from_a_val);
+        a.table[od.state_row + ADSR_S_GATE_LAST] = sd.gate_last ? 1u : 0u;
+    }
+}
+
+
+SRK_DEV void ctl_gate_env(const CtlWork& w)
+{
+    if (w.port == OSC_OUT_SQUARE)
+        ctl_gate_env_body<OSC_OUT_SQUARE>(w);
+    else if (w.port == OSC_OUT_SAW)
+        ctl_gate_env_body<OSC_OUT_SAW>(w);
+    else
+        ctl_gate_env_body<OSC_OUT_SINE>(w);
+}
+
+__global__ __launch_bounds__(64) void render_ctl_gate_env(CtlWork w) { ctl_gate_env(w); }
+
+// ---- fused voice chain (patch P1's shape) -------------------------------------------------------------
+// OSC_A.<port> -> VCF.<port> -> VCA <- ADSR <- OSC_L.<port>; all wires and all state in VGPRs.
+
+template <uint32_t kOscAPort, uint32_t kOscLPort, uint32_t kVcfPort, bool kExact, int kOut>
+__global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRoles r)
+{
+    using namespace dev;
+    __shared__ float mix_tile[kMixRows * 64];
+    const int lane = threadIdx.x;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
+    const bool active = wm.active;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+
+    const DevOp& oa = a.ops[r.osc_a];
+    const DevOp& ol = a.ops[r.osc_l];
+    const DevOp& ov = a.ops[r.vcf];
+    const DevOp& od = a.ops[r.adsr];
+    const DevOp& oc = a.ops[r.vca];
+    const int plane = a.ops[r.out].aux;
+
+    constexpr uint32_t kEx = kExact ? OSC_EXACT : 0u;
+    constexpr uint32_t fa = OSC_AA | kOscAPort | kEx;
+    constexpr uint32_t fl = OSC_AA | kOscLPort | kEx;
+
+    OscRegs sa, sl;
+    OscConst ka, kl;
+    sa.pos = make_f64(row(oa.state_row + OSC_S_POS_LO), row(oa.state_row + OSC_S_POS_HI));
+    sa.sync_last = row(oa.state_row + OSC_S_SYNC_LAST) != 0;
+    sl.pos = make_f64(row(ol.state_row + OSC_S_POS_LO), row(ol.state_row + OSC_S_POS_HI));
+    sl.sync_last = row(ol.state_row + OSC_S_SYNC_LAST) != 0;
+    ka.sr = oa.sample_rate;
+    ka.val = 0.0;
+    ka.delta = oa.delta_row >= 0 ? make_f64(row(oa.delta_row), row(oa.delta_row + 1)) : oa.delta;
+    ka.inv_dt = 1.0f / (float)ka.delta;
+    kl.sr = ol.sample_rate;
+    kl.val = 0.0;
+    kl.delta = ol.delta_row >= 0 ? make_f64(row(ol.delta_row), row(ol.delta_row + 1)) : ol.delta;
+    kl.inv_dt = 1.0f / (float)kl.delta;
+
+    VcfRegs sv;
+    {
+        const int s0 = ov.state_row;
+        sv.f = __uint_as_float(row(s0 + VCF_S_F));
+        sv.p = __uint_as_float(row(s0 + VCF_S_P));
+        sv.q = __uint_as_float(row(s0 + VCF_S_Q));
+        sv.b0 = __uint_as_float(row(s0 + VCF_S_B0 + 0));
+        sv.b1 = __uint_as_float(row(s0 + VCF_S_B0 + 1));
+        sv.b2 = __uint_as_float(row(s0 + VCF_S_B0 + 2));
+        sv.b3 = __uint_as_float(row(s0 + VCF_S_B0 + 3));
+        sv.b4 = __uint_as_float(row(s0 + VCF_S_B0 + 4));
+        sv.freq = __uint_as_float(row(s0 + VCF_S_FREQ));
+        sv.res = __uint_as_float(row(s0 + VCF_S_RES));
+    }
+    if (a.T > 0) vcf_coeffs(sv, vcf_frequency(parv(ov, VCF_P_FREQ), 0.0f, parv(ov, VCF_P_EXP)), vcf_resonance(parv(ov, VCF_P_RES)));
+
+    AdsrRegs sd;
+    sd.phase = __uint_as_float(row(od.state_row + ADSR_S_PHASE));
+    sd.mode = (int)row(od.state_row + ADSR_S_MODE);
+    sd.r_val = __uint_as_float(row(od.state_row + ADSR_S_R_VAL));
+    sd.from_a_val = __uint_as_float(row(od.state_row + ADSR_S_FROM_A));
+    sd.gate_last = row(od.state_row + ADSR_S_GATE_LAST) != 0;
+    const AdsrConst kd = adsr_consts(parv(od, ADSR_P_A), parv(od, ADSR_P_D), parv(od, ADSR_P_S), parv(od, ADSR_P_R), parv(od, ADSR_P_SR));
+    const bool negative = parv(oc, VCA_P_NEG) != 0.0f;
+
+    Emit em = make_emit(a, plane, lane);
+
+    COsc ca, cl;
+    AdsrSeg seg;
+    float x = 0.0f, gate = 0.0f;
+    double pos_a = sa.pos, pos_l = sl.pos;  // oscillator phases after exactly t samples (the loop runs one sample ahead)
+    if (!kExact) {
+        cosc_init(ca, sa.pos, ka.delta);
+        cosc_init(cl, sl.pos, kl.delta);
+        adsr_seg_enter(sd, kd, seg);
+        if (a.T > 0) {  // software pipeline: the oscillators of sample t+1 are evaluated beside the filter of sample t
+            x = cosc_step<kOscAPort>(ca);
+            gate = cosc_step<kOscLPort>(cl);
+        }
+    }
+
+    for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
+        const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+        for (int i = 0; i < n; i++) {
+            float env, x_next = 0.0f, gate_next = 0.0f;
+            if (kExact) {
+                float sine = 0.0f, square = 0.0f, saw = 0.0f;
+                osc_step(fa, sa, ka, 0.0f, 0.0f, sine, square, saw);
+                x = kOscAPort == OSC_OUT_SINE ? sine : (kOscAPort == OSC_OUT_SQUARE ? square : saw);
+                float gs = 0.0f, gq = 0.0f, gw = 0.0f;
+                osc_step(fl, sl, kl, 0.0f, 0.0f, gs, gq, gw);
+                gate = kOscLPort == OSC_OUT_SINE ? gs : (kOscLPort == OSC_OUT_SQUARE ? gq : gw);
+            }
+            float lp, bp, hp;
+            vcf_step<!kExact>(sv, x, lp, bp, hp);
+            const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
+            if (!kExact) {  // next sample's oscillators: same basic block as the filter chain above => they interleave
+                pos_a = ca.pos;
+                pos_l = cl.pos;
+                x_next = cosc_step<kOscAPort>(ca);
+                gate_next = cosc_step<kOscLPort>(cl);
+            }
+            if (kExact)
+                env = adsr_step(ADSR_HAS_GATE, sd, kd, gate);
+            else
+                env = adsr_seg_step(sd, kd, seg, gate);
+            const float o = vca_step(VCA_HAS_AUDIO | VCA_HAS_CV, negative, y, env);
+            emit_put<kOut>(em, mix_tile, o, i, V);
+            if (!kExact) {
+                x = x_next;
+                gate = gate_next;
+            }
+        }
+        emit_flush<kOut>(em, mix_tile, t0, n);
+    }
+    if (!kExact) {
+        sa.pos = pos_a;
+        sl.pos = pos_l;
+        sa.sync_last = sl.sync_last = false;  // sync unconnected: `last` follows the constant 0.0 input
+        adsr_seg_flush(sd, seg);
+    }
+
+    if (active) {
+        auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+        put(oa.state_row + OSC_S_POS_LO, f64_lo(sa.pos));
+        put(oa.state_row + OSC_S_POS_HI, f64_hi(sa.pos));
+        put(oa.state_row + OSC_S_SYNC_LAST, sa.sync_last ? 1u : 0u);
+        put(ol.state_row + OSC_S_POS_LO, f64_lo(sl.pos));
+        put(ol.state_row + OSC_S_POS_HI, f64_hi(sl.pos));
+        put(ol.state_row + OSC_S_SYNC_LAST, sl.sync_last ? 1u : 0u);
+        const int s0 = ov.state_row;
+        put(s0 + VCF_S_F, __float_as_uint(sv.f));
+        put(s0 + VCF_S_P, __float_as_uint(sv.p));
+        put(s0 + VCF_S_Q, __float_as_uint(sv.q));
+        put(s0 + VCF_S_B0 + 0, __float_as_uint(sv.b0));
+        put(s0 + VCF_S_B0 + 1, __float_as_uint(sv.b1));
+        put(s0 + VCF_S_B0 + 2, __float_as_uint(sv.b2));
+        put(s0 + VCF_S_B0 + 3, __float_as_uint(sv.b3));
+        put(s0 + VCF_S_B0 + 4, __float_as_uint(sv.b4));
+        put(s0 + VCF_S_FREQ, __float_as_uint(sv.freq));
+        put(s0 + VCF_S_RES, __float_as_uint(sv.res));
+        put(od.state_row + ADSR_S_PHASE, __float_as_uint(sd.phase));
+        put(od.state_row + ADSR_S_MODE, (uint32_t)sd.mode);
+        put(od.state_row + ADSR_S_R_VAL, __float_as_uint(sd.r_val));
+        put(od.state_row + ADSR_S_FROM_A, __float_as_uint(sd.from_a_val));
+        put(od.state_row + ADSR_S_GATE_LAST, sd.gate_last ? 1u : 0u);
+    }
+}
+
+// ---- fused voice chain, envelope from a control track (P1 after uniform hoisting) ---------------------
+// OSC_A.<port> -> VCF.<port> -> VCA <- track[t]; the track sample is wave-uniform (scalar load, SGPR operand).
+// The loop body is one basic block: the filter chain of sample t interleaves with the oscillator of t+1.
+template <uint32_t kOscAPort, uint32_t kVcfPort, bool kExact, int kOut>
+__global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, ChainRoles r, CtlWork co)
+{
+    using namespace dev;
+    __shared__ float mix_tile[kMixRows * 64];
+    // Block 0 of a co-scheduled launch is not a voice wave: it computes the NEXT chunk's envelope track while the
+    // voice blocks consume this chunk's (written by the previous launch).  Same stream, no events, no second queue.
+    if (blockIdx.x < a.block0) {
+        // a latency chain sharing its SIMD with four throughput-bound voice waves: without priority it gets a
+        // fifth of the issue slots and can outlast the voice blocks (measured: 1.9 -> 2.6 ms per launch)
+        __builtin_amdgcn_s_setprio(3);
+        ctl_gate_env(co);
+        return;
+    }
+    const int lane = threadIdx.x;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
+    const bool active = wm.active;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+
+    const DevOp& oa = a.ops[r.osc_a];
+    const DevOp& ov = a.ops[r.vcf];
+    const DevOp& oc = a.ops[r.vca];
+    const int plane = a.ops[r.out].aux;
+    const float* __restrict__ env_track = a.tracks + (size_t)r.track * a.t_stride;
+
+    constexpr uint32_t fa = OSC_AA | kOscAPort | (kExact ? OSC_EXACT : 0u);
+    OscRegs sa;
+    OscConst ka;
+    sa.pos = make_f64(row(oa.state_row + OSC_S_POS_LO), row(oa.state_row + OSC_S_POS_HI));
+    sa.sync_last = row(oa.state_row + OSC_S_SYNC_LAST) != 0;
+    ka.sr = oa.sample_rate;
+    ka.val = 0.0;
+    ka.delta = oa.delta_row >= 0 ? make_f64(row(oa.delta_row), row(oa.delta_row + 1)) : oa.delta;
+    ka.inv_dt = 1.0f / (float)ka.delta;
+
+    VcfRegs sv;
+    const int s0 = ov.state_row;
+    sv.f = __uint_as_float(row(s0 + VCF_S_F));
+    sv.p = __uint_as_float(row(s0 + VCF_S_P));
+    sv.q = __uint_as_float(row(s0 + VCF_S_Q));
+    sv.b0 = __uint_as_float(row(s0 + VCF_S_B0 + 0));
+    sv.b1 = __uint_as_float(row(s0 + VCF_S_B0 + 1));
+    sv.b2 = __uint_as_float(row(s0 + VCF_S_B0 + 2));
+    sv.b3 = __uint_as_float(row(s0 + VCF_S_B0 + 3));
+    sv.b4 = __uint_as_float(row(s0 + VCF_S_B0 + 4));
+    sv.freq = __uint_as_float(row(s0 + VCF_S_FREQ));
+    sv.res = __uint_as_float(row(s0 + VCF_S_RES));
+    if (a.T > 0) vcf_coeffs(sv, vcf_frequency(parv(ov, VCF_P_FREQ), 0.0f, parv(ov, VCF_P_EXP)), vcf_resonance(parv(ov, VCF_P_RES)));
+    const bool negative = parv(oc, VCA_P_NEG) != 0.0f;
+
+    Emit em = make_emit(a, plane, lane);
+
+    COsc ca;
+    float x = 0.0f;
+    double pos_a = sa.pos;
+    if (!kExact) {
+        cosc_init(ca, sa.pos, ka.delta);
+        if (a.T > 0) x = cosc_step<kOscAPort>(ca);
+    }
+    // The envelope track is wave-uniform.  Lane l prefetches sample t0 + l of the NEXT 64-sample tile with one
+    // coalesced load while the current tile is consumed through v_readlane (SGPR operand): no per-sample memory wait.
+    float env_tile = env_track[min((uint32_t)(lane & (kMixRows - 1)), a.T - 1)];
+    for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
+        const float env_next = env_track[min(t0 + kMixRows + (uint32_t)(lane & (kMixRows - 1)), a.T - 1)];
+        const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+        auto sample = [&](int i) {
+            const float env = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(env_tile), i));
+            if (kExact) {
+                float sine = 0.0f, square = 0.0f, saw = 0.0f;
+                osc_step(fa, sa, ka, 0.0f, 0.0f, sine, square, saw);
+                x = kOscAPort == OSC_OUT_SINE ? sine : (kOscAPort == OSC_OUT_SQUARE ? square : saw);
+            }
+            float lp, bp, hp;
+            vcf_step<!kExact>(sv, x, lp, bp, hp);
+            const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
+            if (!kExact) {
+                pos_a = ca.pos;
+                x = cosc_step<kOscAPort>(ca);  // sample t+1
+            }
+            // vca.rs:132: (negative || cv > 0.0) ? audio * cv : 0.0 — cv is wave-uniform here, so `cv > 0.0` is decided
+            // on the scalar unit from the bit pattern: positive, non-zero, not NaN  <=>  0 < bits <= 0x7f800000
+            const bool cv_pos = (uint32_t)(__float_as_int(env) - 1) < 0x7f800000u;
+            const float o = (negative || cv_pos) ? y * env : 0.0f;
+            emit_put<kOut>(em, mix_tile, o, i, V);
+        };
+        if (n == kMixRows) {  // constant trip count: unrollable (readlane is convergent, so a runtime count is not)
+#pragma unroll 8
+            for (int i = 0; i < kMixRows; i++) sample(i);
+        } else {
+            for (int i = 0; i < n; i++) sample(i);
+        }
+        emit_flush<kOut>(em, mix_tile, t0, n);
+        env_tile = env_next;
+    }
+    if (!kExact) {
+        sa.pos = pos_a;
+        sa.sync_last = false;
+    }
+    if (active) {
+        auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+        put(oa.state_row + OSC_S_POS_LO, f64_lo(sa.pos));
+        put(oa.state_row + OSC_S_POS_HI, f64_hi(sa.pos));
+        put(oa.state_row + OSC_S_SYNC_LAST, sa.sync_last ? 1u : 0u);
+        put(s0 + VCF_S_F, __float_as_uint(sv.f));
+        put(s0 + VCF_S_P, __float_as_uint(sv.p));
+        put(s0 + VCF_S_Q, __float_as_uint(sv.q));
+        put(s0 + VCF_S_B0 + 0, __float_as_uint(sv.b0));
+        put(s0 + VCF_S_B0 + 1, __float_as_uint(sv.b1));
+        put(s0 + VCF_S_B0 + 2, __float_as_uint(sv.b2));
+        put(s0 + VCF_S_B0 + 3, __float_as_uint(sv.b3));
+        put(s0 + VCF_S_B0 + 4, __float_as_uint(sv.b4));
+        put(s0 + VCF_S_FREQ, __float_as_uint(sv.freq));
+        put(s0 + VCF_S_RES, __float_as_uint(sv.res));
+    }
+}
+
+// ---- fused sequencer-driven voice chain (patch P3's shape after hoisting) ------------------------------------------
+//   [MATH(note track, k)] -> OSC.cv ; OSC -> VCF (cutoff CV = envelope track) -> VCA (CV = envelope track) -> OUT,
+//   plus output channels that carry a track unchanged (a raw gate).  The three tracks are wave-uniform: each is
+//   prefetched one 32-sample tile ahead (lane l holds sample l) and read per sample with v_readlane, so "did the note /
+//   the cutoff CV change" is a scalar compare.  Between note changes the oscillator is the carried-phase one; at a
+//   change every lane recomputes its increment 440 / sr * 2^(cv + val) and rebuilds the carried terms from the exact f64
+//   phase (as tile_osc's stepwise path).  The filter coefficients are recomputed only when the cutoff CV's bits changed
+//   (vcf_coeffs re-checks per lane, as filter.rs:61 does).
+template <uint32_t kOscPort, int kOut>
+__global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRoles r)
+{
+    using namespace dev;
+    __shared__ float mix_tile[kMixRows * 64];
+    const int lane = threadIdx.x;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
+    const bool active = wm.active;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+
+    const DevOp& oo = a.ops[r.osc];
+    const DevOp& ov = a.ops[r.vcf];
+    const DevOp& oc = a.ops[r.vca];
+    const int plane = a.ops[r.out].aux;
+    const bool has_math = r.math >= 0, has_cut = r.trk_cutoff >= 0;
+    const uint32_t mflags = has_math ? a.ops[r.math].flags : 0u;
+    const float mconst = has_math ? parv(a.ops[r.math], MATH_P_CONST) : 0.0f;
+    const float* __restrict__ pitch_track = a.tracks + (size_t)r.trk_pitch * a.t_stride;
+    const float* __restrict__ cut_track = a.tracks + (size_t)(has_cut ? r.trk_cutoff : r.trk_env) * a.t_stride;
+    const float* __restrict__ env_track = a.tracks + (size_t)r.trk_env * a.t_stride;
+
+    constexpr uint32_t fo = OSC_HAS_CV | OSC_AA | kOscPort;
+    OscConst ko;
+    ko.sr = oo.sample_rate;
+    ko.val = (double)parv(oo, OSC_P_VAL);
+    ko.delta = 0.0;
+    ko.inv_dt = 0.0f;
+    const double hz_scale = 440.0 / ko.sr;
+    COsc co;
+    co.pos = make_f64(row(oo.state_row + OSC_S_POS_LO), row(oo.state_row + OSC_S_POS_HI));
+    co.delta = 0.0;
+    bool carried = false, have_pitch = false, have_cut = false;
+    uint32_t seen_pitch = 0u, seen_cut = 0u;
+    float cv_lane = 0.0f;
+
+    VcfRegs sv;
+    const int s0 = ov.state_row;
+    sv.f = __uint_as_float(row(s0 + VCF_S_F));
+    sv.p = __uint_as_float(row(s0 + VCF_S_P));
+    sv.q = __uint_as_float(row(s0 + VCF_S_Q));
+    sv.b0 = __uint_as_float(row(s0 + VCF_S_B0 + 0));
+    sv.b1 = __uint_as_float(row(s0 + VCF_S_B0 + 1));
+    sv.b2 = __uint_as_float(row(s0 + VCF_S_B0 + 2));
+    sv.b3 = __uint_as_float(row(s0 + VCF_S_B0 + 3));
+    sv.b4 = __uint_as_float(row(s0 + VCF_S_B0 + 4));
+    sv.freq = __uint_as_float(row(s0 + VCF_S_FREQ));
+    sv.res = __uint_as_float(row(s0 + VCF_S_RES));
+    const float vfreq = parv(ov, VCF_P_FREQ), vexp = parv(ov, VCF_P_EXP), vres = vcf_resonance(parv(ov, VCF_P_RES));
+    const uint32_t vport = ov.flags & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP);
+    if (!has_cut && a.T > 0) vcf_coeffs(sv, vcf_frequency(vfreq, 0.0f, vexp), vres);
+    const bool negative = parv(oc, VCA_P_NEG) != 0.0f;
+
+    Emit em = make_emit(a, plane, lane);
+    float* extra_row[4] = {nullptr, nullptr, nullptr, nullptr};   // frame rows of the track-fed planes (wave-uniform)
+    float* extra_mp[4] = {nullptr, nullptr, nullptr, nullptr};    // ... and their mix partials
+    const float* extra_track[4] = {env_track, env_track, env_track, env_track};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (e >= r.n_extra) continue;
+        extra_track[e] = a.tracks + (size_t)r.extra_trk[e] * a.t_stride;
+        if (a.frames) extra_row[e] = a.frames + (size_t)r.extra_plane[e] * a.plane_stride + wm.wave0;
+        if (a.mixpart) extra_mp[e] = a.mixpart + ((size_t)r.extra_plane[e] * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride;
+    }
+
+    const uint32_t l32 = (uint32_t)(lane & (kMixRows - 1));
+    auto fetch = [&](const float* trk, uint32_t t0) { return trk[min(t0 + l32, a.T - 1)]; };
+    float pitch_tile = fetch(pitch_track, 0), cut_tile = fetch(cut_track, 0), env_tile = fetch(env_track, 0);
+    float extra_tile[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) extra_tile[e] = fetch(extra_track[e], 0);
+    for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
+        const float pitch_next = fetch(pitch_track, t0 + kMixRows), cut_next = fetch(cut_track, t0 + kMixRows), env_next = fetch(env_track, t0 + kMixRows);
+        float extra_next[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) extra_next[e] = fetch(extra_track[e], t0 + kMixRows);
+        const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+        auto sample = [&](int i) {
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(pitch_tile), i);
+            if (!have_pitch || pb != seen_pitch) {  // a new note (scalar test): new increment, carried terms rebuilt
+                have_pitch = true;
+                seen_pitch = pb;
+                const float note = __uint_as_float(pb);
+                cv_lane = has_math ? math_step(mflags, note, 0.0f, mconst) : note;
+                const double delta = hz_scale * exp2_fast((double)cv_lane + ko.val);
+                carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
+                cosc_init(co, co.pos, delta);
+            }
+            float x;
+            if (carried) {
+                x = cosc_step<kOscPort>(co);
+            } else {  // an increment of a quarter cycle or more somewhere in the wave: the literal per-sample form
+                OscRegs g;
+                g.pos = co.pos;
+                g.sync_last = false;
+                g.seen_cv = cv_lane;
+                g.seen_delta = co.delta;
+                float sine = 0.0f, square = 0.0f, saw = 0.0f;
+                osc_step(fo, g, ko, cv_lane, 0.0f, sine, square, saw);
+                x = kOscPort == OSC_OUT_SINE ? sine : (kOscPort == OSC_OUT_SQUARE ? square : saw);
+                co.pos = g.pos;
+            }
+            if (has_cut) {
+                const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cut_tile), i);
+                if (!have_cut || cb != seen_cut) {
+                    have_cut = true;
+                    seen_cut = cb;
+                    vcf_coeffs(sv, vcf_frequency(vfreq, __uint_as_float(cb), vexp), vres);
+                }
+            }
+            float lp, bp, hp;
+            vcf_step<true>(sv, x, lp, bp, hp);
+            const float y = vport == VCF_OUT_LP ? lp : (vport == VCF_OUT_BP ? bp : hp);
+            const float env = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(env_tile), i));
+            const bool cv_pos = (uint32_t)(__float_as_int(env) - 1) < 0x7f800000u;  // env > 0.0 on the scalar unit
+            const float o = (negative || cv_pos) ? y * env : 0.0f;
+            emit_put<kOut>(em, mix_tile, o, i, V);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (e < r.n_extra && extra_row[e]) {
+                    const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(extra_tile[e]), i));
+                    __builtin_nontemporal_store(v, &extra_row[e][em.lane_c]);
+                    extra_row[e] += V;
+                }
+        };
+        if (n == kMixRows) {
+#pragma unroll 4
+            for (int i = 0; i < kMixRows; i++) sample(i);
+        } else {
+            for (int i = 0; i < n; i++) sample(i);
+        }
+        emit_flush<kOut>(em, mix_tile, t0, n);
+#pragma unroll
+        for (int e = 0; e < 4; e++)  // every voice carries the same sample: the wave's partial is count x sample
+            if (e < r.n_extra && extra_mp[e] && lane < n) extra_mp[e][t0 + lane] = (float)em.n_active * extra_tile[e];
+        pitch_tile = pitch_next;
+        cut_tile = cut_next;
+        env_tile = env_next;
+#pragma unroll
+        for (int e = 0; e < 4; e++) extra_tile[e] = extra_next[e];
+    }
+    if (active) {
+        auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+        put(oo.state_row + OSC_S_POS_LO, f64_lo(co.pos));
+        put(oo.state_row + OSC_S_POS_HI, f64_hi(co.pos));
+        put(oo.state_row + OSC_S_SYNC_LAST, 0u);  // sync unconnected: `last` follows the constant 0.0 input
+        put(s0 + VCF_S_F, __float_as_uint(sv.f));
+        put(s0 + VCF_S_P, __float_as_uint(sv.p));
+        put(s0 + VCF_S_Q, __float_as_uint(sv.q));
+        put(s0 + VCF_S_B0 + 0, __float_as_uint(sv.b0));
+        put(s0 + VCF_S_B0 + 1, __float_as_uint(sv.b1));
+        put(s0 + VCF_S_B0 + 2, __float_as_uint(sv.b2));
+        put(s0 + VCF_S_B0 + 3, __float_as_uint(sv.b3));
+        put(s0 + VCF_S_B0 + 4, __float_as_uint(sv.b4));
+        put(s0 + VCF_S_FREQ, __float_as_uint(sv.freq));
+        put(s0 + VCF_S_RES, __float_as_uint(sv.res));
+    }
+}
+
+// ---- fused 2-operator FM with a z^-1 feedback edge (patch P2's shape, buffer_size == 1) --------------------
+//   MATH_FB(in1 = OSC_M.sine delayed by one sample) -> OSC_M.cv ; OSC_M.sine -> MATH_IDX -> OSC_C.cv ; OSC_C.sine -> out
+// The broken edge is a one-sample delay, so the fed-back sine lives in a VGPR ("in-register recurrence").
+// Both oscillators have CV: 2^x and sin per sample per operator (oscillator.rs:45,132-133).  The modulator of
+// sample t+1 depends only on its own sine of sample t, so it runs one sample ahead of the carrier.
+template <bool kExact, int kOut>
+__global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
+{
+    using namespace dev;
+    __shared__ float mix_tile[kMixRows * 64];
+    const int lane = threadIdx.x;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
+    const bool active = wm.active;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+
+    const DevOp& ofb = a.ops[r.adsr];    // MATH on the feedback path   (roles reuse the ChainRoles slots)
+    const DevOp& om = a.ops[r.osc_l];    // modulator
+    const DevOp& oix = a.ops[r.vca];     // MATH scaling the modulation index
+    const DevOp& ocr = a.ops[r.osc_a];   // carrier
+    const int plane = a.ops[r.out].aux;
+    const int ring_row = r.track;        // the z^-1 ring: one state row
+
+    constexpr uint32_t fo = OSC_HAS_CV | OSC_CV_AUDIO_RATE | OSC_AA | OSC_OUT_SINE | (kExact ? OSC_EXACT : 0u);
+    OscRegs sm, sc;
+    OscConst km, kc;
+    sm.pos = make_f64(row(om.state_row + OSC_S_POS_LO), row(om.state_row + OSC_S_POS_HI));
+    sm.sync_last = row(om.state_row + OSC_S_SYNC_LAST) != 0;
+    sc.pos = make_f64(row(ocr.state_row + OSC_S_POS_LO), row(ocr.state_row + OSC_S_POS_HI));
+    sc.sync_last = row(ocr.state_row + OSC_S_SYNC_LAST) != 0;
+    km.sr = om.sample_rate;
+    km.val = (double)parv(om, OSC_P_VAL);
+    km.delta = 0.0;
+    km.inv_dt = 0.0f;
+    kc = km;
+    kc.sr = ocr.sample_rate;
+    kc.val = (double)parv(ocr, OSC_P_VAL);
+    // both MATH modules are Multiply by a constant (host-checked): in1 * constant (math.rs:152)
+    const float c_fb = parv(ofb, MATH_P_CONST), c_ix = parv(oix, MATH_P_CONST);
+    float fed = __uint_as_float(row(ring_row));  // OSC_M.sine of the previous tick (0.0 before the first)
+
+    Emit em = make_emit(a, plane, lane);
+    float sq = 0.0f, sw = 0.0f;
+    float sine_m = 0.0f;
+    double pos_m = sm.pos;  // modulator phase after exactly t samples (the loop runs it one sample ahead)
+    if (a.T > 0) osc_step(fo, sm, km, fed * c_fb, 0.0f, sine_m, sq, sw);  // modulator of sample 0
+    for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
+        const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+        for (int i = 0; i < n; i++) {
+            const float cur = sine_m;  // OSC_M.sine[t]: feeds the carrier now and, through the z^-1 ring, the modulator of t+1
+            float out = 0.0f;
+            osc_step(fo, sc, kc, cur * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
+            pos_m = sm.pos;
+            osc_step(fo, sm, km, cur * c_fb, 0.0f, sine_m, sq, sw);   // modulator of sample t+1 (independent of the carrier)
+            fed = cur;
+            emit_put<kOut>(em, mix_tile, out, i, V);
+        }
+        emit_flush<kOut>(em, mix_tile, t0, n);
+    }
+    sm.pos = pos_m;  // drop the look-ahead step
+    if (active) {
+        auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+        put(om.state_row + OSC_S_POS_LO, f64_lo(sm.pos));
+        put(om.state_row + OSC_S_POS_HI, f64_hi(sm.pos));
+        put(om.state_row + OSC_S_SYNC_LAST, 0u);
+        put(ocr.state_row + OSC_S_POS_LO, f64_lo(sc.pos));
+        put(ocr.state_row + OSC_S_POS_HI, f64_hi(sc.pos));
+        put(ocr.state_row + OSC_S_SYNC_LAST, 0u);
+        put(ring_row, __float_as_uint(fed));
+    }
+}
+
+// ---- mix-down, passes 2 and 3: mix[c][i] = sum over waves of mixpart[plane(c)][w][i] ---------------------------
+// Deterministic (fixed order, no atomics).  Pass 2 splits the waves into kMixSplit groups so that enough loads
+// are in flight to stream the partials at HBM rate: block (x, y) sums group y for 256 consecutive samples into
+// mixgroup[plane][y][i].  Pass 3 adds the kMixSplit group sums and fans planes out to channels.
+constexpr uint32_t kMixSplit = 16;
+
+struct MixArgs {
+    const float* mixpart;   // [planes][n_waves][T]
+    float* mixgroup;        // [planes][kMixSplit][T]
+    float* mix;             // [channels][T]
+    uint32_t T, n_waves, n_channels, n_planes;
+    int32_t channel_plane[8];
+};
+
+__global__ __launch_bounds__(256) void mix_reduce_groups(MixArgs m)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m.T) return;
+    const uint32_t per = (m.n_waves + kMixSplit - 1) / kMixSplit;
+    const uint32_t w0 = blockIdx.y * per, w1 = min(m.n_waves, w0 + per);
+    for (uint32_t plane = 0; plane < m.n_planes; plane++) {
+        const float* p = m.mixpart + (size_t)plane * m.n_waves * m.T + i;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // fixed 8-way split: deterministic, 8 loads in flight per thread
+        uint32_t w = w0;
+        for (; w + 8 <= w1; w += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] += p[(size_t)(w + k) * m.T];
+        }
+        for (; w < w1; w++) s[0] += p[(size_t)w * m.T];
+        m.mixgroup[((size_t)plane * kMixSplit + blockIdx.y) * m.T + i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    }
+}
+
+__global__ __launch_bounds__(256) void mix_reduce_final(MixArgs m)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m.T) return;
+    for (uint32_t c = 0; c < m.n_channels; c++) {
+        const int plane = m.channel_plane[c];
+        float s = 0.0f;
+        if (plane >= 0)
+            for (uint32_t y = 0; y < kMixSplit; y++) s += m.mixgroup[((size_t)plane * kMixSplit + y) * m.T + i];
+        m.mix[(size_t)c * m.T + i] = s;
+    }
+}
+
+__global__ void fill_zero(float* p, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0f;
+}
+
+}  // namespace srack

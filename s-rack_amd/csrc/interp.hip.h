@@ -1,0 +1,690 @@
+// interp.hip.h — the generic tile interpreter: executes a flattened op list tile by tile.
+//
+// Per tile and per op, one module-type device function (`tile_*`) runs `tile` samples with the module's state in
+// VGPRs; wires between ops are [tile][64] f32 tiles in LDS; the voice table (state + per-voice parameters) and the
+// tile's slices of the control tracks sit in LDS.  HBM is touched for: the voice table (once in, once out per launch),
+// rendered frames (coalesced 256 B per wave-store), mix partials, control tracks, the rings of broken feedback edges
+// when buffer_size > 16, and SampleModule's wave (gathered).
+// Kernels: render_interp<exact> (one launch = all voices of a voice program, or the single unit of a control program),
+// render_interp_stages<exact> (the control pipeline: one block per control unit).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernel_args.hip.h"
+#include "modules.hip.h"
+
+namespace srack {
+
+namespace dev {
+
+SRK_DEV double make_f64(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+SRK_DEV uint32_t f64_lo(double d) { return (uint32_t)__double2loint(d); }
+SRK_DEV uint32_t f64_hi(double d) { return (uint32_t)__double2hiint(d); }
+
+struct WaveMap {   // which voices a wave owns
+    uint32_t wave0;     // first voice of the wave
+    uint32_t n_active;  // real voices in it (lanes >= n_active shadow voice wave0 + n_active - 1: same work, same stores)
+    uint32_t voice;     // this lane's voice (meaningful when active)
+    uint32_t vc;        // this lane's voice clamped to a real one (safe to load from)
+    bool active;
+};
+
+template <class Args>
+SRK_DEV WaveMap wave_map(const Args& a, int lane)
+{
+    WaveMap m;
+    m.wave0 = (blockIdx.x - a.block0) * a.lanes;
+    m.n_active = min(a.lanes, a.V - m.wave0);
+    m.active = (uint32_t)lane < m.n_active;
+    m.voice = m.wave0 + (uint32_t)lane;
+    m.vc = m.active ? m.voice : m.wave0 + m.n_active - 1;
+    return m;
+}
+
+// LDS pointers carry their address space: a plain float* inside a struct handed to a noinline function degrades every
+// access to flat_load / flat_store (measured: 25 VMEM instructions and 54 % wait cycles per voice-sample).
+// The op list is read-only, wave-uniform data: seen through the constant address space its fields arrive by scalar
+// loads (s_load_dword*) instead of flat loads on the vector memory path.
+typedef const __attribute__((address_space(4))) DevOp COp;
+typedef const __attribute__((address_space(4))) KernelArgs CArgs;  // the kernel's own argument block, read in place (kernarg segment)
+// Arguments of a non-kernel function travel in VGPRs, so the compiler no longer knows the op pointer is the same in
+// every lane and would fetch each field with a vector load.  readfirstlane makes the uniformity explicit again.
+SRK_DEV COp& uniform_op(COp& op)
+{
+    const uint64_t p = (uint64_t)&op;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return *(COp*)(((uint64_t)hi << 32) | lo);
+}
+SRK_DEV CArgs& uniform_args(CArgs& a)
+{
+    const uint64_t p = (uint64_t)&a;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return *(CArgs*)(((uint64_t)hi << 32) | lo);
+}
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+struct Ctx {            // what every tile function sees
+    lds_u32* rows;      // LDS [n_rows][64]
+    lds_f32* wires;     // LDS [n_slots][tile][64]
+    lds_f32* zero;      // LDS row of zeros: what an unconnected input reads (stride 0)
+    lds_f32* trash;     // LDS row nobody reads: where an unread output goes (stride 0)
+    lds_f32* trk;       // LDS [n_tracks][64]: this tile's samples of every control track (same for all lanes)
+    int tile, n, lane;  // tile capacity, samples in this tile, lane
+};
+
+// Arguments of a non-inlined device function travel in VGPRs, so the compiler must assume they differ per lane: loops
+// over c.n become exec-masked loops and every address sum a vector add.  Everything in Ctx but `lane` IS wave-uniform;
+// saying so (v_readfirstlane) moves loop control and address arithmetic to the scalar unit.
+template <class P>
+SRK_DEV P uniform_lds(P p)
+{
+    return (P)(uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p);  // an LDS address is 32 bits
+}
+SRK_DEV Ctx uniform_ctx(const Ctx& v)
+{
+    Ctx c;
+    c.rows = uniform_lds(v.rows);
+    c.wires = uniform_lds(v.wires);
+    c.zero = uniform_lds(v.zero);
+    c.trash = uniform_lds(v.trash);
+    c.trk = uniform_lds(v.trk);
+    c.tile = __builtin_amdgcn_readfirstlane(v.tile);
+    c.n = __builtin_amdgcn_readfirstlane(v.n);
+    c.lane = v.lane;
+    return c;
+}
+
+#define ROW(r) c.rows[(r) * 64 + c.lane]
+#define WIRE(slot, i) c.wires[((slot) * c.tile + (i)) * 64 + c.lane]
+
+SRK_DEV float par(const Ctx& c, COp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(ROW(op.par_row[k])) : op.par_val[k]; }
+
+// A port as (lane pointer, stride in floats per sample).  Unconnected inputs read the zero row, unread outputs
+// write the trash row, both with stride 0 — so tile loops carry no per-sample "is it wired" branches.
+struct Port {
+    lds_f32* p;
+    int stride;
+};
+SRK_DEV Port in_port(const Ctx& c, int slot)
+{
+    if (slot >= kTrackSlot) return Port{c.trk + (slot - kTrackSlot) * 64, 1};  // a control track: same address in every lane (LDS broadcast)
+    return slot >= 0 ? Port{c.wires + slot * c.tile * 64 + c.lane, 64} : Port{c.zero + c.lane, 0};
+}
+SRK_DEV Port out_port(const Ctx& c, int slot) { return slot >= 0 ? Port{c.wires + slot * c.tile * 64 + c.lane, 64} : Port{c.trash + c.lane, 0}; }
+
+// Runs step(x[NI], y[NO]) for every sample of the tile, kU samples at a time: the kU x NI input reads are issued
+// together, then the kU steps, then the kU x NO writes — one LDS round trip per kU samples instead of per sample.
+// An output may share its slot with an input of the same op (flatten.cpp reuses the slot of an input that dies here):
+// that is safe because a group's inputs are all read before any of its outputs is written, and sample i only lives at row i.
+template <int NI, int NO, class Step>
+SRK_DEV void tile_run(const Ctx& c, const Port (&in)[NI], const Port (&out)[NO], Step step)
+{
+    constexpr int kU = 4;
+    int i = 0;
+    for (; i + kU <= c.n; i += kU) {
+        float x[kU][NI], y[kU][NO];
+#pragma unroll
+        for (int u = 0; u < kU; u++)
+#pragma unroll
+            for (int k = 0; k < NI; k++) x[u][k] = in[k].p[(i + u) * in[k].stride];
+#pragma unroll
+        for (int u = 0; u < kU; u++) step(x[u], y[u]);
+#pragma unroll
+        for (int u = 0; u < kU; u++)
+#pragma unroll
+            for (int k = 0; k < NO; k++) out[k].p[(i + u) * out[k].stride] = y[u][k];
+    }
+    for (; i < c.n; i++) {
+        float x[NI], y[NO];
+#pragma unroll
+        for (int k = 0; k < NI; k++) x[k] = in[k].p[i * in[k].stride];
+        step(x, y);
+#pragma unroll
+        for (int k = 0; k < NO; k++) out[k].p[i * out[k].stride] = y[k];
+    }
+}
+
+// ---- one tile of one module type -----------------------------------------------------------------
+// Every tile function is a template on the kernel flavour, also where the code does not depend on it: the register
+// budget a kernel asks for (amdgpu_waves_per_eu, see render_interp) only reaches callees that no other kernel shares.
+
+template <bool kExact>
+__device__ __noinline__ void tile_osc(const Ctx c_v, COp& op_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    const uint32_t fl = op.flags;
+    const int sr = op.state_row;
+    OscRegs s;
+    s.pos = make_f64(ROW(sr + OSC_S_POS_LO), ROW(sr + OSC_S_POS_HI));
+    s.sync_last = ROW(sr + OSC_S_SYNC_LAST) != 0;
+    OscConst k;
+    k.sr = op.sample_rate;
+    k.val = (double)par(c, op, OSC_P_VAL);
+    k.delta = op.delta_row >= 0 ? make_f64(ROW(op.delta_row), ROW(op.delta_row + 1)) : op.delta;
+    k.inv_dt = 1.0f / (float)k.delta;
+    const Port out[3] = {out_port(c, op.out_slot[0]), out_port(c, op.out_slot[1]), out_port(c, op.out_slot[2])};
+    if (fl & OSC_CONST_FAST) {  // no CV, no sync, one live port, delta < 0.25 for every voice (host-checked)
+        COsc o;
+        cosc_init(o, s.pos, k.delta);
+        const Port none[1] = {in_port(c, -1)};
+        if (fl & OSC_OUT_SAW) {
+            const Port w[1] = {out[2]};
+            tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_saw(o); });
+        } else if (fl & OSC_OUT_SQUARE) {
+            const Port w[1] = {out[1]};
+            tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_square(o); });
+        } else {
+            const Port w[1] = {out[0]};
+            tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_sine(o); });
+        }
+        ROW(sr + OSC_S_POS_LO) = f64_lo(o.pos);
+        ROW(sr + OSC_S_POS_HI) = f64_hi(o.pos);
+        ROW(sr + OSC_S_SYNC_LAST) = 0u;  // sync unconnected: `last` follows the constant 0.0 input
+        return;
+    }
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const uint32_t ports = fl & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
+    if (!kExact && (fl & (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_HAS_SYNC | OSC_AA)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1))) {
+        // A sequencer-driven pitch: the carried-phase oscillator between note changes.  When some lane's CV differs from
+        // the one its increment was computed for (a wave-uniform test), that increment is recomputed — 440 / sr x 2^(cv +
+        // val), as osc_step does — and the carried terms are rebuilt from the exact f64 phase.  An increment of 0.25 or
+        // more (or NaN) breaks the carried form's "one PolyBLEP window at a time": those samples take osc_step.
+        COsc o;
+        float seen_cv = __builtin_nanf("");
+        bool carried = false;
+        const uint32_t f = fl & ~OSC_EXACT;
+        const Port cvp[1] = {in[0]};
+        const Port w[1] = {out[(fl & OSC_OUT_SAW) ? 2 : (fl & OSC_OUT_SQUARE) ? 1 : 0]};
+        o.pos = s.pos;
+        tile_run<1, 1>(c, cvp, w, [&](const float* x, float* y) {
+            const float cv = x[0];
+            if (__builtin_amdgcn_ballot_w64(cv != seen_cv) != 0) {
+                const double delta = (440.0 / k.sr) * exp2_fast((double)cv + k.val);
+                seen_cv = cv;
+                carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
+                cosc_init(o, o.pos, delta);
+            }
+            if (carried) {
+                y[0] = (fl & OSC_OUT_SAW) ? cosc_saw(o) : (fl & OSC_OUT_SQUARE) ? cosc_square(o) : cosc_sine(o);
+            } else {
+                OscRegs g;
+                g.pos = o.pos;
+                g.sync_last = false;
+                g.seen_cv = seen_cv;
+                g.seen_delta = o.delta;
+                float o3[3] = {0.0f, 0.0f, 0.0f};
+                osc_step(f, g, k, cv, 0.0f, o3[0], o3[1], o3[2]);
+                y[0] = (fl & OSC_OUT_SAW) ? o3[2] : (fl & OSC_OUT_SQUARE) ? o3[1] : o3[0];
+                cosc_init(o, g.pos, o.delta);
+            }
+        });
+        ROW(sr + OSC_S_POS_LO) = f64_lo(o.pos);
+        ROW(sr + OSC_S_POS_HI) = f64_hi(o.pos);
+        ROW(sr + OSC_S_SYNC_LAST) = 0u;
+        return;
+    }
+    const uint32_t f = kExact ? (fl | OSC_EXACT) : (fl & ~OSC_EXACT);
+    tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
+        y[0] = y[1] = y[2] = 0.0f;
+        osc_step(f, s, k, x[0], x[1], y[0], y[1], y[2]);
+    });
+    ROW(sr + OSC_S_POS_LO) = f64_lo(s.pos);
+    ROW(sr + OSC_S_POS_HI) = f64_hi(s.pos);
+    ROW(sr + OSC_S_SYNC_LAST) = s.sync_last ? 1u : 0u;
+}
+
+SRK_DEV void vcf_load(const Ctx& c, int sr, VcfRegs& s)
+{
+    s.f = __uint_as_float(ROW(sr + VCF_S_F));
+    s.p = __uint_as_float(ROW(sr + VCF_S_P));
+    s.q = __uint_as_float(ROW(sr + VCF_S_Q));
+    s.b0 = __uint_as_float(ROW(sr + VCF_S_B0 + 0));
+    s.b1 = __uint_as_float(ROW(sr + VCF_S_B0 + 1));
+    s.b2 = __uint_as_float(ROW(sr + VCF_S_B0 + 2));
+    s.b3 = __uint_as_float(ROW(sr + VCF_S_B0 + 3));
+    s.b4 = __uint_as_float(ROW(sr + VCF_S_B0 + 4));
+    s.freq = __uint_as_float(ROW(sr + VCF_S_FREQ));
+    s.res = __uint_as_float(ROW(sr + VCF_S_RES));
+}
+
+SRK_DEV void vcf_store(const Ctx& c, int sr, const VcfRegs& s)
+{
+    ROW(sr + VCF_S_F) = __float_as_uint(s.f);
+    ROW(sr + VCF_S_P) = __float_as_uint(s.p);
+    ROW(sr + VCF_S_Q) = __float_as_uint(s.q);
+    ROW(sr + VCF_S_B0 + 0) = __float_as_uint(s.b0);
+    ROW(sr + VCF_S_B0 + 1) = __float_as_uint(s.b1);
+    ROW(sr + VCF_S_B0 + 2) = __float_as_uint(s.b2);
+    ROW(sr + VCF_S_B0 + 3) = __float_as_uint(s.b3);
+    ROW(sr + VCF_S_B0 + 4) = __float_as_uint(s.b4);
+    ROW(sr + VCF_S_FREQ) = __float_as_uint(s.freq);
+    ROW(sr + VCF_S_RES) = __float_as_uint(s.res);
+}
+
+template <bool kExact>
+__device__ __noinline__ void tile_vcf(const Ctx c_v, COp& op_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    const uint32_t fl = op.flags;
+    VcfRegs s;
+    vcf_load(c, op.state_row, s);
+    const float freq = par(c, op, VCF_P_FREQ), exp_amt = par(c, op, VCF_P_EXP);
+    const float res = vcf_resonance(par(c, op, VCF_P_RES));
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const Port out[3] = {out_port(c, op.out_slot[0]), out_port(c, op.out_slot[1]), out_port(c, op.out_slot[2])};
+    if (fl & VCF_HAS_CV) {
+        tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
+            vcf_coeffs(s, vcf_frequency(freq, x[1], exp_amt), res);
+            vcf_step<!kExact>(s, x[0], y[0], y[1], y[2]);
+        });
+    } else {
+        // constant cutoff: the "did (frequency, res) change" check can only fire on the first sample
+        vcf_coeffs(s, vcf_frequency(freq, 0.0f, exp_amt), res);
+        tile_run<2, 3>(c, in, out, [&](const float* x, float* y) { vcf_step<!kExact>(s, x[0], y[0], y[1], y[2]); });
+    }
+    vcf_store(c, op.state_row, s);
+}
+
+template <bool kExact>
+__device__ __noinline__ void tile_adsr(const Ctx c_v, COp& op_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    const int sr = op.state_row;
+    AdsrRegs s;
+    s.phase = __uint_as_float(ROW(sr + ADSR_S_PHASE));
+    s.mode = (int)ROW(sr + ADSR_S_MODE);
+    s.r_val = __uint_as_float(ROW(sr + ADSR_S_R_VAL));
+    s.from_a_val = __uint_as_float(ROW(sr + ADSR_S_FROM_A));
+    s.gate_last = ROW(sr + ADSR_S_GATE_LAST) != 0;
+    const AdsrConst k = adsr_consts(par(c, op, ADSR_P_A), par(c, op, ADSR_P_D), par(c, op, ADSR_P_S), par(c, op, ADSR_P_R), par(c, op, ADSR_P_SR));
+    const Port in[1] = {in_port(c, op.in_slot[0])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
+    if (op.flags & ADSR_HAS_GATE) {
+        AdsrSeg g;
+        adsr_seg_enter(s, k, g);
+        tile_run<1, 1>(c, in, out, [&](const float* x, float* y) { y[0] = adsr_seg_step(s, k, g, x[0]); });
+        adsr_seg_flush(s, g);
+    } else {
+        tile_run<1, 1>(c, in, out, [&](const float*, float* y) { y[0] = adsr_step(op.flags, s, k, 0.0f); });
+    }
+    ROW(sr + ADSR_S_PHASE) = __float_as_uint(s.phase);
+    ROW(sr + ADSR_S_MODE) = (uint32_t)s.mode;
+    ROW(sr + ADSR_S_R_VAL) = __float_as_uint(s.r_val);
+    ROW(sr + ADSR_S_FROM_A) = __float_as_uint(s.from_a_val);
+    ROW(sr + ADSR_S_GATE_LAST) = s.gate_last ? 1u : 0u;
+}
+
+template <bool kExact>
+__device__ __noinline__ void tile_vca(const Ctx c_v, COp& op_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    const bool negative = par(c, op, VCA_P_NEG) != 0.0f;
+    const uint32_t fl = op.flags;
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
+    tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = vca_step(fl, negative, x[0], x[1]); });
+}
+
+template <bool kExact>
+__device__ __noinline__ void tile_mix(const Ctx c_v, COp& op_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    float gain[4];
+    for (int k = 0; k < 4; k++) gain[k] = par(c, op, MIX_P_GAIN0 + k);
+    const uint32_t fl = op.flags;
+    const Port in[4] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1]), in_port(c, op.in_slot[2]), in_port(c, op.in_slot[3])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
+    tile_run<4, 1>(c, in, out, [&](const float* x, float* y) { y[0] = mixer_step(fl, x, gain); });
+}
+
+template <bool kExact>
+__device__ __noinline__ void tile_math(const Ctx c_v, COp& op_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    const float constant = par(c, op, MATH_P_CONST);
+    const uint32_t fl = op.flags;
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
+    tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = math_step(fl, x[0], x[1], constant); });
+}
+
+template <bool kExact>
+__device__ __noinline__ void tile_nonlin(const Ctx c_v, COp& op_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    const float constant = par(c, op, NONLIN_P_CONST);
+    const uint32_t fl = op.flags;
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
+    tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = nonlin_step(fl, x[0], x[1], constant); });
+}
+
+// SampleModule (sample.rs:192-240) in two passes over the tile: the position state machine does not depend on the
+// samples it reads, so pass 1 leaves each sample's read INDEX in the output wire and pass 2 turns indices into
+// samples with independent gathers from the shared wave (8 loads in flight per lane instead of one per step).
+template <bool kExact>
+__device__ __noinline__ void tile_sample(const Ctx c_v, COp& op_v, CArgs& a_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    CArgs& a = uniform_args(a_v);
+    const int sr = op.state_row;
+    const uint32_t fl = op.flags;
+    SmpRegs s;
+    s.pos = __uint_as_float(ROW(sr + SMP_S_POS));
+    s.playing = ROW(sr + SMP_S_PLAYING) != 0;
+    s.gate_last = ROW(sr + SMP_S_GATE_LAST) != 0;
+    const float ratio = par(c, op, SMP_P_WAVE_SR) / par(c, op, SMP_P_SR);
+    const uint32_t n_wave = (uint32_t)op.seq_len;
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    const Port out[1] = {out_port(c, op.out_slot[0])};
+    tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = __uint_as_float(sample_advance(fl, s, ratio, n_wave, x[0], x[1])); });
+    ROW(sr + SMP_S_POS) = __float_as_uint(s.pos);
+    ROW(sr + SMP_S_PLAYING) = s.playing ? 1u : 0u;
+    ROW(sr + SMP_S_GATE_LAST) = s.gate_last ? 1u : 0u;
+    if (op.out_slot[0] < 0) return;
+    const uint32_t* wave = a.seqtab + op.aux;
+    const Port w = out[0];
+    int i = 0;
+    for (; i + 8 <= c.n; i += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = __float_as_uint(w.p[(i + u) * w.stride]);
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = n_wave ? wave[v[u]] : 0u;  // empty wave: `*out = 0.0`
+#pragma unroll
+        for (int u = 0; u < 8; u++) w.p[(i + u) * w.stride] = __uint_as_float(v[u]);
+    }
+    for (; i < c.n; i++) {
+        const uint32_t idx = __float_as_uint(w.p[i * w.stride]);
+        w.p[i * w.stride] = __uint_as_float(n_wave ? wave[idx] : 0u);
+    }
+}
+
+// Sequencers (sequencer.rs:190-246, 482-533).  The 64 grid cells are wave-shared data: staged once per tile in an LDS
+// row indexed by STEP (not by lane); every lane then gathers the cell of its own current_step.
+struct SeqRegs {
+    uint32_t current_step;
+    bool step_last, sync_last;
+};
+
+SRK_DEV uint32_t seq_advance(SeqRegs& s, float step_in, float sync_in, uint32_t length)
+{
+    if (rising_edge(s.step_last, step_in)) s.current_step = (s.current_step + 1u) & 0xffffu;  // u16 in the reference
+    if (rising_edge(s.sync_last, sync_in)) s.current_step = 0u;
+    uint32_t cs = s.current_step;
+    if (cs >= length) {
+        s.current_step = 0u;
+        cs = 0u;
+    }
+    return cs;
+}
+
+template <bool kExact>
+__device__ __noinline__ void tile_seq(const Ctx c_v, COp& op_v, CArgs& a_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    CArgs& a = uniform_args(a_v);
+    const int sr = op.state_row;
+    SeqRegs s;
+    s.current_step = ROW(sr + SEQ_S_CURRENT);
+    s.step_last = ROW(sr + SEQ_S_STEP_LAST) != 0;
+    s.sync_last = ROW(sr + SEQ_S_SYNC_LAST) != 0;
+    __syncthreads();
+    c.rows[op.seq_row * 64 + c.lane] = a.seqtab[op.aux + c.lane];
+    __syncthreads();
+    const lds_u32* cells = c.rows + op.seq_row * 64;
+    const uint32_t length = (uint32_t)op.seq_len;
+    const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
+    if (op.kind == OP_GRIDSEQ) {
+        float last = __uint_as_float(ROW(sr + GRIDSEQ_S_LAST));
+        const float inv_spo = 1.0f / par(c, op, GRIDSEQ_P_SPO);  // 1.0 / steps_per_octave as f32 (sequencer.rs:236)
+        const Port out[3] = {out_port(c, op.out_slot[0]), out_port(c, op.out_slot[1]), out_port(c, op.out_slot[2])};
+        tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
+            const uint32_t cs = seq_advance(s, x[0], x[1], length);
+            const uint32_t cell = cells[cs];
+            const bool present = cell & 0x80000000u, hold = cell & 0x40000000u;
+            y[0] = present ? (float)(cell & 0xffffu) * inv_spo : last;
+            y[1] = present ? (hold ? 1.0f : x[0]) : 0.0f;
+            y[2] = cs == 0u ? 1.0f : 0.0f;
+            last = y[0];
+        });
+        ROW(sr + GRIDSEQ_S_LAST) = __float_as_uint(last);
+    } else {
+        Port out[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = out_port(c, op.out_slot[k]);
+        tile_run<2, 9>(c, in, out, [&](const float* x, float* y) {
+            const uint32_t cs = seq_advance(s, x[0], x[1], length);
+            const uint32_t cell = cells[cs];
+#pragma unroll
+            for (int ch = 0; ch < 8; ch++) {
+                const uint32_t b = (cell >> (2 * ch)) & 3u;
+                y[ch] = (b & 1u) ? ((b & 2u) ? 1.0f : x[0]) : 0.0f;
+            }
+            y[8] = cs == 0u ? 1.0f : 0.0f;
+        });
+    }
+    ROW(sr + SEQ_S_CURRENT) = s.current_step;
+    ROW(sr + SEQ_S_STEP_LAST) = s.step_last ? 1u : 0u;
+    ROW(sr + SEQ_S_SYNC_LAST) = s.sync_last ? 1u : 0u;
+}
+
+// Sum the first `rows` rows of an LDS tile [..][64] over the 64 lanes.  R = the power of two >= rows (<= 64): lane l
+// owns row l % R and the column segment l / R (64 / R segments of R columns each); columns are visited skewed by the
+// row so the 32 lanes of a half-wave hit 32 different banks.  Lanes whose row is past `rows` idle.  Valid in lanes < rows.
+template <class Ptr>
+SRK_DEV float tile_row_sum(Ptr t, int rows, int lane)
+{
+    const int R = rows <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)rows - 1u));
+    const int row = lane & (R - 1);
+    const int seg = lane / R;
+    const Ptr p = t + row * 64 + seg * R;
+    float sum = 0.0f;
+    if (row < rows)
+        for (int j = 0; j < R; j++) sum += p[(j + row) & (R - 1)];
+    for (int m = R; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
+    return sum;
+}
+
+template <bool kExact>
+__device__ __noinline__ void tile_out(const Ctx c_v, COp& op_v, CArgs& a_v, uint32_t t0, uint32_t voice, bool active)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    CArgs& a = uniform_args(a_v);
+    const int slot = op.in_slot[0], plane = op.aux;
+    const Port in = in_port(c, slot);  // an LDS wire, or a control track when every voice plays the same thing
+    if (a.frames) {
+        float* f = a.frames + (size_t)plane * a.plane_stride + (size_t)t0 * a.V + voice;
+        if (active) {
+            int i = 0;
+            for (; i + 8 <= c.n; i += 8) {  // 8 reads in flight, then 8 coalesced 256-B row stores
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = in.p[(i + u) * in.stride];
+#pragma unroll
+                for (int u = 0; u < 8; u++) f[(size_t)(i + u) * a.V] = v[u];
+            }
+            for (; i < c.n; i++) f[(size_t)i * a.V] = in.p[i * in.stride];
+        }
+    }
+    if (a.mixpart) {
+        float* mp = a.mixpart + ((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride + t0;
+        if (slot >= kTrackSlot) {  // identical voices: the wave's partial is (number of real voices) x sample
+            if (c.lane < c.n) mp[c.lane] = (float)min(a.lanes, a.V - (blockIdx.x - a.block0) * a.lanes) * in.p[c.lane];
+            return;
+        }
+        if (!active)
+            for (int i = 0; i < c.n; i++) WIRE(slot, i) = 0.0f;  // lanes past V contribute nothing
+        __syncthreads();
+        float sum = tile_row_sum(c.wires + slot * c.tile * 64, c.tile, c.lane);
+        if (c.lane < c.n) mp[c.lane] = sum;
+        __syncthreads();
+    }
+}
+
+template <bool kExact>
+__device__ __noinline__ void tile_delay_rd(const Ctx c_v, COp& op_v, CArgs& a_v, uint64_t n_abs, uint32_t voice_c)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    CArgs& a = uniform_args(a_v);
+    const int o = op.out_slot[0];
+    const uint32_t B = (uint32_t)a.prog.buffer_size;
+    if (op.flags & DELAY_RING_GLOBAL) {
+        const float* ring = a.rings + (size_t)op.aux * B * a.V + voice_c;
+        uint32_t p = (uint32_t)(n_abs % B);
+        int i = 0;
+        for (; i + 8 <= c.n; i += 8) {  // 8 ring rows in flight per round trip to HBM / L2
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                v[u] = ring[(size_t)p * a.V];
+                p = p + 1 == B ? 0 : p + 1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) WIRE(o, i + u) = v[u];
+        }
+        for (; i < c.n; i++) {
+            WIRE(o, i) = ring[(size_t)p * a.V];
+            p = p + 1 == B ? 0 : p + 1;
+        }
+    } else {
+        uint32_t p = (uint32_t)(n_abs % B);
+        for (int i = 0; i < c.n; i++) {
+            WIRE(o, i) = __uint_as_float(ROW(op.aux + p));
+            p = p + 1 == B ? 0 : p + 1;
+        }
+    }
+}
+
+template <bool kExact>
+__device__ __noinline__ void tile_delay_wr(const Ctx c_v, COp& op_v, CArgs& a_v, uint64_t n_abs, uint32_t voice, bool active)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    CArgs& a = uniform_args(a_v);
+    const int s = op.in_slot[0];
+    const uint32_t B = (uint32_t)a.prog.buffer_size;
+    uint32_t p = (uint32_t)(n_abs % B);
+    if (op.flags & DELAY_RING_GLOBAL) {
+        float* ring = a.rings + (size_t)op.aux * B * a.V + voice;
+        for (int i = 0; i < c.n; i++) {
+            if (active) ring[(size_t)p * a.V] = WIRE(s, i);
+            p = p + 1 == B ? 0 : p + 1;
+        }
+    } else {
+        for (int i = 0; i < c.n; i++) {
+            ROW(op.aux + p) = __float_as_uint(WIRE(s, i));
+            p = p + 1 == B ? 0 : p + 1;
+        }
+    }
+}
+
+}  // namespace dev
+
+// ---- generic tile interpreter ----------------------------------------------------------------------
+// `a` is the argument block seen through the constant address space (the kernarg segment itself, or one entry of the
+// stage table in global memory): every field arrives by a scalar load, and tile functions can take its address.
+template <bool kExact>
+SRK_DEV void interp_body(dev::CArgs& a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x;
+    if (a.T == 0) return;  // an idle slot of the control pipeline
+    dev::CArgs& ca = a;
+    const dev::WaveMap wm = dev::wave_map(a, lane);
+    const uint32_t voice = wm.voice, voice_c = wm.vc;  // idle lanes shadow the wave's last voice; they never store
+    const bool active = wm.active;
+    const int n_rows = a.prog.n_rows, tile = a.prog.tile;
+    dev::Ctx c;
+    c.rows = (dev::lds_u32*)lds;
+    c.zero = (dev::lds_f32*)(lds + (size_t)n_rows * 64);
+    c.trash = c.zero + 64;
+    c.trk = c.trash + 64;
+    c.wires = c.trk + a.prog.n_tracks * 64;
+    c.zero[lane] = 0.0f;
+    c.tile = tile;
+    c.lane = lane;
+    c.n = 0;
+    for (int r = 0; r < n_rows; r++) c.rows[r * 64 + lane] = a.table[(size_t)r * a.V + voice_c];
+
+    for (uint32_t t0 = 0; t0 < a.T; t0 += (uint32_t)tile) {
+        c.n = (int)min((uint32_t)tile, a.T - t0);
+        if (a.prog.n_tracks > 0) {  // this tile's slice of every control track the program reads: one coalesced load per track
+            __syncthreads();
+            for (int k = 0; k < a.prog.n_tracks; k++)
+                if (lane < c.n) c.trk[k * 64 + lane] = a.tracks[(size_t)a.prog.track_id[k] * a.t_stride + t0 + lane];
+            __syncthreads();
+        }
+        for (int i = 0; i < a.prog.n_ops; i++) {
+            dev::COp& op = ((dev::COp*)a.ops)[i];
+            switch (op.kind) {
+            case OP_OSC: dev::tile_osc<kExact>(c, op); break;
+            case OP_VCF: dev::tile_vcf<kExact>(c, op); break;
+            case OP_ADSR: dev::tile_adsr<kExact>(c, op); break;
+            case OP_VCA: dev::tile_vca<kExact>(c, op); break;
+            case OP_MIX: dev::tile_mix<kExact>(c, op); break;
+            case OP_MATH: dev::tile_math<kExact>(c, op); break;
+            case OP_OUT: dev::tile_out<kExact>(c, op, ca, t0, voice, active); break;
+            case OP_GRIDSEQ:
+            case OP_PATSEQ: dev::tile_seq<kExact>(c, op, ca); break;
+            case OP_NONLIN: dev::tile_nonlin<kExact>(c, op); break;
+            case OP_SAMPLE: dev::tile_sample<kExact>(c, op, ca); break;
+            case OP_DELAY_RD: dev::tile_delay_rd<kExact>(c, op, ca, a.n0 + t0, voice_c); break;
+            case OP_DELAY_WR: dev::tile_delay_wr<kExact>(c, op, ca, a.n0 + t0, voice, active); break;
+            default: break;
+            }
+        }
+    }
+    if (active)
+        for (int r = 0; r < a.prog.n_state_rows; r++) a.table[(size_t)r * a.V + voice] = c.rows[r * 64 + lane];
+}
+
+// Two entry points over one body.  The default flavour is told to fit five waves per SIMD (<= 96 VGPRs; it needs 103
+// unconstrained): resident waves are what hides the latency of the per-module dependency chains, and at the headline
+// size (16 waves per CU) four per SIMD leaves no slack for the dispatcher.  The exact flavour (f64 PolyBLEP / sin / pow,
+// 184 VGPRs) would spill heavily under that cap and is left alone.
+template <bool kExact>
+__global__ __launch_bounds__(64) void render_interp(KernelArgs a);
+template <>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void render_interp<false>(KernelArgs a)
+{
+    interp_body<false>(*(dev::CArgs*)__builtin_amdgcn_kernarg_segment_ptr());
+}
+template <>
+__global__ __launch_bounds__(64) void render_interp<true>(KernelArgs a)
+{
+    interp_body<true>(*(dev::CArgs*)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
+// The control pipeline: block b runs control unit b (one module) on the chunk its entry of `slots` describes (T == 0:
+// nothing to do in this launch).  A unit trails the units it reads by at least one chunk, i.e. it reads tracks written by
+// an EARLIER launch: the kernel boundary provides the ordering; within a launch the units touch disjoint state and
+// disjoint track ranges.
+// (Same register budget as render_interp<false>: the tile functions are shared, and the budget only propagates to
+// callees whose callers all agree.)
+template <bool kExact>
+__global__ __launch_bounds__(64) void render_interp_stages(const KernelArgs* slots);
+template <>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void render_interp_stages<false>(const KernelArgs* slots)
+{
+    interp_body<false>(*(dev::CArgs*)(uintptr_t)(slots + blockIdx.x));
+}
+template <>
+__global__ __launch_bounds__(64) void render_interp_stages<true>(const KernelArgs* slots)
+{
+    interp_body<true>(*(dev::CArgs*)(uintptr_t)(slots + blockIdx.x));
+}
+
+}  // namespace srack

@@ -1,0 +1,39 @@
+// kernel_args.hip.h — the argument blocks shared by the kernels (interp.hip.h, fused.hip.h) and the launch code (render.hip).
+#pragma once
+#include <cstdint>
+
+#include "program.hpp"
+
+namespace srack {
+
+struct KernelArgs {
+    const DevOp* ops;
+    DevProgram prog;
+    uint32_t* table;
+    float* rings;
+    float* frames;
+    float* mixpart;
+    const float* tracks;  // control tracks [n_tracks][t_stride] written by the control program (may be null)
+    const uint32_t* seqtab;  // sequencer grids, 64 cells per sequencer op
+    uint32_t V, T, n_waves;
+    uint32_t lanes;  // voices per wave: 64, or 32 / 16 when there are too few voices to fill the SIMDs (idle lanes shadow the wave's last voice)
+    // A launch covers T samples of a render of t_stride samples; frames / mixpart / tracks arrive pre-offset to
+    // the launch's first sample and keep the whole render's strides.
+    uint64_t plane_stride;  // frames: elements between planes (= t_stride * V)
+    uint32_t t_stride;
+    uint32_t block0;  // blocks [0, block0) of the grid are not voice waves (a co-scheduled control block); wave = blockIdx.x - block0
+    uint64_t n0;  // absolute index of this launch's first sample (phase of the feedback rings)
+};
+
+struct ChainRoles {  // op indices of the fused voice chain (osc_l / adsr unused in the track variant)
+    int osc_a, osc_l, vcf, adsr, vca, out, track;
+};
+
+struct SeqRoles {  // the fused sequencer-driven voice chain: op indices and rows of the track buffer
+    int math, osc, vcf, vca, out;        // math = -1: the oscillator's CV is the note track itself
+    int trk_pitch, trk_cutoff, trk_env;  // trk_cutoff = -1: the filter has no CV
+    int n_extra;                         // further output planes that carry a track as it is
+    int extra_plane[4], extra_trk[4];
+};
+
+}  // namespace srack
