@@ -26,6 +26,9 @@ mod ffi {
         pub fn srack_patch_set_field(p: *mut SrackPatch, module: c_int, field: c_int, value: f64) -> c_int;
         pub fn srack_patch_get_field(p: *const SrackPatch, module: c_int, field: c_int, value: *mut f64) -> c_int;
         pub fn srack_patch_set_step(p: *mut SrackPatch, module: c_int, channel: c_int, step: c_int, state: c_int, value: c_int) -> c_int;
+        pub fn srack_patch_set_wave(p: *mut SrackPatch, module: c_int, samples: *const f32, n_samples: u32, sample_rate: f32) -> c_int;
+        pub fn srack_patch_load_srk(bytes: *const c_void, n_bytes: usize, sample_rate: u32, buffer_size: u32, channels: u32, out: *mut *mut SrackPatch) -> c_int;
+        pub fn srack_patch_save_srk(p: *const SrackPatch, buf: *mut c_void, cap: usize, n_bytes: *mut usize) -> c_int;
         pub fn srack_patch_connect(p: *mut SrackPatch, src: c_int, src_port: c_int, sink: c_int, sink_port: c_int) -> c_int;
         pub fn srack_patch_disconnect(p: *mut SrackPatch, sink: c_int, sink_port: c_int) -> c_int;
         pub fn srack_patch_plan(p: *mut SrackPatch, order: *mut c_int, cap: c_int) -> c_int;
@@ -52,6 +55,8 @@ pub enum ModuleType {
     Math = 6,
     GridSequencer = 7,
     PatternSequencer = 8,
+    NonLinear = 9,
+    Sample = 10,
 }
 
 #[derive(Debug)]
@@ -121,6 +126,26 @@ impl Patch {
     }
     pub fn set_step(&mut self, module: i32, channel: i32, step: i32, state: i32, value: i32) -> Result<(), Error> {
         check(unsafe { ffi::srack_patch_set_step(self.raw, module, channel, step, state, value) }).map(|_| ())
+    }
+    /// What `WaveBox::load` leaves behind (src/synth/sample.rs:31-69): first channel as f32 + the file's sample rate.
+    pub fn set_wave(&mut self, module: i32, samples: &[f32], sample_rate: f32) -> Result<(), Error> {
+        check(unsafe { ffi::srack_patch_set_wave(self.raw, module, samples.as_ptr(), samples.len() as u32, sample_rate) }).map(|_| ())
+    }
+    /// `SynthModuleWorkspaceImpl::deserialize` (src/ui.rs:116-135): a saved rack against this host's AudioConfig.
+    pub fn load_srk(bytes: &[u8], sample_rate: u16, buffer_size: usize, channels: u8) -> Result<Self, Error> {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe {
+            ffi::srack_patch_load_srk(bytes.as_ptr() as *const c_void, bytes.len(), sample_rate as u32, buffer_size as u32, channels as u32, &mut raw)
+        })?;
+        Ok(Self { raw })
+    }
+    /// `serialize` (src/ui.rs:98-114).
+    pub fn save_srk(&self) -> Result<Vec<u8>, Error> {
+        let mut n = 0usize;
+        check(unsafe { ffi::srack_patch_save_srk(self.raw, std::ptr::null_mut(), 0, &mut n) })?;
+        let mut buf = vec![0u8; n];
+        check(unsafe { ffi::srack_patch_save_srk(self.raw, buf.as_mut_ptr() as *mut c_void, n, &mut n) })?;
+        Ok(buf)
     }
     /// `SynthModule::set_input(input_idx, src_module, src_port)`.
     pub fn set_input(&mut self, sink: i32, input_idx: u8, src: i32, src_port: u8) -> Result<(), Error> {
