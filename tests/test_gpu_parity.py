@@ -476,6 +476,31 @@ def test_p3_extreme_transpose_takes_the_literal_oscillator(S, oracle, flags):
     np.testing.assert_array_equal(fr[1], ref[1])
 
 
+@pytest.mark.parametrize("flags", [pytest.param(0, id="fused-pipelined"), pytest.param(2, id="interp-pipelined"), pytest.param(8, id="fused-one-unit")])
+def test_p3_render_continues_across_calls(S, flags):
+    """The control pipeline fills and drains inside every call: render(T) == render(a) ++ render(b) ++ ..., bit for bit,
+    for call lengths around the chunk sizes (1024 x depth, then doubling) and tiles."""
+    V, T = 70, 21000
+    transpose = np.linspace(-1.5, 0.5, V).astype(np.float32)
+
+    def make():
+        p = S.Patch(48000, 1024, 2)
+        ids = S.build_p3(p, clock_val=-2.0)
+        p.configure_voices(V)
+        p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, transpose)
+        return p, ids
+    p, ids = make()
+    whole, _ = p.render(T, flags=flags)
+    q, _ = make()
+    parts = [q.render(n, flags=flags)[0] for n in (1, 1023, 1025, 3000, 4097, 63, T - 9209)]
+    got = np.concatenate(parts, axis=1)
+    np.testing.assert_array_equal(bits(got), bits(whole))
+    for f in (S.GRIDSEQ_CURRENT_STEP, S.GRIDSEQ_LAST):
+        np.testing.assert_array_equal(q.get_voice_field(ids["grid"], f), p.get_voice_field(ids["grid"], f))
+    np.testing.assert_array_equal(q.get_voice_field(ids["adsr_flt"], S.ADSR_PHASE), p.get_voice_field(ids["adsr_flt"], S.ADSR_PHASE))
+    assert np.abs(whole[0]).max() > 0.1 and len(np.unique(whole[1])) >= 2
+
+
 def test_p3_per_voice_clocks(S, oracle):
     """Per-voice clock rates: the sequencers step at different times in different lanes."""
     V, T = 96, 9000
