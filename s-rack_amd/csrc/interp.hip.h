@@ -275,15 +275,35 @@ __device__ __noinline__ void tile_vcf(const Ctx c_v, COp& op_v)
     const float res = vcf_resonance(par(c, op, VCF_P_RES));
     const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
     const Port out[3] = {out_port(c, op.out_slot[0]), out_port(c, op.out_slot[1]), out_port(c, op.out_slot[2])};
+    const uint32_t ports = fl & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP);
+    const bool one = ports && !(ports & (ports - 1));  // the usual case: one port read => one wire written, not three
+    const Port w[1] = {out[ports == VCF_OUT_HP ? 2 : ports == VCF_OUT_BP ? 1 : 0]};
+    auto pick = [&](float lp, float bp, float hp) { return ports == VCF_OUT_LP ? lp : (ports == VCF_OUT_BP ? bp : hp); };
     if (fl & VCF_HAS_CV) {
-        tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
-            vcf_coeffs(s, vcf_frequency(freq, x[1], exp_amt), res);
-            vcf_step<!kExact>(s, x[0], y[0], y[1], y[2]);
-        });
+        if (one)
+            tile_run<2, 1>(c, in, w, [&](const float* x, float* y) {
+                float lp, bp, hp;
+                vcf_coeffs(s, vcf_frequency(freq, x[1], exp_amt), res);
+                vcf_step<!kExact>(s, x[0], lp, bp, hp);
+                y[0] = pick(lp, bp, hp);
+            });
+        else
+            tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
+                vcf_coeffs(s, vcf_frequency(freq, x[1], exp_amt), res);
+                vcf_step<!kExact>(s, x[0], y[0], y[1], y[2]);
+            });
     } else {
         // constant cutoff: the "did (frequency, res) change" check can only fire on the first sample
         vcf_coeffs(s, vcf_frequency(freq, 0.0f, exp_amt), res);
-        tile_run<2, 3>(c, in, out, [&](const float* x, float* y) { vcf_step<!kExact>(s, x[0], y[0], y[1], y[2]); });
+        const Port audio[1] = {in[0]};
+        if (one)
+            tile_run<1, 1>(c, audio, w, [&](const float* x, float* y) {
+                float lp, bp, hp;
+                vcf_step<!kExact>(s, x[0], lp, bp, hp);
+                y[0] = pick(lp, bp, hp);
+            });
+        else
+            tile_run<1, 3>(c, audio, out, [&](const float* x, float* y) { vcf_step<!kExact>(s, x[0], y[0], y[1], y[2]); });
     }
     vcf_store(c, op.state_row, s);
 }
@@ -460,19 +480,43 @@ __device__ __noinline__ void tile_seq(const Ctx c_v, COp& op_v, CArgs& a_v)
         });
         ROW(sr + GRIDSEQ_S_LAST) = __float_as_uint(last);
     } else {
+        // 8 gates + sync, of which a patch reads a few: per group of samples the step machine runs once, then only the
+        // ports somebody reads are computed and written (nine LDS rows per sample made this the slowest control module).
+        const uint32_t live = op.flags & 0x1ffu;
         Port out[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) out[k] = out_port(c, op.out_slot[k]);
-        tile_run<2, 9>(c, in, out, [&](const float* x, float* y) {
-            const uint32_t cs = seq_advance(s, x[0], x[1], length);
-            const uint32_t cell = cells[cs];
+        constexpr int kU = 4;
+        for (int i = 0; i < c.n; i += kU) {
+            const int m = min(kU, c.n - i);
+            float step_in[kU], sync_in[kU];
+            uint32_t cell[kU];
+            bool first[kU];
 #pragma unroll
-            for (int ch = 0; ch < 8; ch++) {
-                const uint32_t b = (cell >> (2 * ch)) & 3u;
-                y[ch] = (b & 1u) ? ((b & 2u) ? 1.0f : x[0]) : 0.0f;
+            for (int u = 0; u < kU; u++) {  // all reads of the group in flight together (the tail re-reads its last sample)
+                const int iu = i + min(u, m - 1);
+                step_in[u] = in[0].p[iu * in[0].stride];
+                sync_in[u] = in[1].p[iu * in[1].stride];
             }
-            y[8] = cs == 0u ? 1.0f : 0.0f;
-        });
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                if (u >= m) break;
+                const uint32_t cs = seq_advance(s, step_in[u], sync_in[u], length);
+                cell[u] = cells[cs];
+                first[u] = cs == 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                if (!((live >> k) & 1u)) continue;  // wave-uniform
+#pragma unroll
+                for (int u = 0; u < kU; u++) {
+                    if (u >= m) break;
+                    const uint32_t b = (cell[u] >> (2 * (k & 7))) & 3u;
+                    const float gate = (b & 1u) ? ((b & 2u) ? 1.0f : step_in[u]) : 0.0f;
+                    out[k].p[(i + u) * out[k].stride] = k == 8 ? (first[u] ? 1.0f : 0.0f) : gate;
+                }
+            }
+        }
     }
     ROW(sr + SEQ_S_CURRENT) = s.current_step;
     ROW(sr + SEQ_S_STEP_LAST) = s.step_last ? 1u : 0u;
