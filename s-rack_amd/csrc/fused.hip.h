@@ -540,19 +540,25 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
 #pragma unroll
         for (int e = 0; e < 4; e++) extra_next[e] = fetch(extra_track[e], t0 + kMixRows);
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
-        auto sample = [&](int i) {
-            const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(pitch_tile), i);
-            if (!have_pitch || pb != seen_pitch) {  // a new note (scalar test): new increment, carried terms rebuilt
-                have_pitch = true;
-                seen_pitch = pb;
-                const float note = __uint_as_float(pb);
-                cv_lane = has_math ? math_step(mflags, note, 0.0f, mconst) : note;
-                const double delta = hz_scale * exp2_fast((double)cv_lane + ko.val);
-                carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
-                cosc_init(co, co.pos, delta);
+        // A note lasts thousands of samples and an envelope rests in sustain or at zero for long stretches: when a whole
+        // tile holds the pitch (the cutoff CV) the oscillator (the coefficients) were last set up for, its samples run
+        // without the per-sample "did it change" branches, which lets the compiler interleave oscillator and filter of
+        // neighbouring samples.  `steady_pitch` / `steady_cut` are compile-time constants inside each unrolled loop.
+        auto sample = [&](int i, bool steady_pitch, bool steady_cut) {
+            if (!steady_pitch) {
+                const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(pitch_tile), i);
+                if (!have_pitch || pb != seen_pitch) {  // a new note (scalar test): new increment, carried terms rebuilt
+                    have_pitch = true;
+                    seen_pitch = pb;
+                    const float note = __uint_as_float(pb);
+                    cv_lane = has_math ? math_step(mflags, note, 0.0f, mconst) : note;
+                    const double delta = hz_scale * exp2_fast((double)cv_lane + ko.val);
+                    carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
+                    cosc_init(co, co.pos, delta);
+                }
             }
             float x;
-            if (carried) {
+            if (steady_pitch || carried) {  // (a steady tile is only declared when the carried form holds)
                 x = cosc_step<kOscPort>(co);
             } else {  // an increment of a quarter cycle or more somewhere in the wave: the literal per-sample form
                 OscRegs g;
@@ -565,13 +571,9 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
                 x = kOscPort == OSC_OUT_SINE ? sine : (kOscPort == OSC_OUT_SQUARE ? square : saw);
                 co.pos = g.pos;
             }
-            if (has_cut) {
-                const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cut_tile), i);
-                if (!have_cut || cb != seen_cut) {
-                    have_cut = true;
-                    seen_cut = cb;
-                    vcf_coeffs(sv, vcf_frequency(vfreq, __uint_as_float(cb), vexp), vres);
-                }
+            if (has_cut && !steady_cut) {  // vcf_coeffs itself recomputes only for lanes whose (frequency, res) changed
+                const float cutv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cut_tile), i));
+                vcf_coeffs(sv, vcf_frequency(vfreq, cutv, vexp), vres);
             }
             float lp, bp, hp;
             vcf_step<true>(sv, x, lp, bp, hp);
@@ -588,11 +590,26 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
                     extra_row[e] += V;
                 }
         };
+        const bool in_tile = (int)l32 < n;
+        const bool steady_pitch = have_pitch && carried && __builtin_amdgcn_ballot_w64(in_tile && __float_as_uint(pitch_tile) != seen_pitch) == 0;
+        const bool steady_cut = !has_cut || (have_cut && __builtin_amdgcn_ballot_w64(in_tile && __float_as_uint(cut_tile) != seen_cut) == 0);
         if (n == kMixRows) {
+            if (steady_pitch && steady_cut) {
+#pragma unroll 8
+                for (int i = 0; i < kMixRows; i++) sample(i, true, true);
+            } else if (steady_pitch) {
+#pragma unroll 8
+                for (int i = 0; i < kMixRows; i++) sample(i, true, false);
+            } else {
 #pragma unroll 4
-            for (int i = 0; i < kMixRows; i++) sample(i);
+                for (int i = 0; i < kMixRows; i++) sample(i, false, false);
+            }
         } else {
-            for (int i = 0; i < n; i++) sample(i);
+            for (int i = 0; i < n; i++) sample(i, false, false);
+        }
+        if (has_cut && !steady_cut) {  // the coefficients now belong to the tile's last cutoff CV
+            have_cut = true;
+            seen_cut = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cut_tile), n - 1);
         }
         emit_flush<kOut>(em, mix_tile, t0, n);
 #pragma unroll
