@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--no-frames", action="store_true", help="mix only (diagnostic; not the metric)")
     ap.add_argument("--no-mix", action="store_true", help="frames only (diagnostic; not the metric)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--workload", choices=["p1", "p3"], default="p1",
+                    help="p1 = BASELINE config 3 (the metric); p3 = the sequencer-driven patch of scope row (f)1, two output planes (diagnostic)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the mix reduce even with one rank (smoke-tests the N > 1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
@@ -115,11 +117,20 @@ def main():
 
     V, T, C = args.voices, args.samples, 2
     p = S.Patch(48000, 1024, C)
-    ids = S.build_p1(p)
-    p.configure_voices(V)
-    det, cut = S.p1_voice_params(V, first_voice=rank * V)  # global voice index => same draw as the 1-GPU run
-    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
-    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    if args.workload == "p1":
+        ids = S.build_p1(p)
+        p.configure_voices(V)
+        det, cut = S.p1_voice_params(V, first_voice=rank * V)  # global voice index => same draw as the 1-GPU run
+        p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+        p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+        what = "BASELINE config 3 per GPU (config 5 at 8 GPUs): patch P1 saw VCO->ladder VCF->ADSR->VCA"
+    else:
+        ids = S.build_p3(p)
+        p.configure_voices(V)
+        u0, u1 = S.voice_uniform(V, 0, first_voice=rank * V), S.voice_uniform(V, 1, first_voice=rank * V)
+        p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, (u0 * np.float32(2.5) - np.float32(2.0)).astype(np.float32))
+        p.set_voice_field(ids["vcf"], S.VCF_FREQ, (np.float32(0.05) + u1 * np.float32(0.35)).astype(np.float32))
+        what = "patch P3 (diagnostic): clock -> grid + pattern sequencers -> per-voice transposed saw VCO -> VCF swept by an envelope -> VCA, raw gate on channel 2"
     n_planes, _ = p.planes()
 
     frames = None if args.no_frames else torch.empty((n_planes, T, V), dtype=torch.float32, device=dev)
@@ -157,7 +168,7 @@ def main():
         # a step may be several launches of the render kernel (chunks that pipeline against the control program):
         # roofline figures are per launch, like rocprofv3's per-kernel average
         launches_per_step = max(1, n_launch // max(1, args.steps))
-        bytes_per_launch = BYTES_PER_VOICE_SAMPLE * V * T / launches_per_step
+        bytes_per_launch = BYTES_PER_VOICE_SAMPLE * n_planes * V * T / launches_per_step  # one f32 per voice-sample per distinct output plane
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
             "metric": "voice-samples/sec @48 kHz offline render",
@@ -169,9 +180,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "BASELINE config 3 per GPU (config 5 at 8 GPUs): patch P1 saw VCO->ladder VCF->ADSR->VCA, "
-                            f"{V} voices/GPU with per-voice randomised detune/cutoff, {T} samples/step @48 kHz, "
-                            "f32 frames [T][V] in HBM + stereo mix-down" + (" + RCCL reduce of the [2][T] mix" if use_dist else ""),
+                "workload": what + f", {V} voices/GPU with per-voice randomised "
+                            + ("detune/cutoff" if args.workload == "p1" else "transpose/cutoff") + f", {T} samples/step @48 kHz, "
+                            f"f32 frames [{n_planes}][T][V] in HBM + stereo mix-down" + (" + RCCL reduce of the [2][T] mix" if use_dist else ""),
                 "voices_per_gpu": V, "samples_per_step": T, "buffer_size": 1024, "render_flags": args.flags,
                 "arithmetic": "f32 wires and modules; oscillator phase accumulator in f64 (as the reference)",
                 "frames_written": frames is not None, "mix_down": not args.no_mix, "program": p.info(),
@@ -187,11 +198,11 @@ def main():
             },
         }
         kname = p.info().split("kernel=")[-1] if "kernel=" in p.info() else ""
-        tr = measured_traffic(kname, V, T) if args.flags == 0 and frames is not None and not args.no_mix else None
+        tr = measured_traffic(kname, V, T) if args.workload == "p1" and args.flags == 0 and frames is not None and not args.no_mix else None
         if tr:
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
             out["roofline"]["traffic_detail"] = tr
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and args.workload == "p1":
             out["cpu_baseline"] = cpu_baseline(S)
     if use_dist:
         dist.barrier()

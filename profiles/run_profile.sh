@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round.  Run ON THE GPU BOX from the repo root:
-#   bash profiles/run_profile.sh r01
+#   bash profiles/run_profile.sh r01                        (the metric: BASELINE config 3)
+#   bash profiles/run_profile.sh r01_p3 "--workload p3"    (any extra bench.py arguments)
 # Pass 1: kernel trace + stats (per-kernel durations).  Passes 2..: PMC counters, each in its own run
 # (never combined with other trace domains).  Output lands in gpurun_out/prof_<tag>/ and the summaries
 # are condensed into profiles/<tag>_*.{csv,json} by profiles/summarize.py.
@@ -10,7 +11,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu"
+BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu ${2:-}"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq.log 2>&1
