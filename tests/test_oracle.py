@@ -468,3 +468,22 @@ def test_pow2_libm_formula_matches_glibc():
     mine = p.astype(np.float32)
     ref = np.array([libm.powf(2.0, float(v)) for v in y], dtype=np.float32)
     np.testing.assert_array_equal(bits(mine), bits(ref))
+
+
+# ---- random patches: the two restatements agree bit for bit on graphs nobody hand-picked -----------------------------
+@pytest.mark.parametrize("seed", range(80))
+def test_random_patches_c_equals_numpy(oracle, seed):
+    from tests.fuzz_patches import random_patch
+    B, build, overrides = random_patch(seed)
+    T = 500 if B < 1024 else 1300
+    g = oracle.OraclePatch(48000, B, 2)
+    ids = build(g)
+    ng = NumpyGraph(48000, B, 2)
+    build(ng)
+    for m, f, fn in overrides:  # one voice: voice 3's draw
+        v = float(fn(8)[3])
+        g.set_field(ids[m], f, v)
+        ng.set_field(ids[m], f, v)
+    assert g.plan() == ng.plan()[0]
+    a, b = g.render(T), ng.render(T)
+    np.testing.assert_array_equal(bits(a), bits(b))

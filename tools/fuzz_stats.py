@@ -2,7 +2,7 @@ import sys, numpy as np, importlib.util
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 import srack_pkg
 from oracle import oracle as O
-spec = importlib.util.spec_from_file_location("fz", "tests/test_gpu_fuzz.py"); fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+from tests import fuzz_patches as fz
 S = srack_pkg.load()
 tot=0; exact=0; worst=0; nonsilent=0
 for seed in range(160):
