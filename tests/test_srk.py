@@ -297,3 +297,19 @@ def test_loaded_p1_renders_like_the_api_built_patch(S):
     b = p.render_channels(3000)
     np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
     assert np.abs(a).max() > 0.05
+
+
+@pytest.mark.parametrize("seed", range(25))
+def test_random_patches_roundtrip(S, seed):
+    """Random graphs (tests/fuzz_patches.py: cycles, sequencer grids, waves): two loads give back the file byte for byte."""
+    from tests.fuzz_patches import random_patch
+    B, build, _ = random_patch(seed)
+    p = S.Patch(48000, B, 2)
+    build(p)
+    raw = p.save_srk()
+    q = S.Patch.load_srk(raw, 48000, B, 2)
+    assert _describe(q) == _describe(p)[::-1]
+    r = S.Patch.load_srk(q.save_srk(), 48000, B, 2)
+    assert _describe(r) == _describe(p) and r.save_srk() == raw
+    assert r.plan() == p.plan()
+    msgpack.unpackb(raw, raw=False, strict_map_key=False)   # and an independent decoder accepts it
