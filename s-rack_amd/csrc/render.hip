@@ -340,7 +340,9 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
     };
     // chunk schedule: short first chunks (only control chunk 0 is exposed), doubling up to kChunkMax
     // With a control pipeline of depth L the first voice chunk waits for L + 1 control launches: those stay short.
-    constexpr uint32_t kChunkFirst = 1024, kChunkMax = 8192;
+    constexpr uint32_t kChunkFirst = 1024;
+    uint32_t kChunkMax = 4096;  // measured on the headline workload: 4096 -> 13.98, 8192 -> 14.14, 16384 -> 14.8 ms per step
+    if (const char* e = getenv("SRACK_CHUNK_MAX")) kChunkMax = (uint32_t)atoi(e);  // tuning knob (tools/)
     uint32_t max_lag = 0;
     for (int lag : h.prog.ctl_lag) max_lag = std::max(max_lag, (uint32_t)lag);
     std::vector<std::pair<uint32_t, uint32_t>> chunks;       // (t_off, len)
