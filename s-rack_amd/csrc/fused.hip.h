@@ -721,8 +721,9 @@ constexpr uint32_t kMixSplit = 16;
 struct MixArgs {
     const float* mixpart;   // [planes][n_waves][T]
     float* mixgroup;        // [planes][kMixSplit][T]
-    float* mix;             // [channels][T]
+    float* mix;             // [channels][mix_stride], T samples of it
     uint32_t T, n_waves, n_channels, n_planes;
+    uint32_t mix_stride;    // samples between channels of `mix` (the whole render's length; T is one segment of it)
     int32_t channel_plane[8];
 };
 
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(256) void mix_reduce_final(MixArgs m)
         float s = 0.0f;
         if (plane >= 0)
             for (uint32_t y = 0; y < kMixSplit; y++) s += m.mixgroup[((size_t)plane * kMixSplit + y) * m.T + i];
-        m.mix[(size_t)c * m.T + i] = s;
+        m.mix[(size_t)c * m.mix_stride + i] = s;
     }
 }
 

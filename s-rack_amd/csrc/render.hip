@@ -289,14 +289,14 @@ static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t 
 // How a render is scheduled.  Without a control program: one launch of the voice kernel.  With one: the
 // render is cut into chunks; control chunk k (one wave, a latency chain) runs on its own stream and voice
 // chunk k waits only for it, so all but the first control chunk hide behind voice kernels of earlier chunks.
-int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_mix, uint32_t flags, void* stream)
+// One segment [t_seg, t_seg + T) of a render of T_total samples.  d_frames / d_mix point at the WHOLE render's buffers.
+static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint32_t T, float* d_frames, float* d_mix, uint32_t flags, hipStream_t st)
 {
-    int rc = ensure_program(h, flags);
-    if (rc != SRACK_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
+    int rc = SRACK_OK;
     const FlatProgram& P = h.prog.voice;
-    const uint32_t V = P.n_voices, T = n_samples, C = (uint32_t)P.hdr.n_channels;
-    if (T == 0) return SRACK_OK;
+    const uint32_t V = P.n_voices, C = (uint32_t)P.hdr.n_channels;
+    if (d_frames) d_frames += (size_t)t_seg * V;
+    if (d_mix) d_mix += t_seg;
     if (!h.dev) {
         rc = upload_program(h);
         if (rc != SRACK_OK) return rc;
@@ -314,10 +314,9 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
     const uint32_t n_waves = (V + lanes - 1) / lanes;
 
     if (P.hdr.n_planes == 0) {  // nothing reaches the output: silence (output.rs:55)
-        if (d_mix) {
-            size_t n = (size_t)C * T;
-            hipLaunchKernelGGL(fill_zero, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_mix, n);
-        }
+        if (d_mix)
+            for (uint32_t c = 0; c < C; c++)
+                hipLaunchKernelGGL(fill_zero, dim3((T + 255) / 256), dim3(256), 0, st, d_mix + (size_t)c * T_total, (size_t)T);
         h.samples_rendered += T;
         return SRACK_OK;
     }
@@ -510,7 +509,7 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         ka.frames = d_frames ? d_frames + (size_t)t_off * V : nullptr;
         ka.mixpart = d_mix ? d->d_mixpart + t_off : nullptr;
         ka.tracks = has_ctl ? d->d_tracks + t_off : nullptr;
-        ka.plane_stride = (uint64_t)T * V;
+        ka.plane_stride = (uint64_t)T_total * V;
         ka.t_stride = T;
         ka.V = V;
         ka.T = len;
@@ -563,6 +562,7 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         m.mixgroup = d->d_mixgroup;
         m.mix = d_mix;
         m.T = T;
+        m.mix_stride = T_total;
         m.n_waves = n_waves;
         m.n_channels = C;
         m.n_planes = (uint32_t)P.hdr.n_planes;
@@ -573,6 +573,24 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
     }
     h.samples_rendered += T;
     return SRACK_OK;
+}
+
+// A render is cut into segments of at most kSegment samples so that the scratch it needs (per-wave mix partials
+// [planes][V/64][T], control tracks [n_tracks][T]) stays bounded however long the render is: 16 MB of partials per
+// 1000 samples at 262 144 voices.  Voice and control state carry over between segments exactly as between calls.
+int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_mix, uint32_t flags, void* stream)
+{
+    int rc = ensure_program(h, flags);
+    if (rc != SRACK_OK) return rc;
+    if (n_samples == 0) return SRACK_OK;
+    if (!h.dev) {
+        rc = upload_program(h);
+        if (rc != SRACK_OK) return rc;
+    }
+    constexpr uint32_t kSegment = 65536;
+    for (uint32_t t = 0; t < n_samples && rc == SRACK_OK; t += kSegment)
+        rc = render_segment(h, n_samples, t, std::min(kSegment, n_samples - t), d_frames, d_mix, flags, (hipStream_t)stream);
+    return rc;
 }
 
 int device_kernel_ms(PatchHandle& h, double* avg_ms, int* n_launches, int reset)

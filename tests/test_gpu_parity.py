@@ -368,10 +368,11 @@ def test_channel_layouts(S, oracle):
             assert not got[2].any() and not mix[2].any()
 
 
-@pytest.mark.parametrize("T", [1, 31, 33, 1023, 1025, 3073, 7169])
+@pytest.mark.parametrize("T", [1, 31, 33, 1023, 1025, 3073, 7169, 65536 + 4097])
 def test_ragged_lengths_across_tiles_and_chunks(S, oracle, T):
-    """Lengths around the 32-sample tile and the 1024/2048/4096-sample chunk borders of the pipelined render."""
-    V = 96
+    """Lengths around the 32-sample tile, the 1024/2048/4096-sample chunk borders of the pipelined render and the
+    65536-sample segments a long render is cut into (bounded scratch)."""
+    V = 96 if T < 65536 else 40
     det, cut = S.p1_voice_params(V, first_voice=99)
     o = oracle.OraclePatch(48000, 1024, 2)
     ids = S.build_p1(o, adsr="finite", lfo_val=1.0)
@@ -382,7 +383,12 @@ def test_ragged_lengths_across_tiles_and_chunks(S, oracle, T):
         p.configure_voices(V)
         p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
         p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
-        assert_close(p.render_channels(T, flags)[0], ref[0])
+        fr, mix = p.render(T, flags=flags)
+        assert_close(fr[0], ref[0])
+        if T > 65536:  # the mix of a segmented render lands at the right offsets of [channels][T]
+            want = ref[0].astype(np.float64).sum(axis=1)
+            scale = np.abs(ref[0].astype(np.float64)).sum(axis=1)
+            assert (np.abs(mix[0] - want) <= 2e-5 * np.maximum(scale, 1.0)).all() and np.array_equal(mix[0], mix[1])
 
 
 def test_empty_render_and_output_selection(S):
