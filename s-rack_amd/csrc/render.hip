@@ -352,8 +352,9 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
             len = std::min(len, T - t_off);
             chunks.emplace_back(t_off, len);
         }
-    } else {
-        chunks.emplace_back(0u, T);
+    } else {  // no control program to overlap with, but short launches still win: the waves of a launch stay within a few
+              // samples of each other, so their frame rows land in the same DRAM pages (FM pair 13.2 -> 9.9 ms per step)
+        for (uint32_t t_off = 0; t_off < T; t_off += kChunkMax) chunks.emplace_back(t_off, std::min(kChunkMax, T - t_off));
     }
     const uint32_t n_chunks = (uint32_t)chunks.size();
     auto get_event = [&](hipEvent_t& e) -> int {
