@@ -336,8 +336,8 @@ int srack_patch_delayed_edges(srack_patch* p, int* quads, int cap)
 int srack_voices_configure(srack_patch* p, uint32_t n_voices)
 {
     CHECK_HANDLE(p);
-    if (n_voices == 0) {
-        set_error("voices_configure: n_voices must be >= 1");
+    if (n_voices == 0 || n_voices > (1u << 24)) {  // a tile of 32 frame rows (32 * V * 4 bytes) must fit a 31-bit buffer offset
+        set_error("voices_configure: n_voices must be 1 .. 16777216");
         return SRACK_ERR_INVALID;
     }
     p->h.n_voices = n_voices;

@@ -22,7 +22,12 @@ constexpr int kMixRows = 32;
 // store needs no exec mask.  Mix: the sample goes into a 32-row LDS tile; every 32 samples (and at the end)
 // the rows are summed over the 64 lanes (tile_row_sum) and one lane per row writes the wave's partial.
 struct Emit {
-    float* frame_row;   // wave-uniform
+    float* frame_row;   // wave-uniform: this wave's 256 B of the current TILE's first frame row
+    // Frames leave through a buffer store: descriptor (SGPRs, rebuilt per tile) + per-lane byte offset (a constant VGPR) +
+    // scalar row offset advanced by V * 4 per sample — no vector arithmetic per store (a global_store needs a 64-bit
+    // v_lshl_add per sample to form its address).
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t soff;      // byte offset of the current row inside the tile
     float* mp;          // wave-uniform: mixpart row of this wave
     bool has_frames, has_mix, full_wave;
     int lane, lane_c;
@@ -35,16 +40,27 @@ SRK_DEV void emit_put(Emit& e, float* mix_tile, float o, int i, uint32_t V)  // 
     const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
     const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
     if (frames) {
-        __builtin_nontemporal_store(o, &e.frame_row[e.lane_c]);  // write-once stream: keep it out of the L2's way
-        e.frame_row += V;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), e.rsrc, e.lane_c * 4, (int)e.soff, 2 /* nt: write-once stream */);
+        e.soff += V * 4u;
     }
     if (mix) mix_tile[i * 64 + e.lane] = o;
 }
 
+SRK_DEV void emit_rebase(Emit& e)  // point the descriptor at frame_row; a tile spans at most 32 rows = 32 * V * 4 bytes
+{
+    e.rsrc = __builtin_amdgcn_make_buffer_rsrc(e.frame_row, 0, 0x7fffffff, 0x00020000);
+    e.soff = 0u;
+}
+
 template <int kOut>
-SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n)  // the tile holds samples t0 .. t0+n-1
+SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n, uint32_t V)  // the tile holds samples t0 .. t0+n-1
 {
     using dev::tile_row_sum;
+    const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
+    if (frames) {
+        e.frame_row += (size_t)n * V;
+        emit_rebase(e);
+    }
     const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
     if (!mix) return;
     if (!e.full_wave && (uint32_t)e.lane >= e.n_active)  // shadow lanes contribute nothing to the mix
@@ -70,6 +86,7 @@ SRK_DEV Emit make_emit(const KernelArgs& a, int plane, int lane)
     e.mp = a.mixpart ? a.mixpart + ((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride : nullptr;
     e.has_frames = e.frame_row != nullptr;
     e.has_mix = e.mp != nullptr;
+    emit_rebase(e);
     return e;
 }
 
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
                 gate = gate_next;
             }
         }
-        emit_flush<kOut>(em, mix_tile, t0, n);
+        emit_flush<kOut>(em, mix_tile, t0, n, V);
     }
     if (!kExact) {
         sa.pos = pos_a;
@@ -429,7 +446,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
         } else {
             for (int i = 0; i < n; i++) sample(i);
         }
-        emit_flush<kOut>(em, mix_tile, t0, n);
+        emit_flush<kOut>(em, mix_tile, t0, n, V);
         env_tile = env_next;
     }
     if (!kExact) {
@@ -519,12 +536,14 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
     Emit em = make_emit(a, plane, lane);
     float* extra_row[4] = {nullptr, nullptr, nullptr, nullptr};   // frame rows of the track-fed planes (wave-uniform)
     float* extra_mp[4] = {nullptr, nullptr, nullptr, nullptr};    // ... and their mix partials
+    __amdgpu_buffer_rsrc_t extra_rsrc[4];
     const float* extra_track[4] = {env_track, env_track, env_track, env_track};
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         if (e >= r.n_extra) continue;
         extra_track[e] = a.tracks + (size_t)r.extra_trk[e] * a.t_stride;
         if (a.frames) extra_row[e] = a.frames + (size_t)r.extra_plane[e] * a.plane_stride + wm.wave0;
+        extra_rsrc[e] = __builtin_amdgcn_make_buffer_rsrc(extra_row[e], 0, 0x7fffffff, 0x00020000);
         if (a.mixpart) extra_mp[e] = a.mixpart + ((size_t)r.extra_plane[e] * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride;
     }
 
@@ -584,10 +603,9 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
             emit_put<kOut>(em, mix_tile, o, i, V);
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                if (e < r.n_extra && extra_row[e]) {
+                if (e < r.n_extra && extra_row[e]) {  // same tile-relative row offset as the main plane (em.soff was just advanced)
                     const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(extra_tile[e]), i));
-                    __builtin_nontemporal_store(v, &extra_row[e][em.lane_c]);
-                    extra_row[e] += V;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), extra_rsrc[e], em.lane_c * 4, (int)(em.soff - V * 4u), 2);
                 }
         };
         const bool in_tile = (int)l32 < n;
@@ -611,7 +629,13 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
             have_cut = true;
             seen_cut = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cut_tile), n - 1);
         }
-        emit_flush<kOut>(em, mix_tile, t0, n);
+        emit_flush<kOut>(em, mix_tile, t0, n, V);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (e < r.n_extra && extra_row[e]) {
+                extra_row[e] += (size_t)n * V;
+                extra_rsrc[e] = __builtin_amdgcn_make_buffer_rsrc(extra_row[e], 0, 0x7fffffff, 0x00020000);
+            }
 #pragma unroll
         for (int e = 0; e < 4; e++)  // every voice carries the same sample: the wave's partial is count x sample
             if (e < r.n_extra && extra_mp[e] && lane < n) extra_mp[e][t0 + lane] = (float)em.n_active * extra_tile[e];
@@ -697,7 +721,7 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
             fed = cur;
             emit_put<kOut>(em, mix_tile, out, i, V);
         }
-        emit_flush<kOut>(em, mix_tile, t0, n);
+        emit_flush<kOut>(em, mix_tile, t0, n, V);
     }
     sm.pos = pos_m;  // drop the look-ahead step
     if (active) {
