@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
         sv.freq = __uint_as_float(row(s0 + VCF_S_FREQ));
         sv.res = __uint_as_float(row(s0 + VCF_S_RES));
     }
-    if (a.T > 0) vcf_coeffs(sv, vcf_frequency(parv(ov, VCF_P_FREQ), 0.0f, parv(ov, VCF_P_EXP)), vcf_resonance(parv(ov, VCF_P_RES)));
+    if (a.T > 0) vcf_coeffs<!kExact>(sv, vcf_frequency(parv(ov, VCF_P_FREQ), 0.0f, parv(ov, VCF_P_EXP)), vcf_resonance(parv(ov, VCF_P_RES)));
 
     AdsrRegs sd;
     sd.phase = __uint_as_float(row(od.state_row + ADSR_S_PHASE));
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
     sv.b4 = __uint_as_float(row(s0 + VCF_S_B0 + 4));
     sv.freq = __uint_as_float(row(s0 + VCF_S_FREQ));
     sv.res = __uint_as_float(row(s0 + VCF_S_RES));
-    if (a.T > 0) vcf_coeffs(sv, vcf_frequency(parv(ov, VCF_P_FREQ), 0.0f, parv(ov, VCF_P_EXP)), vcf_resonance(parv(ov, VCF_P_RES)));
+    if (a.T > 0) vcf_coeffs<!kExact>(sv, vcf_frequency(parv(ov, VCF_P_FREQ), 0.0f, parv(ov, VCF_P_EXP)), vcf_resonance(parv(ov, VCF_P_RES)));
     const bool negative = parv(oc, VCA_P_NEG) != 0.0f;
 
     Emit em = make_emit(a, plane, lane);
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
     sv.res = __uint_as_float(row(s0 + VCF_S_RES));
     const float vfreq = parv(ov, VCF_P_FREQ), vexp = parv(ov, VCF_P_EXP), vres = vcf_resonance(parv(ov, VCF_P_RES));
     const uint32_t vport = ov.flags & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP);
-    if (!has_cut && a.T > 0) vcf_coeffs(sv, vcf_frequency(vfreq, 0.0f, vexp), vres);
+    if (!has_cut && a.T > 0) vcf_coeffs<true>(sv, vcf_frequency(vfreq, 0.0f, vexp), vres);
     const bool negative = parv(oc, VCA_P_NEG) != 0.0f;
 
     Emit em = make_emit(a, plane, lane);
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
             }
             if (has_cut && !steady_cut) {  // vcf_coeffs itself recomputes only for lanes whose (frequency, res) changed
                 const float cutv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cut_tile), i));
-                vcf_coeffs(sv, vcf_frequency(vfreq, cutv, vexp), vres);
+                vcf_coeffs<true>(sv, vcf_frequency(vfreq, cutv, vexp), vres);
             }
             float lp, bp, hp;
             vcf_step<true>(sv, x, lp, bp, hp);

@@ -283,18 +283,18 @@ __device__ __noinline__ void tile_vcf(const Ctx c_v, COp& op_v)
         if (one)
             tile_run<2, 1>(c, in, w, [&](const float* x, float* y) {
                 float lp, bp, hp;
-                vcf_coeffs(s, vcf_frequency(freq, x[1], exp_amt), res);
+                vcf_coeffs<!kExact>(s, vcf_frequency(freq, x[1], exp_amt), res);
                 vcf_step<!kExact>(s, x[0], lp, bp, hp);
                 y[0] = pick(lp, bp, hp);
             });
         else
             tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
-                vcf_coeffs(s, vcf_frequency(freq, x[1], exp_amt), res);
+                vcf_coeffs<!kExact>(s, vcf_frequency(freq, x[1], exp_amt), res);
                 vcf_step<!kExact>(s, x[0], y[0], y[1], y[2]);
             });
     } else {
         // constant cutoff: the "did (frequency, res) change" check can only fire on the first sample
-        vcf_coeffs(s, vcf_frequency(freq, 0.0f, exp_amt), res);
+        vcf_coeffs<!kExact>(s, vcf_frequency(freq, 0.0f, exp_amt), res);
         const Port audio[1] = {in[0]};
         if (one)
             tile_run<1, 1>(c, audio, w, [&](const float* x, float* y) {

@@ -6,8 +6,10 @@
 // compile-time constant and every `if (flags & ...)` folds away.
 //
 // Numerics contract (build: -ffp-contract=off, f32 denormals on, correctly rounded f32 divide):
-//   * VCF / ADSR / VCA / mixer / math: the same IEEE f32 operations in the same order as the
-//     reference => bit-identical to the CPU tick given identical inputs.
+//   * ADSR / VCA / mixer / math / sequencers: the same IEEE f32 operations in the same order as the
+//     reference => bit-identical to the CPU tick given identical inputs.  The ladder filter likewise in
+//     the exact mode; in the default mode its multiply-subtract pairs are fma-contracted and its clamps
+//     are v_med3 (vcf_step<kFast>): ~1e-7 relative, inside the 1e-5 contract.
 //   * oscillator phase: f64 accumulate + exact wrap => bit-identical `pos` whenever delta is
 //     (constant pitch: delta is computed on the host with glibc pow, like the reference).
 //   * oscillator outputs, default mode: PolyBLEP and sine evaluated in f32 from f64-exact phase
@@ -312,15 +314,24 @@ SRK_DEV float clamp1(float x)
     return fmaxf(fminf(x, 1.0f), -1.0f);
 }
 
-// filter.rs:61-68 — recompute only when (frequency, res) changed
+// filter.rs:61-68 — recompute only when (frequency, res) changed.  kFast folds the polynomials' multiply-adds into fmas
+// (10 instructions instead of 14; matters when an envelope sweeps the cutoff and the coefficients change every sample).
+template <bool kFast = false>
 SRK_DEV void vcf_coeffs(VcfRegs& s, float frequency, float res)
 {
     const bool changed = frequency != s.freq || res != s.res;
     if (__builtin_amdgcn_ballot_w64(changed) != 0) {  // wave-uniform skip; lanes whose pair is unchanged keep their coefficients
         const float q = 1.0f - frequency;
-        const float p = frequency + 0.8f * frequency * q;
-        const float f = p * 2.0f - 1.0f;
-        const float qq = res * (1.0f + 0.5f * q * (1.0f - q + 5.6f * q * q));
+        float p, f, qq;
+        if (kFast) {
+            p = __builtin_fmaf(0.8f * frequency, q, frequency);
+            f = __builtin_fmaf(p, 2.0f, -1.0f);
+            qq = res * __builtin_fmaf(0.5f * q, __builtin_fmaf(5.6f * q, q, 1.0f - q), 1.0f);
+        } else {
+            p = frequency + 0.8f * frequency * q;
+            f = p * 2.0f - 1.0f;
+            qq = res * (1.0f + 0.5f * q * (1.0f - q + 5.6f * q * q));
+        }
         s.freq = changed ? frequency : s.freq;
         s.res = changed ? res : s.res;
         s.p = changed ? p : s.p;
@@ -329,24 +340,42 @@ SRK_DEV void vcf_coeffs(VcfRegs& s, float frequency, float res)
     }
 }
 
-// filter.rs:69-82 — returns lowpass; band/highpass through references (caller stores only live ports)
-template <bool kMed3 = false>
+// filter.rs:69-82 — returns lowpass; band/highpass through references (caller stores only live ports).
+// kFast = false: the reference's f32 operations one by one, each rounded (bit-identical to the CPU tick given identical
+// inputs; the exact render mode).  kFast = true (default mode): every `a * b - c * d` / `x - a * b` of the ladder keeps
+// one product and folds the other into an fma — one rounding less per stage, i.e. closer to the real-number result than
+// the reference itself, 6 of the filter's 27 instructions saved — and the clamps are v_med3.  The ladder is a damped
+// recurrence (poles inside the unit circle, states clamped to [-1, 1]), so a 1-ulp difference per stage does not grow:
+// the GPU tests hold default-mode renders to 1e-5 of the oracle over full-second renders.
+template <bool kFast = false>
 SRK_DEV void vcf_step(VcfRegs& s, float input, float& lowpass, float& bandpass, float& highpass)
 {
-    input = input - (s.q * s.b4);
-    float t1 = s.b1;
-    s.b1 = (input + s.b0) * s.p - s.b1 * s.f;
-    float t2 = s.b2;
-    s.b2 = (s.b1 + t1) * s.p - s.b2 * s.f;
-    t1 = s.b3;
-    s.b3 = (s.b2 + t2) * s.p - s.b3 * s.f;
-    s.b4 = (s.b3 + t1) * s.p - s.b4 * s.f;
-    s.b4 = s.b4 - (s.b4 * s.b4 * s.b4) * 0.166667f;
-    s.b0 = clamp1<kMed3>(input);
-    s.b1 = clamp1<kMed3>(s.b1);
-    s.b2 = clamp1<kMed3>(s.b2);
-    s.b3 = clamp1<kMed3>(s.b3);
-    s.b4 = clamp1<kMed3>(s.b4);
+    if (kFast) {
+        input = __builtin_fmaf(-s.q, s.b4, input);
+        float t1 = s.b1;
+        s.b1 = __builtin_fmaf(input + s.b0, s.p, -(s.b1 * s.f));
+        float t2 = s.b2;
+        s.b2 = __builtin_fmaf(s.b1 + t1, s.p, -(s.b2 * s.f));
+        t1 = s.b3;
+        s.b3 = __builtin_fmaf(s.b2 + t2, s.p, -(s.b3 * s.f));
+        s.b4 = __builtin_fmaf(s.b3 + t1, s.p, -(s.b4 * s.f));
+        s.b4 = __builtin_fmaf(-(s.b4 * s.b4 * s.b4), 0.166667f, s.b4);
+    } else {
+        input = input - (s.q * s.b4);
+        float t1 = s.b1;
+        s.b1 = (input + s.b0) * s.p - s.b1 * s.f;
+        float t2 = s.b2;
+        s.b2 = (s.b1 + t1) * s.p - s.b2 * s.f;
+        t1 = s.b3;
+        s.b3 = (s.b2 + t2) * s.p - s.b3 * s.f;
+        s.b4 = (s.b3 + t1) * s.p - s.b4 * s.f;
+        s.b4 = s.b4 - (s.b4 * s.b4 * s.b4) * 0.166667f;
+    }
+    s.b0 = clamp1<kFast>(input);
+    s.b1 = clamp1<kFast>(s.b1);
+    s.b2 = clamp1<kFast>(s.b2);
+    s.b3 = clamp1<kFast>(s.b3);
+    s.b4 = clamp1<kFast>(s.b4);
     lowpass = s.b4;
     highpass = input - s.b4;
     bandpass = 3.0f * (s.b3 - s.b4);
