@@ -1,6 +1,7 @@
 // capi.cpp — the extern "C" boundary declared in include/srack_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -423,7 +424,10 @@ int srack_voices_get_field(srack_patch* p, int module, int field, double* values
         const uint32_t sv = ctl ? 0u : v;
         if (loc.f64) {
             uint64_t u = (uint64_t)rows[sv] | ((uint64_t)rows[(size_t)V + sv] << 32);
-            std::memcpy(&values[v], &u, 8);
+            if (loc.fixed64)
+                values[v] = std::ldexp((double)u, -64);  // phase * 2^64 (the fused kernel's fixed-point oscillator)
+            else
+                std::memcpy(&values[v], &u, 8);
         } else if (loc.flag) {
             values[v] = (double)(int32_t)rows[sv];
         } else {

@@ -718,7 +718,38 @@ void Builder::match_fused(bool has_rings)
         if (ok) out.fused = FUSED_VOICE_CHAIN;
     } else {
         ok = A.in_ctl[(size_t)src_of(vca->module, 1).src] && vca->in_slot[1] >= kTrackSlot;
-        if (ok) out.fused = FUSED_VOICE_CHAIN_TRACK;
+        if (ok) {
+            out.fused = FUSED_VOICE_CHAIN_TRACK;
+            // Default mode, saw port: the kernel keeps the oscillator phase in 64-bit fixed point (modules.hip.h, FOsc).
+            // State and increment change representation here, once: phase * 2^64 as u64 in the same two rows.
+            DevOp& osc = out.ops[(size_t)out.op_of_module[(size_t)src_of(vcf->module, 0).src]];
+            if ((osc.flags & OSC_OUT_SAW) && !(osc.flags & OSC_EXACT)) {
+                auto to_fixed = [](double x) {  // x in [0, 1): exact whenever x has no bits below 2^-64
+                    const double y = std::ldexp(x - std::floor(x), 64);
+                    return y >= 18446744073709551616.0 ? ~0ull : (uint64_t)y;
+                };
+                auto convert_rows = [&](int lo_row) {
+                    uint32_t* lo = &out.table[(size_t)lo_row * V];
+                    uint32_t* hi = &out.table[(size_t)(lo_row + 1) * V];
+                    for (uint32_t v = 0; v < V; v++) {
+                        const uint64_t bits = ((uint64_t)hi[v] << 32) | lo[v];
+                        double d;
+                        std::memcpy(&d, &bits, 8);
+                        const uint64_t f = to_fixed(d);
+                        lo[v] = (uint32_t)f;
+                        hi[v] = (uint32_t)(f >> 32);
+                    }
+                };
+                osc.flags |= OSC_FIXED_PHASE;
+                convert_rows(osc.state_row + OSC_S_POS_LO);
+                if (osc.delta_row >= 0) {
+                    convert_rows(osc.delta_row);
+                } else {
+                    const uint64_t f = to_fixed(osc.delta);
+                    std::memcpy(&osc.delta, &f, 8);
+                }
+            }
+        }
     }
 }
 
@@ -738,6 +769,7 @@ StateLoc FlatProgram::locate(const Graph& g, int module, int field) const
         if (field == SRACK_OSC_POS) {
             loc.row = op.state_row + OSC_S_POS_LO;
             loc.f64 = true;
+            loc.fixed64 = (op.flags & OSC_FIXED_PHASE) != 0;
         } else {
             loc.row = op.state_row + OSC_S_SYNC_LAST;
             loc.flag = true;

@@ -26,6 +26,7 @@ enum FusedKind : int {
 struct StateLoc {  // where a module's state field lives in the voice table
     int row = -1;   // first row (-1: field is not device state)
     bool f64 = false;
+    bool fixed64 = false;  // two rows holding value * 2^64 as u64 (OSC_FIXED_PHASE)
     bool flag = false;
 };
 

@@ -407,10 +407,20 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
 
     Emit em = make_emit(a, plane, lane);
 
+    // default mode, saw: the phase lives in 64-bit fixed point (modules.hip.h, FOsc); the host stores state and increment so
+    constexpr bool kFixed = !kExact && kOscAPort == OSC_OUT_SAW;
     COsc ca;
+    FOsc fa_osc;
     float x = 0.0f;
     double pos_a = sa.pos;
-    if (!kExact) {
+    uint32_t fpos_lo = 0u, fpos_hi = 0u;
+    if (kFixed) {
+        const uint64_t dbits = oa.delta_row >= 0 ? ((uint64_t)row(oa.delta_row + 1) << 32) | row(oa.delta_row) : (uint64_t)__double_as_longlong(oa.delta);
+        fosc_init(fa_osc, row(oa.state_row + OSC_S_POS_LO), row(oa.state_row + OSC_S_POS_HI), (uint32_t)dbits, (uint32_t)(dbits >> 32));
+        fpos_lo = fa_osc.lo;
+        fpos_hi = fa_osc.hi;
+        if (a.T > 0) x = fosc_saw(fa_osc);
+    } else if (!kExact) {
         cosc_init(ca, sa.pos, ka.delta);
         if (a.T > 0) x = cosc_step<kOscAPort>(ca);
     }
@@ -430,7 +440,11 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
             float lp, bp, hp;
             vcf_step<!kExact>(sv, x, lp, bp, hp);
             const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
-            if (!kExact) {
+            if (kFixed) {
+                fpos_lo = fa_osc.lo;
+                fpos_hi = fa_osc.hi;
+                x = fosc_saw(fa_osc);  // sample t+1
+            } else if (!kExact) {
                 pos_a = ca.pos;
                 x = cosc_step<kOscAPort>(ca);  // sample t+1
             }
@@ -455,8 +469,8 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
     }
     if (active) {
         auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
-        put(oa.state_row + OSC_S_POS_LO, f64_lo(sa.pos));
-        put(oa.state_row + OSC_S_POS_HI, f64_hi(sa.pos));
+        put(oa.state_row + OSC_S_POS_LO, kFixed ? fpos_lo : f64_lo(sa.pos));
+        put(oa.state_row + OSC_S_POS_HI, kFixed ? fpos_hi : f64_hi(sa.pos));
         put(oa.state_row + OSC_S_SYNC_LAST, sa.sync_last ? 1u : 0u);
         put(s0 + VCF_S_F, __float_as_uint(sv.f));
         put(s0 + VCF_S_P, __float_as_uint(sv.p));

@@ -29,11 +29,20 @@ struct WaveMap {   // which voices a wave owns
     bool active;
 };
 
+// Which group of `lanes` voices this workgroup owns.  (Tried: an XCD-aware map — workgroups are dealt to the 8 XCDs
+// round-robin, so give XCD k the k-th contiguous eighth of the voices and let neighbouring 256-B pieces of a frame row
+// leave through the same L2.  No measurable difference on the headline workload: 12.4 ms per step either way.)
+template <class Args>
+SRK_DEV uint32_t wave_index(const Args& a)
+{
+    return blockIdx.x - a.block0;
+}
+
 template <class Args>
 SRK_DEV WaveMap wave_map(const Args& a, int lane)
 {
     WaveMap m;
-    m.wave0 = (blockIdx.x - a.block0) * a.lanes;
+    m.wave0 = wave_index(a) * a.lanes;
     m.n_active = min(a.lanes, a.V - m.wave0);
     m.active = (uint32_t)lane < m.n_active;
     m.voice = m.wave0 + (uint32_t)lane;
@@ -565,7 +574,7 @@ __device__ __noinline__ void tile_out(const Ctx c_v, COp& op_v, CArgs& a_v, uint
     if (a.mixpart) {
         float* mp = a.mixpart + ((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride + t0;
         if (slot >= kTrackSlot) {  // identical voices: the wave's partial is (number of real voices) x sample
-            if (c.lane < c.n) mp[c.lane] = (float)min(a.lanes, a.V - (blockIdx.x - a.block0) * a.lanes) * in.p[c.lane];
+            if (c.lane < c.n) mp[c.lane] = (float)min(a.lanes, a.V - wave_index(a) * a.lanes) * in.p[c.lane];
             return;
         }
         if (!active)

@@ -296,6 +296,59 @@ SRK_DEV float cosc_step(COsc& o)
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same constant-pitch saw with the phase in 64-bit FIXED POINT (pos = phase * 2^64) — default mode of the fused
+// voice kernels only (OSC_FIXED_PHASE, set by the host).  The reference accumulates the phase in f64 and wraps with
+// fmod; on this hardware that is a v_add_f64, a v_fract_f64 and a v_cvt_f32_f64 per sample, each at half rate or less:
+// 6 issue slots.  Two 32-bit integer adds and a v_cvt_f32_u32 do the same in 3, and the wrap is the carry.  The two
+// accumulators differ by rounding only: f64 rounds every add to 2^-53 (a random walk of ~2e-14 after a second of
+// audio), fixed point truncates the increment once to 2^-64 (a drift of < 3e-15 after a second) — both 9 orders of
+// magnitude below the 1e-5 contract, and neither is "the" real-number phase.  f32(pos) — the only way the phase reaches
+// the output — is the conversion of the upper 32 bits: the same value up to a double rounding that is itself below
+// f32 resolution.  The exact mode, the interpreter and every gate-producing oscillator keep the f64 phase.
+// ---------------------------------------------------------------------------------------------
+struct FOsc {
+    uint32_t lo, hi;    // pos * 2^64
+    uint32_t dlo, dhi;  // delta * 2^64
+    float c32;          // f32(hi) = f32(pos) * 2^32
+    float ta;           // f32(pos) / dt
+    float inv_s;        // 2^-32 / f32(delta)
+};
+
+SRK_DEV void fosc_init(FOsc& o, uint32_t lo, uint32_t hi, uint32_t dlo, uint32_t dhi)
+{
+    o.lo = lo;
+    o.hi = hi;
+    o.dlo = dlo;
+    o.dhi = dhi;
+    const double delta = __builtin_fma((double)dhi, 0x1p-32, (double)dlo * 0x1p-64);  // exact: 64 bits fit after the fma's single rounding to 53
+    o.inv_s = (1.0f / (float)delta) * 0x1p-32f;
+    o.c32 = (float)hi;
+    o.ta = o.c32 * o.inv_s;
+}
+
+// saw port: as cosc_saw, with the carried terms derived from the upper phase word
+SRK_DEV float fosc_saw(FOsc& o)
+{
+    uint32_t nlo, nhi;
+    const bool c0 = __builtin_add_overflow(o.lo, o.dlo, &nlo);
+    const bool c1 = __builtin_add_overflow(o.hi, o.dhi, &nhi);
+    const bool c2 = __builtin_add_overflow(nhi, (uint32_t)c0, &nhi);
+    const bool wrapped = c1 | c2;                                  // pos + delta >= 1: `pos %= 1.0` is the dropped carry
+    const float cn = (float)nhi;
+    const float tn = cn * o.inv_s;
+    const float base = __builtin_fmaf(o.c32, 0x1p-31f, -1.0f);    // (pos as f32) * 2.0 - 1.0: the power-of-two scale is exact
+    const float u = fmaxf(1.0f - o.ta, 0.0f);
+    const float s1 = __builtin_fmaf(u, u, base);
+    const float s2 = keep(__builtin_fmaf(-tn, tn, s1));
+    const float saw = wrapped ? s2 : s1;
+    o.lo = nlo;
+    o.hi = nhi;
+    o.c32 = cn;
+    o.ta = tn;
+    return saw;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Moog ladder — InternalMoogFilterState::calc + clamp_buffers, filter.rs:58-92
 // ---------------------------------------------------------------------------------------------
 struct VcfRegs {

@@ -40,6 +40,7 @@ enum : uint32_t {
     OSC_CONST_FAST = 1u << 7, // host-proved: no CV, no sync, one live port, PolyBLEP on, every voice's delta < 0.25
                               // => the carried-phase oscillator (modules.hip.h, COsc) may be used
     OSC_CV_AUDIO_RATE = 1u << 8,  // the CV changes every sample (FM): do not bother caching 2^cv per CV value
+    OSC_FIXED_PHASE = 1u << 10,   // pos rows and delta (rows or DevOp::delta's bit pattern) hold phase * 2^64 as u64, not f64 (fused voice kernels, default mode, saw)
     OSC_CV_STEPWISE = 1u << 9,    // host-proved: the CV is a sequencer's note CV (plus constants): constant between steps
     // OP_VCF
     VCF_HAS_AUDIO = 1u << 0,
