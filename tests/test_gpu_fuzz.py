@@ -16,8 +16,10 @@ from tests.fuzz_patches import random_patch  # noqa: E402
 
 
 @pytest.mark.parametrize("seed", range(160))
-def test_random_patch_matches_oracle(seed, oracle):
+def test_random_patch_matches_oracle(seed, oracle, monkeypatch):
     S = srack_pkg.load()
+    if seed % 2:  # few voices normally run as quarter-filled waves (more waves, same cost); odd seeds force the full,
+        monkeypatch.setenv("SRACK_WANT_WAVES", "1")  # 64-lane waves large renders use — with a ragged last wave
     B, build, overrides = random_patch(seed)
     V, T = (67, 1300) if B < 1024 else (131, 2300)  # past the first control chunk (1024) and, at B = 1024, past two ring periods
     o = oracle.OraclePatch(48000, B, 2)
