@@ -38,3 +38,26 @@ def test_random_patch_matches_oracle(seed, oracle, monkeypatch):
         same = fr.view(np.uint32) == ref.view(np.uint32)
         # everything in these patches is bit-exact in exact-oscillator mode (tools/fuzz_stats.py: 960 of 960 renders)
         assert same.all(), f"seed {seed} flags {flags}: {1 - same.mean():.5f} of the samples differ; {p.info()}"
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_patch_renders_continue_across_calls(seed):
+    """State carries over between calls in every mode, default (approximating) modes included: render(T) equals
+    render(a) ++ render(b) ++ render(c) bit for bit, whatever kernels, tiles, chunks and control units the patch got."""
+    S = srack_pkg.load()
+    B, build, overrides = random_patch(seed)
+    rng = np.random.default_rng(1000 + seed)
+    V, T = 70, 2600
+    cuts = sorted(int(c) for c in rng.choice(np.arange(1, T), size=2, replace=False))
+    values = [(m, f, fn(V)) for m, f, fn in overrides]  # drawn once: the generators are stateful
+    for flags in (0, 2, 4, 1):
+        outs = []
+        for parts in ([T], [cuts[0], cuts[1] - cuts[0], T - cuts[1]]):
+            p = S.Patch(48000, B, 2)
+            ids = build(p)
+            p.configure_voices(V)
+            for m, f, vals in values:
+                p.set_voice_field(ids[m], f, vals)
+            outs.append(np.concatenate([p.render_channels(n, flags) for n in parts], axis=1))
+        same = outs[0].view(np.uint32) == outs[1].view(np.uint32)
+        assert same.all(), f"seed {seed} flags {flags} cuts {cuts}: {1 - same.mean():.5f} of the samples differ"
