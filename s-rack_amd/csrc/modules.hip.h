@@ -12,8 +12,8 @@
 //     are v_med3 (vcf_step<kFast>): ~1e-7 relative, inside the 1e-5 contract.
 //   * oscillator phase: f64 accumulate + exact wrap => bit-identical `pos` whenever delta is
 //     (constant pitch: delta is computed on the host with glibc pow, like the reference).
-//   * oscillator outputs, default mode: PolyBLEP and sine evaluated in f32 from f64-exact phase
-//     differences (abs error ~1e-7, inside the 1e-5 contract); OSC_EXACT mode: f64 with true
+//   * oscillator outputs, default mode: PolyBLEP evaluated in f32 from f64-exact phase differences (abs
+//     error ~1e-7, inside the 1e-5 contract); the sine in f64 with one rounding to f32 (sine_fast); OSC_EXACT mode: f64 with true
 //     division / ocml sin / pow exactly as oscillator.rs spells them (saw and square bit-identical).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -113,28 +113,27 @@ SRK_DEV float poly_blep_fast(float t, float tm1, float inv_dt)
     return ta < 1.0f ? fa : hi;
 }
 
-// sin(2*pi*x) for x in [-0.25, 0.25], odd minimax-style polynomial evaluated in f32 (abs err < 6e-8)
-SRK_DEV float sin2pi_quarter(float x)
-{
-    const float c1 = 6.28318530717958647692f, c3 = -41.3417022403997602f, c5 = 81.6052492760750e+0f, c7 = -76.7058597530613f,
-                c9 = 42.0586939448620f, c11 = -15.0946425768229f, c13 = 3.81995258484692f;
-    float x2 = x * x;
-    float p = __builtin_fmaf(c13, x2, c11);
-    p = __builtin_fmaf(p, x2, c9);
-    p = __builtin_fmaf(p, x2, c7);
-    p = __builtin_fmaf(p, x2, c5);
-    p = __builtin_fmaf(p, x2, c3);
-    p = __builtin_fmaf(p, x2, c1);
-    return p * x;
-}
-
-// sin(2*pi*pos), pos in [0,1): reduce around 0.5 in f64 (exact), fold to a quarter wave in f32.
+// sin(2*pi*pos), pos in [0,1), as the reference's `(pos * PI * 2.0).sin() as f32` (oscillator.rs:133) up to the final
+// rounding: folded to a quarter wave exactly (f64 subtractions of values in [-0.5, 0.5]), odd Taylor polynomial of
+// degree 15 in f64 (truncation 6e-12 at |x| = 1/4), ONE rounding to f32.  The result is the correctly rounded f32 sine
+// except within ~1e-11 of a rounding boundary — i.e. it has the reference's own, unbiased, half-ulp error.  That matters
+// because a sine that feeds a pitch CV (FM, vibrato) is INTEGRATED by the next oscillator's phase: an f32 evaluation
+// (6e-8, biased) let config 4 drift to 5e-5 after one second; with this one default mode stays at f32 rounding level.
 SRK_DEV float sine_fast(double pos)
 {
-    float q = (float)(pos - 0.5);                 // [-0.5, 0.5); sin(2 pi pos) = -sin(2 pi q)
-    float r = __builtin_copysignf(0.5f, q) - q;   // reflection: sin(2 pi q) = sin(2 pi r) for |q| > 1/4
-    float x = __builtin_fabsf(q) > 0.25f ? r : q;
-    return -sin2pi_quarter(x);
+    const double q = pos - 0.5;                          // [-0.5, 0.5); sin(2 pi pos) = -sin(2 pi q)
+    const double r = __builtin_copysign(0.5, q) - q;     // reflection: sin(2 pi q) = sin(2 pi r) for |q| > 1/4
+    const double x = __builtin_fabs(q) > 0.25 ? r : q;
+    const double x2 = x * x;
+    double p = -0.7181223017785006;                      // -(2 pi)^15 / 15!
+    p = __builtin_fma(p, x2, 3.819952584848282);         //  (2 pi)^13 / 13!
+    p = __builtin_fma(p, x2, -15.09464257682299);        // -(2 pi)^11 / 11!
+    p = __builtin_fma(p, x2, 42.058693944897655);        //  (2 pi)^9 / 9!
+    p = __builtin_fma(p, x2, -76.70585975306139);        // -(2 pi)^7 / 7!
+    p = __builtin_fma(p, x2, 81.60524927607506);         //  (2 pi)^5 / 5!
+    p = __builtin_fma(p, x2, -41.34170224039976);        // -(2 pi)^3 / 3!
+    p = __builtin_fma(p, x2, 6.283185307179586);         //  2 pi
+    return (float)(-(p * x));
 }
 
 SRK_DEV double wrap01(double x)

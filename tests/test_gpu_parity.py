@@ -170,6 +170,24 @@ def test_cfg4_golden(S, B):
 
 
 # ---- every port of every module type, through the interpreter ---------------------------------------------
+def test_cfg4_full_second_per_voice_params(S, oracle):
+    """Config 4 for the whole second with the per-voice beta / index draw: the modulator's sine drives two pitches, so its
+    error is integrated — default mode has to deliver the reference's own half-ulp sine to stay inside the contract."""
+    V, T = 48, 48000
+    beta, index = S.p2_voice_params(V)
+    for B in (1, 1024):
+        o = oracle.OraclePatch(48000, B, 2)
+        ids = S.build_p2(o)
+        ref, _ = o.render_batch(V, T, [(ids["mul_fb"], S.MATH_CONSTANT, beta), (ids["mul_idx"], S.MATH_CONSTANT, index)], threads=8)
+        for flags in (0, 1):
+            p = S.Patch(48000, B, 2)
+            S.build_p2(p)
+            p.configure_voices(V)
+            p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, beta)
+            p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
+            assert assert_close(p.render_channels(T, flags), ref) < 2e-6
+
+
 def _everything(g):
     lfo, osc, osc2, vcf, adsr, vca, mix, sub, add, vca_neg, out = [g.add_module(t) for t in (1, 1, 1, 2, 3, 4, 5, 6, 6, 4, 0)]
     for m, f, v in ((lfo, 0, -1.5), (osc, 0, 0.25), (osc, 1, 0), (osc2, 0, 1.0 / 12.0), (vcf, 0, 0.35), (vcf, 1, 0.8), (vcf, 2, 0.25),
