@@ -868,6 +868,61 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
         }
     }
 
+    // ---- 2b. approximated ports that drive a pitch ----------------------------------------------------
+    // Default mode evaluates PolyBLEP in f32 and the ladder filter with fma contraction (~1e-7, slightly biased).  Harmless on
+    // the way to the output;
+    // but an oscillator's CV — and the sample player's — is INTEGRATED into a phase, so a biased 1e-7 on a saw or
+    // square that modulates a pitch grows with time (measured: 2e-4 on the carrier's saw after one second of
+    // feed-forward FM from a 1760 Hz saw).  Such patches are rendered with the exact oscillator throughout.  (The sine
+    // port is exempt: its default evaluation already carries the reference's own half-ulp error.)
+    if (!(render_flags & SRACK_RENDER_EXACT_OSC)) {
+        // Which outputs carry an input's VALUE on (as opposed to its sign: gates, sync and step inputs are thresholds)?
+        auto carried_to = [&](int type, int in_port) -> uint32_t {  // mask of output ports
+            switch (type) {
+            case SRACK_MOD_OSCILLATOR: return in_port == SRACK_OSC_IN_CV ? 7u : 0u;
+            case SRACK_MOD_MOOG_FILTER: return 7u;
+            case SRACK_MOD_VCA:
+            case SRACK_MOD_MONO_MIXER:
+            case SRACK_MOD_MATH:
+            case SRACK_MOD_NONLINEAR: return 1u;
+            case SRACK_MOD_SAMPLE: return in_port == SRACK_SAMPLE_IN_CV ? 1u : 0u;
+            case SRACK_MOD_GRID_SEQUENCER: return in_port == SRACK_SEQ_IN_STEP ? 1u << SRACK_GRIDSEQ_OUT_GATE : 0u;  // gate = the clock itself
+            case SRACK_MOD_PATTERN_SEQUENCER: return in_port == SRACK_SEQ_IN_STEP ? 0xffu : 0u;
+            default: return 0u;  // ADSR: the gate is a threshold; OutputModule: a sink
+            }
+        };
+        auto is_pitch_input = [&](int module, int port) {
+            const int t = g.modules[(size_t)module].type;
+            return (t == SRACK_MOD_OSCILLATOR && port == SRACK_OSC_IN_CV) || (t == SRACK_MOD_SAMPLE && port == SRACK_SAMPLE_IN_CV);
+        };
+        std::vector<uint32_t> tainted((size_t)n_mod, 0u);  // per module: output ports that carry an approximated saw / square value
+        for (int m = 0; m < n_mod; m++) {
+            if (!A.live[(size_t)m]) continue;
+            if (g.modules[(size_t)m].type == SRACK_MOD_OSCILLATOR) tainted[(size_t)m] = A.port_live[(size_t)m] & 6u;   // square, saw
+            if (g.modules[(size_t)m].type == SRACK_MOD_MOOG_FILTER) tainted[(size_t)m] = A.port_live[(size_t)m] & 7u;  // the fma-contracted ladder
+        }
+        bool drives_pitch = false;
+        for (bool changed = true; changed && !drives_pitch;) {
+            changed = false;
+            for (int k = 0; k < n_mod && !drives_pitch; k++) {
+                if (!A.live[(size_t)k]) continue;
+                const Module& sink = g.modules[(size_t)k];
+                for (int port = 0; port < sink.n_in; port++) {
+                    const InputRef& in = sink.in[(size_t)port];
+                    if (in.src < 0 || !(tainted[(size_t)in.src] & (1u << in.port))) continue;
+                    if (is_pitch_input(k, port)) drives_pitch = true;
+                    const uint32_t add = carried_to(sink.type, port) & ~tainted[(size_t)k];
+                    if (add) {
+                        tainted[(size_t)k] |= add;
+                        changed = true;
+                    }
+                }
+            }
+        }
+        if (drives_pitch) render_flags |= SRACK_RENDER_EXACT_OSC;
+    }
+    out.effective_flags = render_flags;
+
     // ---- 3. voice-invariant sub-graph ----------------------------------------------------------------
     if (n_voices > 1 && !(render_flags & SRACK_RENDER_NO_UNIFORM_HOIST)) {
         std::vector<char>& u = A.in_ctl;

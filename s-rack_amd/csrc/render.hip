@@ -588,6 +588,7 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         rc = upload_program(h);
         if (rc != SRACK_OK) return rc;
     }
+    flags = h.prog.effective_flags;  // e.g. the exact oscillator forced for a patch whose approximated ports drive a pitch
     constexpr uint32_t kSegment = 65536;
     for (uint32_t t = 0; t < n_samples && rc == SRACK_OK; t += kSegment)
         rc = render_segment(h, n_samples, t, std::min(kSegment, n_samples - t), d_frames, d_mix, flags, (hipStream_t)stream);
