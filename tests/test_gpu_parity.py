@@ -354,6 +354,49 @@ def test_full_size_voices_short_render(S, oracle):
     assert (np.abs(mix[0] - own) <= 1e-5 * np.maximum(scale, 1.0)).all()
 
 
+def test_cfg3_exactly_as_benchmarked(S, oracle):
+    """BASELINE config 3 at full size, the very workload bench.py times: 262 144 voices x 48 000 samples (50 GB of frames,
+    kept on the device), default mode.  67 sampled voices against the oracle for the whole second, and the stereo mix
+    against an f64 sum of all the frames (read back 256 rows at a time)."""
+    import ctypes as C
+    V, T = 262144, 48000
+    det, cut = S.p1_voice_params(V)
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p1(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    d_fr, d_mx = C.c_void_p(), C.c_void_p()
+    assert S.lib.srack_device_alloc(C.byref(d_fr), T * V * 4) == 0 and S.lib.srack_device_alloc(C.byref(d_mx), 2 * T * 4) == 0
+    try:
+        p.render_raw(T, d_fr, d_mx, 0, None)
+        assert S.lib.srack_device_sync(None) == 0
+        assert "kernel=render_voice_chain_track" in p.info()
+        pick = np.unique(np.concatenate([np.arange(0, V, 4099), [0, 63, 64, V - 65, V - 64, V - 1]]))
+        got = np.empty((T, len(pick)), dtype=np.float32)
+        own, scale = np.empty(T), np.empty(T)
+        rows = 256
+        buf = np.empty((rows, V), dtype=np.float32)
+        for t0 in range(0, T, rows):
+            n = min(rows, T - t0)
+            assert S.lib.srack_device_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + t0 * V * 4), n * V * 4, None) == 0
+            assert S.lib.srack_device_sync(None) == 0
+            got[t0:t0 + n] = buf[:n, pick]
+            own[t0:t0 + n] = buf[:n].sum(axis=1, dtype=np.float64)
+            scale[t0:t0 + n] = np.abs(buf[:n]).sum(axis=1, dtype=np.float64)
+        mix = np.empty((2, T), dtype=np.float32)
+        assert S.lib.srack_device_to_host(mix.ctypes.data_as(C.c_void_p), d_mx, mix.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
+    finally:
+        S.lib.srack_device_free(d_fr)
+        S.lib.srack_device_free(d_mx)
+    o = oracle.OraclePatch(48000, 1024, 2)
+    S.build_p1(o)
+    ref, _ = o.render_batch(len(pick), T, [(ids["osc_a"], S.OSC_VAL, det[pick]), (ids["vcf"], S.VCF_FREQ, cut[pick])], threads=8)
+    assert assert_close(got, ref[0]) < 2e-6
+    assert np.abs(got).max() > 0.1
+    assert (np.abs(mix[0].astype(np.float64) - own) <= 1e-5 * np.maximum(scale, 1.0)).all() and np.array_equal(mix[0], mix[1])
+
+
 # ---- edge cases: channel counts, ragged lengths, chunk boundaries, empty renders ----------------------------------
 def test_channel_layouts(S, oracle):
     """1 and 4 output channels; distinct wires, a shared wire and an unconnected channel."""
