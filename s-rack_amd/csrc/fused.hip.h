@@ -424,14 +424,14 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
         cosc_init(ca, sa.pos, ka.delta);
         if (a.T > 0) x = cosc_step<kOscAPort>(ca);
     }
-    // The envelope track is wave-uniform.  Lane l prefetches sample t0 + l of the NEXT 64-sample tile with one
-    // coalesced load while the current tile is consumed through v_readlane (SGPR operand): no per-sample memory wait.
-    float env_tile = env_track[min((uint32_t)(lane & (kMixRows - 1)), a.T - 1)];
+    // The envelope track is wave-uniform data written by an earlier launch: it is read through the scalar unit (constant
+    // address space => s_load_dwordx8/x16 straight into SGPRs, a tile at a time), costing no vector instruction at all.
+    typedef const __attribute__((address_space(4))) float CFloat;
+    CFloat* env_s = (CFloat*)(uintptr_t)env_track;
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
-        const float env_next = env_track[min(t0 + kMixRows + (uint32_t)(lane & (kMixRows - 1)), a.T - 1)];
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
         auto sample = [&](int i) {
-            const float env = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(env_tile), i));
+            const float env = env_s[t0 + (uint32_t)i];
             if (kExact) {
                 float sine = 0.0f, square = 0.0f, saw = 0.0f;
                 osc_step(fa, sa, ka, 0.0f, 0.0f, sine, square, saw);
@@ -461,7 +461,6 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
             for (int i = 0; i < n; i++) sample(i);
         }
         emit_flush<kOut>(em, mix_tile, t0, n, V);
-        env_tile = env_next;
     }
     if (!kExact) {
         sa.pos = pos_a;

@@ -247,7 +247,7 @@ SRK_DEV float cosc_saw(COsc& o)
     const float w32 = (float)w;
     const float tn = w32 * o.inv_dt;
     const float base = __builtin_fmaf(o.p32, 2.0f, -1.0f);     // (pos as f32) * 2.0 - 1.0, exact as an fma
-    const float u = fmaxf(1.0f - o.ta, 0.0f);
+    const float u = __builtin_amdgcn_fmed3f(1.0f - o.ta, 0.0f, 1.0f);  // = max(1 - ta, 0) since ta >= 0; written as a [0,1] clamp so it folds into the subtract's output modifier
     const float s1 = __builtin_fmaf(u, u, base);               // base - (2t - t^2 - 1)
     const float s2 = keep(__builtin_fmaf(-tn, tn, s1));        // base - (t'^2 + 2t' + 1)
     const float saw = wrapped ? s2 : s1;
@@ -336,7 +336,7 @@ SRK_DEV float fosc_saw(FOsc& o)
     const float cn = (float)nhi;
     const float tn = cn * o.inv_s;
     const float base = __builtin_fmaf(o.c32, 0x1p-31f, -1.0f);    // (pos as f32) * 2.0 - 1.0: the power-of-two scale is exact
-    const float u = fmaxf(1.0f - o.ta, 0.0f);
+    const float u = __builtin_amdgcn_fmed3f(1.0f - o.ta, 0.0f, 1.0f);  // = max(1 - ta, 0) since ta >= 0; written as a [0,1] clamp so it folds into the subtract's output modifier
     const float s1 = __builtin_fmaf(u, u, base);
     const float s2 = keep(__builtin_fmaf(-tn, tn, s1));
     const float saw = wrapped ? s2 : s1;
