@@ -560,14 +560,23 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
         if (a.mixpart) extra_mp[e] = a.mixpart + ((size_t)r.extra_plane[e] * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride;
     }
 
+    // Per-sample track values come through the scalar unit (constant address space => s_load into SGPRs); the VGPR tiles
+    // below (lane l = sample l of the tile) only serve the once-per-tile "did anything change" ballots and the mix partials.
+    typedef const __attribute__((address_space(4))) float CFloat;
+    CFloat* pitch_s = (CFloat*)(uintptr_t)pitch_track;
+    CFloat* cut_s = (CFloat*)(uintptr_t)cut_track;
+    CFloat* env_s = (CFloat*)(uintptr_t)env_track;
+    CFloat* extra_s[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) extra_s[e] = (CFloat*)(uintptr_t)extra_track[e];
     const uint32_t l32 = (uint32_t)(lane & (kMixRows - 1));
     auto fetch = [&](const float* trk, uint32_t t0) { return trk[min(t0 + l32, a.T - 1)]; };
-    float pitch_tile = fetch(pitch_track, 0), cut_tile = fetch(cut_track, 0), env_tile = fetch(env_track, 0);
+    float pitch_tile = fetch(pitch_track, 0), cut_tile = fetch(cut_track, 0);
     float extra_tile[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) extra_tile[e] = fetch(extra_track[e], 0);
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
-        const float pitch_next = fetch(pitch_track, t0 + kMixRows), cut_next = fetch(cut_track, t0 + kMixRows), env_next = fetch(env_track, t0 + kMixRows);
+        const float pitch_next = fetch(pitch_track, t0 + kMixRows), cut_next = fetch(cut_track, t0 + kMixRows);
         float extra_next[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) extra_next[e] = fetch(extra_track[e], t0 + kMixRows);
@@ -578,7 +587,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
         // neighbouring samples.  `steady_pitch` / `steady_cut` are compile-time constants inside each unrolled loop.
         auto sample = [&](int i, bool steady_pitch, bool steady_cut) {
             if (!steady_pitch) {
-                const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(pitch_tile), i);
+                const uint32_t pb = __float_as_uint(pitch_s[t0 + (uint32_t)i]);
                 if (!have_pitch || pb != seen_pitch) {  // a new note (scalar test): new increment, carried terms rebuilt
                     have_pitch = true;
                     seen_pitch = pb;
@@ -604,20 +613,20 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
                 co.pos = g.pos;
             }
             if (has_cut && !steady_cut) {  // vcf_coeffs itself recomputes only for lanes whose (frequency, res) changed
-                const float cutv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cut_tile), i));
+                const float cutv = cut_s[t0 + (uint32_t)i];
                 vcf_coeffs<true>(sv, vcf_frequency(vfreq, cutv, vexp), vres);
             }
             float lp, bp, hp;
             vcf_step<true>(sv, x, lp, bp, hp);
             const float y = vport == VCF_OUT_LP ? lp : (vport == VCF_OUT_BP ? bp : hp);
-            const float env = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(env_tile), i));
+            const float env = env_s[t0 + (uint32_t)i];
             const bool cv_pos = (uint32_t)(__float_as_int(env) - 1) < 0x7f800000u;  // env > 0.0 on the scalar unit
             const float o = (negative || cv_pos) ? y * env : 0.0f;
             emit_put<kOut>(em, mix_tile, o, i, V);
 #pragma unroll
             for (int e = 0; e < 4; e++)
                 if (e < r.n_extra && extra_row[e]) {  // same tile-relative row offset as the main plane (em.soff was just advanced)
-                    const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(extra_tile[e]), i));
+                    const float v = extra_s[e][t0 + (uint32_t)i];
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), extra_rsrc[e], em.lane_c * 4, (int)(em.soff - V * 4u), 2);
                 }
         };
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
         }
         if (has_cut && !steady_cut) {  // the coefficients now belong to the tile's last cutoff CV
             have_cut = true;
-            seen_cut = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cut_tile), n - 1);
+            seen_cut = __float_as_uint(cut_s[t0 + (uint32_t)(n - 1)]);
         }
         emit_flush<kOut>(em, mix_tile, t0, n, V);
 #pragma unroll
@@ -654,7 +663,6 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
             if (e < r.n_extra && extra_mp[e] && lane < n) extra_mp[e][t0 + lane] = (float)em.n_active * extra_tile[e];
         pitch_tile = pitch_next;
         cut_tile = cut_next;
-        env_tile = env_next;
 #pragma unroll
         for (int e = 0; e < 4; e++) extra_tile[e] = extra_next[e];
     }
