@@ -635,11 +635,17 @@ void Builder::match_fused(bool has_rings)
         auto is_fm_osc = [](const DevOp& op) {
             return op.kind == OP_OSC && (op.flags & (OSC_HAS_CV | OSC_HAS_SYNC | OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW)) == (OSC_HAS_CV | OSC_OUT_SINE);
         };
-        if (H.buffer_size == 1 && H.n_ops == 7 && H.n_planes == 1 && o[0].kind == OP_DELAY_RD && !(o[0].flags & DELAY_RING_GLOBAL) && is_scale(o[1]) &&
+        // ... at buffer_size 1 (the delayed sine is last tick's: a register) or >= 32 (a ring in HBM whose reads a 32-sample
+        // tile can issue up front); in between, a tile would read what it has just written
+        const bool z1 = H.buffer_size == 1 && !(o[0].flags & DELAY_RING_GLOBAL), far = H.buffer_size >= 32 && (o[0].flags & DELAY_RING_GLOBAL);
+        if ((z1 || far) && H.n_ops == 7 && H.n_planes == 1 && o[0].kind == OP_DELAY_RD && is_scale(o[1]) &&
             is_fm_osc(o[2]) && o[3].kind == OP_DELAY_WR && is_scale(o[4]) && is_fm_osc(o[5]) && o[6].kind == OP_OUT && o[0].module == o[2].module &&
             o[1].in_slot[0] == o[0].out_slot[0] && o[2].in_slot[0] == o[1].out_slot[0] && o[3].in_slot[0] == o[2].out_slot[0] &&
             o[4].in_slot[0] == o[2].out_slot[0] && o[5].in_slot[0] == o[4].out_slot[0] && o[6].in_slot[0] == o[5].out_slot[0] && o[0].aux == o[3].aux)
+        {
             out.fused = FUSED_FM_PAIR;
+            out.fused_variant = far ? 1 : 0;  // 1: ring in HBM
+        }
         return;
     }
     if (is_ctl) return;  // the voice-chain shapes below are per-voice programs

@@ -757,6 +757,88 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
     }
 }
 
+// ---- the same FM pair with the app's default delay: buffer_size >= 32, the ring in HBM ---------------------------------
+// The modulator of sample t reads what it produced buffer_size samples ago (ring[(n0 + t) mod B], [B][V] f32, voice-
+// minor) and overwrites it.  A 32-sample tile's reads were all written before the tile began (B >= 32), so they are
+// issued together at the tile's start; the modulator no longer depends on its own previous sample, which leaves the
+// compiler free to overlap modulator and carrier of neighbouring samples.
+template <bool kExact, int kOut>
+__global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRoles r)
+{
+    using namespace dev;
+    __shared__ float mix_tile[kMixRows * 64];
+    const int lane = threadIdx.x;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
+    const bool active = wm.active;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+
+    const DevOp& ofb = a.ops[r.adsr];    // MATH on the feedback path   (roles reuse the ChainRoles slots)
+    const DevOp& om = a.ops[r.osc_l];    // modulator
+    const DevOp& oix = a.ops[r.vca];     // MATH scaling the modulation index
+    const DevOp& ocr = a.ops[r.osc_a];   // carrier
+    const int plane = a.ops[r.out].aux;
+    const uint32_t B = (uint32_t)a.prog.buffer_size;
+    float* ring = a.rings + (size_t)r.track * B * V;  // r.track: the ring's id
+
+    constexpr uint32_t fo = OSC_HAS_CV | OSC_CV_AUDIO_RATE | OSC_AA | OSC_OUT_SINE | (kExact ? OSC_EXACT : 0u);
+    OscRegs sm, sc;
+    OscConst km, kc;
+    sm.pos = make_f64(row(om.state_row + OSC_S_POS_LO), row(om.state_row + OSC_S_POS_HI));
+    sm.sync_last = false;
+    sc.pos = make_f64(row(ocr.state_row + OSC_S_POS_LO), row(ocr.state_row + OSC_S_POS_HI));
+    sc.sync_last = false;
+    km.sr = om.sample_rate;
+    km.val = (double)parv(om, OSC_P_VAL);
+    km.delta = 0.0;
+    km.inv_dt = 0.0f;
+    kc = km;
+    kc.sr = ocr.sample_rate;
+    kc.val = (double)parv(ocr, OSC_P_VAL);
+    const float c_fb = parv(ofb, MATH_P_CONST), c_ix = parv(oix, MATH_P_CONST);
+
+    Emit em = make_emit(a, plane, lane);
+    float sq = 0.0f, sw = 0.0f;
+    uint32_t p0 = (uint32_t)(a.n0 % B);  // ring position of the tile's first sample
+    for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
+        const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+        float fed[kMixRows];
+#pragma unroll
+        for (int i = 0; i < kMixRows; i++) {  // (past the end of a short last tile: harmless re-reads of valid ring rows)
+            const uint32_t p = p0 + (uint32_t)i < B ? p0 + (uint32_t)i : p0 + (uint32_t)i - B;
+            fed[i] = ring[(size_t)p * V + vc];
+        }
+        auto sample = [&](int i) {
+            float sine_m = 0.0f, out = 0.0f;
+            osc_step(fo, sm, km, fed[i] * c_fb, 0.0f, sine_m, sq, sw);   // modulator of sample t
+            const uint32_t p = p0 + (uint32_t)i < B ? p0 + (uint32_t)i : p0 + (uint32_t)i - B;
+            if (active) ring[(size_t)p * V + voice] = sine_m;
+            osc_step(fo, sc, kc, sine_m * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
+            emit_put<kOut>(em, mix_tile, out, i, V);
+        };
+        if (n == kMixRows) {
+#pragma unroll 4
+            for (int i = 0; i < kMixRows; i++) sample(i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kMixRows; i++)
+                if (i < n) sample(i);
+        }
+        emit_flush<kOut>(em, mix_tile, t0, n, V);
+        p0 = p0 + (uint32_t)n < B ? p0 + (uint32_t)n : p0 + (uint32_t)n - B;
+    }
+    if (active) {
+        auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+        put(om.state_row + OSC_S_POS_LO, f64_lo(sm.pos));
+        put(om.state_row + OSC_S_POS_HI, f64_hi(sm.pos));
+        put(om.state_row + OSC_S_SYNC_LAST, 0u);
+        put(ocr.state_row + OSC_S_POS_LO, f64_lo(sc.pos));
+        put(ocr.state_row + OSC_S_POS_HI, f64_hi(sc.pos));
+        put(ocr.state_row + OSC_S_SYNC_LAST, 0u);
+    }
+}
+
 // ---- mix-down, passes 2 and 3: mix[c][i] = sum over waves of mixpart[plane(c)][w][i] ---------------------------
 // Deterministic (fixed order, no atomics).  Pass 2 splits the waves into kMixSplit groups so that enough loads
 // are in flight to stream the partials at HBM rate: block (x, y) sums group y for 256 consecutive samples into

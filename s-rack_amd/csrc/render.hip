@@ -248,6 +248,38 @@ static void launch_seq(uint32_t osc_port, int out_mode, const KernelArgs& ka, co
         launch_seq2<OSC_OUT_SINE>(out_mode, ka, r, grid, st);
 }
 
+// kRing: the feedback delay is a ring in HBM (buffer_size >= 32) instead of last tick's value in a register (buffer_size 1)
+template <bool kRing>
+static void launch_fm_pair2(bool exact, int out_mode, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
+{
+#define SRK_FM(E, O)                                                                                   \
+    do {                                                                                               \
+        if (kRing)                                                                                     \
+            hipLaunchKernelGGL((render_fm_pair_ring<E, O>), grid, dim3(64), 0, st, ka, roles);         \
+        else                                                                                           \
+            hipLaunchKernelGGL((render_fm_pair<E, O>), grid, dim3(64), 0, st, ka, roles);              \
+    } while (0)
+    if (exact)
+        SRK_FM(true, 0);
+    else if (out_mode == 3)
+        SRK_FM(false, 3);
+    else if (out_mode == 1)
+        SRK_FM(false, 1);
+    else if (out_mode == 2)
+        SRK_FM(false, 2);
+    else
+        SRK_FM(false, 0);
+#undef SRK_FM
+}
+
+static void launch_fm_pair(bool ring, bool exact, int out_mode, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
+{
+    if (ring)
+        launch_fm_pair2<true>(exact, out_mode, ka, roles, grid, st);
+    else
+        launch_fm_pair2<false>(exact, out_mode, ka, roles, grid, st);
+}
+
 static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_t st)
 {
     size_t lds = ((size_t)P.hdr.n_rows + 2 + (size_t)P.hdr.n_tracks + (size_t)P.hdr.n_slots * P.hdr.tile) * 256;  // + zero, trash and track rows
@@ -277,10 +309,7 @@ static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t 
         roles.osc_a = 5;
         roles.out = 6;
         roles.track = Cp.ops[0].aux;
-        if (Cp.render_flags & SRACK_RENDER_EXACT_OSC)
-            hipLaunchKernelGGL((render_fm_pair<true, 0>), dim3(1), dim3(64), 0, st, kc, roles);
-        else
-            hipLaunchKernelGGL((render_fm_pair<false, 1>), dim3(1), dim3(64), 0, st, kc, roles);
+        launch_fm_pair(Cp.fused_variant == 1, (Cp.render_flags & SRACK_RENDER_EXACT_OSC) != 0, 1, kc, roles, dim3(1), st);
     } else {
         launch_interp(Cp, kc, st);
     }
@@ -534,16 +563,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
             launch_seq(seq_port, out_mode, ka, seq, dim3(n_waves), st);
         } else if (fm_pair) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
-            if (flags & SRACK_RENDER_EXACT_OSC)
-                hipLaunchKernelGGL((render_fm_pair<true, 0>), dim3(n_waves), dim3(64), 0, st, ka, roles);
-            else if (out_mode == 3)
-                hipLaunchKernelGGL((render_fm_pair<false, 3>), dim3(n_waves), dim3(64), 0, st, ka, roles);
-            else if (out_mode == 1)
-                hipLaunchKernelGGL((render_fm_pair<false, 1>), dim3(n_waves), dim3(64), 0, st, ka, roles);
-            else if (out_mode == 2)
-                hipLaunchKernelGGL((render_fm_pair<false, 2>), dim3(n_waves), dim3(64), 0, st, ka, roles);
-            else
-                hipLaunchKernelGGL((render_fm_pair<false, 0>), dim3(n_waves), dim3(64), 0, st, ka, roles);
+            launch_fm_pair(P.fused_variant == 1, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, ka, roles, dim3(n_waves), st);
         } else {
             launch_interp(P, ka, st);
         }
