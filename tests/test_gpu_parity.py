@@ -781,3 +781,43 @@ def test_wave_roundtrip_and_state_readback(S):
     fr, _ = p.render(10)
     assert (fr[0] == w[0]).all()                       # never triggered: holds samples[0]
     assert (p.get_voice_field(smp, S.SAMPLE_PLAYING) == 0).all()
+
+
+def test_dist_reduce_mix_through_rccl(S):
+    """srack_dist_reduce_mix is ncclReduce(sum, f32, root) on the caller's communicator: exercised here with a one-rank
+    RCCL communicator made through the library's own C API (the N > 1 arithmetic is covered by tests/test_dist.py)."""
+    import ctypes as C
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        try:
+            rccl = C.CDLL("/opt/rocm/lib/librccl.so")
+        except OSError:
+            pytest.skip("librccl not found")
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        p = S.Patch(48000, 64, 2)
+        S.build_p1(p, adsr="finite", lfo_val=2.0)
+        p.configure_voices(100)
+        T = 700
+        _, want = p.render(T)
+        q = S.Patch(48000, 64, 2)
+        S.build_p1(q, adsr="finite", lfo_val=2.0)
+        q.configure_voices(100)
+        d_mix = C.c_void_p()
+        assert S.lib.srack_device_alloc(C.byref(d_mix), 2 * T * 4) == 0
+        q.render_raw(T, None, d_mix, 0, None)
+        assert S.lib.srack_dist_reduce_mix(comm, d_mix, 2 * T, 0, None) == 0, S.lib.srack_last_error()
+        got = np.empty((2, T), dtype=np.float32)
+        assert S.lib.srack_device_to_host(got.ctypes.data_as(C.c_void_p), d_mix, got.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
+        S.lib.srack_device_free(d_mix)
+        np.testing.assert_array_equal(got, want)
+        assert S.lib.srack_dist_reduce_mix(None, d_mix, 1, 0, None) == S.ERR_INVALID
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
