@@ -6,19 +6,26 @@
 //   2. dead-port elimination: an oscillator / filter port nobody reads is not computed
 //      (the reference always computes all three, oscillator.rs:133-149; results on the read
 //      ports are unaffected).
+//  2b. approximated values that reach a pitch CV force the exact oscillator and the literal filter
+//      for the whole patch (default mode would otherwise integrate its 1e-7 into a phase).
 //   3. uniform hoisting: a module whose fields carry no per-voice override and whose inputs all
 //      come from such modules produces the same samples for every voice.  That sub-graph becomes
 //      the CONTROL program, evaluated once (one voice) into control tracks; the VOICE program reads
-//      the tracks with OP_TRACK_RD.  (The reference has one instance of everything; "N voices" is
-//      this build's axis, so sharing voice-invariant work changes no sample.)
+//      the tracks in place (input slot >= kTrackSlot).  (The reference has one instance of
+//      everything; "N voices" is this build's axis, so sharing voice-invariant work changes no sample.)
+//  3b. a control program of four or more modules is cut into one unit per module, pipelined by
+//      dependency depth (render.hip runs the units side by side, one chunk apart per depth).
 //   4. wires whose source runs after its sink (broken feedback edges) become a ring of
-//      buffer_size samples per voice: OP_DELAY_RD before the sink, OP_DELAY_WR after the source.
+//      buffer_size samples per voice: OP_DELAY_RD before the sink, OP_DELAY_WR after the source; a
+//      ring starts from the source's saved output buffer when a .srk supplied one.
 //   5. constant hoisting: an oscillator without CV has a constant increment
 //      delta = 440 * 2^f64(val) / f64(sample_rate); it is computed here with glibc pow — the very
 //      value the reference recomputes every sample (oscillator.rs:43-48,132) — per voice.
-//   6. wire slots by linear scan over the op sequence; voice-table rows for state and per-voice
-//      parameters; tile size from the LDS budget.
-//   7. pattern match for the fused chain kernels.
+//   6. wire slots by linear scan over the op sequence, in place where an input dies at the op that
+//      reads it; voice-table rows for state and per-voice parameters; interpreter tile length from a
+//      residency model (LDS granules per CU, rounds of resident waves).
+//   7. pattern match for the fused kernels (P1's chain per voice / with a track, the sequencer-driven
+//      chain, the FM pair with a register or an HBM ring, the gate -> envelope control program).
 #include "flatten.hpp"
 
 #include <algorithm>

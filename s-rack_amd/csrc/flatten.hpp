@@ -48,7 +48,7 @@ struct FlatProgram {
 
 // The flattened patch: the per-voice program and, when part of the graph is voice-invariant (no
 // per-voice override anywhere upstream), a control program that evaluates that part ONCE (one
-// voice) into control tracks [n_tracks][T] which the voice program reads with OP_TRACK_RD.
+// voice) into control tracks [n_tracks][T] which the voice program reads in place (input slot >= kTrackSlot).
 struct FlatPair {
     FlatProgram voice;
     // The control program, valid iff n_tracks > 0; its "planes" are the tracks.  One wave evaluating one voice is a

@@ -20,7 +20,7 @@ enum OpKind : int32_t {
     OP_OUT = 7,        // OutputModule::calc          output.rs:46-60 (+ frame store and mix-down)
     OP_DELAY_RD = 8,   // broken feedback edge: ring[(n - B) mod B] -> slot   (sink side)
     OP_DELAY_WR = 9,   // slot -> ring[n mod B]                               (source side)
-    OP_TRACK_RD = 10,  // control track (voice-invariant sub-graph, evaluated once) -> slot
+    // (10 was OP_TRACK_RD: control tracks are read in place now — an input slot >= kTrackSlot — not copied into a wire)
     OP_GRIDSEQ = 11,   // GridSequencerModule::calc    sequencer.rs:190-246
     OP_PATSEQ = 12,    // PatternSequencerModule::calc sequencer.rs:482-533
     OP_NONLIN = 13,    // NonLinearModule::calc        math.rs:291-311
@@ -104,7 +104,7 @@ struct DevOp {
     // OP_OSC without CV: delta = 440 * 2^val / sample_rate, hoisted to the host in f64
     // (bit-equal to the reference's per-sample value, oscillator.rs:43-48,132)
     int32_t delta_row;          // >= 0: two per-voice rows (lo, hi); -1: uniform => delta
-    int32_t aux;                // OP_OUT: plane; OP_DELAY_*: ring id / first LDS row; OP_TRACK_RD: track index; sequencers: dword offset of the 64 cells in seqtab; OP_SAMPLE: dword offset of the wave in seqtab
+    int32_t aux;                // OP_OUT: plane; OP_DELAY_*: ring id / first LDS row; sequencers: dword offset of the 64 cells in seqtab; OP_SAMPLE: dword offset of the wave in seqtab
     int32_t seq_row;            // sequencers: LDS row the 64 cells are staged in (shared by the wave, indexed by step)
     int32_t seq_len;            // sequencers: sequence length (1..64); OP_SAMPLE: wave length in samples
     double delta;
