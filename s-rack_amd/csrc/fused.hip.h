@@ -11,6 +11,10 @@
 
 #include "interp.hip.h"
 
+#ifndef SRK_FRAME_AUX
+#define SRK_FRAME_AUX 2  // cache policy of the frame stores: nt (write-once stream); tools/ builds variants with -DSRK_FRAME_AUX=
+#endif
+
 namespace srack {
 
 constexpr int kMixRows = 32;
@@ -40,7 +44,7 @@ SRK_DEV void emit_put(Emit& e, float* mix_tile, float o, int i, uint32_t V)  // 
     const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
     const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
     if (frames) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), e.rsrc, e.lane_c * 4, (int)e.soff, 2 /* nt: write-once stream */);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), e.rsrc, e.lane_c * 4, (int)e.soff, SRK_FRAME_AUX);
         e.soff += V * 4u;
     }
     if (mix) mix_tile[i * 64 + e.lane] = o;
