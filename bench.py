@@ -137,6 +137,8 @@ def main():
     mix = torch.empty((C, T), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
+    p.reserve(T, want_mix=not args.no_mix, flags=args.flags)  # set-up, like the allocations above: flatten, upload, scratch buffers
+
     def step():
         p.render_raw(T, frames.data_ptr() if frames is not None else None, None if args.no_mix else mix.data_ptr(), args.flags, stream.cuda_stream)
         if use_dist and not args.no_mix:

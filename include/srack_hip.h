@@ -248,6 +248,11 @@ int srack_render_planes(srack_patch* p, int* channel_plane, int cap);
 int srack_render(srack_patch* p, uint32_t n_samples, float* d_frames, float* d_mix,
                  uint32_t flags, void* stream);
 
+/* Optional: do everything a later srack_render(p, <= n_samples, ..., flags) would do on first use — flatten the graph,
+ * upload the programs and the voice table, size the scratch buffers (mix partials when want_mix, control tracks) — so
+ * that the first render costs what every render costs.  Renders nothing and leaves the voice state untouched. */
+int srack_render_reserve(srack_patch* p, uint32_t n_samples, int want_mix, uint32_t flags);
+
 /* Scratch the render needs for the mix-down partials etc. is owned by the handle; this reports it. */
 int srack_render_info(srack_patch* p, char* buf, size_t cap); /* human-readable: kernel picked, ops, rows */
 

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "srack_patch_set_field", "srack_patch_get_field", "srack_patch_set_step", "srack_patch_get_step", "srack_patch_set_wave", "srack_patch_get_wave", "srack_patch_load_srk", "srack_patch_save_srk", "srack_patch_module_id",
     "srack_patch_set_module_position", "srack_patch_get_module_position", "srack_patch_set_output_buffer", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
     "srack_patch_plan", "srack_patch_plan_list", "srack_patch_removed_edges", "srack_patch_delayed_edges",
-    "srack_voices_configure", "srack_voices_set_field_f32", "srack_voices_set_field_f64", "srack_render_planes", "srack_render",
+    "srack_voices_configure", "srack_voices_set_field_f32", "srack_voices_set_field_f64", "srack_render_planes", "srack_render", "srack_render_reserve",
     "srack_render_info", "srack_render_kernel_ms", "srack_voices_get_field", "srack_device_count", "srack_device_set",
     "srack_device_alloc", "srack_device_free", "srack_device_to_host", "srack_device_sync", "srack_dist_reduce_mix",
 ]
@@ -78,6 +78,7 @@ def _load():
     L.srack_voices_set_field_f64.argtypes = [vp, i32, i32, dp]
     L.srack_render_planes.argtypes = [vp, ip, i32]
     L.srack_render.argtypes = [vp, u32, vp, vp, u32, vp]
+    L.srack_render_reserve.argtypes = [vp, u32, i32, u32]
     L.srack_render_info.argtypes = [vp, C.c_char_p, sz]
     L.srack_render_kernel_ms.argtypes = [vp, dp, ip, i32]
     L.srack_voices_get_field.argtypes = [vp, i32, i32, dp]
@@ -260,6 +261,10 @@ class Patch:
         buf = (C.c_int * 8)()
         n = _check(lib.srack_render_planes(self.h, buf, 8))
         return n, list(buf[:self.channels])
+
+    def reserve(self, n_samples, want_mix=True, flags=0):
+        """First-use set-up (flatten, upload, scratch buffers) ahead of the first render."""
+        _check(lib.srack_render_reserve(self.h, n_samples, 1 if want_mix else 0, flags))
 
     def render_raw(self, n_samples, d_frames=None, d_mix=None, flags=0, stream=None):
         """Device pointers (ints) in; asynchronous on `stream`."""

@@ -370,6 +370,16 @@ int srack_render(srack_patch* p, uint32_t n_samples, float* d_frames, float* d_m
     return device_render(p->h, n_samples, d_frames, d_mix, flags, stream);
 }
 
+int srack_render_reserve(srack_patch* p, uint32_t n_samples, int want_mix, uint32_t flags)
+{
+    CHECK_HANDLE(p);
+    if (p->h.n_voices == 0) {
+        set_error("render_reserve: call srack_voices_configure first");
+        return SRACK_ERR_STATE;
+    }
+    return device_reserve(p->h, n_samples, want_mix != 0, flags);
+}
+
 int srack_render_info(srack_patch* p, char* buf, size_t cap)
 {
     CHECK_HANDLE(p);

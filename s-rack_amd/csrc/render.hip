@@ -318,6 +318,16 @@ static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t 
 // How a render is scheduled.  Without a control program: one launch of the voice kernel.  With one: the
 // render is cut into chunks; control chunk k (one wave, a latency chain) runs on its own stream and voice
 // chunk k waits only for it, so all but the first control chunk hide behind voice kernels of earlier chunks.
+static uint32_t lanes_per_wave(uint32_t V)
+{
+    const uint32_t kSimds = 1024;
+    uint32_t want_waves = kSimds;
+    if (const char* e = getenv("SRACK_WANT_WAVES")) want_waves = (uint32_t)atoi(e);  // tuning knob (tools/): waves to aim for
+    uint32_t lanes = 64;
+    while (lanes > 16 && (V + lanes - 1) / lanes * 2 <= want_waves) lanes >>= 1;
+    return lanes;
+}
+
 // One segment [t_seg, t_seg + T) of a render of T_total samples.  d_frames / d_mix point at the WHOLE render's buffers.
 static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint32_t T, float* d_frames, float* d_mix, uint32_t flags, hipStream_t st)
 {
@@ -335,11 +345,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     // With few voices, half- or quarter-filled waves double / quadruple the number of waves: a VALU instruction
     // costs the same for 16 lanes as for 64, so this only pays while SIMDs would otherwise sit idle (VALU-bound
     // kernels: up to one wave per SIMD) or while waves are latency-bound (FM pair, interpreter: up to four).
-    const uint32_t kSimds = 1024;
-    uint32_t want_waves = kSimds;
-    if (const char* e = getenv("SRACK_WANT_WAVES")) want_waves = (uint32_t)atoi(e);  // tuning knob (tools/): waves to aim for
-    uint32_t lanes = 64;
-    while (lanes > 16 && (V + lanes - 1) / lanes * 2 <= want_waves) lanes >>= 1;
+    const uint32_t lanes = lanes_per_wave(V);
     const uint32_t n_waves = (V + lanes - 1) / lanes;
 
     if (P.hdr.n_planes == 0) {  // nothing reaches the output: silence (output.rs:55)
@@ -613,6 +619,29 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
     for (uint32_t t = 0; t < n_samples && rc == SRACK_OK; t += kSegment)
         rc = render_segment(h, n_samples, t, std::min(kSegment, n_samples - t), d_frames, d_mix, flags, (hipStream_t)stream);
     return rc;
+}
+
+// Everything a render of up to n_samples needs except the render itself: the flattened programs on the device and the
+// scratch buffers (mix partials, control tracks) at their final size.  Lets a host keep first-render set-up (a 786 MB
+// hipMalloc at the headline size) out of its real-time / timed path.
+int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t flags)
+{
+    int rc = ensure_program(h, flags);
+    if (rc != SRACK_OK) return rc;
+    if (!h.dev) {
+        rc = upload_program(h);
+        if (rc != SRACK_OK) return rc;
+    }
+    DeviceState* d = h.dev;
+    const FlatProgram& P = h.prog.voice;
+    const uint32_t T = std::min(n_samples, 65536u);  // one segment
+    const uint32_t lanes = lanes_per_wave(P.n_voices), n_waves = (P.n_voices + lanes - 1) / lanes;
+    if (want_mix && P.hdr.n_planes > 0) {
+        if ((rc = grow(d->d_mixpart, d->mixpart_bytes, sizeof(float) * (size_t)P.hdr.n_planes * n_waves * T)) != SRACK_OK) return rc;
+        if ((rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * T)) != SRACK_OK) return rc;
+    }
+    if (h.prog.n_tracks > 0 && (rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
+    return SRACK_OK;
 }
 
 int device_kernel_ms(PatchHandle& h, double* avg_ms, int* n_launches, int reset)

@@ -33,6 +33,7 @@ struct PatchHandle {
 int ensure_program(PatchHandle& h, uint32_t flags);
 
 int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_mix, uint32_t flags, void* stream);
+int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t flags);
 int device_kernel_ms(PatchHandle& h, double* avg_ms, int* n_launches, int reset);
 int device_read_rows(PatchHandle& h, int ctl_stage /* -1: the voice program */, int first_row, int n_rows, uint32_t* host_dst);
 void device_release(DeviceState* d);

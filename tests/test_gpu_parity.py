@@ -821,3 +821,21 @@ def test_dist_reduce_mix_through_rccl(S):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_reserve_changes_nothing_but_the_first_call(S):
+    """srack_render_reserve does the first-use set-up ahead of time: same samples, voice state untouched."""
+    def make():
+        p = S.Patch(48000, 1024, 2)
+        ids = S.build_p3(p)
+        p.configure_voices(90)
+        p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, np.linspace(-1, 0, 90).astype(np.float32))
+        return p, ids
+    a, ids = make()
+    a.reserve(5000)
+    assert (a.get_voice_field(ids["osc"], S.OSC_POS) == 0).all()
+    fa, ma = a.render(5000)
+    b, _ = make()
+    fb, mb = b.render(5000)
+    np.testing.assert_array_equal(bits(fa), bits(fb))
+    np.testing.assert_array_equal(bits(ma), bits(mb))

@@ -205,6 +205,9 @@ def test_no_gpu_render_fails_loudly(S):
     with pytest.raises(S.SrackError) as e:
         p.render(16)
     assert e.value.code == S.ERR_DEVICE
+    with pytest.raises(S.SrackError) as e:
+        p.reserve(16)
+    assert e.value.code == S.ERR_DEVICE
 
 
 def test_sequencer_graph_api(S):
