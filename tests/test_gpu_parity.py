@@ -839,3 +839,23 @@ def test_reserve_changes_nothing_but_the_first_call(S):
     fb, mb = b.render(5000)
     np.testing.assert_array_equal(bits(fa), bits(fb))
     np.testing.assert_array_equal(bits(ma), bits(mb))
+
+
+def test_long_render_crosses_segments_with_a_control_pipeline(S, oracle):
+    """Three seconds of P3 (two segment borders at 65536 and 131072 samples, pipelined control units refilling each time)."""
+    V, T = 40, 144000
+    transpose = np.linspace(-2.0, 0.0, V).astype(np.float32)
+    o = oracle.OraclePatch(48000, 1024, 2)
+    ids = S.build_p3(o)
+    ref, _ = o.render_batch(V, T, [(ids["transpose"], S.MATH_CONSTANT, transpose)], threads=8)
+    for flags in (0, 2):
+        p = S.Patch(48000, 1024, 2)
+        S.build_p3(p)
+        p.configure_voices(V)
+        p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, transpose)
+        fr, mix = p.render(T, flags=flags)
+        assert_close(fr[0], ref[0])
+        np.testing.assert_array_equal(fr[1], ref[1])
+        want = ref.astype(np.float64).sum(axis=2)
+        scale = np.abs(ref.astype(np.float64)).sum(axis=2)
+        assert (np.abs(mix - want) <= 2e-5 * np.maximum(scale, 1.0)).all()
