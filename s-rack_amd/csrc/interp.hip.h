@@ -158,90 +158,127 @@ SRK_DEV void tile_run(const Ctx& c, const Port (&in)[NI], const Port (&out)[NO],
 // Every tile function is a template on the kernel flavour, also where the code does not depend on it: the register
 // budget a kernel asks for (amdgpu_waves_per_eu, see render_interp) only reaches callees that no other kernel shares.
 
+// The oscillator has three tile functions, one per regime, so that the f64 sine / pow of the general one does not cost
+// the two carried-phase ones registers (under the 96-VGPR budget the single function spilled 112 bytes).
+struct OscSetup {
+    OscRegs s;
+    OscConst k;
+};
+SRK_DEV OscSetup osc_setup(const Ctx& c, COp& op)
+{
+    OscSetup u;
+    const int sr = op.state_row;
+    u.s.pos = make_f64(ROW(sr + OSC_S_POS_LO), ROW(sr + OSC_S_POS_HI));
+    u.s.sync_last = ROW(sr + OSC_S_SYNC_LAST) != 0;
+    u.k.sr = op.sample_rate;
+    u.k.val = (double)par(c, op, OSC_P_VAL);
+    u.k.delta = op.delta_row >= 0 ? make_f64(ROW(op.delta_row), ROW(op.delta_row + 1)) : op.delta;
+    u.k.inv_dt = 1.0f / (float)u.k.delta;
+    return u;
+}
+SRK_DEV void osc_store(const Ctx& c, COp& op, double pos, bool sync_last)
+{
+    const int sr = op.state_row;
+    ROW(sr + OSC_S_POS_LO) = f64_lo(pos);
+    ROW(sr + OSC_S_POS_HI) = f64_hi(pos);
+    ROW(sr + OSC_S_SYNC_LAST) = sync_last ? 1u : 0u;
+}
+
+// no CV, no sync, one live port, delta < 0.25 for every voice (host-checked): the carried-phase oscillator
 template <bool kExact>
-__device__ __noinline__ void tile_osc(const Ctx c_v, COp& op_v)
+__device__ __noinline__ void tile_osc_const(const Ctx c_v, COp& op_v)
 {
     const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     const uint32_t fl = op.flags;
-    const int sr = op.state_row;
-    OscRegs s;
-    s.pos = make_f64(ROW(sr + OSC_S_POS_LO), ROW(sr + OSC_S_POS_HI));
-    s.sync_last = ROW(sr + OSC_S_SYNC_LAST) != 0;
-    OscConst k;
-    k.sr = op.sample_rate;
-    k.val = (double)par(c, op, OSC_P_VAL);
-    k.delta = op.delta_row >= 0 ? make_f64(ROW(op.delta_row), ROW(op.delta_row + 1)) : op.delta;
-    k.inv_dt = 1.0f / (float)k.delta;
-    const Port out[3] = {out_port(c, op.out_slot[0]), out_port(c, op.out_slot[1]), out_port(c, op.out_slot[2])};
-    if (fl & OSC_CONST_FAST) {  // no CV, no sync, one live port, delta < 0.25 for every voice (host-checked)
-        COsc o;
-        cosc_init(o, s.pos, k.delta);
-        const Port none[1] = {in_port(c, -1)};
-        if (fl & OSC_OUT_SAW) {
-            const Port w[1] = {out[2]};
-            tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_saw(o); });
-        } else if (fl & OSC_OUT_SQUARE) {
-            const Port w[1] = {out[1]};
-            tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_square(o); });
-        } else {
-            const Port w[1] = {out[0]};
-            tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_sine(o); });
+    const OscSetup u = osc_setup(c, op);
+    COsc o;
+    cosc_init(o, u.s.pos, u.k.delta);
+    const Port w[1] = {out_port(c, op.out_slot[(fl & OSC_OUT_SAW) ? 2 : (fl & OSC_OUT_SQUARE) ? 1 : 0])};
+    const Port none[1] = {w[0]};  // no input: the dummy read goes to the op's own output row
+    if (fl & OSC_OUT_SAW)
+        tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_saw(o); });
+    else if (fl & OSC_OUT_SQUARE)
+        tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_square(o); });
+    else
+        tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_sine(o); });
+    osc_store(c, op, o.pos, false);  // sync unconnected: `last` follows the constant 0.0 input
+}
+
+// A sequencer-driven pitch: the carried-phase oscillator between note changes.  When some lane's CV differs from the one
+// its increment was computed for (a wave-uniform test), that increment is recomputed — 440 / sr x 2^(cv + val), as
+// osc_step does — and the carried terms are rebuilt from the exact f64 phase.  An increment of 0.25 or more (or NaN)
+// breaks the carried form's "one PolyBLEP window at a time": those samples take osc_step.
+template <bool kExact>
+__device__ __noinline__ void tile_osc_stepwise(const Ctx c_v, COp& op_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    const uint32_t fl = op.flags;
+    const OscSetup u = osc_setup(c, op);
+    const OscConst k = u.k;
+    COsc o;
+    float seen_cv = __builtin_nanf("");
+    bool carried = false;
+    const uint32_t f = fl & ~OSC_EXACT;
+    const Port cvp[1] = {in_port(c, op.in_slot[0])};
+    const Port w[1] = {out_port(c, op.out_slot[(fl & OSC_OUT_SAW) ? 2 : (fl & OSC_OUT_SQUARE) ? 1 : 0])};
+    o.pos = u.s.pos;
+    o.delta = 0.0;
+    tile_run<1, 1>(c, cvp, w, [&](const float* x, float* y) {
+        const float cv = x[0];
+        if (__builtin_amdgcn_ballot_w64(cv != seen_cv) != 0) {
+            const double delta = (440.0 / k.sr) * exp2_fast((double)cv + k.val);
+            seen_cv = cv;
+            carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
+            cosc_init(o, o.pos, delta);
         }
-        ROW(sr + OSC_S_POS_LO) = f64_lo(o.pos);
-        ROW(sr + OSC_S_POS_HI) = f64_hi(o.pos);
-        ROW(sr + OSC_S_SYNC_LAST) = 0u;  // sync unconnected: `last` follows the constant 0.0 input
-        return;
-    }
+        if (carried) {
+            y[0] = (fl & OSC_OUT_SAW) ? cosc_saw(o) : (fl & OSC_OUT_SQUARE) ? cosc_square(o) : cosc_sine(o);
+        } else {
+            OscRegs g;
+            g.pos = o.pos;
+            g.sync_last = false;
+            g.seen_cv = seen_cv;
+            g.seen_delta = o.delta;
+            float o3[3] = {0.0f, 0.0f, 0.0f};
+            osc_step(f, g, k, cv, 0.0f, o3[0], o3[1], o3[2]);
+            y[0] = (fl & OSC_OUT_SAW) ? o3[2] : (fl & OSC_OUT_SQUARE) ? o3[1] : o3[0];
+            cosc_init(o, g.pos, o.delta);
+        }
+    });
+    osc_store(c, op, o.pos, false);
+}
+
+// everything else: CV at audio rate, sync, several live ports, no anti-aliasing, the exact flavour
+template <bool kExact>
+__device__ __noinline__ void tile_osc_general(const Ctx c_v, COp& op_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    const uint32_t fl = op.flags;
+    OscSetup u = osc_setup(c, op);
     const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
-    const uint32_t ports = fl & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
-    if (!kExact && (fl & (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_HAS_SYNC | OSC_AA)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1))) {
-        // A sequencer-driven pitch: the carried-phase oscillator between note changes.  When some lane's CV differs from
-        // the one its increment was computed for (a wave-uniform test), that increment is recomputed — 440 / sr x 2^(cv +
-        // val), as osc_step does — and the carried terms are rebuilt from the exact f64 phase.  An increment of 0.25 or
-        // more (or NaN) breaks the carried form's "one PolyBLEP window at a time": those samples take osc_step.
-        COsc o;
-        float seen_cv = __builtin_nanf("");
-        bool carried = false;
-        const uint32_t f = fl & ~OSC_EXACT;
-        const Port cvp[1] = {in[0]};
-        const Port w[1] = {out[(fl & OSC_OUT_SAW) ? 2 : (fl & OSC_OUT_SQUARE) ? 1 : 0]};
-        o.pos = s.pos;
-        tile_run<1, 1>(c, cvp, w, [&](const float* x, float* y) {
-            const float cv = x[0];
-            if (__builtin_amdgcn_ballot_w64(cv != seen_cv) != 0) {
-                const double delta = (440.0 / k.sr) * exp2_fast((double)cv + k.val);
-                seen_cv = cv;
-                carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
-                cosc_init(o, o.pos, delta);
-            }
-            if (carried) {
-                y[0] = (fl & OSC_OUT_SAW) ? cosc_saw(o) : (fl & OSC_OUT_SQUARE) ? cosc_square(o) : cosc_sine(o);
-            } else {
-                OscRegs g;
-                g.pos = o.pos;
-                g.sync_last = false;
-                g.seen_cv = seen_cv;
-                g.seen_delta = o.delta;
-                float o3[3] = {0.0f, 0.0f, 0.0f};
-                osc_step(f, g, k, cv, 0.0f, o3[0], o3[1], o3[2]);
-                y[0] = (fl & OSC_OUT_SAW) ? o3[2] : (fl & OSC_OUT_SQUARE) ? o3[1] : o3[0];
-                cosc_init(o, g.pos, o.delta);
-            }
-        });
-        ROW(sr + OSC_S_POS_LO) = f64_lo(o.pos);
-        ROW(sr + OSC_S_POS_HI) = f64_hi(o.pos);
-        ROW(sr + OSC_S_SYNC_LAST) = 0u;
-        return;
-    }
+    const Port out[3] = {out_port(c, op.out_slot[0]), out_port(c, op.out_slot[1]), out_port(c, op.out_slot[2])};
     const uint32_t f = kExact ? (fl | OSC_EXACT) : (fl & ~OSC_EXACT);
     tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
         y[0] = y[1] = y[2] = 0.0f;
-        osc_step(f, s, k, x[0], x[1], y[0], y[1], y[2]);
+        osc_step(f, u.s, u.k, x[0], x[1], y[0], y[1], y[2]);
     });
-    ROW(sr + OSC_S_POS_LO) = f64_lo(s.pos);
-    ROW(sr + OSC_S_POS_HI) = f64_hi(s.pos);
-    ROW(sr + OSC_S_SYNC_LAST) = s.sync_last ? 1u : 0u;
+    osc_store(c, op, u.s.pos, u.s.sync_last);
+}
+
+template <bool kExact>
+SRK_DEV void tile_osc(const Ctx& c, COp& op)
+{
+    const uint32_t fl = op.flags;  // wave-uniform (scalar load)
+    const uint32_t ports = fl & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
+    if (fl & OSC_CONST_FAST)
+        tile_osc_const<kExact>(c, op);
+    else if (!kExact && (fl & (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_HAS_SYNC | OSC_AA)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1)))
+        tile_osc_stepwise<kExact>(c, op);
+    else
+        tile_osc_general<kExact>(c, op);
 }
 
 SRK_DEV void vcf_load(const Ctx& c, int sr, VcfRegs& s)
