@@ -97,7 +97,7 @@ lib = _load()
 
 def _check(rc):
     if rc < 0:
-        raise SrackError(rc, lib.srack_last_error().decode())
+        raise SrackError(rc, lib.srack_last_error().decode(errors="replace"))
     return rc
 
 

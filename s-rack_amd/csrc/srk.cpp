@@ -401,7 +401,9 @@ Module parse_module(Reader& r, Graph& scratch)
     }
     if (variant == "NoiseModuleV0" || variant == "FreeverbModuleV0")
         throw UnsupportedError("srk: " + variant + " is outside the render path's scope (unseedable RNG / un-vendored freeverb crate)");
-    r.fail("unknown SynthModuleType variant '" + variant + "'");
+    std::string shown;
+    for (char ch : variant.substr(0, 48)) shown += (ch >= 0x20 && ch < 0x7f) ? ch : '?';  // a damaged file: keep the message printable
+    r.fail("unknown SynthModuleType variant '" + shown + "'");
 }
 
 // ---- MessagePack writer (rmp's shortest encodings) ----------------------------------------------------------------------
