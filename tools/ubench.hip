@@ -48,6 +48,29 @@ __global__ __launch_bounds__(256) void probe(float* out, float seed)
                 f[k] = v.x;
                 f[(k + 4) & 7] = v.y;
             }
+            if (OP == 18) {  // v_permlane32_swap: two registers exchanged in place
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(f[k]), "+v"(f[(k + 4) & 7]));
+            }
+            if (OP == 19) {
+                asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(f[k]), "+v"(f[(k + 4) & 7]));
+            }
+            if (OP == 20) {
+                asm volatile("v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(f[k]));
+            }
+            if (OP == 21) {
+                asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(f[k]));
+            }
+            if (OP == 22) asm volatile("v_mul_f32_e64 %0, %0, -%1" : "+v"(f[k]) : "v"(a));
+            if (OP == 23) asm volatile("v_cvt_f32_u32_e32 %0, %0" : "+v"(f[k]));
+            if (OP == 24) asm volatile("v_add_co_u32_e32 %0, vcc, %0, %2\n\tv_addc_co_u32_e32 %1, vcc, %1, %2, vcc" : "+v"(n[k]), "+v"(f[k]) : "v"(a) : "vcc");
+            if (OP == 25) asm volatile("v_sub_f32_e64 %0, 1.0, %0 clamp" : "+v"(f[k]));
+            if (OP == 26) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(f[k]) : "v"(a) : "vcc");
+            if (OP == 27) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(f[k]), "v"(a) : "vcc");
+            if (OP == 28) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(f[k]) : "v"(a), "v"(b));
+            if (OP == 29) asm volatile("v_fma_f32 %0, %0, %1, -1.0" : "+v"(f[k]) : "s"(a));
+            if (OP == 30) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(f[k]) : "v"(a), "s"(0x5555555555555555ull));
+            if (OP == 31) asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(f[k]) : "v"(a));
+            if (OP == 32) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(f[k]) : "s"(a));
             if (OP == 17) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 f2 v = {f[k], f[(k + 4) & 7]};
@@ -128,6 +151,21 @@ int main()
     run<9, 8>("v_ashr+v_add i32", d_out, 2);
     run<16, 4>("v_pk_fma_f32 (2 values)", d_out, 1);
     run<17, 4>("v_pk_mul_f32 (2 values)", d_out, 1);
+    run<18, 4>("v_permlane32_swap", d_out, 1);
+    run<19, 4>("v_permlane16_swap", d_out, 1);
+    run<20, 8>("v_add_f32_dpp row_mirror", d_out, 1);
+    run<21, 8>("v_add_f32_dpp quad_perm", d_out, 1);
+    run<22, 8>("v_mul_f32_e64 neg", d_out, 1);
+    run<23, 8>("v_cvt_f32_u32", d_out, 1);
+    run<24, 8>("v_add_co+v_addc_co", d_out, 2);
+    run<25, 8>("v_sub_f32_e64 clamp", d_out, 1);
+    run<26, 8>("v_cndmask_e32 (vcc)", d_out, 1);
+    run<27, 8>("v_cmp_lt_f32 (vcc)", d_out, 1);
+    run<28, 8>("v_fmac_f32_e32", d_out, 1);
+    run<29, 8>("v_fma_f32 sgpr operand", d_out, 1);
+    run<30, 8>("v_cndmask_e64 (sgpr mask)", d_out, 1);
+    run<31, 8>("v_max_f32", d_out, 1);
+    run<32, 8>("v_mul_f32 sgpr operand", d_out, 1);
     run<13, 8>("f32 divide (IEEE)", d_out, 1);
     run<14, 8>("v_rcp_f32", d_out, 1);
     for (int w : {1, 2, 4, 8}) run_occ<0, 1>("v_fma_f32 dep", d_out, w);
