@@ -186,7 +186,7 @@ def main():
                             + ("detune/cutoff" if args.workload == "p1" else "transpose/cutoff") + f", {T} samples/step @48 kHz, "
                             f"f32 frames [{n_planes}][T][V] in HBM + stereo mix-down" + (" + RCCL reduce of the [2][T] mix" if use_dist else ""),
                 "voices_per_gpu": V, "samples_per_step": T, "buffer_size": 1024, "render_flags": args.flags,
-                "arithmetic": "f32 wires and modules; oscillator phase accumulator in f64 (as the reference)",
+                "arithmetic": "f32 wires and modules; oscillator phase accumulator 64-bit: f64 as the reference, 2^-64 fixed point in the default-mode fused saw kernel (DESIGN.md section 3)",
                 "frames_written": frames is not None, "mix_down": not args.no_mix, "program": p.info(),
             },
             "roofline": {

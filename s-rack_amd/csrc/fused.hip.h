@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
             emit_put<kOut>(em, mix_tile, o, i, V);
         };
         if (n == kMixRows) {  // constant trip count: unrollable (readlane is convergent, so a runtime count is not)
-#pragma unroll 8
+#pragma unroll 32
             for (int i = 0; i < kMixRows; i++) sample(i);
         } else {
             for (int i = 0; i < n; i++) sample(i);
