@@ -59,7 +59,12 @@ enum {
     /* scope table (f) rank 4: the remaining per-voice modules */
     SRACK_MOD_NONLINEAR   = 9,  /* math::NonLinearModule       src/synth/math.rs:176-311     */
     SRACK_MOD_SAMPLE      = 10, /* sample::SampleModule        src/synth/sample.rs:72-240    */
-    SRACK_MOD__COUNT      = 11
+    /* White noise: out = (rand::random::<f32>() - 0.5) * 2.0 per sample (oscillator.rs:381-387).  The reference draws from
+     * rand 0.8's thread-local, OS-seeded ChaCha12: no two runs of it agree, so only the DISTRIBUTION can be matched — the
+     * 2^24 equally likely values k * 2^-23 - 1 of rand's Standard f32 — and the draw itself is this library's: a
+     * counter-based splitmix64 stream per (seed, module, voice), see srack_patch_set_noise_seed. */
+    SRACK_MOD_NOISE       = 11, /* oscillator::NoiseModule     src/synth/oscillator.rs:308-393 */
+    SRACK_MOD__COUNT      = 12
 };
 
 /* ---- ports (u8 in the reference) --------------------------------------------------------- */
@@ -209,7 +214,7 @@ int srack_patch_delayed_edges(srack_patch* p, int* quads, int cap);
 /* FileFormat{modules, connections, positions} (ui.rs:578-586) in rmp-serde 1.3.0's compact MessagePack form.
  * load = SynthModuleWorkspaceImpl::deserialize (ui.rs:116-135) against the host's AudioConfig: the module list comes
  * out in REVERSE file order (ui.rs:654-660), V0 variants migrate, saved buffers survive only at the same buffer_size,
- * connections with unknown ids or bad ports are dropped.  Noise / Freeverb modules => SRACK_ERR_UNSUPPORTED.
+ * connections with unknown ids or bad ports are dropped.  Freeverb modules => SRACK_ERR_UNSUPPORTED.
  * save = serialize (ui.rs:98-114): writes at most `cap` bytes to `buf` (may be NULL) and the full size to *n_bytes. */
 int srack_patch_load_srk(const void* bytes, size_t n_bytes, uint32_t sample_rate, uint32_t buffer_size, uint32_t channels, srack_patch** out);
 int srack_patch_save_srk(const srack_patch* p, void* buf, size_t cap, size_t* n_bytes);
@@ -221,6 +226,14 @@ int srack_patch_get_module_position(const srack_patch* p, int module, float* x, 
 /* Contents of one output buffer before the first tick (what a loaded file carries): `n` = buffer_size samples, or 0
  * for a fresh, zeroed buffer.  Only the sink of a broken feedback edge ever observes it. */
 int srack_patch_set_output_buffer(srack_patch* p, int module, int port, const float* samples, uint32_t n);
+/* Noise modules (SRACK_MOD_NOISE).  With sm(x) = splitmix64's output function applied to x + 0x9E3779B97F4A7C15,
+ *   base(module)  = sm(seed ^ sm(module))                       module = its index in the patch
+ *   key(voice)    = sm(base ^ (first_voice + voice))            voice  = its index in this handle
+ *   sample n      = ((sm(key + n * 0x9E3779B97F4A7C15) >> 40) * 2^-24 - 0.5) * 2.0
+ * i.e. sample n is output n of a splitmix64 generator seeded with key; n counts the samples rendered since
+ * srack_voices_configure.  Independent of chunking, of the render flags and of how voices are sharded: a rank that owns
+ * the global voices [r*V, (r+1)*V) passes first_voice = r*V.  Defaults: seed 0, first_voice 0. */
+int srack_patch_set_noise_seed(srack_patch* p, uint64_t seed, uint64_t first_voice);
 
 /* ---- voices: N independent instances of the patch ----------------------------------------- */
 /* Fix the number of voices (lanes) and drop any earlier per-voice data and device state. */

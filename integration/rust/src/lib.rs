@@ -26,6 +26,7 @@ mod ffi {
         pub fn srack_patch_set_field(p: *mut SrackPatch, module: c_int, field: c_int, value: f64) -> c_int;
         pub fn srack_patch_get_field(p: *const SrackPatch, module: c_int, field: c_int, value: *mut f64) -> c_int;
         pub fn srack_patch_set_step(p: *mut SrackPatch, module: c_int, channel: c_int, step: c_int, state: c_int, value: c_int) -> c_int;
+        pub fn srack_patch_set_noise_seed(p: *mut SrackPatch, seed: u64, first_voice: u64) -> c_int;
         pub fn srack_patch_set_wave(p: *mut SrackPatch, module: c_int, samples: *const f32, n_samples: u32, sample_rate: f32) -> c_int;
         pub fn srack_patch_load_srk(bytes: *const c_void, n_bytes: usize, sample_rate: u32, buffer_size: u32, channels: u32, out: *mut *mut SrackPatch) -> c_int;
         pub fn srack_patch_save_srk(p: *const SrackPatch, buf: *mut c_void, cap: usize, n_bytes: *mut usize) -> c_int;
@@ -57,6 +58,7 @@ pub enum ModuleType {
     PatternSequencer = 8,
     NonLinear = 9,
     Sample = 10,
+    Noise = 11,
 }
 
 #[derive(Debug)]
@@ -128,6 +130,11 @@ impl Patch {
         check(unsafe { ffi::srack_patch_set_step(self.raw, module, channel, step, state, value) }).map(|_| ())
     }
     /// What `WaveBox::load` leaves behind (src/synth/sample.rs:31-69): first channel as f32 + the file's sample rate.
+    /// NoiseModule streams are keyed by (seed, module, first_voice + voice); the reference's generator is OS-seeded.
+    pub fn set_noise_seed(&mut self, seed: u64, first_voice: u64) -> Result<(), Error> {
+        check(unsafe { ffi::srack_patch_set_noise_seed(self.raw, seed, first_voice) }).map(|_| ())
+    }
+
     pub fn set_wave(&mut self, module: i32, samples: &[f32], sample_rate: f32) -> Result<(), Error> {
         check(unsafe { ffi::srack_patch_set_wave(self.raw, module, samples.as_ptr(), samples.len() as u32, sample_rate) }).map(|_| ())
     }

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsrack_oracle.so")
 
 # module types / fields: numeric vocabulary of include/srack_hip.h
-MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH, MOD_GRID_SEQUENCER, MOD_PATTERN_SEQUENCER, MOD_NONLINEAR, MOD_SAMPLE = range(11)
+MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH, MOD_GRID_SEQUENCER, MOD_PATTERN_SEQUENCER, MOD_NONLINEAR, MOD_SAMPLE, MOD_NOISE = range(12)
 
 
 def build(force=False):
@@ -54,6 +54,8 @@ def lib():
         L.or_set_step.argtypes = [vp, i32, i32, i32, i32, i32]
         L.or_set_wave.argtypes = [vp, i32, fp, u32, C.c_float]
         L.or_set_output_buffer.argtypes = [vp, i32, i32, fp]
+        L.or_set_noise_seed.restype = None
+        L.or_set_noise_seed.argtypes = [vp, u64, u64]
         L.or_plan.argtypes = [vp]
         L.or_plan_list.argtypes = [vp, i32, ip, i32]
         L.or_get_plan.argtypes = [vp, ip, i32]
@@ -125,6 +127,10 @@ class OraclePatch:
         assert a.size == self.buffer_size
         if self.L.or_set_output_buffer(self.h, module, port, _fp(a)) < 0:
             raise ValueError("or_set_output_buffer failed")
+
+    def set_noise_seed(self, seed, voice=0):
+        """Noise streams: seed and the GLOBAL index of the voice this patch is (render_batch: of its voice 0)."""
+        self.L.or_set_noise_seed(self.h, seed, voice)
 
     def get_field(self, module, field):
         v = C.c_double()

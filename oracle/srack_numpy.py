@@ -412,7 +412,40 @@ class Sample(Module):  # sample.rs:72-240
                     self.pos = self.pos + self.wave_sample_rate / self.sample_rate * powf(TWO, cv_in[idx] if cv_in is not None else ZERO)
 
 
-CLASSES = [Output, Oscillator, MoogFilter, ADSR, VCA, MonoMixer, Math, GridSequencer, PatternSequencer, NonLinear, Sample]  # index = SRACK_MOD_*
+_M64 = (1 << 64) - 1
+
+
+def splitmix64(x):  # the output function applied to x + golden gamma (Steele, Lea, Flood 2014); Python ints, mod 2^64
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+class Noise(Module):  # oscillator.rs:308-393
+    """`(rand::random::<f32>() - 0.5) * 2.0` per sample (oscillator.rs:385).  rand 0.8's Standard f32 is 24 random bits
+    * 2^-24; the reference's bits come from an OS-seeded thread-local ChaCha12 (unreproducible), here from the
+    counter-based stream documented in include/srack_hip.h: sample n = output n of splitmix64 seeded with
+    key = sm(sm(seed ^ sm(module)) ^ global_voice)."""
+    n_in, n_out = 0, 1
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.module_index = 0  # set by the graph adapter
+        self.n = 0
+
+    def calc(self):
+        base = splitmix64(self.cfg.get("noise_seed", 0) ^ splitmix64(self.module_index))
+        key = splitmix64(base ^ self.cfg.get("noise_voice", 0))
+        out = self.outs[0]
+        for i in range(len(out)):
+            z = splitmix64((key + (self.n + i) * 0x9E3779B97F4A7C15) & _M64)
+            r = f32(z >> 40) * f32(2.0 ** -24)
+            out[i] = (r - f32(0.5)) * TWO
+        self.n += len(out)
+
+
+CLASSES = [Output, Oscillator, MoogFilter, ADSR, VCA, MonoMixer, Math, GridSequencer, PatternSequencer, NonLinear, Sample, Noise]  # index = SRACK_MOD_*
 
 
 def get_inputs(m):  # synth.rs:214-218

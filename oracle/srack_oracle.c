@@ -116,6 +116,7 @@ typedef struct {
         struct { float gain[4]; } mix;
         struct { float constant; int operation; } math;
         struct { float constant; } nonlin;
+        struct { uint64_t n; } noise; /* samples drawn so far */
         or_sample smp;
         or_seq seq;
     } u;
@@ -132,6 +133,8 @@ typedef struct or_patch {
     /* removed scheduler edges recorded by the planner: (from, module) pairs */
     int* removed;
     int n_removed;
+    /* NoiseModule streams (no reference counterpart: rand::random is OS-seeded): or_set_noise_seed */
+    uint64_t noise_seed, noise_voice;
 } or_patch;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -232,6 +235,11 @@ int or_add_module(or_patch* p, int type)
         m->n_in = 2;
         m->n_out = 1;
         m->u.nonlin.constant = 1.0f;
+        break;
+    case SRACK_MOD_NOISE: /* oscillator.rs:314-320 */
+        m->n_in = 0;
+        m->n_out = 1;
+        m->u.noise.n = 0;
         break;
     case SRACK_MOD_SAMPLE: /* sample.rs:88-101; WaveBox::default() => no samples, sample_rate 0.0, new false */
         m->n_in = 2;
@@ -957,6 +965,34 @@ static void or_calc_output(or_patch* p, or_module* m)
     }
 }
 
+/* NoiseModule::calc, oscillator.rs:381-387: `*sample = (rand::random::<f32>() - 0.5) * 2.0`.
+ * rand 0.8.5 (Cargo.toml:29): random::<f32>() = thread_rng().gen() = Standard: (next_u32() >> 8) as f32 * 2^-24, i.e. one
+ * of 2^24 equally likely multiples of 2^-24 in [0, 1); thread_rng is ChaCha12 seeded from the OS, so the reference's
+ * sequence differs on every run and cannot be a parity target.  What is restated is the map from 24 random bits to
+ * the sample; the bits come from the documented counter-based stream of include/srack_hip.h
+ * (srack_patch_set_noise_seed): sample n of a voice = output n of splitmix64 seeded with the voice's key. */
+static uint64_t or_splitmix64(uint64_t x);
+static void or_calc_noise(or_patch* p, or_module* m)
+{
+    const int module = (int)(m - p->modules);
+    const uint64_t base = or_splitmix64(p->noise_seed ^ or_splitmix64((uint64_t)module));
+    const uint64_t key = or_splitmix64(base ^ p->noise_voice);
+    float* out = m->out[0];
+    for (uint32_t i = 0; i < p->buffer_size; i++) {
+        const uint64_t z = or_splitmix64(key + (m->u.noise.n + i) * 0x9E3779B97F4A7C15ull);
+        const float r = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+        out[i] = (r - 0.5f) * 2.0f;
+    }
+    m->u.noise.n += p->buffer_size;
+}
+
+/* seed and GLOBAL index of the voice this patch object is (or_render_batch: proto's index + v) */
+void or_set_noise_seed(or_patch* p, uint64_t seed, uint64_t voice)
+{
+    p->noise_seed = seed;
+    p->noise_voice = voice;
+}
+
 static void or_calc(or_patch* p, or_module* m)
 {
     switch (m->type) {
@@ -969,6 +1005,7 @@ static void or_calc(or_patch* p, or_module* m)
     case SRACK_MOD_MATH: or_calc_math(p, m); break;
     case SRACK_MOD_NONLINEAR: or_calc_nonlin(p, m); break;
     case SRACK_MOD_SAMPLE: or_calc_sample(p, m); break;
+    case SRACK_MOD_NOISE: or_calc_noise(p, m); break;
     case SRACK_MOD_GRID_SEQUENCER: or_calc_gridseq(p, m); break;
     case SRACK_MOD_PATTERN_SEQUENCER: or_calc_patseq(p, m); break;
     }
@@ -1081,6 +1118,7 @@ static void* or_batch_worker(void* arg)
     float* tmp = (float*)malloc(sizeof(float) * (size_t)C * T);
     for (uint32_t v = j->v0; v < j->v1; v++) {
         or_patch* p = or_patch_clone(j->proto);
+        p->noise_voice = j->proto->noise_voice + v;
         for (int k = 0; k < j->n_ov; k++) or_set_field(p, j->ov[k].module, j->ov[k].field, j->ov[k].values[v]);
         or_render(p, T, tmp, -1, 0, NULL);
         if (j->frames)

@@ -249,6 +249,15 @@ int srack_patch_set_output_buffer(srack_patch* p, int module, int port, const fl
     return p->h.graph.set_output_buffer(module, port, samples, n);
 }
 
+int srack_patch_set_noise_seed(srack_patch* p, uint64_t seed, uint64_t first_voice)
+{
+    CHECK_HANDLE(p);
+    p->h.graph.cfg.noise_seed = seed;
+    p->h.graph.cfg.noise_first_voice = first_voice;
+    p->h.graph.revision++;  // the keys are part of the flattened program
+    return SRACK_OK;
+}
+
 int srack_patch_connect(srack_patch* p, int src_module, int src_port, int sink_module, int sink_port)
 {
     CHECK_HANDLE(p);

@@ -350,6 +350,13 @@ int Builder::build()
             if (connected(1)) op.flags |= MATH_HAS_IN2;
             param(op, NONLIN_P_CONST, m, SRACK_NONLIN_CONSTANT, deferred);
             break;
+        case SRACK_MOD_NOISE: {  // stateless: sample n of voice v is a function of (seed, module, first_voice + v, n)
+            op.kind = OP_NOISE;
+            const uint64_t base = noise_base_key(g.cfg.noise_seed, m), first = g.cfg.noise_first_voice;
+            std::memcpy(&op.delta, &base, 8);
+            std::memcpy(&op.sample_rate, &first, 8);
+            break;
+        }
         case SRACK_MOD_SAMPLE: {
             op.kind = OP_SAMPLE;
             if (connected(0)) op.flags |= SMP_HAS_GATE;
@@ -939,7 +946,7 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
     // ---- 3. voice-invariant sub-graph ----------------------------------------------------------------
     if (n_voices > 1 && !(render_flags & SRACK_RENDER_NO_UNIFORM_HOIST)) {
         std::vector<char>& u = A.in_ctl;
-        for (int m = 0; m < n_mod; m++) u[(size_t)m] = A.live[(size_t)m] && m != output;
+        for (int m = 0; m < n_mod; m++) u[(size_t)m] = A.live[(size_t)m] && m != output && g.modules[(size_t)m].type != SRACK_MOD_NOISE;  // every voice draws its own noise
         for (const auto& o : overrides) u[(size_t)o.module] = 0;
         const auto& pos = g.plan.position;
         for (bool changed = true; changed;) {

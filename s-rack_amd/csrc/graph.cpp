@@ -14,6 +14,16 @@ const char* last_error() { return g_error.c_str(); }
 
 // Module ids only have to be unique strings (they key the connection list of a .srk file, ui.rs:612-637); the layout
 // follows a version-4 UUID so files written here look like the reference's.
+uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+uint64_t noise_base_key(uint64_t seed, int module) { return splitmix64(seed ^ splitmix64((uint64_t)module)); }
+
 std::string new_module_id()
 {
     static std::atomic<uint64_t> counter{0};
@@ -48,6 +58,7 @@ int Graph::fields_of_type(int type)
     case SRACK_MOD_PATTERN_SEQUENCER: return SRACK_PATSEQ__NFIELDS;
     case SRACK_MOD_NONLINEAR: return SRACK_NONLIN__NFIELDS;
     case SRACK_MOD_SAMPLE: return SRACK_SAMPLE__NFIELDS;
+    case SRACK_MOD_NOISE: return 0;
     default: return -1;
     }
 }
@@ -167,6 +178,10 @@ int Graph::add_module(int type)
         m.n_out = 1;
         m.fields[SRACK_SAMPLE_SAMPLE_RATE] = (double)(float)cfg.sample_rate;
         m.fields[SRACK_SAMPLE_GATE_LAST] = 1.0;
+        break;
+    case SRACK_MOD_NOISE:  // oscillator.rs:314-320: no inputs, one output, no parameters
+        m.n_in = 0;
+        m.n_out = 1;
         break;
     }
     m.in.assign((size_t)m.n_in, InputRef{});

@@ -46,7 +46,12 @@ struct AudioConfig {  // synth.rs:20-25
     uint32_t sample_rate = 48000;
     uint32_t buffer_size = 1024;
     uint32_t channels = 2;
+    // not in the reference (its NoiseModule draws from an OS-seeded thread-local generator): srack_patch_set_noise_seed
+    uint64_t noise_seed = 0, noise_first_voice = 0;
 };
+
+uint64_t splitmix64(uint64_t x);                         // output function applied to x + 0x9E3779B97F4A7C15
+uint64_t noise_base_key(uint64_t seed, int module);      // sm(seed ^ sm(module)), see srack_hip.h
 
 struct Edge {  // a wire src.port -> sink.port
     int src, src_port, sink, sink_port;

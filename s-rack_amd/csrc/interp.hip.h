@@ -433,6 +433,18 @@ __device__ __noinline__ void tile_nonlin(const Ctx c_v, COp& op_v)
     tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = nonlin_step(fl, x[0], x[1], constant); });
 }
 
+// NoiseModule: stateless — the tile's samples are n_abs .. n_abs + c.n - 1 of this voice's stream.
+template <bool kExact>
+__device__ __noinline__ void tile_noise(const Ctx c_v, COp& op_v, uint64_t n_abs, uint32_t voice_c)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    const uint64_t base = (uint64_t)__double_as_longlong(op.delta), first = (uint64_t)__double_as_longlong(op.sample_rate);
+    const uint64_t key = noise_voice_key(base, first + voice_c);
+    const Port out = out_port(c, op.out_slot[0]);
+    for (int i = 0; i < c.n; i++) out.p[i * out.stride] = noise_sample(key, n_abs + (uint64_t)i);
+}
+
 // SampleModule (sample.rs:192-240) in two passes over the tile: the position state machine does not depend on the
 // samples it reads, so pass 1 leaves each sample's read INDEX in the output wire and pass 2 turns indices into
 // samples with independent gathers from the shared wave (8 loads in flight per lane instead of one per step).
@@ -731,6 +743,7 @@ SRK_DEV void interp_body(dev::CArgs& a)
             case OP_PATSEQ: dev::tile_seq<kExact>(c, op, ca); break;
             case OP_NONLIN: dev::tile_nonlin<kExact>(c, op); break;
             case OP_SAMPLE: dev::tile_sample<kExact>(c, op, ca); break;
+            case OP_NOISE: dev::tile_noise<kExact>(c, op, a.n0 + t0, voice_c); break;
             case OP_DELAY_RD: dev::tile_delay_rd<kExact>(c, op, ca, a.n0 + t0, voice_c); break;
             case OP_DELAY_WR: dev::tile_delay_wr<kExact>(c, op, ca, a.n0 + t0, voice, active); break;
             default: break;

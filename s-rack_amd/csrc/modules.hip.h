@@ -624,6 +624,26 @@ SRK_DEV float math_step(uint32_t flags, float in1, float in2, float constant)
 }
 
 // ---------------------------------------------------------------------------------------------
+// NoiseModule — oscillator.rs:381-387: `(rand::random::<f32>() - 0.5) * 2.0`.  rand 0.8's Standard f32 is
+// (next_u32() >> 8) as f32 * 2^-24: 2^24 equally likely values in [0, 1).  The reference's generator is the OS-seeded
+// thread-local ChaCha12, so only that distribution is reproducible; the draw is this library's (srack_hip.h): sample n of
+// a voice is output n of a splitmix64 generator seeded with the voice's key.  (r - 0.5) * 2 is exact in f32.
+// ---------------------------------------------------------------------------------------------
+SRK_DEV uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+SRK_DEV uint64_t noise_voice_key(uint64_t base, uint64_t global_voice) { return splitmix64(base ^ global_voice); }
+SRK_DEV float noise_sample(uint64_t key, uint64_t n)
+{
+    const uint32_t k24 = (uint32_t)(splitmix64(key + n * 0x9E3779B97F4A7C15ull) >> 40);
+    return ((float)k24 * 0x1p-24f - 0.5f) * 2.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // NonLinearModule — math.rs:203-205: `if a > 0.0 { a.powf(b) } else { -(-a).powf(b) }`
 // ---------------------------------------------------------------------------------------------
 // f32 powf(x, b) for the common case (x finite > 0, b finite, result a normal float) as 2^(b*log2 x) in f64:

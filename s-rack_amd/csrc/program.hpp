@@ -24,7 +24,8 @@ enum OpKind : int32_t {
     OP_GRIDSEQ = 11,   // GridSequencerModule::calc    sequencer.rs:190-246
     OP_PATSEQ = 12,    // PatternSequencerModule::calc sequencer.rs:482-533
     OP_NONLIN = 13,    // NonLinearModule::calc        math.rs:291-311
-    OP_SAMPLE = 14     // SampleModule::calc           sample.rs:192-240
+    OP_SAMPLE = 14,    // SampleModule::calc           sample.rs:192-240
+    OP_NOISE = 15      // NoiseModule::calc            oscillator.rs:381-387 (the draw: srack_hip.h, srack_patch_set_noise_seed)
 };
 
 // per-kind flag bits -----------------------------------------------------------------------------
@@ -107,8 +108,8 @@ struct DevOp {
     int32_t aux;                // OP_OUT: plane; OP_DELAY_*: ring id / first LDS row; sequencers: dword offset of the 64 cells in seqtab; OP_SAMPLE: dword offset of the wave in seqtab
     int32_t seq_row;            // sequencers: LDS row the 64 cells are staged in (shared by the wave, indexed by step)
     int32_t seq_len;            // sequencers: sequence length (1..64); OP_SAMPLE: wave length in samples
-    double delta;
-    double sample_rate;         // OP_OSC: f64(sample_rate), the divisor of oscillator.rs:132
+    double delta;               // OP_NOISE: the bit pattern of the module's u64 base key
+    double sample_rate;         // OP_OSC: f64(sample_rate), the divisor of oscillator.rs:132; OP_NOISE: the bit pattern of the u64 first_voice
 };
 
 struct DevProgram {

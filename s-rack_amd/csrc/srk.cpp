@@ -399,8 +399,15 @@ Module parse_module(Reader& r, Graph& scratch)
         r.boolean();  // ui_dirty
         return m;
     }
-    if (variant == "NoiseModuleV0" || variant == "FreeverbModuleV0")
-        throw UnsupportedError("srk: " + variant + " is outside the render path's scope (unseedable RNG / un-vendored freeverb crate)");
+    if (variant == "NoiseModuleV0") {  // oscillator.rs:308-312: id, out
+        r.array_of(2, "NoiseModule");
+        Module m = fresh(SRACK_MOD_NOISE);
+        m.id = r.str();
+        keep_buffer(m, 0, r.audio_buffer(), cfg);
+        return m;
+    }
+    if (variant == "FreeverbModuleV0")
+        throw UnsupportedError("srk: " + variant + " is outside the render path's scope (its arithmetic lives in the un-vendored freeverb crate)");
     std::string shown;
     for (char ch : variant.substr(0, 48)) shown += (ch >= 0x20 && ch < 0x7f) ? ch : '?';  // a damaged file: keep the message printable
     r.fail("unknown SynthModuleType variant '" + shown + "'");
@@ -577,6 +584,12 @@ void write_module(Writer& w, const Module& m, const AudioConfig& cfg)
         w.str(m.id);
         write_buffer(w, m, 0, B);
         w.f32(F(SRACK_NONLIN_CONSTANT));
+        break;
+    case SRACK_MOD_NOISE:
+        w.variant("NoiseModuleV0");
+        w.array(2);
+        w.str(m.id);
+        write_buffer(w, m, 0, B);
         break;
     case SRACK_MOD_SAMPLE:
         w.variant("SampleModuleV0");

@@ -8,7 +8,7 @@ import numpy as np
 
 # numeric vocabulary of include/srack_hip.h
 (MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH, MOD_GRID_SEQUENCER,
- MOD_PATTERN_SEQUENCER, MOD_NONLINEAR, MOD_SAMPLE) = range(11)
+ MOD_PATTERN_SEQUENCER, MOD_NONLINEAR, MOD_SAMPLE, MOD_NOISE) = range(12)
 OSC_VAL, OSC_ANTIALIASING, OSC_POS, OSC_SYNC_LAST = range(4)
 (VCF_FREQ, VCF_RES, VCF_EXP_AMT, VCF_ST_F, VCF_ST_P, VCF_ST_Q, VCF_ST_B0, VCF_ST_B1, VCF_ST_B2, VCF_ST_B3,
  VCF_ST_B4, VCF_ST_FREQ, VCF_ST_RES) = range(13)

@@ -5,18 +5,23 @@ import srack_pkg
 
 W = srack_pkg.load_workloads()
 
-OSC, VCF, ADSR, VCA, MIX, MATH, GRID, PAT, SMP = 1, 2, 3, 4, 5, 6, 7, 8, 10
-N_IN = {OSC: 2, VCF: 2, ADSR: 1, VCA: 2, MIX: 4, MATH: 2, GRID: 2, PAT: 2, SMP: 2}
-OUT_PORTS = {OSC: [1, 2], VCF: [0, 1, 2], ADSR: [0], VCA: [0], MIX: [0], MATH: [0], GRID: [0, 1, 2], PAT: [0, 3, 7, 8], SMP: [0]}
+OSC, VCF, ADSR, VCA, MIX, MATH, GRID, PAT, SMP, NOISE = 1, 2, 3, 4, 5, 6, 7, 8, 10, 11
+N_IN = {OSC: 2, VCF: 2, ADSR: 1, VCA: 2, MIX: 4, MATH: 2, GRID: 2, PAT: 2, SMP: 2, NOISE: 0}
+OUT_PORTS = {OSC: [1, 2], VCF: [0, 1, 2], ADSR: [0], VCA: [0], MIX: [0], MATH: [0], GRID: [0, 1, 2], PAT: [0, 3, 7, 8], SMP: [0], NOISE: [0]}
 
 
-def random_patch(seed):
-    """-> (B, build(g) -> None, overrides [(module, field, values per voice fn)])"""
-    rng = np.random.default_rng(seed)
+def random_patch(seed, noise=False):
+    """-> (B, build(g) -> None, overrides [(module, field, values per voice fn)]).  noise=True: a fifth of the modules are
+    NoiseModules (a separate family of patches: the seeds of the noise-free family keep their meaning)."""
+    rng = np.random.default_rng(seed if not noise else (seed, 0x4e6f))
     B = int(rng.choice([1, 3, 16, 64, 1024]))
     n = int(rng.integers(4, 11))
     types = [OSC, OSC] + [int(rng.choice([OSC, VCF, ADSR, VCA, MIX, MATH, GRID, PAT, SMP], p=[.2, .15, .12, .13, .1, .15, .05, .05, .05])) for _ in range(n - 2)]
     rng.shuffle(types)
+    if noise:
+        types = [NOISE if rng.random() < 0.2 else t for t in types]
+        if NOISE not in types:
+            types[int(rng.integers(0, n))] = NOISE
     fields, steps, conns, waves = [], [], [], []
     for m, t in enumerate(types):
         if t == OSC:
@@ -74,6 +79,8 @@ def random_patch(seed):
             g.connect(shift(s), sp, shift(k), kp)
         for s, sp, c in out_conns:
             g.connect(shift(s), sp, build.out, c)
+        if noise:
+            g.set_noise_seed(seed * 7919 + 1, 1000 * seed)
         return ids
 
     overrides = []

@@ -15,7 +15,11 @@ class NumpyGraph:
 
     def add_module(self, mtype):
         self.modules.append(N.CLASSES[mtype](self.cfg))
+        self.modules[-1].module_index = len(self.modules) - 1  # (NoiseModule keys its stream by it)
         return len(self.modules) - 1
+
+    def set_noise_seed(self, seed, voice=0):
+        self.cfg["noise_seed"], self.cfg["noise_voice"] = int(seed), int(voice)
 
     def connect(self, src, src_port, sink, sink_port):
         self.modules[sink].inputs[sink_port] = (self.modules[src], src_port)

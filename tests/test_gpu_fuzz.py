@@ -1,7 +1,8 @@
 """Differential fuzzing of the whole render path: random patches, GPU (several render modes) against the CPU oracle.
 
 Patches are random graphs over the module types whose GPU arithmetic is bit-exact in exact-oscillator mode (oscillator
-saw / square ports, ladder filter, ADSR, VCA, mixer, math, both sequencers, the sample player), wired at random — cycles included, so the
+saw / square ports, ladder filter, ADSR, VCA, mixer, math, both sequencers, the sample player, and — in a second family of
+patches — the noise source), wired at random — cycles included, so the
 planner's broken edges become delay rings — with random parameters and random per-voice overrides.  What this is after
 is the host side: planning, dead-code elimination, uniform hoisting, control units, wire-slot reuse, rings, tiles.
 """
@@ -15,12 +16,12 @@ pytestmark = pytest.mark.gpu
 from tests.fuzz_patches import random_patch  # noqa: E402
 
 
-@pytest.mark.parametrize("seed", range(160))
-def test_random_patch_matches_oracle(seed, oracle, monkeypatch):
+@pytest.mark.parametrize("seed,noise", [(s, False) for s in range(160)] + [(s, True) for s in range(40)])
+def test_random_patch_matches_oracle(seed, noise, oracle, monkeypatch):
     S = srack_pkg.load()
     if seed % 2:  # few voices normally run as quarter-filled waves (more waves, same cost); odd seeds force the full,
         monkeypatch.setenv("SRACK_WANT_WAVES", "1")  # 64-lane waves large renders use — with a ragged last wave
-    B, build, overrides = random_patch(seed)
+    B, build, overrides = random_patch(seed, noise)
     V, T = (67, 1300) if B < 1024 else (131, 2300)  # past the first control chunk (1024) and, at B = 1024, past two ring periods
     o = oracle.OraclePatch(48000, B, 2)
     ids = build(o)
@@ -40,12 +41,12 @@ def test_random_patch_matches_oracle(seed, oracle, monkeypatch):
         assert same.all(), f"seed {seed} flags {flags}: {1 - same.mean():.5f} of the samples differ; {p.info()}"
 
 
-@pytest.mark.parametrize("seed", range(60))
-def test_random_patch_renders_continue_across_calls(seed):
+@pytest.mark.parametrize("seed,noise", [(s, False) for s in range(60)] + [(s, True) for s in range(20)])
+def test_random_patch_renders_continue_across_calls(seed, noise):
     """State carries over between calls in every mode, default (approximating) modes included: render(T) equals
     render(a) ++ render(b) ++ render(c) bit for bit, whatever kernels, tiles, chunks and control units the patch got."""
     S = srack_pkg.load()
-    B, build, overrides = random_patch(seed)
+    B, build, overrides = random_patch(seed, noise)
     rng = np.random.default_rng(1000 + seed)
     V, T = 70, 2600
     cuts = sorted(int(c) for c in rng.choice(np.arange(1, T), size=2, replace=False))

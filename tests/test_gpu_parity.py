@@ -859,3 +859,80 @@ def test_long_render_crosses_segments_with_a_control_pipeline(S, oracle):
         want = ref.astype(np.float64).sum(axis=2)
         scale = np.abs(ref.astype(np.float64)).sum(axis=2)
         assert (np.abs(mix - want) <= 2e-5 * np.maximum(scale, 1.0)).all()
+
+
+# ---- NoiseModule (oscillator.rs:308-393): the library's counter-based stream, bit for bit against the oracle ------------------
+def _noise_patch(g, S, seed, first_voice):
+    nz, vcf, vca, out = g.add_module(S.MOD_NOISE), g.add_module(S.MOD_MOOG_FILTER), g.add_module(S.MOD_VCA), g.add_module(S.MOD_OUTPUT)
+    g.connect(nz, 0, vcf, 0)
+    g.connect(vcf, 0, vca, 0)
+    g.connect(nz, 0, vca, 1)       # noise as a CV too: the VCA opens where the noise is positive
+    g.connect(vca, 0, out, 0)
+    g.connect(nz, 0, out, 1)       # channel 1 = the raw noise
+    g.set_noise_seed(seed, first_voice)
+    return dict(nz=nz, vcf=vcf)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", MODES)
+@pytest.mark.parametrize("V", [1, 70, 300])
+def test_noise_vs_oracle(S, oracle, V, flags):
+    T, seed, first = 700, 0xC0FFEE1234, 2**33 + 5
+    o = oracle.OraclePatch(48000, 64, 2)
+    ids = _noise_patch(o, S, seed, first)
+    cut = np.linspace(0.05, 0.6, V).astype(np.float32)
+    ref, ref_mix = o.render_batch(V, T, [(ids["vcf"], S.VCF_FREQ, cut)], mix=True, threads=4)
+    p = S.Patch(48000, 64, 2)
+    _noise_patch(p, S, seed, first)
+    p.configure_voices(V)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    fr, mix = p.render(T, flags=flags)
+    np.testing.assert_array_equal(bits(fr[1]), bits(ref[1]))           # the draw itself: exact in every mode
+    if flags & 1:
+        np.testing.assert_array_equal(bits(fr[0]), bits(ref[0]))       # exact modes: the ladder and the VCA too
+    else:
+        assert_close(fr[0], ref[0])
+    scale = np.abs(ref.astype(np.float64)).sum(axis=2)
+    assert (np.abs(mix - ref_mix) <= 2e-5 * np.maximum(scale, 1.0)).all()
+    assert len({fr[1, :, v].tobytes() for v in range(V)}) == V         # one stream per voice
+
+
+@pytest.mark.gpu
+def test_noise_is_chunk_and_shard_invariant(S):
+    V, T = 200, 1000
+    def make(first, voices):
+        p = S.Patch(48000, 32, 2)
+        _noise_patch(p, S, 77, first)
+        p.configure_voices(voices)
+        return p
+    whole, _ = make(0, V).render(T)
+    q = make(0, V)
+    parts = [q.render(n)[0] for n in (1, 31, 32, 500, 436)]
+    np.testing.assert_array_equal(bits(np.concatenate(parts, axis=1)), bits(whole))   # sample n is a function of n, not of the chunking
+    lo, hi = make(0, 120).render(T)[0], make(120, 80).render(T)[0]                    # two ranks: voices [0,120) and [120,200)
+    np.testing.assert_array_equal(bits(np.concatenate([lo, hi], axis=2)), bits(whole))
+    r = make(0, V)
+    r.set_noise_seed(78)
+    r.configure_voices(V)
+    assert not np.array_equal(r.render(T)[0][1], whole[1])
+
+
+@pytest.mark.gpu
+def test_noise_statistics_at_scale(S):
+    """65 536 voices x 512 samples of raw noise: the grid of rand's Standard f32, mean, variance, no voice-to-voice correlation."""
+    V, T = 65536, 512
+    p = S.Patch(48000, 1024, 1)
+    nz, out = p.add_module(S.MOD_NOISE), p.add_module(S.MOD_OUTPUT)
+    p.connect(nz, 0, out, 0)
+    p.configure_voices(V)
+    fr, mix = p.render(T)
+    x = fr[0].astype(np.float64)
+    k = (x + 1.0) * 2.0 ** 23
+    assert (k == np.round(k)).all() and x.min() >= -1.0 and x.max() < 1.0
+    n = x.size
+    assert abs(x.mean()) < 5 / np.sqrt(3 * n) and abs(x.var() - 1 / 3) < 1e-3
+    assert abs(np.corrcoef(x[:, 0::2].ravel(), x[:, 1::2].ravel())[0, 1]) < 5 / np.sqrt(n / 2)   # neighbouring voices
+    assert abs(np.corrcoef(x[:-1].ravel(), x[1:].ravel())[0, 1]) < 5 / np.sqrt(n)                 # consecutive samples
+    counts = np.bincount((k.astype(np.int64) >> 18).ravel(), minlength=64)
+    assert 25 < ((counts - n / 64) ** 2 / (n / 64)).sum() < 120
+    assert (np.abs(mix[0] - x.sum(axis=1)) <= 1e-5 * np.maximum(np.abs(x).sum(axis=1), 1.0)).all()

@@ -55,8 +55,8 @@ def test_error_behaviour(S):
     with pytest.raises(S.SrackError) as e:
         p.connect(7, 0, out, 0)
     assert e.value.code == S.ERR_INVALID
-    with pytest.raises(S.SrackError) as e:  # NoiseModule / Freeverb etc. are out of scope
-        p.add_module(11)
+    with pytest.raises(S.SrackError) as e:  # FreeverbModule (un-vendored crate) is out of scope
+        p.add_module(12)
     assert e.value.code == S.ERR_UNSUPPORTED
     for bad in ((0, 64, 2), (70000, 64, 2), (48000, 0, 2), (48000, 64, 0), (48000, 64, 9)):
         with pytest.raises(S.SrackError):
@@ -266,3 +266,34 @@ def test_sample_and_nonlinear_graph_api(S):
         p.set_voice_field(smp, S.SAMPLE_WAVE_NEW, np.zeros(256))
         p.info()
     assert e.value.code == S.ERR_UNSUPPORTED
+
+
+def test_noise_module_graph_api(S):
+    """oscillator.rs:308-393: no inputs, one output, no parameters; usable as a source like any other module."""
+    p = S.Patch(48000, 64, 2)
+    nz, vcf, out = p.add_module(S.MOD_NOISE), p.add_module(S.MOD_MOOG_FILTER), p.add_module(S.MOD_OUTPUT)
+    assert (p.get_num_inputs(nz), p.get_num_outputs(nz)) == (0, 1)
+    with pytest.raises(S.SrackError) as e:
+        p.connect(vcf, 0, nz, 0)                 # set_input is Err(())
+    assert e.value.code == S.ERR_PORT
+    with pytest.raises(S.SrackError) as e:
+        p.connect(nz, 1, vcf, 0)                 # get_output(1) is Err(())
+    assert e.value.code == S.ERR_PORT
+    with pytest.raises(S.SrackError):
+        p.set_field(nz, 0, 1.0)                  # no fields
+    p.connect(nz, 0, vcf, 0)
+    p.connect(vcf, 0, out, 0)
+    p.connect(nz, 0, out, 1)
+    assert p.plan() == [nz, vcf, out]
+    p.set_noise_seed(1234, first_voice=5)
+    p.configure_voices(128)
+    info = p.info()                              # every voice draws its own noise: nothing is hoisted to the control program
+    assert "ctl[" not in info and "ops=4" in info, info
+
+
+def test_mix_tree_lane_map_is_documented_formula():
+    """(kept from the register-tree mix-down experiment, DESIGN section 4: the lane -> sample map of the reduction tree)"""
+    L = np.arange(64)
+    row, bank, hi = L >> 4, (L >> 2) & 3, (L >> 1) & 1
+    slot = 16 * hi + 8 * (bank & 1) + 4 * (bank >> 1) + 2 * (row & 1) + (row >> 1)
+    assert sorted(set(slot.tolist())) == list(range(32)) and (np.bincount(slot) == 2).all()

@@ -471,10 +471,10 @@ def test_pow2_libm_formula_matches_glibc():
 
 
 # ---- random patches: the two restatements agree bit for bit on graphs nobody hand-picked -----------------------------
-@pytest.mark.parametrize("seed", range(80))
-def test_random_patches_c_equals_numpy(oracle, seed):
+@pytest.mark.parametrize("seed,noise", [(s, False) for s in range(80)] + [(s, True) for s in range(20)])
+def test_random_patches_c_equals_numpy(oracle, seed, noise):
     from tests.fuzz_patches import random_patch
-    B, build, overrides = random_patch(seed)
+    B, build, overrides = random_patch(seed, noise)
     T = 500 if B < 1024 else 1300
     g = oracle.OraclePatch(48000, B, 2)
     ids = build(g)
@@ -487,3 +487,71 @@ def test_random_patches_c_equals_numpy(oracle, seed):
     assert g.plan() == ng.plan()[0]
     a, b = g.render(T), ng.render(T)
     np.testing.assert_array_equal(bits(a), bits(b))
+
+
+# ---- NoiseModule (oscillator.rs:308-393): the reference's draw is OS-seeded, so what is pinned is the map from 24 random bits
+# to the sample, the published splitmix64 vectors for the bit source, and C == NumPy ---------------------------------------------
+def _noise_patch(g, seed, voice):
+    nz, vcf, out = g.add_module(11), g.add_module(2), g.add_module(0)
+    g.connect(nz, 0, vcf, 0)
+    g.connect(vcf, 0, out, 0)
+    g.connect(nz, 0, out, 1)
+    g.set_noise_seed(seed, voice)
+    return nz
+
+
+def test_splitmix64_published_vectors(oracle):
+    from oracle.srack_numpy import splitmix64
+    # Vigna's splitmix64.c seeded with 0: x += gamma; return mix(x) — the first four outputs
+    want = [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F, 0xF88BB8A8724C81EC]
+    assert [splitmix64((n * 0x9E3779B97F4A7C15) & (2**64 - 1)) for n in range(4)] == want
+    # the C oracle's copy, through the one export that uses it: (sm(seed ^ (2 voice + k)) >> 40) * 2^-24
+    assert oracle.lib().or_voice_uniform(0, 0, 0) == np.float32((want[0] >> 40) * 2.0 ** -24)
+
+
+@pytest.mark.parametrize("seed,voice", [(0, 0), (1234, 7), (2**64 - 1, 2**40 + 3)])
+def test_noise_c_equals_numpy_and_is_the_documented_stream(oracle, seed, voice):
+    from oracle.srack_numpy import splitmix64
+    B, T = 16, 400
+    g, ng = oracle.OraclePatch(48000, B, 2), NumpyGraph(48000, B, 2)
+    nz = _noise_patch(g, seed, voice)
+    _noise_patch(ng, seed, voice)
+    a, b = g.render(T), ng.render(T)
+    np.testing.assert_array_equal(bits(a), bits(b))
+    key = splitmix64(splitmix64(seed ^ splitmix64(nz)) ^ voice)
+    want = [((splitmix64((key + n * 0x9E3779B97F4A7C15) % 2**64) >> 40) * 2.0 ** -24 - 0.5) * 2.0 for n in range(T)]
+    np.testing.assert_array_equal(a[1], np.array(want, dtype=np.float32))  # channel 1 = the raw noise
+    assert np.abs(a[0]).max() > 0.01                                        # channel 0 went through the ladder
+
+
+def test_noise_distribution_matches_rand_standard_f32(oracle):
+    """rand 0.8 Standard f32 = 24 uniform bits * 2^-24; (r - 0.5) * 2 => the 2^24 values k * 2^-23 - 1, equally likely."""
+    g = oracle.OraclePatch(48000, 1024, 2)
+    _noise_patch(g, 99, 0)
+    x = g.render(1 << 18)[1].astype(np.float64)
+    k = (x + 1.0) * 2.0 ** 23
+    assert (k == np.round(k)).all() and k.min() >= 0 and k.max() < 2 ** 24 and x.min() >= -1.0 and x.max() < 1.0
+    n = x.size
+    assert abs(x.mean()) < 5 * (1 / np.sqrt(3)) / np.sqrt(n) and abs(x.var() - 1 / 3) < 0.005
+    for lag in (1, 2, 7, 1024):
+        assert abs(np.corrcoef(x[:-lag], x[lag:])[0, 1]) < 5 / np.sqrt(n)
+    counts = np.bincount((k.astype(np.int64) >> 18), minlength=64)       # 64 equal bins: chi-square, 63 degrees of freedom
+    chi2 = ((counts - n / 64) ** 2 / (n / 64)).sum()
+    assert 25 < chi2 < 120
+    low = np.bincount(k.astype(np.int64) & 63, minlength=64)              # and the LOW six of the 24 bits
+    assert 25 < ((low - n / 64) ** 2 / (n / 64)).sum() < 120
+
+
+def test_noise_voices_are_independent_streams_and_shard_by_first_voice(oracle):
+    B, T, V = 32, 512, 6
+    g = oracle.OraclePatch(48000, B, 2)
+    _noise_patch(g, 5, 0)
+    fr, _ = g.render_batch(V, T)
+    assert len({fr[1, :, v].tobytes() for v in range(V)}) == V
+    assert abs(np.corrcoef(fr[1, :, 0], fr[1, :, 1])[0, 1]) < 0.2
+    h = oracle.OraclePatch(48000, B, 2)
+    _noise_patch(h, 5, 4)                                                  # a shard that starts at global voice 4
+    np.testing.assert_array_equal(h.render_batch(2, T)[0], fr[:, :, 4:6])
+    k = oracle.OraclePatch(48000, B, 2)
+    _noise_patch(k, 6, 0)                                                  # another seed: another stream
+    assert not np.array_equal(k.render(T), g.render(T))
