@@ -48,7 +48,8 @@ enum class ModuleType : int {  // the hot-path subset of SynthModuleType (synth.
     PatternSequencer = SRACK_MOD_PATTERN_SEQUENCER,
     NonLinear = SRACK_MOD_NONLINEAR,
     Sample = SRACK_MOD_SAMPLE,
-    Noise = SRACK_MOD_NOISE
+    Noise = SRACK_MOD_NOISE,
+    Freeverb = SRACK_MOD_FREEVERB
 };
 
 class Error : public std::runtime_error {  // what the reference would panic with
@@ -164,7 +165,7 @@ private:
 inline std::string SharedSynthModule::get_name() const
 {
     static const char* names[] = {"Output", "Oscillator", "Moog Filter", "ADSR", "VCA", "Mono Mixer", "Math",
-                                  "Grid Sequencer", "Pattern Sequencer", "Non-Linear", "Sample", "Noise"};  // each module's get_name()
+                                  "Grid Sequencer", "Pattern Sequencer", "Non-Linear", "Sample", "Noise", "Freeverb"};  // each module's get_name()
     int t = srack_patch_module_type(ws_->p_, index_);
     if (t == SRACK_MOD_MATH) {
         static const char* ops[] = {"Add", "Subtract", "Multiply"};  // math.rs:37-43

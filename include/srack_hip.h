@@ -64,7 +64,13 @@ enum {
      * 2^24 equally likely values k * 2^-23 - 1 of rand's Standard f32 — and the draw itself is this library's: a
      * counter-based splitmix64 stream per (seed, module, voice), see srack_patch_set_noise_seed. */
     SRACK_MOD_NOISE       = 11, /* oscillator::NoiseModule     src/synth/oscillator.rs:308-393 */
-    SRACK_MOD__COUNT      = 12
+    /* Stereo reverb: the module (freeverb.rs:8-274) routes six parameters into, and ticks, `freeverb::Freeverb` of the
+     * freeverb crate 0.1.0 (Cargo.lock:1479-1482), which is NOT vendored in the reference tree.  The crate is restated
+     * from its published algorithm — Jezar's Freeverb: eight parallel lowpass-feedback combs and four series allpasses per
+     * channel, the classic tunings scaled by sample_rate / 44100, f64 throughout — see oracle/srack_oracle.c for the
+     * restatement and its status ("parity unpinned": no reference test or vector exercises it). */
+    SRACK_MOD_FREEVERB    = 12, /* freeverb::FreeverbModule    src/synth/freeverb.rs:8-274     */
+    SRACK_MOD__COUNT      = 13
 };
 
 /* ---- ports (u8 in the reference) --------------------------------------------------------- */
@@ -75,6 +81,8 @@ enum { SRACK_VCF_OUT_LOWPASS = 0, SRACK_VCF_OUT_BANDPASS = 1, SRACK_VCF_OUT_HIGH
 enum { SRACK_ADSR_IN_GATE = 0 };                                            /* adsr.rs:77-82 */
 enum { SRACK_VCA_IN_AUDIO = 0, SRACK_VCA_IN_CV = 1 };                       /* vca.rs:50-56 */
 enum { SRACK_SAMPLE_IN_GATE = 0, SRACK_SAMPLE_IN_CV = 1 };                  /* sample.rs:166-172 */
+enum { SRACK_FREEVERB_IN_LEFT = 0, SRACK_FREEVERB_IN_RIGHT = 1 };           /* freeverb.rs:139-145 */
+enum { SRACK_FREEVERB_OUT_LEFT = 0, SRACK_FREEVERB_OUT_RIGHT = 1 };         /* freeverb.rs:192-198 */
 enum { SRACK_SEQ_IN_STEP = 0, SRACK_SEQ_IN_SYNC = 1 };                      /* sequencer.rs:253-259, 543-549 */
 enum { SRACK_GRIDSEQ_OUT_CV = 0, SRACK_GRIDSEQ_OUT_GATE = 1, SRACK_GRIDSEQ_OUT_SYNC = 2 }; /* sequencer.rs:291-298 */
 enum { SRACK_PATSEQ_OUT_GATE0 = 0, SRACK_PATSEQ_OUT_SYNC = 8 };             /* gates 0..7, then sync (sequencer.rs:578-586) */
@@ -134,6 +142,16 @@ enum { /* SampleModule + WaveBox, sample.rs:15-20, 72-85 (the samples themselves
     SRACK_SAMPLE_PLAYING = 4,          /* bool (state) */
     SRACK_SAMPLE_GATE_LAST = 5,        /* transition_detector.last (state) */
     SRACK_SAMPLE__NFIELDS = 6
+};
+enum { /* FreeverbModule, freeverb.rs:19-30: the *_ctl members (what the sliders hold; calc() copies them into the reverb, :88-114).
+        * All f64 except FREEZE (bool).  Per-voice overrides are not supported for this module. */
+    SRACK_FREEVERB_DAMPENING = 0,      /* default 0.5, slider 0..2 */
+    SRACK_FREEVERB_FREEZE = 1,         /* default false */
+    SRACK_FREEVERB_WET = 2,            /* default 1.0 */
+    SRACK_FREEVERB_WIDTH = 3,          /* default 0.5 */
+    SRACK_FREEVERB_ROOM_SIZE = 4,      /* default 0.5 */
+    SRACK_FREEVERB_DRY = 5,            /* default 0.0 */
+    SRACK_FREEVERB__NFIELDS = 6
 };
 /* step contents for srack_patch_set_step.
  * Grid: sequence[step] = None | Some((value, hold)) (sequencer.rs:19);  Pattern: sequence[channel][step] = None | Some(false) | Some(true). */
@@ -214,7 +232,7 @@ int srack_patch_delayed_edges(srack_patch* p, int* quads, int cap);
 /* FileFormat{modules, connections, positions} (ui.rs:578-586) in rmp-serde 1.3.0's compact MessagePack form.
  * load = SynthModuleWorkspaceImpl::deserialize (ui.rs:116-135) against the host's AudioConfig: the module list comes
  * out in REVERSE file order (ui.rs:654-660), V0 variants migrate, saved buffers survive only at the same buffer_size,
- * connections with unknown ids or bad ports are dropped.  Freeverb modules => SRACK_ERR_UNSUPPORTED.
+ * connections with unknown ids or bad ports are dropped.  Every SynthModuleType variant of the reference loads.
  * save = serialize (ui.rs:98-114): writes at most `cap` bytes to `buf` (may be NULL) and the full size to *n_bytes. */
 int srack_patch_load_srk(const void* bytes, size_t n_bytes, uint32_t sample_rate, uint32_t buffer_size, uint32_t channels, srack_patch** out);
 int srack_patch_save_srk(const srack_patch* p, void* buf, size_t cap, size_t* n_bytes);

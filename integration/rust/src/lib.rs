@@ -59,6 +59,7 @@ pub enum ModuleType {
     NonLinear = 9,
     Sample = 10,
     Noise = 11,
+    Freeverb = 12,
 }
 
 #[derive(Debug)]

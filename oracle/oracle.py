@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsrack_oracle.so")
 
 # module types / fields: numeric vocabulary of include/srack_hip.h
-MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH, MOD_GRID_SEQUENCER, MOD_PATTERN_SEQUENCER, MOD_NONLINEAR, MOD_SAMPLE, MOD_NOISE = range(12)
+MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH, MOD_GRID_SEQUENCER, MOD_PATTERN_SEQUENCER, MOD_NONLINEAR, MOD_SAMPLE, MOD_NOISE, MOD_FREEVERB = range(13)
 
 
 def build(force=False):

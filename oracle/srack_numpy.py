@@ -445,7 +445,141 @@ class Noise(Module):  # oscillator.rs:308-393
         self.n += len(out)
 
 
-CLASSES = [Output, Oscillator, MoogFilter, ADSR, VCA, MonoMixer, Math, GridSequencer, PatternSequencer, NonLinear, Sample, Noise]  # index = SRACK_MOD_*
+class _FvDelay:  # freeverb crate, delay_line.rs
+    def __init__(self, length):
+        self.buf = [0.0] * length
+        self.i = 0
+
+    def read(self):
+        return self.buf[self.i]
+
+    def write_and_advance(self, v):
+        self.buf[self.i] = v
+        self.i = 0 if self.i == len(self.buf) - 1 else self.i + 1
+
+
+class _FvComb:  # comb.rs
+    def __init__(self, length):
+        self.d = _FvDelay(length)
+        self.feedback, self.filter_state, self.dampening, self.dampening_inverse = 0.5, 0.0, 0.5, 0.5
+
+    def tick(self, x):
+        out = self.d.read()
+        self.filter_state = out * self.dampening_inverse + self.filter_state * self.dampening
+        self.d.write_and_advance(x + self.filter_state * self.feedback)
+        return out
+
+
+class _FvAllPass:  # all_pass.rs
+    def __init__(self, length):
+        self.d = _FvDelay(length)
+
+    def tick(self, x):
+        delayed = self.d.read()
+        self.d.write_and_advance(x + delayed * 0.5)
+        return -x + delayed
+
+
+class _Freeverb:
+    """freeverb crate 0.1.0 (Cargo.lock:1479-1482), un-vendored: restated from its published algorithm (Jezar's Freeverb in
+    Ian Hobson's Rust port) — PARITY UNPINNED, see oracle/srack_oracle.c.  Python floats are IEEE doubles, as the crate's f64."""
+    COMBS = (1116, 1188, 1277, 1356, 1422, 1491, 1557, 1617)
+    ALLPASSES = (556, 441, 341, 225)
+
+    def __init__(self, sr):
+        adj = lambda n: int(float(n) * float(sr) / 44100.0)
+        self.combs = [(_FvComb(adj(n)), _FvComb(adj(n + 23))) for n in self.COMBS]
+        self.allpasses = [(_FvAllPass(adj(n)), _FvAllPass(adj(n + 23))) for n in self.ALLPASSES]
+        self.wet_gains = (0.0, 0.0)
+        self.wet = self.width = self.dry = self.input_gain = self.dampening = self.room_size = 0.0
+        self.frozen = False
+        self.set_wet(1.0)
+        self.set_width(0.5)
+        self.set_dampening(0.5)
+        self.set_room_size(0.5)
+        self.frozen, self.input_gain = False, 1.0  # set_frozen(false)
+        self.update_combs()
+
+    def update_combs(self):
+        fb, damp = (1.0, 0.0) if self.frozen else (self.room_size, self.dampening)
+        for pair in self.combs:
+            for c in pair:
+                c.feedback, c.dampening, c.dampening_inverse = fb, damp, 1.0 - damp
+
+    def update_wet_gains(self):
+        self.wet_gains = (self.wet * (self.width / 2.0 + 0.5), self.wet * ((1.0 - self.width) / 2.0))
+
+    def set_dampening(self, v):
+        self.dampening = v * 0.4
+        self.update_combs()
+
+    def set_freeze(self, frozen):
+        self.frozen = frozen
+        self.update_combs()
+
+    def set_wet(self, v):
+        self.wet = v * 3.0
+        self.update_wet_gains()
+
+    def set_width(self, v):
+        self.width = v
+        self.update_wet_gains()
+
+    def set_room_size(self, v):
+        self.room_size = v * 0.28 + 0.7
+        self.update_combs()
+
+    def set_dry(self, v):
+        self.dry = v
+
+    def tick(self, in0, in1):
+        x = (in0 + in1) * 0.015 * self.input_gain
+        o0 = o1 = 0.0
+        for a, b in self.combs:
+            o0 += a.tick(x)
+            o1 += b.tick(x)
+        for a, b in self.allpasses:
+            o0 = a.tick(o0)
+            o1 = b.tick(o1)
+        g0, g1 = self.wet_gains
+        return o0 * g0 + o1 * g1 + in0 * self.dry, o1 * g0 + o0 * g1 + in1 * self.dry
+
+
+class Freeverb(Module):  # freeverb.rs:8-274
+    n_in, n_out = 2, 2
+    PARAMS = ("dampening", "freeze", "wet", "width", "room_size", "dry")
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.freeverb = None
+        self.sample_rate = int(cfg["sample_rate"])
+        self.dampening = self.dampening_ctl = 0.5
+        self.freeze = self.freeze_ctl = False
+        self.wet = self.wet_ctl = 1.0
+        self.width = self.width_ctl = 0.5
+        self.room_size = self.room_size_ctl = 0.5
+        self.dry = self.dry_ctl = 0.0
+
+    def set_freeverb(self, all_):  # freeverb.rs:88-114
+        for name in self.PARAMS:
+            ctl = getattr(self, name + "_ctl")
+            if ctl != getattr(self, name) or all_:
+                setattr(self, name, ctl)
+                getattr(self.freeverb, "set_" + name)(ctl)
+
+    def calc(self):  # freeverb.rs:208-270
+        if self.freeverb is None:
+            self.freeverb = _Freeverb(self.sample_rate)
+            self.set_freeverb(True)
+        else:
+            self.set_freeverb(False)
+        l, r = self.resolve(0), self.resolve(1)
+        for i in range(len(self.outs[0])):
+            o0, o1 = self.freeverb.tick(float(l[i]) if l is not None else 0.0, float(r[i]) if r is not None else 0.0)
+            self.outs[0][i], self.outs[1][i] = f32(o0), f32(o1)
+
+
+CLASSES = [Output, Oscillator, MoogFilter, ADSR, VCA, MonoMixer, Math, GridSequencer, PatternSequencer, NonLinear, Sample, Noise, Freeverb]  # index = SRACK_MOD_*
 
 
 def get_inputs(m):  # synth.rs:214-218

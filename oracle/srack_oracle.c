@@ -103,6 +103,38 @@ typedef struct {
     int wave_new;
 } or_sample;
 
+/* ---- freeverb crate 0.1.0 (Cargo.lock:1479-1482; registry checksum 68732b37...8343e), NOT vendored under /root/reference -------
+ * PARITY UNPINNED: restated from the crate's published algorithm — Jezar's public-domain Freeverb as ported to Rust by
+ * Ian Hobson (github.com/irh/freeverb-rs, src/freeverb.rs, comb.rs, all_pass.rs, delay_line.rs) — not from a source file
+ * in this tree; no reference test or golden vector exercises the module, so nothing here is checked against the real crate.
+ * What the restatement fixes: eight parallel combs and four series allpasses per channel; tunings 1116 1188 1277 1356 1422
+ * 1491 1557 1617 / 556 441 341 225 (+23 for the right channel), each scaled as `(len as f64 * sr as f64 / 44100.0) as usize`;
+ * FIXED_GAIN 0.015, SCALE_WET 3, SCALE_DAMPENING 0.4, SCALE_ROOM 0.28, OFFSET_ROOM 0.7, allpass feedback 0.5; all f64.
+ * The module's own part (freeverb.rs) IS in the tree and is followed line by line (or_calc_freeverb). */
+#define OR_FV_COMBS 8
+#define OR_FV_ALLPASSES 4
+typedef struct {
+    double* buffer;
+    uint32_t len, index;
+} or_fv_delay; /* DelayLine: read() = buffer[index]; write_and_advance(v): buffer[index] = v, index = index + 1 wrapped */
+
+typedef struct {
+    or_fv_delay delay;
+    double feedback, filter_state, dampening, dampening_inverse;
+} or_fv_comb;
+
+typedef struct {
+    int initialised;      /* freeverb: Option<Freeverb> is Some (freeverb.rs:17, 209-214) */
+    or_fv_comb comb[OR_FV_COMBS][2];
+    or_fv_delay allpass[OR_FV_ALLPASSES][2];
+    double wet_gain0, wet_gain1, wet, width, dry, input_gain, dampening, room_size;
+    int frozen;
+    /* the module's members, freeverb.rs:18-30 */
+    uint32_t sample_rate;
+    double p_dampening, p_dampening_ctl, p_wet, p_wet_ctl, p_width, p_width_ctl, p_room_size, p_room_size_ctl, p_dry, p_dry_ctl;
+    int p_freeze, p_freeze_ctl;
+} or_freeverb;
+
 typedef struct {
     int type;
     int n_in, n_out;
@@ -117,6 +149,7 @@ typedef struct {
         struct { float constant; int operation; } math;
         struct { float constant; } nonlin;
         struct { uint64_t n; } noise; /* samples drawn so far */
+        or_freeverb fv;
         or_sample smp;
         or_seq seq;
     } u;
@@ -149,12 +182,23 @@ or_patch* or_patch_new(uint32_t sample_rate, uint32_t buffer_size, uint32_t chan
     return p;
 }
 
+static void or_fv_release(or_freeverb* f)
+{
+    if (!f->initialised) return;
+    for (int k = 0; k < OR_FV_COMBS; k++)
+        for (int c = 0; c < 2; c++) free(f->comb[k][c].delay.buffer);
+    for (int k = 0; k < OR_FV_ALLPASSES; k++)
+        for (int c = 0; c < 2; c++) free(f->allpass[k][c].buffer);
+    f->initialised = 0;
+}
+
 void or_patch_free(or_patch* p)
 {
     if (!p) return;
     for (int i = 0; i < p->n_modules; i++) {
         for (int k = 0; k < OR_MAX_OUT; k++) free(p->modules[i].out[k]);
         if (p->modules[i].type == SRACK_MOD_SAMPLE) free(p->modules[i].u.smp.samples);
+        if (p->modules[i].type == SRACK_MOD_FREEVERB) or_fv_release(&p->modules[i].u.fv);
     }
     free(p->modules);
     free(p->plan);
@@ -236,6 +280,15 @@ int or_add_module(or_patch* p, int type)
         m->n_out = 1;
         m->u.nonlin.constant = 1.0f;
         break;
+    case SRACK_MOD_FREEVERB: /* freeverb.rs:60-82 */
+        m->n_in = 2;
+        m->n_out = 2;
+        m->u.fv.sample_rate = p->sample_rate;
+        m->u.fv.p_dampening = m->u.fv.p_dampening_ctl = 0.5;
+        m->u.fv.p_wet = m->u.fv.p_wet_ctl = 1.0;
+        m->u.fv.p_width = m->u.fv.p_width_ctl = 0.5;
+        m->u.fv.p_room_size = m->u.fv.p_room_size_ctl = 0.5;
+        break;
     case SRACK_MOD_NOISE: /* oscillator.rs:314-320 */
         m->n_in = 0;
         m->n_out = 1;
@@ -298,7 +351,19 @@ int or_disconnect(or_patch* p, int sink, int sink_port)
     return 0;
 }
 
-static double* or_field_f64(or_module* m, int field) { return (m->type == SRACK_MOD_OSCILLATOR && field == SRACK_OSC_POS) ? &m->u.osc.pos : NULL; }
+static double* or_field_f64(or_module* m, int field)
+{
+    if (m->type == SRACK_MOD_OSCILLATOR && field == SRACK_OSC_POS) return &m->u.osc.pos;
+    if (m->type == SRACK_MOD_FREEVERB) switch (field) { /* the sliders' members: calc() copies them into the reverb (freeverb.rs:88-114) */
+        case SRACK_FREEVERB_DAMPENING: return &m->u.fv.p_dampening_ctl;
+        case SRACK_FREEVERB_WET: return &m->u.fv.p_wet_ctl;
+        case SRACK_FREEVERB_WIDTH: return &m->u.fv.p_width_ctl;
+        case SRACK_FREEVERB_ROOM_SIZE: return &m->u.fv.p_room_size_ctl;
+        case SRACK_FREEVERB_DRY: return &m->u.fv.p_dry_ctl;
+        default: break;
+        }
+    return NULL;
+}
 
 static float* or_field_f32(or_module* m, int field)
 {
@@ -380,6 +445,9 @@ static int* or_field_int(or_module* m, int field)
         if (field == SRACK_GRIDSEQ_LENGTH) return &m->u.seq.length;
         if (field == SRACK_GRIDSEQ_STEP_LAST) return &m->u.seq.td.last;
         if (field == SRACK_GRIDSEQ_SYNC_LAST) return &m->u.seq.sync_td.last;
+        break;
+    case SRACK_MOD_FREEVERB:
+        if (field == SRACK_FREEVERB_FREEZE) return &m->u.fv.p_freeze_ctl;
         break;
     case SRACK_MOD_SAMPLE:
         if (field == SRACK_SAMPLE_PLAYING) return &m->u.smp.playing;
@@ -965,6 +1033,125 @@ static void or_calc_output(or_patch* p, or_module* m)
     }
 }
 
+/* ---- the crate, restated (see the banner at or_freeverb) ---------------------------------------------------------------- */
+static void or_fv_delay_new(or_fv_delay* d, uint32_t len)
+{
+    d->buffer = (double*)calloc(len ? len : 1, sizeof(double));
+    d->len = len;
+    d->index = 0;
+}
+static double or_fv_read(const or_fv_delay* d) { return d->buffer[d->index]; }
+static void or_fv_write_and_advance(or_fv_delay* d, double v)
+{
+    d->buffer[d->index] = v;
+    d->index = d->index == d->len - 1 ? 0 : d->index + 1;
+}
+static double or_fv_comb_tick(or_fv_comb* c, double input)
+{
+    const double output = or_fv_read(&c->delay);
+    c->filter_state = output * c->dampening_inverse + c->filter_state * c->dampening;
+    or_fv_write_and_advance(&c->delay, input + c->filter_state * c->feedback);
+    return output;
+}
+static double or_fv_allpass_tick(or_fv_delay* d, double input)
+{
+    const double delayed = or_fv_read(d);
+    const double output = -input + delayed;
+    or_fv_write_and_advance(d, input + delayed * 0.5);
+    return output;
+}
+static void or_fv_update_combs(or_freeverb* f)
+{
+    const double feedback = f->frozen ? 1.0 : f->room_size, dampening = f->frozen ? 0.0 : f->dampening;
+    for (int k = 0; k < OR_FV_COMBS; k++)
+        for (int c = 0; c < 2; c++) {
+            f->comb[k][c].feedback = feedback;
+            f->comb[k][c].dampening = dampening;
+            f->comb[k][c].dampening_inverse = 1.0 - dampening;
+        }
+}
+static void or_fv_update_wet_gains(or_freeverb* f)
+{
+    f->wet_gain0 = f->wet * (f->width / 2.0 + 0.5);
+    f->wet_gain1 = f->wet * ((1.0 - f->width) / 2.0);
+}
+static void or_fv_set_dampening(or_freeverb* f, double v) { f->dampening = v * 0.4; or_fv_update_combs(f); }
+static void or_fv_set_freeze(or_freeverb* f, int frozen) { f->frozen = frozen; or_fv_update_combs(f); } /* (pub set_freeze leaves input_gain alone) */
+static void or_fv_set_wet(or_freeverb* f, double v) { f->wet = v * 3.0; or_fv_update_wet_gains(f); }
+static void or_fv_set_width(or_freeverb* f, double v) { f->width = v; or_fv_update_wet_gains(f); }
+static void or_fv_set_room_size(or_freeverb* f, double v) { f->room_size = v * 0.28 + 0.7; or_fv_update_combs(f); }
+static void or_fv_set_dry(or_freeverb* f, double v) { f->dry = v; }
+static uint32_t or_fv_adjust_length(uint32_t length, uint32_t sr) { return (uint32_t)((double)length * (double)sr / 44100.0); }
+static const uint32_t OR_FV_COMB_TUNING[OR_FV_COMBS] = {1116, 1188, 1277, 1356, 1422, 1491, 1557, 1617};
+static const uint32_t OR_FV_ALLPASS_TUNING[OR_FV_ALLPASSES] = {556, 441, 341, 225};
+static void or_fv_new(or_freeverb* f, uint32_t sr) /* Freeverb::new(sr) */
+{
+    for (int k = 0; k < OR_FV_COMBS; k++)
+        for (int c = 0; c < 2; c++) {
+            or_fv_delay_new(&f->comb[k][c].delay, or_fv_adjust_length(OR_FV_COMB_TUNING[k] + (c ? 23u : 0u), sr));
+            f->comb[k][c].feedback = 0.5;
+            f->comb[k][c].filter_state = 0.0;
+            f->comb[k][c].dampening = 0.5;
+            f->comb[k][c].dampening_inverse = 0.5;
+        }
+    for (int k = 0; k < OR_FV_ALLPASSES; k++)
+        for (int c = 0; c < 2; c++) or_fv_delay_new(&f->allpass[k][c], or_fv_adjust_length(OR_FV_ALLPASS_TUNING[k] + (c ? 23u : 0u), sr));
+    f->wet_gain0 = f->wet_gain1 = f->wet = f->width = f->dry = f->input_gain = f->dampening = f->room_size = 0.0;
+    f->frozen = 0;
+    or_fv_set_wet(f, 1.0);
+    or_fv_set_width(f, 0.5);
+    or_fv_set_dampening(f, 0.5);
+    or_fv_set_room_size(f, 0.5);
+    f->frozen = 0; /* set_frozen(false): */
+    f->input_gain = 1.0;
+    or_fv_update_combs(f);
+    f->initialised = 1;
+}
+static void or_fv_tick(or_freeverb* f, double in0, double in1, double* o0, double* o1)
+{
+    const double input_mixed = (in0 + in1) * 0.015 * f->input_gain;
+    double out0 = 0.0, out1 = 0.0;
+    for (int k = 0; k < OR_FV_COMBS; k++) {
+        out0 += or_fv_comb_tick(&f->comb[k][0], input_mixed);
+        out1 += or_fv_comb_tick(&f->comb[k][1], input_mixed);
+    }
+    for (int k = 0; k < OR_FV_ALLPASSES; k++) {
+        out0 = or_fv_allpass_tick(&f->allpass[k][0], out0);
+        out1 = or_fv_allpass_tick(&f->allpass[k][1], out1);
+    }
+    *o0 = out0 * f->wet_gain0 + out1 * f->wet_gain1 + in0 * f->dry;
+    *o1 = out1 * f->wet_gain0 + out0 * f->wet_gain1 + in1 * f->dry;
+}
+
+/* ---- the module: FreeverbModule::set_freeverb + calc, freeverb.rs:88-114, 208-270 (in the tree; followed literally) ------ */
+static void or_fv_set_freeverb(or_freeverb* f, int all)
+{
+    if (f->p_dampening_ctl != f->p_dampening || all) { f->p_dampening = f->p_dampening_ctl; or_fv_set_dampening(f, f->p_dampening); }
+    if (f->p_freeze_ctl != f->p_freeze || all) { f->p_freeze = f->p_freeze_ctl; or_fv_set_freeze(f, f->p_freeze); }
+    if (f->p_wet_ctl != f->p_wet || all) { f->p_wet = f->p_wet_ctl; or_fv_set_wet(f, f->p_wet); }
+    if (f->p_width_ctl != f->p_width || all) { f->p_width = f->p_width_ctl; or_fv_set_width(f, f->p_width); }
+    if (f->p_room_size_ctl != f->p_room_size || all) { f->p_room_size = f->p_room_size_ctl; or_fv_set_room_size(f, f->p_room_size); }
+    if (f->p_dry_ctl != f->p_dry || all) { f->p_dry = f->p_dry_ctl; or_fv_set_dry(f, f->p_dry); }
+}
+static void or_calc_freeverb(or_patch* p, or_module* m)
+{
+    or_freeverb* f = &m->u.fv;
+    if (!f->initialised) {
+        or_fv_new(f, f->sample_rate);
+        or_fv_set_freeverb(f, 1);
+    } else {
+        or_fv_set_freeverb(f, 0);
+    }
+    const float* l = or_resolve(p, m, 0);
+    const float* r = or_resolve(p, m, 1);
+    for (uint32_t i = 0; i < p->buffer_size; i++) { /* the four (Some / None) arms of :231-265 feed 0.0 for a missing side */
+        double o0, o1;
+        or_fv_tick(f, l ? (double)l[i] : 0.0, r ? (double)r[i] : 0.0, &o0, &o1);
+        m->out[0][i] = (float)o0;
+        m->out[1][i] = (float)o1;
+    }
+}
+
 /* NoiseModule::calc, oscillator.rs:381-387: `*sample = (rand::random::<f32>() - 0.5) * 2.0`.
  * rand 0.8.5 (Cargo.toml:29): random::<f32>() = thread_rng().gen() = Standard: (next_u32() >> 8) as f32 * 2^-24, i.e. one
  * of 2^24 equally likely multiples of 2^-24 in [0, 1); thread_rng is ChaCha12 seeded from the OS, so the reference's
@@ -1006,6 +1193,7 @@ static void or_calc(or_patch* p, or_module* m)
     case SRACK_MOD_NONLINEAR: or_calc_nonlin(p, m); break;
     case SRACK_MOD_SAMPLE: or_calc_sample(p, m); break;
     case SRACK_MOD_NOISE: or_calc_noise(p, m); break;
+    case SRACK_MOD_FREEVERB: or_calc_freeverb(p, m); break;
     case SRACK_MOD_GRID_SEQUENCER: or_calc_gridseq(p, m); break;
     case SRACK_MOD_PATTERN_SEQUENCER: or_calc_patseq(p, m); break;
     }
@@ -1074,6 +1262,7 @@ or_patch* or_patch_clone(const or_patch* src)
                 p->modules[i].out[k] = (float*)malloc(sizeof(float) * src->buffer_size);
                 memcpy(p->modules[i].out[k], src->modules[i].out[k], sizeof(float) * src->buffer_size);
             }
+        if (src->modules[i].type == SRACK_MOD_FREEVERB) p->modules[i].u.fv.initialised = 0; /* Clone: `freeverb: None` (freeverb.rs:41) */
         if (src->modules[i].type == SRACK_MOD_SAMPLE && src->modules[i].u.smp.samples) {
             const or_sample* ss = &src->modules[i].u.smp;
             p->modules[i].u.smp.samples = (float*)malloc(sizeof(float) * ss->n_samples);

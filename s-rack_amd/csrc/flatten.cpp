@@ -350,6 +350,46 @@ int Builder::build()
             if (connected(1)) op.flags |= MATH_HAS_IN2;
             param(op, NONLIN_P_CONST, m, SRACK_NONLIN_CONSTANT, deferred);
             break;
+        case SRACK_MOD_FREEVERB: {  // freeverb.rs + the freeverb crate's Freeverb::new / set_* (restated; see oracle/srack_oracle.c)
+            op.kind = OP_FREEVERB;
+            for (int f = 0; f < SRACK_FREEVERB__NFIELDS; f++)
+                if (find_override(m, f)) {
+                    set_error("flatten: per-voice overrides of FreeverbModule parameters are not supported");
+                    return SRACK_ERR_UNSUPPORTED;
+                }
+            static const uint32_t comb_tuning[8] = {1116, 1188, 1277, 1356, 1422, 1491, 1557, 1617}, allpass_tuning[4] = {556, 441, 341, 225};
+            const uint32_t sr = g.cfg.sample_rate;
+            uint32_t len[kFvLines], first[kFvLines], total = 0;
+            for (int j = 0; j < kFvLines; j++) {
+                const uint32_t tuning = (j < 16 ? comb_tuning[j / 2] : allpass_tuning[(j - 16) / 2]) + ((j & 1) ? 23u : 0u);
+                len[j] = (uint32_t)((double)tuning * (double)sr / 44100.0);  // adjust_length: `(length as f64 * sr as f64 / 44100.0) as usize`
+                if (len[j] < 4) {  // (a zero-length line panics in the crate; the tile function reads four samples of a line at a time)
+                    set_error("flatten: FreeverbModule needs a sample rate of at least 784 Hz");
+                    return SRACK_ERR_UNSUPPORTED;
+                }
+                first[j] = total;
+                total += len[j];
+            }
+            // Freeverb::new's defaults, then set_freeverb(all = true) in its order (freeverb.rs:88-114): every setter runs once
+            const double dampening = field(m, SRACK_FREEVERB_DAMPENING) * 0.4, room = field(m, SRACK_FREEVERB_ROOM_SIZE) * 0.28 + 0.7;
+            const bool frozen = field(m, SRACK_FREEVERB_FREEZE) != 0.0;
+            const double wet = field(m, SRACK_FREEVERB_WET) * 3.0, width = field(m, SRACK_FREEVERB_WIDTH);
+            const double comb_damp = frozen ? 0.0 : dampening;
+            const double par[7] = {frozen ? 1.0 : room, comb_damp, 1.0 - comb_damp, wet * (width / 2.0 + 0.5), wet * ((1.0 - width) / 2.0),
+                                   field(m, SRACK_FREEVERB_DRY), 1.0 /* input_gain: set by new(); the public set_freeze leaves it alone */};
+            op.aux = (int)out.seqtab.size();
+            out.seqtab.insert(out.seqtab.end(), len, len + kFvLines);
+            out.seqtab.insert(out.seqtab.end(), first, first + kFvLines);
+            for (double d : par) {
+                uint64_t u;
+                std::memcpy(&u, &d, 8);
+                out.seqtab.push_back((uint32_t)u);
+                out.seqtab.push_back((uint32_t)(u >> 32));
+            }
+            op.delta_row = (int)out.fv_rows;
+            out.fv_rows += (uint32_t)kFvStates + total;
+            break;
+        }
         case SRACK_MOD_NOISE: {  // stateless: sample n of voice v is a function of (seed, module, first_voice + v, n)
             op.kind = OP_NOISE;
             const uint64_t base = noise_base_key(g.cfg.noise_seed, m), first = g.cfg.noise_first_voice;

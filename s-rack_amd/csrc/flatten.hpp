@@ -36,6 +36,7 @@ struct FlatProgram {
     std::vector<uint32_t> table;      // [n_rows][n_voices] initial voice table (state rows, then parameter rows)
     std::vector<uint32_t> seqtab;     // sequencer grids, 64 cells per sequencer op (DevOp::aux is the dword offset)
     std::vector<float> ring_init;     // [n_rings][B] initial ring contents, same for every voice; empty = zeros
+    uint32_t fv_rows = 0;             // rows (of n_voices doubles each) of the OP_FREEVERB blocks, zero-initialised
     std::vector<int> op_of_module;    // module index -> op index, -1 if the module cannot reach the output
     int fused = FUSED_NONE;
     int fused_variant = 0;            // kernel-specific (which oscillator port / filter port the chain uses)

@@ -59,6 +59,7 @@ int Graph::fields_of_type(int type)
     case SRACK_MOD_NONLINEAR: return SRACK_NONLIN__NFIELDS;
     case SRACK_MOD_SAMPLE: return SRACK_SAMPLE__NFIELDS;
     case SRACK_MOD_NOISE: return 0;
+    case SRACK_MOD_FREEVERB: return SRACK_FREEVERB__NFIELDS;
     default: return -1;
     }
 }
@@ -78,7 +79,10 @@ bool Graph::field_is_state(int type, int field)
     }
 }
 
-bool Graph::field_is_f64(int type, int field) { return type == SRACK_MOD_OSCILLATOR && field == SRACK_OSC_POS; }
+bool Graph::field_is_f64(int type, int field)
+{
+    return (type == SRACK_MOD_OSCILLATOR && field == SRACK_OSC_POS) || (type == SRACK_MOD_FREEVERB && field != SRACK_FREEVERB_FREEZE);
+}
 
 bool Graph::field_is_flag(int type, int field)
 {
@@ -90,6 +94,7 @@ bool Graph::field_is_flag(int type, int field)
     case SRACK_MOD_GRID_SEQUENCER: return field != SRACK_GRIDSEQ_LAST;  // integers and detector bits; `last` is an f32
     case SRACK_MOD_PATTERN_SEQUENCER: return true;
     case SRACK_MOD_SAMPLE: return field == SRACK_SAMPLE_WAVE_NEW || field == SRACK_SAMPLE_PLAYING || field == SRACK_SAMPLE_GATE_LAST;
+    case SRACK_MOD_FREEVERB: return field == SRACK_FREEVERB_FREEZE;
     default: return false;
     }
 }
@@ -182,6 +187,14 @@ int Graph::add_module(int type)
     case SRACK_MOD_NOISE:  // oscillator.rs:314-320: no inputs, one output, no parameters
         m.n_in = 0;
         m.n_out = 1;
+        break;
+    case SRACK_MOD_FREEVERB:  // freeverb.rs:60-82
+        m.n_in = 2;
+        m.n_out = 2;
+        m.fields[SRACK_FREEVERB_DAMPENING] = 0.5;
+        m.fields[SRACK_FREEVERB_WET] = 1.0;
+        m.fields[SRACK_FREEVERB_WIDTH] = 0.5;
+        m.fields[SRACK_FREEVERB_ROOM_SIZE] = 0.5;
         break;
     }
     m.in.assign((size_t)m.n_in, InputRef{});

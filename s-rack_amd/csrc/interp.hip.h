@@ -433,6 +433,113 @@ __device__ __noinline__ void tile_nonlin(const Ctx c_v, COp& op_v)
     tile_run<2, 1>(c, in, out, [&](const float* x, float* y) { y[0] = nonlin_step(fl, x[0], x[1], constant); });
 }
 
+// FreeverbModule (freeverb.rs:208-270) around the freeverb crate's Freeverb::tick, restated (PARITY UNPINNED: the crate is
+// not vendored in the reference tree; oracle/srack_oracle.c states what the restatement rests on).  All arithmetic in f64,
+// one operation per rounding, as the crate's:
+//   input_mixed = (l + r) * 0.015 * input_gain
+//   comb:    out = line.read(); state = out * (1 - damp) + state * damp; line.write(input_mixed + state * feedback)
+//   allpass: d = line.read(); out = -in + d; line.write(in + d * 0.5)
+//   l' = out.0 * wet_gains.0 + out.1 * wet_gains.1 + l * dry   (and mirrored for r')
+// The 24 delay lines live in HBM, one double per voice per slot (voice-minor: a wave reads 512 contiguous bytes per slot).
+// Every line advances one slot per sample from slot 0 at sample 0, so its position is n mod length — no per-voice index.
+// The combs are parallel and a line is read `length` >= 4 samples after it was written, so a group of four samples of one
+// line is four independent loads, then the four recurrence steps, then four stores: line by line, group by group.
+template <bool kExact>
+__device__ __noinline__ void tile_freeverb(const Ctx c_v, COp& op_v, CArgs& a_v, uint64_t n_abs, uint32_t voice, uint32_t voice_c, bool active)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    CArgs& a = uniform_args(a_v);
+    typedef const __attribute__((address_space(4))) uint32_t CU32;
+    CU32* tab = (CU32*)(uintptr_t)(a.seqtab + op.aux);
+    // lane j < 24 holds line j's length, first row and the slot of the tile's first sample
+    const int jl = c.lane < kFvLines ? c.lane : 0;
+    const uint32_t len_l = a.seqtab[op.aux + jl], first_l = a.seqtab[op.aux + kFvLines + jl];
+    const uint32_t idx_l = (uint32_t)(n_abs % (uint64_t)len_l);
+    auto dbl = [&](int k) { return __hiloint2double((int)tab[2 * kFvLines + 2 * k + 1], (int)tab[2 * kFvLines + 2 * k]); };
+    const double feedback = dbl(0), damp = dbl(1), damp_inv = dbl(2), wet0 = dbl(3), wet1 = dbl(4), dry = dbl(5), gain = dbl(6);
+    const size_t V = a.V;
+    double* blk = a.fv + (size_t)op.delta_row * V;
+    const double* ld = blk + voice_c;
+    double* st = blk + voice;
+    double fs[kFvStates];
+#pragma unroll
+    for (int k = 0; k < kFvStates; k++) fs[k] = ld[(size_t)k * V];
+    const Port in_l = in_port(c, op.in_slot[0]), in_r = in_port(c, op.in_slot[1]);
+    const Port out_l = out_port(c, op.out_slot[0]), out_r = out_port(c, op.out_slot[1]);
+    constexpr int G = 4;
+    for (int s0 = 0; s0 < c.n; s0 += G) {
+        const int m = min(G, c.n - s0);
+        float l[G], r[G];
+        double x[G], o0[G], o1[G];
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const int s = s0 + min(i, m - 1);  // (past the end of a short last group: re-read its last sample; the result is dropped)
+            l[i] = in_l.p[s * in_l.stride];
+            r[i] = in_r.p[s * in_r.stride];
+            x[i] = ((double)l[i] + (double)r[i]) * 0.015 * gain;
+            o0[i] = 0.0;
+            o1[i] = 0.0;
+        }
+        // one line over the group: `io` carries the line's input in and its output out
+        auto line = [&](int j, auto step) {
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)len_l, j), first = (uint32_t)__builtin_amdgcn_readlane((int)first_l, j);
+            uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)idx_l, j) + (uint32_t)s0;
+            while (pos >= len) pos -= len;
+            const size_t row0 = (size_t)kFvStates + first;
+            uint32_t p[G];
+            double rd[G];
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                p[i] = pos + (uint32_t)i;
+                if (p[i] >= len) p[i] -= len;
+                rd[i] = ld[(row0 + p[i]) * V];
+            }
+#pragma unroll
+            for (int i = 0; i < G; i++)
+                if (i < m) {
+                    const double w = step(i, rd[i]);
+                    if (active) st[(row0 + p[i]) * V] = w;
+                }
+        };
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            line(2 * k, [&](int i, double out) {
+                fs[2 * k] = out * damp_inv + fs[2 * k] * damp;
+                o0[i] += out;
+                return x[i] + fs[2 * k] * feedback;
+            });
+            line(2 * k + 1, [&](int i, double out) {
+                fs[2 * k + 1] = out * damp_inv + fs[2 * k + 1] * damp;
+                o1[i] += out;
+                return x[i] + fs[2 * k + 1] * feedback;
+            });
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            line(16 + 2 * k, [&](int i, double delayed) {
+                const double in = o0[i];
+                o0[i] = -in + delayed;
+                return in + delayed * 0.5;
+            });
+            line(17 + 2 * k, [&](int i, double delayed) {
+                const double in = o1[i];
+                o1[i] = -in + delayed;
+                return in + delayed * 0.5;
+            });
+        }
+#pragma unroll
+        for (int i = 0; i < G; i++)
+            if (i < m) {
+                out_l.p[(s0 + i) * out_l.stride] = (float)(o0[i] * wet0 + o1[i] * wet1 + (double)l[i] * dry);
+                out_r.p[(s0 + i) * out_r.stride] = (float)(o1[i] * wet0 + o0[i] * wet1 + (double)r[i] * dry);
+            }
+    }
+    if (active)
+#pragma unroll
+        for (int k = 0; k < kFvStates; k++) st[(size_t)k * V] = fs[k];
+}
+
 // NoiseModule: stateless — the tile's samples are n_abs .. n_abs + c.n - 1 of this voice's stream.
 template <bool kExact>
 __device__ __noinline__ void tile_noise(const Ctx c_v, COp& op_v, uint64_t n_abs, uint32_t voice_c)
@@ -744,6 +851,7 @@ SRK_DEV void interp_body(dev::CArgs& a)
             case OP_NONLIN: dev::tile_nonlin<kExact>(c, op); break;
             case OP_SAMPLE: dev::tile_sample<kExact>(c, op, ca); break;
             case OP_NOISE: dev::tile_noise<kExact>(c, op, a.n0 + t0, voice_c); break;
+            case OP_FREEVERB: dev::tile_freeverb<kExact>(c, op, ca, a.n0 + t0, voice, voice_c, active); break;
             case OP_DELAY_RD: dev::tile_delay_rd<kExact>(c, op, ca, a.n0 + t0, voice_c); break;
             case OP_DELAY_WR: dev::tile_delay_wr<kExact>(c, op, ca, a.n0 + t0, voice, active); break;
             default: break;

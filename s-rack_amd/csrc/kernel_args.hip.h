@@ -23,6 +23,7 @@ struct KernelArgs {
     uint32_t t_stride;
     uint32_t block0;  // blocks [0, block0) of the grid are not voice waves (a co-scheduled control block); wave = blockIdx.x - block0
     uint64_t n0;  // absolute index of this launch's first sample (phase of the feedback rings)
+    double* fv;   // OP_FREEVERB blocks: rows of V doubles (program.hpp), zero at n0 = 0 (may be null)
 };
 
 struct ChainRoles {  // op indices of the fused voice chain (osc_l / adsr unused in the track variant)

@@ -25,7 +25,8 @@ enum OpKind : int32_t {
     OP_PATSEQ = 12,    // PatternSequencerModule::calc sequencer.rs:482-533
     OP_NONLIN = 13,    // NonLinearModule::calc        math.rs:291-311
     OP_SAMPLE = 14,    // SampleModule::calc           sample.rs:192-240
-    OP_NOISE = 15      // NoiseModule::calc            oscillator.rs:381-387 (the draw: srack_hip.h, srack_patch_set_noise_seed)
+    OP_NOISE = 15,     // NoiseModule::calc            oscillator.rs:381-387 (the draw: srack_hip.h, srack_patch_set_noise_seed)
+    OP_FREEVERB = 16   // FreeverbModule::calc         freeverb.rs:208-270 + the freeverb crate's tick (restated, modules.hip.h)
 };
 
 // per-kind flag bits -----------------------------------------------------------------------------
@@ -70,6 +71,14 @@ enum : uint32_t {
     DELAY_RING_GLOBAL = 1u << 0  // ring in HBM ([B][V] f32); otherwise B consecutive LDS rows
 };
 
+// OP_FREEVERB: 24 delay lines per module (8 combs + 4 allpasses, x 2 channels), f64, one sample per voice per slot, in
+// a per-program HBM block of rows of V doubles: rows [0, 16) the combs' filter states, then the lines back to back.
+// Line j = 2 * unit + channel (units 0..7 combs, 8..11 allpasses).  DevOp::aux = dword offset of the op's table in
+// seqtab: [24] line lengths, [24] first rows of the lines (relative to row 16), then 7 doubles (lo, hi): comb
+// feedback, comb dampening, 1 - dampening, wet_gains.0, wet_gains.1, dry, input_gain.  DevOp::delta_row = the
+// block's first row in KernelArgs::fv.
+constexpr int kFvLines = 24, kFvStates = 16, kFvTableDwords = 2 * kFvLines + 14;
+
 constexpr int kMaxIn = 8;  // OutputModule: one input per channel (u8 in the reference; capped at 8 here)
 constexpr int kMaxOut = 9;  // PatternSequencerModule: 8 gates + sync
 constexpr int kMaxPar = 8;
@@ -104,7 +113,7 @@ struct DevOp {
     float par_val[kMaxPar];
     // OP_OSC without CV: delta = 440 * 2^val / sample_rate, hoisted to the host in f64
     // (bit-equal to the reference's per-sample value, oscillator.rs:43-48,132)
-    int32_t delta_row;          // >= 0: two per-voice rows (lo, hi); -1: uniform => delta
+    int32_t delta_row;          // >= 0: two per-voice rows (lo, hi); -1: uniform => delta.  OP_FREEVERB: first row of its block in KernelArgs::fv
     int32_t aux;                // OP_OUT: plane; OP_DELAY_*: ring id / first LDS row; sequencers: dword offset of the 64 cells in seqtab; OP_SAMPLE: dword offset of the wave in seqtab
     int32_t seq_row;            // sequencers: LDS row the 64 cells are staged in (shared by the wave, indexed by step)
     int32_t seq_len;            // sequencers: sequence length (1..64); OP_SAMPLE: wave length in samples

@@ -46,8 +46,11 @@ struct DevProg {  // device copy of one FlatProgram
     uint32_t* d_table = nullptr;
     float* d_rings = nullptr;
     uint32_t* d_seqtab = nullptr;
+    double* d_fv = nullptr;  // OP_FREEVERB blocks: [fv_rows][n_voices] f64
     void release()
     {
+        (void)hipFree(d_fv);
+        d_fv = nullptr;
         (void)hipFree(d_ops);
         (void)hipFree(d_table);
         (void)hipFree(d_rings);
@@ -139,6 +142,11 @@ static int upload_one(const FlatProgram& P, DevProg& d)
     if (!P.seqtab.empty()) {
         HIP_TRY(hipMalloc(&d.d_seqtab, sizeof(uint32_t) * P.seqtab.size()));
         HIP_TRY(hipMemcpy(d.d_seqtab, P.seqtab.data(), sizeof(uint32_t) * P.seqtab.size(), hipMemcpyHostToDevice));
+    }
+    if (P.fv_rows > 0) {  // delay lines and filter states of the reverbs: DelayLine::new is vec![0.0; n], filter_state 0.0
+        const size_t bytes = sizeof(double) * (size_t)P.fv_rows * P.n_voices;
+        HIP_TRY(hipMalloc(&d.d_fv, bytes));
+        HIP_TRY(hipMemset(d.d_fv, 0, bytes));
     }
     if (P.hdr.n_rings > 0) {
         size_t bytes = sizeof(float) * (size_t)P.hdr.n_rings * (size_t)P.hdr.buffer_size * P.n_voices;
@@ -425,6 +433,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
             kc.table = d->ctl[s].d_table;
             kc.rings = d->ctl[s].d_rings;
             kc.seqtab = d->ctl[s].d_seqtab;
+            kc.fv = d->ctl[s].d_fv;
             kc.frames = d->d_tracks + t_off;  // the control program's planes are the tracks: [n_tracks][T][1]
             kc.tracks = d->d_tracks + t_off;  // ... and later stages read earlier stages' tracks from the same buffer
             kc.plane_stride = T;
@@ -542,6 +551,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         ka.table = d->voice.d_table;
         ka.rings = d->voice.d_rings;
         ka.seqtab = d->voice.d_seqtab;
+        ka.fv = d->voice.d_fv;
         ka.frames = d_frames ? d_frames + (size_t)t_off * V : nullptr;
         ka.mixpart = d_mix ? d->d_mixpart + t_off : nullptr;
         ka.tracks = has_ctl ? d->d_tracks + t_off : nullptr;

@@ -406,8 +406,27 @@ Module parse_module(Reader& r, Graph& scratch)
         keep_buffer(m, 0, r.audio_buffer(), cfg);
         return m;
     }
-    if (variant == "FreeverbModuleV0")
-        throw UnsupportedError("srk: " + variant + " is outside the render path's scope (its arithmetic lives in the un-vendored freeverb crate)");
+    if (variant == "FreeverbModuleV0") {  // freeverb.rs:8-31 minus the serde(skip) members: id, left_out, right_out, sample_rate, then
+        r.array_of(16, "FreeverbModule");  // (value, ctl) pairs of dampening, freeze, wet, width, room_size, dry
+        Module m = fresh(SRACK_MOD_FREEVERB);
+        m.id = r.str();
+        keep_buffer(m, 0, r.audio_buffer(), cfg);
+        keep_buffer(m, 1, r.audio_buffer(), cfg);
+        r.integer_in(0, 1000000000, "sample_rate");  // set_audio_config (freeverb.rs:126-133) replaces it with the host's; the reverb itself is never saved
+        // calc() builds the reverb on the first block after a load and applies every *_ctl (set_freeverb(true)): the ctl members are the parameters
+        auto pair = [&](int field) {
+            r.number();
+            m.fields[(size_t)field] = r.number();
+        };
+        pair(SRACK_FREEVERB_DAMPENING);
+        r.boolean();
+        m.fields[SRACK_FREEVERB_FREEZE] = r.boolean() ? 1.0 : 0.0;
+        pair(SRACK_FREEVERB_WET);
+        pair(SRACK_FREEVERB_WIDTH);
+        pair(SRACK_FREEVERB_ROOM_SIZE);
+        pair(SRACK_FREEVERB_DRY);
+        return m;
+    }
     std::string shown;
     for (char ch : variant.substr(0, 48)) shown += (ch >= 0x20 && ch < 0x7f) ? ch : '?';  // a damaged file: keep the message printable
     r.fail("unknown SynthModuleType variant '" + shown + "'");
@@ -584,6 +603,21 @@ void write_module(Writer& w, const Module& m, const AudioConfig& cfg)
         w.str(m.id);
         write_buffer(w, m, 0, B);
         w.f32(F(SRACK_NONLIN_CONSTANT));
+        break;
+    case SRACK_MOD_FREEVERB:
+        w.variant("FreeverbModuleV0");
+        w.array(16);
+        w.str(m.id);
+        write_buffer(w, m, 0, B);
+        write_buffer(w, m, 1, B);
+        w.uint(cfg.sample_rate);
+        for (int f : {SRACK_FREEVERB_DAMPENING, SRACK_FREEVERB_FREEZE, SRACK_FREEVERB_WET, SRACK_FREEVERB_WIDTH, SRACK_FREEVERB_ROOM_SIZE, SRACK_FREEVERB_DRY})
+            for (int twice = 0; twice < 2; twice++) {  // the applied value and the slider's: equal once a block has run
+                if (f == SRACK_FREEVERB_FREEZE)
+                    w.boolean(m.fields[(size_t)f] != 0.0);
+                else
+                    w.f64(m.fields[(size_t)f]);
+            }
         break;
     case SRACK_MOD_NOISE:
         w.variant("NoiseModuleV0");

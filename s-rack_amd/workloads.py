@@ -8,7 +8,7 @@ import numpy as np
 
 # numeric vocabulary of include/srack_hip.h
 (MOD_OUTPUT, MOD_OSCILLATOR, MOD_MOOG_FILTER, MOD_ADSR, MOD_VCA, MOD_MONO_MIXER, MOD_MATH, MOD_GRID_SEQUENCER,
- MOD_PATTERN_SEQUENCER, MOD_NONLINEAR, MOD_SAMPLE, MOD_NOISE) = range(12)
+ MOD_PATTERN_SEQUENCER, MOD_NONLINEAR, MOD_SAMPLE, MOD_NOISE, MOD_FREEVERB) = range(13)
 OSC_VAL, OSC_ANTIALIASING, OSC_POS, OSC_SYNC_LAST = range(4)
 (VCF_FREQ, VCF_RES, VCF_EXP_AMT, VCF_ST_F, VCF_ST_P, VCF_ST_Q, VCF_ST_B0, VCF_ST_B1, VCF_ST_B2, VCF_ST_B3,
  VCF_ST_B4, VCF_ST_FREQ, VCF_ST_RES) = range(13)
@@ -22,6 +22,7 @@ MATH_ADD, MATH_SUBTRACT, MATH_MULTIPLY = range(3)
  GRIDSEQ_LAST) = range(7)
 PATSEQ_LENGTH, PATSEQ_CURRENT_STEP, PATSEQ_STEP_LAST, PATSEQ_SYNC_LAST = range(4)
 NONLIN_CONSTANT = 0
+FREEVERB_DAMPENING, FREEVERB_FREEZE, FREEVERB_WET, FREEVERB_WIDTH, FREEVERB_ROOM_SIZE, FREEVERB_DRY = range(6)
 SAMPLE_SAMPLE_RATE, SAMPLE_WAVE_SAMPLE_RATE, SAMPLE_WAVE_NEW, SAMPLE_POS, SAMPLE_PLAYING, SAMPLE_GATE_LAST = range(6)
 STEP_NONE, STEP_ON, STEP_HOLD = range(3)
 GRIDSEQ_OUT_CV, GRIDSEQ_OUT_GATE, GRIDSEQ_OUT_SYNC = range(3)

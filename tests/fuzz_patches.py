@@ -5,21 +5,21 @@ import srack_pkg
 
 W = srack_pkg.load_workloads()
 
-OSC, VCF, ADSR, VCA, MIX, MATH, GRID, PAT, SMP, NOISE = 1, 2, 3, 4, 5, 6, 7, 8, 10, 11
-N_IN = {OSC: 2, VCF: 2, ADSR: 1, VCA: 2, MIX: 4, MATH: 2, GRID: 2, PAT: 2, SMP: 2, NOISE: 0}
-OUT_PORTS = {OSC: [1, 2], VCF: [0, 1, 2], ADSR: [0], VCA: [0], MIX: [0], MATH: [0], GRID: [0, 1, 2], PAT: [0, 3, 7, 8], SMP: [0], NOISE: [0]}
+OSC, VCF, ADSR, VCA, MIX, MATH, GRID, PAT, SMP, NOISE, VERB = 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12
+N_IN = {OSC: 2, VCF: 2, ADSR: 1, VCA: 2, MIX: 4, MATH: 2, GRID: 2, PAT: 2, SMP: 2, NOISE: 0, VERB: 2}
+OUT_PORTS = {OSC: [1, 2], VCF: [0, 1, 2], ADSR: [0], VCA: [0], MIX: [0], MATH: [0], GRID: [0, 1, 2], PAT: [0, 3, 7, 8], SMP: [0], NOISE: [0], VERB: [0, 1]}
 
 
 def random_patch(seed, noise=False):
     """-> (B, build(g) -> None, overrides [(module, field, values per voice fn)]).  noise=True: a fifth of the modules are
-    NoiseModules (a separate family of patches: the seeds of the noise-free family keep their meaning)."""
+    NoiseModules and a tenth FreeverbModules (a separate family of patches: the seeds of the first family keep their meaning)."""
     rng = np.random.default_rng(seed if not noise else (seed, 0x4e6f))
     B = int(rng.choice([1, 3, 16, 64, 1024]))
     n = int(rng.integers(4, 11))
     types = [OSC, OSC] + [int(rng.choice([OSC, VCF, ADSR, VCA, MIX, MATH, GRID, PAT, SMP], p=[.2, .15, .12, .13, .1, .15, .05, .05, .05])) for _ in range(n - 2)]
     rng.shuffle(types)
     if noise:
-        types = [NOISE if rng.random() < 0.2 else t for t in types]
+        types = [NOISE if u < 0.2 else VERB if u < 0.3 else t for t, u in zip(types, rng.random(n))]
         if NOISE not in types:
             types[int(rng.integers(0, n))] = NOISE
     fields, steps, conns, waves = [], [], [], []
@@ -40,6 +40,10 @@ def random_patch(seed, noise=False):
             fields += [(m, W.MIX_GAIN0 + k, float(np.float32(rng.uniform(0, 1.2)))) for k in range(4)]
         elif t == MATH:
             fields += [(m, W.MATH_CONSTANT, float(np.float32(rng.uniform(-1, 1)))), (m, W.MATH_OPERATION, int(rng.integers(0, 3)))]
+        elif t == VERB:
+            fields += [(m, f, float(rng.uniform(lo, hi))) for f, lo, hi in ((W.FREEVERB_DAMPENING, 0, 2), (W.FREEVERB_WET, 0, 1), (W.FREEVERB_WIDTH, 0, 1),
+                                                                            (W.FREEVERB_ROOM_SIZE, 0, 1), (W.FREEVERB_DRY, 0, 1))]
+            fields.append((m, W.FREEVERB_FREEZE, int(rng.random() < 0.2)))
         elif t == SMP:
             waves.append((m, rng.uniform(-1, 1, int(rng.integers(1, 400))).astype(np.float32), float(rng.choice([8000.0, 44100.0, 48000.0, 96000.0]))))
         elif t in (GRID, PAT):

@@ -92,6 +92,9 @@ class NumpyGraph:
                 m.playing = bool(value)
             else:
                 m.td.last = bool(value)
+        elif isinstance(m, N.Freeverb):
+            name = N.Freeverb.PARAMS[field] + "_ctl"
+            setattr(m, name, bool(value) if field == 1 else float(value))
         else:
             raise ValueError("no fields")
 

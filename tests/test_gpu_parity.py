@@ -936,3 +936,80 @@ def test_noise_statistics_at_scale(S):
     counts = np.bincount((k.astype(np.int64) >> 18).ravel(), minlength=64)
     assert 25 < ((counts - n / 64) ** 2 / (n / 64)).sum() < 120
     assert (np.abs(mix[0] - x.sum(axis=1)) <= 1e-5 * np.maximum(np.abs(x).sum(axis=1), 1.0)).all()
+
+
+# ---- FreeverbModule: the module's routing (freeverb.rs) and the restated freeverb crate, GPU against the oracle ----------------
+def _freeverb_patch(g, S, params=(), right=True):
+    osc, osc2, fv, out = g.add_module(S.MOD_OSCILLATOR), g.add_module(S.MOD_OSCILLATOR), g.add_module(S.MOD_FREEVERB), g.add_module(S.MOD_OUTPUT)
+    g.set_field(osc, S.OSC_VAL, -1.0)
+    g.set_field(osc2, S.OSC_VAL, 0.37)
+    g.connect(osc, S.OSC_OUT_SAW, fv, 0)
+    if right:
+        g.connect(osc2, S.OSC_OUT_SQUARE, fv, 1)
+    g.connect(fv, 0, out, 0)
+    g.connect(fv, 1, out, 1)
+    for f, v in params:
+        g.set_field(fv, f, v)
+    return dict(osc=osc, fv=fv)
+
+
+FV_PARAMS = [pytest.param((), True, id="defaults"),
+             pytest.param(((0, 1.7), (2, 0.6), (3, 1.0), (4, 0.9), (5, 0.8)), True, id="long-wide-dry"),
+             pytest.param(((1, 1), (5, 0.25), (4, 0.3)), False, id="frozen-left-only")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", MODES)
+@pytest.mark.parametrize("params,right", FV_PARAMS)
+def test_freeverb_per_voice_vs_oracle(S, oracle, params, right, flags):
+    """Per-voice detune in front of the reverb => one reverb per voice (24 delay lines each, in HBM)."""
+    V, T = 70, 4200                                    # the longest comb is 1785 samples at 48 kHz: two trips round, and past a 4096-sample launch
+    det = np.linspace(-2.0, 1.0, V).astype(np.float32)
+    o = oracle.OraclePatch(48000, 64, 2)
+    ids = _freeverb_patch(o, S, params, right)
+    ref, _ = o.render_batch(V, T, [(ids["osc"], S.OSC_VAL, det)], threads=8)
+    p = S.Patch(48000, 64, 2)
+    _freeverb_patch(p, S, params, right)
+    p.configure_voices(V)
+    p.set_voice_field(ids["osc"], S.OSC_VAL, det)
+    fr, _ = p.render(T, flags=flags)
+    if flags & 1:
+        np.testing.assert_array_equal(bits(fr), bits(ref))
+    else:
+        assert_close(fr, ref)
+    assert np.abs(ref[:, 3000:]).max() > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 9, 11])
+def test_freeverb_voice_invariant_runs_in_the_control_program(S, oracle, flags):
+    """Nothing upstream of the reverb differs between voices: it is evaluated once, by a control unit, and reaches the voices as tracks."""
+    V, T = 96, 5000
+    o = oracle.OraclePatch(48000, 128, 2)
+    _freeverb_patch(o, S, ((2, 0.8), (5, 0.4)))
+    ref = o.render(T)
+    p = S.Patch(48000, 128, 2)
+    _freeverb_patch(p, S, ((2, 0.8), (5, 0.4)))
+    p.configure_voices(V)
+    fr, mix = p.render(T, flags=flags)
+    assert "ctl[" in p.info() and "tracks=2" in p.info(), p.info()   # (info describes the program the last render used)
+    for v in (0, 17, V - 1):
+        if flags & 1:
+            np.testing.assert_array_equal(bits(fr[:, :, v]), bits(ref))
+        else:
+            assert_close(fr[:, :, v], ref)
+
+
+@pytest.mark.gpu
+def test_freeverb_continues_across_calls(S):
+    V, T = 40, 9000
+    det = np.linspace(-1.0, 1.0, V).astype(np.float32)
+    for flags in (0, 1):
+        outs = []
+        for parts in ([T], [1, 63, 4097, 1000, 3839]):
+            p = S.Patch(48000, 32, 2)
+            ids = _freeverb_patch(p, S)
+            p.configure_voices(V)
+            p.set_voice_field(ids["osc"], S.OSC_VAL, det)
+            outs.append(np.concatenate([p.render(n, flags=flags)[0] for n in parts], axis=1))
+        np.testing.assert_array_equal(bits(outs[0]), bits(outs[1]))

@@ -55,8 +55,8 @@ def test_error_behaviour(S):
     with pytest.raises(S.SrackError) as e:
         p.connect(7, 0, out, 0)
     assert e.value.code == S.ERR_INVALID
-    with pytest.raises(S.SrackError) as e:  # FreeverbModule (un-vendored crate) is out of scope
-        p.add_module(12)
+    with pytest.raises(S.SrackError) as e:  # the reference has thirteen module types (synth.rs:295-311)
+        p.add_module(13)
     assert e.value.code == S.ERR_UNSUPPORTED
     for bad in ((0, 64, 2), (70000, 64, 2), (48000, 0, 2), (48000, 64, 0), (48000, 64, 9)):
         with pytest.raises(S.SrackError):
@@ -297,3 +297,34 @@ def test_mix_tree_lane_map_is_documented_formula():
     row, bank, hi = L >> 4, (L >> 2) & 3, (L >> 1) & 1
     slot = 16 * hi + 8 * (bank & 1) + 4 * (bank >> 1) + 2 * (row & 1) + (row >> 1)
     assert sorted(set(slot.tolist())) == list(range(32)) and (np.bincount(slot) == 2).all()
+
+
+def test_freeverb_module_graph_api(S):
+    """freeverb.rs:60-82, 135-206: two inputs (Left, Right), two outputs, the *_ctl defaults; parameters are f64."""
+    p = S.Patch(48000, 64, 2)
+    osc, fv, out = p.add_module(S.MOD_OSCILLATOR), p.add_module(S.MOD_FREEVERB), p.add_module(S.MOD_OUTPUT)
+    assert (p.get_num_inputs(fv), p.get_num_outputs(fv)) == (2, 2)
+    assert [p.get_field(fv, f) for f in range(6)] == [0.5, 0.0, 1.0, 0.5, 0.5, 0.0]
+    p.set_field(fv, S.FREEVERB_ROOM_SIZE, 0.1 + 0.2)                 # not representable in f32: kept as the f64 it is
+    assert p.get_field(fv, S.FREEVERB_ROOM_SIZE) == 0.1 + 0.2
+    for bad in ((osc, 0, fv, 2), (fv, 2, out, 0)):
+        with pytest.raises(S.SrackError) as e:
+            p.connect(*bad)
+        assert e.value.code == S.ERR_PORT
+    p.connect(osc, 2, fv, 0)
+    p.connect(fv, 0, out, 0)
+    p.connect(fv, 1, out, 1)
+    assert p.plan() == [osc, fv, out]
+    p.configure_voices(64)
+    assert "ops=" in p.info()
+    with pytest.raises(S.SrackError) as e:                             # the reverb's parameters are voice-invariant here
+        p.set_voice_field(fv, S.FREEVERB_WET, np.linspace(0, 1, 64))
+        p.info()
+    assert e.value.code == S.ERR_UNSUPPORTED
+    q = S.Patch(700, 64, 2)                                            # 225 * 700 / 44100 = 3 samples: below the supported line length
+    a, b = q.add_module(S.MOD_FREEVERB), q.add_module(S.MOD_OUTPUT)
+    q.connect(a, 0, b, 0)
+    q.configure_voices(1)
+    with pytest.raises(S.SrackError) as e:
+        q.info()
+    assert e.value.code == S.ERR_UNSUPPORTED

@@ -555,3 +555,60 @@ def test_noise_voices_are_independent_streams_and_shard_by_first_voice(oracle):
     k = oracle.OraclePatch(48000, B, 2)
     _noise_patch(k, 6, 0)                                                  # another seed: another stream
     assert not np.array_equal(k.render(T), g.render(T))
+
+
+# ---- FreeverbModule (freeverb.rs): the module is in the tree, the freeverb crate 0.1.0 is not — restated, PARITY UNPINNED ------------
+def _freeverb_patch(g, params=(), both=True):
+    osc, osc2, fv, out = g.add_module(1), g.add_module(1), g.add_module(12), g.add_module(0)
+    g.set_field(osc, 0, -1.0)
+    g.set_field(osc2, 0, 0.37)
+    g.connect(osc, 2, fv, 0)
+    if both:
+        g.connect(osc2, 1, fv, 1)
+    g.connect(fv, 0, out, 0)
+    g.connect(fv, 1, out, 1)
+    for f, v in params:
+        g.set_field(fv, f, v)
+    return fv
+
+
+@pytest.mark.parametrize("params,both", [((), True), (((0, 1.7), (2, 0.6), (3, 1.0), (4, 0.9), (5, 0.8)), True), (((1, 1), (5, 0.25)), False),
+                                         (((3, 0.0), (4, 0.0), (0, 0.0)), True)])
+def test_freeverb_c_equals_numpy(oracle, params, both):
+    B, T = 64, 3000                       # past the longest comb (1760 + 25 samples at 48 kHz): feedback has come round
+    g, ng = oracle.OraclePatch(48000, B, 2), NumpyGraph(48000, B, 2)
+    _freeverb_patch(g, params, both)
+    _freeverb_patch(ng, params, both)
+    a, b = g.render(T), ng.render(T)
+    np.testing.assert_array_equal(bits(a), bits(b))
+    assert np.isfinite(a).all() and np.abs(a[:, 2000:]).max() > 1e-3
+
+
+def test_freeverb_published_structure(oracle):
+    """What Jezar's Freeverb is known to do, observed from outside: a dry-only setting is the identity on the fed channel, and
+    the tank stays silent until the shortest comb (1116 samples; 1116 + 23 on the right) has come round."""
+    B, sr = 32, 44100                      # at 44.1 kHz the tunings are the published ones unscaled
+    # dry only: output = input * dry on the left, 0 on the right (input.1 = 0)
+    g = oracle.OraclePatch(sr, B, 2)
+    k, fv, out = g.add_module(6), g.add_module(12), g.add_module(0)
+    g.set_field(k, 0, 0.5)
+    g.connect(k, 0, fv, 0)
+    g.connect(fv, 0, out, 0)
+    g.connect(fv, 1, out, 1)
+    g.set_field(fv, 2, 0.0)                # wet 0
+    g.set_field(fv, 5, 0.75)               # dry
+    y = g.render(3000)
+    np.testing.assert_array_equal(y[0], np.full(3000, np.float32(0.5 * 0.75)))
+    assert not y[1].any()
+    # wet only, constant input 0.5: nothing comes out before the shortest comb (1116) has wrapped: the allpasses pass
+    # -input + delayed of a zero comb sum, so the first non-zero sample is at n = 1116 on the left, 1139 on the right
+    g = oracle.OraclePatch(sr, B, 2)
+    k, fv, out = g.add_module(6), g.add_module(12), g.add_module(0)
+    g.set_field(k, 0, 0.5)
+    g.connect(k, 0, fv, 0)
+    g.connect(fv, 0, out, 0)
+    g.connect(fv, 1, out, 1)
+    g.set_field(fv, 3, 1.0)                # width 1: wet_gains = (wet, 0): the channels do not mix
+    y = g.render(1300)
+    assert np.flatnonzero(y[0])[0] == 1116 and np.flatnonzero(y[1])[0] == 1116 + 23
+    assert y[0][1116] == np.float32(0.5 * 0.015 * 3.0)   # the comb's first echo through four sign-flipping allpasses, times wet 1.0 * SCALE_WET

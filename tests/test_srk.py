@@ -154,6 +154,28 @@ def test_noise_module_file_form(S):
     assert S.Patch.load_srk(s2, 48000, B, 2).save_srk() == s1
 
 
+def test_freeverb_module_file_form(S):
+    """freeverb.rs:8-31 without the serde(skip) members: id, left_out, right_out, sample_rate, six (value, ctl) pairs.  The ctl
+    member is what calc() applies on the first block after a load (set_freeverb(true), freeverb.rs:209-212)."""
+    B = 8
+    fv = {"FreeverbModuleV0": ["id-fv", buf(B), buf(B, 0.5), 44100, F64(0.5), F64(1.25), False, True, F64(1.0), F64(0.3),
+                               F64(0.5), F64(0.9), F64(0.5), F64(0.1 + 0.2), F64(0.0), F64(0.75)]}
+    data = enc([[fv, output("id-out", B)], [["id-fv", 1, "id-out", 0]], []])
+    p = S.Patch.load_srk(data, 48000, B, 2)
+    ids = [p.module_id(m) for m in range(2)]
+    m = ids.index("id-fv")
+    assert p.module_type(m) == S.MOD_FREEVERB
+    assert [p.get_field(m, f) for f in range(6)] == [1.25, 1.0, 0.3, 0.9, 0.1 + 0.2, 0.75]
+    modules, conns, _ = msgpack.unpackb(p.save_srk(), raw=False)
+    saved = next(x["FreeverbModuleV0"] for x in modules if "FreeverbModuleV0" in x)
+    assert saved[0] == "id-fv" and saved[2] == [0.5] * B and saved[3] == 48000            # the host's rate (set_audio_config)
+    assert saved[4:] == [1.25, 1.25, True, True, 0.3, 0.3, 0.9, 0.9, 0.1 + 0.2, 0.1 + 0.2, 0.75, 0.75]
+    raw = p.save_srk()
+    assert raw.count(b"\xcb") == 10                                                        # the ten f64 members stay float64
+    s2 = S.Patch.load_srk(raw, 48000, B, 2).save_srk()
+    assert S.Patch.load_srk(s2, 48000, B, 2).save_srk() == raw
+
+
 # ---- load ----------------------------------------------------------------------------------------------------------------------
 def _describe(p):
     out = []
@@ -245,9 +267,9 @@ def test_load_errors(S):
     with pytest.raises(S.SrackError) as e:
         S.Patch.load_srk(good + b"\x00")
     assert e.value.code == S.ERR_INVALID
-    with pytest.raises(S.SrackError) as e:                                # its arithmetic lives in the un-vendored freeverb crate
+    with pytest.raises(S.SrackError) as e:                                # a FreeverbModule with members missing
         S.Patch.load_srk(enc([[{"FreeverbModuleV0": ["f"]}], [], []]))
-    assert e.value.code == S.ERR_UNSUPPORTED
+    assert e.value.code == S.ERR_INVALID
     with pytest.raises(S.SrackError) as e:
         S.Patch.load_srk(enc([[{"TeleportModuleV9": []}], [], []]))
     assert e.value.code == S.ERR_INVALID and "TeleportModuleV9" in str(e.value)
