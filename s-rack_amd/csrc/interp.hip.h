@@ -481,53 +481,69 @@ __device__ __noinline__ void tile_freeverb(const Ctx c_v, COp& op_v, CArgs& a_v,
             o0[i] = 0.0;
             o1[i] = 0.0;
         }
-        // one line over the group: `io` carries the line's input in and its output out
-        auto line = [&](int j, auto step) {
+        // A unit's left and right lines over the group: both lines' four slots are loaded before either recurrence runs (one
+        // memory round trip per pair of lines instead of one per line — the tile function is latency-bound).
+        struct Slots {
+            size_t row0;
+            uint32_t p[G];
+        };
+        auto locate = [&](int j) {
             const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)len_l, j), first = (uint32_t)__builtin_amdgcn_readlane((int)first_l, j);
             uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)idx_l, j) + (uint32_t)s0;
             while (pos >= len) pos -= len;
-            const size_t row0 = (size_t)kFvStates + first;
-            uint32_t p[G];
-            double rd[G];
+            Slots q;
+            q.row0 = (size_t)kFvStates + first;
 #pragma unroll
             for (int i = 0; i < G; i++) {
-                p[i] = pos + (uint32_t)i;
-                if (p[i] >= len) p[i] -= len;
-                rd[i] = ld[(row0 + p[i]) * V];
+                q.p[i] = pos + (uint32_t)i;
+                if (q.p[i] >= len) q.p[i] -= len;
+            }
+            return q;
+        };
+        auto unit = [&](int j, auto step_l, auto step_r) {
+            const Slots ql = locate(j), qr = locate(j + 1);
+            double rl[G], rr[G];
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                rl[i] = ld[(ql.row0 + ql.p[i]) * V];
+                rr[i] = ld[(qr.row0 + qr.p[i]) * V];
             }
 #pragma unroll
             for (int i = 0; i < G; i++)
                 if (i < m) {
-                    const double w = step(i, rd[i]);
-                    if (active) st[(row0 + p[i]) * V] = w;
+                    const double wl = step_l(i, rl[i]), wr = step_r(i, rr[i]);
+                    if (active) {
+                        st[(ql.row0 + ql.p[i]) * V] = wl;
+                        st[(qr.row0 + qr.p[i]) * V] = wr;
+                    }
                 }
         };
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            line(2 * k, [&](int i, double out) {
-                fs[2 * k] = out * damp_inv + fs[2 * k] * damp;
-                o0[i] += out;
-                return x[i] + fs[2 * k] * feedback;
-            });
-            line(2 * k + 1, [&](int i, double out) {
-                fs[2 * k + 1] = out * damp_inv + fs[2 * k + 1] * damp;
-                o1[i] += out;
-                return x[i] + fs[2 * k + 1] * feedback;
-            });
-        }
+        for (int k = 0; k < 8; k++)
+            unit(2 * k,
+                 [&](int i, double out) {
+                     fs[2 * k] = out * damp_inv + fs[2 * k] * damp;
+                     o0[i] += out;
+                     return x[i] + fs[2 * k] * feedback;
+                 },
+                 [&](int i, double out) {
+                     fs[2 * k + 1] = out * damp_inv + fs[2 * k + 1] * damp;
+                     o1[i] += out;
+                     return x[i] + fs[2 * k + 1] * feedback;
+                 });
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            line(16 + 2 * k, [&](int i, double delayed) {
-                const double in = o0[i];
-                o0[i] = -in + delayed;
-                return in + delayed * 0.5;
-            });
-            line(17 + 2 * k, [&](int i, double delayed) {
-                const double in = o1[i];
-                o1[i] = -in + delayed;
-                return in + delayed * 0.5;
-            });
-        }
+        for (int k = 0; k < 4; k++)
+            unit(16 + 2 * k,
+                 [&](int i, double delayed) {
+                     const double in = o0[i];
+                     o0[i] = -in + delayed;
+                     return in + delayed * 0.5;
+                 },
+                 [&](int i, double delayed) {
+                     const double in = o1[i];
+                     o1[i] = -in + delayed;
+                     return in + delayed * 0.5;
+                 });
 #pragma unroll
         for (int i = 0; i < G; i++)
             if (i < m) {
