@@ -18,13 +18,15 @@
 namespace srack {
 
 constexpr int kMixRows = 32;
+constexpr int kMixPitch = 68;  // floats per LDS row of the mix tile: 64 lanes + 4 of padding (see emit_flush)
+constexpr int kMixTile = kMixRows * kMixPitch;
 
 // ---- per-sample output of the fused kernels ---------------------------------------------------------------
 // kOut: 0 = decide at run time (exact-mode kernels), 1 = frames only, 2 = mix only, 3 = frames + mix.
 // Frames: SGPR row base advanced by V per sample + a constant per-lane offset; lanes past V (only in the
 // last wave) shadow voice V-1, compute the identical sample and store it to the identical address, so the
 // store needs no exec mask.  Mix: the sample goes into a 32-row LDS tile; every 32 samples (and at the end)
-// the rows are summed over the 64 lanes (tile_row_sum) and one lane per row writes the wave's partial.
+// the rows are summed over the 64 lanes (emit_flush) and one lane per row writes the wave's partial.
 struct Emit {
     float* frame_row;   // wave-uniform: this wave's 256 B of the current TILE's first frame row
     // Frames leave through a buffer store: descriptor (SGPRs, rebuilt per tile) + per-lane byte offset (a constant VGPR) +
@@ -47,7 +49,7 @@ SRK_DEV void emit_put(Emit& e, float* mix_tile, float o, int i, uint32_t V)  // 
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), e.rsrc, e.lane_c * 4, (int)e.soff, SRK_FRAME_AUX);
         e.soff += V * 4u;
     }
-    if (mix) mix_tile[i * 64 + e.lane] = o;
+    if (mix) mix_tile[i * kMixPitch + e.lane] = o;  // (ds_write_addtid_b32 — no address VGPR — measured: no gain)
 }
 
 SRK_DEV void emit_rebase(Emit& e)  // point the descriptor at frame_row; a tile spans at most 32 rows = 32 * V * 4 bytes
@@ -59,7 +61,6 @@ SRK_DEV void emit_rebase(Emit& e)  // point the descriptor at frame_row; a tile 
 template <int kOut>
 SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n, uint32_t V)  // the tile holds samples t0 .. t0+n-1
 {
-    using dev::tile_row_sum;
     const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
     if (frames) {
         e.frame_row += (size_t)n * V;
@@ -68,9 +69,17 @@ SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n, uint32_t V
     const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
     if (!mix) return;
     if (!e.full_wave && (uint32_t)e.lane >= e.n_active)  // shadow lanes contribute nothing to the mix
-        for (int r = 0; r < kMixRows; r++) mix_tile[r * 64 + e.lane] = 0.0f;
+        for (int r = 0; r < kMixRows; r++) mix_tile[r * kMixPitch + e.lane] = 0.0f;
     __syncthreads();
-    const float sum = tile_row_sum(mix_tile, kMixRows, e.lane);
+    // lane l sums half (l >> 5) of row (l & 31) with eight 16-byte reads; row pitch 68 floats = 272 B keeps them 16-B aligned and
+    // spreads the 16 lanes of a ds_read_b128 group (rows r .. r+15) over all 64 banks (bank = 4 r + 4 q mod 64)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* p = (const f4*)(mix_tile + (e.lane & 31) * kMixPitch + (e.lane >> 5) * 32);
+    f4 acc = p[0];
+#pragma unroll
+    for (int q = 1; q < 8; q++) acc += p[q];
+    float sum = (acc.x + acc.y) + (acc.z + acc.w);
+    sum += __shfl_xor(sum, 32);
     if (e.lane < n) e.mp[t0 + e.lane] = sum;
     __syncthreads();
 }
@@ -211,7 +220,7 @@ template <uint32_t kOscAPort, uint32_t kOscLPort, uint32_t kVcfPort, bool kExact
 __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRoles r)
 {
     using namespace dev;
-    __shared__ float mix_tile[kMixRows * 64];
+    __shared__ __attribute__((aligned(16))) float mix_tile[kMixTile];
     const int lane = threadIdx.x;
     const WaveMap wm = wave_map(a, lane);
     const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
@@ -361,7 +370,7 @@ template <uint32_t kOscAPort, uint32_t kVcfPort, bool kExact, int kOut>
 __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, ChainRoles r, CtlWork co)
 {
     using namespace dev;
-    __shared__ float mix_tile[kMixRows * 64];
+    __shared__ __attribute__((aligned(16))) float mix_tile[kMixTile];
     // Block 0 of a co-scheduled launch is not a voice wave: it computes the NEXT chunk's envelope track while the
     // voice blocks consume this chunk's (written by the previous launch).  Same stream, no events, no second queue.
     if (blockIdx.x < a.block0) {
@@ -500,7 +509,7 @@ template <uint32_t kOscPort, int kOut>
 __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRoles r)
 {
     using namespace dev;
-    __shared__ float mix_tile[kMixRows * 64];
+    __shared__ __attribute__((aligned(16))) float mix_tile[kMixTile];
     const int lane = threadIdx.x;
     const WaveMap wm = wave_map(a, lane);
     const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
@@ -697,7 +706,7 @@ template <bool kExact, int kOut>
 __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
 {
     using namespace dev;
-    __shared__ float mix_tile[kMixRows * 64];
+    __shared__ __attribute__((aligned(16))) float mix_tile[kMixTile];
     const int lane = threadIdx.x;
     const WaveMap wm = wave_map(a, lane);
     const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
@@ -770,7 +779,7 @@ template <bool kExact, int kOut>
 __global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRoles r)
 {
     using namespace dev;
-    __shared__ float mix_tile[kMixRows * 64];
+    __shared__ __attribute__((aligned(16))) float mix_tile[kMixTile];
     const int lane = threadIdx.x;
     const WaveMap wm = wave_map(a, lane);
     const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
