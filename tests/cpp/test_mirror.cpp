@@ -76,6 +76,15 @@ static int topological_sort()
     REQUIRE(modules[2].get_input(3).has_value() && !modules[2].get_input(3)->has_value());
     REQUIRE(modules[1].get_input(0)->value().first == modules[0]);
     REQUIRE(out.get_num_inputs() == 2 && out.get_num_outputs() == 0 && modules[0].get_name() == "Mono Mixer");
+    {   // every module type of the reference has a mirror, named as its get_name() (synth.rs:421-470)
+        Workspace all(ac);
+        const char* names[] = {"Output", "Oscillator", "Moog Filter", "ADSR", "VCA", "Mono Mixer", "Add", "Grid Sequencer", "Pattern Sequencer",
+                               "Non-Linear", "Sample", "Noise", "Freeverb"};
+        for (int t = 0; t < SRACK_MOD__COUNT; t++) REQUIRE(all.add((ModuleType)t).get_name() == names[t]);
+        SharedSynthModule nz = all.add(ModuleType::Noise), fv = all.add(ModuleType::Freeverb);
+        REQUIRE(nz.get_num_inputs() == 0 && nz.get_num_outputs() == 1 && fv.get_num_inputs() == 2 && fv.get_num_outputs() == 2);
+        REQUIRE(fv.set_input(1, nz, 0) && !nz.set_input(0, fv, 0));
+    }
     std::printf("topological_sort ok\n");
     return 0;
 }
