@@ -844,13 +844,25 @@ SRK_DEV void interp_body(dev::CArgs& a)
     c.n = 0;
     for (int r = 0; r < n_rows; r++) c.rows[r * 64 + lane] = a.table[(size_t)r * a.V + voice_c];
 
+    // Control tracks are staged 64 samples at a time — a whole LDS row per track, one coalesced load each — and c.trk slides
+    // over the staged window tile by tile.  The load's latency is exposed (nothing can be in flight across the calls of the
+    // tile functions), so it is paid once per 64 samples instead of once per tile (tile = 12: 750 instead of 4000 round trips
+    // per second of audio; worth 2 % on P1 through the interpreter — the per-call overhead of the tile functions is the
+    // larger cost there: tools/interp_ops.py).
+    dev::lds_f32* const trk_base = c.trk;
+    uint32_t staged_t0 = 0, staged_n = 0;
     for (uint32_t t0 = 0; t0 < a.T; t0 += (uint32_t)tile) {
         c.n = (int)min((uint32_t)tile, a.T - t0);
-        if (a.prog.n_tracks > 0) {  // this tile's slice of every control track the program reads: one coalesced load per track
-            __syncthreads();
-            for (int k = 0; k < a.prog.n_tracks; k++)
-                if (lane < c.n) c.trk[k * 64 + lane] = a.tracks[(size_t)a.prog.track_id[k] * a.t_stride + t0 + lane];
-            __syncthreads();
+        if (a.prog.n_tracks > 0) {
+            if (t0 + (uint32_t)c.n > staged_t0 + staged_n) {
+                staged_t0 = t0;
+                staged_n = min(64u, a.T - t0);
+                __syncthreads();
+                for (int k = 0; k < a.prog.n_tracks; k++)
+                    if ((uint32_t)lane < staged_n) trk_base[k * 64 + lane] = a.tracks[(size_t)a.prog.track_id[k] * a.t_stride + t0 + lane];
+                __syncthreads();
+            }
+            c.trk = trk_base + (t0 - staged_t0);
         }
         for (int i = 0; i < a.prog.n_ops; i++) {
             dev::COp& op = ((dev::COp*)a.ops)[i];
