@@ -29,6 +29,13 @@ def _worker(rank, world, port, V, T, q):
     ids = W.build_p1(g, adsr="finite", lfo_val=-2.0)
     det, cut = W.p1_voice_params(V, first_voice=rank * V)  # same call bench.py makes
     frames, mix = g.render_batch(V, T, [(ids["osc_a"], W.OSC_VAL, det), (ids["vcf"], W.VCF_FREQ, cut)], mix=True, threads=1)
+    # a noise voice on top: its streams are keyed by the GLOBAL voice index (set_noise_seed(seed, first_voice = rank * V))
+    nz = O.OraclePatch(48000, 1024, 2)
+    n, o = nz.add_module(O.MOD_NOISE), nz.add_module(O.MOD_OUTPUT)
+    nz.connect(n, 0, o, 0)
+    nz.connect(n, 0, o, 1)
+    nz.set_noise_seed(2024, rank * V)
+    mix = mix + nz.render_batch(V, T, mix=True)[1]
     part = torch.from_numpy(mix.astype(np.float32))
     dist.reduce(part, dst=0, op=dist.ReduceOp.SUM)
     gathered = [torch.zeros(V, dtype=torch.float32) for _ in range(world)] if rank == 0 else None
@@ -58,7 +65,14 @@ def test_two_rank_shards_match_single_process(W, oracle):
     g = oracle.OraclePatch(48000, 1024, 2)
     ids = W.build_p1(g, adsr="finite", lfo_val=-2.0)
     frames, mix = g.render_batch(world * V, T, [(ids["osc_a"], W.OSC_VAL, det), (ids["vcf"], W.VCF_FREQ, cut)], mix=True, threads=2)
-    scale = np.abs(frames.astype(np.float64)).sum(axis=2)
+    nz = oracle.OraclePatch(48000, 1024, 2)
+    n, o = nz.add_module(oracle.MOD_NOISE), nz.add_module(oracle.MOD_OUTPUT)
+    nz.connect(n, 0, o, 0)
+    nz.connect(n, 0, o, 1)
+    nz.set_noise_seed(2024, 0)
+    nframes, nmix = nz.render_batch(world * V, T, mix=True)
+    mix = mix + nmix
+    scale = np.abs(frames.astype(np.float64)).sum(axis=2) + np.abs(nframes.astype(np.float64)).sum(axis=2)
     assert (np.abs(reduced - mix) <= 1e-5 * np.maximum(scale, 1.0)).all()
     assert np.abs(mix).max() > 0.5
 
