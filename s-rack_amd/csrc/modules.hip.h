@@ -85,6 +85,69 @@ SRK_DEV double exp2_fast(double x)
     return __builtin_ldexp(p, (int)n);
 }
 
+// 2^e, correctly rounded (exact render mode).  The reference evaluates `2.0_f64.powf(e)` with the host's libm, whose pow is
+// within 0.52 ulp of the true value, i.e. the correctly rounded double except for a fraction of a percent of the arguments.
+// ocml's pow / exp2 are ~1 ulp functions: 19 % of their results differ from the host's in the last bit (tools/powcheck.hip),
+// and although an oscillator's f32 output shows that only rarely, a patch that feeds it back (chaotic FM loops, a clock
+// derived from the saw) then parts from the oracle for good.  So the power is evaluated here in double-double arithmetic
+// (~2^-100 relative) and rounded once: e = n + f, |f| <= 1/2; y = f ln2 (ln2 as hi + lo); exp(y) = (exp(y / 8))^8 with a
+// degree-13 Taylor polynomial (|y / 8| < 0.0434: truncation 2^-99).  Finite results only; the rest goes to ocml's pow.
+struct DD {
+    double hi, lo;
+};
+SRK_DEV DD dd_fast_two_sum(double a, double b)  // |a| >= |b|
+{
+    const double s = a + b;
+    return DD{s, b - (s - a)};
+}
+SRK_DEV DD dd_two_sum(double a, double b)
+{
+    const double s = a + b, bb = s - a;
+    return DD{s, (a - (s - bb)) + (b - bb)};
+}
+SRK_DEV DD dd_mul(DD a, DD b)
+{
+    const double p = a.hi * b.hi;
+    const double e = __builtin_fma(a.hi, b.hi, -p) + (a.hi * b.lo + a.lo * b.hi);
+    return dd_fast_two_sum(p, e);
+}
+SRK_DEV DD dd_add(DD a, DD b)
+{
+    DD s = dd_two_sum(a.hi, b.hi);
+    s.lo += a.lo + b.lo;
+    return dd_fast_two_sum(s.hi, s.lo);
+}
+SRK_DEV DD dd_mul_d(DD a, double b)
+{
+    const double p = a.hi * b;
+    const double e = __builtin_fma(a.hi, b, -p) + a.lo * b;
+    return dd_fast_two_sum(p, e);
+}
+SRK_DEV double exp2_cr(double e)
+{
+    if (!(e > -1000.0 && e < 1000.0)) return pow(2.0, e);  // overflow / gradual underflow / NaN: the library's special cases
+    const double n = __builtin_rint(e);
+    const double f = e - n;  // exact
+    // y = f * ln2 / 8
+    const DD ln2_8 = {0x1.62e42fefa39efp-4, 0x1.abc9e3b39803fp-59};  // ln 2 / 8 = hi + lo
+    const DD y = dd_mul_d(ln2_8, f);
+    // exp(y) = 1 + y (1 + y/2 (1 + y/3 ( ... (1 + y/13))))
+    DD acc = {1.0, 0.0};
+#pragma unroll
+    for (int k = 13; k >= 1; k--) {
+        DD t = dd_mul(acc, y);
+        // t / k: k is a small integer; 1/k as a double-double
+        const double rk = 1.0 / (double)k;
+        const double rk_lo = __builtin_fma(-rk, (double)k, 1.0) / (double)k;  // 1/k = rk + rk_lo
+        t = dd_mul(t, DD{rk, rk_lo});
+        acc = dd_add(DD{1.0, 0.0}, t);
+    }
+    acc = dd_mul(acc, acc);
+    acc = dd_mul(acc, acc);
+    acc = dd_mul(acc, acc);
+    return __builtin_ldexp(acc.hi + acc.lo, (int)n);
+}
+
 // poly_blep, f64, literally (oscillator.rs:50-67)
 SRK_DEV double poly_blep_exact(double t, double dt)
 {
@@ -157,7 +220,7 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
         if ((flags & OSC_CV_AUDIO_RATE) || __builtin_amdgcn_ballot_w64(cv != s.seen_cv) != 0) {
             const double e = (double)cv + c.val;
             // exact mode: 440 * 2^e / sr as written; default mode: (440 / sr) * 2^e with the series above
-            s.seen_delta = (flags & OSC_EXACT) ? 440.0 * pow(2.0, e) / c.sr : (440.0 / c.sr) * exp2_fast(e);
+            s.seen_delta = (flags & OSC_EXACT) ? 440.0 * exp2_cr(e) / c.sr : (440.0 / c.sr) * exp2_fast(e);
             s.seen_cv = cv;
         }
         delta = s.seen_delta;

@@ -16,7 +16,10 @@ pytestmark = pytest.mark.gpu
 from tests.fuzz_patches import random_patch  # noqa: E402
 
 
-@pytest.mark.parametrize("seed,noise", [(s, False) for s in range(160)] + [(s, True) for s in range(40)])
+# seeds past 159: found by tools/fuzz_soak.py — patches whose oscillators take an audio-rate pitch CV inside a feedback loop, where one
+# last-bit difference in 2^cv (ocml's pow against the host libm's) used to grow into different samples (780, 867, 944: fixed by
+# exp2_cr), and patches that overflow into NaNs (707, 774, 1000, 1157)
+@pytest.mark.parametrize("seed,noise", [(s, False) for s in list(range(160)) + [707, 774, 780, 867, 944, 1000, 1157]] + [(s, True) for s in range(40)])
 def test_random_patch_matches_oracle(seed, noise, oracle, monkeypatch):
     S = srack_pkg.load()
     if seed % 2:  # few voices normally run as quarter-filled waves (more waves, same cost); odd seeds force the full,
@@ -36,7 +39,8 @@ def test_random_patch_matches_oracle(seed, noise, oracle, monkeypatch):
         assert p.plan() == o.plan()
         fr = p.render_channels(T, flags)
         assert np.isfinite(fr).all() == np.isfinite(ref).all()
-        same = fr.view(np.uint32) == ref.view(np.uint32)
+        # (a NaN is a NaN: x86's default NaN is 0xffc00000, the GPU's 0x7fc00000 — seeds 707, 774, 1000, 1157 blow up and hold thousands)
+        same = (fr.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(fr) & np.isnan(ref))
         # everything in these patches is bit-exact in exact-oscillator mode (tools/fuzz_stats.py: 960 of 960 renders)
         assert same.all(), f"seed {seed} flags {flags}: {1 - same.mean():.5f} of the samples differ; {p.info()}"
 

@@ -1,0 +1,65 @@
+// powcheck.hip — how often does a device 2^e differ from the host libm's pow(2, e)?  (exact-mode oscillators with a CV compute
+// 440 * 2^e / sr per sample on the device; the oracle uses the host libm, as the reference does.)
+//   ocml pow:  ~19 % of the results differ in the last bit(s)
+//   exp2_cr:   double-double evaluation, correctly rounded => differs only where the host libm itself misrounds
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../s-rack_amd/csrc/modules.hip.h"
+__global__ void k(const double* e, double* out, double* out2, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out[i] = 440.0 * pow(2.0, e[i]) / 48000.0;
+        out2[i] = 440.0 * srack::dev::exp2_cr(e[i]) / 48000.0;
+    }
+}
+__global__ void kraw(const double* e, double* out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = srack::dev::exp2_cr(e[i]);
+}
+int main()
+{
+    const int n = 1 << 22;
+    std::vector<double> e(n), got(n), got2(n);
+    uint64_t s = 12345;
+    for (int i = 0; i < n; i++) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        const float cv = (float)((double)(s >> 11) / 9007199254740992.0 * 12.0 - 6.0);  // an f32 CV
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        const float val = (float)((double)(s >> 11) / 9007199254740992.0 * 9.0 - 6.0);  // an f32 `val`
+        e[i] = (double)cv + (double)val;
+    }
+    double *de, *dout, *dout2;
+    hipMalloc(&de, n * 8); hipMalloc(&dout, n * 8); hipMalloc(&dout2, n * 8);
+    hipMemcpy(de, e.data(), n * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, de, dout, dout2, n);
+    hipMemcpy(got.data(), dout, n * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(got2.data(), dout2, n * 8, hipMemcpyDeviceToHost);
+    int bad = 0, bad2 = 0, badp = 0, bade = 0, cr_vs_l = 0, libm_vs_l = 0;
+    std::vector<double> raw(n);
+    {   // the bare power, against the x87 long-double exp2l rounded to double (11 extra bits: decides all but ~0.05 % of the roundings)
+        double* dr; hipMalloc(&dr, n * 8);
+        hipLaunchKernelGGL(kraw, dim3(n / 256), dim3(256), 0, 0, de, dr, n);
+        hipMemcpy(raw.data(), dr, n * 8, hipMemcpyDeviceToHost);
+        for (int i = 0; i < n; i++) {
+            const double l = (double)exp2l((long double)e[i]), m = std::pow(2.0, e[i]);
+            if (memcmp(&l, &raw[i], 8)) cr_vs_l++;
+            if (memcmp(&l, &m, 8)) libm_vs_l++;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        const double want = 440.0 * std::pow(2.0, e[i]) / 48000.0, want2 = 440.0 * std::exp2(e[i]) / 48000.0;
+        if (memcmp(&want, &got[i], 8)) bad++;
+        if (memcmp(&want, &got2[i], 8)) bad2++;
+        if (memcmp(&want2, &got2[i], 8)) bade++;
+        if (memcmp(&want, &want2, 8)) badp++;
+    }
+    printf("bare 2^e against RN(exp2l): exp2_cr differs in %d, libm pow in %d\n", cr_vs_l, libm_vs_l);
+    printf("of %d: ocml pow != libm pow %d;  exp2_cr != libm pow %d;  exp2_cr != libm exp2 %d;  libm pow != libm exp2 %d\n", n, bad, bad2, bade, badp);
+    return 0;
+}
