@@ -187,7 +187,7 @@ class ADSR(Module):  # adsr.rs
                     if is_transition:
                         self.phase, self.mode = ZERO, ATTACK
                 elif self.mode == SUSTAIN:
-                    if not high:
+                    if gate is None or bool(gate[idx] <= ZERO):  # adsr.rs:175 spells it `<= 0.0`: a NaN gate holds the sustain
                         self.phase, self.mode = ZERO, RELEASE
                     if is_transition:
                         self.phase, self.mode = ZERO, ATTACK

@@ -530,6 +530,7 @@ SRK_DEV float adsr_step(uint32_t flags, AdsrRegs& s, const AdsrConst& c, float g
     const float g = has_gate ? gate : 0.0f;
     const bool is_transition = rising_edge(s.gate_last, g);
     const bool high = has_gate && gate > 0.0f;
+    const bool low = !has_gate || gate <= 0.0f;  // adsr.rs:175 spells Sustain's test `<= 0.0`: a NaN gate is neither high nor low
     switch (s.mode) {
     case SRACK_ADSR_MODE_NONE:
         if (high) {
@@ -559,7 +560,7 @@ SRK_DEV float adsr_step(uint32_t flags, AdsrRegs& s, const AdsrConst& c, float g
         }
         break;
     case SRACK_ADSR_MODE_SUSTAIN:
-        if (!high) {  // gate_in_buf.is_none() || gate <= 0.0
+        if (low) {  // gate_in_buf.is_none() || gate <= 0.0
             s.phase = 0.0f;
             s.mode = SRACK_ADSR_MODE_RELEASE;
         }

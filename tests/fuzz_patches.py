@@ -7,7 +7,9 @@ W = srack_pkg.load_workloads()
 
 OSC, VCF, ADSR, VCA, MIX, MATH, GRID, PAT, SMP, NOISE, VERB = 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12
 N_IN = {OSC: 2, VCF: 2, ADSR: 1, VCA: 2, MIX: 4, MATH: 2, GRID: 2, PAT: 2, SMP: 2, NOISE: 0, VERB: 2}
-OUT_PORTS = {OSC: [1, 2], VCF: [0, 1, 2], ADSR: [0], VCA: [0], MIX: [0], MATH: [0], GRID: [0, 1, 2], PAT: [0, 3, 7, 8], SMP: [0], NOISE: [0], VERB: [0, 1]}
+import os
+# (FUZZ_SINE=1: tools/fuzz_soak.py also draws the oscillators' sine port)
+OUT_PORTS = {OSC: [0, 1, 2] if os.environ.get("FUZZ_SINE") else [1, 2], VCF: [0, 1, 2], ADSR: [0], VCA: [0], MIX: [0], MATH: [0], GRID: [0, 1, 2], PAT: [0, 3, 7, 8], SMP: [0], NOISE: [0], VERB: [0, 1]}
 
 
 def random_patch(seed, noise=False):

@@ -1013,3 +1013,22 @@ def test_freeverb_continues_across_calls(S):
             p.set_voice_field(ids["osc"], S.OSC_VAL, det)
             outs.append(np.concatenate([p.render(n, flags=flags)[0] for n in parts], axis=1))
         np.testing.assert_array_equal(bits(outs[0]), bits(outs[1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", MODES)
+def test_adsr_sustain_holds_on_a_nan_gate(S, oracle, flags):
+    """adsr.rs:175 spells Sustain's exit `gate <= 0.0`: a NaN gate is neither high nor low (tools/fuzz_soak.py found the shortcut)."""
+    from tests.test_oracle import _nan_gate_patch
+    o = oracle.OraclePatch(48000, 1, 2)
+    _nan_gate_patch(o)
+    ref = o.render(600)
+    for V in (1, 70):
+        p = S.Patch(48000, 1, 2)
+        _nan_gate_patch(p)
+        p.configure_voices(V)
+        fr, _ = p.render(600, flags=flags)
+        for v in (0, V - 1):
+            np.testing.assert_array_equal(bits(fr[0, :, v]), bits(ref[0]))
+            np.testing.assert_array_equal(np.isnan(fr[1, :, v]), np.isnan(ref[1]))
+    assert (ref[0][200:] == np.float32(0.6)).all()

@@ -612,3 +612,36 @@ def test_freeverb_published_structure(oracle):
     y = g.render(1300)
     assert np.flatnonzero(y[0])[0] == 1116 and np.flatnonzero(y[1])[0] == 1116 + 23
     assert y[0][1116] == np.float32(0.5 * 0.015 * 3.0)   # the comb's first echo through four sign-flipping allpasses, times wet 1.0 * SCALE_WET
+
+
+def _nan_gate_patch(g):
+    # s = m + 1; m = 2 s (through the loop's one-block delay): 2, 6, 14, ... overflows to inf after ~128 blocks of one sample;
+    # d = m - m is 0 until then and NaN afterwards; gate = d + 1: high, then NaN
+    s_, m, d, gate, adsr, out = g.add_module(6), g.add_module(6), g.add_module(6), g.add_module(6), g.add_module(3), g.add_module(0)
+    g.set_field(s_, 0, 1.0)
+    g.connect(m, 0, s_, 0)
+    g.set_field(m, 0, 2.0)
+    g.set_field(m, 1, 2)              # MULTIPLY
+    g.connect(s_, 0, m, 0)
+    g.set_field(d, 1, 1)              # SUBTRACT
+    g.connect(m, 0, d, 0)
+    g.connect(m, 0, d, 1)
+    g.set_field(gate, 0, 1.0)
+    g.connect(d, 0, gate, 0)
+    g.connect(gate, 0, adsr, 0)
+    for f, v in ((0, 0.0005), (1, 0.0005), (2, 0.6), (3, 0.01)):
+        g.set_field(adsr, f, v)
+    g.connect(adsr, 0, out, 0)
+    g.connect(gate, 0, out, 1)
+
+
+def test_adsr_sustain_holds_on_a_nan_gate(oracle):
+    """adsr.rs:175: Sustain leaves on `gate <= 0.0`, not on `!(gate > 0.0)`: a NaN gate (an overflowed patch) holds the level.
+    Found by tools/fuzz_soak.py (seed 320 with sine ports): the NumPy twin and the GPU both had the shortcut, the C oracle did not."""
+    g, ng = oracle.OraclePatch(48000, 1, 2), NumpyGraph(48000, 1, 2)
+    _nan_gate_patch(g)
+    _nan_gate_patch(ng)
+    a, b = g.render(600), ng.render(600)
+    np.testing.assert_array_equal(bits(a[0]), bits(b[0]))
+    assert a[1][60] == 1.0 and np.isnan(a[1][200:]).all()          # the gate: high, then NaN
+    assert a[0][100] == np.float32(0.6) and (a[0][200:] == np.float32(0.6)).all()   # sustain reached, and held through the NaNs

@@ -43,3 +43,7 @@ for seed in map(int, args):
         both = ~nan_r & ~nan_g
         print(f"   NaN masks equal: {bool((nan_r == nan_g).all())}; non-NaN samples differing: {int((fr.view(np.uint32)[both] != ref.view(np.uint32)[both]).sum())} of {int(both.sum())};"
               f" NaN patterns ref {sorted(set(hex(x) for x in ref.view(np.uint32)[nan_r][:2000]))[:4]} gpu {sorted(set(hex(x) for x in fr.view(np.uint32)[nan_g][:2000]))[:4]}")
+        idx = np.argwhere(both & (fr.view(np.uint32) != ref.view(np.uint32)))
+        idx = idx[np.argsort(idx[:, 1], kind="stable")][:6]
+        for c_, t_, v_ in idx:
+            print(f"      ch {c_} sample {t_} voice {v_}: gpu {fr[c_, t_, v_]!r} ref {ref[c_, t_, v_]!r}; ref around {ref[c_, max(t_-2,0):t_+2, v_]}")
