@@ -22,6 +22,12 @@ import numpy as np
 _libm = ctypes.CDLL("libm.so.6")
 _libm.powf.restype = ctypes.c_float
 _libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+# math.pow / math.sin / math.fmod raise OverflowError / ValueError where libm returns inf / NaN (a patch that blows up): call libm itself
+for _name in ("pow", "fmod"):
+    getattr(_libm, _name).restype = ctypes.c_double
+    getattr(_libm, _name).argtypes = [ctypes.c_double, ctypes.c_double]
+_libm.sin.restype = ctypes.c_double
+_libm.sin.argtypes = [ctypes.c_double]
 
 
 def powf(a, b):
@@ -29,6 +35,14 @@ def powf(a, b):
 
 f32 = np.float32
 ZERO, ONE, TWO = f32(0.0), f32(1.0), f32(2.0)
+
+
+def fmin(a, b):  # Rust's f32::min: if one operand is NaN the other is returned (Python's min(a, b) would keep a NaN first operand)
+    return b if a != a else (a if b != b else (b if b < a else a))
+
+
+def fmax(a, b):  # Rust's f32::max
+    return b if a != a else (a if b != b else (b if b > a else a))
 
 
 class TransitionDetector:  # synth.rs:276-298
@@ -89,20 +103,20 @@ class Oscillator(Module):  # oscillator.rs
             if self.sync.is_transition(sync_val):
                 self.pos = 0.0
             if cv is not None:
-                hz = 440.0 * math.pow(2.0, float(cv[i]) + float(self.val))
+                hz = 440.0 * _libm.pow(2.0, float(cv[i]) + float(self.val))
             else:
-                hz = 440.0 * math.pow(2.0, float(self.val))
+                hz = 440.0 * _libm.pow(2.0, float(self.val))
             delta = hz / float(self.sample_rate)
-            sine[i] = f32(math.sin(self.pos * math.pi * 2.0))
+            sine[i] = f32(_libm.sin(self.pos * math.pi * 2.0))
             lvl = f32(-1.0) if self.pos < 0.5 else f32(1.0)
             if self.antialiasing:
-                square[i] = lvl - f32(self.poly_blep(self.pos, delta) - self.poly_blep(math.fmod(self.pos + 0.5, 1.0), delta))
+                square[i] = lvl - f32(self.poly_blep(self.pos, delta) - self.poly_blep(_libm.fmod(self.pos + 0.5, 1.0), delta))
                 saw[i] = (f32(self.pos) * TWO - ONE) - f32(self.poly_blep(self.pos, delta))
             else:
                 square[i] = lvl - ZERO
                 saw[i] = (f32(self.pos) * TWO - ONE) - ZERO
             self.pos += delta
-            self.pos = math.fmod(self.pos, 1.0)
+            self.pos = _libm.fmod(self.pos, 1.0)
 
 
 class MoogFilter(Module):  # filter.rs
@@ -134,17 +148,17 @@ class MoogFilter(Module):  # filter.rs
         b[4] = b[4] - (b[4] * b[4] * b[4]) * f32(0.166667)
         b[0] = x
         for k in range(5):
-            b[k] = max(min(b[k], ONE), f32(-1.0))
+            b[k] = fmax(fmin(b[k], ONE), f32(-1.0))  # x.min(1.0).max(-1.0), filter.rs:89
         return b[4], x - b[4], f32(3.0) * (b[3] - b[4])
 
     def calc(self):  # filter.rs:182-221
         audio_in, cv_in = self.resolve(0), self.resolve(1)
         lowpass, bandpass, highpass = self.outs
-        res = min(max(self.res, ZERO), ONE)
+        res = fmin(fmax(self.res, ZERO), ONE)
         for idx in range(len(lowpass)):
             audio = audio_in[idx] if audio_in is not None else ZERO
             cv = cv_in[idx] if cv_in is not None else ZERO
-            frequency = min(max(self.freq + cv * self.exp_amt, ZERO), f32(0.9))
+            frequency = fmin(fmax(self.freq + cv * self.exp_amt, ZERO), f32(0.9))
             lowpass[idx], highpass[idx], bandpass[idx] = self.state_calc(audio, frequency, res)
 
 

@@ -421,7 +421,8 @@ struct VcfRegs {
 
 // clamp_buffers: x.min(1.0).max(-1.0) (filter.rs:89).  kMed3: one v_med3_f32 instead of min+max —
 // identical for every non-NaN x; a NaN (only reachable when an inf/NaN is fed into the filter)
-// becomes -1.0 instead of the reference's +1.0.  The exact render mode uses the literal form.
+// becomes -1.0 instead of the reference's +1.0 (v_med3 of a NaN is the minimum of the other two; writing it as -med3(-x, -1, 1)
+// does not help: the compiler folds the negations into med3(x, 1, -1)).  The exact render mode uses the literal form.
 template <bool kMed3>
 SRK_DEV float clamp1(float x)
 {

@@ -1032,3 +1032,38 @@ def test_adsr_sustain_holds_on_a_nan_gate(S, oracle, flags):
             np.testing.assert_array_equal(bits(fr[0, :, v]), bits(ref[0]))
             np.testing.assert_array_equal(np.isnan(fr[1, :, v]), np.isnan(ref[1]))
     assert (ref[0][200:] == np.float32(0.6)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", MODES)
+def test_filter_clamps_a_nan_to_plus_one(S, oracle, flags):
+    """filter.rs:89 `x.min(1.0).max(-1.0)`: Rust's min / max drop a NaN operand, so a NaN that reaches the ladder turns its states
+    into +1.0 (not NaN).  Exact modes reproduce that; the default mode's one-instruction clamp (v_med3) saturates to -1.0 instead —
+    the documented difference for a patch that has already blown up (modules.hip.h, clamp1)."""
+    def build(g):
+        s_, m, d, vcf, out = g.add_module(S.MOD_MATH), g.add_module(S.MOD_MATH), g.add_module(S.MOD_MATH), g.add_module(S.MOD_MOOG_FILTER), g.add_module(S.MOD_OUTPUT)
+        g.set_field(s_, S.MATH_CONSTANT, 1.0)
+        g.connect(m, 0, s_, 0)
+        g.set_field(m, S.MATH_CONSTANT, 2.0)
+        g.set_field(m, S.MATH_OPERATION, S.MATH_MULTIPLY)
+        g.connect(s_, 0, m, 0)             # m = 2 (m + 1): overflows to inf after ~128 one-sample blocks
+        g.set_field(d, S.MATH_OPERATION, S.MATH_SUBTRACT)
+        g.connect(m, 0, d, 0)
+        g.connect(m, 0, d, 1)              # m - m: 0, then NaN
+        g.connect(d, 0, vcf, 0)
+        g.connect(vcf, 0, out, 0)          # low-pass
+        g.connect(vcf, 1, out, 1)          # band-pass = 3 (b3 - b4)
+    o = oracle.OraclePatch(48000, 1, 2)
+    build(o)
+    ref = o.render(400)
+    assert (ref[0][200:] == 1.0).all() and (ref[1][200:] == 0.0).all()
+    p = S.Patch(48000, 1, 2)
+    build(p)
+    p.configure_voices(70)
+    fr, _ = p.render(400, flags=flags)
+    for v in (0, 69):
+        if flags & 1:
+            np.testing.assert_array_equal(fr[:, :, v], ref)
+        else:
+            np.testing.assert_array_equal(fr[:, :150, v][np.isfinite(ref[:, :150]) & (ref[:, :150] == 0)], 0.0)   # before the NaN arrives
+            assert (np.abs(fr[0, 200:, v]) == 1.0).all() and (fr[1, 200:, v] == 0.0).all()                        # saturated, finite
