@@ -102,4 +102,17 @@ def random_patch(seed, noise=False):
                 overrides.append((m, W.MIX_GAIN0 + 1, lambda V, r=np.random.default_rng(seed * 131 + m): r.uniform(0, 1, V).astype(np.float32)))
             elif t == ADSR:
                 overrides.append((m, W.ADSR_S_VAL, lambda V, r=np.random.default_rng(seed * 131 + m): r.uniform(0, 1, V).astype(np.float32)))
+    if os.environ.get("FUZZ_MORE_OV"):  # (tools/fuzz_soak.py: per-voice overrides of further parameters and of initial STATE)
+        r2 = np.random.default_rng((seed, 0x0F))
+        more = {OSC: [(W.OSC_POS, 0.0, 1.0)], VCF: [(W.VCF_RES, 0.0, 1.0), (W.VCF_EXP_AMT, 0.0, 1.0), (W.VCF_ST_B2, -1.0, 1.0)],
+                ADSR: [(W.ADSR_A_SEC, 0.0, 0.004), (W.ADSR_D_SEC, 0.0005, 0.01), (W.ADSR_R_SEC, 0.0005, 0.01), (W.ADSR_PHASE, 0.0, 1.0)],
+                MIX: [(W.MIX_GAIN0, 0.0, 1.0), (W.MIX_GAIN3, -1.0, 1.0)]}
+        for m, t in enumerate(types):
+            for f, lo_, hi_ in more.get(t, []):
+                if r2.random() < 0.35:
+                    gen = np.random.default_rng((seed, m, f))
+                    if f == W.OSC_POS:
+                        overrides.append((m, f, lambda V, g=gen: g.uniform(0.0, 1.0, V)))  # f64 state
+                    else:
+                        overrides.append((m, f, lambda V, g=gen, a=lo_, b=hi_: g.uniform(a, b, V).astype(np.float32)))
     return B, build, overrides
