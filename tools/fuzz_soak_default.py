@@ -1,0 +1,41 @@
+"""Default (approximating) render modes past the pinned seeds: how many random patches stay within the 1e-5 contract for every sample?
+usage: <first> <last> [noise]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import srack_pkg
+from oracle import oracle as O
+from tests.fuzz_patches import random_patch
+S = srack_pkg.load()
+O.build()
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+noise = len(sys.argv) > 3
+worst, n, n_bad, t0 = [], 0, 0, time.time()
+for seed in range(lo, hi):
+    B, build, overrides = random_patch(seed, noise)
+    V, T = (67, 1300) if B < 1024 else (131, 2300)
+    o = O.OraclePatch(48000, B, 2)
+    ids = build(o)
+    ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]
+    ref, _ = o.render_batch(V, T, ov, threads=8)
+    r64 = ref.astype(np.float64)
+    for flags in (0, 2, 4):
+        p = S.Patch(48000, B, 2)
+        build(p)
+        p.configure_voices(V)
+        for m, f, vals in ov:
+            p.set_voice_field(m, f, vals)
+        fr = p.render_channels(T, flags)
+        n += 1
+        ok = np.isfinite(r64) & np.isfinite(fr)
+        mask_same = (np.isnan(fr) == np.isnan(ref)).all() and (np.isinf(fr) == np.isinf(ref)).all()
+        err = np.abs(fr.astype(np.float64)[ok] - r64[ok]) / np.maximum(np.abs(r64[ok]), 1.0)
+        e = float(err.max()) if err.size else 0.0
+        if e > 1e-5 or not mask_same:
+            n_bad += 1
+            worst.append((seed, flags, e, float((err > 1e-5).mean()) if err.size else 0.0, mask_same, "exact" if (p.info().find("kernel=") >= 0 and False) else ""))
+print(f"default modes, seeds {lo}..{hi - 1} noise={noise}: {n} renders, {n_bad} leave the 1e-5 band somewhere, {time.time() - t0:.0f} s")
+seeds = sorted(set(w[0] for w in worst))
+print(f"  {len(seeds)} patches: {seeds[:60]}")
+for w in worst[:12]:
+    print("  seed %d flags %d: max rel err %.2e, %.5f of the samples outside, non-finite masks equal %s %s" % w)
