@@ -175,6 +175,18 @@ SRK_DEV float poly_blep_fast(float t, float tm1, float inv_dt)
     const float hi = tb > -1.0f ? fb : 0.0f;
     return ta < 1.0f ? fa : hi;
 }
+// The same polynomials with the reference's own f64 branch decisions (`t < dt`, else `t > 1.0 - dt`).  Needed whenever the
+// increment may exceed 1/2: the two windows then OVERLAP, the branches no longer meet at 0 at a border, and a border decided
+// by the rounded f32 quotient picks the wrong polynomial — which happens systematically, not rarely: an oscillator that starts at
+// phase 0 sits exactly ON the border t == dt after its first step (found by tools/fv_soak.py at sample rate 1000: errors of 0.7).
+SRK_DEV float poly_blep_sel(float t, float tm1, float inv_dt, bool first, bool second)
+{
+    float ta = t * inv_dt;
+    float tb = tm1 * inv_dt;
+    float fa = keep(__builtin_fmaf(ta, 2.0f - ta, -1.0f));
+    float fb = keep(__builtin_fmaf(tb, tb + 2.0f, 1.0f));
+    return first ? fa : (second ? fb : 0.0f);
+}
 
 // sin(2*pi*pos), pos in [0,1), as the reference's `(pos * PI * 2.0).sin() as f32` (oscillator.rs:133) up to the final
 // rounding: folded to a quarter wave exactly (f64 subtractions of values in [-0.5, 0.5]), odd Taylor polynomial of
@@ -242,14 +254,15 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
     if (flags & (OSC_OUT_SQUARE | OSC_OUT_SAW)) {
         const float p32 = (float)pos;            // `self.pos as f32`
         float blep0 = 0.0f;
-        if (flags & OSC_AA) blep0 = poly_blep_fast(p32, (float)(pos - 1.0), inv_dt);
+        const double upper = 1.0 - delta;        // the reference's `1.0 - dt`, rounded as it rounds it
+        if (flags & OSC_AA) blep0 = poly_blep_sel(p32, (float)(pos - 1.0), inv_dt, pos < delta, pos > upper);
         if (flags & OSC_OUT_SAW) saw = __builtin_fmaf(p32, 2.0f, -1.0f) - blep0;  // p32*2 is exact => fma == mul,sub
         if (flags & OSC_OUT_SQUARE) {
             float blep1 = 0.0f;
             if (flags & OSC_AA) {
                 double p2 = pos + 0.5;               // (pos + 0.5) % 1.0
                 p2 = p2 >= 1.0 ? p2 - 1.0 : p2;
-                blep1 = poly_blep_fast((float)p2, (float)(p2 - 1.0), inv_dt);
+                blep1 = poly_blep_sel((float)p2, (float)(p2 - 1.0), inv_dt, p2 < delta, p2 > upper);
             }
             square = (pos < 0.5 ? -1.0f : 1.0f) - (blep0 - blep1);
         }

@@ -1067,3 +1067,36 @@ def test_filter_clamps_a_nan_to_plus_one(S, oracle, flags):
         else:
             np.testing.assert_array_equal(fr[:, :150, v][np.isfinite(ref[:, :150]) & (ref[:, :150] == 0)], 0.0)   # before the NaN arrives
             assert (np.abs(fr[0, 200:, v]) == 1.0).all() and (fr[1, 200:, v] == 0.0).all()                        # saturated, finite
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", MODES)
+def test_oscillator_increments_beyond_half_a_cycle(S, oracle, flags):
+    """At sample rate 1000 the audible range reaches increments of 0.1 ... 1.1 cycles per sample.  Past 1/2 the two PolyBLEP windows
+    overlap (oscillator.rs:53-66 tests `t < dt` first, then `t > 1.0 - dt`) and the branches no longer meet at a border — and an
+    oscillator that starts at phase 0 lands exactly ON the border after one step.  (tools/fv_soak.py found the default mode deciding
+    that border from a rounded f32 quotient: errors of 0.7.)"""
+    sr, V, T = 1000, 64, 3000
+    val = np.linspace(-3.0, 1.32, V).astype(np.float32)
+    def build(g):
+        osc, osc2, out = g.add_module(S.MOD_OSCILLATOR), g.add_module(S.MOD_OSCILLATOR), g.add_module(S.MOD_OUTPUT)
+        g.connect(osc, S.OSC_OUT_SAW, out, 0)
+        g.connect(osc2, S.OSC_OUT_SQUARE, out, 1)
+        g.set_field(osc2, S.OSC_VAL, 0.5)
+        g.connect(osc, S.OSC_OUT_SAW, osc2, 0)       # and one driven through its pitch CV
+        return osc
+    o = oracle.OraclePatch(sr, 64, 2)
+    osc = build(o)
+    ref, _ = o.render_batch(V, T, [(osc, S.OSC_VAL, val)], threads=8)
+    delta = 440.0 * 2.0 ** val.astype(np.float64) / sr
+    assert delta.min() < 0.1 and delta.max() > 1.05
+    p = S.Patch(sr, 64, 2)
+    build(p)
+    p.configure_voices(V)
+    p.set_voice_field(osc, S.OSC_VAL, val)
+    fr, _ = p.render(T, flags=flags)
+    if flags & 1:
+        np.testing.assert_array_equal(bits(fr[0]), bits(ref[0]))
+    assert_close(fr[0], ref[0])
+    # (channel 1 integrates the saw into a pitch: exact oscillator is forced by the flattener, compared loosely in default modes)
+    assert_close(fr[1], ref[1], tol=1e-5 if flags & 1 else 2.5)
