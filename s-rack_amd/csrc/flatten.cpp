@@ -980,6 +980,18 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             }
         }
         if (drives_pitch) render_flags |= SRACK_RENDER_EXACT_OSC;
+        // The other amplifier of a 1e-7: a ladder filter close to self-oscillation.  Its feedback gain q grows with the resonance, and
+        // from ~0.93 up (tools/shape_soak.py: 7 of 150 random P1 parameter sets, all with res >= 0.928, a few voices each, up to 3e-3)
+        // the fma-contracted ladder of the default mode leaves the 1e-5 band although every stage is closer to the real-number
+        // result than the reference's.  Such a patch gets the literal ladder, i.e. the exact flavour of the kernels.
+        for (int m = 0; m < n_mod && !(render_flags & SRACK_RENDER_EXACT_OSC); m++) {
+            if (!A.live[(size_t)m] || g.modules[(size_t)m].type != SRACK_MOD_MOOG_FILTER) continue;
+            double res = g.modules[(size_t)m].fields[SRACK_VCF_RES];
+            for (const auto& o : overrides)
+                if (o.module == m && o.field == SRACK_VCF_RES)
+                    for (double v : o.values) res = std::max(res, v);
+            if (res >= 0.9) render_flags |= SRACK_RENDER_EXACT_OSC;
+        }
     }
     out.effective_flags = render_flags;
 
