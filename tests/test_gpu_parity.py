@@ -1100,3 +1100,30 @@ def test_oscillator_increments_beyond_half_a_cycle(S, oracle, flags):
     assert_close(fr[0], ref[0])
     # (channel 1 integrates the saw into a pitch: exact oscillator is forced by the flattener, compared loosely in default modes)
     assert_close(fr[1], ref[1], tol=1e-5 if flags & 1 else 2.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", FAST_MODES)
+def test_p1_near_self_oscillation_stays_within_tolerance(S, oracle, flags):
+    """Resonance 0.97, cutoffs up to 0.85, band-pass port: the ladder's feedback gain multiplies every rounding difference.  The default
+    modes used to leave 1e-5 here (tools/shape_soak.py); the flattener now hands such a patch the literal ladder."""
+    V, T = 70, 5000
+    def build(g):
+        ids = S.build_p1(g, adsr="finite", lfo_val=-4.0)
+        g.set_field(ids["vcf"], S.VCF_RES, 0.97)
+        g.set_field(ids["vcf"], S.VCF_EXP_AMT, 0.4)
+        g.disconnect(ids["vca"], 0)
+        g.connect(ids["vcf"], S.VCF_OUT_BANDPASS, ids["vca"], 0)
+        return ids
+    det, cut = np.linspace(-2.0, 2.0, V).astype(np.float32), np.linspace(0.1, 0.85, V).astype(np.float32)
+    o = oracle.OraclePatch(8000, 1024, 2)
+    ids = build(o)
+    ref, _ = o.render_batch(V, T, [(ids["osc_a"], S.OSC_VAL, det), (ids["vcf"], S.VCF_FREQ, cut)], threads=8)
+    p = S.Patch(8000, 1024, 2)
+    build(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    fr, _ = p.render(T, flags=flags)        # (one plane: both channels carry the VCA)
+    assert_close(fr[0], ref[0])
+    assert np.abs(ref).max() > 0.05
