@@ -193,7 +193,14 @@ int srack_patch_module_type(const srack_patch* p, int module);
 int srack_module_num_inputs(const srack_patch* p, int module);  /* SynthModule::get_num_inputs  */
 int srack_module_num_outputs(const srack_patch* p, int module); /* SynthModule::get_num_outputs */
 
-/* field access = the struct members egui sliders / serde touch.  Uniform across voices. */
+/* field access = the struct members egui sliders / serde touch.  Uniform across voices.
+ * NOTE on state: the voices' running state lives on the device between renders.  Any edit of the patch after a render — a module,
+ * a connection, a field (srack_patch_set_field, set_step, set_wave, set_noise_seed), a per-voice field, or a different `flags` argument
+ * to srack_render — makes the next render re-flatten the patch and START AGAIN from the state stored in the patch (the state fields
+ * as last set; the modules' defaults otherwise), sample counter 0.  Rendering with unchanged patch and flags continues seamlessly.
+ * (The reference's sliders change a parameter without touching module state; carrying the device state across an edit is listed
+ * under "what would come next" in DESIGN.md.  Until then: read the state back with srack_voices_get_field and set it as per-voice
+ * fields before the edit's first render.) */
 int srack_patch_set_field(srack_patch* p, int module, int field, double value);
 int srack_patch_get_field(const srack_patch* p, int module, int field, double* value);
 
