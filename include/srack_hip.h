@@ -199,8 +199,9 @@ int srack_module_num_outputs(const srack_patch* p, int module); /* SynthModule::
  * to srack_render — makes the next render re-flatten the patch and START AGAIN from the state stored in the patch (the state fields
  * as last set; the modules' defaults otherwise), sample counter 0.  Rendering with unchanged patch and flags continues seamlessly.
  * (The reference's sliders change a parameter without touching module state; carrying the device state across an edit is listed
- * under "what would come next" in DESIGN.md.  Until then: read the state back with srack_voices_get_field and set it as per-voice
- * fields before the edit's first render.) */
+ * under "what would come next" in DESIGN.md.  Until then: read the state fields back with srack_voices_get_field and set them as
+ * per-voice fields before the edit's first render — tested bit for bit in tests/test_gpu_parity.py; the contents of feedback delay
+ * rings, reverb lines and the noise sample counter are not reachable that way and restart.) */
 int srack_patch_set_field(srack_patch* p, int module, int field, double value);
 int srack_patch_get_field(const srack_patch* p, int module, int field, double* value);
 
