@@ -198,12 +198,17 @@ int srack_module_num_outputs(const srack_patch* p, int module); /* SynthModule::
  * a connection, a field (srack_patch_set_field, set_step, set_wave, set_noise_seed), a per-voice field, or a different `flags` argument
  * to srack_render — makes the next render re-flatten the patch and START AGAIN from the state stored in the patch (the state fields
  * as last set; the modules' defaults otherwise), sample counter 0.  Rendering with unchanged patch and flags continues seamlessly.
- * (The reference's sliders change a parameter without touching module state; carrying the device state across an edit is listed
- * under "what would come next" in DESIGN.md.  Until then: read the state fields back with srack_voices_get_field and set them as
- * per-voice fields before the edit's first render — tested bit for bit in tests/test_gpu_parity.py; the contents of feedback delay
- * rings, reverb lines and the noise sample counter are not reachable that way and restart.) */
+ * (The reference's sliders change a parameter without touching module state: srack_patch_keep_state below carries the modules'
+ * state across an edit.  By hand it is: read the state fields back with srack_voices_get_field BEFORE the edit and set them as
+ * per-voice fields — both tested bit for bit in tests/test_gpu_parity.py.) */
 int srack_patch_set_field(srack_patch* p, int module, int field, double value);
 int srack_patch_get_field(const srack_patch* p, int module, int field, double* value);
+/* keep != 0: from now on an edit between renders no longer restarts the voices.  Before the patch is re-flattened, every
+ * module's state fields (phases, filter states, envelope phases and modes, detector bits, sequencer steps, sampler positions) are
+ * read back from the device, per voice, and become the starting state of the re-flattened program; the sample counter runs on.
+ * What is NOT carried: the contents of feedback delay rings and of reverb lines (they restart empty).  srack_voices_configure
+ * always starts afresh.  Default: off (an edit restarts the voices, as documented above). */
+int srack_patch_keep_state(srack_patch* p, int keep);
 
 /* Sequencer grid cells (the egui grid editors write these, sequencer.rs:137-184, 437-478).
  * Grid sequencer: channel must be 0, `value` is the note index (u16); pattern sequencer: channel 0..7, value ignored. */

@@ -27,6 +27,7 @@ mod ffi {
         pub fn srack_patch_get_field(p: *const SrackPatch, module: c_int, field: c_int, value: *mut f64) -> c_int;
         pub fn srack_patch_set_step(p: *mut SrackPatch, module: c_int, channel: c_int, step: c_int, state: c_int, value: c_int) -> c_int;
         pub fn srack_patch_set_noise_seed(p: *mut SrackPatch, seed: u64, first_voice: u64) -> c_int;
+        pub fn srack_patch_keep_state(p: *mut SrackPatch, keep: c_int) -> c_int;
         pub fn srack_patch_set_wave(p: *mut SrackPatch, module: c_int, samples: *const f32, n_samples: u32, sample_rate: f32) -> c_int;
         pub fn srack_patch_load_srk(bytes: *const c_void, n_bytes: usize, sample_rate: u32, buffer_size: u32, channels: u32, out: *mut *mut SrackPatch) -> c_int;
         pub fn srack_patch_save_srk(p: *const SrackPatch, buf: *mut c_void, cap: usize, n_bytes: *mut usize) -> c_int;
@@ -131,6 +132,11 @@ impl Patch {
         check(unsafe { ffi::srack_patch_set_step(self.raw, module, channel, step, state, value) }).map(|_| ())
     }
     /// What `WaveBox::load` leaves behind (src/synth/sample.rs:31-69): first channel as f32 + the file's sample rate.
+    /// Edits between renders carry the modules' state over instead of restarting the voices (the reference's sliders do not reset state).
+    pub fn keep_state(&mut self, keep: bool) -> Result<(), Error> {
+        check(unsafe { ffi::srack_patch_keep_state(self.raw, keep as c_int) }).map(|_| ())
+    }
+
     /// NoiseModule streams are keyed by (seed, module, first_voice + voice); the reference's generator is OS-seeded.
     pub fn set_noise_seed(&mut self, seed: u64, first_voice: u64) -> Result<(), Error> {
         check(unsafe { ffi::srack_patch_set_noise_seed(self.raw, seed, first_voice) }).map(|_| ())

@@ -249,6 +249,13 @@ int srack_patch_set_output_buffer(srack_patch* p, int module, int port, const fl
     return p->h.graph.set_output_buffer(module, port, samples, n);
 }
 
+int srack_patch_keep_state(srack_patch* p, int keep)
+{
+    CHECK_HANDLE(p);
+    p->h.keep_state = keep != 0;
+    return SRACK_OK;
+}
+
 int srack_patch_set_noise_seed(srack_patch* p, uint64_t seed, uint64_t first_voice)
 {
     CHECK_HANDLE(p);
@@ -353,6 +360,7 @@ int srack_voices_configure(srack_patch* p, uint32_t n_voices)
     p->h.n_voices = n_voices;
     p->h.overrides.clear();
     p->h.voices_revision++;
+    p->h.voices_fresh = true;
     return SRACK_OK;
 }
 
@@ -420,25 +428,37 @@ int srack_voices_get_field(srack_patch* p, int module, int field, double* values
     }
     int rc = ensure_program(h, h.prog_valid ? h.prog_flags : 0u);
     if (rc != SRACK_OK) return rc;
-    // a module evaluated by the control program has ONE state, shared by every voice
-    const int stage = h.prog.n_tracks > 0 && module >= 0 && module < (int)h.prog.ctl_stage.size() ? h.prog.ctl_stage[(size_t)module] : -1;
-    const bool ctl = stage >= 0;
-    const FlatProgram& P = ctl ? h.prog.ctl[(size_t)stage] : h.prog.voice;
-    StateLoc loc = P.locate(h.graph, module, field);
-    if (loc.row < 0) {  // a parameter, or a module that is not evaluated: the field value itself
-        double x;
-        rc = h.graph.get_field(module, field, &x);
-        if (rc != SRACK_OK) return rc;
-        for (uint32_t v = 0; v < h.n_voices; v++) values[v] = x;
-        for (const auto& o : h.overrides)
-            if (o.module == module && o.field == field)
-                for (uint32_t v = 0; v < h.n_voices; v++) values[v] = o.values[v];
+    std::vector<double> got;
+    if (read_device_state(h, module, field, got)) {
+        for (uint32_t v = 0; v < h.n_voices; v++) values[v] = got[v];
         return SRACK_OK;
     }
+    // a parameter, or a module that is not evaluated: the field value itself
+    double x;
+    rc = h.graph.get_field(module, field, &x);
+    if (rc != SRACK_OK) return rc;
+    for (uint32_t v = 0; v < h.n_voices; v++) values[v] = x;
+    for (const auto& o : h.overrides)
+        if (o.module == module && o.field == field)
+            for (uint32_t v = 0; v < h.n_voices; v++) values[v] = o.values[v];
+    return SRACK_OK;
+}
+
+extern "C++" {
+namespace srack {
+bool read_device_state(PatchHandle& h, int module, int field, std::vector<double>& values)
+{
+    if (!h.prog_valid || !h.dev || module < 0 || module >= (int)h.graph.modules.size()) return false;
+    // a module evaluated by the control program has ONE state, shared by every voice
+    const int stage = h.prog.n_tracks > 0 && module < (int)h.prog.ctl_stage.size() ? h.prog.ctl_stage[(size_t)module] : -1;
+    const bool ctl = stage >= 0;
+    const FlatProgram& P = ctl ? h.prog.ctl[(size_t)stage] : h.prog.voice;
+    const StateLoc loc = P.locate(h.graph, module, field);
+    if (loc.row < 0) return false;
     const uint32_t V = P.n_voices;
     std::vector<uint32_t> rows((size_t)V * (loc.f64 ? 2 : 1));
-    rc = device_read_rows(h, stage, loc.row, loc.f64 ? 2 : 1, rows.data());
-    if (rc != SRACK_OK) return rc;
+    if (device_read_rows(h, stage, loc.row, loc.f64 ? 2 : 1, rows.data()) != SRACK_OK) return false;
+    values.resize(h.n_voices);
     for (uint32_t v = 0; v < h.n_voices; v++) {
         const uint32_t sv = ctl ? 0u : v;
         if (loc.f64) {
@@ -455,8 +475,10 @@ int srack_voices_get_field(srack_patch* p, int module, int field, double* values
             values[v] = (double)f;
         }
     }
-    return SRACK_OK;
+    return true;
 }
+}  // namespace srack
+}  // extern "C++"
 
 // ---- device helpers -------------------------------------------------------------------------------
 int srack_device_count(int* n)

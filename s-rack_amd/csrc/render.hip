@@ -108,13 +108,33 @@ int ensure_program(PatchHandle& h, uint32_t flags)
 {
     if (h.prog_valid && h.prog_graph_revision == h.graph.revision && h.prog_voices_revision == h.voices_revision && h.prog_flags == flags)
         return SRACK_OK;
+    // srack_patch_keep_state: what the modules hold on the device becomes the state the re-flattened program starts from —
+    // per voice for the modules of the voice program (a per-voice override of the state field), once for a module the control
+    // program evaluates (it stays voice-invariant: the field itself).  Rings and reverb lines are not carried.
+    const bool carry = h.keep_state && h.prog_valid && h.dev && !h.voices_fresh && h.samples_rendered > 0;
+    if (carry) {
+        std::vector<double> values;
+        for (int m = 0; m < (int)h.graph.modules.size(); m++) {
+            Module& mod = h.graph.modules[(size_t)m];
+            for (int f = 0; f < (int)mod.fields.size(); f++) {
+                if (!Graph::field_is_state(mod.type, f) || !read_device_state(h, m, f, values)) continue;
+                const bool in_ctl = h.prog.n_tracks > 0 && m < (int)h.prog.ctl_stage.size() && h.prog.ctl_stage[(size_t)m] >= 0;
+                for (auto it = h.overrides.begin(); it != h.overrides.end();) it = (it->module == m && it->field == f) ? h.overrides.erase(it) : it + 1;
+                if (in_ctl)
+                    mod.fields[(size_t)f] = values[0];
+                else
+                    h.overrides.push_back(VoiceOverride{m, f, values});
+            }
+        }
+    }
     int rc = flatten(h.graph, h.n_voices, h.overrides, flags, h.prog);
     if (rc != SRACK_OK) return rc;
     h.prog_valid = true;
     h.prog_graph_revision = h.graph.revision;
     h.prog_voices_revision = h.voices_revision;
     h.prog_flags = flags;
-    h.samples_rendered = 0;
+    if (!carry) h.samples_rendered = 0;
+    h.voices_fresh = false;
     if (h.dev) {  // device copies are rebuilt lazily by device_render
         device_release(h.dev);
         h.dev = nullptr;

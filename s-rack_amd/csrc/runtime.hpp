@@ -24,6 +24,8 @@ struct PatchHandle {
 
     DeviceState* dev = nullptr;
     uint64_t samples_rendered = 0;  // absolute tick count: phase of the feedback rings
+    bool keep_state = false;        // srack_patch_keep_state: carry the modules' device state across a re-flatten
+    bool voices_fresh = true;       // set by srack_voices_configure: nothing on the device belongs to these voices yet
 
     ~PatchHandle();
 };
@@ -36,6 +38,8 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
 int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t flags);
 int device_kernel_ms(PatchHandle& h, double* avg_ms, int* n_launches, int reset);
 int device_read_rows(PatchHandle& h, int ctl_stage /* -1: the voice program */, int first_row, int n_rows, uint32_t* host_dst);
+// One state field of one module as the CURRENT program holds it on the device, per voice (no re-flatten); false: not device state.
+bool read_device_state(PatchHandle& h, int module, int field, std::vector<double>& values);
 void device_release(DeviceState* d);
 const char* device_kernel_name(const PatchHandle& h);
 

@@ -1173,3 +1173,46 @@ def test_state_carried_across_an_edit_by_hand(S, flags):
     cont = s_.render_channels(T2, flags)
     np.testing.assert_array_equal(bits(a1), bits(whole[:, :T1]))
     np.testing.assert_array_equal(bits(cont), bits(whole[:, T1:]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [1, 3, 0, 2])
+@pytest.mark.parametrize("shape", ["p1", "p3"])
+def test_keep_state_carries_the_voices_across_edits(S, shape, flags):
+    """srack_patch_keep_state: an edit between renders re-flattens the patch but the modules' state (per voice, and once for the
+    modules the control program evaluates) is carried over.  An edit that changes nothing audible must therefore continue the render:
+    bit for bit in exact modes; in default modes the fused kernels' 64-bit fixed-point phase passes through a double (2^-53)."""
+    V, T1, T2, T3 = 70, 1500, 900, 1300
+    def make():
+        p = S.Patch(48000, 64, 2)
+        if shape == "p1":
+            ids = S.build_p1(p, adsr="finite", lfo_val=-3.0)
+            p.configure_voices(V)
+            p.set_voice_field(ids["osc_a"], S.OSC_VAL, np.linspace(-2.0, 1.0, V).astype(np.float32))
+            p.set_voice_field(ids["vcf"], S.VCF_FREQ, np.linspace(0.05, 0.5, V).astype(np.float32))
+            knob = (ids["vca"], S.VCA_NEGATIVE, 0)
+        else:
+            ids = S.build_p3(p, clock_val=-3.0, length=6)
+            p.configure_voices(V)
+            p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, np.linspace(-2.0, 0.5, V).astype(np.float32))
+            p.set_voice_field(ids["vcf"], S.VCF_FREQ, np.linspace(0.05, 0.4, V).astype(np.float32))
+            knob = (ids["vca"], S.VCA_NEGATIVE, 0)
+        return p, knob
+    whole = make()[0].render_channels(T1 + T2 + T3, flags)
+    p, knob = make()
+    p.keep_state(True)
+    parts = [p.render_channels(T1, flags)]
+    p.set_field(*knob)                                 # an edit (same value): re-flatten
+    parts.append(p.render_channels(T2, flags))
+    p.set_field(*knob)
+    parts.append(p.render_channels(T3, flags))
+    got = np.concatenate(parts, axis=1)
+    if flags & 1:
+        np.testing.assert_array_equal(bits(got), bits(whole))
+    else:
+        assert_close(got, whole)
+    # without keep_state the same sequence restarts the voices at every edit
+    q, knob = make()
+    q.render_channels(T1, flags)
+    q.set_field(*knob)
+    np.testing.assert_array_equal(bits(q.render_channels(T2, flags)), bits(whole[:, :T2]))
