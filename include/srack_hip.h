@@ -205,9 +205,11 @@ int srack_patch_set_field(srack_patch* p, int module, int field, double value);
 int srack_patch_get_field(const srack_patch* p, int module, int field, double* value);
 /* keep != 0: from now on an edit between renders no longer restarts the voices.  Before the patch is re-flattened, every
  * module's state fields (phases, filter states, envelope phases and modes, detector bits, sequencer steps, sampler positions) are
- * read back from the device, per voice, and become the starting state of the re-flattened program; the sample counter runs on.
- * What is NOT carried: the contents of feedback delay rings and of reverb lines (they restart empty).  srack_voices_configure
- * always starts afresh.  Default: off (an edit restarts the voices, as documented above). */
+ * read back from the device, per voice, and become the starting state of the re-flattened program; the delay rings of feedback
+ * edges and the reverbs' delay lines move device to device into the ring / reverb of the same module; the sample counter runs on.
+ * (A ring or reverb whose module changes sides between the per-voice program and the voice-invariant control program in the
+ * edit, or whose buffer_size-dependent length changes, restarts empty.)  srack_voices_configure always starts afresh.
+ * Default: off (an edit restarts the voices, as documented above). */
 int srack_patch_keep_state(srack_patch* p, int keep);
 
 /* Sequencer grid cells (the egui grid editors write these, sequencer.rs:137-184, 437-478).

@@ -387,6 +387,7 @@ int Builder::build()
                 out.seqtab.push_back((uint32_t)(u >> 32));
             }
             op.delta_row = (int)out.fv_rows;
+            out.carry.push_back(FlatProgram::CarryTag{m, 0, 2, (int64_t)out.fv_rows, (int64_t)kFvStates + total});
             out.fv_rows += (uint32_t)kFvStates + total;
             break;
         }
@@ -522,6 +523,7 @@ int Builder::build()
         }
     }
     if (!out.ring_init.empty()) out.ring_init.resize((size_t)n_global * B, 0.0f);
+    for (const Ring& r : rings) out.carry.push_back(FlatProgram::CarryTag{r.src, r.port, rings_in_lds ? 0 : 1, rings_in_lds ? r.first_row : r.global_id, B});
     for (DevOp& op : out.ops)
         if (op.kind == OP_DELAY_RD || op.kind == OP_DELAY_WR) {
             const Ring& r = rings[(size_t)op.aux];

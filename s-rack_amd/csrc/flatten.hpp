@@ -37,6 +37,14 @@ struct FlatProgram {
     std::vector<uint32_t> seqtab;     // sequencer grids, 64 cells per sequencer op (DevOp::aux is the dword offset)
     std::vector<float> ring_init;     // [n_rings][B] initial ring contents, same for every voice; empty = zeros
     uint32_t fv_rows = 0;             // rows (of n_voices doubles each) of the OP_FREEVERB blocks, zero-initialised
+    // Device state that is not a module field, named so that srack_patch_keep_state can find it again after a re-flatten:
+    // a feedback ring (the source's port) or a reverb's block.  where: 0 = `count` rows of the voice table from row `first`,
+    // 1 = global ring `first` (count = buffer_size rows of floats), 2 = rows [first, first + count) of the freeverb buffer.
+    struct CarryTag {
+        int module, port, where;
+        int64_t first, count;
+    };
+    std::vector<CarryTag> carry;
     std::vector<int> op_of_module;    // module index -> op index, -1 if the module cannot reach the output
     int fused = FUSED_NONE;
     int fused_variant = 0;            // kernel-specific (which oscillator port / filter port the chain uses)

@@ -102,7 +102,11 @@ void device_release(DeviceState* d)
     delete d;
 }
 
-PatchHandle::~PatchHandle() { device_release(dev); }
+PatchHandle::~PatchHandle()
+{
+    device_release(dev);
+    device_release(dev_old);
+}
 
 int ensure_program(PatchHandle& h, uint32_t flags)
 {
@@ -111,8 +115,8 @@ int ensure_program(PatchHandle& h, uint32_t flags)
     // srack_patch_keep_state: what the modules hold on the device becomes the state the re-flattened program starts from —
     // per voice for the modules of the voice program (a per-voice override of the state field), once for a module the control
     // program evaluates (it stays voice-invariant: the field itself).  Rings and reverb lines are not carried.
-    const bool carry = h.keep_state && h.prog_valid && h.dev && !h.voices_fresh && h.samples_rendered > 0;
-    if (carry) {
+    const bool carry = h.keep_state && h.prog_valid && !h.voices_fresh && h.samples_rendered > 0;
+    if (carry && h.dev) {
         std::vector<double> values;
         for (int m = 0; m < (int)h.graph.modules.size(); m++) {
             Module& mod = h.graph.modules[(size_t)m];
@@ -127,6 +131,12 @@ int ensure_program(PatchHandle& h, uint32_t flags)
             }
         }
     }
+    std::vector<PatchHandle::OldTag> pending_tags;  // what the program about to be replaced holds besides module fields
+    if (carry && h.dev) {
+        for (const auto& t : h.prog.voice.carry) pending_tags.push_back({-1, h.prog.voice.n_voices, t});
+        for (size_t s = 0; s < h.prog.ctl.size(); s++)
+            for (const auto& t : h.prog.ctl[s].carry) pending_tags.push_back({(int)s, h.prog.ctl[s].n_voices, t});
+    }
     int rc = flatten(h.graph, h.n_voices, h.overrides, flags, h.prog);
     if (rc != SRACK_OK) return rc;
     h.prog_valid = true;
@@ -136,8 +146,19 @@ int ensure_program(PatchHandle& h, uint32_t flags)
     if (!carry) h.samples_rendered = 0;
     h.voices_fresh = false;
     if (h.dev) {  // device copies are rebuilt lazily by device_render
-        device_release(h.dev);
+        if (carry) {  // (a second edit before any render finds h.dev empty and leaves the stash of the first in place)
+            device_release(h.dev_old);
+            h.dev_old = h.dev;
+            h.old_tags = std::move(pending_tags);
+        } else {
+            device_release(h.dev);
+        }
         h.dev = nullptr;
+    }
+    if (!carry) {
+        device_release(h.dev_old);
+        h.dev_old = nullptr;
+        h.old_tags.clear();
     }
     return SRACK_OK;
 }
@@ -187,12 +208,47 @@ static int upload_one(const FlatProgram& P, DevProg& d)
     return SRACK_OK;
 }
 
+// srack_patch_keep_state, second half: feedback rings and reverb lines of the replaced program move device to device into the
+// same ring / the same reverb of the new one (matched by the module and port they belong to; same length, same voice count).
+static int transplant(PatchHandle& h)
+{
+    DeviceState* o = h.dev_old;
+    HIP_TRY(hipDeviceSynchronize());  // the last render may still be running on the caller's stream
+    auto prog_of = [&](DeviceState* d, int stage) -> DevProg& { return stage < 0 ? d->voice : d->ctl[(size_t)stage]; };
+    auto visit = [&](int stage, const FlatProgram& P) -> int {
+        for (const auto& t : P.carry)
+            for (const auto& ot : h.old_tags) {
+                if (ot.tag.module != t.module || ot.tag.port != t.port || ot.tag.where != t.where || ot.tag.count != t.count || ot.n_voices != P.n_voices) continue;
+                if (ot.stage >= (int)o->ctl.size()) continue;
+                const DevProg &src = prog_of(o, ot.stage), &dst = prog_of(h.dev, stage);
+                const size_t V = P.n_voices;
+                if (t.where == 0 && src.d_table && dst.d_table)
+                    HIP_TRY(hipMemcpy(dst.d_table + (size_t)t.first * V, src.d_table + (size_t)ot.tag.first * V, sizeof(uint32_t) * (size_t)t.count * V, hipMemcpyDeviceToDevice));
+                if (t.where == 1 && src.d_rings && dst.d_rings)
+                    HIP_TRY(hipMemcpy(dst.d_rings + (size_t)t.first * t.count * V, src.d_rings + (size_t)ot.tag.first * t.count * V, sizeof(float) * (size_t)t.count * V, hipMemcpyDeviceToDevice));
+                if (t.where == 2 && src.d_fv && dst.d_fv)
+                    HIP_TRY(hipMemcpy(dst.d_fv + (size_t)t.first * V, src.d_fv + (size_t)ot.tag.first * V, sizeof(double) * (size_t)t.count * V, hipMemcpyDeviceToDevice));
+                break;
+            }
+        return SRACK_OK;
+    };
+    int rc = visit(-1, h.prog.voice);
+    for (size_t s = 0; s < h.prog.ctl.size() && rc == SRACK_OK; s++) rc = visit((int)s, h.prog.ctl[s]);
+    return rc;
+}
+
 static int upload_program(PatchHandle& h)
 {
     h.dev = new DeviceState();
     int rc = upload_one(h.prog.voice, h.dev->voice);
     h.dev->ctl.resize(h.prog.ctl.size());
     for (size_t s = 0; s < h.prog.ctl.size() && rc == SRACK_OK; s++) rc = upload_one(h.prog.ctl[s], h.dev->ctl[s]);
+    if (rc == SRACK_OK && h.dev_old) {
+        rc = transplant(h);
+        device_release(h.dev_old);
+        h.dev_old = nullptr;
+        h.old_tags.clear();
+    }
     return rc;
 }
 

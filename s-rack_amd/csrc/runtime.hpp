@@ -26,6 +26,15 @@ struct PatchHandle {
     uint64_t samples_rendered = 0;  // absolute tick count: phase of the feedback rings
     bool keep_state = false;        // srack_patch_keep_state: carry the modules' device state across a re-flatten
     bool voices_fresh = true;       // set by srack_voices_configure: nothing on the device belongs to these voices yet
+    // keep_state: the device state of the program that was replaced, kept until the new one is uploaded (rings and reverb lines
+    // move device to device), with what it held and where
+    DeviceState* dev_old = nullptr;
+    struct OldTag {
+        int stage;  // -1: the voice program
+        uint32_t n_voices;
+        FlatProgram::CarryTag tag;
+    };
+    std::vector<OldTag> old_tags;
 
     ~PatchHandle();
 };

@@ -1216,3 +1216,37 @@ def test_keep_state_carries_the_voices_across_edits(S, shape, flags):
     q.render_channels(T1, flags)
     q.set_field(*knob)
     np.testing.assert_array_equal(bits(q.render_channels(T2, flags)), bits(whole[:, :T2]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [1, 3, 0, 2])
+@pytest.mark.parametrize("B,reverb", [(1, True), (8, True), (64, True), (1, False), (1024, False)])   # (without the reverb: the fused FM kernels)
+def test_keep_state_carries_feedback_rings_and_reverb_lines(S, B, reverb, flags):
+    """... and the state that is not a module field: the delay ring of a feedback edge (a state row of the voice table for
+    buffer_size <= 16, a ring in HBM above) and a reverb's 24 delay lines, device to device into the re-flattened program."""
+    V, T1, T2 = 66, 2100, 1900
+    def make():
+        p = S.Patch(48000, B, 2)
+        ids = S.build_p2(p, beta=0.25, index=0.8)                      # FM pair: OSC_M.sine -> MUL_FB -> OSC_M.cv is a delayed edge
+        fv = p.add_module(S.MOD_FREEVERB)
+        if reverb:
+            p.disconnect(ids["out"], 1)
+            p.connect(ids["osc_c"], S.OSC_OUT_SINE, fv, 0)
+            p.connect(fv, 1, ids["out"], 1)                             # channel 1 through a reverb
+        p.configure_voices(V)
+        p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, np.linspace(0.0, 0.5, V).astype(np.float32))
+        p.set_voice_field(ids["osc_c"], S.OSC_VAL, np.linspace(-1.0, 1.0, V).astype(np.float32))
+        return p, (fv, S.FREEVERB_DRY, 0.0)
+    whole = make()[0].render_channels(T1 + T2, flags)
+    p, knob = make()
+    p.keep_state(True)
+    first = p.render_channels(T1, flags)
+    p.set_field(*knob)
+    p.set_field(*knob)                                                  # two edits before the next render: still one carry
+    second = p.render_channels(T2, flags)
+    got = np.concatenate([first, second], axis=1)
+    if flags & 1:
+        np.testing.assert_array_equal(bits(got), bits(whole))
+    else:
+        assert_close(got, whole)
+    assert np.abs(whole[1, T1:]).max() > 1e-3
