@@ -309,6 +309,7 @@ int Graph::set_wave(int module, const float* samples, uint32_t n, float sample_r
     m.fields[SRACK_SAMPLE_WAVE_SAMPLE_RATE] = (double)sample_rate;
     m.fields[SRACK_SAMPLE_WAVE_NEW] = 1.0;
     revision++;
+    modules[(size_t)module].wave_revision = revision;
     return SRACK_OK;
 }
 

@@ -33,6 +33,7 @@ struct Module {
     // pattern: bits 2c / 2c+1 = present / hold of channel c.
     std::vector<uint32_t> cells;
     std::vector<float> wave;  // SampleModule: wavebox.samples
+    uint64_t wave_revision = 0;  // Graph::revision when the wave (and with it wavebox.new) was last set
     // what a .srk file carries besides the fields (ui.rs:578-586): the module's UUID string, its workspace position,
     // and the contents of its output buffers — the latter is what the sink of a broken feedback edge reads during
     // the first block after a load (empty = zeros, AudioBuffer::new)

@@ -128,6 +128,9 @@ int ensure_program(PatchHandle& h, uint32_t flags)
                     mod.fields[(size_t)f] = values[0];
                 else
                     h.overrides.push_back(VoiceOverride{m, f, values});
+                // a sample player that has run has consumed its `wavebox.new` (sample.rs:199-203) — unless the wave was set after
+                // the program that ran was flattened
+                if (mod.type == SRACK_MOD_SAMPLE && mod.wave_revision <= h.prog_graph_revision) mod.fields[SRACK_SAMPLE_WAVE_NEW] = 0.0;
             }
         }
     }

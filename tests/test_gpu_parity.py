@@ -1177,7 +1177,7 @@ def test_state_carried_across_an_edit_by_hand(S, flags):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags", [1, 3, 0, 2])
-@pytest.mark.parametrize("shape", ["p1", "p3"])
+@pytest.mark.parametrize("shape", ["p1", "p3", "p4"])
 def test_keep_state_carries_the_voices_across_edits(S, shape, flags):
     """srack_patch_keep_state: an edit between renders re-flattens the patch but the modules' state (per voice, and once for the
     modules the control program evaluates) is carried over.  An edit that changes nothing audible must therefore continue the render:
@@ -1191,6 +1191,13 @@ def test_keep_state_carries_the_voices_across_edits(S, shape, flags):
             p.set_voice_field(ids["osc_a"], S.OSC_VAL, np.linspace(-2.0, 1.0, V).astype(np.float32))
             p.set_voice_field(ids["vcf"], S.VCF_FREQ, np.linspace(0.05, 0.5, V).astype(np.float32))
             knob = (ids["vca"], S.VCA_NEGATIVE, 0)
+        elif shape == "p4":   # the sample player: its `wavebox.new` must count as consumed once it has run (tools/fuzz_soak_keep.py)
+            ids = S.build_p4(p)
+            p.configure_voices(V)
+            depth, expo = S.p4_voice_params(V)
+            p.set_voice_field(ids["depth"], S.MATH_CONSTANT, depth)
+            p.set_voice_field(ids["shaper"], S.NONLIN_CONSTANT, expo)
+            knob = (ids["shaper"], S.NONLIN_CONSTANT, 0.75)
         else:
             ids = S.build_p3(p, clock_val=-3.0, length=6)
             p.configure_voices(V)
