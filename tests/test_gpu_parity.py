@@ -1257,3 +1257,37 @@ def test_keep_state_carries_feedback_rings_and_reverb_lines(S, B, reverb, flags)
     else:
         assert_close(got, whole)
     assert np.abs(whole[1, T1:]).max() > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [1, 3, 5])
+def test_keep_state_parameter_change_matches_the_oracle(S, oracle, flags):
+    """The reference's case: a slider moves while the graph runs — the next block sees the new value, module state is untouched.
+    Oracle: one stateful patch object per sampled voice, set_field between two renders (block-aligned).  GPU: keep_state."""
+    V, B, T1, T2 = 70, 64, 1536, 2048
+    det = np.linspace(-2.0, 1.0, V).astype(np.float32)
+    cut = np.linspace(0.05, 0.5, V).astype(np.float32)
+    def edits(ids):
+        return [(ids["vcf"], S.VCF_RES, 0.8), (ids["adsr"], S.ADSR_S_VAL, 0.9), (ids["osc_lfo"], S.OSC_VAL, -2.0), (ids["vca"], S.VCA_NEGATIVE, 1)]
+    p = S.Patch(48000, B, 2)
+    ids = S.build_p1(p, adsr="finite", lfo_val=-3.0)
+    p.configure_voices(V)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    p.keep_state(True)
+    a = p.render_channels(T1, flags)
+    for m, f, v in edits(ids):
+        p.set_field(m, f, v)
+    b = p.render_channels(T2, flags)
+    for v in (0, 17, 42, 69):
+        o = oracle.OraclePatch(48000, B, 2)
+        oi = S.build_p1(o, adsr="finite", lfo_val=-3.0)
+        o.set_field(oi["osc_a"], S.OSC_VAL, float(det[v]))
+        o.set_field(oi["vcf"], S.VCF_FREQ, float(cut[v]))
+        ra = o.render(T1)
+        for m, f, x in edits(oi):
+            o.set_field(m, f, x)
+        rb = o.render(T2)
+        np.testing.assert_array_equal(bits(a[:, :, v]), bits(ra))
+        np.testing.assert_array_equal(bits(b[:, :, v]), bits(rb))
+    assert np.abs(b).max() > 0.05
