@@ -705,7 +705,7 @@ void Builder::match_fused(bool has_rings)
         return;
     }
     if (is_ctl) return;  // the voice-chain shapes below are per-voice programs
-    int n_kind[16] = {0};
+    int n_kind[kOpKinds] = {0};
     for (const DevOp& op : out.ops) n_kind[op.kind]++;
     const DevProgram& H = out.hdr;
     // Sequencer-driven subtractive voice (patch P3 after hoisting): the note CV, the filter envelope and the amplitude

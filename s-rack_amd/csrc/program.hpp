@@ -26,7 +26,8 @@ enum OpKind : int32_t {
     OP_NONLIN = 13,    // NonLinearModule::calc        math.rs:291-311
     OP_SAMPLE = 14,    // SampleModule::calc           sample.rs:192-240
     OP_NOISE = 15,     // NoiseModule::calc            oscillator.rs:381-387 (the draw: srack_hip.h, srack_patch_set_noise_seed)
-    OP_FREEVERB = 16   // FreeverbModule::calc         freeverb.rs:208-270 + the freeverb crate's tick (restated, modules.hip.h)
+    OP_FREEVERB = 16,  // FreeverbModule::calc         freeverb.rs:208-270 + the freeverb crate's tick (restated, modules.hip.h)
+    kOpKinds = 17      // (arrays indexed by kind are sized with this: an n_kind[16] overran when OP_FREEVERB arrived — found under ASan)
 };
 
 // per-kind flag bits -----------------------------------------------------------------------------
