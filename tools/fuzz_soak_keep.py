@@ -33,7 +33,16 @@ for seed in range(lo, hi):
             parts = []
             for k in (cuts[0], cuts[1] - cuts[0], T - cuts[1]):
                 parts.append(p.render_channels(k, flags))
-                p.set_field(osc, S.OSC_ANTIALIASING, p.get_field(osc, S.OSC_ANTIALIASING))   # same value: a re-flatten and nothing else
+                kind = (seed + len(parts)) % 3
+                if kind == 0:
+                    p.set_field(osc, S.OSC_ANTIALIASING, p.get_field(osc, S.OSC_ANTIALIASING))   # same value: a re-flatten and nothing else
+                elif kind == 1:
+                    p.add_module(S.MOD_MATH)                                                     # a module nothing reads
+                else:                                                                            # a wire pulled and put back
+                    wired = [(m, k, p.get_input(m, k)) for m in range(p.num_modules()) for k in range(p.get_num_inputs(m)) if p.get_input(m, k) is not None]
+                    m, k, src = wired[(seed * 7) % len(wired)]
+                    p.disconnect(m, k)
+                    p.connect(src[0], src[1], m, k)
             outs.append(np.concatenate(parts, axis=1))
         if len(outs) < 2: continue
         n += 1
