@@ -1291,3 +1291,40 @@ def test_keep_state_parameter_change_matches_the_oracle(S, oracle, flags):
         np.testing.assert_array_equal(bits(a[:, :, v]), bits(ra))
         np.testing.assert_array_equal(bits(b[:, :, v]), bits(rb))
     assert np.abs(b).max() > 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [1, 3, 5])
+def test_keep_state_rewiring_matches_the_oracle(S, oracle, flags):
+    """... and a cable plugged in while the graph runs: the envelope also sweeps the filter from the next block on, a second
+    oscillator is added and mixed in.  State of everything that already ran is untouched (stateful oracle objects per sampled voice)."""
+    V, B, T1, T2 = 70, 64, 1536, 2048
+    det = np.linspace(-2.0, 1.0, V).astype(np.float32)
+    cut = np.linspace(0.05, 0.4, V).astype(np.float32)
+    def rewire(g, ids):
+        g.connect(ids["adsr"], 0, ids["vcf"], 1)                      # envelope -> cutoff CV
+        osc2, mix = g.add_module(S.MOD_OSCILLATOR), g.add_module(S.MOD_MONO_MIXER)
+        g.set_field(osc2, S.OSC_VAL, 0.5)
+        g.disconnect(ids["vcf"], 0)
+        g.connect(ids["osc_a"], S.OSC_OUT_SAW, mix, 0)
+        g.connect(osc2, S.OSC_OUT_SQUARE, mix, 1)
+        g.connect(mix, 0, ids["vcf"], 0)                              # saw + a new square into the filter
+    p = S.Patch(48000, B, 2)
+    ids = S.build_p1(p, adsr="finite", lfo_val=-3.0)
+    p.configure_voices(V)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    p.keep_state(True)
+    a = p.render_channels(T1, flags)
+    rewire(p, ids)
+    b = p.render_channels(T2, flags)
+    for v in (0, 23, 69):
+        o = oracle.OraclePatch(48000, B, 2)
+        oi = S.build_p1(o, adsr="finite", lfo_val=-3.0)
+        o.set_field(oi["osc_a"], S.OSC_VAL, float(det[v]))
+        o.set_field(oi["vcf"], S.VCF_FREQ, float(cut[v]))
+        ra = o.render(T1)
+        rewire(o, oi)
+        rb = o.render(T2)
+        np.testing.assert_array_equal(bits(a[:, :, v]), bits(ra))
+        np.testing.assert_array_equal(bits(b[:, :, v]), bits(rb))
