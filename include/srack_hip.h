@@ -209,6 +209,8 @@ int srack_patch_get_field(const srack_patch* p, int module, int field, double* v
  * edges and the reverbs' delay lines move device to device into the ring / reverb of the same module; the sample counter runs on.
  * (A ring or reverb whose module changes sides between the per-voice program and the voice-invariant control program in the
  * edit, or whose buffer_size-dependent length changes, restarts empty.)  srack_voices_configure always starts afresh.
+ * With keep, every module of the plan is evaluated, as the reference's execute() does — by default modules that cannot influence
+ * any output are skipped and their state stays as stored — so that a module wired into the audible graph later has run all along.
  * Default: off (an edit restarts the voices, as documented above). */
 int srack_patch_keep_state(srack_patch* p, int keep);
 

@@ -252,6 +252,7 @@ int srack_patch_set_output_buffer(srack_patch* p, int module, int port, const fl
 int srack_patch_keep_state(srack_patch* p, int keep)
 {
     CHECK_HANDLE(p);
+    if (p->h.keep_state != (keep != 0)) p->h.graph.revision++;  // (the flattened program differs: with keep, every planned module is evaluated)
     p->h.keep_state = keep != 0;
     return SRACK_OK;
 }

@@ -930,6 +930,22 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
         }
     }
 
+    if (render_flags & kFlattenEvalAll) {  // everything the planner scheduled runs (plan_execution covers all_modules, synth.rs:107-212)
+        for (int m : g.plan.order) {
+            if (g.modules[(size_t)m].type == SRACK_MOD_OUTPUT && m != output) continue;  // (a second OutputModule is never observable)
+            A.live[(size_t)m] = 1;
+            for (const InputRef& in : g.modules[(size_t)m].in)
+                if (in.src >= 0) {
+                    if (in.src == m) {
+                        set_error("module " + std::to_string(m) + " is wired to itself: the reference deadlocks on this (synth.rs:99,251)");
+                        return SRACK_ERR_SELF_LOOP;
+                    }
+                    A.port_live[(size_t)in.src] |= 1u << in.port;
+                }
+        }
+        render_flags &= ~kFlattenEvalAll;
+    }
+
     // ---- 2b. approximated ports that drive a pitch ----------------------------------------------------
     // Default mode evaluates PolyBLEP in f32 and the ladder filter with fma contraction (~1e-7, slightly biased).  Harmless on
     // the way to the output;

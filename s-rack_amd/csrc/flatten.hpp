@@ -73,6 +73,10 @@ struct FlatPair {
     std::string description;
 };
 
+// Internal render flag (srack_patch_keep_state): evaluate every module of the plan, as the reference's execute() does, not only those
+// the output can hear — so that a module rewired into the audible graph later has the state it would have had in the reference.
+constexpr uint32_t kFlattenEvalAll = 1u << 16;
+
 // Returns SRACK_OK or an error; on success `out` is complete.
 int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overrides, uint32_t render_flags, FlatPair& out);
 

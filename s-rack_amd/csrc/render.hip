@@ -140,7 +140,7 @@ int ensure_program(PatchHandle& h, uint32_t flags)
         for (size_t s = 0; s < h.prog.ctl.size(); s++)
             for (const auto& t : h.prog.ctl[s].carry) pending_tags.push_back({(int)s, h.prog.ctl[s].n_voices, t});
     }
-    int rc = flatten(h.graph, h.n_voices, h.overrides, flags, h.prog);
+    int rc = flatten(h.graph, h.n_voices, h.overrides, flags | (h.keep_state ? kFlattenEvalAll : 0u), h.prog);
     if (rc != SRACK_OK) return rc;
     h.prog_valid = true;
     h.prog_graph_revision = h.graph.revision;
