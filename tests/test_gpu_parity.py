@@ -1328,3 +1328,34 @@ def test_keep_state_rewiring_matches_the_oracle(S, oracle, flags):
         rb = o.render(T2)
         np.testing.assert_array_equal(bits(a[:, :, v]), bits(ra))
         np.testing.assert_array_equal(bits(b[:, :, v]), bits(rb))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [1, 3])
+def test_keep_state_runs_modules_nobody_hears_yet(S, oracle, flags):
+    """The reference's execute() ticks every module of the workspace, wired to the output or not (plan_execution covers all_modules).
+    With keep_state so does the flattened program: an oscillator patched in later has been running all along."""
+    V, B, T1, T2 = 66, 64, 1024, 1024
+    def build(g):
+        ids = S.build_p1(g, adsr="finite", lfo_val=-3.0)
+        ids["spare"] = g.add_module(S.MOD_OSCILLATOR)       # free-running, wired to nothing
+        g.set_field(ids["spare"], S.OSC_VAL, -1.3)
+        return ids
+    def patch_in(g, ids):
+        g.disconnect(ids["out"], 1)
+        g.connect(ids["spare"], S.OSC_OUT_SAW, ids["out"], 1)
+    p = S.Patch(48000, B, 2)
+    ids = build(p)
+    p.configure_voices(V)
+    p.keep_state(True)
+    p.render_channels(T1, flags)
+    patch_in(p, ids)
+    b = p.render_channels(T2, flags)
+    o = oracle.OraclePatch(48000, B, 2)
+    oi = build(o)
+    o.render(T1)
+    patch_in(o, oi)
+    rb = o.render(T2)
+    for v in (0, V - 1):
+        np.testing.assert_array_equal(bits(b[:, :, v]), bits(rb))
+    assert abs(float(rb[1][0]) + 1.0) > 1e-3        # the saw did not start from phase 0
