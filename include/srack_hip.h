@@ -207,8 +207,8 @@ int srack_patch_get_field(const srack_patch* p, int module, int field, double* v
  * module's state fields (phases, filter states, envelope phases and modes, detector bits, sequencer steps, sampler positions) are
  * read back from the device, per voice, and become the starting state of the re-flattened program; the delay rings of feedback
  * edges and the reverbs' delay lines move device to device into the ring / reverb of the same module; the sample counter runs on.
- * (A ring or reverb whose module changes sides between the per-voice program and the voice-invariant control program in the
- * edit, or whose buffer_size-dependent length changes, restarts empty.)  srack_voices_configure always starts afresh.
+ * (A ring or reverb whose module moves between the per-voice program and the voice-invariant control program in the edit is
+ * broadcast to every voice, respectively taken from voice 0.)  srack_voices_configure always starts afresh.
  * With keep, every module of the plan is evaluated, as the reference's execute() does — by default modules that cannot influence
  * any output are skipped and their state stays as stored — so that a module wired into the audible graph later has run all along.
  * Default: off (an edit restarts the voices, as documented above). */

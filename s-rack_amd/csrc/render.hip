@@ -211,6 +211,14 @@ static int upload_one(const FlatProgram& P, DevProg& d)
     return SRACK_OK;
 }
 
+// rows of `elem`-byte items: dst[row][v] = src[row][0] for every voice (a ring or reverb that was voice-invariant becomes per-voice)
+template <class T>
+__global__ void rows_broadcast(T* dst, const T* src, uint32_t V)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < V) dst[(size_t)blockIdx.y * V + v] = src[blockIdx.y];
+}
+
 // srack_patch_keep_state, second half: feedback rings and reverb lines of the replaced program move device to device into the
 // same ring / the same reverb of the new one (matched by the module and port they belong to; same length, same voice count).
 static int transplant(PatchHandle& h)
@@ -221,10 +229,34 @@ static int transplant(PatchHandle& h)
     auto visit = [&](int stage, const FlatProgram& P) -> int {
         for (const auto& t : P.carry)
             for (const auto& ot : h.old_tags) {
-                if (ot.tag.module != t.module || ot.tag.port != t.port || ot.tag.where != t.where || ot.tag.count != t.count || ot.n_voices != P.n_voices) continue;
+                if (ot.tag.module != t.module || ot.tag.port != t.port || ot.tag.where != t.where || ot.tag.count != t.count) continue;
                 if (ot.stage >= (int)o->ctl.size()) continue;
                 const DevProg &src = prog_of(o, ot.stage), &dst = prog_of(h.dev, stage);
                 const size_t V = P.n_voices;
+                if (ot.n_voices != P.n_voices) {
+                    // the module changed sides between the per-voice program and the voice-invariant control program (V = 1)
+                    const size_t Vo = ot.n_voices, rows = (size_t)t.count;
+                    const size_t df = t.where == 1 ? (size_t)t.first * rows : (size_t)t.first, sf = ot.tag.where == 1 ? (size_t)ot.tag.first * rows : (size_t)ot.tag.first;
+                    if (Vo != 1 && V != 1) continue;
+                    if (t.where == 2) {
+                        if (!src.d_fv || !dst.d_fv) continue;
+                        if (Vo == 1)
+                            hipLaunchKernelGGL(rows_broadcast<double>, dim3((uint32_t)((V + 255) / 256), (uint32_t)rows), dim3(256), 0, 0, dst.d_fv + df * V, src.d_fv + sf, (uint32_t)V);
+                        else  // one voice stands for all: voice 0
+                            HIP_TRY(hipMemcpy2D(dst.d_fv + df, sizeof(double), src.d_fv + sf * Vo, sizeof(double) * Vo, sizeof(double), rows, hipMemcpyDeviceToDevice));
+                    } else {
+                        uint32_t* d4 = t.where == 0 ? dst.d_table : (uint32_t*)dst.d_rings;
+                        const uint32_t* s4 = t.where == 0 ? src.d_table : (const uint32_t*)src.d_rings;
+                        if (!d4 || !s4) continue;
+                        if (Vo == 1)
+                            hipLaunchKernelGGL(rows_broadcast<uint32_t>, dim3((uint32_t)((V + 255) / 256), (uint32_t)rows), dim3(256), 0, 0, d4 + df * V, s4 + sf, (uint32_t)V);
+                        else
+                            HIP_TRY(hipMemcpy2D(d4 + df, 4, s4 + sf * Vo, 4 * Vo, 4, rows, hipMemcpyDeviceToDevice));
+                    }
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipDeviceSynchronize());
+                    break;
+                }
                 if (t.where == 0 && src.d_table && dst.d_table)
                     HIP_TRY(hipMemcpy(dst.d_table + (size_t)t.first * V, src.d_table + (size_t)ot.tag.first * V, sizeof(uint32_t) * (size_t)t.count * V, hipMemcpyDeviceToDevice));
                 if (t.where == 1 && src.d_rings && dst.d_rings)

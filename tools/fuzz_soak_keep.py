@@ -31,8 +31,10 @@ for seed in range(lo, hi):
             osc = next((m for m in range(p.num_modules()) if p.module_type(m) == S.MOD_OSCILLATOR), None)
             if osc is None: break
             parts = []
+            exact_modes = (1, 3, 5, 7, 9, 11)
             for k in (cuts[0], cuts[1] - cuts[0], T - cuts[1]):
-                parts.append(p.render_channels(k, flags))
+                # exact modes: each part in ANOTHER exact mode (fused / interpreter / per-voice / one control unit): a flags change is an edit too
+                parts.append(p.render_channels(k, exact_modes[(seed + len(parts) + flags) % 6] if flags & 1 else flags))
                 kind = (seed + len(parts)) % 3
                 if kind == 0:
                     p.set_field(osc, S.OSC_ANTIALIASING, p.get_field(osc, S.OSC_ANTIALIASING))   # same value: a re-flatten and nothing else
