@@ -12,6 +12,7 @@ for noise in (False, True):
                 p = S.Patch(48000, B, 2)
                 ids = build(p)
                 p.configure_voices(V)
+                if flags & 1: p.keep_state(True)     # (the whole plan is flattened, not only what the output hears)
                 for m, f, fn in overrides:
                     p.set_voice_field(ids[m], f, fn(V))
                 try:
