@@ -23,6 +23,7 @@ for seed in range(lo, hi):
         p = S.Patch(48000, B, 2)
         build(p)
         p.configure_voices(V)
+        if os.environ.get("FUZZ_KEEP"): p.keep_state(True)   # (every planned module evaluated, not only what the output hears)
         for m, f, vals in ov:
             p.set_voice_field(m, f, vals)
         fr = p.render_channels(T, flags)
