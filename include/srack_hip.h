@@ -250,7 +250,9 @@ int srack_patch_delayed_edges(srack_patch* p, int* quads, int cap);
  * load = SynthModuleWorkspaceImpl::deserialize (ui.rs:116-135) against the host's AudioConfig: the module list comes
  * out in REVERSE file order (ui.rs:654-660), V0 variants migrate, saved buffers survive only at the same buffer_size,
  * connections with unknown ids or bad ports are dropped.  Every SynthModuleType variant of the reference loads.
- * save = serialize (ui.rs:98-114): writes at most `cap` bytes to `buf` (may be NULL) and the full size to *n_bytes. */
+ * save = serialize (ui.rs:98-114): writes at most `cap` bytes to `buf` (may be NULL) and the full size to *n_bytes.  The state
+ * members written are the ones stored in the patch; with srack_patch_keep_state, after a render, they are the RUNNING state of
+ * voice 0 (the app saves the rack as it plays; a rack file is one instance). */
 int srack_patch_load_srk(const void* bytes, size_t n_bytes, uint32_t sample_rate, uint32_t buffer_size, uint32_t channels, srack_patch** out);
 int srack_patch_save_srk(const srack_patch* p, void* buf, size_t cap, size_t* n_bytes);
 /* SynthModule::get_id: the UUID string that keys a file's connection list.  Returns its length. */

@@ -207,7 +207,28 @@ int srack_patch_load_srk(const void* bytes, size_t n_bytes, uint32_t sample_rate
 int srack_patch_save_srk(const srack_patch* p, void* buf, size_t cap, size_t* n_bytes)
 {
     CHECK_HANDLE(p);
-    const std::vector<uint8_t> bytes = save_srk(p->h.graph);
+    // The app saves the running rack: every module struct as it is at that moment.  With srack_patch_keep_state (voices running on
+    // across edits) the file therefore carries the CURRENT state — of voice 0, a rack file being one instance — not the stored one.
+    // (Port buffers are written as stored: only the sink of a broken feedback edge ever reads them.)
+    PatchHandle& h = const_cast<srack_patch*>(p)->h;
+    std::vector<uint8_t> bytes;
+    if (h.keep_state && h.prog_valid && h.dev && h.prog_graph_revision == h.graph.revision && h.samples_rendered > 0) {
+        Graph snap = h.graph;
+        std::vector<double> values;
+        for (int m = 0; m < (int)snap.modules.size(); m++) {
+            Module& mod = snap.modules[(size_t)m];
+            bool ran = false;
+            for (int f = 0; f < (int)mod.fields.size(); f++)
+                if (Graph::field_is_state(mod.type, f) && read_device_state(h, m, f, values)) {
+                    mod.fields[(size_t)f] = values[0];
+                    ran = true;
+                }
+            if (ran && mod.type == SRACK_MOD_SAMPLE) mod.fields[SRACK_SAMPLE_WAVE_NEW] = 0.0;  // consumed by the first tick (sample.rs:199-203)
+        }
+        bytes = save_srk(snap);
+    } else {
+        bytes = save_srk(h.graph);
+    }
     if (n_bytes) *n_bytes = bytes.size();
     if (buf && cap) std::memcpy(buf, bytes.data(), bytes.size() < cap ? bytes.size() : cap);
     return SRACK_OK;

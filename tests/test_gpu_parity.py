@@ -1359,3 +1359,31 @@ def test_keep_state_runs_modules_nobody_hears_yet(S, oracle, flags):
     for v in (0, V - 1):
         np.testing.assert_array_equal(bits(b[:, :, v]), bits(rb))
     assert abs(float(rb[1][0]) + 1.0) > 1e-3        # the saw did not start from phase 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [1, 3])
+def test_saving_a_running_rack_under_keep_state(S, flags):
+    """The app saves the rack as it plays (ui.rs:98-114 serialises the live module structs).  With keep_state, save_srk writes the
+    running state of voice 0: a patch loaded from that file continues voice 0's render bit for bit (P1: no port buffer is ever read)."""
+    V, B, T1, T2 = 5, 64, 1408, 1600
+    def make():
+        p = S.Patch(48000, B, 2)
+        ids = S.build_p1(p, adsr="finite", lfo_val=-3.0)
+        p.set_field(ids["osc_a"], S.OSC_VAL, 0.3)
+        p.configure_voices(V)
+        return p
+    whole = make().render_channels(T1 + T2, flags)
+    p = make()
+    p.keep_state(True)
+    p.render_channels(T1, flags)
+    data = p.save_srk()
+    q = S.Patch.load_srk(data, 48000, B, 2)
+    q.configure_voices(1)
+    cont = q.render_channels(T2, flags)
+    np.testing.assert_array_equal(bits(cont[:, :, 0]), bits(whole[:, T1:, 0]))
+    r = make()                                  # without keep_state the file holds the stored (initial) state
+    r.render_channels(T1, flags)
+    fresh = S.Patch.load_srk(r.save_srk(), 48000, B, 2)
+    fresh.configure_voices(1)
+    np.testing.assert_array_equal(bits(fresh.render_channels(T2, flags)[:, :, 0]), bits(whole[:, :T2, 0]))
