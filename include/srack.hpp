@@ -140,6 +140,10 @@ public:
 
     // ---- the batch counterpart of `execute(&plan)` ---------------------------------------------------
     void configure_voices(uint32_t n_voices) { check(srack_voices_configure(p_, n_voices)); }
+    // the reference's sliders and cables change under a running graph: edits between execute_batch calls keep the voices' state
+    void keep_state(bool keep = true) { check(srack_patch_keep_state(p_, keep ? 1 : 0)); }
+    // NoiseModule streams: (seed, module, first_voice + voice); the reference's generator is OS-seeded
+    void set_noise_seed(uint64_t seed, uint64_t first_voice = 0) { check(srack_patch_set_noise_seed(p_, seed, first_voice)); }
     void set_voice_field(const SharedSynthModule& m, int field, const float* values) { check(srack_voices_set_field_f32(p_, m.index(), field, values)); }
     int planes(int* channel_plane = nullptr, int cap = 0) { return check(srack_render_planes(p_, channel_plane, cap)); }
     // n_samples ticks for every voice, continuing from the current state; device pointers, asynchronous on `stream`
