@@ -1,22 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — voice-samples/sec of the batch render on N MI355X (one process per GPU).
 
-Workload (BASELINE.json config 3 per GPU; config 5 = 8 ranks of it):
-    patch P1 (saw VCO -> ladder VCF -> VCA, ADSR gated by an LFO square), 262 144 voices per GPU with
-    per-voice randomised detune / cutoff, 1 s @ 48 kHz per step, f32 frames [T][V] + stereo mix-down.
-A step = one srack_render() of all voices for T samples (frames resident in HBM) + the mix-down
-(+ for N > 1 the RCCL sum of the [2][T] partial mixes to rank 0).  Voices are sharded by global
-voice index, no exchange during the render => weak scaling.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg4_b1024|p3] [--flags F]
+
+Workloads (BASELINE.json `configs`; SURVEY 8(d) spells them out):
+    cfg3 (default; = config 5 at 8 GPUs)  patch P1 saw VCO -> ladder VCF -> VCA, ADSR gated by an LFO square; 262 144 voices per GPU,
+                 per-voice randomised detune / cutoff — the configuration the metric is quoted on
+    cfg2         the same patch, 4 096 IDENTICAL voices (plumbing: everything is voice-invariant, one latency chain)
+    cfg4         patch P2, 2-operator FM with a feedback edge, 65 536 voices, buffer_size 1 (z^-1 held in a register)
+    cfg4_b1024   the same at the app's buffer_size 1024 (the feedback delay is a ring in HBM)
+    p3           the sequencer-driven patch of scope row (f)1, two output planes (diagnostic)
+A step = one srack_render() of all this rank's voices for T samples (frames resident in HBM) + the mix-down (+ for N > 1
+the RCCL sum of the [2][T] partial mixes to rank 0, through the product's own communicator: srack_dist_init /
+srack_dist_reduce_mix).  Voices are sharded by global voice index, no exchange during the render => weak scaling.
+
+N > 1: either a launcher provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run), or —
+when WORLD_SIZE is not set — bench.py starts the N ranks itself (one per device) and relays rank 0's JSON line.
+The control plane (barrier, max over ranks, handing the RCCL unique id around) is torch.distributed/gloo on CPU tensors;
+the data path never touches it.
 
 Prints ONE JSON line (rank 0): metric/value/unit per the driver's contract, plus
-  roofline     — achieved = 4 B x V x T / avg duration of the render kernel (HIP events on the
-                 kernel's own stream, read back through srack_render_kernel_ms), peak 8 TB/s HBM
-  cpu_baseline — the C oracle in the reference's structure (block-major execute, one object graph
-                 per voice, all oscillator ports computed) on the host cores, bounded sample (N = 1 only).
+  roofline     — achieved = algorithmic bytes of a step / step time (4 B x planes x V x T / t_render, per GPU),
+                 peak 8 TB/s HBM; `frac_kernel` is the same for the dominant kernel alone (HIP events on the kernel's own
+                 stream, read back through srack_render_kernel_ms — the figure rocprofv3's per-kernel average reproduces)
+  cpu_baseline — the C oracle in the reference's structure (block-major execute, one object graph per voice, all
+                 oscillator ports computed) on the host cores, bounded sample (N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,48 +41,258 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured streaming ceiling ~6290
 HBM_STREAM_GBS = 6290.0
-BYTES_PER_VOICE_SAMPLE = 4   # one f32 frame per voice per sample
+BYTES_PER_VOICE_SAMPLE = 4   # one f32 frame per voice per sample per distinct output plane
+# Vector f64 issue ceiling: 256 CUs x 4 SIMDs x 16 lanes per clock (half the f32 rate) x 2.4 GHz = 39.3e12 lane-operations/s
+# (the spec's 78.6 TFLOP/s counts an FMA as two).
+F64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
+# f64 VALU instructions per voice-sample in the loop body of render_fm_pair<false, 3> (two oscillators with CV: 2^x series +
+# sine polynomial + phase accumulate each), counted in the gfx950 ISA by tools/isa_count.py; profiles/ holds the listing.
+FM_PAIR_F64_OPS = {"render_fm_pair": None, "render_fm_pair_ring": None}
+
+WORKLOADS = ("cfg3", "cfg2", "cfg4", "cfg4_b1024", "p3")
 
 
-def cpu_baseline(S, voices_per_core=6, n_samples=48000):
-    """The oracle timed on this host: `cores` threads x voices_per_core voices x 1 s of P1 (about 10-30 s of CPU work
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: bench.py --gpus N without an external launcher
+# ---------------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks, cmd, env=None, timeout=None):
+    """Starts `cmd` n_ranks times (RANK = LOCAL_RANK = 0 .. n-1, WORLD_SIZE = n, rendezvous on 127.0.0.1), relays rank 0's
+    stdout to ours and every rank's stderr to ours.  Returns the first non-zero exit code (the other ranks are then stopped), else 0."""
+    base = dict(os.environ if env is None else env)
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
+    procs = []
+    for r in range(n_ranks):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc, out0 = 0, b""
+    deadline = None if timeout is None else time.time() + timeout
+    try:
+        pending = set(range(n_ranks))
+        while pending:
+            for r in sorted(pending):
+                try:
+                    if r == 0:
+                        o, _ = procs[0].communicate(timeout=0.2)
+                        out0 += o or b""
+                    else:
+                        procs[r].wait(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.discard(r)
+                if procs[r].returncode != 0 and rc == 0:
+                    rc = procs[r].returncode
+            if rc != 0 or (deadline is not None and time.time() > deadline):
+                rc = rc or 124
+                break
+    finally:
+        for p in procs:  # exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# control plane: barrier / max over ranks / one broadcast, on CPU tensors (gloo)
+# ---------------------------------------------------------------------------------------------------------------------
+class ControlPlane:
+    def __init__(self, world, rank):
+        self.world, self.rank = world, rank
+        self.dist = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def max(self, x):
+        if not self.dist:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def bcast_bytes(self, payload, n):
+        """rank 0's `payload` (n bytes) on every rank"""
+        if not self.dist:
+            return payload
+        import torch
+        t = torch.zeros(n, dtype=torch.uint8)
+        if self.rank == 0:
+            t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+        self.dist.broadcast(t, src=0)
+        return bytes(t.numpy().tobytes())
+
+    def close(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the product path on one rank
+# ---------------------------------------------------------------------------------------------------------------------
+class HipBackend:
+    """One rank of the render: patch + voices on this rank's GPU, frames / mix buffers in HBM, the product's RCCL communicator."""
+
+    name = "hip"
+
+    def __init__(self, args, world, rank, local_rank, cp):
+        import torch
+        import srack_pkg
+        self.torch = torch
+        self.S = S = srack_pkg.load()
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.args, self.world, self.rank = args, world, rank
+        V, T, C = args.voices, args.samples, 2
+        w = args.workload
+        B = 1 if w == "cfg4" else 1024
+        p = self.p = S.Patch(48000, B, C)
+        first = rank * V  # global voice index => same draw as the 1-GPU run of the same voices
+        if w in ("cfg3", "cfg2"):
+            ids = S.build_p1(p)
+            p.configure_voices(V)
+            if w == "cfg3":
+                det, cut = S.p1_voice_params(V, first_voice=first)
+                p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+                p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+                self.what = ("BASELINE config 3 per GPU (config 5 at 8 GPUs): patch P1 saw VCO->ladder VCF->ADSR->VCA, "
+                             f"{V} voices/GPU with per-voice randomised detune/cutoff")
+            else:
+                self.what = (f"BASELINE config 2: patch P1, {V} IDENTICAL voices (every module is voice-invariant: one wave evaluates the patch "
+                             "once — a latency chain — and the frames are a broadcast)")
+        elif w in ("cfg4", "cfg4_b1024"):
+            ids = S.build_p2(p)
+            p.configure_voices(V)
+            beta, index = S.p2_voice_params(V, first_voice=first)
+            p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, beta)
+            p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
+            self.what = (f"BASELINE config 4: patch P2 2-op FM with a feedback edge, {V} voices with per-voice feedback / index, "
+                         f"buffer_size {B} (" + ("z^-1 feedback in a register" if B == 1 else "the app's block size: the feedback delay is a ring in HBM") + ")")
+        else:
+            ids = S.build_p3(p)
+            p.configure_voices(V)
+            u0, u1 = S.voice_uniform(V, 0, first_voice=first), S.voice_uniform(V, 1, first_voice=first)
+            p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, (u0 * np.float32(2.5) - np.float32(2.0)).astype(np.float32))
+            p.set_voice_field(ids["vcf"], S.VCF_FREQ, (np.float32(0.05) + u1 * np.float32(0.35)).astype(np.float32))
+            self.what = ("patch P3 (diagnostic): clock -> grid + pattern sequencers -> per-voice transposed saw VCO -> VCF swept by an "
+                         f"envelope -> VCA, raw gate on channel 2, {V} voices/GPU with per-voice transpose/cutoff")
+        self.buffer_size = B
+        self.n_planes, _ = p.planes()
+        self.frames = None if args.no_frames else torch.empty((self.n_planes, T, V), dtype=torch.float32, device=self.dev)
+        self.mix = torch.empty((C, T), dtype=torch.float32, device=self.dev)
+        self.stream = torch.cuda.current_stream(self.dev)
+        p.reserve(T, want_mix=not args.no_mix, flags=args.flags)  # set-up, like the allocations above: flatten, upload, scratch buffers
+        self.comm = None
+        self.ranks_seen = 1
+        if world > 1 or args.force_dist:
+            uid = cp.bcast_bytes(S.MixComm.unique_id() if rank == 0 else None, S.DIST_ID_BYTES)
+            self.comm = S.MixComm(uid, world, rank)
+            self.ranks_seen = self.comm.count()
+
+    def step(self):
+        a = self.args
+        self.p.render_raw(a.samples, self.frames.data_ptr() if self.frames is not None else None, None if a.no_mix else self.mix.data_ptr(),
+                          a.flags, self.stream.cuda_stream)
+        if self.comm is not None and not a.no_mix:
+            self.comm.reduce_mix(self.mix.data_ptr(), self.mix.numel(), 0, self.stream.cuda_stream)  # RCCL over xGMI: [2][T] f32 partial mixes
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def arm_kernel_timer(self):
+        self.p.kernel_ms(reset=True)
+
+    def kernel_ms(self):
+        return self.p.kernel_ms(reset=True)
+
+    def info(self):
+        return self.p.info()
+
+    def close(self):
+        if self.comm is not None:
+            self.sync()
+            self.comm.destroy()
+
+
+def cpu_baseline(S, workload, n_samples=48000):
+    """The oracle timed on this host: `cores` threads x a few voices x 1 s of the workload's patch (about 10-30 s of CPU work
     in total across cores; wall time a few seconds)."""
     from oracle import oracle as O
     O.build()
     cores = os.cpu_count() or 1
+    fm = workload in ("cfg4", "cfg4_b1024")
+    voices_per_core = 2 if fm else 6
     V = cores * voices_per_core
-    g = O.OraclePatch(48000, 1024, 2)
-    ids = S.build_p1(g)
-    det, cut = S.p1_voice_params(V)
-    ov = [(ids["osc_a"], S.OSC_VAL, det), (ids["vcf"], S.VCF_FREQ, cut)]
-    g.render_batch(min(V, cores), 4800, ov[:0], frames=False, mix=True, threads=cores)  # warm the threads
+    B = 1 if workload == "cfg4" else 1024
+    g = O.OraclePatch(48000, B, 2)
+    if fm:
+        ids = S.build_p2(g)
+        beta, index = S.p2_voice_params(V)
+        ov = [(ids["mul_fb"], S.MATH_CONSTANT, beta), (ids["mul_idx"], S.MATH_CONSTANT, index)]
+        patch = "P2 (cfg4 draw)"
+    else:
+        ids = S.build_p1(g)
+        det, cut = S.p1_voice_params(V)
+        ov = [(ids["osc_a"], S.OSC_VAL, det), (ids["vcf"], S.VCF_FREQ, cut)] if workload != "cfg2" else []
+        patch = "P1 (cfg3 draw)" if workload != "cfg2" else "P1 (identical voices, each evaluated: the reference has no notion of sharing)"
+    g.render_batch(min(V, cores), 4800, [], frames=False, mix=True, threads=cores)  # warm the threads
     best = None
     for _ in range(3):
         t = time.perf_counter()
         g.render_batch(V, n_samples, ov, frames=False, mix=True, threads=cores)
         dt = time.perf_counter() - t
         best = dt if best is None else min(best, dt)
-    t = time.perf_counter()
-    g.render_batch(voices_per_core, n_samples, [(m, f, v[:voices_per_core]) for m, f, v in ov], frames=False, mix=True, threads=1)
-    dt1 = time.perf_counter() - t
+    single = None
+    for _ in range(3):
+        t = time.perf_counter()
+        g.render_batch(voices_per_core, n_samples, [(m, f, v[:voices_per_core]) for m, f, v in ov], frames=False, mix=True, threads=1)
+        dt1 = time.perf_counter() - t
+        single = dt1 if single is None else min(single, dt1)
     return {
         "value": V * n_samples / best, "unit": "voice-samples/s", "cores": cores, "kind": "port",
-        "sample": f"{V} voices x {n_samples} samples of patch P1 (cfg3 draw), buffer_size 1024, {cores} threads, best of 3",
-        "single_thread_value": voices_per_core * n_samples / dt1,
+        "sample": f"{V} voices x {n_samples} samples of patch {patch}, buffer_size {B}, {cores} threads, best of 3",
+        "single_thread_value": voices_per_core * n_samples / single,
+        "single_thread_sample": f"{voices_per_core} voices x {n_samples} samples, 1 thread, best of 3",
         "note": "C restatement of the reference tick (oracle/srack_oracle.c); the Rust reference cannot be built here. "
                 "Omits the reference's per-block RwLock/Arc/Vec overhead, so it is a slightly optimistic stand-in.",
     }
 
 
-def measured_traffic(kernel_name, V, T):
-    """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC summary (profiles/*_summary.json,
-    written by profiles/summarize.py from separate WRITE_SIZE / FETCH_SIZE passes of this very command), or None.
-    Only valid for the default workload the profile was taken on."""
+def profiled_traffic(kernel_name, workload, V, T):
+    """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC summary (profiles/*_summary.json, written
+    by profiles/summarize.py from separate WRITE_SIZE / FETCH_SIZE passes of this very command), or None.  NOT measured in
+    this run — a profiler cannot run inside the timed region — and only valid for the default size of the workload."""
     import glob
-    if (V, T) != (262144, 48000):
+    if (V, T) != (default_voices(workload), 48000):
         return None
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+    suffix = {"cfg3": ("_summary.json",), "p3": ("_p3_summary.json",), "cfg4": ("_cfg4_summary.json",), "cfg4_b1024": ("_cfg4_b1024_summary.json",),
+              "cfg2": ("_cfg2_summary.json",)}[workload]
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_summary.json"))):
+        base = os.path.basename(path)
+        if workload == "cfg3" and base.count("_") != 1:
+            continue
+        if workload != "cfg3" and not base.endswith(suffix):
+            continue
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
@@ -76,144 +300,159 @@ def measured_traffic(kernel_name, V, T):
         for name, v in d.get("derived", {}).items():
             if kernel_name and kernel_name in name and "hbm_traffic_bytes" in v:
                 best = {"bytes_per_launch": v["hbm_traffic_bytes"], "write": v.get("hbm_write_bytes"),
-                        "read_corrected": v.get("hbm_read_bytes_gfx950_corrected"), "source": os.path.basename(path)}
+                        "read_corrected": v.get("hbm_read_bytes_gfx950_corrected"), "source": "profiles/" + base}
     return best
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--voices", type=int, default=262144, help="voices per GPU")
-    ap.add_argument("--samples", type=int, default=48000, help="samples per step (1 s @ 48 kHz)")
-    ap.add_argument("--flags", type=int, default=0, help="SRACK_RENDER_* flags (1 exact osc, 2 no fusion, 4 no uniform hoist)")
-    ap.add_argument("--no-frames", action="store_true", help="mix only (diagnostic; not the metric)")
-    ap.add_argument("--no-mix", action="store_true", help="frames only (diagnostic; not the metric)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--workload", choices=["p1", "p3"], default="p1",
-                    help="p1 = BASELINE config 3 (the metric); p3 = the sequencer-driven patch of scope row (f)1, two output planes (diagnostic)")
-    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the mix reduce even with one rank (smoke-tests the N > 1 code path on a 1-GPU box)")
-    args = ap.parse_args()
+def default_voices(workload):
+    return {"cfg3": 262144, "p3": 262144, "cfg2": 4096, "cfg4": 65536, "cfg4_b1024": 65536}[workload]
 
-    import torch
-    import torch.distributed as dist
-    import srack_pkg
-    S = srack_pkg.load()
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the timing protocol (every rank)
+# ---------------------------------------------------------------------------------------------------------------------
+def run_rank(args, backend_cls=HipBackend):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-
-    V, T, C = args.voices, args.samples, 2
-    p = S.Patch(48000, 1024, C)
-    if args.workload == "p1":
-        ids = S.build_p1(p)
-        p.configure_voices(V)
-        det, cut = S.p1_voice_params(V, first_voice=rank * V)  # global voice index => same draw as the 1-GPU run
-        p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
-        p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
-        what = "BASELINE config 3 per GPU (config 5 at 8 GPUs): patch P1 saw VCO->ladder VCF->ADSR->VCA"
-    else:
-        ids = S.build_p3(p)
-        p.configure_voices(V)
-        u0, u1 = S.voice_uniform(V, 0, first_voice=rank * V), S.voice_uniform(V, 1, first_voice=rank * V)
-        p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, (u0 * np.float32(2.5) - np.float32(2.0)).astype(np.float32))
-        p.set_voice_field(ids["vcf"], S.VCF_FREQ, (np.float32(0.05) + u1 * np.float32(0.35)).astype(np.float32))
-        what = "patch P3 (diagnostic): clock -> grid + pattern sequencers -> per-voice transposed saw VCO -> VCF swept by an envelope -> VCA, raw gate on channel 2"
-    n_planes, _ = p.planes()
-
-    frames = None if args.no_frames else torch.empty((n_planes, T, V), dtype=torch.float32, device=dev)
-    mix = torch.empty((C, T), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev)
-
-    p.reserve(T, want_mix=not args.no_mix, flags=args.flags)  # set-up, like the allocations above: flatten, upload, scratch buffers
-
-    def step():
-        p.render_raw(T, frames.data_ptr() if frames is not None else None, None if args.no_mix else mix.data_ptr(), args.flags, stream.cuda_stream)
-        if use_dist and not args.no_mix:
-            dist.reduce(mix, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: [2][T] f32 partial mixes
+    cp = ControlPlane(world, rank)
+    be = backend_cls(args, world, rank, local_rank, cp)
 
     def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        be.sync()
+        cp.barrier()
+        be.sync()
 
     for _ in range(args.warmup):
-        step()
+        be.step()
     fence()
-    p.kernel_ms(reset=True)
+    be.arm_kernel_timer()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        be.step()
     host_enqueue = time.perf_counter() - t0  # host time to enqueue K steps (diagnostic: is the host the bottleneck?)
     fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms, n_launch = p.kernel_ms(reset=True)
+    elapsed = cp.max(time.perf_counter() - t0)
+    kernel_ms, n_launch = be.kernel_ms()
 
+    out = None
     if rank == 0:
+        V, T = args.voices, args.samples
+        n_planes = be.n_planes
         voice_samples = float(world) * V * T * args.steps
+        step_s = elapsed / args.steps
         # a step may be several launches of the render kernel (chunks that pipeline against the control program):
-        # roofline figures are per launch, like rocprofv3's per-kernel average
+        # the kernel-only figures are per launch, like rocprofv3's per-kernel average
         launches_per_step = max(1, n_launch // max(1, args.steps))
-        bytes_per_launch = BYTES_PER_VOICE_SAMPLE * n_planes * V * T / launches_per_step  # one f32 per voice-sample per distinct output plane
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        bytes_per_step = BYTES_PER_VOICE_SAMPLE * n_planes * V * T        # per GPU: one f32 per voice-sample per distinct output plane
+        bytes_per_launch = bytes_per_step / launches_per_step
+        achieved = bytes_per_step / step_s / 1e9
+        achieved_kernel = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        info = be.info()
+        kname = info.split("kernel=")[-1] if "kernel=" in info else ""
         out = {
             "metric": "voice-samples/sec @48 kHz offline render",
             "value": voice_samples / elapsed,
             "unit": "voice-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": step_s * 1e3,
             "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "ranks_seen": getattr(be, "ranks_seen", world),
             "config": {
-                "workload": what + f", {V} voices/GPU with per-voice randomised "
-                            + ("detune/cutoff" if args.workload == "p1" else "transpose/cutoff") + f", {T} samples/step @48 kHz, "
-                            f"f32 frames [{n_planes}][T][V] in HBM + stereo mix-down" + (" + RCCL reduce of the [2][T] mix" if use_dist else ""),
-                "voices_per_gpu": V, "samples_per_step": T, "buffer_size": 1024, "render_flags": args.flags,
-                "arithmetic": "f32 wires and modules; oscillator phase accumulator 64-bit: f64 as the reference, 2^-64 fixed point in the default-mode fused saw kernel (DESIGN.md section 3)",
-                "frames_written": frames is not None, "mix_down": not args.no_mix, "program": p.info(),
+                "workload": be.what + f", {T} samples/step @48 kHz, f32 frames [{n_planes}][T][V] in HBM + stereo mix-down"
+                            + (" + RCCL reduce of the [2][T] mix (srack_dist_reduce_mix)" if getattr(be, "comm", None) is not None else ""),
+                "name": args.workload, "voices_per_gpu": V, "samples_per_step": T, "buffer_size": getattr(be, "buffer_size", 1024),
+                "render_flags": args.flags, "backend": be.name,
+                "arithmetic": "f32 wires and modules; oscillator phase accumulator 64-bit: f64 as the reference, 2^-64 fixed point in the "
+                              "default-mode fused saw kernel (DESIGN.md section 3)",
+                "frames_written": not args.no_frames, "mix_down": not args.no_mix, "program": info,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "traffic_detail": None,
+                "definition": "algorithmic bytes of a step (4 B x planes x voices x samples, per GPU) / step time (max over ranks)",
                 "frac_of_measured_stream_ceiling": achieved / HBM_STREAM_GBS,
-                "kernel_ms": kernel_ms, "kernel_launches": n_launch, "launches_per_step": launches_per_step,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "achieved_kernel": achieved_kernel, "frac_kernel": achieved_kernel / HBM_PEAK_GBS,
+                "kernel": kname, "kernel_ms": kernel_ms, "kernel_launches": n_launch, "launches_per_step": launches_per_step,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_step": bytes_per_step,
                 "voice_samples_per_s_kernel": V * T / launches_per_step / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
+                "traffic": None,
             },
         }
-        kname = p.info().split("kernel=")[-1] if "kernel=" in p.info() else ""
-        tr = measured_traffic(kname, V, T) if args.workload == "p1" and args.flags == 0 and frames is not None and not args.no_mix else None
+        if args.workload in ("cfg4", "cfg4_b1024") and FM_PAIR_F64_OPS.get(kname):
+            ops = FM_PAIR_F64_OPS[kname]
+            lane_ops = ops * V * T / step_s
+            out["roofline"].update({
+                "bound": "valu_f64", "achieved": lane_ops / 1e12, "peak": F64_LANE_OPS_PEAK / 1e12, "unit": "T f64 lane-ops/s",
+                "frac": lane_ops / F64_LANE_OPS_PEAK, "f64_ops_per_voice_sample": ops,
+                "definition": "f64 VALU instructions per voice-sample of the kernel's loop body (ISA count, tools/isa_count.py) x voice-samples/s, "
+                              "against 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz",
+                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "achieved_kernel": achieved_kernel, "frac_kernel": achieved_kernel / HBM_PEAK_GBS},
+            })
+        if args.workload == "cfg2":
+            out["roofline"]["note"] = ("identical voices: the whole patch is one voice-invariant latency chain evaluated by ONE wave, the frames are "
+                                       "a broadcast of its track — a few percent of the HBM roofline by construction (plumbing configuration)")
+        tr = profiled_traffic(kname, args.workload, V, T) if be.name == "hip" and args.flags == 0 and not args.no_frames and not args.no_mix else None
         if tr:
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
-            out["roofline"]["traffic_detail"] = tr
-        if world == 1 and not args.no_cpu and args.workload == "p1":
-            out["cpu_baseline"] = cpu_baseline(S)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)  # RCCL prints its banner through C stdio: push it out before the one JSON line
+            out["roofline"]["traffic_detail"] = dict(tr, measured_in_this_run=False,
+                                                     note="rocprofv3 PMC passes of this command (profiles/run_profile.sh); a profiler cannot run inside the timed region")
+        if world == 1 and not args.no_cpu and args.workload != "p3" and be.name == "hip":
+            out["cpu_baseline"] = cpu_baseline(be.S, args.workload)
+    be.close()
+    cp.close()
+    return out
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=WORKLOADS + ("p1",), default="cfg3", help="cfg3 = the metric (p1 is its old name); see the module docstring")
+    ap.add_argument("--voices", type=int, default=0, help="voices per GPU (default: the workload's BASELINE size)")
+    ap.add_argument("--samples", type=int, default=48000, help="samples per step (1 s @ 48 kHz)")
+    ap.add_argument("--flags", type=int, default=0, help="SRACK_RENDER_* flags (1 exact osc, 2 no fusion, 4 no uniform hoist, 8 no control stages)")
+    ap.add_argument("--no-frames", action="store_true", help="mix only (diagnostic; not the metric)")
+    ap.add_argument("--no-mix", action="store_true", help="frames only (diagnostic; not the metric)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the RCCL communicator and run the mix reduce even with one rank (exercises the N > 1 code path on a 1-GPU box)")
+    args = ap.parse_args(argv)
+    if args.workload == "p1":
+        args.workload = "cfg3"
+    if args.voices <= 0:
+        args.voices = default_voices(args.workload)
+    return args
+
+
+def main(argv=None, backend_cls=HipBackend, self_cmd=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (one rank per device)
+        cmd = self_cmd or [sys.executable, os.path.abspath(__file__)]
+        return launch_ranks(args.gpus, cmd + argv)
+    # Libraries chat on stdout through C stdio (gloo: "[Gloo] Rank 0 is connected to ...", RCCL: its version banner).  stdout is for
+    # the ONE JSON line: while the ranks work, file descriptor 1 points at stderr.
+    import ctypes
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        out = run_rank(args, backend_cls)
+    finally:
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+    if out is not None:
         print(json.dumps(out), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SRACK_ABI_VERSION 1
+#define SRACK_ABI_VERSION 2 /* 2: srack_dist_unique_id / init / comm_count / destroy; save_srk rejects a short buffer */
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -323,9 +323,23 @@ int srack_device_to_host(void* h_dst, const void* d_src, size_t bytes, void* str
 int srack_device_sync(void* stream);
 
 /* ---- multi-GPU mix-down --------------------------------------------------------------------- */
-/* Voices shard across ranks with no exchange during the render; the only collective is the sum of
- * the per-rank partial mixes.  `comm` is an RCCL `ncclComm_t` the host created (one rank per GPU);
- * the call is ncclReduce(sum, f32, root) on `stream`.  In-place on `d_mix`. */
+/* Voices shard across ranks (one process per GPU) with no exchange during the render; the only collective is the sum of
+ * the per-rank partial mixes over RCCL / xGMI.  The reference has no counterpart: it is single-threaded
+ * (src/main.rs:59-63); SURVEY 8(b) item 8 / 8(e) define this surface.
+ *
+ *   rank 0:      srack_dist_unique_id(id)                  ncclGetUniqueId; the host carries the SRACK_DIST_ID_BYTES to
+ *                                                          every rank over any side channel it has
+ *   every rank:  srack_device_set(local_rank); srack_dist_init(id, n_ranks, rank, &comm)     ncclCommInitRank
+ *                srack_render(...); srack_dist_reduce_mix(comm, d_mix, channels * n_samples, 0, stream)
+ *                srack_dist_destroy(comm)
+ *
+ * `comm` is a plain RCCL `ncclComm_t`: a host that already owns one may pass it to srack_dist_reduce_mix directly.
+ * srack_dist_reduce_mix is ncclReduce(sum, f32, root) on `stream`, in place on `d_mix`. */
+#define SRACK_DIST_ID_BYTES 128
+int srack_dist_unique_id(void* id_out /* SRACK_DIST_ID_BYTES */);
+int srack_dist_init(const void* id /* SRACK_DIST_ID_BYTES */, int n_ranks, int rank, void** comm_out);
+int srack_dist_comm_count(void* comm, int* n_ranks); /* ncclCommCount: the ranks the communicator really spans */
+int srack_dist_destroy(void* comm);
 int srack_dist_reduce_mix(void* comm, float* d_mix, size_t count, int root, void* stream);
 
 #ifdef __cplusplus

@@ -28,7 +28,8 @@ ABI_SYMBOLS = [
     "srack_patch_plan", "srack_patch_plan_list", "srack_patch_removed_edges", "srack_patch_delayed_edges",
     "srack_voices_configure", "srack_voices_set_field_f32", "srack_voices_set_field_f64", "srack_render_planes", "srack_render", "srack_render_reserve",
     "srack_render_info", "srack_render_kernel_ms", "srack_voices_get_field", "srack_device_count", "srack_device_set",
-    "srack_device_alloc", "srack_device_free", "srack_device_to_host", "srack_device_sync", "srack_dist_reduce_mix",
+    "srack_device_alloc", "srack_device_free", "srack_device_to_host", "srack_device_sync",
+    "srack_dist_unique_id", "srack_dist_init", "srack_dist_comm_count", "srack_dist_destroy", "srack_dist_reduce_mix",
 ]
 
 
@@ -90,6 +91,10 @@ def _load():
     L.srack_device_free.argtypes = [vp]
     L.srack_device_to_host.argtypes = [vp, vp, sz, vp]
     L.srack_device_sync.argtypes = [vp]
+    L.srack_dist_unique_id.argtypes = [C.c_char_p]
+    L.srack_dist_init.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
+    L.srack_dist_comm_count.argtypes = [vp, ip]
+    L.srack_dist_destroy.argtypes = [vp]
     L.srack_dist_reduce_mix.argtypes = [vp, vp, sz, i32, vp]
     return L
 
@@ -107,6 +112,43 @@ def device_count():
     n = C.c_int(0)
     lib.srack_device_count(C.byref(n))
     return n.value
+
+
+DIST_ID_BYTES = 128
+
+
+class MixComm:
+    """The path's one collective behind the C ABI: an RCCL communicator over the ranks that share a render (one process per
+    GPU), used for nothing but the sum of the per-rank partial mixes (srack_dist_*).
+
+    Rank 0 calls `MixComm.unique_id()` and hands the 128 bytes to every rank over whatever side channel the host has;
+    every rank then constructs `MixComm(id, n_ranks, rank)` with its device already selected (srack_device_set)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(DIST_ID_BYTES)
+        _check(lib.srack_dist_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, unique_id, n_ranks, rank):
+        assert len(unique_id) == DIST_ID_BYTES
+        self.comm = C.c_void_p()
+        _check(lib.srack_dist_init(bytes(unique_id), n_ranks, rank, C.byref(self.comm)))
+        self.n_ranks, self.rank = n_ranks, rank
+
+    def count(self):
+        n = C.c_int()
+        _check(lib.srack_dist_comm_count(self.comm, C.byref(n)))
+        return n.value
+
+    def reduce_mix(self, d_mix, count, root=0, stream=None):
+        """ncclReduce(sum, f32) of `count` floats at device pointer `d_mix`, in place, asynchronous on `stream`."""
+        _check(lib.srack_dist_reduce_mix(self.comm, d_mix, count, root, stream))
+
+    def destroy(self):
+        if self.comm:
+            _check(lib.srack_dist_destroy(self.comm))
+            self.comm = C.c_void_p()
 
 
 class Patch:

@@ -37,8 +37,36 @@ struct srack_patch {
         }                                                                   \
     } while (0)
 
+// No C++ exception may cross the C boundary (a Rust or ctypes host cannot unwind it): allocation failures become
+// SRACK_ERR_NOMEM, anything else SRACK_ERR_INVALID with the text in srack_last_error().
+template <class F>
+static int guarded(F&& f) noexcept
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        try { set_error("out of memory"); } catch (...) {}
+        return SRACK_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        try { set_error(std::string("internal error: ") + e.what()); } catch (...) {}
+        return SRACK_ERR_INVALID;
+    } catch (...) {
+        try { set_error("internal error"); } catch (...) {}
+        return SRACK_ERR_INVALID;
+    }
+}
+
+// `(int)x` of a NaN or of a value outside int's range is undefined: flags and enum-like fields are clamped first
+static double as_flag(double x)
+{
+    if (!(x == x)) return 0.0;
+    if (x > 2147483647.0) return 2147483647.0;
+    if (x < -2147483648.0) return -2147483648.0;
+    return (double)(int)x;
+}
+
 template <typename T>
-static int set_voice_field(srack_patch* p, int module, int field, const T* values)
+static int set_voice_field_impl(srack_patch* p, int module, int field, const T* values)
 {
     CHECK_HANDLE(p);
     PatchHandle& h = p->h;
@@ -59,13 +87,20 @@ static int set_voice_field(srack_patch* p, int module, int field, const T* value
     const bool f64 = Graph::field_is_f64(type, field), flag = Graph::field_is_flag(type, field);
     for (uint32_t v = 0; v < h.n_voices; v++) {
         double x = (double)values[v];
-        o.values[v] = f64 ? x : (flag ? (double)(int)x : (double)(float)x);
+        o.values[v] = f64 ? x : (flag ? as_flag(x) : (double)(float)x);
     }
     for (auto it = h.overrides.begin(); it != h.overrides.end();)
         it = (it->module == module && it->field == field) ? h.overrides.erase(it) : it + 1;
     h.overrides.push_back(std::move(o));
     h.voices_revision++;
+    if (Graph::field_is_state(type, field)) h.state_writes.insert({module, field});  // keep_state: the host's value wins over the carried one
     return SRACK_OK;
+}
+
+template <typename T>
+static int set_voice_field(srack_patch* p, int module, int field, const T* values)
+{
+    return guarded([&]() -> int { return set_voice_field_impl(p, module, field, values); });
 }
 
 extern "C" {
@@ -75,46 +110,54 @@ const char* srack_last_error(void) { return last_error(); }
 
 int srack_patch_create(uint32_t sample_rate, uint32_t buffer_size, uint32_t channels, srack_patch** out)
 {
-    if (!out) {
-        set_error("srack_patch_create: out is null");
-        return SRACK_ERR_INVALID;
-    }
-    *out = nullptr;
-    if (sample_rate == 0 || sample_rate > 65535u) {  // AudioConfig.sample_rate is a u16 (synth.rs:22)
-        set_error("srack_patch_create: sample_rate must fit the reference's u16 (1..65535)");
-        return SRACK_ERR_INVALID;
-    }
-    if (buffer_size == 0) {
-        set_error("srack_patch_create: buffer_size must be >= 1");
-        return SRACK_ERR_INVALID;
-    }
-    if (channels == 0 || channels > 8) {
-        set_error("srack_patch_create: channels must be 1..8");
-        return SRACK_ERR_INVALID;
-    }
-    auto* p = new (std::nothrow) srack_patch();
-    if (!p) return SRACK_ERR_NOMEM;
-    p->h.graph.cfg = AudioConfig{sample_rate, buffer_size, channels};
-    *out = p;
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        if (!out) {
+            set_error("srack_patch_create: out is null");
+            return SRACK_ERR_INVALID;
+        }
+        *out = nullptr;
+        if (sample_rate == 0 || sample_rate > 65535u) {  // AudioConfig.sample_rate is a u16 (synth.rs:22)
+            set_error("srack_patch_create: sample_rate must fit the reference's u16 (1..65535)");
+            return SRACK_ERR_INVALID;
+        }
+        if (buffer_size == 0) {
+            set_error("srack_patch_create: buffer_size must be >= 1");
+            return SRACK_ERR_INVALID;
+        }
+        if (channels == 0 || channels > 8) {
+            set_error("srack_patch_create: channels must be 1..8");
+            return SRACK_ERR_INVALID;
+        }
+        auto* p = new (std::nothrow) srack_patch();
+        if (!p) return SRACK_ERR_NOMEM;
+        p->h.graph.cfg = AudioConfig{sample_rate, buffer_size, channels};
+        *out = p;
+        return SRACK_OK;
+    });
 }
 
 int srack_patch_destroy(srack_patch* p)
 {
-    delete p;
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        delete p;
+        return SRACK_OK;
+    });
 }
 
 int srack_patch_add_module(srack_patch* p, int module_type)
 {
-    CHECK_HANDLE(p);
-    return p->h.graph.add_module(module_type);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        return p->h.graph.add_module(module_type);
+    });
 }
 
 int srack_patch_num_modules(const srack_patch* p)
 {
-    CHECK_HANDLE(p);
-    return (int)p->h.graph.modules.size();
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        return (int)p->h.graph.modules.size();
+    });
 }
 
 static const Module* get_module(const srack_patch* p, int module)
@@ -128,262 +171,332 @@ static const Module* get_module(const srack_patch* p, int module)
 
 int srack_patch_module_type(const srack_patch* p, int module)
 {
-    const Module* m = get_module(p, module);
-    return m ? m->type : SRACK_ERR_INVALID;
+    return guarded([&]() -> int {
+        const Module* m = get_module(p, module);
+        return m ? m->type : SRACK_ERR_INVALID;
+    });
 }
 
 int srack_module_num_inputs(const srack_patch* p, int module)
 {
-    const Module* m = get_module(p, module);
-    return m ? m->n_in : SRACK_ERR_INVALID;
+    return guarded([&]() -> int {
+        const Module* m = get_module(p, module);
+        return m ? m->n_in : SRACK_ERR_INVALID;
+    });
 }
 
 int srack_module_num_outputs(const srack_patch* p, int module)
 {
-    const Module* m = get_module(p, module);
-    return m ? m->n_out : SRACK_ERR_INVALID;
+    return guarded([&]() -> int {
+        const Module* m = get_module(p, module);
+        return m ? m->n_out : SRACK_ERR_INVALID;
+    });
 }
 
 int srack_patch_set_field(srack_patch* p, int module, int field, double value)
 {
-    CHECK_HANDLE(p);
-    return p->h.graph.set_field(module, field, value);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        const int rc = p->h.graph.set_field(module, field, value);
+        if (rc == SRACK_OK && Graph::field_is_state(p->h.graph.modules[(size_t)module].type, field)) {
+            // keep_state: the host's value wins over the running one — also over the per-voice values an earlier carry left behind
+            PatchHandle& h = p->h;
+            h.state_writes.insert({module, field});
+            if (h.keep_state)
+                for (auto it = h.overrides.begin(); it != h.overrides.end();) it = (it->module == module && it->field == field) ? h.overrides.erase(it) : it + 1;
+        }
+        return rc;
+    });
 }
 
 int srack_patch_get_field(const srack_patch* p, int module, int field, double* value)
 {
-    CHECK_HANDLE(p);
-    return p->h.graph.get_field(module, field, value);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        return p->h.graph.get_field(module, field, value);
+    });
 }
 
 int srack_patch_set_step(srack_patch* p, int module, int channel, int step, int state, int value)
 {
-    CHECK_HANDLE(p);
-    return p->h.graph.set_step(module, channel, step, state, value);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        return p->h.graph.set_step(module, channel, step, state, value);
+    });
 }
 
 int srack_patch_get_step(const srack_patch* p, int module, int channel, int step, int* state, int* value)
 {
-    CHECK_HANDLE(p);
-    return p->h.graph.get_step(module, channel, step, state, value);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        return p->h.graph.get_step(module, channel, step, state, value);
+    });
 }
 
 int srack_patch_set_wave(srack_patch* p, int module, const float* samples, uint32_t n_samples, float sample_rate)
 {
-    CHECK_HANDLE(p);
-    return p->h.graph.set_wave(module, samples, n_samples, sample_rate);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        return p->h.graph.set_wave(module, samples, n_samples, sample_rate);
+    });
 }
 
 int srack_patch_get_wave(const srack_patch* p, int module, float* samples, uint32_t cap, float* sample_rate)
 {
-    CHECK_HANDLE(p);
-    const Module* m = get_module(p, module);
-    if (!m || m->type != SRACK_MOD_SAMPLE) {
-        set_error("get_wave: not a SampleModule");
-        return SRACK_ERR_INVALID;
-    }
-    if (samples)
-        for (size_t i = 0; i < m->wave.size() && i < (size_t)cap; i++) samples[i] = m->wave[i];
-    if (sample_rate) *sample_rate = (float)m->fields[SRACK_SAMPLE_WAVE_SAMPLE_RATE];
-    return (int)m->wave.size();
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        const Module* m = get_module(p, module);
+        if (!m || m->type != SRACK_MOD_SAMPLE) {
+            set_error("get_wave: not a SampleModule");
+            return SRACK_ERR_INVALID;
+        }
+        if (samples)
+            for (size_t i = 0; i < m->wave.size() && i < (size_t)cap; i++) samples[i] = m->wave[i];
+        if (sample_rate) *sample_rate = (float)m->fields[SRACK_SAMPLE_WAVE_SAMPLE_RATE];
+        return (int)m->wave.size();
+    });
 }
 
 int srack_patch_load_srk(const void* bytes, size_t n_bytes, uint32_t sample_rate, uint32_t buffer_size, uint32_t channels, srack_patch** out)
 {
-    if (!bytes && n_bytes) {
-        set_error("srack_patch_load_srk: bytes is null");
-        return SRACK_ERR_INVALID;
-    }
-    int rc = srack_patch_create(sample_rate, buffer_size, channels, out);
-    if (rc != SRACK_OK) return rc;
-    rc = load_srk((const uint8_t*)bytes, n_bytes, (*out)->h.graph);
-    if (rc != SRACK_OK) {
-        delete *out;
-        *out = nullptr;
-    }
-    return rc;
+    return guarded([&]() -> int {
+        if (!bytes && n_bytes) {
+            set_error("srack_patch_load_srk: bytes is null");
+            return SRACK_ERR_INVALID;
+        }
+        int rc = srack_patch_create(sample_rate, buffer_size, channels, out);
+        if (rc != SRACK_OK) return rc;
+        rc = load_srk((const uint8_t*)bytes, n_bytes, (*out)->h.graph);
+        if (rc != SRACK_OK) {
+            delete *out;
+            *out = nullptr;
+        }
+        return rc;
+    });
 }
 
 int srack_patch_save_srk(const srack_patch* p, void* buf, size_t cap, size_t* n_bytes)
 {
-    CHECK_HANDLE(p);
-    // The app saves the running rack: every module struct as it is at that moment.  With srack_patch_keep_state (voices running on
-    // across edits) the file therefore carries the CURRENT state — of voice 0, a rack file being one instance — not the stored one.
-    // (Port buffers are written as stored: only the sink of a broken feedback edge ever reads them.)
-    PatchHandle& h = const_cast<srack_patch*>(p)->h;
-    std::vector<uint8_t> bytes;
-    if (h.keep_state && h.prog_valid && h.dev && h.prog_graph_revision == h.graph.revision && h.samples_rendered > 0) {
-        Graph snap = h.graph;
-        std::vector<double> values;
-        for (int m = 0; m < (int)snap.modules.size(); m++) {
-            Module& mod = snap.modules[(size_t)m];
-            bool ran = false;
-            for (int f = 0; f < (int)mod.fields.size(); f++)
-                if (Graph::field_is_state(mod.type, f) && read_device_state(h, m, f, values)) {
-                    mod.fields[(size_t)f] = values[0];
-                    ran = true;
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        // The app saves the running rack: every module struct as it is at that moment.  With srack_patch_keep_state (voices running on
+        // across edits) the file therefore carries the CURRENT state — of voice 0, a rack file being one instance — not the stored one.
+        // (Port buffers are written as stored: only the sink of a broken feedback edge ever reads them.)
+        PatchHandle& h = const_cast<srack_patch*>(p)->h;
+        std::vector<uint8_t> bytes;
+        if (h.keep_state && h.samples_rendered > 0) {
+            // the running state: on the device while the program that rendered is still there (also after an edit the next render
+            // has not picked up yet); otherwise where the last re-flatten committed it (fields, per-voice overrides: voice 0).
+            // A state field the host wrote since keeps the host's value.
+            Graph snap = h.graph;
+            std::vector<double> values;
+            for (int m = 0; m < (int)snap.modules.size(); m++) {
+                Module& mod = snap.modules[(size_t)m];
+                bool ran = false;
+                for (int f = 0; f < (int)mod.fields.size(); f++) {
+                    if (!Graph::field_is_state(mod.type, f) || h.state_writes.count({m, f})) continue;
+                    if (h.prog_valid && h.dev && read_device_state(h, m, f, values)) {
+                        mod.fields[(size_t)f] = values[0];
+                        ran = true;
+                    } else {
+                        for (const auto& o : h.overrides)
+                            if (o.module == m && o.field == f && !o.values.empty()) mod.fields[(size_t)f] = o.values[0];
+                    }
                 }
-            if (ran && mod.type == SRACK_MOD_SAMPLE) mod.fields[SRACK_SAMPLE_WAVE_NEW] = 0.0;  // consumed by the first tick (sample.rs:199-203)
+                if (ran && mod.type == SRACK_MOD_SAMPLE && mod.wave_revision <= h.prog_graph_revision) mod.fields[SRACK_SAMPLE_WAVE_NEW] = 0.0;  // consumed by the first tick (sample.rs:199-203)
+            }
+            bytes = save_srk(snap);
+        } else {
+            bytes = save_srk(h.graph);
         }
-        bytes = save_srk(snap);
-    } else {
-        bytes = save_srk(h.graph);
-    }
-    if (n_bytes) *n_bytes = bytes.size();
-    if (buf && cap) std::memcpy(buf, bytes.data(), bytes.size() < cap ? bytes.size() : cap);
-    return SRACK_OK;
+        if (n_bytes) *n_bytes = bytes.size();
+        if (buf && cap < bytes.size()) {  // never hand back a truncated file that still parses as MessagePack up to the cut
+            set_error("save_srk: buffer too small (" + std::to_string(cap) + " bytes, the file needs " + std::to_string(bytes.size()) + "); call with buf = NULL for the size");
+            return SRACK_ERR_INVALID;
+        }
+        if (buf) std::memcpy(buf, bytes.data(), bytes.size());
+        return SRACK_OK;
+    });
 }
 
 int srack_patch_module_id(const srack_patch* p, int module, char* buf, size_t cap)
 {
-    CHECK_HANDLE(p);
-    const Module* m = get_module(p, module);
-    if (!m) return SRACK_ERR_INVALID;
-    if (buf && cap) std::snprintf(buf, cap, "%s", m->id.c_str());
-    return (int)m->id.size();
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        const Module* m = get_module(p, module);
+        if (!m) return SRACK_ERR_INVALID;
+        if (buf && cap) std::snprintf(buf, cap, "%s", m->id.c_str());
+        return (int)m->id.size();
+    });
 }
 
 int srack_patch_set_module_position(srack_patch* p, int module, float x, float y)
 {
-    CHECK_HANDLE(p);
-    if (!get_module(p, module)) return SRACK_ERR_INVALID;
-    Module& m = p->h.graph.modules[(size_t)module];
-    m.has_pos = true;
-    m.pos_x = x;
-    m.pos_y = y;
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        if (!get_module(p, module)) return SRACK_ERR_INVALID;
+        Module& m = p->h.graph.modules[(size_t)module];
+        m.has_pos = true;
+        m.pos_x = x;
+        m.pos_y = y;
+        return SRACK_OK;
+    });
 }
 
 int srack_patch_get_module_position(const srack_patch* p, int module, float* x, float* y)
 {
-    CHECK_HANDLE(p);
-    const Module* m = get_module(p, module);
-    if (!m) return SRACK_ERR_INVALID;
-    if (x) *x = m->pos_x;
-    if (y) *y = m->pos_y;
-    return m->has_pos ? 1 : 0;
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        const Module* m = get_module(p, module);
+        if (!m) return SRACK_ERR_INVALID;
+        if (x) *x = m->pos_x;
+        if (y) *y = m->pos_y;
+        return m->has_pos ? 1 : 0;
+    });
 }
 
 int srack_patch_set_output_buffer(srack_patch* p, int module, int port, const float* samples, uint32_t n)
 {
-    CHECK_HANDLE(p);
-    return p->h.graph.set_output_buffer(module, port, samples, n);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        return p->h.graph.set_output_buffer(module, port, samples, n);
+    });
 }
 
 int srack_patch_keep_state(srack_patch* p, int keep)
 {
-    CHECK_HANDLE(p);
-    if (p->h.keep_state != (keep != 0)) p->h.graph.revision++;  // (the flattened program differs: with keep, every planned module is evaluated)
-    p->h.keep_state = keep != 0;
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        if (p->h.keep_state != (keep != 0)) p->h.graph.revision++;  // (the flattened program differs: with keep, every planned module is evaluated)
+        p->h.keep_state = keep != 0;
+        return SRACK_OK;
+    });
 }
 
 int srack_patch_set_noise_seed(srack_patch* p, uint64_t seed, uint64_t first_voice)
 {
-    CHECK_HANDLE(p);
-    p->h.graph.cfg.noise_seed = seed;
-    p->h.graph.cfg.noise_first_voice = first_voice;
-    p->h.graph.revision++;  // the keys are part of the flattened program
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        p->h.graph.cfg.noise_seed = seed;
+        p->h.graph.cfg.noise_first_voice = first_voice;
+        p->h.graph.revision++;  // the keys are part of the flattened program
+        return SRACK_OK;
+    });
 }
 
 int srack_patch_connect(srack_patch* p, int src_module, int src_port, int sink_module, int sink_port)
 {
-    CHECK_HANDLE(p);
-    return p->h.graph.connect(src_module, src_port, sink_module, sink_port);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        return p->h.graph.connect(src_module, src_port, sink_module, sink_port);
+    });
 }
 
 int srack_patch_disconnect(srack_patch* p, int sink_module, int sink_port)
 {
-    CHECK_HANDLE(p);
-    return p->h.graph.disconnect(sink_module, sink_port);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        return p->h.graph.disconnect(sink_module, sink_port);
+    });
 }
 
 int srack_patch_get_input(const srack_patch* p, int sink_module, int sink_port, int* src_module, int* src_port)
 {
-    const Module* m = get_module(p, sink_module);
-    if (!m) return SRACK_ERR_INVALID;
-    if (sink_port < 0 || sink_port >= m->n_in) {
-        set_error("get_input: port index out of range");
-        return SRACK_ERR_PORT;
-    }
-    if (src_module) *src_module = m->in[(size_t)sink_port].src;
-    if (src_port) *src_port = m->in[(size_t)sink_port].port;
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        const Module* m = get_module(p, sink_module);
+        if (!m) return SRACK_ERR_INVALID;
+        if (sink_port < 0 || sink_port >= m->n_in) {
+            set_error("get_input: port index out of range");
+            return SRACK_ERR_PORT;
+        }
+        if (src_module) *src_module = m->in[(size_t)sink_port].src;
+        if (src_port) *src_port = m->in[(size_t)sink_port].port;
+        return SRACK_OK;
+    });
 }
 
 int srack_patch_plan(srack_patch* p, int* order, int cap)
 {
-    CHECK_HANDLE(p);
-    Graph& g = p->h.graph;
-    int n = g.make_plan();
-    if (g.plan.output < 0) {
-        set_error("plan: no OutputModule in the module list (plan is empty)");
-        return SRACK_ERR_NO_OUTPUT;
-    }
-    for (int i = 0; i < n && i < cap && order; i++) order[i] = g.plan.order[(size_t)i];
-    return n;
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        Graph& g = p->h.graph;
+        int n = g.make_plan();
+        if (g.plan.output < 0) {
+            set_error("plan: no OutputModule in the module list (plan is empty)");
+            return SRACK_ERR_NO_OUTPUT;
+        }
+        for (int i = 0; i < n && i < cap && order; i++) order[i] = g.plan.order[(size_t)i];
+        return n;
+    });
 }
 
 int srack_patch_plan_list(srack_patch* p, int output, const int* all_modules, int n_all, int* order, int cap)
 {
-    CHECK_HANDLE(p);
-    Graph& g = p->h.graph;
-    const int n_mod = (int)g.modules.size();
-    if (output < 0 || output >= n_mod || !all_modules) {
-        set_error("plan_list: bad output / list");
-        return SRACK_ERR_INVALID;
-    }
-    std::vector<int> all(all_modules, all_modules + n_all);
-    for (int m : all)
-        if (m < 0 || m >= n_mod) {
-            set_error("plan_list: module index out of range");
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        Graph& g = p->h.graph;
+        const int n_mod = (int)g.modules.size();
+        if (output < 0 || output >= n_mod || !all_modules || n_all < 0) {
+            set_error("plan_list: bad output / list");
             return SRACK_ERR_INVALID;
         }
-    int n = g.make_plan(output, all);
-    for (int i = 0; i < n && i < cap && order; i++) order[i] = g.plan.order[(size_t)i];
-    g.plan.valid = false;  // a shuffled list is a test device; renders always plan in list order
-    return n;
+        std::vector<int> all(all_modules, all_modules + n_all);
+        for (int m : all)
+            if (m < 0 || m >= n_mod) {
+                set_error("plan_list: module index out of range");
+                return SRACK_ERR_INVALID;
+            }
+        int n = g.make_plan(output, all);
+        for (int i = 0; i < n && i < cap && order; i++) order[i] = g.plan.order[(size_t)i];
+        g.plan.valid = false;  // a shuffled list is a test device; renders always plan in list order
+        return n;
+    });
 }
 
 int srack_patch_removed_edges(srack_patch* p, int* pairs, int cap)
 {
-    CHECK_HANDLE(p);
-    const auto& r = p->h.graph.plan.removed;
-    for (size_t i = 0; i < r.size() && (int)i < cap && pairs; i++) {
-        pairs[2 * i] = r[i].first;
-        pairs[2 * i + 1] = r[i].second;
-    }
-    return (int)r.size();
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        const auto& r = p->h.graph.plan.removed;
+        for (size_t i = 0; i < r.size() && (int)i < cap && pairs; i++) {
+            pairs[2 * i] = r[i].first;
+            pairs[2 * i + 1] = r[i].second;
+        }
+        return (int)r.size();
+    });
 }
 
 int srack_patch_delayed_edges(srack_patch* p, int* quads, int cap)
 {
-    CHECK_HANDLE(p);
-    Graph& g = p->h.graph;
-    if (!g.plan.valid) g.make_plan();
-    auto edges = g.delayed_edges();
-    for (size_t i = 0; i < edges.size() && (int)i < cap && quads; i++) {
-        quads[4 * i + 0] = edges[i].src;
-        quads[4 * i + 1] = edges[i].src_port;
-        quads[4 * i + 2] = edges[i].sink;
-        quads[4 * i + 3] = edges[i].sink_port;
-    }
-    return (int)edges.size();
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        Graph& g = p->h.graph;
+        if (!g.plan.valid) g.make_plan();
+        auto edges = g.delayed_edges();
+        for (size_t i = 0; i < edges.size() && (int)i < cap && quads; i++) {
+            quads[4 * i + 0] = edges[i].src;
+            quads[4 * i + 1] = edges[i].src_port;
+            quads[4 * i + 2] = edges[i].sink;
+            quads[4 * i + 3] = edges[i].sink_port;
+        }
+        return (int)edges.size();
+    });
 }
 
 int srack_voices_configure(srack_patch* p, uint32_t n_voices)
 {
-    CHECK_HANDLE(p);
-    if (n_voices == 0 || n_voices > (1u << 24)) {  // a tile of 32 frame rows (32 * V * 4 bytes) must fit a 31-bit buffer offset
-        set_error("voices_configure: n_voices must be 1 .. 16777216");
-        return SRACK_ERR_INVALID;
-    }
-    p->h.n_voices = n_voices;
-    p->h.overrides.clear();
-    p->h.voices_revision++;
-    p->h.voices_fresh = true;
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        if (n_voices == 0 || n_voices > (1u << 24)) {  // a tile of 32 frame rows (32 * V * 4 bytes) must fit a 31-bit buffer offset
+            set_error("voices_configure: n_voices must be 1 .. 16777216");
+            return SRACK_ERR_INVALID;
+        }
+        p->h.n_voices = n_voices;
+        p->h.overrides.clear();
+        p->h.voices_revision++;
+        p->h.voices_fresh = true;
+        return SRACK_OK;
+    });
 }
 
 int srack_voices_set_field_f32(srack_patch* p, int module, int field, const float* values) { return set_voice_field(p, module, field, values); }
@@ -391,79 +504,91 @@ int srack_voices_set_field_f64(srack_patch* p, int module, int field, const doub
 
 int srack_render_planes(srack_patch* p, int* channel_plane, int cap)
 {
-    CHECK_HANDLE(p);
-    int rc = ensure_program(p->h, p->h.prog_valid ? p->h.prog_flags : 0u);
-    if (rc != SRACK_OK) return rc;
-    const DevProgram& H = p->h.prog.voice.hdr;
-    for (int c = 0; c < H.n_channels && c < cap && channel_plane; c++) channel_plane[c] = H.channel_plane[c];
-    return H.n_planes;
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        int rc = ensure_program(p->h, p->h.prog_valid ? p->h.prog_flags : 0u);
+        if (rc != SRACK_OK) return rc;
+        const DevProgram& H = p->h.prog.voice.hdr;
+        for (int c = 0; c < H.n_channels && c < cap && channel_plane; c++) channel_plane[c] = H.channel_plane[c];
+        return H.n_planes;
+    });
 }
 
 int srack_render(srack_patch* p, uint32_t n_samples, float* d_frames, float* d_mix, uint32_t flags, void* stream)
 {
-    CHECK_HANDLE(p);
-    if (p->h.n_voices == 0) {
-        set_error("render: call srack_voices_configure first");
-        return SRACK_ERR_STATE;
-    }
-    return device_render(p->h, n_samples, d_frames, d_mix, flags, stream);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        if (p->h.n_voices == 0) {
+            set_error("render: call srack_voices_configure first");
+            return SRACK_ERR_STATE;
+        }
+        return device_render(p->h, n_samples, d_frames, d_mix, flags, stream);
+    });
 }
 
 int srack_render_reserve(srack_patch* p, uint32_t n_samples, int want_mix, uint32_t flags)
 {
-    CHECK_HANDLE(p);
-    if (p->h.n_voices == 0) {
-        set_error("render_reserve: call srack_voices_configure first");
-        return SRACK_ERR_STATE;
-    }
-    return device_reserve(p->h, n_samples, want_mix != 0, flags);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        if (p->h.n_voices == 0) {
+            set_error("render_reserve: call srack_voices_configure first");
+            return SRACK_ERR_STATE;
+        }
+        return device_reserve(p->h, n_samples, want_mix != 0, flags);
+    });
 }
 
 int srack_render_info(srack_patch* p, char* buf, size_t cap)
 {
-    CHECK_HANDLE(p);
-    int rc = ensure_program(p->h, p->h.prog_valid ? p->h.prog_flags : 0u);
-    if (rc != SRACK_OK) return rc;
-    std::string s = p->h.prog.description;
-    const char* k = device_kernel_name(p->h);
-    if (k && *k) s += std::string(" kernel=") + k;
-    if (buf && cap) {
-        std::strncpy(buf, s.c_str(), cap - 1);
-        buf[cap - 1] = 0;
-    }
-    return (int)s.size();
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        int rc = ensure_program(p->h, p->h.prog_valid ? p->h.prog_flags : 0u);
+        if (rc != SRACK_OK) return rc;
+        std::string s = p->h.prog.description;
+        const char* k = device_kernel_name(p->h);
+        if (k && *k) s += std::string(" kernel=") + k;
+        if (buf && cap) {
+            std::strncpy(buf, s.c_str(), cap - 1);
+            buf[cap - 1] = 0;
+        }
+        return (int)s.size();
+    });
 }
 
 int srack_render_kernel_ms(srack_patch* p, double* avg_ms, int* n_launches, int reset)
 {
-    CHECK_HANDLE(p);
-    return device_kernel_ms(p->h, avg_ms, n_launches, reset);
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        return device_kernel_ms(p->h, avg_ms, n_launches, reset);
+    });
 }
 
 int srack_voices_get_field(srack_patch* p, int module, int field, double* values)
 {
-    CHECK_HANDLE(p);
-    PatchHandle& h = p->h;
-    if (!values || h.n_voices == 0) {
-        set_error("voices_get_field: bad arguments / voices not configured");
-        return SRACK_ERR_INVALID;
-    }
-    int rc = ensure_program(h, h.prog_valid ? h.prog_flags : 0u);
-    if (rc != SRACK_OK) return rc;
-    std::vector<double> got;
-    if (read_device_state(h, module, field, got)) {
-        for (uint32_t v = 0; v < h.n_voices; v++) values[v] = got[v];
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        PatchHandle& h = p->h;
+        if (!values || h.n_voices == 0) {
+            set_error("voices_get_field: bad arguments / voices not configured");
+            return SRACK_ERR_INVALID;
+        }
+        int rc = ensure_program(h, h.prog_valid ? h.prog_flags : 0u);
+        if (rc != SRACK_OK) return rc;
+        std::vector<double> got;
+        if (read_device_state(h, module, field, got)) {
+            for (uint32_t v = 0; v < h.n_voices; v++) values[v] = got[v];
+            return SRACK_OK;
+        }
+        // a parameter, or a module that is not evaluated: the field value itself
+        double x;
+        rc = h.graph.get_field(module, field, &x);
+        if (rc != SRACK_OK) return rc;
+        for (uint32_t v = 0; v < h.n_voices; v++) values[v] = x;
+        for (const auto& o : h.overrides)
+            if (o.module == module && o.field == field)
+                for (uint32_t v = 0; v < h.n_voices; v++) values[v] = o.values[v];
         return SRACK_OK;
-    }
-    // a parameter, or a module that is not evaluated: the field value itself
-    double x;
-    rc = h.graph.get_field(module, field, &x);
-    if (rc != SRACK_OK) return rc;
-    for (uint32_t v = 0; v < h.n_voices; v++) values[v] = x;
-    for (const auto& o : h.overrides)
-        if (o.module == module && o.field == field)
-            for (uint32_t v = 0; v < h.n_voices; v++) values[v] = o.values[v];
-    return SRACK_OK;
+    });
 }
 
 extern "C++" {
@@ -505,43 +630,55 @@ bool read_device_state(PatchHandle& h, int module, int field, std::vector<double
 // ---- device helpers -------------------------------------------------------------------------------
 int srack_device_count(int* n)
 {
-    int c = 0;
-    hipError_t e = hipGetDeviceCount(&c);
-    if (e != hipSuccess) c = 0;
-    if (n) *n = c;
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        int c = 0;
+        hipError_t e = hipGetDeviceCount(&c);
+        if (e != hipSuccess) c = 0;
+        if (n) *n = c;
+        return SRACK_OK;
+    });
 }
 
 int srack_device_set(int device)
 {
-    HIP_TRY_C(hipSetDevice(device));
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        HIP_TRY_C(hipSetDevice(device));
+        return SRACK_OK;
+    });
 }
 
 int srack_device_alloc(void** d_ptr, size_t bytes)
 {
-    if (!d_ptr) return SRACK_ERR_INVALID;
-    HIP_TRY_C(hipMalloc(d_ptr, bytes));
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        if (!d_ptr) return SRACK_ERR_INVALID;
+        HIP_TRY_C(hipMalloc(d_ptr, bytes));
+        return SRACK_OK;
+    });
 }
 
 int srack_device_free(void* d_ptr)
 {
-    HIP_TRY_C(hipFree(d_ptr));
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        HIP_TRY_C(hipFree(d_ptr));
+        return SRACK_OK;
+    });
 }
 
 int srack_device_to_host(void* h_dst, const void* d_src, size_t bytes, void* stream)
 {
-    HIP_TRY_C(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        HIP_TRY_C(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));
+        return SRACK_OK;
+    });
 }
 
 int srack_device_sync(void* stream)
 {
-    HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));
-    return SRACK_OK;
+    return guarded([&]() -> int {
+        HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));
+        return SRACK_OK;
+    });
 }
 
 }  // extern "C"

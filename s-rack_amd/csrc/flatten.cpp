@@ -620,13 +620,13 @@ int Builder::build()
         const int fixed_rows = H.n_rows + 2 + H.n_tracks;  // voice table + zero and trash rows + one row per control track
         auto lds_bytes = [&](int tile) { return (fixed_rows + H.n_slots * tile) * 256; };
         int tile_max = kTileMax;
-        if (const char* e = getenv("SRACK_TILE_MAX")) tile_max = atoi(e);  // tuning knob (tools/)
+        if (const char* e = getenv("SRACK_TILE_MAX")) tile_max = std::min(std::max(atoi(e), 1), 64);  // tuning knob (tools/), clamped
         if (!rings.empty()) tile_max = std::min(tile_max, B);              // a tile may not span more than one ring period
         int tile = 0;
         if (is_ctl) {  // one wave: residency is irrelevant, long tiles are not (a row holds 64 samples of a track: the cap)
             if (!getenv("SRACK_TILE_MAX")) tile_max = rings.empty() ? 64 : std::min(64, B);
             int budget = 56 * 1024;
-            if (const char* e = getenv("SRACK_LDS_BUDGET")) budget = atoi(e);
+            if (const char* e = getenv("SRACK_LDS_BUDGET")) budget = std::min(std::max(atoi(e), 1024), 64 * 1024);
             for (tile = std::max(tile_max, 1); tile > 1 && lds_bytes(tile) > budget; tile >>= 1) {}
         } else {
             constexpr int kCUs = 256, kLdsPerCU = 160 * 1024, kGranule = 1280, kWaveSlots = 20;  // 5 waves per SIMD (<= 96 VGPRs)

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 
 namespace srack {
@@ -228,7 +229,7 @@ int Graph::set_field(int module, int field, double value)
     if (field_is_f64(m.type, field))
         m.fields[(size_t)field] = value;
     else if (field_is_flag(m.type, field))
-        m.fields[(size_t)field] = (double)(int)value;
+        m.fields[(size_t)field] = !(value == value) ? 0.0 : (double)(int)std::fmin(std::fmax(value, -2147483648.0), 2147483647.0);  // (int) of a NaN / out-of-range double is undefined
     else
         m.fields[(size_t)field] = (double)(float)value;  // the struct member is an f32
     revision++;

@@ -41,6 +41,34 @@ namespace srack {
         }                                                                                               \
     } while (0)
 
+// Tuning knobs of tools/ (not part of the interface): read once per process and clamped to values the schedule can run with.
+struct Knobs {
+    uint32_t want_waves = 1024;  // waves to aim for when there are few voices (one per SIMD)
+    uint32_t chunk_max = 4096;   // samples per launch; measured on the headline workload: 4096 -> 13.98, 8192 -> 14.14, 16384 -> 14.8 ms per step
+    bool debug_occ = false;
+    int high_prio_ctl = 1;       // the control stream is created with the highest priority (its own pool of hardware queues)
+};
+static const Knobs& knobs()
+{
+    static const Knobs k = [] {
+        Knobs v;
+        auto num = [](const char* name, long lo, long hi, long dflt) {
+            const char* e = getenv(name);
+            if (!e || !*e) return dflt;
+            char* end = nullptr;
+            const long x = strtol(e, &end, 10);
+            if (end == e) return dflt;
+            return std::min(std::max(x, lo), hi);
+        };
+        v.want_waves = (uint32_t)num("SRACK_WANT_WAVES", 1, 1 << 20, 1024);
+        v.chunk_max = (uint32_t)num("SRACK_CHUNK_MAX", 256, 65536, 4096);
+        v.debug_occ = getenv("SRACK_DEBUG_OCC") != nullptr;
+        v.high_prio_ctl = (int)num("SRACK_CTL_HIGH_PRIO", 0, 1, 1);
+        return v;
+    }();
+    return k;
+}
+
 struct DevProg {  // device copy of one FlatProgram
     DevOp* d_ops = nullptr;
     uint32_t* d_table = nullptr;
@@ -116,18 +144,24 @@ int ensure_program(PatchHandle& h, uint32_t flags)
     // per voice for the modules of the voice program (a per-voice override of the state field), once for a module the control
     // program evaluates (it stays voice-invariant: the field itself).  Rings and reverb lines are not carried.
     const bool carry = h.keep_state && h.prog_valid && !h.voices_fresh && h.samples_rendered > 0;
+    // The carried values are collected first and committed only once flatten() has succeeded: a failed flatten leaves the patch as
+    // the host last saw it.  A state field the host wrote since the last flatten keeps the host's value.
+    Graph carried_graph;
+    std::vector<VoiceOverride> carried_ov;
     if (carry && h.dev) {
+        carried_graph = h.graph;
+        carried_ov = h.overrides;
         std::vector<double> values;
-        for (int m = 0; m < (int)h.graph.modules.size(); m++) {
-            Module& mod = h.graph.modules[(size_t)m];
+        for (int m = 0; m < (int)carried_graph.modules.size(); m++) {
+            Module& mod = carried_graph.modules[(size_t)m];
             for (int f = 0; f < (int)mod.fields.size(); f++) {
-                if (!Graph::field_is_state(mod.type, f) || !read_device_state(h, m, f, values)) continue;
+                if (!Graph::field_is_state(mod.type, f) || h.state_writes.count({m, f}) || !read_device_state(h, m, f, values)) continue;
                 const bool in_ctl = h.prog.n_tracks > 0 && m < (int)h.prog.ctl_stage.size() && h.prog.ctl_stage[(size_t)m] >= 0;
-                for (auto it = h.overrides.begin(); it != h.overrides.end();) it = (it->module == m && it->field == f) ? h.overrides.erase(it) : it + 1;
+                for (auto it = carried_ov.begin(); it != carried_ov.end();) it = (it->module == m && it->field == f) ? carried_ov.erase(it) : it + 1;
                 if (in_ctl)
                     mod.fields[(size_t)f] = values[0];
                 else
-                    h.overrides.push_back(VoiceOverride{m, f, values});
+                    carried_ov.push_back(VoiceOverride{m, f, values});
                 // a sample player that has run has consumed its `wavebox.new` (sample.rs:199-203) — unless the wave was set after
                 // the program that ran was flattened
                 if (mod.type == SRACK_MOD_SAMPLE && mod.wave_revision <= h.prog_graph_revision) mod.fields[SRACK_SAMPLE_WAVE_NEW] = 0.0;
@@ -140,8 +174,16 @@ int ensure_program(PatchHandle& h, uint32_t flags)
         for (size_t s = 0; s < h.prog.ctl.size(); s++)
             for (const auto& t : h.prog.ctl[s].carry) pending_tags.push_back({(int)s, h.prog.ctl[s].n_voices, t});
     }
-    int rc = flatten(h.graph, h.n_voices, h.overrides, flags | (h.keep_state ? kFlattenEvalAll : 0u), h.prog);
+    const bool use_carried = carry && h.dev;
+    FlatPair fresh;
+    int rc = flatten(use_carried ? carried_graph : h.graph, h.n_voices, use_carried ? carried_ov : h.overrides, flags | (h.keep_state ? kFlattenEvalAll : 0u), fresh);
     if (rc != SRACK_OK) return rc;
+    if (use_carried) {  // commit: the carried state is now what the patch holds (the plan made by flatten travels with the graph)
+        h.graph = std::move(carried_graph);
+        h.overrides = std::move(carried_ov);
+    }
+    h.prog = std::move(fresh);
+    h.state_writes.clear();
     h.prog_valid = true;
     h.prog_graph_revision = h.graph.revision;
     h.prog_voices_revision = h.voices_revision;
@@ -402,7 +444,7 @@ static void launch_fm_pair(bool ring, bool exact, int out_mode, const KernelArgs
 static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_t st)
 {
     size_t lds = ((size_t)P.hdr.n_rows + 2 + (size_t)P.hdr.n_tracks + (size_t)P.hdr.n_slots * P.hdr.tile) * 256;  // + zero, trash and track rows
-    if (getenv("SRACK_DEBUG_OCC")) {  // tools/: what the runtime says about resident workgroups per CU for this LDS size
+    if (knobs().debug_occ) {  // tools/: what the runtime says about resident workgroups per CU for this LDS size
         int n = -1;
         hipError_t e = (P.render_flags & SRACK_RENDER_EXACT_OSC) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_interp<true>, 64, lds)
                                                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_interp<false>, 64, lds);
@@ -439,9 +481,7 @@ static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t 
 // chunk k waits only for it, so all but the first control chunk hide behind voice kernels of earlier chunks.
 static uint32_t lanes_per_wave(uint32_t V)
 {
-    const uint32_t kSimds = 1024;
-    uint32_t want_waves = kSimds;
-    if (const char* e = getenv("SRACK_WANT_WAVES")) want_waves = (uint32_t)atoi(e);  // tuning knob (tools/): waves to aim for
+    const uint32_t want_waves = knobs().want_waves;
     uint32_t lanes = 64;
     while (lanes > 16 && (V + lanes - 1) / lanes * 2 <= want_waves) lanes >>= 1;
     return lanes;
@@ -471,8 +511,15 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         if (d_mix)
             for (uint32_t c = 0; c < C; c++)
                 hipLaunchKernelGGL(fill_zero, dim3((T + 255) / 256), dim3(256), 0, st, d_mix + (size_t)c * T_total, (size_t)T);
-        h.samples_rendered += T;
-        return SRACK_OK;
+        // Under srack_patch_keep_state the program holds every planned module (the reference's execute() ticks them all, heard or
+        // not): they must keep running — phases, envelopes, sequencer steps, rings — or a wire patched into the output later would
+        // find them frozen while the sample counter moved on.  The kernels run with nothing to write.
+        if (!h.keep_state || (P.ops.empty() && h.prog.n_tracks == 0)) {
+            h.samples_rendered += T;
+            return SRACK_OK;
+        }
+        d_frames = nullptr;
+        d_mix = nullptr;
     }
     if (d_mix && (rc = grow(d->d_mixpart, d->mixpart_bytes, sizeof(float) * (size_t)P.hdr.n_planes * n_waves * T)) != SRACK_OK) return rc;
     if (d_mix && (rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * T)) != SRACK_OK) return rc;
@@ -494,8 +541,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     // chunk schedule: short first chunks (only control chunk 0 is exposed), doubling up to kChunkMax
     // With a control pipeline of depth L the first voice chunk waits for L + 1 control launches: those stay short.
     constexpr uint32_t kChunkFirst = 1024;
-    uint32_t kChunkMax = 4096;  // measured on the headline workload: 4096 -> 13.98, 8192 -> 14.14, 16384 -> 14.8 ms per step
-    if (const char* e = getenv("SRACK_CHUNK_MAX")) kChunkMax = (uint32_t)atoi(e);  // tuning knob (tools/)
+    const uint32_t kChunkMax = knobs().chunk_max;
     uint32_t max_lag = 0;
     for (int lag : h.prog.ctl_lag) max_lag = std::max(max_lag, (uint32_t)lag);
     std::vector<std::pair<uint32_t, uint32_t>> chunks;       // (t_off, len)
@@ -526,7 +572,16 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         hipLaunchKernelGGL(render_ctl_gate_env, dim3(1), dim3(64), 0, st, ctl_work(chunks[0].first, chunks[0].second));
         HIP_TRY(hipGetLastError());
     } else if (has_ctl) {
-        if (!d->ctl_stream) HIP_TRY(hipStreamCreateWithFlags(&d->ctl_stream, hipStreamNonBlocking));
+        if (!d->ctl_stream) {
+            // Highest priority: HIP keeps a separate pool of hardware queues per priority, so this stream does not end up sharing
+            // a queue with the caller's stream once other libraries (RCCL) have created streams of their own — the overlap of
+            // control chunks with voice chunks depends on the two running on different queues.
+            int prio_lo = 0, prio_hi = 0;
+            if (knobs().high_prio_ctl && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_hi != prio_lo)
+                HIP_TRY(hipStreamCreateWithPriority(&d->ctl_stream, hipStreamNonBlocking, prio_hi));
+            else
+                HIP_TRY(hipStreamCreateWithFlags(&d->ctl_stream, hipStreamNonBlocking));
+        }
         if (!d->ev_begin) HIP_TRY(hipEventCreateWithFlags(&d->ev_begin, hipEventDisableTiming));
         while (d->ev_chunk.size() < n_chunks) {
             hipEvent_t e;
@@ -680,8 +735,11 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         }
         if (has_ctl && !co_ctl) HIP_TRY(hipStreamWaitEvent(st, d->ev_chunk[k], 0));
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if ((rc = get_event(e0)) != SRACK_OK || (rc = get_event(e1)) != SRACK_OK) return rc;
-        HIP_TRY(hipEventRecord(e0, st));
+        const bool timed = h.timing_armed;  // only a host that asked for srack_render_kernel_ms pays for the event pair
+        if (timed) {
+            if ((rc = get_event(e0)) != SRACK_OK || (rc = get_event(e1)) != SRACK_OK) return rc;
+            HIP_TRY(hipEventRecord(e0, st));
+        }
         if (fused) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             launch_fused(osc_port, vcf_port, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, track, ka, roles, co, dim3(n_waves + ka.block0), st);
@@ -695,12 +753,14 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
             launch_interp(P, ka, st);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(e1, st));
-        d->timings.emplace_back(e0, e1);
-        if (d->timings.size() > 4096) {  // nobody is reading them: recycle the oldest
-            d->pool.push_back(d->timings.front().first);
-            d->pool.push_back(d->timings.front().second);
-            d->timings.erase(d->timings.begin());
+        if (timed) {
+            HIP_TRY(hipEventRecord(e1, st));
+            d->timings.emplace_back(e0, e1);
+            if (d->timings.size() > 4096) {  // nobody is reading them: recycle the oldest
+                d->pool.push_back(d->timings.front().first);
+                d->pool.push_back(d->timings.front().second);
+                d->timings.erase(d->timings.begin());
+            }
         }
     }
 
@@ -767,6 +827,7 @@ int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t f
 
 int device_kernel_ms(PatchHandle& h, double* avg_ms, int* n_launches, int reset)
 {
+    h.timing_armed = reset >= 0;  // the first call arms the per-launch event pairs; reset < 0 reads what there is and disarms
     double total = 0.0;
     int n = 0;
     if (h.dev) {

@@ -1,7 +1,9 @@
 // runtime.hpp — the object behind `srack_patch*`: graph + voices + flattened program + device state.
 #pragma once
 #include <cstdint>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "flatten.hpp"
@@ -35,6 +37,10 @@ struct PatchHandle {
         FlatProgram::CarryTag tag;
     };
     std::vector<OldTag> old_tags;
+    // keep_state: (module, field) pairs of STATE fields the host wrote since the last flatten — the carry leaves those alone
+    // (an explicit srack_patch_set_field / srack_voices_set_field_* on a state field wins over the running value)
+    std::set<std::pair<int, int>> state_writes;
+    bool timing_armed = false;      // srack_render_kernel_ms has been called: renders bracket the dominant kernel with HIP events
 
     ~PatchHandle();
 };

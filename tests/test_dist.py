@@ -83,3 +83,63 @@ def test_voice_draw_is_shard_invariant(W):
         part = W.p1_voice_params(v1 - v0, first_voice=v0)
         np.testing.assert_array_equal(part[0], full[0][v0:v1])
         np.testing.assert_array_equal(part[1], full[1][v0:v1])
+
+
+# ---- bench.py's own N > 1 machinery (launcher, rendezvous, control plane, timing protocol, one JSON line), no GPU -----------
+def _run_bench_cpu(tmp_path, gpus, extra=(), env_extra=None):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["SRACK_TEST_MIX_OUT"] = str(tmp_path / "mix.npy")
+    env["SRACK_TEST_STEPS_OUT"] = str(tmp_path / "steps")
+    env.update(env_extra or {})
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_cpu_rank.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+           "--voices", "12", "--samples", "1200", "--no-cpu", *extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks(tmp_path, W, oracle):
+    """`bench.py --gpus 2` with no launcher around it: bench.py starts the ranks itself, rank 0 prints the one line, the value is
+    the whole job's, and the reduced mix equals a single-process render of all the voices."""
+    out = _run_bench_cpu(tmp_path, 2)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["scaling"] == "weak" and out["unit"] == "voice-samples/s"
+    assert abs(out["value"] - 2 * 12 * 1200 / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    for r in range(2):  # every rank ran warmup + steps, no more
+        assert open(str(tmp_path / "steps") + f".{r}").read() == "3"
+    reduced = np.load(tmp_path / "mix.npy")
+    det, cut = W.p1_voice_params(24)
+    g = oracle.OraclePatch(48000, 1024, 2)
+    ids = W.build_p1(g, adsr="finite", lfo_val=-2.0)
+    frames, mix = g.render_batch(24, 1200, [(ids["osc_a"], W.OSC_VAL, det), (ids["vcf"], W.VCF_FREQ, cut)], mix=True, threads=2)
+    scale = np.abs(frames.astype(np.float64)).sum(axis=2)
+    assert (np.abs(reduced - mix) <= 1e-5 * np.maximum(scale, 1.0)).all()
+    assert np.abs(mix).max() > 0.5
+
+
+def test_bench_under_an_external_launcher(tmp_path):
+    """The driver's form: a launcher exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; bench.py must not start ranks of its own."""
+    import bench
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_cpu_rank.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--voices", "4", "--samples", "600", "--no-cpu"]
+    env = dict(os.environ, SRACK_TEST_STEPS_OUT=str(tmp_path / "steps"))
+    rc = bench.launch_ranks(2, cmd, env=env, timeout=240)  # stands in for torch.distributed.run: same environment contract
+    assert rc == 0
+    assert sorted(os.listdir(tmp_path)) == ["steps.0", "steps.1"]  # two ranks, not four
+
+
+def test_bench_single_rank_needs_no_rendezvous(tmp_path):
+    out = _run_bench_cpu(tmp_path, 1)
+    assert out["n_gpus"] == 1 and out["ranks_seen"] == 1
+
+
+def test_launcher_reports_a_failing_rank():
+    import bench
+    rc = bench.launch_ranks(2, [sys.executable, "-c", "import os, sys, time; time.sleep(0.3 if os.environ['RANK'] == '0' else 30); sys.exit(7 if os.environ['RANK'] == '0' else 0)"], timeout=60)
+    assert rc == 7  # and the sleeping rank was stopped rather than waited for

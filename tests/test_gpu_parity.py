@@ -1387,3 +1387,85 @@ def test_saving_a_running_rack_under_keep_state(S, flags):
     fresh = S.Patch.load_srk(r.save_srk(), 48000, B, 2)
     fresh.configure_voices(1)
     np.testing.assert_array_equal(bits(fresh.render_channels(T2, flags)[:, :, 0]), bits(whole[:, :T2, 0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [1, 3])
+def test_keep_state_runs_the_rack_while_the_output_is_unwired(S, oracle, flags):
+    """Nothing wired into the OutputModule yet (or the output muted): the render is silence, but under keep_state the planned modules
+    keep ticking as in the reference's execute() — the phases, envelopes and sample counter a later patch cable finds are the
+    reference's, not frozen ones."""
+    V, B, T1, T2 = 66, 64, 1500, 1024
+    def build(g):
+        ids = S.build_p1(g, adsr="finite", lfo_val=-3.0)
+        g.disconnect(ids["out"], 0)
+        g.disconnect(ids["out"], 1)
+        return ids
+    def patch_in(g, ids):
+        g.connect(ids["vca"], 0, ids["out"], 0)
+        g.connect(ids["osc_a"], S.OSC_OUT_SAW, ids["out"], 1)
+    p = S.Patch(48000, B, 2)
+    ids = build(p)
+    p.configure_voices(V)
+    p.keep_state(True)
+    fr, mix = p.render(T1, flags=flags)
+    assert fr.shape[0] == 0 and not mix.any()
+    patch_in(p, ids)
+    b = p.render_channels(T2, flags)
+    o = oracle.OraclePatch(48000, B, 2)
+    oi = build(o)
+    o.render(T1)
+    patch_in(o, oi)
+    rb = o.render(T2)
+    for v in (0, V - 1):
+        np.testing.assert_array_equal(bits(b[:, :, v]), bits(rb))
+    assert np.abs(rb[0]).max() > 0.01 and abs(float(rb[1][0]) + 1.0) > 1e-3   # audible, and the saw did not start from phase 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [1, 3])
+def test_keep_state_host_write_to_a_state_field_wins(S, flags):
+    """Under keep_state a re-flatten starts from the running state — except where the host has just written a state field itself
+    (a phase reset, an envelope forced to None): that value is the one the next render starts from."""
+    V, B, T = 5, 64, 1024
+    p = S.Patch(48000, B, 2)
+    ids = S.build_p1(p, adsr="finite", lfo_val=-3.0)
+    p.configure_voices(V)
+    det, _ = S.p1_voice_params(V)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.keep_state(True)
+    p.render_channels(T, flags)
+    running = p.get_voice_field(ids["osc_a"], S.OSC_POS)
+    assert (running != 0.25).all()
+    p.set_field(ids["osc_a"], S.OSC_POS, 0.25)                       # all voices (replaces what an earlier carry left per voice)
+    p.set_field(ids["vcf"], S.VCF_RES, 0.4)                          # plus an ordinary parameter edit
+    got = p.get_voice_field(ids["osc_a"], S.OSC_POS)
+    np.testing.assert_array_equal(got, np.full(V, 0.25))
+    filt = p.get_voice_field(ids["vcf"], S.VCF_ST_B4)                # ... while everything else keeps running
+    assert np.abs(filt).max() > 0
+    p.render_channels(16, flags)
+    pos = np.full(V, 0.25)
+    for _ in range(16):
+        pos = np.fmod(pos + 440.0 * np.power(2.0, det.astype(np.float64)) / 48000.0, 1.0)
+    np.testing.assert_array_equal(p.get_voice_field(ids["osc_a"], S.OSC_POS), pos)
+    per_voice = np.linspace(0.1, 0.5, V)
+    p.set_voice_field(ids["osc_a"], S.OSC_POS, per_voice)            # the per-voice form
+    p.set_field(ids["vcf"], S.VCF_RES, 0.45)
+    np.testing.assert_array_equal(p.get_voice_field(ids["osc_a"], S.OSC_POS), per_voice)
+
+
+@pytest.mark.gpu
+def test_kernel_timer_is_off_until_asked_for(S):
+    p = S.Patch(48000, 1024, 2)
+    S.build_p1(p)
+    p.configure_voices(64)
+    lib = S.lib
+    import ctypes as C
+    p.render(2048)
+    ms, n = C.c_double(), C.c_int()
+    assert lib.srack_render_kernel_ms(p.h, C.byref(ms), C.byref(n), 0) == 0 and n.value == 0   # nothing was recorded; this call arms
+    p.render(2048)
+    assert lib.srack_render_kernel_ms(p.h, C.byref(ms), C.byref(n), 1) == 0 and n.value >= 1 and ms.value > 0
+    assert lib.srack_render_kernel_ms(p.h, C.byref(ms), C.byref(n), -1) == 0 and n.value == 0  # read + disarm
+    p.render(2048)
+    assert lib.srack_render_kernel_ms(p.h, C.byref(ms), C.byref(n), -1) == 0 and n.value == 0

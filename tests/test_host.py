@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(S):
     L = ctypes.CDLL(S.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.srack_abi_version() == 1
+    assert L.srack_abi_version() == 2
 
 
 def test_module_defaults_match_reference_new(S):
@@ -328,3 +328,33 @@ def test_freeverb_module_graph_api(S):
     with pytest.raises(S.SrackError) as e:
         q.info()
     assert e.value.code == S.ERR_UNSUPPORTED
+
+
+def test_save_srk_rejects_a_short_buffer(S):
+    """A truncated MessagePack file can still parse up to the cut: the call fails instead of handing one back."""
+    import ctypes as C
+    p = S.Patch(48000, 64, 2)
+    S.build_p1(p)
+    n = C.c_size_t()
+    assert S.lib.srack_patch_save_srk(p.h, None, 0, C.byref(n)) == S.OK and n.value > 100
+    buf = C.create_string_buffer(n.value)
+    need = n.value
+    assert S.lib.srack_patch_save_srk(p.h, buf, need - 1, C.byref(n)) == S.ERR_INVALID
+    assert n.value == need and b"too small" in S.lib.srack_last_error()
+    assert S.lib.srack_patch_save_srk(p.h, buf, need, C.byref(n)) == S.OK
+    assert buf.raw == p.save_srk()
+
+
+def test_hostile_numbers_and_lists_do_not_crash(S):
+    """NaN / huge values in integer-like fields, a negative list length: clamped or rejected, never undefined behaviour."""
+    import ctypes as C
+    p = S.Patch(48000, 64, 2)
+    ids = S.build_p1(p)
+    for bad in (float("nan"), 1e300, -1e300, float("inf")):
+        p.set_field(ids["adsr"], S.ADSR_MODE, bad)
+        assert p.get_field(ids["adsr"], S.ADSR_MODE) in (0.0, 2147483647.0, -2147483648.0)
+    p.configure_voices(3)
+    p.set_voice_field(ids["adsr"], S.ADSR_MODE, np.array([np.nan, 1e30, -1e30]))
+    arr = (C.c_int * 2)(0, 1)
+    out = (C.c_int * 8)()
+    assert S.lib.srack_patch_plan_list(p.h, ids["out"], arr, -5, out, 8) == S.ERR_INVALID
