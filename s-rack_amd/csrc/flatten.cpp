@@ -288,8 +288,8 @@ int Builder::build()
                         small = 440.0 * std::pow(2.0, (double)(float)o->values[v]) / op.sample_rate < 0.25;
                 }
                 const uint32_t ports = op.flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
-                if (small && !(op.flags & (OSC_HAS_SYNC | OSC_EXACT)) && (op.flags & OSC_AA) && ports && !(ports & (ports - 1)))
-                    op.flags |= OSC_CONST_FAST;
+                if (small && !(op.flags & OSC_HAS_SYNC) && (op.flags & OSC_AA) && ports && !(ports & (ports - 1)))
+                    op.flags |= (op.flags & OSC_EXACT) ? OSC_CONST_SMALL : (OSC_CONST_SMALL | OSC_CONST_FAST);
             }
             break;
         }
@@ -661,7 +661,7 @@ int Builder::build()
 
     if (!(render_flags & SRACK_RENDER_NO_FUSION)) match_fused(!rings.empty());
     if (is_ctl && !(render_flags & SRACK_RENDER_NO_FUSION) && rings.empty() && H.n_ops == 3 && out.ops[0].kind == OP_OSC &&
-        out.ops[1].kind == OP_ADSR && out.ops[2].kind == OP_OUT && (out.ops[0].flags & OSC_CONST_FAST) && (out.ops[1].flags & ADSR_HAS_GATE) &&
+        out.ops[1].kind == OP_ADSR && out.ops[2].kind == OP_OUT && (out.ops[0].flags & OSC_CONST_SMALL) && (out.ops[1].flags & ADSR_HAS_GATE) &&
         g.modules[(size_t)out.ops[1].module].in[0].src == out.ops[0].module && out.ops[2].module == out.ops[1].module)
         out.fused = FUSED_CTL_GATE_ENV;  // uniform parameters only (V == 1, no overrides): par_val / delta are used directly
 

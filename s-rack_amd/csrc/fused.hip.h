@@ -113,10 +113,13 @@ struct CtlWork {
     uint32_t* table;   // the control program's one-voice table
     float* track;      // this chunk's first sample of the envelope track
     uint32_t T;        // samples to produce (0: nothing to do)
-    uint32_t port;     // OSC_OUT_* of the gate oscillator
+    uint32_t port;     // OSC_OUT_* of the gate oscillator, | OSC_EXACT in the exact render mode
 };
 
-template <uint32_t kOscPort>
+// kExact: a sample inside a PolyBLEP window takes the reference's f64 formulas (osc_step with OSC_EXACT) instead of the f32
+// ones.  Outside the windows the square is exactly -1 / +1 in the reference too, the phase recurrence is the same f64 add and
+// exact wrap, and the segmented envelope performs adsr.rs's own operations: the speculative groups serve both modes.
+template <uint32_t kOscPort, bool kExact>
 SRK_DEV void ctl_gate_env_body(const CtlWork& a)
 {
     using namespace dev;
@@ -180,7 +183,23 @@ SRK_DEV void ctl_gate_env_body(const CtlWork& a)
             }
             const int stop = min(n, j + 4);
             for (; j < stop; j++) {
-                const float gate = cosc_step<kOscPort>(cl);
+                float gate;
+                if (kExact) {
+                    OscRegs g;
+                    g.pos = cl.pos;
+                    g.sync_last = false;
+                    OscConst kc;
+                    kc.delta = cl.delta;
+                    kc.val = 0.0;
+                    kc.sr = 0.0;
+                    kc.inv_dt = 0.0f;
+                    float o3[3] = {0.0f, 0.0f, 0.0f};
+                    osc_step(OSC_AA | OSC_EXACT | kOscPort, g, kc, 0.0f, 0.0f, o3[0], o3[1], o3[2]);
+                    gate = kOscPort == OSC_OUT_SINE ? o3[0] : (kOscPort == OSC_OUT_SQUARE ? o3[1] : o3[2]);
+                    cl.pos = g.pos;
+                } else {
+                    gate = cosc_step<kOscPort>(cl);
+                }
                 const float env = adsr_seg_step(sd, kd, seg, gate);
                 keep_v = lane == j ? env : keep_v;
             }
@@ -201,17 +220,25 @@ SRK_DEV void ctl_gate_env_body(const CtlWork& a)
 }
 
 
+template <bool kExact>
 SRK_DEV void ctl_gate_env(const CtlWork& w)
 {
-    if (w.port == OSC_OUT_SQUARE)
-        ctl_gate_env_body<OSC_OUT_SQUARE>(w);
-    else if (w.port == OSC_OUT_SAW)
-        ctl_gate_env_body<OSC_OUT_SAW>(w);
+    const uint32_t port = w.port & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
+    if (port == OSC_OUT_SQUARE)
+        ctl_gate_env_body<OSC_OUT_SQUARE, kExact>(w);
+    else if (port == OSC_OUT_SAW)
+        ctl_gate_env_body<OSC_OUT_SAW, kExact>(w);
     else
-        ctl_gate_env_body<OSC_OUT_SINE>(w);
+        ctl_gate_env_body<OSC_OUT_SINE, kExact>(w);
 }
 
-__global__ __launch_bounds__(64) void render_ctl_gate_env(CtlWork w) { ctl_gate_env(w); }
+__global__ __launch_bounds__(64) void render_ctl_gate_env(CtlWork w)
+{
+    if (w.port & OSC_EXACT)
+        ctl_gate_env<true>(w);
+    else
+        ctl_gate_env<false>(w);
+}
 
 // ---- fused voice chain (patch P1's shape) -------------------------------------------------------------
 // OSC_A.<port> -> VCF.<port> -> VCA <- ADSR <- OSC_L.<port>; all wires and all state in VGPRs.
@@ -377,7 +404,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
         // a latency chain sharing its SIMD with four throughput-bound voice waves: without priority it gets a
         // fifth of the issue slots and can outlast the voice blocks (measured: 1.9 -> 2.6 ms per launch)
         __builtin_amdgcn_s_setprio(3);
-        ctl_gate_env(co);
+        ctl_gate_env<kExact>(co);
         return;
     }
     const int lane = threadIdx.x;
@@ -441,8 +468,40 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
     // address space => s_load_dwordx8/x16 straight into SGPRs, a tile at a time), costing no vector instruction at all.
     typedef const __attribute__((address_space(4))) float CFloat;
     CFloat* env_s = (CFloat*)(uintptr_t)env_track;
+    // Exact mode, saw: the oscillator writes a whole tile first (modules.hip.h, XSaw: windowless values, then each lane repairs
+    // its own PolyBLEP rows with the reference's f64 division), into the rows of the mix tile that the samples' outputs overwrite
+    // one by one afterwards.  Its preconditions also make every filter input finite, which licenses the v_med3 clamps.
+    XSaw xo;
+    const bool xs = kExact && kOscAPort == OSC_OUT_SAW && xsaw_usable(sa.pos, ka.delta) && vcf_nan_free(sv);
+    if (xs) xsaw_init(xo, sa.pos, ka.delta);
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+        if (xs) {
+            xsaw_tile(xo, mix_tile + lane, kMixPitch, n);
+            auto sample_x = [&](int i, float xin) {
+                const float env = env_s[t0 + (uint32_t)i];
+                float lp, bp, hp;
+                vcf_step<false, true>(sv, xin, lp, bp, hp);
+                const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
+                const bool cv_pos = (uint32_t)(__float_as_int(env) - 1) < 0x7f800000u;
+                const float o = (negative || cv_pos) ? y * env : 0.0f;
+                emit_put<kOut>(em, mix_tile, o, i, V);
+            };
+            if (n == kMixRows) {  // eight rows of the tile in flight per LDS round trip; a row is read before its output overwrites it
+#pragma unroll
+                for (int i0 = 0; i0 < kMixRows; i0 += 8) {
+                    float xin[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) xin[u] = mix_tile[(i0 + u) * kMixPitch + lane];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) sample_x(i0 + u, xin[u]);
+                }
+            } else {
+                for (int i = 0; i < n; i++) sample_x(i, mix_tile[i * kMixPitch + lane]);
+            }
+            emit_flush<kOut>(em, mix_tile, t0, n, V);
+            continue;
+        }
         auto sample = [&](int i) {
             const float env = env_s[t0 + (uint32_t)i];
             if (kExact) {
@@ -478,6 +537,10 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
     if (!kExact) {
         sa.pos = pos_a;
         sa.sync_last = false;
+    }
+    if (xs) {
+        sa.pos = xo.pos;
+        sa.sync_last = false;  // sync unconnected: `last` follows the constant 0.0 input
     }
     if (active) {
         auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };

@@ -217,6 +217,18 @@ SRK_DEV double wrap01(double x)
     return x - __builtin_floor(x);
 }
 
+// fmod(x, 1.0) bit for bit, without the library's bit-serial loop: for x >= 0 the remainder is x - floor(x), exact in f64
+// (floor(x) shares x's exponent or lies below it; x >= 2^52 is an integer: 0, as fmod's; +inf and NaN give NaN both ways).
+// A negative x — only reachable from a negative phase a host stored itself — keeps the dividend's sign in fmod: the library.
+SRK_DEV double fmod1(double x)
+{
+    double r = x - __builtin_floor(x);
+    if (__builtin_amdgcn_ballot_w64(x < 0.0) != 0) {
+        if (x < 0.0) r = fmod(x, 1.0);
+    }
+    return r;
+}
+
 SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, float sync, float& sine, float& square, float& saw)
 {
     if (flags & OSC_HAS_SYNC) {
@@ -243,9 +255,9 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
         const bool aa = flags & OSC_AA;
         if (flags & OSC_OUT_SINE) sine = (float)sin(pos * 3.14159265358979323846 * 2.0);
         if (flags & OSC_OUT_SQUARE)
-            square = (pos < 0.5 ? -1.0f : 1.0f) - (aa ? (float)(poly_blep_exact(pos, delta) - poly_blep_exact(fmod(pos + 0.5, 1.0), delta)) : 0.0f);
+            square = (pos < 0.5 ? -1.0f : 1.0f) - (aa ? (float)(poly_blep_exact(pos, delta) - poly_blep_exact(fmod1(pos + 0.5), delta)) : 0.0f);
         if (flags & OSC_OUT_SAW) saw = ((float)pos * 2.0f - 1.0f) - (aa ? (float)poly_blep_exact(pos, delta) : 0.0f);
-        s.pos = fmod(pos + delta, 1.0);
+        s.pos = fmod1(pos + delta);
         return;
     }
     float inv_dt = c.inv_dt;
@@ -424,6 +436,105 @@ SRK_DEV float fosc_saw(FOsc& o)
 }
 
 // ---------------------------------------------------------------------------------------------
+// The exact render mode's constant-pitch saw, a tile at a time (bit-identical to oscillator.rs:50-67,135-152).
+// The reference's saw is `((pos as f32) * 2.0 - 1.0) - (poly_blep(pos, delta) as f32)` and poly_blep is 0.0 outside its two
+// windows, `t < dt` (the first dt after the phase wrapped) and `t > 1.0 - dt` (the last dt before it wraps).  Inside a window
+// it needs a true f64 division — and a wave pays for that whenever ANY of its 64 lanes is inside one: 69 % of the samples at
+// 440 Hz, although each single lane is inside a window for 1.8 % of them.  So the tile is produced in two passes:
+//   pass 1  every row gets the windowless value (exact there: x - 0.0 == x) while the phase advances; a lane whose step
+//           wrapped (RN(pos + delta) >= 1) notes the row and its phase.  Both windows are adjacent to a wrap and nowhere else:
+//           `pos > RN(1 - dt)` implies RN(pos + dt) >= 1 (rounding is monotonic), and without a wrap the next phase is
+//           RN(pos + dt) >= dt, i.e. outside the first window.  The converse need not hold: the repair pass uses the
+//           reference's own comparisons, so a noted row that is not inside a window after all just subtracts 0.0.
+//   pass 2  each lane repairs its noted rows: the second-window value of the row that wrapped and the first-window value of
+//           the row after it, each with the reference's f64 division and polynomial, subtracted in place in the LDS tile.
+//           The divergent part runs once per tile (once more if some lane wraps twice within the tile), not per sample.
+// The row after the tile's last row belongs to the next tile: every tile starts by checking its row 0 for the first window
+// (which also covers the very first sample of a render, e.g. phase 0).
+// Preconditions (checked once per launch, wave-uniform; otherwise the caller takes osc_step): 0 <= pos < 1, 0 <= delta <= 1/2.
+// ---------------------------------------------------------------------------------------------
+struct XSaw {
+    double pos, delta;
+    double pend_pos;     // phase of the noted row
+    int pend_row;        // the noted row (-1: none)
+    float row0_fix;      // first-window value of the tile's row 0 (0.0 outside the window)
+};
+
+SRK_DEV bool xsaw_usable(double pos, double delta)
+{
+    return __builtin_amdgcn_ballot_w64(!(pos >= 0.0 && pos < 1.0 && delta >= 0.0 && delta <= 0.5)) == 0;
+}
+
+// the two arms of poly_blep, each alone (a sample is in at most one: `if t < dt {..} else if t > 1.0 - dt {..}`)
+SRK_DEV double poly_blep_first(double t, double dt)
+{
+    if (dt == 0.0 || !(t < dt)) return 0.0;
+    t /= dt;
+    return t + t - t * t - 1.0;
+}
+SRK_DEV double poly_blep_second(double t, double dt)
+{
+    if (dt == 0.0 || t < dt || !(t > 1.0 - dt)) return 0.0;
+    t = (t - 1.0) / dt;
+    return t * t + t + t + 1.0;
+}
+
+SRK_DEV void xsaw_init(XSaw& o, double pos, double delta)
+{
+    o.pos = pos;
+    o.delta = delta;
+    o.pend_pos = 0.0;
+    o.pend_row = -1;
+    o.row0_fix = 0.0f;
+}
+
+// `tile`: this lane's column of an LDS tile, `pitch` floats between rows
+template <class Ptr>
+SRK_DEV void xsaw_repair(XSaw& o, Ptr tile, int pitch, int n)
+{
+    if (o.pend_row >= 0) {
+        const float b = (float)poly_blep_second(o.pend_pos, o.delta);
+        tile[o.pend_row * pitch] = tile[o.pend_row * pitch] - b;
+        if (o.pend_row + 1 < n) {  // (the tile's last row: its successor is row 0 of the next tile, see xsaw_tile)
+            const double p1 = __builtin_amdgcn_fract(o.pend_pos + o.delta);
+            const float a = (float)poly_blep_first(p1, o.delta);
+            tile[(o.pend_row + 1) * pitch] = tile[(o.pend_row + 1) * pitch] - a;
+        }
+        o.pend_row = -1;
+    }
+}
+
+// n rows (n <= 32) of the saw into the tile; on return o.pos is the phase after n samples
+template <class Ptr>
+SRK_DEV void xsaw_tile(XSaw& o, Ptr tile, int pitch, int n)
+{
+    float fix0 = 0.0f;
+    if (__builtin_amdgcn_ballot_w64(o.pos < o.delta) != 0) fix0 = (float)poly_blep_first(o.pos, o.delta);
+    auto row = [&](int i) {
+        const double pos = o.pos;
+        const float base = __builtin_fmaf((float)pos, 2.0f, -1.0f);  // (pos as f32) * 2.0 - 1.0: the doubling is exact, so the fma rounds once like mul, sub
+        tile[i * pitch] = i == 0 ? base - fix0 : base;
+        const double np = pos + o.delta;
+        const bool wrapped = np >= 1.0;
+        o.pos = __builtin_amdgcn_fract(np);  // fmod(np, 1.0) for 0 <= np < 2: exact
+        if (__builtin_amdgcn_ballot_w64(wrapped) != 0) {
+            if (__builtin_amdgcn_ballot_w64(wrapped && o.pend_row >= 0) != 0) xsaw_repair(o, tile, pitch, n);
+            if (wrapped) {
+                o.pend_pos = pos;
+                o.pend_row = i;
+            }
+        }
+    };
+    if (n == 32) {
+#pragma unroll 8
+        for (int i = 0; i < 32; i++) row(i);
+    } else {
+        for (int i = 0; i < n; i++) row(i);
+    }
+    if (__builtin_amdgcn_ballot_w64(o.pend_row >= 0) != 0) xsaw_repair(o, tile, pitch, n);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Moog ladder — InternalMoogFilterState::calc + clamp_buffers, filter.rs:58-92
 // ---------------------------------------------------------------------------------------------
 struct VcfRegs {
@@ -476,7 +587,10 @@ SRK_DEV void vcf_coeffs(VcfRegs& s, float frequency, float res)
 // the reference itself, 6 of the filter's 27 instructions saved — and the clamps are v_med3.  The ladder is a damped
 // recurrence (poles inside the unit circle, states clamped to [-1, 1]), so a 1-ulp difference per stage does not grow:
 // the GPU tests hold default-mode renders to 1e-5 of the oracle over full-second renders.
-template <bool kFast = false>
+// kMed3 (default: as kFast): the clamps as v_med3_f32.  Identical to min/max for every non-NaN value, so the exact flavour may
+// use it too whenever no NaN can reach the filter: its states are clamped to [-1, 1] and its coefficients are finite, so a NaN
+// can only come in through the input (see vcf_nan_free).
+template <bool kFast = false, bool kMed3 = kFast>
 SRK_DEV void vcf_step(VcfRegs& s, float input, float& lowpass, float& bandpass, float& highpass)
 {
     if (kFast) {
@@ -500,14 +614,22 @@ SRK_DEV void vcf_step(VcfRegs& s, float input, float& lowpass, float& bandpass, 
         s.b4 = (s.b3 + t1) * s.p - s.b4 * s.f;
         s.b4 = s.b4 - (s.b4 * s.b4 * s.b4) * 0.166667f;
     }
-    s.b0 = clamp1<kFast>(input);
-    s.b1 = clamp1<kFast>(s.b1);
-    s.b2 = clamp1<kFast>(s.b2);
-    s.b3 = clamp1<kFast>(s.b3);
-    s.b4 = clamp1<kFast>(s.b4);
+    s.b0 = clamp1<kMed3>(input);
+    s.b1 = clamp1<kMed3>(s.b1);
+    s.b2 = clamp1<kMed3>(s.b2);
+    s.b3 = clamp1<kMed3>(s.b3);
+    s.b4 = clamp1<kMed3>(s.b4);
     lowpass = s.b4;
     highpass = input - s.b4;
     bandpass = 3.0f * (s.b3 - s.b4);
+}
+
+// No lane of the wave holds a NaN (or an infinity) in the filter's state or coefficients: with a finite input every later
+// value is finite too (the states are clamped, the arithmetic is sums and products of bounded numbers).
+SRK_DEV bool vcf_nan_free(const VcfRegs& s)
+{
+    auto fin = [](float x) { return __builtin_fabsf(x) < __builtin_inff(); };
+    return __builtin_amdgcn_ballot_w64(!(fin(s.f) && fin(s.p) && fin(s.q) && fin(s.b0) && fin(s.b1) && fin(s.b2) && fin(s.b3) && fin(s.b4))) == 0;
 }
 
 // (self.freq + cv * self.exp_amt).max(0.0).min(0.9), filter.rs:213

@@ -45,6 +45,8 @@ enum : uint32_t {
     OSC_CV_AUDIO_RATE = 1u << 8,  // the CV changes every sample (FM): do not bother caching 2^cv per CV value
     OSC_FIXED_PHASE = 1u << 10,   // pos rows and delta (rows or DevOp::delta's bit pattern) hold phase * 2^64 as u64, not f64 (fused voice kernels, default mode, saw)
     OSC_CV_STEPWISE = 1u << 9,    // host-proved: the CV is a sequencer's note CV (plus constants): constant between steps
+    OSC_CONST_SMALL = 1u << 11,   // host-proved, whatever the render mode: no CV, no sync, one live port, PolyBLEP on, every voice's delta < 0.25
+                                  // (OSC_CONST_FAST = this and not OSC_EXACT)
     // OP_VCF
     VCF_HAS_AUDIO = 1u << 0,
     VCF_HAS_CV = 1u << 1,

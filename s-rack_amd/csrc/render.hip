@@ -353,7 +353,9 @@ static void launch_fused4(bool track, const KernelArgs& ka, const ChainRoles& ro
 template <uint32_t A, uint32_t F>
 static void launch_fused3(bool exact, int out_mode, bool track, const KernelArgs& ka, const ChainRoles& roles, const CtlWork& co, dim3 grid, hipStream_t st)
 {
-    if (exact)  // exact mode is the validation flavour: one instantiation, output mode decided at run time
+    if (exact && out_mode == 3 && track)  // frames + mix, the usual request, also gets the compile-time output mode in exact mode
+        hipLaunchKernelGGL((render_voice_chain_track<A, F, true, 3>), grid, dim3(64), 0, st, ka, roles, co);
+    else if (exact)  // otherwise one instantiation, output mode decided at run time
         launch_fused4<A, F, true, 0>(track, ka, roles, co, grid, st);
     else if (out_mode == 3)
         launch_fused4<A, F, false, 3>(track, ka, roles, co, grid, st);
@@ -460,7 +462,7 @@ static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t 
 {
     if (Cp.fused == FUSED_CTL_GATE_ENV) {
         CtlWork w{kc.ops, kc.table, kc.frames + (size_t)Cp.ops[2].aux * kc.plane_stride, kc.T,
-                  Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW)};
+                  Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_EXACT)};
         hipLaunchKernelGGL(render_ctl_gate_env, dim3(1), dim3(64), 0, st, w);
     } else if (Cp.fused == FUSED_FM_PAIR) {
         ChainRoles roles{};
@@ -536,7 +538,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     auto ctl_work = [&](uint32_t t_off, uint32_t len) {
         const FlatProgram& Cp = h.prog.ctl[0];
         return CtlWork{d->ctl[0].d_ops, d->ctl[0].d_table, d->d_tracks + (size_t)Cp.ops[2].aux * T + t_off, len,
-                       Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW)};
+                       Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_EXACT)};
     };
     // chunk schedule: short first chunks (only control chunk 0 is exposed), doubling up to kChunkMax
     // With a control pipeline of depth L the first voice chunk waits for L + 1 control launches: those stay short.

@@ -1395,7 +1395,7 @@ def test_keep_state_runs_the_rack_while_the_output_is_unwired(S, oracle, flags):
     """Nothing wired into the OutputModule yet (or the output muted): the render is silence, but under keep_state the planned modules
     keep ticking as in the reference's execute() — the phases, envelopes and sample counter a later patch cable finds are the
     reference's, not frozen ones."""
-    V, B, T1, T2 = 66, 64, 1500, 1024
+    V, B, T1, T2 = 66, 64, 1536, 1024   # (whole blocks: the oracle, like the reference, only ticks in units of buffer_size)
     def build(g):
         ids = S.build_p1(g, adsr="finite", lfo_val=-3.0)
         g.disconnect(ids["out"], 0)

@@ -1,0 +1,34 @@
+#!/bin/bash
+# quick pass: parity suite + selected bench lines (arguments: names of bench variants to run)
+set -u
+OUT=gpurun_out/b
+mkdir -p $OUT
+export TMPDIR=/tmp
+( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $OUT/pytest.log 2>&1
+grep -E "passed|failed" $OUT/pytest.log | tail -3
+run() { name=$1; shift; timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu "$@" > $OUT/$name.json 2> $OUT/$name.err; echo "$name rc=$?"; python - <<PY
+import json
+try:
+    d=json.loads(open("$OUT/$name.json").read().strip().splitlines()[-1])
+    r=d["roofline"]
+    print("   ms/step %.2f  value %.3e  frac %.3f  frac_kernel %.3f  kernel %s x%d %.3f ms" % (d["ms_per_step"], d["value"], r.get("hbm",r)["frac"], r.get("hbm",r)["frac_kernel"], r["kernel"], r["launches_per_step"], r["kernel_ms"]))
+except Exception as e:
+    print("   parse failed", e)
+PY
+}
+for v in "$@"; do
+  case $v in
+    cfg3) run cfg3 ;;
+    exact) run cfg3_exact --flags 1 ;;
+    interp) run cfg3_interp --flags 2 ;;
+    interp_exact) run cfg3_interp_exact --flags 3 ;;
+    nohoist) run cfg3_nohoist --flags 4 ;;
+    nohoist_exact) run cfg3_nohoist_exact --flags 5 ;;
+    cfg2) run cfg2 --workload cfg2 ;;
+    cfg4) run cfg4 --workload cfg4 ;;
+    cfg4b) run cfg4_b1024 --workload cfg4_b1024 ;;
+    p3) run p3 --workload p3 ;;
+    p3_dist) run p3_dist --workload p3 --force-dist ;;
+    p3_interp) run p3_interp --workload p3 --flags 2 ;;
+  esac
+done
