@@ -22,8 +22,15 @@
 #ifndef SRACK_HIP_H
 #define SRACK_HIP_H
 
+#ifndef __HIPCC_RTC__ /* (device code specialised at run time sees this header through hiprtc: no libc headers there) */
 #include <stddef.h>
 #include <stdint.h>
+#else
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -164,12 +171,23 @@ enum {
     /* oscillator PolyBLEP in f64 with true division and f64 sin/pow, as the reference spells it
      * (oscillator.rs:43-67,132-152): saw/square bit-identical to the CPU tick, at ~2x VALU cost. */
     SRACK_RENDER_EXACT_OSC  = 1u << 0,
-    /* never pick a fused chain kernel; run every op through the generic tile interpreter */
+    /* never pick one of the hand-matched fused chain kernels: the patch takes the general path — a kernel specialised
+     * for the flattened program at run time (below), or the tile interpreter */
     SRACK_RENDER_NO_FUSION  = 1u << 1,
     /* do not hoist voice-invariant sub-graphs into the control track; evaluate them per lane */
     SRACK_RENDER_NO_UNIFORM_HOIST = 1u << 2,
     /* evaluate the control program as one stage instead of a pipeline of dependency depths */
-    SRACK_RENDER_NO_CTL_STAGES = 1u << 3
+    SRACK_RENDER_NO_CTL_STAGES = 1u << 3,
+    /* The general path.  A patch that matches none of the fused shapes is rendered by a kernel SPECIALISED for its flattened
+     * program: the op list is turned into one straight-line HIP kernel over the same per-module device functions (wires and
+     * module state in registers, control tracks through scalar loads, frames through buffer stores) and compiled for gfx950
+     * with hiprtc, once per program structure (parameter values are not part of it), when the program is first used
+     * (srack_render_reserve / first render: ~1 s).  By default that happens for renders of 4096 voices or more; smaller
+     * ones, programs with the one module the generator does not cover (FreeverbModule) and hosts without hiprtc use the tile
+     * interpreter, which executes the same device functions
+     * tile by tile with the wires in LDS.  Both are parity-tested against the oracle. */
+    SRACK_RENDER_NO_SPECIALIZE = 1u << 4, /* always the tile interpreter */
+    SRACK_RENDER_SPECIALIZE    = 1u << 5  /* specialise whatever the voice count (fails loudly if it cannot) */
 };
 
 typedef struct srack_patch srack_patch; /* opaque: the workspace's module list + plan + device voice state */
@@ -302,6 +320,12 @@ int srack_render(srack_patch* p, uint32_t n_samples, float* d_frames, float* d_m
  * upload the programs and the voice table, size the scratch buffers (mix partials when want_mix, control tracks) — so
  * that the first render costs what every render costs.  Renders nothing and leaves the voice state untouched. */
 int srack_render_reserve(srack_patch* p, uint32_t n_samples, int want_mix, uint32_t flags);
+
+/* Diagnostics of the specialised kernel (tests, tools): the HIP source generated for the voice program of the current patch
+ * under `flags` (returns its length, copies at most cap - 1 characters; SRACK_ERR_UNSUPPORTED if the program holds an op the
+ * generator does not cover), and its compilation for gfx950 without rendering anything (needs hiprtc, but no GPU). */
+int srack_render_kernel_source(srack_patch* p, uint32_t flags, char* buf, size_t cap);
+int srack_render_kernel_compile(srack_patch* p, uint32_t flags);
 
 /* Scratch the render needs for the mix-down partials etc. is owned by the handle; this reports it. */
 int srack_render_info(srack_patch* p, char* buf, size_t cap); /* human-readable: kernel picked, ops, rows */

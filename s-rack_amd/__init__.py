@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrack_hip.so")
 
 OK, ERR_INVALID, ERR_PORT, ERR_NO_OUTPUT, ERR_SELF_LOOP, ERR_STATE, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7, -8
-RENDER_DEFAULT, RENDER_EXACT_OSC, RENDER_NO_FUSION, RENDER_NO_UNIFORM_HOIST, RENDER_NO_CTL_STAGES = 0, 1, 2, 4, 8
+RENDER_DEFAULT, RENDER_EXACT_OSC, RENDER_NO_FUSION, RENDER_NO_UNIFORM_HOIST, RENDER_NO_CTL_STAGES, RENDER_NO_SPECIALIZE, RENDER_SPECIALIZE = 0, 1, 2, 4, 8, 16, 32
 
 # every symbol include/srack_hip.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = [
@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "srack_patch_set_module_position", "srack_patch_get_module_position", "srack_patch_set_output_buffer", "srack_patch_set_noise_seed", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
     "srack_patch_plan", "srack_patch_plan_list", "srack_patch_removed_edges", "srack_patch_delayed_edges",
     "srack_voices_configure", "srack_voices_set_field_f32", "srack_voices_set_field_f64", "srack_render_planes", "srack_render", "srack_render_reserve",
-    "srack_render_info", "srack_render_kernel_ms", "srack_voices_get_field", "srack_device_count", "srack_device_set",
+    "srack_render_info", "srack_render_kernel_source", "srack_render_kernel_compile", "srack_render_kernel_ms", "srack_voices_get_field", "srack_device_count", "srack_device_set",
     "srack_device_alloc", "srack_device_free", "srack_device_to_host", "srack_device_sync",
     "srack_dist_unique_id", "srack_dist_init", "srack_dist_comm_count", "srack_dist_destroy", "srack_dist_reduce_mix",
 ]
@@ -84,6 +84,8 @@ def _load():
     L.srack_render_reserve.argtypes = [vp, u32, i32, u32]
     L.srack_render_info.argtypes = [vp, C.c_char_p, sz]
     L.srack_render_kernel_ms.argtypes = [vp, dp, ip, i32]
+    L.srack_render_kernel_source.argtypes = [vp, u32, C.c_char_p, sz]
+    L.srack_render_kernel_compile.argtypes = [vp, u32]
     L.srack_voices_get_field.argtypes = [vp, i32, i32, dp]
     L.srack_device_count.argtypes = [ip]
     L.srack_device_set.argtypes = [i32]
@@ -326,6 +328,17 @@ class Patch:
         buf = C.create_string_buffer(512)
         _check(lib.srack_render_info(self.h, buf, 512))
         return buf.value.decode()
+
+    def kernel_source(self, flags=0):
+        """The HIP source of the voice kernel specialised for this patch (SrackError(ERR_UNSUPPORTED) if the generator cannot express it)."""
+        n = _check(lib.srack_render_kernel_source(self.h, flags, None, 0))
+        buf = C.create_string_buffer(n + 1)
+        _check(lib.srack_render_kernel_source(self.h, flags, buf, n + 1))
+        return buf.value.decode()
+
+    def kernel_compile(self, flags=0):
+        """Compile that source for gfx950 with hiprtc (no GPU needed)."""
+        _check(lib.srack_render_kernel_compile(self.h, flags))
 
     def kernel_ms(self, reset=True):
         ms, n = C.c_double(), C.c_int()

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "jit.hpp"
 #include "runtime.hpp"
 
 using namespace srack;
@@ -552,6 +553,41 @@ int srack_render_info(srack_patch* p, char* buf, size_t cap)
             buf[cap - 1] = 0;
         }
         return (int)s.size();
+    });
+}
+
+int srack_render_kernel_source(srack_patch* p, uint32_t flags, char* buf, size_t cap)
+{
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        if (p->h.n_voices == 0) {
+            set_error("render_kernel_source: call srack_voices_configure first");
+            return SRACK_ERR_STATE;
+        }
+        int rc = ensure_program(p->h, flags);
+        if (rc != SRACK_OK) return rc;
+        std::string src;
+        rc = jit_source(p->h.prog.voice, 3, src);
+        if (rc != SRACK_OK) return rc;
+        if (buf && cap) {
+            std::strncpy(buf, src.c_str(), cap - 1);
+            buf[cap - 1] = 0;
+        }
+        return (int)src.size();
+    });
+}
+
+int srack_render_kernel_compile(srack_patch* p, uint32_t flags)
+{
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        if (p->h.n_voices == 0) {
+            set_error("render_kernel_compile: call srack_voices_configure first");
+            return SRACK_ERR_STATE;
+        }
+        int rc = ensure_program(p->h, flags);
+        if (rc != SRACK_OK) return rc;
+        return jit_compile_only(p->h.prog.voice, 3);
     });
 }
 

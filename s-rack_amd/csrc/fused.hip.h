@@ -11,97 +11,7 @@
 
 #include "interp.hip.h"
 
-#ifndef SRK_FRAME_AUX
-#define SRK_FRAME_AUX 2  // cache policy of the frame stores: nt (write-once stream); tools/ builds variants with -DSRK_FRAME_AUX=
-#endif
-
 namespace srack {
-
-constexpr int kMixRows = 32;
-constexpr int kMixPitch = 68;  // floats per LDS row of the mix tile: 64 lanes + 4 of padding (see emit_flush)
-constexpr int kMixTile = kMixRows * kMixPitch;
-
-// ---- per-sample output of the fused kernels ---------------------------------------------------------------
-// kOut: 0 = decide at run time (exact-mode kernels), 1 = frames only, 2 = mix only, 3 = frames + mix.
-// Frames: SGPR row base advanced by V per sample + a constant per-lane offset; lanes past V (only in the
-// last wave) shadow voice V-1, compute the identical sample and store it to the identical address, so the
-// store needs no exec mask.  Mix: the sample goes into a 32-row LDS tile; every 32 samples (and at the end)
-// the rows are summed over the 64 lanes (emit_flush) and one lane per row writes the wave's partial.
-struct Emit {
-    float* frame_row;   // wave-uniform: this wave's 256 B of the current TILE's first frame row
-    // Frames leave through a buffer store: descriptor (SGPRs, rebuilt per tile) + per-lane byte offset (a constant VGPR) +
-    // scalar row offset advanced by V * 4 per sample — no vector arithmetic per store (a global_store needs a 64-bit
-    // v_lshl_add per sample to form its address).
-    __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t soff;      // byte offset of the current row inside the tile
-    float* mp;          // wave-uniform: mixpart row of this wave
-    bool has_frames, has_mix, full_wave;
-    int lane, lane_c;
-    uint32_t n_active;  // lanes of this wave that are real voices
-};
-
-template <int kOut>
-SRK_DEV void emit_put(Emit& e, float* mix_tile, float o, int i, uint32_t V)  // i = row of the current 32-sample tile
-{
-    const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
-    const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
-    if (frames) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), e.rsrc, e.lane_c * 4, (int)e.soff, SRK_FRAME_AUX);
-        e.soff += V * 4u;
-    }
-    if (mix) mix_tile[i * kMixPitch + e.lane] = o;  // (ds_write_addtid_b32 — no address VGPR — measured: no gain)
-}
-
-SRK_DEV void emit_rebase(Emit& e)  // point the descriptor at frame_row; a tile spans at most 32 rows = 32 * V * 4 bytes
-{
-    e.rsrc = __builtin_amdgcn_make_buffer_rsrc(e.frame_row, 0, 0x7fffffff, 0x00020000);
-    e.soff = 0u;
-}
-
-template <int kOut>
-SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n, uint32_t V)  // the tile holds samples t0 .. t0+n-1
-{
-    const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
-    if (frames) {
-        e.frame_row += (size_t)n * V;
-        emit_rebase(e);
-    }
-    const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
-    if (!mix) return;
-    if (!e.full_wave && (uint32_t)e.lane >= e.n_active)  // shadow lanes contribute nothing to the mix
-        for (int r = 0; r < kMixRows; r++) mix_tile[r * kMixPitch + e.lane] = 0.0f;
-    __syncthreads();
-    // lane l sums half (l >> 5) of row (l & 31) with eight 16-byte reads; row pitch 68 floats = 272 B keeps them 16-B aligned and
-    // spreads the 16 lanes of a ds_read_b128 group (rows r .. r+15) over all 64 banks (bank = 4 r + 4 q mod 64)
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const f4* p = (const f4*)(mix_tile + (e.lane & 31) * kMixPitch + (e.lane >> 5) * 32);
-    f4 acc = p[0];
-#pragma unroll
-    for (int q = 1; q < 8; q++) acc += p[q];
-    float sum = (acc.x + acc.y) + (acc.z + acc.w);
-    sum += __shfl_xor(sum, 32);
-    if (e.lane < n) e.mp[t0 + e.lane] = sum;
-    __syncthreads();
-}
-
-SRK_DEV Emit make_emit(const KernelArgs& a, int plane, int lane)
-{
-    using dev::WaveMap;
-    using dev::wave_map;
-    Emit e;
-    const WaveMap wm = wave_map(a, lane);
-    const uint32_t wave0 = wm.wave0;
-    e.n_active = wm.n_active;
-    e.full_wave = e.n_active == 64u;
-    e.lane = lane;
-    e.lane_c = min(lane, (int)e.n_active - 1);
-    e.frame_row = a.frames ? a.frames + (size_t)plane * a.plane_stride + wave0 : nullptr;
-    e.mp = a.mixpart ? a.mixpart + ((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride : nullptr;
-    e.has_frames = e.frame_row != nullptr;
-    e.has_mix = e.mp != nullptr;
-    emit_rebase(e);
-    return e;
-}
 
 // ---- fused control chain: OSC (constant pitch) -> ADSR -> track ---------------------------------------------
 // The voice-invariant half of patch P1's shape: one voice, one wave, every lane computes the same numbers.

@@ -12,43 +12,11 @@
 
 #include "kernel_args.hip.h"
 #include "modules.hip.h"
+#include "wave.hip.h"
 
 namespace srack {
 
 namespace dev {
-
-SRK_DEV double make_f64(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
-SRK_DEV uint32_t f64_lo(double d) { return (uint32_t)__double2loint(d); }
-SRK_DEV uint32_t f64_hi(double d) { return (uint32_t)__double2hiint(d); }
-
-struct WaveMap {   // which voices a wave owns
-    uint32_t wave0;     // first voice of the wave
-    uint32_t n_active;  // real voices in it (lanes >= n_active shadow voice wave0 + n_active - 1: same work, same stores)
-    uint32_t voice;     // this lane's voice (meaningful when active)
-    uint32_t vc;        // this lane's voice clamped to a real one (safe to load from)
-    bool active;
-};
-
-// Which group of `lanes` voices this workgroup owns.  (Tried: an XCD-aware map — workgroups are dealt to the 8 XCDs
-// round-robin, so give XCD k the k-th contiguous eighth of the voices and let neighbouring 256-B pieces of a frame row
-// leave through the same L2.  No measurable difference on the headline workload: 12.4 ms per step either way.)
-template <class Args>
-SRK_DEV uint32_t wave_index(const Args& a)
-{
-    return blockIdx.x - a.block0;
-}
-
-template <class Args>
-SRK_DEV WaveMap wave_map(const Args& a, int lane)
-{
-    WaveMap m;
-    m.wave0 = wave_index(a) * a.lanes;
-    m.n_active = min(a.lanes, a.V - m.wave0);
-    m.active = (uint32_t)lane < m.n_active;
-    m.voice = m.wave0 + (uint32_t)lane;
-    m.vc = m.active ? m.voice : m.wave0 + m.n_active - 1;
-    return m;
-}
 
 // LDS pointers carry their address space: a plain float* inside a struct handed to a noinline function degrades every
 // access to flat_load / flat_store (measured: 25 VMEM instructions and 54 % wait cycles per voice-sample).
@@ -205,10 +173,7 @@ __device__ __noinline__ void tile_osc_const(const Ctx c_v, COp& op_v)
     osc_store(c, op, o.pos, false);  // sync unconnected: `last` follows the constant 0.0 input
 }
 
-// A sequencer-driven pitch: the carried-phase oscillator between note changes.  When some lane's CV differs from the one
-// its increment was computed for (a wave-uniform test), that increment is recomputed — 440 / sr x 2^(cv + val), as
-// osc_step does — and the carried terms are rebuilt from the exact f64 phase.  An increment of 0.25 or more (or NaN)
-// breaks the carried form's "one PolyBLEP window at a time": those samples take osc_step.
+// A sequencer-driven pitch: the carried-phase oscillator between note changes (modules.hip.h, StepOsc).
 template <bool kExact>
 __device__ __noinline__ void tile_osc_stepwise(const Ctx c_v, COp& op_v)
 {
@@ -217,37 +182,17 @@ __device__ __noinline__ void tile_osc_stepwise(const Ctx c_v, COp& op_v)
     const uint32_t fl = op.flags;
     const OscSetup u = osc_setup(c, op);
     const OscConst k = u.k;
-    COsc o;
-    float seen_cv = __builtin_nanf("");
-    bool carried = false;
-    const uint32_t f = fl & ~OSC_EXACT;
+    StepOsc so;
+    steposc_init(so, u.s.pos);
     const Port cvp[1] = {in_port(c, op.in_slot[0])};
     const Port w[1] = {out_port(c, op.out_slot[(fl & OSC_OUT_SAW) ? 2 : (fl & OSC_OUT_SQUARE) ? 1 : 0])};
-    o.pos = u.s.pos;
-    o.delta = 0.0;
-    tile_run<1, 1>(c, cvp, w, [&](const float* x, float* y) {
-        const float cv = x[0];
-        if (__builtin_amdgcn_ballot_w64(cv != seen_cv) != 0) {
-            const double delta = (440.0 / k.sr) * exp2_fast((double)cv + k.val);
-            seen_cv = cv;
-            carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
-            cosc_init(o, o.pos, delta);
-        }
-        if (carried) {
-            y[0] = (fl & OSC_OUT_SAW) ? cosc_saw(o) : (fl & OSC_OUT_SQUARE) ? cosc_square(o) : cosc_sine(o);
-        } else {
-            OscRegs g;
-            g.pos = o.pos;
-            g.sync_last = false;
-            g.seen_cv = seen_cv;
-            g.seen_delta = o.delta;
-            float o3[3] = {0.0f, 0.0f, 0.0f};
-            osc_step(f, g, k, cv, 0.0f, o3[0], o3[1], o3[2]);
-            y[0] = (fl & OSC_OUT_SAW) ? o3[2] : (fl & OSC_OUT_SQUARE) ? o3[1] : o3[0];
-            cosc_init(o, g.pos, o.delta);
-        }
-    });
-    osc_store(c, op, o.pos, false);
+    if (fl & OSC_OUT_SAW)
+        tile_run<1, 1>(c, cvp, w, [&](const float* x, float* y) { y[0] = steposc_step<OSC_OUT_SAW>(so, k, x[0]); });
+    else if (fl & OSC_OUT_SQUARE)
+        tile_run<1, 1>(c, cvp, w, [&](const float* x, float* y) { y[0] = steposc_step<OSC_OUT_SQUARE>(so, k, x[0]); });
+    else
+        tile_run<1, 1>(c, cvp, w, [&](const float* x, float* y) { y[0] = steposc_step<OSC_OUT_SINE>(so, k, x[0]); });
+    osc_store(c, op, so.o.pos, false);
 }
 
 // everything else: CV at audio rate, sync, several live ports, no anti-aliasing, the exact flavour
@@ -610,25 +555,9 @@ __device__ __noinline__ void tile_sample(const Ctx c_v, COp& op_v, CArgs& a_v)
     }
 }
 
-// Sequencers (sequencer.rs:190-246, 482-533).  The 64 grid cells are wave-shared data: staged once per tile in an LDS
-// row indexed by STEP (not by lane); every lane then gathers the cell of its own current_step.
-struct SeqRegs {
-    uint32_t current_step;
-    bool step_last, sync_last;
-};
-
-SRK_DEV uint32_t seq_advance(SeqRegs& s, float step_in, float sync_in, uint32_t length)
-{
-    if (rising_edge(s.step_last, step_in)) s.current_step = (s.current_step + 1u) & 0xffffu;  // u16 in the reference
-    if (rising_edge(s.sync_last, sync_in)) s.current_step = 0u;
-    uint32_t cs = s.current_step;
-    if (cs >= length) {
-        s.current_step = 0u;
-        cs = 0u;
-    }
-    return cs;
-}
-
+// Sequencers (sequencer.rs:190-246, 482-533): the step machine and the cell decoding live in modules.hip.h.  The 64 grid cells
+// are wave-shared data: staged once per tile in an LDS row indexed by STEP (not by lane); every lane then gathers the cell
+// of its own current_step.
 template <bool kExact>
 __device__ __noinline__ void tile_seq(const Ctx c_v, COp& op_v, CArgs& a_v)
 {
@@ -652,12 +581,7 @@ __device__ __noinline__ void tile_seq(const Ctx c_v, COp& op_v, CArgs& a_v)
         const Port out[3] = {out_port(c, op.out_slot[0]), out_port(c, op.out_slot[1]), out_port(c, op.out_slot[2])};
         tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
             const uint32_t cs = seq_advance(s, x[0], x[1], length);
-            const uint32_t cell = cells[cs];
-            const bool present = cell & 0x80000000u, hold = cell & 0x40000000u;
-            y[0] = present ? (float)(cell & 0xffffu) * inv_spo : last;
-            y[1] = present ? (hold ? 1.0f : x[0]) : 0.0f;
-            y[2] = cs == 0u ? 1.0f : 0.0f;
-            last = y[0];
+            gridseq_outputs(cells[cs], cs, x[0], inv_spo, last, y[0], y[1], y[2]);
         });
         ROW(sr + GRIDSEQ_S_LAST) = __float_as_uint(last);
     } else {
@@ -692,9 +616,7 @@ __device__ __noinline__ void tile_seq(const Ctx c_v, COp& op_v, CArgs& a_v)
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
                     if (u >= m) break;
-                    const uint32_t b = (cell[u] >> (2 * (k & 7))) & 3u;
-                    const float gate = (b & 1u) ? ((b & 2u) ? 1.0f : step_in[u]) : 0.0f;
-                    out[k].p[(i + u) * out[k].stride] = k == 8 ? (first[u] ? 1.0f : 0.0f) : gate;
+                    out[k].p[(i + u) * out[k].stride] = k == 8 ? (first[u] ? 1.0f : 0.0f) : patseq_gate(cell[u], k, step_in[u]);
                 }
             }
         }

@@ -1,6 +1,8 @@
 // kernel_args.hip.h — the argument blocks shared by the kernels (interp.hip.h, fused.hip.h) and the launch code (render.hip).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <cstdint>
+#endif
 
 #include "program.hpp"
 

@@ -16,9 +16,15 @@
 //     error ~1e-7, inside the 1e-5 contract); the sine in f64 with one rounding to f32 (sine_fast); OSC_EXACT mode: f64 with true
 //     division / ocml sin / pow exactly as oscillator.rs spells them (saw and square bit-identical).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
+#ifdef __HIPCC_RTC__
+#include "srack_hip.h"
+#else
 #include "../../include/srack_hip.h"
+#endif
 #include "program.hpp"
 
 namespace srack {
@@ -32,6 +38,22 @@ SRK_DEV float keep(float x)
 {
     asm("" : "+v"(x));
     return x;
+}
+
+// The 0.0 an unconnected input reads (`None => 0.0` in every calc()).  Where a kernel is specialised for a program the port
+// flags are compile-time constants and that zero becomes a literal — and the AMDGPU backend folds `(0.0 - a) - b` into
+// `(-a) - b`, which turns +0.0 into -0.0 when a and b are both +0.0 (seen on a filter without audio input: a channel of -0.0
+// where the reference has +0.0).  Those kernels define SRK_OPAQUE_ZERO: the zero then comes out of an empty asm statement the
+// optimiser cannot see through, and the arithmetic stays the reference's.
+SRK_DEV float zero_f32()
+{
+#ifdef SRK_OPAQUE_ZERO
+    float z = 0.0f;
+    asm("" : "+v"(z));
+    return z;
+#else
+    return 0.0f;
+#endif
 }
 
 // TransitionDetector::is_transition, synth.rs:292-297
@@ -380,6 +402,49 @@ SRK_DEV float cosc_step(COsc& o)
     if (kPort == OSC_OUT_SAW) return cosc_saw(o);
     if (kPort == OSC_OUT_SQUARE) return cosc_square(o);
     return cosc_sine(o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A sequencer-driven pitch (default mode; host-proved OSC_CV_STEPWISE, PolyBLEP on, no sync, one live port): the carried-
+// phase oscillator between note changes.  When some lane's CV differs from the one its increment was computed for (a wave-
+// uniform test), that increment is recomputed — 440 / sr x 2^(cv + val), as osc_step does — and the carried terms are rebuilt
+// from the exact f64 phase.  An increment of 0.25 or more (or NaN) breaks the carried form's "one PolyBLEP window at a
+// time": those samples take osc_step.  Shared by the tile interpreter and the kernels specialised at run time.
+// ---------------------------------------------------------------------------------------------
+struct StepOsc {
+    COsc o;
+    float seen_cv;
+    bool carried;
+};
+
+SRK_DEV void steposc_init(StepOsc& s, double pos)
+{
+    s.o.pos = pos;
+    s.o.delta = 0.0;
+    s.seen_cv = __builtin_nanf("");
+    s.carried = false;
+}
+
+template <uint32_t kPort>
+SRK_DEV float steposc_step(StepOsc& s, const OscConst& k, float cv)
+{
+    COsc& o = s.o;
+    if (__builtin_amdgcn_ballot_w64(cv != s.seen_cv) != 0) {
+        const double delta = (440.0 / k.sr) * exp2_fast((double)cv + k.val);
+        s.seen_cv = cv;
+        s.carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
+        cosc_init(o, o.pos, delta);
+    }
+    if (s.carried) return cosc_step<kPort>(o);
+    OscRegs g;
+    g.pos = o.pos;
+    g.sync_last = false;
+    g.seen_cv = s.seen_cv;
+    g.seen_delta = o.delta;
+    float o3[3] = {0.0f, 0.0f, 0.0f};
+    osc_step(OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA | kPort, g, k, cv, 0.0f, o3[0], o3[1], o3[2]);
+    cosc_init(o, g.pos, o.delta);
+    return kPort == OSC_OUT_SAW ? o3[2] : (kPort == OSC_OUT_SQUARE ? o3[1] : o3[0]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -799,13 +864,13 @@ SRK_DEV float adsr_seg_step(AdsrRegs& s, const AdsrConst& c, AdsrSeg& g, float g
 // ---------------------------------------------------------------------------------------------
 SRK_DEV float vca_step(uint32_t flags, bool negative, float audio, float cv)
 {
-    if ((flags & (VCA_HAS_AUDIO | VCA_HAS_CV)) != (VCA_HAS_AUDIO | VCA_HAS_CV)) return 0.0f;  // output.fill(0.0)
+    if ((flags & (VCA_HAS_AUDIO | VCA_HAS_CV)) != (VCA_HAS_AUDIO | VCA_HAS_CV)) return zero_f32();  // output.fill(0.0)
     return (negative || cv > 0.0f) ? audio * cv : 0.0f;
 }
 
 SRK_DEV float mixer_step(uint32_t connected, const float in[4], const float gain[4])
 {
-    float out = 0.0f;  // output.fill(0.0), then one `*dst += src * gain` pass per connected input
+    float out = zero_f32();  // output.fill(0.0), then one `*dst += src * gain` pass per connected input
 #pragma unroll
     for (int k = 0; k < 4; k++)
         if (connected & (1u << k)) out = out + in[k] * gain[k];
@@ -814,7 +879,7 @@ SRK_DEV float mixer_step(uint32_t connected, const float in[4], const float gain
 
 SRK_DEV float math_step(uint32_t flags, float in1, float in2, float constant)
 {
-    float a = (flags & MATH_HAS_IN1) ? in1 : 0.0f;
+    float a = (flags & MATH_HAS_IN1) ? in1 : zero_f32();
     float b = (flags & MATH_HAS_IN2) ? in2 : constant;
     switch ((flags >> MATH_OP_SHIFT) & 3u) {
     case SRACK_MATH_ADD: return a + b;
@@ -864,7 +929,7 @@ SRK_DEV float powf_pos(float x, float b)
 
 SRK_DEV float nonlin_step(uint32_t flags, float in1, float in2, float constant)
 {
-    const float a = (flags & MATH_HAS_IN1) ? in1 : 0.0f;
+    const float a = (flags & MATH_HAS_IN1) ? in1 : zero_f32();
     const float b = (flags & MATH_HAS_IN2) ? in2 : constant;
     const bool pos = a > 0.0f;
     const float r = powf_pos(pos ? a : -a, b);
@@ -908,6 +973,43 @@ SRK_DEV float pow2f_libm(float y)
     p = z * r2 + p;
     p = p * s;
     return (float)p;                              // subnormal results round here, as in libm
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sequencers — GridSequencerModule::calc sequencer.rs:190-246, PatternSequencerModule::calc :482-533
+// ---------------------------------------------------------------------------------------------
+struct SeqRegs {
+    uint32_t current_step;
+    bool step_last, sync_last;
+};
+
+SRK_DEV uint32_t seq_advance(SeqRegs& s, float step_in, float sync_in, uint32_t length)
+{
+    if (rising_edge(s.step_last, step_in)) s.current_step = (s.current_step + 1u) & 0xffffu;  // u16 in the reference
+    if (rising_edge(s.sync_last, sync_in)) s.current_step = 0u;
+    uint32_t cs = s.current_step;
+    if (cs >= length) {
+        s.current_step = 0u;
+        cs = 0u;
+    }
+    return cs;
+}
+
+// a grid cell: bit 31 = Some, bit 30 = hold, low 16 bits = the note value; `last` = the CV held through rests
+SRK_DEV void gridseq_outputs(uint32_t cell, uint32_t cs, float step_in, float inv_spo, float& last, float& cv, float& gate, float& sync)
+{
+    const bool present = cell & 0x80000000u, hold = cell & 0x40000000u;
+    cv = present ? (float)(cell & 0xffffu) * inv_spo : last;
+    gate = present ? (hold ? 1.0f : step_in) : 0.0f;
+    sync = cs == 0u ? 1.0f : 0.0f;
+    last = cv;
+}
+
+// a pattern cell: two bits per channel (bit 0 = Some, bit 1 = held)
+SRK_DEV float patseq_gate(uint32_t cell, int channel, float step_in)
+{
+    const uint32_t b = (cell >> (2 * (channel & 7))) & 3u;
+    return (b & 1u) ? ((b & 2u) ? 1.0f : step_in) : 0.0f;
 }
 
 struct SmpRegs {

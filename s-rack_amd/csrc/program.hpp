@@ -5,7 +5,15 @@
 // tile interpreter and in a VGPR in the fused kernels.  Plain C structs: shared by host C++ and
 // device code, copied to the device verbatim.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <cstdint>
+#else  // the run-time compiler (hiprtc) has no standard headers; its fixed-width types live in a namespace of its own
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+typedef unsigned long uintptr_t;
+#endif
 
 namespace srack {
 

@@ -22,6 +22,7 @@
 
 #include "fused.hip.h"
 #include "interp.hip.h"
+#include "jit.hpp"
 #include "kernel_args.hip.h"
 #include "modules.hip.h"
 #include "runtime.hpp"
@@ -102,6 +103,8 @@ struct DeviceState {
     size_t mixgroup_bytes = 0;
     float* d_tracks = nullptr;
     size_t tracks_bytes = 0;
+    const JitKernel* jit[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the specialised voice kernel per output mode (1 frames, 2 mix, 3 both, 4 neither)
+    bool jit_failed = false;  // specialisation was tried by default and is not available: the interpreter renders
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timings;  // (start, stop) pairs of the dominant kernel, not yet read
     std::vector<hipEvent_t> pool;
     const char* kernel_name = "";
@@ -458,6 +461,30 @@ static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_
         hipLaunchKernelGGL(render_interp<false>, dim3(ka.n_waves), dim3(64), lds, st, ka);
 }
 
+// The general path: a kernel specialised for the program (jit.cpp), or the tile interpreter.  Specialising costs a compilation
+// (~1 s) the first time a program structure is seen, so by default it is reserved for renders wide enough to repay it.
+constexpr uint32_t kSpecializeMinVoices = 4096;
+static int resolve_specialized(PatchHandle& h, uint32_t flags, int out_mode, const JitKernel** out)
+{
+    *out = nullptr;
+    const FlatProgram& P = h.prog.voice;
+    DeviceState* d = h.dev;
+    if (P.fused != FUSED_NONE || (flags & SRACK_RENDER_NO_SPECIALIZE) || P.ops.empty()) return SRACK_OK;
+    const bool forced = (flags & SRACK_RENDER_SPECIALIZE) != 0;
+    if (!forced && (P.n_voices < kSpecializeMinVoices || d->jit_failed || !jit_supported(P))) return SRACK_OK;
+    if (!d->jit[out_mode]) {
+        const int rc = jit_get(P, out_mode, &d->jit[out_mode]);
+        if (rc != SRACK_OK) {
+            if (forced) return rc;  // asked for explicitly: fail loudly
+            fprintf(stderr, "[srack] no specialised kernel for this program (%s): rendering through the tile interpreter\n", last_error());
+            d->jit_failed = true;
+            return SRACK_OK;
+        }
+    }
+    *out = d->jit[out_mode];
+    return SRACK_OK;
+}
+
 static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t st)
 {
     if (Cp.fused == FUSED_CTL_GATE_ENV) {
@@ -701,6 +728,11 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         if (seq.math < 0) seq.trk_pitch = track_row(P.ops[(size_t)seq.osc].in_slot[0]);
         d->kernel_name = "render_voice_chain_seq";
     }
+    const JitKernel* special = nullptr;
+    if (P.fused == FUSED_NONE) {
+        if ((rc = resolve_specialized(h, flags, (d_frames ? 1 : 0) | (d_mix ? 2 : 0) ? (d_frames ? 1 : 0) | (d_mix ? 2 : 0) : 4, &special)) != SRACK_OK) return rc;
+        if (special) d->kernel_name = "render_specialized";
+    }
     const bool fm_pair = P.fused == FUSED_FM_PAIR;
     if (fm_pair) {  // op order fixed by the matcher: DELAY_RD, MATH_FB, OSC_M, DELAY_WR, MATH_IDX, OSC_C, OUT
         roles.adsr = 1;
@@ -751,6 +783,8 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         } else if (fm_pair) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             launch_fm_pair(P.fused_variant == 1, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, ka, roles, dim3(n_waves), st);
+        } else if (special) {
+            if ((rc = jit_launch(*special, ka, n_waves, st)) != SRACK_OK) return rc;
         } else {
             launch_interp(P, ka, st);
         }
@@ -824,6 +858,8 @@ int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t f
         if ((rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * T)) != SRACK_OK) return rc;
     }
     if (h.prog.n_tracks > 0 && (rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
+    const JitKernel* special = nullptr;  // compile now what the first render would otherwise compile (frames + mix, or frames only)
+    if (P.fused == FUSED_NONE && (rc = resolve_specialized(h, h.prog.effective_flags, want_mix ? 3 : 1, &special)) != SRACK_OK) return rc;
     return SRACK_OK;
 }
 

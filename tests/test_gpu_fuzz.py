@@ -30,14 +30,24 @@ def test_random_patch_matches_oracle(seed, noise, oracle, monkeypatch):
     ids = build(o)
     ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]
     ref, _ = o.render_batch(V, T, ov, threads=8)
-    for flags in (1, 3, 5, 7, 9, 11):  # exact oscillator x {fused, interpreter} x {hoisted (pipelined / one control unit), everything per voice}
+    # exact oscillator x {fused, interpreter} x {hoisted (pipelined / one control unit), everything per voice}, then the kernels
+    # specialised at run time (32 | 2: hoisted / per voice) for the patches the generator covers (a third of the seeds: each is a compilation)
+    for flags in (1, 3, 5, 7, 9, 11) + ((35, 39) if seed % 3 == 0 else ()):
         p = S.Patch(48000, B, 2)
         ids = build(p)
         p.configure_voices(V)
         for m, f, vals in ov:
             p.set_voice_field(m, f, vals)
         assert p.plan() == o.plan()
+        if flags & 32:
+            try:
+                p.kernel_source(flags)
+            except S.SrackError as e:
+                assert e.code == S.ERR_UNSUPPORTED  # a reverb: the interpreter's (covered above)
+                continue
         fr = p.render_channels(T, flags)
+        if flags & 32:
+            assert "render_specialized" in p.info()
         assert np.isfinite(fr).all() == np.isfinite(ref).all()
         # (a NaN is a NaN: x86's default NaN is 0xffc00000, the GPU's 0x7fc00000 — seeds 707, 774, 1000, 1157 blow up and hold thousands)
         same = (fr.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(fr) & np.isnan(ref))

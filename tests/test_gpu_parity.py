@@ -38,9 +38,13 @@ def bits(a):
 
 
 # render flags: 1 exact oscillator, 2 no fused kernels (tile interpreter), 4 no uniform hoisting (everything per voice)
-MODES = [pytest.param(0, id="fused"), pytest.param(2, id="interp"), pytest.param(1, id="fused-exact"), pytest.param(3, id="interp-exact"),
-         pytest.param(4, id="fused-nohoist"), pytest.param(6, id="interp-nohoist"), pytest.param(5, id="fused-exact-nohoist")]
-FAST_MODES = [pytest.param(0, id="fused"), pytest.param(2, id="interp"), pytest.param(4, id="fused-nohoist"), pytest.param(6, id="interp-nohoist")]
+#               32 the general path through a kernel specialised for the program at run time (with 2: instead of a fused kernel)
+MODES_BASE = [pytest.param(0, id="fused"), pytest.param(2, id="interp"), pytest.param(1, id="fused-exact"), pytest.param(3, id="interp-exact"),
+              pytest.param(4, id="fused-nohoist"), pytest.param(6, id="interp-nohoist"), pytest.param(5, id="fused-exact-nohoist")]
+MODES = MODES_BASE + [pytest.param(34, id="special"), pytest.param(35, id="special-exact"), pytest.param(38, id="special-nohoist"),
+                      pytest.param(39, id="special-exact-nohoist")]
+FAST_MODES = [pytest.param(0, id="fused"), pytest.param(2, id="interp"), pytest.param(4, id="fused-nohoist"), pytest.param(6, id="interp-nohoist"),
+              pytest.param(34, id="special"), pytest.param(38, id="special-nohoist")]
 
 
 # ---- the reference's oscillator test, through the whole GPU path --------------------------------
@@ -71,7 +75,7 @@ def test_cfg1_golden(S, adsr, flags):
     p.configure_voices(1)
     out = p.render_channels(48000, flags)
     assert ("fused=1" in p.info()) == (not flags & 2)  # one voice: nothing is hoisted
-    assert ("kernel=render_interp" in p.info()) == bool(flags & 2)
+    assert ("kernel=render_interp" in p.info()) == (flags & 34 == 2) and ("kernel=render_specialized" in p.info()) == (flags & 34 == 34)
     if flags & 1:  # exact oscillator: saw and square are pure f64 arithmetic => the whole chain is bit-identical
         np.testing.assert_array_equal(bits(out[0, :, 0]), bits(gold))
     else:
@@ -112,7 +116,7 @@ def test_p1_voices_vs_oracle_and_mix(S, oracle, V, flags):
     p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
     fr, mix = p.render(T, frames=True, mix=True, flags=flags)
     assert fr.shape == (1, T, V)
-    want = "render_interp" if flags & 2 else ("render_voice_chain" if (flags & 4 or V == 1) else "render_voice_chain_track")
+    want = "render_specialized" if flags & 34 == 34 else "render_interp" if flags & 2 else ("render_voice_chain" if (flags & 4 or V == 1) else "render_voice_chain_track")
     assert p.info().endswith("kernel=" + want), p.info()
     assert_close(fr[0], ref[0])
     # mix-down: sum over voices, checked against the f64 sum of the GPU's own frames and of the oracle's
@@ -959,7 +963,7 @@ FV_PARAMS = [pytest.param((), True, id="defaults"),
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", MODES)
+@pytest.mark.parametrize("flags", MODES_BASE)   # (the reverb is not covered by the kernel generator: the interpreter renders it)
 @pytest.mark.parametrize("params,right", FV_PARAMS)
 def test_freeverb_per_voice_vs_oracle(S, oracle, params, right, flags):
     """Per-voice detune in front of the reverb => one reverb per voice (24 delay lines each, in HBM)."""

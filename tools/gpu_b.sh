@@ -4,7 +4,7 @@ set -u
 OUT=gpurun_out/b
 mkdir -p $OUT
 export TMPDIR=/tmp
-( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $OUT/pytest.log 2>&1
+( time timeout 1500 python -m pytest tests -m gpu -q ) > $OUT/pytest.log 2>&1
 grep -E "passed|failed" $OUT/pytest.log | tail -3
 run() { name=$1; shift; timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu "$@" > $OUT/$name.json 2> $OUT/$name.err; echo "$name rc=$?"; python - <<PY
 import json
