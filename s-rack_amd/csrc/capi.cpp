@@ -567,7 +567,7 @@ int srack_render_kernel_source(srack_patch* p, uint32_t flags, char* buf, size_t
         int rc = ensure_program(p->h, flags);
         if (rc != SRACK_OK) return rc;
         std::string src;
-        rc = jit_source(p->h.prog.voice, 3, src);
+        rc = jit_source(p->h.prog, 3, jit_ctl_supported(p->h.prog), src);
         if (rc != SRACK_OK) return rc;
         if (buf && cap) {
             std::strncpy(buf, src.c_str(), cap - 1);
@@ -587,7 +587,7 @@ int srack_render_kernel_compile(srack_patch* p, uint32_t flags)
         }
         int rc = ensure_program(p->h, flags);
         if (rc != SRACK_OK) return rc;
-        return jit_compile_only(p->h.prog.voice, 3);
+        return jit_compile_only(p->h.prog, 3, jit_ctl_supported(p->h.prog));
     });
 }
 

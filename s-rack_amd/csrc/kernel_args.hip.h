@@ -26,6 +26,9 @@ struct KernelArgs {
     uint32_t block0;  // blocks [0, block0) of the grid are not voice waves (a co-scheduled control block); wave = blockIdx.x - block0
     uint64_t n0;  // absolute index of this launch's first sample (phase of the feedback rings)
     double* fv;   // OP_FREEVERB blocks: rows of V doubles (program.hpp), zero at n0 = 0 (may be null)
+    // Kernels specialised at run time only (jit.cpp): blocks [0, block0) of a launch are the control program's units, block b
+    // running unit b on the chunk ctl_slots[b] describes (T == 0: nothing to do in this launch).
+    const KernelArgs* ctl_slots;
 };
 
 struct ChainRoles {  // op indices of the fused voice chain (osc_l / adsr unused in the track variant)

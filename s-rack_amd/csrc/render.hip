@@ -48,6 +48,7 @@ struct Knobs {
     uint32_t chunk_max = 4096;   // samples per launch; measured on the headline workload: 4096 -> 13.98, 8192 -> 14.14, 16384 -> 14.8 ms per step
     bool debug_occ = false;
     int high_prio_ctl = 1;       // the control stream is created with the highest priority (its own pool of hardware queues)
+    int special_ctl = 1;         // specialised kernels carry the control program's units (0: control program on its own stream)
 };
 static const Knobs& knobs()
 {
@@ -65,6 +66,7 @@ static const Knobs& knobs()
         v.chunk_max = (uint32_t)num("SRACK_CHUNK_MAX", 256, 65536, 4096);
         v.debug_occ = getenv("SRACK_DEBUG_OCC") != nullptr;
         v.high_prio_ctl = (int)num("SRACK_CTL_HIGH_PRIO", 0, 1, 1);
+        v.special_ctl = (int)num("SRACK_SPECIAL_CTL", 0, 1, 1);
         return v;
     }();
     return k;
@@ -464,24 +466,33 @@ static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_
 // The general path: a kernel specialised for the program (jit.cpp), or the tile interpreter.  Specialising costs a compilation
 // (~1 s) the first time a program structure is seen, so by default it is reserved for renders wide enough to repay it.
 constexpr uint32_t kSpecializeMinVoices = 4096;
-static int resolve_specialized(PatchHandle& h, uint32_t flags, int out_mode, const JitKernel** out)
+// Which programs take a specialised kernel: those no hand-written kernel matches, and two shapes whose hand-written kernels the
+// specialised ones outrun on MI355X (P1 with everything per voice: 21.2 -> 18.1 ms per step; the sequencer-driven chain P3:
+// 29.5 -> 24.5).  The flagship track kernel and the FM pair keep their hand-written kernels.
+static bool specializable_shape(int fused) { return fused == FUSED_NONE || fused == FUSED_VOICE_CHAIN || fused == FUSED_VOICE_CHAIN_SEQ; }
+
+static int resolve_specialized(PatchHandle& h, uint32_t flags, int out_mode, const JitKernel** out, bool* with_ctl)
 {
     *out = nullptr;
+    *with_ctl = false;
     const FlatProgram& P = h.prog.voice;
     DeviceState* d = h.dev;
-    if (P.fused != FUSED_NONE || (flags & SRACK_RENDER_NO_SPECIALIZE) || P.ops.empty()) return SRACK_OK;
+    if (!specializable_shape(P.fused) || (flags & SRACK_RENDER_NO_SPECIALIZE) || P.ops.empty()) return SRACK_OK;
     const bool forced = (flags & SRACK_RENDER_SPECIALIZE) != 0;
     if (!forced && (P.n_voices < kSpecializeMinVoices || d->jit_failed || !jit_supported(P))) return SRACK_OK;
+    // the control program's units ride along in the same launches whenever the generator covers them all
+    const bool ctl = h.prog.n_tracks > 0 && knobs().special_ctl && jit_ctl_supported(h.prog);
     if (!d->jit[out_mode]) {
-        const int rc = jit_get(P, out_mode, &d->jit[out_mode]);
+        const int rc = jit_get(h.prog, out_mode, ctl, &d->jit[out_mode]);
         if (rc != SRACK_OK) {
             if (forced) return rc;  // asked for explicitly: fail loudly
-            fprintf(stderr, "[srack] no specialised kernel for this program (%s): rendering through the tile interpreter\n", last_error());
+            fprintf(stderr, "[srack] no specialised kernel for this program (%s): rendering through the pre-built kernels\n", last_error());
             d->jit_failed = true;
             return SRACK_OK;
         }
     }
     *out = d->jit[out_mode];
+    *with_ctl = ctl;
     return SRACK_OK;
 }
 
@@ -597,7 +608,66 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     };
 
     if (has_ctl && (rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
-    if (co_ctl) {  // chunk 0's track: the only control work that is not hidden (1024 samples, ~0.15 ms)
+    const JitKernel* special = nullptr;  // a kernel specialised for this program (jit.cpp), if the program takes one
+    bool special_ctl = false;            // ... with the control program's units as extra blocks of every launch
+    {
+        const int om = (d_frames ? 1 : 0) | (d_mix ? 2 : 0);
+        if ((rc = resolve_specialized(h, flags, om ? om : 4, &special, &special_ctl)) != SRACK_OK) return rc;
+    }
+    // One argument block per (launch, control unit): launch j runs unit s on chunk j - lag[s]; chunk c is complete after launch
+    // c + max_lag.  (A control program that was not cut into units is one unit with lag 0.)
+    auto stage_args = [&](uint32_t s, uint32_t k) {
+        const uint32_t t_off = chunks[k].first, len = chunks[k].second;
+        KernelArgs kc{};
+        kc.ops = d->ctl[s].d_ops;
+        kc.prog = h.prog.ctl[s].hdr;
+        kc.table = d->ctl[s].d_table;
+        kc.rings = d->ctl[s].d_rings;
+        kc.seqtab = d->ctl[s].d_seqtab;
+        kc.fv = d->ctl[s].d_fv;
+        kc.frames = d->d_tracks + t_off;  // the control program's planes are the tracks: [n_tracks][T][1]
+        kc.tracks = d->d_tracks + t_off;  // ... and later stages read earlier stages' tracks from the same buffer
+        kc.plane_stride = T;
+        kc.t_stride = T;
+        kc.V = 1;
+        kc.T = len;
+        kc.n_waves = 1;
+        kc.lanes = 64;
+        kc.n0 = h.samples_rendered + t_off;
+        return kc;
+    };
+    const uint32_t n_ctl_launch = n_chunks + max_lag;
+    auto upload_stage_slots = [&](hipStream_t on) -> int {
+        d->h_stage_slots.assign((size_t)n_ctl_launch * n_stages, KernelArgs{});
+        for (uint32_t s2 = 0; s2 < n_stages; s2++)
+            for (uint32_t k = 0; k < n_chunks; k++) {
+                KernelArgs& slot = d->h_stage_slots[(size_t)(k + (uint32_t)h.prog.ctl_lag[s2]) * n_stages + s2];
+                slot = stage_args(s2, k);
+                slot.block0 = s2;  // the unit's one wave is wave 0 of its program
+            }
+        const size_t bytes = sizeof(KernelArgs) * d->h_stage_slots.size();
+        if (bytes > d->stage_slots_cap) {
+            (void)hipFree(d->d_stage_slots);
+            d->d_stage_slots = nullptr;
+            d->stage_slots_cap = 0;
+            HIP_TRY(hipMalloc(&d->d_stage_slots, bytes));
+            d->stage_slots_cap = bytes;
+        }
+        HIP_TRY(hipMemcpyAsync(d->d_stage_slots, d->h_stage_slots.data(), bytes, hipMemcpyHostToDevice, on));
+        return SRACK_OK;
+    };
+    if (special && special_ctl) {
+        // Co-scheduled control units: everything on the caller's stream.  Launches 0 .. max_lag of the control pipeline run alone
+        // (they complete chunk 0: the only exposed control work, kept short by the 1024-sample first chunks); voice launch k then
+        // carries control launch k + max_lag + 1 as its first blocks, which completes chunk k + 1 while chunk k is consumed.
+        if ((rc = upload_stage_slots(st)) != SRACK_OK) return rc;
+        for (uint32_t j = 0; j <= max_lag && j < n_ctl_launch; j++) {
+            KernelArgs kp{};
+            kp.block0 = n_stages;
+            kp.ctl_slots = d->d_stage_slots + (size_t)j * n_stages;
+            if ((rc = jit_launch(*special, kp, n_stages, st)) != SRACK_OK) return rc;
+        }
+    } else if (co_ctl) {  // chunk 0's track: the only control work that is not hidden (1024 samples, ~0.15 ms)
         hipLaunchKernelGGL(render_ctl_gate_env, dim3(1), dim3(64), 0, st, ctl_work(chunks[0].first, chunks[0].second));
         HIP_TRY(hipGetLastError());
     } else if (has_ctl) {
@@ -620,50 +690,15 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         // the track buffer may still be read by the previous render on `st`: start after it
         HIP_TRY(hipEventRecord(d->ev_begin, st));
         HIP_TRY(hipStreamWaitEvent(d->ctl_stream, d->ev_begin, 0));
-        auto stage_args = [&](uint32_t s, uint32_t k) {
-            const uint32_t t_off = chunks[k].first, len = chunks[k].second;
-            KernelArgs kc{};
-            kc.ops = d->ctl[s].d_ops;
-            kc.prog = h.prog.ctl[s].hdr;
-            kc.table = d->ctl[s].d_table;
-            kc.rings = d->ctl[s].d_rings;
-            kc.seqtab = d->ctl[s].d_seqtab;
-            kc.fv = d->ctl[s].d_fv;
-            kc.frames = d->d_tracks + t_off;  // the control program's planes are the tracks: [n_tracks][T][1]
-            kc.tracks = d->d_tracks + t_off;  // ... and later stages read earlier stages' tracks from the same buffer
-            kc.plane_stride = T;
-            kc.t_stride = T;
-            kc.V = 1;
-            kc.T = len;
-            kc.n_waves = 1;
-            kc.lanes = 64;
-            kc.n0 = h.samples_rendered + t_off;
-            return kc;
-        };
         const bool staged = h.prog.ctl[0].fused == FUSED_NONE;  // the interpreter: all stages side by side in one launch
         if (staged) {
-            // launch j runs unit s on chunk j - lag[s]; chunk c is complete after launch c + max_lag
-            const uint32_t n_launch = n_chunks + max_lag;
-            d->h_stage_slots.assign((size_t)n_launch * n_stages, KernelArgs{});
+            const uint32_t n_launch = n_ctl_launch;
             size_t lds = 0;
-            for (uint32_t s = 0; s < n_stages; s++) {
-                const DevProgram& H = h.prog.ctl[s].hdr;
+            for (uint32_t s2 = 0; s2 < n_stages; s2++) {
+                const DevProgram& H = h.prog.ctl[s2].hdr;
                 lds = std::max(lds, ((size_t)H.n_rows + 2 + (size_t)H.n_tracks + (size_t)H.n_slots * H.tile) * 256);
-                for (uint32_t k = 0; k < n_chunks; k++) {
-                    KernelArgs& slot = d->h_stage_slots[(size_t)(k + (uint32_t)h.prog.ctl_lag[s]) * n_stages + s];
-                    slot = stage_args(s, k);
-                    slot.block0 = s;  // the stage's one wave is wave 0 of its program
-                }
             }
-            const size_t bytes = sizeof(KernelArgs) * d->h_stage_slots.size();
-            if (bytes > d->stage_slots_cap) {
-                (void)hipFree(d->d_stage_slots);
-                d->d_stage_slots = nullptr;
-                d->stage_slots_cap = 0;
-                HIP_TRY(hipMalloc(&d->d_stage_slots, bytes));
-                d->stage_slots_cap = bytes;
-            }
-            HIP_TRY(hipMemcpyAsync(d->d_stage_slots, d->h_stage_slots.data(), bytes, hipMemcpyHostToDevice, d->ctl_stream));
+            if ((rc = upload_stage_slots(d->ctl_stream)) != SRACK_OK) return rc;
             for (uint32_t j = 0; j < n_launch; j++) {
                 const KernelArgs* slots = d->d_stage_slots + (size_t)j * n_stages;
                 if (flags & SRACK_RENDER_EXACT_OSC)
@@ -728,11 +763,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         if (seq.math < 0) seq.trk_pitch = track_row(P.ops[(size_t)seq.osc].in_slot[0]);
         d->kernel_name = "render_voice_chain_seq";
     }
-    const JitKernel* special = nullptr;
-    if (P.fused == FUSED_NONE) {
-        if ((rc = resolve_specialized(h, flags, (d_frames ? 1 : 0) | (d_mix ? 2 : 0) ? (d_frames ? 1 : 0) | (d_mix ? 2 : 0) : 4, &special)) != SRACK_OK) return rc;
-        if (special) d->kernel_name = "render_specialized";
-    }
+    if (special) d->kernel_name = "render_specialized";
     const bool fm_pair = P.fused == FUSED_FM_PAIR;
     if (fm_pair) {  // op order fixed by the matcher: DELAY_RD, MATH_FB, OSC_M, DELAY_WR, MATH_IDX, OSC_C, OUT
         roles.adsr = 1;
@@ -767,14 +798,20 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
             co = ctl_work(chunks[k + 1].first, chunks[k + 1].second);
             ka.block0 = 1;
         }
-        if (has_ctl && !co_ctl) HIP_TRY(hipStreamWaitEvent(st, d->ev_chunk[k], 0));
+        if (has_ctl && !co_ctl && !(special && special_ctl)) HIP_TRY(hipStreamWaitEvent(st, d->ev_chunk[k], 0));
+        if (special && special_ctl && k + max_lag + 1 < n_ctl_launch) {  // this launch's first blocks: the control units' next launch
+            ka.block0 = n_stages;
+            ka.ctl_slots = d->d_stage_slots + (size_t)(k + max_lag + 1) * n_stages;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = h.timing_armed;  // only a host that asked for srack_render_kernel_ms pays for the event pair
         if (timed) {
             if ((rc = get_event(e0)) != SRACK_OK || (rc = get_event(e1)) != SRACK_OK) return rc;
             HIP_TRY(hipEventRecord(e0, st));
         }
-        if (fused) {
+        if (special) {
+            if ((rc = jit_launch(*special, ka, n_waves + ka.block0, st)) != SRACK_OK) return rc;
+        } else if (fused) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             launch_fused(osc_port, vcf_port, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, track, ka, roles, co, dim3(n_waves + ka.block0), st);
         } else if (seq_chain) {
@@ -783,8 +820,6 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         } else if (fm_pair) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             launch_fm_pair(P.fused_variant == 1, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, ka, roles, dim3(n_waves), st);
-        } else if (special) {
-            if ((rc = jit_launch(*special, ka, n_waves, st)) != SRACK_OK) return rc;
         } else {
             launch_interp(P, ka, st);
         }
@@ -859,7 +894,8 @@ int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t f
     }
     if (h.prog.n_tracks > 0 && (rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
     const JitKernel* special = nullptr;  // compile now what the first render would otherwise compile (frames + mix, or frames only)
-    if (P.fused == FUSED_NONE && (rc = resolve_specialized(h, h.prog.effective_flags, want_mix ? 3 : 1, &special)) != SRACK_OK) return rc;
+    bool special_ctl = false;
+    if ((rc = resolve_specialized(h, h.prog.effective_flags, want_mix ? 3 : 1, &special, &special_ctl)) != SRACK_OK) return rc;
     return SRACK_OK;
 }
 

@@ -22,6 +22,8 @@ SRK_DEV double make_f64(uint32_t lo, uint32_t hi) { return __hiloint2double((int
 SRK_DEV uint32_t f64_lo(double d) { return (uint32_t)__double2loint(d); }
 SRK_DEV uint32_t f64_hi(double d) { return (uint32_t)__double2hiint(d); }
 
+SRK_DEV float readlane_f32(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }  // `lane` wave-uniform
+
 struct WaveMap {   // which voices a wave owns
     uint32_t wave0;     // first voice of the wave
     uint32_t n_active;  // real voices in it (lanes >= n_active shadow voice wave0 + n_active - 1: same work, same stores)

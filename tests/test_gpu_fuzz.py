@@ -65,7 +65,18 @@ def test_random_patch_renders_continue_across_calls(seed, noise):
     V, T = 70, 2600
     cuts = sorted(int(c) for c in rng.choice(np.arange(1, T), size=2, replace=False))
     values = [(m, f, fn(V)) for m, f, fn in overrides]  # drawn once: the generators are stateful
-    for flags in (0, 2, 4, 1):
+    for flags in (0, 2, 4, 1) + ((34, 39) if seed % 4 == 0 else ()):  # ... and through the specialised kernels (the interpreter renders what they do not cover)
+        if flags & 32:
+            p = S.Patch(48000, B, 2)
+            ids = build(p)
+            p.configure_voices(V)
+            for m, f, vals in values:
+                p.set_voice_field(ids[m], f, vals)
+            try:
+                p.kernel_source(flags)
+            except S.SrackError as e:
+                assert e.code == S.ERR_UNSUPPORTED
+                continue
         outs = []
         for parts in ([T], [cuts[0], cuts[1] - cuts[0], T - cuts[1]]):
             p = S.Patch(48000, B, 2)

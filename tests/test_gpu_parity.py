@@ -495,7 +495,9 @@ def test_render_without_outputs_still_advances_state(S):
 
 # ---- scope table (f) rank 1: sequencer-driven patch ---------------------------------------------------------------
 @pytest.mark.parametrize("flags", [pytest.param(0, id="hoist"), pytest.param(4, id="nohoist"), pytest.param(1, id="exact"), pytest.param(2, id="hoist-interp"),
-                                   pytest.param(8, id="hoist-one-control-unit"), pytest.param(10, id="hoist-interp-one-control-unit")])
+                                   pytest.param(8, id="hoist-one-control-unit"), pytest.param(10, id="hoist-interp-one-control-unit"),
+                                   pytest.param(32, id="special"), pytest.param(34, id="special-nofusion"), pytest.param(35, id="special-exact"),
+                                   pytest.param(42, id="special-one-control-unit"), pytest.param(38, id="special-nohoist")])
 def test_p3_sequencers_vs_oracle(S, oracle, flags):
     V, T = 150, 12000
     transpose = np.linspace(-2.0, 0.5, V).astype(np.float32)
@@ -514,6 +516,8 @@ def test_p3_sequencers_vs_oracle(S, oracle, flags):
     if not flags & 4:  # five pipelined control units, or one when staging is off
         assert p.info().count("ctl[") == (1 if flags & 8 else 5)
         assert ("fused=5" in p.info()) == (not flags & 3)
+    if flags & 32:  # the specialised kernel, with the control units as the first blocks of its launches
+        assert "kernel=render_specialized" in p.info()
     assert_close(fr[0], ref[0])
     np.testing.assert_array_equal(fr[1], ref[1])  # a raw pattern gate: exactly 0.0 / 1.0 / the clock's square
     scale = np.abs(ref.astype(np.float64)).sum(axis=2)
@@ -547,7 +551,8 @@ def test_p3_extreme_transpose_takes_the_literal_oscillator(S, oracle, flags):
     np.testing.assert_array_equal(fr[1], ref[1])
 
 
-@pytest.mark.parametrize("flags", [pytest.param(0, id="fused-pipelined"), pytest.param(2, id="interp-pipelined"), pytest.param(8, id="fused-one-unit")])
+@pytest.mark.parametrize("flags", [pytest.param(0, id="fused-pipelined"), pytest.param(2, id="interp-pipelined"), pytest.param(8, id="fused-one-unit"),
+                                   pytest.param(32, id="special-pipelined"), pytest.param(40, id="special-one-unit")])
 def test_p3_render_continues_across_calls(S, flags):
     """The control pipeline fills and drains inside every call: render(T) == render(a) ++ render(b) ++ ..., bit for bit,
     for call lengths around the chunk sizes (1024 x depth, then doubling) and tiles."""
@@ -617,7 +622,8 @@ def _p4_pair(S, oracle, V, T, B=1024, **kw):
     return p, ids, ref, ref_mix
 
 
-@pytest.mark.parametrize("flags", [pytest.param(1, id="exact"), pytest.param(5, id="exact-nohoist")])
+@pytest.mark.parametrize("flags", [pytest.param(1, id="exact"), pytest.param(5, id="exact-nohoist"), pytest.param(35, id="special-exact"),
+                                   pytest.param(39, id="special-exact-nohoist")])
 def test_p4_sample_nonlinear_vs_oracle(S, oracle, flags):
     """With the exact oscillator the vibrato CV has the oracle's bits, so the read position — an index — must too."""
     V, T = 130, 9000
@@ -852,7 +858,7 @@ def test_long_render_crosses_segments_with_a_control_pipeline(S, oracle):
     o = oracle.OraclePatch(48000, 1024, 2)
     ids = S.build_p3(o)
     ref, _ = o.render_batch(V, T, [(ids["transpose"], S.MATH_CONSTANT, transpose)], threads=8)
-    for flags in (0, 2):
+    for flags in (0, 2, 32):
         p = S.Patch(48000, 1024, 2)
         S.build_p3(p)
         p.configure_voices(V)

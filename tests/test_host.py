@@ -358,3 +358,83 @@ def test_hostile_numbers_and_lists_do_not_crash(S):
     arr = (C.c_int * 2)(0, 1)
     out = (C.c_int * 8)()
     assert S.lib.srack_patch_plan_list(p.h, ids["out"], arr, -5, out, 8) == S.ERR_INVALID
+
+
+# ---- the kernel generator of the general path (jit.cpp), as far as it goes without a GPU: source + compilation for gfx950 ----------
+def _have_hiprtc():
+    import ctypes
+    for name in ("libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"):
+        try:
+            ctypes.CDLL(name)
+            return True
+        except OSError:
+            pass
+    return False
+
+
+def test_specialised_kernel_source_of_p1_and_p3(S):
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p1(p)
+    p.configure_voices(128)
+    det, cut = S.p1_voice_params(128)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    src = p.kernel_source(S.RENDER_NO_FUSION)
+    assert 'extern "C" __global__' in src and "srk_voice(KernelArgs a)" in src
+    assert "cosc_step<0x20u>" in src and "vcf_step<true>" in src and "emit_put<KOUT>" in src  # the carried-phase saw, the default-mode ladder
+    assert "srk_ctl0" in src and "adsr_seg_step" in src and "a.ctl_slots[blockIdx.x]" in src   # the gate -> envelope unit rides along
+    assert "rowf(14)" in src and "a.ops[1].par_val[2]" in src                               # per-voice cutoff from its row, uniform exp_amt from the op list
+    exact = p.kernel_source(S.RENDER_NO_FUSION | S.RENDER_EXACT_OSC)
+    assert "vcf_step<false>" in exact and "osc_step(" in exact
+    # parameter VALUES are not part of the kernel: an edit does not ask for another compilation
+    p.set_field(ids["vcf"], S.VCF_RES, 0.7)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut[::-1].copy())
+    assert p.kernel_source(S.RENDER_NO_FUSION) == src
+    q = S.Patch(48000, 1024, 2)
+    qi = S.build_p3(q)
+    q.configure_voices(70)
+    q.set_voice_field(qi["transpose"], S.MATH_CONSTANT, np.linspace(-1, 0, 70).astype(np.float32))
+    src3 = q.kernel_source(0)
+    assert src3.count("static __device__ __forceinline__ void srk_ctl") == 5 and "steposc_step<0x20u>" in src3 and "emit_track_put" in src3
+    assert "seq_advance" in src3 and "readlane_f32(trk" in src3
+    r = S.Patch(48000, 64, 2)   # the one module the generator leaves to the interpreter
+    v, o = r.add_module(S.MOD_FREEVERB), r.add_module(S.MOD_OUTPUT)
+    r.connect(v, 0, o, 0)
+    r.configure_voices(4)
+    with pytest.raises(S.SrackError) as e:
+        r.kernel_source(S.RENDER_NO_UNIFORM_HOIST)
+    assert e.value.code == S.ERR_UNSUPPORTED
+
+
+@pytest.mark.skipif(not _have_hiprtc(), reason="no libhiprtc on this host")
+def test_specialised_kernels_compile_for_gfx950(S):
+    """hiprtc cross-compiles without a GPU: the generated source of the BASELINE patches and of a few random ones (rings of every
+    size class, sequencers and a sample player per voice) must at least be valid HIP for the library's target."""
+    from tests.fuzz_patches import random_patch
+    cases = []
+    for B in (1, 7, 24, 1024):
+        p = S.Patch(48000, B, 2)
+        S.build_p2(p)
+        p.configure_voices(64)
+        cases.append((p, S.RENDER_NO_FUSION))
+    p = S.Patch(48000, 1024, 2)
+    S.build_p4(p)
+    p.configure_voices(64)
+    cases.append((p, S.RENDER_NO_UNIFORM_HOIST))
+    for seed in (0, 3, 9):
+        B, build, overrides = random_patch(seed)
+        for flags in (3, 7):
+            p = S.Patch(48000, B, 2)
+            ids = build(p)
+            p.configure_voices(70)
+            for m, f, fn in overrides:
+                p.set_voice_field(ids[m], f, fn(70))
+            cases.append((p, flags))
+    n = 0
+    for p, flags in cases:
+        try:
+            p.kernel_compile(flags)
+            n += 1
+        except S.SrackError as e:
+            assert e.code == S.ERR_UNSUPPORTED, str(e)[:2000]
+    assert n >= 9

@@ -4,7 +4,7 @@ set -u
 OUT=gpurun_out/b
 mkdir -p $OUT
 export TMPDIR=/tmp
-( time timeout 1500 python -m pytest tests -m gpu -q ) > $OUT/pytest.log 2>&1
+( time timeout 1500 python -m pytest tests -m gpu -q ${PYTEST_ARGS:-} ) > $OUT/pytest.log 2>&1
 grep -E "passed|failed" $OUT/pytest.log | tail -3
 run() { name=$1; shift; timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu "$@" > $OUT/$name.json 2> $OUT/$name.err; echo "$name rc=$?"; python - <<PY
 import json
@@ -30,5 +30,15 @@ for v in "$@"; do
     p3) run p3 --workload p3 ;;
     p3_dist) run p3_dist --workload p3 --force-dist ;;
     p3_interp) run p3_interp --workload p3 --flags 2 ;;
+  esac
+done
+for v in "$@"; do
+  case $v in
+    special_nohoist) run cfg3_special_nohoist --flags 6 ;;
+    p3_special) run p3_special --workload p3 --flags 2 ;;
+    cfg4_special) run cfg4_special --workload cfg4 --flags 2 ;;
+    cfg4b_special) run cfg4b_special --workload cfg4_b1024 --flags 2 ;;
+    cfg2_special) run cfg2_special --workload cfg2 --flags 34 ;;
+    interp_only) run cfg3_interp_only --flags 18 ;;
   esac
 done
