@@ -45,9 +45,13 @@ BYTES_PER_VOICE_SAMPLE = 4   # one f32 frame per voice per sample per distinct o
 # Vector f64 issue ceiling: 256 CUs x 4 SIMDs x 16 lanes per clock (half the f32 rate) x 2.4 GHz = 39.3e12 lane-operations/s
 # (the spec's 78.6 TFLOP/s counts an FMA as two).
 F64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
-# f64 VALU instructions per voice-sample in the loop body of render_fm_pair<false, 3> (two oscillators with CV: 2^x series +
-# sine polynomial + phase accumulate each), counted in the gfx950 ISA by tools/isa_count.py; profiles/ holds the listing.
-FM_PAIR_F64_OPS = {"render_fm_pair": None, "render_fm_pair_ring": None}
+# f64-rate VALU instructions per voice-sample in the loop body of render_fm_pair<false, 3> (two oscillators with CV: the 2^x
+# polynomial, the sine polynomial, phase accumulate and wrap, converts and compares on doubles), counted in the gfx950 ISA
+# (hipcc -S of render.hip; the listing is reproduced in DESIGN.md section 4).  tools/ubench.hip measures the pipe itself:
+# v_fma_f64 saturates at 33.3 T lane-ops/s on this part (8 waves per SIMD), and ONE wave per SIMD — all that 65 536 voices
+# give — reaches 25-30 T with 4-8 independent chains.
+FM_PAIR_F64_OPS = {"render_fm_pair": 60, "render_fm_pair_ring": 60}
+F64_LANE_OPS_MEASURED = 33.3e12
 
 WORKLOADS = ("cfg3", "cfg2", "cfg4", "cfg4_b1024", "p3")
 
@@ -386,8 +390,8 @@ def run_rank(args, backend_cls=HipBackend):
             lane_ops = ops * V * T / step_s
             out["roofline"].update({
                 "bound": "valu_f64", "achieved": lane_ops / 1e12, "peak": F64_LANE_OPS_PEAK / 1e12, "unit": "T f64 lane-ops/s",
-                "frac": lane_ops / F64_LANE_OPS_PEAK, "f64_ops_per_voice_sample": ops,
-                "definition": "f64 VALU instructions per voice-sample of the kernel's loop body (ISA count, tools/isa_count.py) x voice-samples/s, "
+                "frac": lane_ops / F64_LANE_OPS_PEAK, "frac_of_measured_f64_rate": lane_ops / F64_LANE_OPS_MEASURED, "f64_ops_per_voice_sample": ops,
+                "definition": "f64-rate VALU instructions per voice-sample of the kernel's loop body (ISA count) x voice-samples/s, "
                               "against 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz",
                 "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "achieved_kernel": achieved_kernel, "frac_kernel": achieved_kernel / HBM_PEAK_GBS},

@@ -74,6 +74,7 @@ struct Analysis {  // whole-graph facts shared by both programs
     std::vector<uint32_t> port_live;
     std::vector<char> in_ctl;
     std::vector<int> stage;                          // per module: control stage (>= 0) or -1 = voice program
+    std::vector<char> sine_loose;                    // per oscillator: its sine port cannot reach a pitch input (OSC_SINE_LOOSE)
     std::vector<std::pair<int, int>> tracks;         // (module, port) exported by a control stage
     std::map<std::pair<int, int>, int> track_of;
 };
@@ -270,6 +271,7 @@ int Builder::build()
             if (pl & 2u) op.flags |= OSC_OUT_SQUARE;
             if (pl & 4u) op.flags |= OSC_OUT_SAW;
             if (render_flags & SRACK_RENDER_EXACT_OSC) op.flags |= OSC_EXACT;
+            if (A.sine_loose[(size_t)m]) op.flags |= OSC_SINE_LOOSE;
             op.sample_rate = (double)g.cfg.sample_rate;  // `self.sample_rate as f64`, u16 in the reference
             {   // pos: f64 state, two rows (lo, hi)
                 const VoiceOverride* o = find_override(m, SRACK_OSC_POS);
@@ -724,7 +726,7 @@ void Builder::match_fused(bool has_rings)
         auto is_track = [](int slot) { return slot >= kTrackSlot; };
         const uint32_t ports = osc->flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
         const uint32_t vcf_ports = vcf->flags & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP);
-        bool ok = (osc->flags & ~(OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1));
+        bool ok = (osc->flags & ~(OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_SINE_LOOSE)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1));
         if (ok && math)
             ok = src_of(osc->module, 0).src == math->module && (math->flags & (MATH_HAS_IN1 | MATH_HAS_IN2)) == MATH_HAS_IN1 && is_track(math->in_slot[0]);
         else if (ok)
@@ -953,7 +955,7 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
     // square that modulates a pitch grows with time (measured: 2e-4 on the carrier's saw after one second of
     // feed-forward FM from a 1760 Hz saw).  Such patches are rendered with the exact oscillator throughout.  (The sine
     // port is exempt: its default evaluation already carries the reference's own half-ulp error.)
-    if (!(render_flags & SRACK_RENDER_EXACT_OSC)) {
+    {
         // Which outputs carry an input's VALUE on (as opposed to its sign: gates, sync and step inputs are thresholds)?
         auto carried_to = [&](int type, int in_port) -> uint32_t {  // mask of output ports
             switch (type) {
@@ -973,31 +975,47 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             const int t = g.modules[(size_t)module].type;
             return (t == SRACK_MOD_OSCILLATOR && port == SRACK_OSC_IN_CV) || (t == SRACK_MOD_SAMPLE && port == SRACK_SAMPLE_IN_CV);
         };
+        // Does a value that starts on the given output ports reach a pitch input (port by port through the graph)?
+        auto reaches_pitch = [&](std::vector<uint32_t> tainted) {
+            for (bool changed = true; changed;) {
+                changed = false;
+                for (int k = 0; k < n_mod; k++) {
+                    if (!A.live[(size_t)k]) continue;
+                    const Module& sink = g.modules[(size_t)k];
+                    for (int port = 0; port < sink.n_in; port++) {
+                        const InputRef& in = sink.in[(size_t)port];
+                        if (in.src < 0 || !(tainted[(size_t)in.src] & (1u << in.port))) continue;
+                        if (is_pitch_input(k, port)) return true;
+                        const uint32_t add = carried_to(sink.type, port) & ~tainted[(size_t)k];
+                        if (add) {
+                            tainted[(size_t)k] |= add;
+                            changed = true;
+                        }
+                    }
+                }
+            }
+            return false;
+        };
+        // An oscillator's sine port that cannot reach a pitch may be evaluated in f32 in the default mode (modules.hip.h, sine_loose).
+        A.sine_loose.assign((size_t)n_mod, 0);
+        if (!(render_flags & SRACK_RENDER_EXACT_OSC))
+            for (int m = 0; m < n_mod; m++)
+                if (A.live[(size_t)m] && g.modules[(size_t)m].type == SRACK_MOD_OSCILLATOR && (A.port_live[(size_t)m] & 1u)) {
+                    std::vector<uint32_t> from((size_t)n_mod, 0u);
+                    from[(size_t)m] = 1u;
+                    A.sine_loose[(size_t)m] = !reaches_pitch(from);
+                }
+      if (!(render_flags & SRACK_RENDER_EXACT_OSC)) {
         std::vector<uint32_t> tainted((size_t)n_mod, 0u);  // per module: output ports that carry an approximated saw / square value
         for (int m = 0; m < n_mod; m++) {
             if (!A.live[(size_t)m]) continue;
             if (g.modules[(size_t)m].type == SRACK_MOD_OSCILLATOR) tainted[(size_t)m] = A.port_live[(size_t)m] & 6u;   // square, saw
             if (g.modules[(size_t)m].type == SRACK_MOD_MOOG_FILTER) tainted[(size_t)m] = A.port_live[(size_t)m] & 7u;  // the fma-contracted ladder
         }
-        bool drives_pitch = false;
-        for (bool changed = true; changed && !drives_pitch;) {
-            changed = false;
-            for (int k = 0; k < n_mod && !drives_pitch; k++) {
-                if (!A.live[(size_t)k]) continue;
-                const Module& sink = g.modules[(size_t)k];
-                for (int port = 0; port < sink.n_in; port++) {
-                    const InputRef& in = sink.in[(size_t)port];
-                    if (in.src < 0 || !(tainted[(size_t)in.src] & (1u << in.port))) continue;
-                    if (is_pitch_input(k, port)) drives_pitch = true;
-                    const uint32_t add = carried_to(sink.type, port) & ~tainted[(size_t)k];
-                    if (add) {
-                        tainted[(size_t)k] |= add;
-                        changed = true;
-                    }
-                }
-            }
+        if (reaches_pitch(tainted)) {
+            render_flags |= SRACK_RENDER_EXACT_OSC;
+            std::fill(A.sine_loose.begin(), A.sine_loose.end(), 0);  // (the exact oscillator has one sine)
         }
-        if (drives_pitch) render_flags |= SRACK_RENDER_EXACT_OSC;
         // The other amplifier of a 1e-7: a ladder filter close to self-oscillation.  Its feedback gain q grows with the resonance, and
         // from ~0.93 up (tools/shape_soak.py: 7 of 150 random P1 parameter sets, all with res >= 0.928, a few voices each, up to 3e-3)
         // the fma-contracted ladder of the default mode leaves the 1e-5 band although every stage is closer to the real-number
@@ -1008,8 +1026,12 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             for (const auto& o : overrides)
                 if (o.module == m && o.field == SRACK_VCF_RES)
                     for (double v : o.values) res = std::max(res, v);
-            if (res >= 0.9) render_flags |= SRACK_RENDER_EXACT_OSC;
+            if (res >= 0.9) {
+                render_flags |= SRACK_RENDER_EXACT_OSC;
+                std::fill(A.sine_loose.begin(), A.sine_loose.end(), 0);
+            }
         }
+      }
     }
     out.effective_flags = render_flags;
 

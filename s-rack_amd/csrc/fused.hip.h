@@ -695,6 +695,7 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
     const int ring_row = r.track;        // the z^-1 ring: one state row
 
     constexpr uint32_t fo = OSC_HAS_CV | OSC_CV_AUDIO_RATE | OSC_AA | OSC_OUT_SINE | (kExact ? OSC_EXACT : 0u);
+    constexpr uint32_t fo_carrier = fo | OSC_SINE_LOOSE;  // the carrier's sine only feeds the OutputModule (the matched shape): nothing integrates it
     OscRegs sm, sc;
     OscConst km, kc;
     sm.pos = make_f64(row(om.state_row + OSC_S_POS_LO), row(om.state_row + OSC_S_POS_HI));
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
         for (int i = 0; i < n; i++) {
             const float cur = sine_m;  // OSC_M.sine[t]: feeds the carrier now and, through the z^-1 ring, the modulator of t+1
             float out = 0.0f;
-            osc_step(fo, sc, kc, cur * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
+            osc_step(fo_carrier, sc, kc, cur * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
             pos_m = sm.pos;
             osc_step(fo, sm, km, cur * c_fb, 0.0f, sine_m, sq, sw);   // modulator of sample t+1 (independent of the carrier)
             fed = cur;
@@ -769,6 +770,7 @@ __global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRol
     float* ring = a.rings + (size_t)r.track * B * V;  // r.track: the ring's id
 
     constexpr uint32_t fo = OSC_HAS_CV | OSC_CV_AUDIO_RATE | OSC_AA | OSC_OUT_SINE | (kExact ? OSC_EXACT : 0u);
+    constexpr uint32_t fo_carrier = fo | OSC_SINE_LOOSE;  // the carrier's sine only feeds the OutputModule (the matched shape): nothing integrates it
     OscRegs sm, sc;
     OscConst km, kc;
     sm.pos = make_f64(row(om.state_row + OSC_S_POS_LO), row(om.state_row + OSC_S_POS_HI));
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRol
             osc_step(fo, sm, km, fed[i] * c_fb, 0.0f, sine_m, sq, sw);   // modulator of sample t
             const uint32_t p = p0 + (uint32_t)i < B ? p0 + (uint32_t)i : p0 + (uint32_t)i - B;
             if (active) ring[(size_t)p * V + voice] = sine_m;
-            osc_step(fo, sc, kc, sine_m * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
+            osc_step(fo_carrier, sc, kc, sine_m * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
             emit_put<kOut>(em, mix_tile, out, i, V);
         };
         if (n == kMixRows) {

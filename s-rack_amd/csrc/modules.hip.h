@@ -85,25 +85,27 @@ struct OscConst {    // per-voice constants, set up once per kernel (or tile)
     float inv_dt;    // 1 / f32(delta) for the f32 PolyBLEP (constant pitch)
 };
 
-// 2^x in f64 for the CV path of the default mode: x = n + f, |f| <= 1/2, degree-10 Taylor series of 2^f
-// (truncation (ln2/2)^11/11! ~ 2e-13 relative), scaled by 2^n with ldexp.  The phase increment needs ~1e-10
-// relative accuracy to keep the accumulated phase error of a 1 s render below 1e-7 cycles; this leaves three
-// orders of magnitude.  Overflow / NaN propagate through ldexp like pow's.
+// 2^x in f64 for the CV path of the default mode: x = n + f, |f| <= 1/2, a degree-8 polynomial for 2^f (Chebyshev
+// interpolant: max relative error 1.1e-12 on the interval), scaled by 2^n with ldexp.  The phase increment needs ~1e-10
+// relative accuracy to keep the accumulated phase error of a 1 s render below 1e-7 cycles; this leaves two orders of
+// magnitude.  Evaluated by Estrin's scheme — 8 fma + 3 mul with a dependency depth of 4 instead of Horner's 10: the FM
+// kernels run ONE wave per SIMD, where the length of the per-sample dependency chain, not the instruction count, sets the
+// pace.  Overflow / NaN propagate through ldexp like pow's.
 SRK_DEV double exp2_fast(double x)
 {
     const double n = __builtin_rint(x);
     const double f = x - n;
-    double p = 7.0549116208011233299e-09;                 // ln2^10 / 10!
-    p = __builtin_fma(p, f, 1.0178086009239699728e-07);   // ln2^9 / 9!
-    p = __builtin_fma(p, f, 1.3215486790144309488e-06);   // ln2^8 / 8!
-    p = __builtin_fma(p, f, 1.5252733804059840280e-05);   // ln2^7 / 7!
-    p = __builtin_fma(p, f, 1.5403530393381609954e-04);   // ln2^6 / 6!
-    p = __builtin_fma(p, f, 1.3333558146428443423e-03);   // ln2^5 / 5!
-    p = __builtin_fma(p, f, 9.6181291076284771619e-03);   // ln2^4 / 4!
-    p = __builtin_fma(p, f, 5.5504108664821579953e-02);   // ln2^3 / 3!
-    p = __builtin_fma(p, f, 2.4022650695910071233e-01);   // ln2^2 / 2!
-    p = __builtin_fma(p, f, 6.9314718055994530942e-01);   // ln2
-    p = __builtin_fma(p, f, 1.0);
+    const double f2 = f * f;
+    const double a01 = __builtin_fma(0.6931471805459332, f, 1.0000000000000004);
+    const double a23 = __builtin_fma(0.055504109412108156, f, 0.24022650695814518);
+    const double a45 = __builtin_fma(0.0013333450563173552, f, 0.009618129159053034);
+    const double a67 = __builtin_fma(1.5310080611926545e-05, f, 0.00015403456082633648);
+    const double f4 = f2 * f2;
+    const double b0 = __builtin_fma(a23, f2, a01);
+    const double b1 = __builtin_fma(a67, f2, a45);
+    const double f8 = f4 * f4;
+    const double c = __builtin_fma(b1, f4, b0);
+    const double p = __builtin_fma(1.3255179556479267e-06, f8, c);
     return __builtin_ldexp(p, (int)n);
 }
 
@@ -211,26 +213,43 @@ SRK_DEV float poly_blep_sel(float t, float tm1, float inv_dt, bool first, bool s
 }
 
 // sin(2*pi*pos), pos in [0,1), as the reference's `(pos * PI * 2.0).sin() as f32` (oscillator.rs:133) up to the final
-// rounding: folded to a quarter wave exactly (f64 subtractions of values in [-0.5, 0.5]), odd Taylor polynomial of
-// degree 15 in f64 (truncation 6e-12 at |x| = 1/4), ONE rounding to f32.  The result is the correctly rounded f32 sine
-// except within ~1e-11 of a rounding boundary — i.e. it has the reference's own, unbiased, half-ulp error.  That matters
-// because a sine that feeds a pitch CV (FM, vibrato) is INTEGRATED by the next oscillator's phase: an f32 evaluation
-// (6e-8, biased) let config 4 drift to 5e-5 after one second; with this one default mode stays at f32 rounding level.
-SRK_DEV float sine_fast(double pos)
+// rounding: folded to a quarter wave exactly (f64 subtractions of values in [-0.5, 0.5]), an odd polynomial of degree 13 in
+// f64 (Chebyshev interpolant of sin(2 pi x) / x in x^2: max error 8e-14 on |x| <= 1/4; Estrin's scheme, dependency depth 3),
+// ONE rounding to f32.  The result is the correctly rounded f32 sine except within ~1e-13 of a rounding boundary — i.e. it
+// has the reference's own, unbiased, half-ulp error.  That matters because a sine that feeds a pitch CV (FM, vibrato) is
+// INTEGRATED by the next oscillator's phase: an f32 evaluation (6e-8, biased) let config 4 drift to 5e-5 after one second;
+// with this one default mode stays at f32 rounding level.
+SRK_DEV double sine_fold(double pos)  // x in [-1/4, 1/4] with sin(2 pi pos) = -sin(2 pi x)
 {
     const double q = pos - 0.5;                          // [-0.5, 0.5); sin(2 pi pos) = -sin(2 pi q)
     const double r = __builtin_copysign(0.5, q) - q;     // reflection: sin(2 pi q) = sin(2 pi r) for |q| > 1/4
-    const double x = __builtin_fabs(q) > 0.25 ? r : q;
-    const double x2 = x * x;
-    double p = -0.7181223017785006;                      // -(2 pi)^15 / 15!
-    p = __builtin_fma(p, x2, 3.819952584848282);         //  (2 pi)^13 / 13!
-    p = __builtin_fma(p, x2, -15.09464257682299);        // -(2 pi)^11 / 11!
-    p = __builtin_fma(p, x2, 42.058693944897655);        //  (2 pi)^9 / 9!
-    p = __builtin_fma(p, x2, -76.70585975306139);        // -(2 pi)^7 / 7!
-    p = __builtin_fma(p, x2, 81.60524927607506);         //  (2 pi)^5 / 5!
-    p = __builtin_fma(p, x2, -41.34170224039976);        // -(2 pi)^3 / 3!
-    p = __builtin_fma(p, x2, 6.283185307179586);         //  2 pi
+    return __builtin_fabs(q) > 0.25 ? r : q;
+}
+SRK_DEV float sine_fast(double pos)
+{
+    const double x = sine_fold(pos);
+    const double z = x * x;
+    const double a01 = __builtin_fma(-41.34170223990684, z, 6.283185307179272);
+    const double a23 = __builtin_fma(-76.70584757807868, z, 81.60524914955879);
+    const double a45 = __builtin_fma(-15.081496425342264, z, 42.05813586028645);
+    const double z2 = z * z;
+    const double b0 = __builtin_fma(a23, z2, a01);
+    const double b1 = __builtin_fma(3.6659216216293173, z2, a45);
+    const double z4 = z2 * z2;
+    const double p = __builtin_fma(b1, z4, b0);
     return (float)(-(p * x));
+}
+// The same sine for a port whose value cannot reach a pitch input (host-proved, OSC_SINE_LOOSE): nothing integrates its error,
+// so f32 arithmetic after the exact f64 fold is inside the 1e-5 contract (max error 2e-7: a degree-9 polynomial in f32).
+SRK_DEV float sine_loose(double pos)
+{
+    const float x = (float)sine_fold(pos);
+    const float z = x * x;
+    const float a01 = __builtin_fmaf(-41.34168243408203f, z, 6.2831854820251465f);
+    const float a23 = __builtin_fmaf(-76.58116912841797f, z, 81.60247802734375f);
+    const float z2 = z * z;
+    const float p = __builtin_fmaf(__builtin_fmaf(39.75982666015625f, z2, a23), z2, a01);
+    return -(p * x);
 }
 
 SRK_DEV double wrap01(double x)
@@ -284,7 +303,7 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
     }
     float inv_dt = c.inv_dt;
     if (flags & OSC_HAS_CV) inv_dt = 1.0f / (float)delta;
-    if (flags & OSC_OUT_SINE) sine = sine_fast(pos);
+    if (flags & OSC_OUT_SINE) sine = (flags & OSC_SINE_LOOSE) ? sine_loose(pos) : sine_fast(pos);
     if (flags & (OSC_OUT_SQUARE | OSC_OUT_SAW)) {
         const float p32 = (float)pos;            // `self.pos as f32`
         float blep0 = 0.0f;

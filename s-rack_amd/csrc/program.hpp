@@ -53,6 +53,8 @@ enum : uint32_t {
     OSC_CV_AUDIO_RATE = 1u << 8,  // the CV changes every sample (FM): do not bother caching 2^cv per CV value
     OSC_FIXED_PHASE = 1u << 10,   // pos rows and delta (rows or DevOp::delta's bit pattern) hold phase * 2^64 as u64, not f64 (fused voice kernels, default mode, saw)
     OSC_CV_STEPWISE = 1u << 9,    // host-proved: the CV is a sequencer's note CV (plus constants): constant between steps
+    OSC_SINE_LOOSE = 1u << 12,    // host-proved: the sine port's value cannot reach a pitch input (an oscillator's or the sample player's CV), so
+                                  // nothing integrates its rounding: default mode may evaluate it in f32 after the exact f64 fold
     OSC_CONST_SMALL = 1u << 11,   // host-proved, whatever the render mode: no CV, no sync, one live port, PolyBLEP on, every voice's delta < 0.25
                                   // (OSC_CONST_FAST = this and not OSC_EXACT)
     // OP_VCF

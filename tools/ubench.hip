@@ -173,5 +173,13 @@ int main()
     for (int w : {1, 2, 4, 8}) run_occ<0, 4>("v_fma_f32 4 chains", d_out, w);
     for (int w : {1, 4}) run_occ<1, 1>("v_add_f64 dep", d_out, w);
     for (int w : {1, 4}) run_occ<6, 1>("v_med3_f32 dep", d_out, w);
+    // f64 at the occupancy of the FM kernels (65 536 voices = one wave per SIMD): how many independent chains fill the pipe?
+    for (int w : {1, 2, 4}) run_occ<2, 1>("v_fma_f64 dep", d_out, w);
+    for (int w : {1, 2, 4}) run_occ<2, 2>("v_fma_f64 2 chains", d_out, w);
+    for (int w : {1, 2, 4}) run_occ<2, 4>("v_fma_f64 4 chains", d_out, w);
+    for (int w : {1, 2}) run_occ<2, 8>("v_fma_f64 8 chains", d_out, w);
+    for (int w : {1, 4}) run_occ<12, 4>("v_mul_f64 4 chains", d_out, w);
+    for (int w : {1, 4}) run_occ<5, 4>("v_floor_f64 4 chains", d_out, w);
+    for (int w : {1, 4}) run_occ<4, 4>("v_cvt_f32_f64 4 chains", d_out, w);
     return 0;
 }
