@@ -302,7 +302,8 @@ def profiled_traffic(kernel_name, workload, V, T):
         except (OSError, ValueError):
             continue
         for name, v in d.get("derived", {}).items():
-            if kernel_name and kernel_name in name and "hbm_traffic_bytes" in v:
+            # (a kernel specialised at run time appears under its entry point's name in the profiler)
+            if kernel_name and (kernel_name in name or (kernel_name == "render_specialized" and name.startswith("srk_voice"))) and "hbm_traffic_bytes" in v:
                 best = {"bytes_per_launch": v["hbm_traffic_bytes"], "write": v.get("hbm_write_bytes"),
                         "read_corrected": v.get("hbm_read_bytes_gfx950_corrected"), "source": "profiles/" + base}
     return best

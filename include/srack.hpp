@@ -166,6 +166,45 @@ private:
     srack_patch* p_ = nullptr;
 };
 
+// The multi-GPU half (no reference counterpart: s-rack is single-threaded, main.rs:59-63): one process per GPU, voices sharded by
+// global voice index, and one collective — the sum of the per-rank partial mixes.  Rank 0 makes the id, the host carries its
+// 128 bytes to every rank, every rank constructs a MixComm with its device already selected (srack_device_set).
+class MixComm {
+public:
+    static std::string unique_id()
+    {
+        std::string id((size_t)SRACK_DIST_ID_BYTES, '\0');
+        const int rc = srack_dist_unique_id(&id[0]);
+        if (rc < 0) throw Error(rc, srack_last_error());
+        return id;
+    }
+    MixComm(const std::string& id, int n_ranks, int rank)
+    {
+        if (id.size() != (size_t)SRACK_DIST_ID_BYTES) throw Error(SRACK_ERR_INVALID, "MixComm: the id is SRACK_DIST_ID_BYTES bytes");
+        const int rc = srack_dist_init(id.data(), n_ranks, rank, &comm_);
+        if (rc < 0) throw Error(rc, srack_last_error());
+    }
+    MixComm(const MixComm&) = delete;
+    MixComm& operator=(const MixComm&) = delete;
+    ~MixComm() { srack_dist_destroy(comm_); }
+    int count() const
+    {
+        int n = 0;
+        const int rc = srack_dist_comm_count(comm_, &n);
+        if (rc < 0) throw Error(rc, srack_last_error());
+        return n;
+    }
+    // ncclReduce(sum, f32) of `count` floats at device pointer d_mix, in place, asynchronous on `stream`
+    void reduce_mix(float* d_mix, size_t count, int root = 0, void* stream = nullptr)
+    {
+        const int rc = srack_dist_reduce_mix(comm_, d_mix, count, root, stream);
+        if (rc < 0) throw Error(rc, srack_last_error());
+    }
+
+private:
+    void* comm_ = nullptr;
+};
+
 inline std::string SharedSynthModule::get_name() const
 {
     static const char* names[] = {"Output", "Oscillator", "Moog Filter", "ADSR", "VCA", "Mono Mixer", "Math",

@@ -41,8 +41,30 @@ mod ffi {
         pub fn srack_device_alloc(d_ptr: *mut *mut c_void, bytes: usize) -> c_int;
         pub fn srack_device_free(d_ptr: *mut c_void) -> c_int;
         pub fn srack_device_to_host(h_dst: *mut c_void, d_src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
+        pub fn srack_device_set(device: c_int) -> c_int;
+        pub fn srack_render_reserve(p: *mut SrackPatch, n_samples: u32, want_mix: c_int, flags: u32) -> c_int;
+        pub fn srack_dist_unique_id(id_out: *mut u8) -> c_int;
+        pub fn srack_dist_init(id: *const u8, n_ranks: c_int, rank: c_int, comm_out: *mut *mut c_void) -> c_int;
+        pub fn srack_dist_comm_count(comm: *mut c_void, n_ranks: *mut c_int) -> c_int;
+        pub fn srack_dist_reduce_mix(comm: *mut c_void, d_mix: *mut f32, count: usize, root: c_int, stream: *mut c_void) -> c_int;
+        pub fn srack_dist_destroy(comm: *mut c_void) -> c_int;
     }
 }
+
+/// Render flags (values of `SRACK_RENDER_*`).
+pub mod render_flags {
+    pub const DEFAULT: u32 = 0;
+    pub const EXACT_OSC: u32 = 1 << 0;
+    pub const NO_FUSION: u32 = 1 << 1;
+    pub const NO_UNIFORM_HOIST: u32 = 1 << 2;
+    pub const NO_CTL_STAGES: u32 = 1 << 3;
+    /// the general path always through the tile interpreter
+    pub const NO_SPECIALIZE: u32 = 1 << 4;
+    /// the general path through a kernel specialised for the program, whatever the voice count
+    pub const SPECIALIZE: u32 = 1 << 5;
+}
+
+pub const DIST_ID_BYTES: usize = 128;
 
 /// Module types of the hot path (values of `SRACK_MOD_*`).
 #[repr(i32)]
@@ -204,6 +226,41 @@ impl Drop for Patch {
 
 pub fn abi_version() -> i32 {
     unsafe { ffi::srack_abi_version() }
+}
+
+/// The multi-GPU half: one process per GPU, voices sharded by global voice index, and ONE collective — the RCCL sum of the
+/// per-rank partial mixes.  (No reference counterpart: s-rack is single-threaded, src/main.rs:59-63.)
+/// Rank 0 makes the id; the host carries its 128 bytes to every rank; every rank calls `MixComm::new` with its device selected.
+pub struct MixComm {
+    raw: *mut c_void,
+}
+
+impl MixComm {
+    pub fn unique_id() -> Result<[u8; DIST_ID_BYTES], Error> {
+        let mut id = [0u8; DIST_ID_BYTES];
+        check(unsafe { ffi::srack_dist_unique_id(id.as_mut_ptr()) })?;
+        Ok(id)
+    }
+    pub fn new(id: &[u8; DIST_ID_BYTES], n_ranks: i32, rank: i32) -> Result<Self, Error> {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { ffi::srack_dist_init(id.as_ptr(), n_ranks, rank, &mut raw) })?;
+        Ok(MixComm { raw })
+    }
+    pub fn count(&self) -> Result<i32, Error> {
+        let mut n = 0;
+        check(unsafe { ffi::srack_dist_comm_count(self.raw, &mut n) })?;
+        Ok(n)
+    }
+    /// ncclReduce(sum, f32) of the `[channels][n_samples]` partial mix, in place, on the default stream.
+    pub fn reduce_mix(&self, mix: &DeviceBuffer, count: usize, root: i32) -> Result<(), Error> {
+        check(unsafe { ffi::srack_dist_reduce_mix(self.raw, mix.as_f32(), count, root, std::ptr::null_mut()) }).map(|_| ())
+    }
+}
+
+impl Drop for MixComm {
+    fn drop(&mut self) {
+        unsafe { ffi::srack_dist_destroy(self.raw) };
+    }
 }
 
 #[cfg(test)]

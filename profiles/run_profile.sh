@@ -12,6 +12,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu ${2:-}"
+# the un-profiled bench line of the same configuration (more steps; cpu_baseline only for the headline tag)
+python $ROOT/bench.py --steps 10 --warmup 3 ${3:---no-cpu} ${2:-} > $ROOT/profiles/${TAG}_bench.json 2> $OUT/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq.log 2>&1

@@ -614,7 +614,7 @@ int Builder::build()
     // A wave's module chains are latency-bound, so a round of resident waves costs nearly the same whether the CU
     // holds 4 or 15 of them; what costs is another round, and a tile's fixed work (op fields, state rows in and out,
     // the call) paid more often when tiles are short.  The model is fitted to P1 through the interpreter on MI355X
-    // (tools/occ_probe.sh): a round with r waves per CU takes 17 + 0.7 r (ms at 48 000 samples), the last round holds
+    // (measured with SRACK_TILE_MAX sweeps in round 1): a round with r waves per CU takes 17 + 0.7 r (ms at 48 000 samples), the last round holds
     // the remainder, a tile's fixed work is worth ~8 samples, and a CU that would be exactly full spills a few waves
     // into an extra, nearly empty round.  It predicts the measured times of eleven (tile, voices) pairs within 15 %
     // after a common scale, which is all a choice between tile lengths needs.

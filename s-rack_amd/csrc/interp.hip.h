@@ -770,7 +770,7 @@ SRK_DEV void interp_body(dev::CArgs& a)
     // over the staged window tile by tile.  The load's latency is exposed (nothing can be in flight across the calls of the
     // tile functions), so it is paid once per 64 samples instead of once per tile (tile = 12: 750 instead of 4000 round trips
     // per second of audio; worth 2 % on P1 through the interpreter — the per-call overhead of the tile functions is the
-    // larger cost there: tools/interp_ops.py).
+    // larger cost there).
     dev::lds_f32* const trk_base = c.trk;
     uint32_t staged_t0 = 0, staged_n = 0;
     for (uint32_t t0 = 0; t0 < a.T; t0 += (uint32_t)tile) {

@@ -119,15 +119,51 @@ static int produces_440()
     return 0;
 }
 
+// The multi-GPU surface with one rank (a 1-GPU box): unique id -> communicator -> count -> the mix reduce through it.
+static int one_rank_mix_comm()
+{
+    AudioConfig ac;
+    ac.sample_rate = 48000;
+    ac.buffer_size = 64;
+    ac.channels = 2;
+    Workspace ws(ac);
+    SharedSynthModule osc = ws.add(ModuleType::Oscillator);
+    SharedSynthModule out = ws.add(ModuleType::Output);
+    REQUIRE(out.set_input(0, osc, SRACK_OSC_OUT_SAW));
+    REQUIRE(out.set_input(1, osc, SRACK_OSC_OUT_SAW));
+    ws.configure_voices(100);
+    const uint32_t T = 512;
+    float *d_mix = nullptr, *d_mix2 = nullptr;
+    ws.check(srack_device_alloc((void**)&d_mix, 2 * T * sizeof(float)));
+    ws.check(srack_device_alloc((void**)&d_mix2, 2 * T * sizeof(float)));
+    ws.execute_batch(T, nullptr, d_mix);
+    std::vector<float> before(2 * T), after(2 * T);
+    ws.check(srack_device_to_host(before.data(), d_mix, before.size() * sizeof(float), nullptr));
+    MixComm comm(MixComm::unique_id(), 1, 0);
+    if (comm.count() != 1) return 1;
+    comm.reduce_mix(d_mix, 2 * T, 0, nullptr);
+    ws.check(srack_device_to_host(after.data(), d_mix, after.size() * sizeof(float), nullptr));
+    for (size_t i = 0; i < before.size(); i++)
+        if (before[i] != after[i]) return 1;  // a sum over one rank is the identity
+    float peak = 0.0f;
+    for (float v : before) peak = std::fmax(peak, std::fabs(v));
+    if (!(peak > 10.0f)) return 1;  // 100 saws in phase
+    srack_device_free(d_mix);
+    srack_device_free(d_mix2);
+    std::printf("one_rank_mix_comm ok\n");
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     try {
         if (argc > 1 && !std::strcmp(argv[1], "topo")) return topological_sort();
         if (argc > 1 && !std::strcmp(argv[1], "dco")) return produces_440();
+        if (argc > 1 && !std::strcmp(argv[1], "dist")) return one_rank_mix_comm();
     } catch (const Error& e) {
         std::printf("srack::Error %d: %s\n", e.code, e.what());
         return 2;
     }
-    std::printf("usage: test_mirror topo|dco\n");
+    std::printf("usage: test_mirror topo|dco|dist\n");
     return 3;
 }

@@ -30,3 +30,11 @@ def test_produces_440_cpp(mirror_bin):
     r = subprocess.run([mirror_bin, "dco"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "produces_440 ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_one_rank_mix_comm_cpp(mirror_bin):
+    """srack_dist_unique_id / init / comm_count / reduce_mix / destroy from a compiled C++ host (include/srack.hpp: MixComm)."""
+    r = subprocess.run([mirror_bin, "dist"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "one_rank_mix_comm ok" in r.stdout

@@ -18,6 +18,8 @@ for noise in (False, True):
                 try:
                     p.info() if False else p.reserve(64, True, flags)
                     p.get_voice_field(ids[0], 0)
+                    if seed % 5 == 0:
+                        p.kernel_source(flags)   # the kernel generator (source only: no compilation)
                     data = p.save_srk()
                     q = S.Patch.load_srk(data, 48000, B, 2)
                     q.configure_voices(V); q.reserve(64, True, flags)
