@@ -165,6 +165,8 @@ class HipBackend:
             raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
+        if S.lib.srack_device_set(local_rank) != 0:  # the library renders on the calling thread's current device: say it in its own words too
+            raise SystemExit("srack_device_set(%d): %s" % (local_rank, S.lib.srack_last_error().decode(errors="replace")))
         self.args, self.world, self.rank = args, world, rank
         V, T, C = args.voices, args.samples, 2
         w = args.workload

@@ -401,6 +401,51 @@ def test_cfg3_exactly_as_benchmarked(S, oracle):
     assert (np.abs(mix[0].astype(np.float64) - own) <= 1e-5 * np.maximum(scale, 1.0)).all() and np.array_equal(mix[0], mix[1])
 
 
+@pytest.mark.parametrize("B,kernel", [(1, "render_fm_pair"), (1024, "render_fm_pair")])
+def test_cfg4_exactly_as_benchmarked(S, oracle, B, kernel):
+    """BASELINE config 4 at full size, the workload `bench.py --workload cfg4` (and cfg4_b1024) times: 65 536 voices x 48 000
+    samples of the 2-operator FM patch with its feedback edge, per-voice feedback / index (12.6 GB of frames, kept on the device),
+    default mode.  37 sampled voices against the oracle for the whole second — the feedback makes every error an integrated
+    one — and the mix against an f64 sum of all the frames."""
+    import ctypes as C
+    V, T = 65536, 48000
+    beta, index = S.p2_voice_params(V)
+    p = S.Patch(48000, B, 2)
+    ids = S.build_p2(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, beta)
+    p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
+    d_fr, d_mx = C.c_void_p(), C.c_void_p()
+    assert S.lib.srack_device_alloc(C.byref(d_fr), T * V * 4) == 0 and S.lib.srack_device_alloc(C.byref(d_mx), 2 * T * 4) == 0
+    try:
+        p.render_raw(T, d_fr, d_mx, 0, None)
+        assert S.lib.srack_device_sync(None) == 0
+        assert "kernel=" + kernel in p.info()
+        pick = np.unique(np.concatenate([np.arange(0, V, 2113), [0, 63, 64, V - 65, V - 64, V - 1]]))
+        got = np.empty((T, len(pick)), dtype=np.float32)
+        own, scale = np.empty(T), np.empty(T)
+        rows = 1024
+        buf = np.empty((rows, V), dtype=np.float32)
+        for t0 in range(0, T, rows):
+            n = min(rows, T - t0)
+            assert S.lib.srack_device_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + t0 * V * 4), n * V * 4, None) == 0
+            assert S.lib.srack_device_sync(None) == 0
+            got[t0:t0 + n] = buf[:n, pick]
+            own[t0:t0 + n] = buf[:n].sum(axis=1, dtype=np.float64)
+            scale[t0:t0 + n] = np.abs(buf[:n]).sum(axis=1, dtype=np.float64)
+        mix = np.empty((2, T), dtype=np.float32)
+        assert S.lib.srack_device_to_host(mix.ctypes.data_as(C.c_void_p), d_mx, mix.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
+    finally:
+        S.lib.srack_device_free(d_fr)
+        S.lib.srack_device_free(d_mx)
+    o = oracle.OraclePatch(48000, B, 2)
+    S.build_p2(o)
+    ref, _ = o.render_batch(len(pick), T, [(ids["mul_fb"], S.MATH_CONSTANT, beta[pick]), (ids["mul_idx"], S.MATH_CONSTANT, index[pick])], threads=8)
+    assert assert_close(got, ref[0]) < 3e-6   # (the carrier's sine is evaluated in f32 after the exact fold: 2e-7, not integrated by anything)
+    assert np.abs(got).max() > 0.9
+    assert (np.abs(mix[0].astype(np.float64) - own) <= 1e-5 * np.maximum(scale, 1.0)).all() and np.array_equal(mix[0], mix[1])
+
+
 # ---- edge cases: channel counts, ragged lengths, chunk boundaries, empty renders ----------------------------------
 def test_channel_layouts(S, oracle):
     """1 and 4 output channels; distinct wires, a shared wire and an unconnected channel."""
