@@ -91,6 +91,9 @@ struct OscConst {    // per-voice constants, set up once per kernel (or tile)
 // magnitude.  Evaluated by Estrin's scheme — 8 fma + 3 mul with a dependency depth of 4 instead of Horner's 10: the FM
 // kernels run ONE wave per SIMD, where the length of the per-sample dependency chain, not the instruction count, sets the
 // pace.  Overflow / NaN propagate through ldexp like pow's.
+// (Measured and dropped: the libm-style form — a 32-entry table of 2^(k/32) from constant memory plus a degree-4 polynomial, 9
+// f64-rate instructions instead of 15.  The table load sits inside the modulator's feedback recurrence and its latency cannot be
+// hidden at one wave per SIMD: config 4 went from 9.4 to 16.5 ms per step.)
 SRK_DEV double exp2_fast(double x)
 {
     const double n = __builtin_rint(x);
