@@ -11,6 +11,10 @@
 
 #include "interp.hip.h"
 
+#ifndef SRK_FM_UNROLL
+#define SRK_FM_UNROLL 8
+#endif
+
 namespace srack {
 
 // ---- fused control chain: OSC (constant pitch) -> ADSR -> track ---------------------------------------------
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
     if (a.T > 0) osc_step(fo, sm, km, fed * c_fb, 0.0f, sine_m, sq, sw);  // modulator of sample 0
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
-        for (int i = 0; i < n; i++) {
+        auto sample = [&](int i) {
             const float cur = sine_m;  // OSC_M.sine[t]: feeds the carrier now and, through the z^-1 ring, the modulator of t+1
             float out = 0.0f;
             osc_step(fo_carrier, sc, kc, cur * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
@@ -728,6 +732,12 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
             osc_step(fo, sm, km, cur * c_fb, 0.0f, sine_m, sq, sw);   // modulator of sample t+1 (independent of the carrier)
             fed = cur;
             emit_put<kOut>(em, mix_tile, out, i, V);
+        };
+        if (n == kMixRows) {  // straight-line code over several samples: the tail of one sample's chains overlaps the head of the next's
+#pragma unroll SRK_FM_UNROLL
+            for (int i = 0; i < kMixRows; i++) sample(i);
+        } else {
+            for (int i = 0; i < n; i++) sample(i);
         }
         emit_flush<kOut>(em, mix_tile, t0, n, V);
     }
