@@ -116,6 +116,7 @@ class ControlPlane:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the ranks meet on the loopback interface (a container's hostname may not resolve)
             dist.init_process_group("gloo", rank=rank, world_size=world)
             self.dist = dist
 

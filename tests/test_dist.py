@@ -143,3 +143,20 @@ def test_launcher_reports_a_failing_rank():
     import bench
     rc = bench.launch_ranks(2, [sys.executable, "-c", "import os, sys, time; time.sleep(0.3 if os.environ['RANK'] == '0' else 30); sys.exit(7 if os.environ['RANK'] == '0' else 0)"], timeout=60)
     assert rc == 7  # and the sleeping rank was stopped rather than waited for
+
+
+@pytest.mark.gpu
+def test_bench_with_more_ranks_than_gpus_fails_cleanly():
+    """`bench.py --gpus N` on a box with fewer devices: the rank without a device exits with an error, the launcher stops the others
+    (they would wait in the rendezvous for ever) and reports the failure — no hang, no JSON line."""
+    import subprocess
+    import srack_pkg
+    S = srack_pkg.load()
+    n = S.device_count() + 1
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--voices", "4096",
+                        "--samples", "2048", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
