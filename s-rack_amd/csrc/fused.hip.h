@@ -799,14 +799,21 @@ __global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRol
     Emit em = make_emit(a, plane, lane);
     float sq = 0.0f, sw = 0.0f;
     uint32_t p0 = (uint32_t)(a.n0 % B);  // ring position of the tile's first sample
+    auto ring_at = [&](uint32_t p) { return p < B ? p : p - B; };
+    auto load_tile = [&](float (&dst)[kMixRows], uint32_t first) {  // (past the end of a short last tile: harmless re-reads of valid ring rows)
+#pragma unroll
+        for (int i = 0; i < kMixRows; i++) dst[i] = ring[(size_t)ring_at(first + (uint32_t)i) * V + vc];
+    };
+    // With buffer_size >= 64 the NEXT tile's 32 values are older than this tile too: they are fetched while this tile computes
+    // (one wave per SIMD at 65 536 voices: nobody else hides the 32 loads' latency; the app's 1024: 12.7 -> see DESIGN section 4).
+    const bool ahead = B >= 2u * (uint32_t)kMixRows;
+    float fed[kMixRows];
+    load_tile(fed, p0);
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
-        float fed[kMixRows];
-#pragma unroll
-        for (int i = 0; i < kMixRows; i++) {  // (past the end of a short last tile: harmless re-reads of valid ring rows)
-            const uint32_t p = p0 + (uint32_t)i < B ? p0 + (uint32_t)i : p0 + (uint32_t)i - B;
-            fed[i] = ring[(size_t)p * V + vc];
-        }
+        const bool more = t0 + kMixRows < a.T;
+        float nxt[kMixRows];
+        if (ahead && more) load_tile(nxt, ring_at(p0 + (uint32_t)kMixRows));
         auto sample = [&](int i) {
             float sine_m = 0.0f, out = 0.0f;
             osc_step(fo, sm, km, fed[i] * c_fb, 0.0f, sine_m, sq, sw);   // modulator of sample t
@@ -816,7 +823,7 @@ __global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRol
             emit_put<kOut>(em, mix_tile, out, i, V);
         };
         if (n == kMixRows) {
-#pragma unroll 4
+#pragma unroll SRK_FM_UNROLL
             for (int i = 0; i < kMixRows; i++) sample(i);
         } else {
 #pragma unroll
@@ -824,7 +831,15 @@ __global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRol
                 if (i < n) sample(i);
         }
         emit_flush<kOut>(em, mix_tile, t0, n, V);
-        p0 = p0 + (uint32_t)n < B ? p0 + (uint32_t)n : p0 + (uint32_t)n - B;
+        p0 = ring_at(p0 + (uint32_t)n);
+        if (more) {
+            if (ahead) {
+#pragma unroll
+                for (int i = 0; i < kMixRows; i++) fed[i] = nxt[i];
+            } else {
+                load_tile(fed, p0);
+            }
+        }
     }
     if (active) {
         auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };

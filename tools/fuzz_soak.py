@@ -19,13 +19,19 @@ for seed in range(lo, hi):
     ids = build(o)
     ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]
     ref, _ = o.render_batch(V, T, ov, threads=8)
-    for flags in (1, 3, 5, 7, 9, 11):
+    # FUZZ_SPECIAL=1: only the kernels specialised at run time (hoisted / pipelined, one control unit, everything per voice)
+    for flags in ((35, 43, 39) if os.environ.get("FUZZ_SPECIAL") else (1, 3, 5, 7, 9, 11)):
         p = S.Patch(48000, B, 2)
         build(p)
         p.configure_voices(V)
         if os.environ.get("FUZZ_KEEP"): p.keep_state(True)   # (every planned module evaluated, not only what the output hears)
         for m, f, vals in ov:
             p.set_voice_field(m, f, vals)
+        if flags & 32:
+            try:
+                p.kernel_source(flags)
+            except S.SrackError:
+                continue  # a reverb: the interpreter's
         fr = p.render_channels(T, flags)
         n += 1
         # NaNs compare as NaNs: x86's default NaN has the sign bit set (0xffc00000), the GPU's has not (0x7fc00000)

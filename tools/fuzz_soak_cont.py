@@ -15,7 +15,17 @@ for seed in range(lo, hi):
     V, T = 70, 2600 if seed % 5 else 9000   # (every fifth patch crosses 4096-sample launch borders)
     cuts = sorted(int(c) for c in rng.choice(np.arange(1, T), size=2, replace=False))
     values = [(m, f, fn(V)) for m, f, fn in overrides]
-    for flags in (0, 2, 4, 1):
+    for flags in ((34, 38, 35) if os.environ.get("FUZZ_SPECIAL") else (0, 2, 4, 1)):
+        if flags & 32:
+            p = S.Patch(48000, B, 2)
+            ids = build(p)
+            p.configure_voices(V)
+            for m, f, vals in values:
+                p.set_voice_field(ids[m], f, vals)
+            try:
+                p.kernel_source(flags)
+            except S.SrackError:
+                continue
         outs = []
         for parts in ([T], [cuts[0], cuts[1] - cuts[0], T - cuts[1]]):
             p = S.Patch(48000, B, 2)
