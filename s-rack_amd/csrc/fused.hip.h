@@ -210,6 +210,7 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
         sv.res = __uint_as_float(row(s0 + VCF_S_RES));
     }
     if (a.T > 0) vcf_coeffs<!kExact>(sv, vcf_frequency(parv(ov, VCF_P_FREQ), 0.0f, parv(ov, VCF_P_EXP)), vcf_resonance(parv(ov, VCF_P_RES)));
+    bool sv_fin = !kExact || vcf_nan_free(sv);  // (exact mode: v_med3 clamps while nothing can turn into a NaN, modules.hip.h vcf_run)
 
     AdsrRegs sd;
     sd.phase = __uint_as_float(row(od.state_row + ADSR_S_PHASE));
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
                 gate = kOscLPort == OSC_OUT_SINE ? gs : (kOscLPort == OSC_OUT_SQUARE ? gq : gw);
             }
             float lp, bp, hp;
-            vcf_step<!kExact>(sv, x, lp, bp, hp);
+            vcf_run<!kExact>(sv, sv_fin, x, lp, bp, hp);
             const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
             if (!kExact) {  // next sample's oscillators: same basic block as the filter chain above => they interleave
                 pos_a = ca.pos;
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
     sv.freq = __uint_as_float(row(s0 + VCF_S_FREQ));
     sv.res = __uint_as_float(row(s0 + VCF_S_RES));
     if (a.T > 0) vcf_coeffs<!kExact>(sv, vcf_frequency(parv(ov, VCF_P_FREQ), 0.0f, parv(ov, VCF_P_EXP)), vcf_resonance(parv(ov, VCF_P_RES)));
+    bool sv_fin = !kExact || vcf_nan_free(sv);  // (exact mode: v_med3 clamps while nothing can turn into a NaN, modules.hip.h vcf_run)
     const bool negative = parv(oc, VCA_P_NEG) != 0.0f;
 
     Emit em = make_emit(a, plane, lane);
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
                 x = kOscAPort == OSC_OUT_SINE ? sine : (kOscAPort == OSC_OUT_SQUARE ? square : saw);
             }
             float lp, bp, hp;
-            vcf_step<!kExact>(sv, x, lp, bp, hp);
+            vcf_run<!kExact>(sv, sv_fin, x, lp, bp, hp);
             const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
             if (kFixed) {
                 fpos_lo = fa_osc.lo;

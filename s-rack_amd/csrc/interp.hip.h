@@ -262,6 +262,7 @@ __device__ __noinline__ void tile_vcf(const Ctx c_v, COp& op_v)
     const uint32_t fl = op.flags;
     VcfRegs s;
     vcf_load(c, op.state_row, s);
+    bool fin = !kExact || vcf_nan_free(s);
     const float freq = par(c, op, VCF_P_FREQ), exp_amt = par(c, op, VCF_P_EXP);
     const float res = vcf_resonance(par(c, op, VCF_P_RES));
     const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
@@ -275,13 +276,13 @@ __device__ __noinline__ void tile_vcf(const Ctx c_v, COp& op_v)
             tile_run<2, 1>(c, in, w, [&](const float* x, float* y) {
                 float lp, bp, hp;
                 vcf_coeffs<!kExact>(s, vcf_frequency(freq, x[1], exp_amt), res);
-                vcf_step<!kExact>(s, x[0], lp, bp, hp);
+                vcf_run<!kExact>(s, fin, x[0], lp, bp, hp);
                 y[0] = pick(lp, bp, hp);
             });
         else
             tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
                 vcf_coeffs<!kExact>(s, vcf_frequency(freq, x[1], exp_amt), res);
-                vcf_step<!kExact>(s, x[0], y[0], y[1], y[2]);
+                vcf_run<!kExact>(s, fin, x[0], y[0], y[1], y[2]);
             });
     } else {
         // constant cutoff: the "did (frequency, res) change" check can only fire on the first sample
@@ -290,11 +291,11 @@ __device__ __noinline__ void tile_vcf(const Ctx c_v, COp& op_v)
         if (one)
             tile_run<1, 1>(c, audio, w, [&](const float* x, float* y) {
                 float lp, bp, hp;
-                vcf_step<!kExact>(s, x[0], lp, bp, hp);
+                vcf_run<!kExact>(s, fin, x[0], lp, bp, hp);
                 y[0] = pick(lp, bp, hp);
             });
         else
-            tile_run<1, 3>(c, audio, out, [&](const float* x, float* y) { vcf_step<!kExact>(s, x[0], y[0], y[1], y[2]); });
+            tile_run<1, 3>(c, audio, out, [&](const float* x, float* y) { vcf_run<!kExact>(s, fin, x[0], y[0], y[1], y[2]); });
     }
     vcf_store(c, op.state_row, s);
 }

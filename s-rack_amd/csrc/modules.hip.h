@@ -719,6 +719,27 @@ SRK_DEV bool vcf_nan_free(const VcfRegs& s)
     return __builtin_amdgcn_ballot_w64(!(fin(s.f) && fin(s.p) && fin(s.q) && fin(s.b0) && fin(s.b1) && fin(s.b2) && fin(s.b3) && fin(s.b4))) == 0;
 }
 
+// The ladder as a kernel calls it.  kFast: the default mode's contracted form.  Otherwise the literal operations — with the clamps
+// as v_med3 (half the instructions of min + max) whenever that cannot be told from the reference: the two differ only on a NaN,
+// and a NaN can only come from a NaN / infinite input or from an input so large that the cubic overflows (inf - inf).  `fin` (wave-
+// uniform) says the state is finite — vcf_nan_free at load, and true after any step, whose clamps leave finite values behind (a
+// NaN clamps to 1.0 in the literal form; the coefficients are products of clamped numbers) — and an input below 1e6 in every lane
+// keeps every intermediate finite.  Anything else takes the literal min / max for that sample.
+template <bool kFast>
+SRK_DEV void vcf_run(VcfRegs& s, bool& fin, float input, float& lowpass, float& bandpass, float& highpass)
+{
+    if (kFast) {
+        vcf_step<true>(s, input, lowpass, bandpass, highpass);
+        return;
+    }
+    if (fin && __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(input) < 1e6f)) == 0) {
+        vcf_step<false, true>(s, input, lowpass, bandpass, highpass);
+    } else {
+        vcf_step<false, false>(s, input, lowpass, bandpass, highpass);
+        fin = true;
+    }
+}
+
 // (self.freq + cv * self.exp_amt).max(0.0).min(0.9), filter.rs:213
 SRK_DEV float vcf_frequency(float freq, float cv, float exp_amt) { return fminf(fmaxf(freq + cv * exp_amt, 0.0f), 0.9f); }
 SRK_DEV float vcf_resonance(float res) { return fminf(fmaxf(res, 0.0f), 1.0f); }  // filter.rs:214

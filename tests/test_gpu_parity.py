@@ -1125,6 +1125,38 @@ def test_filter_clamps_a_nan_to_plus_one(S, oracle, flags):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags", [pytest.param(1, id="fused-exact"), pytest.param(3, id="interp-exact"), pytest.param(35, id="special-exact"),
+                                   pytest.param(39, id="special-exact-nohoist"), pytest.param(7, id="interp-exact-nohoist")])
+def test_filter_with_an_exploding_input(S, oracle, flags):
+    """The exact ladder clamps with v_med3 only while that cannot be told from `min(1.0).max(-1.0)`: an input that grows through 1e6, 1e30
+    and inf makes the cubic overflow into inf - inf = NaN inside the filter — the literal form has to take over in time, sample for sample."""
+    def build(g):
+        s_, m, vcf, out = g.add_module(S.MOD_MATH), g.add_module(S.MOD_MATH), g.add_module(S.MOD_MOOG_FILTER), g.add_module(S.MOD_OUTPUT)
+        g.set_field(s_, S.MATH_CONSTANT, 1.0)
+        g.connect(m, 0, s_, 0)
+        g.set_field(m, S.MATH_CONSTANT, 1.7)
+        g.set_field(m, S.MATH_OPERATION, S.MATH_MULTIPLY)
+        g.connect(s_, 0, m, 0)             # m = 1.7 (m + 1): 1e6 after ~25 one-sample blocks, inf after ~170
+        g.connect(m, 0, vcf, 0)
+        g.connect(vcf, 0, out, 0)          # low-pass
+        g.connect(vcf, 2, out, 1)          # high-pass = input - b4: follows the input up to inf
+        return dict(vcf=vcf)
+    V = 70
+    res = np.linspace(0.0, 0.85, V).astype(np.float32)
+    o = oracle.OraclePatch(48000, 1, 2)
+    ids = build(o)
+    ref, _ = o.render_batch(V, 300, [(ids["vcf"], S.VCF_RES, res)], threads=4)
+    assert np.isinf(ref[1, 250:]).all() or np.isnan(ref[1, 250:]).any()
+    p = S.Patch(48000, 1, 2)
+    build(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["vcf"], S.VCF_RES, res)
+    fr, _ = p.render(300, flags=flags)
+    same = (bits(fr) == bits(ref)) | (np.isnan(fr) & np.isnan(ref))
+    assert same.all(), f"{1 - same.mean():.4f} of the samples differ, first at {np.argwhere(~same)[0]}"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("flags", MODES)
 def test_oscillator_increments_beyond_half_a_cycle(S, oracle, flags):
     """At sample rate 1000 the audible range reaches increments of 0.1 ... 1.1 cycles per sample.  Past 1/2 the two PolyBLEP windows
