@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — voice-samples/sec of the batch render on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg4_b1024|p3] [--flags F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg4_b1024|p3|p4] [--flags F]
 
 Workloads (BASELINE.json `configs`; SURVEY 8(d) spells them out):
     cfg3 (default; = config 5 at 8 GPUs)  patch P1 saw VCO -> ladder VCF -> VCA, ADSR gated by an LFO square; 262 144 voices per GPU,
@@ -10,6 +10,7 @@ Workloads (BASELINE.json `configs`; SURVEY 8(d) spells them out):
     cfg4         patch P2, 2-operator FM with a feedback edge, 65 536 voices, buffer_size 1 (z^-1 held in a register)
     cfg4_b1024   the same at the app's buffer_size 1024 (the feedback delay is a ring in HBM)
     p3           the sequencer-driven patch of scope row (f)1, two output planes (diagnostic)
+    p4           the clocked sample player with vibrato and waveshaper of scope row (f)4, two output planes (diagnostic)
 A step = one srack_render() of all this rank's voices for T samples (frames resident in HBM) + the mix-down (+ for N > 1
 the RCCL sum of the [2][T] partial mixes to rank 0, through the product's own communicator: srack_dist_init /
 srack_dist_reduce_mix).  Voices are sharded by global voice index, no exchange during the render => weak scaling.
@@ -53,7 +54,7 @@ F64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
 FM_PAIR_F64_OPS = {"render_fm_pair": 60, "render_fm_pair_ring": 60}
 F64_LANE_OPS_MEASURED = 33.3e12
 
-WORKLOADS = ("cfg3", "cfg2", "cfg4", "cfg4_b1024", "p3")
+WORKLOADS = ("cfg3", "cfg2", "cfg4", "cfg4_b1024", "p3", "p4")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -194,6 +195,14 @@ class HipBackend:
             p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
             self.what = (f"BASELINE config 4: patch P2 2-op FM with a feedback edge, {V} voices with per-voice feedback / index, "
                          f"buffer_size {B} (" + ("z^-1 feedback in a register" if B == 1 else "the app's block size: the feedback delay is a ring in HBM") + ")")
+        elif w == "p4":
+            ids = S.build_p4(p)
+            p.configure_voices(V)
+            depth, expo = S.p4_voice_params(V, first_voice=first)
+            p.set_voice_field(ids["depth"], S.MATH_CONSTANT, depth)
+            p.set_voice_field(ids["shaper"], S.NONLIN_CONSTANT, expo)
+            self.what = ("patch P4 (diagnostic): clock -> sample player with per-voice vibrato depth -> sign-preserving waveshaper with a per-voice "
+                         f"exponent, raw sample on channel 2, {V} voices/GPU")
         else:
             ids = S.build_p3(p)
             p.configure_voices(V)
@@ -293,7 +302,7 @@ def profiled_traffic(kernel_name, workload, V, T):
         return None
     best = None
     suffix = {"cfg3": ("_summary.json",), "p3": ("_p3_summary.json",), "cfg4": ("_cfg4_summary.json",), "cfg4_b1024": ("_cfg4_b1024_summary.json",),
-              "cfg2": ("_cfg2_summary.json",)}[workload]
+              "cfg2": ("_cfg2_summary.json",), "p4": ("_p4_summary.json",)}[workload]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_summary.json"))):
         base = os.path.basename(path)
         if workload == "cfg3" and base.count("_") != 1:
@@ -313,7 +322,7 @@ def profiled_traffic(kernel_name, workload, V, T):
 
 
 def default_voices(workload):
-    return {"cfg3": 262144, "p3": 262144, "cfg2": 4096, "cfg4": 65536, "cfg4_b1024": 65536}[workload]
+    return {"cfg3": 262144, "p3": 262144, "p4": 131072, "cfg2": 4096, "cfg4": 65536, "cfg4_b1024": 65536}[workload]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -408,7 +417,7 @@ def run_rank(args, backend_cls=HipBackend):
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
             out["roofline"]["traffic_detail"] = dict(tr, measured_in_this_run=False,
                                                      note="rocprofv3 PMC passes of this command (profiles/run_profile.sh); a profiler cannot run inside the timed region")
-        if world == 1 and not args.no_cpu and args.workload != "p3" and be.name == "hip":
+        if world == 1 and not args.no_cpu and args.workload not in ("p3", "p4") and be.name == "hip":
             out["cpu_baseline"] = cpu_baseline(be.S, args.workload)
     be.close()
     cp.close()

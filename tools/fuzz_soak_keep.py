@@ -31,7 +31,8 @@ for seed in range(lo, hi):
             osc = next((m for m in range(p.num_modules()) if p.module_type(m) == S.MOD_OSCILLATOR), None)
             if osc is None: break
             parts = []
-            exact_modes = (1, 3, 5, 7, 9, 11)
+            # FUZZ_SPECIAL=1 (first patch family only: no reverbs): specialised kernels alternate with interpreter / fused ones
+            exact_modes = (35, 3, 39, 7, 43, 1) if os.environ.get("FUZZ_SPECIAL") else (1, 3, 5, 7, 9, 11)
             for k in (cuts[0], cuts[1] - cuts[0], T - cuts[1]):
                 # exact modes: each part in ANOTHER exact mode (fused / interpreter / per-voice / one control unit): a flags change is an edit too
                 parts.append(p.render_channels(k, exact_modes[(seed + len(parts) + flags) % 6] if flags & 1 else flags))

@@ -40,5 +40,7 @@ for v in "$@"; do
     cfg4b_special) run cfg4b_special --workload cfg4_b1024 --flags 2 ;;
     cfg2_special) run cfg2_special --workload cfg2 --flags 34 ;;
     interp_only) run cfg3_interp_only --flags 18 ;;
+    p4) run p4 --workload p4 ;;
+    p4_interp) run p4_interp --workload p4 --flags 16 ;;
   esac
 done
