@@ -6,8 +6,10 @@
 //   2. dead-port elimination: an oscillator / filter port nobody reads is not computed
 //      (the reference always computes all three, oscillator.rs:133-149; results on the read
 //      ports are unaffected).
-//  2b. approximated values that reach a pitch CV force the exact oscillator and the literal filter
-//      for the whole patch (default mode would otherwise integrate its 1e-7 into a phase).
+//  2b. default mode: an oscillator whose saw / square, a filter whose output can reach a pitch CV gets the
+//      exact PolyBLEP / the literal ladder — that module only (the phase accumulator behind the pitch would
+//      integrate its biased 1e-7); a filter inside a feedback loop gets the literal ladder too; a pitch
+//      input that sits on a loop, or a resonance of 0.9 or more, puts the whole patch into the exact flavour.
 //   3. uniform hoisting: a module whose fields carry no per-voice override and whose inputs all
 //      come from such modules produces the same samples for every voice.  That sub-graph becomes
 //      the CONTROL program, evaluated once (one voice) into control tracks; the VOICE program reads
@@ -75,6 +77,8 @@ struct Analysis {  // whole-graph facts shared by both programs
     std::vector<char> in_ctl;
     std::vector<int> stage;                          // per module: control stage (>= 0) or -1 = voice program
     std::vector<char> sine_loose;                    // per oscillator: its sine port cannot reach a pitch input (OSC_SINE_LOOSE)
+    std::vector<char> exact_src;                     // per oscillator / filter, default mode: an approximated output of it can reach a pitch input
+                                                     // (OSC_EXACT_BLEP / VCF_LITERAL)
     std::vector<std::pair<int, int>> tracks;         // (module, port) exported by a control stage
     std::map<std::pair<int, int>, int> track_of;
 };
@@ -272,6 +276,7 @@ int Builder::build()
             if (pl & 4u) op.flags |= OSC_OUT_SAW;
             if (render_flags & SRACK_RENDER_EXACT_OSC) op.flags |= OSC_EXACT;
             if (A.sine_loose[(size_t)m]) op.flags |= OSC_SINE_LOOSE;
+            if (A.exact_src[(size_t)m] && !(op.flags & OSC_EXACT)) op.flags |= OSC_EXACT_BLEP;
             op.sample_rate = (double)g.cfg.sample_rate;  // `self.sample_rate as f64`, u16 in the reference
             {   // pos: f64 state, two rows (lo, hi)
                 const VoiceOverride* o = find_override(m, SRACK_OSC_POS);
@@ -290,7 +295,7 @@ int Builder::build()
                         small = 440.0 * std::pow(2.0, (double)(float)o->values[v]) / op.sample_rate < 0.25;
                 }
                 const uint32_t ports = op.flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
-                if (small && !(op.flags & OSC_HAS_SYNC) && (op.flags & OSC_AA) && ports && !(ports & (ports - 1)))
+                if (small && !(op.flags & (OSC_HAS_SYNC | OSC_EXACT_BLEP)) && (op.flags & OSC_AA) && ports && !(ports & (ports - 1)))
                     op.flags |= (op.flags & OSC_EXACT) ? OSC_CONST_SMALL : (OSC_CONST_SMALL | OSC_CONST_FAST);
             }
             break;
@@ -302,6 +307,7 @@ int Builder::build()
             if (pl & 1u) op.flags |= VCF_OUT_LP;
             if (pl & 2u) op.flags |= VCF_OUT_BP;
             if (pl & 4u) op.flags |= VCF_OUT_HP;
+            if (A.exact_src[(size_t)m] && !(render_flags & SRACK_RENDER_EXACT_OSC)) op.flags |= VCF_LITERAL;
             op.state_row = state_row_f32(m, SRACK_VCF_ST_F);
             state_row_f32(m, SRACK_VCF_ST_P);
             state_row_f32(m, SRACK_VCF_ST_Q);
@@ -726,12 +732,12 @@ void Builder::match_fused(bool has_rings)
         auto is_track = [](int slot) { return slot >= kTrackSlot; };
         const uint32_t ports = osc->flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
         const uint32_t vcf_ports = vcf->flags & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP);
-        bool ok = (osc->flags & ~(OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_SINE_LOOSE)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1));
+        bool ok = (osc->flags & ~(OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_SINE_LOOSE)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA)  /* (no OSC_EXACT_BLEP) */ && ports && !(ports & (ports - 1));
         if (ok && math)
             ok = src_of(osc->module, 0).src == math->module && (math->flags & (MATH_HAS_IN1 | MATH_HAS_IN2)) == MATH_HAS_IN1 && is_track(math->in_slot[0]);
         else if (ok)
             ok = is_track(osc->in_slot[0]);
-        ok = ok && (vcf->flags & VCF_HAS_AUDIO) && src_of(vcf->module, 0).src == osc->module && vcf_ports && !(vcf_ports & (vcf_ports - 1)) &&
+        ok = ok && !(vcf->flags & VCF_LITERAL) && (vcf->flags & VCF_HAS_AUDIO) && src_of(vcf->module, 0).src == osc->module && vcf_ports && !(vcf_ports & (vcf_ports - 1)) &&
              (!(vcf->flags & VCF_HAS_CV) || is_track(vcf->in_slot[1]));
         ok = ok && vca->flags == (VCA_HAS_AUDIO | VCA_HAS_CV) && src_of(vca->module, 0).src == vcf->module && is_track(vca->in_slot[1]);
         int n_main = 0;
@@ -769,7 +775,7 @@ void Builder::match_fused(bool has_rings)
     };
     const uint32_t vcf_ports = vcf->flags & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP);
     bool ok = vca->flags == (VCA_HAS_AUDIO | VCA_HAS_CV) && src_of(vca->module, 0).src == vcf->module && src_of(outp->module, 0).src >= 0 &&
-              (vcf->flags & (VCF_HAS_AUDIO | VCF_HAS_CV)) == VCF_HAS_AUDIO && vcf_ports && !(vcf_ports & (vcf_ports - 1)) &&
+              (vcf->flags & (VCF_HAS_AUDIO | VCF_HAS_CV | VCF_LITERAL)) == VCF_HAS_AUDIO && vcf_ports && !(vcf_ports & (vcf_ports - 1)) &&
               osc_ok(src_of(vcf->module, 0).src);
     for (int c = 0; c < H.n_channels && ok; c++) {
         const InputRef& in = src_of(outp->module, c);
@@ -975,8 +981,27 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             const int t = g.modules[(size_t)module].type;
             return (t == SRACK_MOD_OSCILLATOR && port == SRACK_OSC_IN_CV) || (t == SRACK_MOD_SAMPLE && port == SRACK_SAMPLE_IN_CV);
         };
-        // Does a value that starts on the given output ports reach a pitch input (port by port through the graph)?
-        auto reaches_pitch = [&](std::vector<uint32_t> tainted) {
+        // Inputs that only look at the SIGN of what they read: an ADSR's gate, an oscillator's sync, a sequencer's step and sync, the sample
+        // player's gate, and the VCA's CV (`cv > 0.0` opens it).  An error of 1e-7 does not pass through them — unless it flips the sign at a
+        // zero crossing, which moves an edge by a sample.
+        auto is_threshold_input = [&](int module, int port) {
+            switch (g.modules[(size_t)module].type) {
+            case SRACK_MOD_ADSR: return true;
+            case SRACK_MOD_OSCILLATOR: return port == SRACK_OSC_IN_SYNC;
+            case SRACK_MOD_GRID_SEQUENCER:
+            case SRACK_MOD_PATTERN_SEQUENCER: return true;
+            case SRACK_MOD_SAMPLE: return port == SRACK_SAMPLE_IN_GATE;
+            case SRACK_MOD_VCA: return port == SRACK_VCA_IN_CV;
+            default: return false;
+            }
+        };
+        // Which pitch inputs does a value that starts on the given output ports reach (port by port through the graph)?  -> per module: 1 if
+        // its pitch input is reached.  also_thresholds: inputs that take the value's sign count as well (any hit sets hit_any).
+        // influence_all: follow EVERY input to all of the module's outputs (a gate, a sync or a step input does not carry the value on, but
+        // it decides when things happen: enough to close a loop).
+        auto pitches_reached = [&](std::vector<uint32_t> tainted, bool also_thresholds, bool& hit_any, bool influence_all = false) {
+            std::vector<char> hit((size_t)n_mod, 0);
+            hit_any = false;
             for (bool changed = true; changed;) {
                 changed = false;
                 for (int k = 0; k < n_mod; k++) {
@@ -985,8 +1010,9 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                     for (int port = 0; port < sink.n_in; port++) {
                         const InputRef& in = sink.in[(size_t)port];
                         if (in.src < 0 || !(tainted[(size_t)in.src] & (1u << in.port))) continue;
-                        if (is_pitch_input(k, port)) return true;
-                        const uint32_t add = carried_to(sink.type, port) & ~tainted[(size_t)k];
+                        if (is_pitch_input(k, port)) hit[(size_t)k] = 1, hit_any = true;
+                        if (also_thresholds && is_threshold_input(k, port)) hit_any = true;
+                        const uint32_t add = (influence_all ? (sink.n_out >= 32 ? ~0u : (1u << sink.n_out) - 1u) : carried_to(sink.type, port)) & ~tainted[(size_t)k];
                         if (add) {
                             tainted[(size_t)k] |= add;
                             changed = true;
@@ -994,27 +1020,85 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                     }
                 }
             }
-            return false;
+            return hit;
         };
-        // An oscillator's sine port that cannot reach a pitch may be evaluated in f32 in the default mode (modules.hip.h, sine_loose).
+        auto reaches_pitch = [&](const std::vector<uint32_t>& tainted, bool also_thresholds = false) {
+            bool any = false;
+            pitches_reached(tainted, also_thresholds, any);
+            return any;
+        };
+        // An oscillator's sine port that can reach neither a pitch nor a threshold may be evaluated in f32 in the default mode (modules.hip.h,
+        // sine_loose: 2e-7, where the f64 form is the correctly rounded sine and therefore has the reference's own zero crossings).
         A.sine_loose.assign((size_t)n_mod, 0);
         if (!(render_flags & SRACK_RENDER_EXACT_OSC))
             for (int m = 0; m < n_mod; m++)
                 if (A.live[(size_t)m] && g.modules[(size_t)m].type == SRACK_MOD_OSCILLATOR && (A.port_live[(size_t)m] & 1u)) {
                     std::vector<uint32_t> from((size_t)n_mod, 0u);
                     from[(size_t)m] = 1u;
-                    A.sine_loose[(size_t)m] = !reaches_pitch(from);
+                    A.sine_loose[(size_t)m] = !reaches_pitch(from, true);
                 }
+      A.exact_src.assign((size_t)n_mod, 0);
       if (!(render_flags & SRACK_RENDER_EXACT_OSC)) {
-        std::vector<uint32_t> tainted((size_t)n_mod, 0u);  // per module: output ports that carry an approximated saw / square value
+        // Module by module: an oscillator whose saw / square, a filter whose output can reach a pitch input gets the exact PolyBLEP / the
+        // literal ladder — that module only.  (Until round 2 one such module switched the whole patch to the exact flavour, whose 2^cv in
+        // double-double and library sine made e.g. a saw-LFO vibrato patch an order of magnitude slower than it has to be: what is
+        // integrated is the producer's biased 1e-7, not the consumer's 1e-12.)
+        bool loop_through_pitch = false;
         for (int m = 0; m < n_mod; m++) {
             if (!A.live[(size_t)m]) continue;
-            if (g.modules[(size_t)m].type == SRACK_MOD_OSCILLATOR) tainted[(size_t)m] = A.port_live[(size_t)m] & 6u;   // square, saw
-            if (g.modules[(size_t)m].type == SRACK_MOD_MOOG_FILTER) tainted[(size_t)m] = A.port_live[(size_t)m] & 7u;  // the fma-contracted ladder
+            const int t = g.modules[(size_t)m].type;
+            const uint32_t ports = t == SRACK_MOD_OSCILLATOR ? (A.port_live[(size_t)m] & 6u) : t == SRACK_MOD_MOOG_FILTER ? (A.port_live[(size_t)m] & 7u) : 0u;
+            if (!ports) continue;
+            std::vector<uint32_t> from((size_t)n_mod, 0u);
+            from[(size_t)m] = ports;
+            bool any = false;
+            const std::vector<char> hit = pitches_reached(from, false, any);
+            A.exact_src[(size_t)m] = any;
+            // ... unless the pitch it reaches closes a LOOP: a module whose own output comes back to its pitch input iterates a map, and in
+            // such a loop the consumer's 1e-12 (the polynomial 2^cv against the reference's libm) can grow like anything else (random
+            // patches with saw / filter feedback into a pitch part from the oracle within a few hundred samples).  Only the exact flavour of
+            // the WHOLE patch — phases bit-identical to the reference's — follows the reference there, as before round 2.
+            for (int k = 0; k < n_mod && any; k++) {
+                if (!hit[(size_t)k]) continue;
+                std::vector<uint32_t> back((size_t)n_mod, 0u);
+                back[(size_t)k] = g.modules[(size_t)k].type == SRACK_MOD_OSCILLATOR ? 7u : 1u;
+                bool any2 = false;
+                if (pitches_reached(back, false, any2, true)[(size_t)k]) loop_through_pitch = true;
+            }
         }
-        if (reaches_pitch(tainted)) {
+        // A filter inside ANY feedback loop iterates its own rounding too: the fma-contracted ladder stays within 1e-5 of the reference while
+        // its differences die out (a damped recurrence, section 2 of DESIGN.md), not when a loop feeds them back in — through a mixer into
+        // its own input, or through a gate that restarts a sample player (random patches of that kind left the band after a few thousand
+        // samples).  Such a filter runs the literal ladder.
+        for (int m = 0; m < n_mod; m++) {
+            if (!A.live[(size_t)m] || g.modules[(size_t)m].type != SRACK_MOD_MOOG_FILTER || A.exact_src[(size_t)m]) continue;
+            std::vector<char> seen((size_t)n_mod, 0);
+            std::vector<int> stack{m};
+            bool back = false;
+            while (!stack.empty() && !back) {
+                const int k = stack.back();
+                stack.pop_back();
+                for (int j = 0; j < n_mod && !back; j++) {  // every module j that reads k
+                    if (!A.live[(size_t)j]) continue;
+                    bool reads = false;
+                    for (const InputRef& in : g.modules[(size_t)j].in) reads = reads || in.src == k;
+                    if (!reads) continue;
+                    if (j == m) back = true;
+                    if (!seen[(size_t)j]) {
+                        seen[(size_t)j] = 1;
+                        stack.push_back(j);
+                    }
+                }
+            }
+            if (back) A.exact_src[(size_t)m] = 1;
+        }
+        if (loop_through_pitch) {
             render_flags |= SRACK_RENDER_EXACT_OSC;
             std::fill(A.sine_loose.begin(), A.sine_loose.end(), 0);  // (the exact oscillator has one sine)
+        }
+        if (getenv("SRACK_TAINT_GLOBAL")) {  // (tools/: the pre-round-2 rule — one such module switches the whole patch to the exact flavour)
+            for (int m = 0; m < n_mod; m++)
+                if (A.exact_src[(size_t)m]) render_flags |= SRACK_RENDER_EXACT_OSC;
         }
         // The other amplifier of a 1e-7: a ladder filter close to self-oscillation.  Its feedback gain q grows with the resonance, and
         // from ~0.93 up (tools/shape_soak.py: 7 of 150 random P1 parameter sets, all with res >= 0.928, a few voices each, up to 3e-3)

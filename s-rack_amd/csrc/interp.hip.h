@@ -220,7 +220,7 @@ SRK_DEV void tile_osc(const Ctx& c, COp& op)
     const uint32_t ports = fl & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
     if (fl & OSC_CONST_FAST)
         tile_osc_const<kExact>(c, op);
-    else if (!kExact && (fl & (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_HAS_SYNC | OSC_AA)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1)))
+    else if (!kExact && (fl & (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_HAS_SYNC | OSC_AA | OSC_EXACT_BLEP)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1)))
         tile_osc_stepwise<kExact>(c, op);
     else
         tile_osc_general<kExact>(c, op);
@@ -254,15 +254,14 @@ SRK_DEV void vcf_store(const Ctx& c, int sr, const VcfRegs& s)
     ROW(sr + VCF_S_RES) = __float_as_uint(s.res);
 }
 
-template <bool kExact>
-__device__ __noinline__ void tile_vcf(const Ctx c_v, COp& op_v)
+// kFast: the default mode's contracted ladder; otherwise the literal one (exact mode, or VCF_LITERAL: an output reaches a pitch input)
+template <bool kFast>
+SRK_DEV void tile_vcf_body(const Ctx& c, COp& op)
 {
-    const Ctx c = uniform_ctx(c_v);
-    COp& op = uniform_op(op_v);
     const uint32_t fl = op.flags;
     VcfRegs s;
     vcf_load(c, op.state_row, s);
-    bool fin = !kExact || vcf_nan_free(s);
+    bool fin = kFast || vcf_nan_free(s);
     const float freq = par(c, op, VCF_P_FREQ), exp_amt = par(c, op, VCF_P_EXP);
     const float res = vcf_resonance(par(c, op, VCF_P_RES));
     const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
@@ -275,29 +274,40 @@ __device__ __noinline__ void tile_vcf(const Ctx c_v, COp& op_v)
         if (one)
             tile_run<2, 1>(c, in, w, [&](const float* x, float* y) {
                 float lp, bp, hp;
-                vcf_coeffs<!kExact>(s, vcf_frequency(freq, x[1], exp_amt), res);
-                vcf_run<!kExact>(s, fin, x[0], lp, bp, hp);
+                vcf_coeffs<kFast>(s, vcf_frequency(freq, x[1], exp_amt), res);
+                vcf_run<kFast>(s, fin, x[0], lp, bp, hp);
                 y[0] = pick(lp, bp, hp);
             });
         else
             tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
-                vcf_coeffs<!kExact>(s, vcf_frequency(freq, x[1], exp_amt), res);
-                vcf_run<!kExact>(s, fin, x[0], y[0], y[1], y[2]);
+                vcf_coeffs<kFast>(s, vcf_frequency(freq, x[1], exp_amt), res);
+                vcf_run<kFast>(s, fin, x[0], y[0], y[1], y[2]);
             });
     } else {
         // constant cutoff: the "did (frequency, res) change" check can only fire on the first sample
-        vcf_coeffs<!kExact>(s, vcf_frequency(freq, 0.0f, exp_amt), res);
+        vcf_coeffs<kFast>(s, vcf_frequency(freq, 0.0f, exp_amt), res);
         const Port audio[1] = {in[0]};
         if (one)
             tile_run<1, 1>(c, audio, w, [&](const float* x, float* y) {
                 float lp, bp, hp;
-                vcf_run<!kExact>(s, fin, x[0], lp, bp, hp);
+                vcf_run<kFast>(s, fin, x[0], lp, bp, hp);
                 y[0] = pick(lp, bp, hp);
             });
         else
-            tile_run<1, 3>(c, audio, out, [&](const float* x, float* y) { vcf_run<!kExact>(s, fin, x[0], y[0], y[1], y[2]); });
+            tile_run<1, 3>(c, audio, out, [&](const float* x, float* y) { vcf_run<kFast>(s, fin, x[0], y[0], y[1], y[2]); });
     }
     vcf_store(c, op.state_row, s);
+}
+
+template <bool kExact>
+__device__ __noinline__ void tile_vcf(const Ctx c_v, COp& op_v)
+{
+    const Ctx c = uniform_ctx(c_v);
+    COp& op = uniform_op(op_v);
+    if (kExact || (op.flags & VCF_LITERAL))
+        tile_vcf_body<false>(c, op);
+    else
+        tile_vcf_body<true>(c, op);
 }
 
 template <bool kExact>

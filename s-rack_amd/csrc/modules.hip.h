@@ -307,6 +307,16 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
     float inv_dt = c.inv_dt;
     if (flags & OSC_HAS_CV) inv_dt = 1.0f / (float)delta;
     if (flags & OSC_OUT_SINE) sine = (flags & OSC_SINE_LOOSE) ? sine_loose(pos) : sine_fast(pos);
+    if ((flags & OSC_EXACT_BLEP) && (flags & (OSC_OUT_SQUARE | OSC_OUT_SAW))) {
+        // saw / square exactly as the reference spells them (they reach a pitch input somewhere: an f32 PolyBLEP's biased 1e-7 would be
+        // integrated into a phase); the phase itself, the increment and the sine keep the default arithmetic
+        const bool aa = flags & OSC_AA;
+        if (flags & OSC_OUT_SQUARE)
+            square = (pos < 0.5 ? -1.0f : 1.0f) - (aa ? (float)(poly_blep_exact(pos, delta) - poly_blep_exact(fmod1(pos + 0.5), delta)) : 0.0f);
+        if (flags & OSC_OUT_SAW) saw = ((float)pos * 2.0f - 1.0f) - (aa ? (float)poly_blep_exact(pos, delta) : 0.0f);
+        s.pos = wrap01(pos + delta);
+        return;
+    }
     if (flags & (OSC_OUT_SQUARE | OSC_OUT_SAW)) {
         const float p32 = (float)pos;            // `self.pos as f32`
         float blep0 = 0.0f;

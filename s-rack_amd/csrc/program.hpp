@@ -55,6 +55,9 @@ enum : uint32_t {
     OSC_CV_STEPWISE = 1u << 9,    // host-proved: the CV is a sequencer's note CV (plus constants): constant between steps
     OSC_SINE_LOOSE = 1u << 12,    // host-proved: the sine port's value cannot reach a pitch input (an oscillator's or the sample player's CV), so
                                   // nothing integrates its rounding: default mode may evaluate it in f32 after the exact f64 fold
+    OSC_EXACT_BLEP = 1u << 13,    // host-proved need, default mode only: this oscillator's saw / square can reach a pitch input, where an error is
+                                  // INTEGRATED — its PolyBLEP is evaluated as in exact mode (f64, true division); everything else about it
+                                  // (2^cv, sine, the rest of the patch) stays in the default arithmetic
     OSC_CONST_SMALL = 1u << 11,   // host-proved, whatever the render mode: no CV, no sync, one live port, PolyBLEP on, every voice's delta < 0.25
                                   // (OSC_CONST_FAST = this and not OSC_EXACT)
     // OP_VCF
@@ -63,6 +66,7 @@ enum : uint32_t {
     VCF_OUT_LP = 1u << 3,
     VCF_OUT_BP = 1u << 4,
     VCF_OUT_HP = 1u << 5,
+    VCF_LITERAL = 1u << 6,    // default mode only: an output can reach a pitch input — the ladder runs the reference's operations one by one (no fma contraction)
     // OP_ADSR
     ADSR_HAS_GATE = 1u << 0,
     // OP_VCA

@@ -1559,3 +1559,48 @@ def test_kernel_timer_is_off_until_asked_for(S):
     assert lib.srack_render_kernel_ms(p.h, C.byref(ms), C.byref(n), -1) == 0 and n.value == 0  # read + disarm
     p.render(2048)
     assert lib.srack_render_kernel_ms(p.h, C.byref(ms), C.byref(n), -1) == 0 and n.value == 0
+
+
+def _vibrato(g, S, loop):
+    """P1 whose audio oscillator's pitch is modulated by a SAW (an approximated value reaches a pitch input): by a free-running LFO
+    (feed-forward), or — loop — by the audio oscillator's own saw through a Multiply (a loop through the pitch input)."""
+    ids = S.build_p1(g, adsr="finite", lfo_val=-3.0)
+    depth = g.add_module(S.MOD_MATH)
+    g.set_field(depth, S.MATH_OPERATION, S.MATH_MULTIPLY)
+    g.set_field(depth, S.MATH_CONSTANT, 0.03)
+    if loop:
+        g.connect(ids["osc_a"], S.OSC_OUT_SAW, depth, 0)
+    else:
+        lfo = g.add_module(S.MOD_OSCILLATOR)
+        g.set_field(lfo, S.OSC_VAL, -6.0)
+        g.connect(lfo, S.OSC_OUT_SAW, depth, 0)
+    g.connect(depth, 0, ids["osc_a"], 0)   # port 0: the 1 V/oct CV
+    return ids
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [pytest.param(0, id="default"), pytest.param(2, id="interp"), pytest.param(34, id="special")])
+@pytest.mark.parametrize("loop", [False, True], ids=["feed-forward", "loop"])
+def test_a_saw_that_reaches_a_pitch(S, oracle, loop, flags):
+    """A saw that modulates a pitch is INTEGRATED by the phase accumulator behind it: the default mode's f32 PolyBLEP (a biased 1e-7) left
+    2e-4 on the carrier after one second.  Feed-forward, the producing oscillator alone gets the exact PolyBLEP (OSC_EXACT_BLEP) and the
+    rest of the patch keeps the default arithmetic; a loop through the pitch input puts the whole patch into the exact flavour.  Either
+    way the full second stays inside the contract."""
+    V, T, B = 24, 48000, 64
+    det, cut = S.p1_voice_params(V)
+    o = oracle.OraclePatch(48000, B, 2)
+    ids = _vibrato(o, S, loop)
+    ref, _ = o.render_batch(V, T, [(ids["osc_a"], S.OSC_VAL, det), (ids["vcf"], S.VCF_FREQ, cut)], threads=8)
+    p = S.Patch(48000, B, 2)
+    _vibrato(p, S, loop)
+    p.configure_voices(V)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    src = p.kernel_source(flags)
+    assert ("vcf_run<false>" in src) == loop and ("vcf_run<true>" in src) == (not loop)   # the ladder tells which flavour the patch got
+    fr = p.render_channels(T, flags)
+    if loop:  # the exact flavour: saw and filter bit-identical
+        np.testing.assert_array_equal(bits(fr), bits(ref))
+    else:
+        assert assert_close(fr, ref) < 5e-6
+    assert np.abs(ref[0]).max() > 0.05

@@ -381,11 +381,11 @@ def test_specialised_kernel_source_of_p1_and_p3(S):
     p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
     src = p.kernel_source(S.RENDER_NO_FUSION)
     assert 'extern "C" __global__' in src and "srk_voice(KernelArgs a)" in src
-    assert "cosc_step<0x20u>" in src and "vcf_step<true>" in src and "emit_put<KOUT>" in src  # the carried-phase saw, the default-mode ladder
+    assert "cosc_step<0x20u>" in src and "vcf_run<true>" in src and "emit_put<KOUT>" in src  # the carried-phase saw, the default-mode ladder
     assert "srk_ctl0" in src and "adsr_seg_step" in src and "a.ctl_slots[blockIdx.x]" in src   # the gate -> envelope unit rides along
     assert "rowf(14)" in src and "a.ops[1].par_val[2]" in src                               # per-voice cutoff from its row, uniform exp_amt from the op list
     exact = p.kernel_source(S.RENDER_NO_FUSION | S.RENDER_EXACT_OSC)
-    assert "vcf_step<false>" in exact and "osc_step(" in exact
+    assert "vcf_run<false>" in exact and "osc_step(" in exact
     # parameter VALUES are not part of the kernel: an edit does not ask for another compilation
     p.set_field(ids["vcf"], S.VCF_RES, 0.7)
     p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut[::-1].copy())

@@ -44,3 +44,10 @@ for v in "$@"; do
     p4_interp) run p4_interp --workload p4 --flags 16 ;;
   esac
 done
+for v in "$@"; do
+  case $v in
+    cfg4_exact) run cfg4_exact --workload cfg4 --flags 1 --steps 2 --warmup 1 ;;
+    cfg4_special_exact) run cfg4_special_exact --workload cfg4 --flags 3 --steps 2 --warmup 1 ;;
+    p3_exact) run p3_exact --workload p3 --flags 1 --steps 2 --warmup 1 ;;
+  esac
+done
