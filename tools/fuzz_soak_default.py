@@ -19,13 +19,19 @@ for seed in range(lo, hi):
     ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]
     ref, _ = o.render_batch(V, T, ov, threads=8)
     r64 = ref.astype(np.float64)
-    for flags in (0, 2, 4):
+    # FUZZ_SPECIAL=1: the same through the kernels specialised at run time (what 4096 voices and more get by default)
+    for flags in ((34, 38) if os.environ.get("FUZZ_SPECIAL") else (0, 2, 4)):
         p = S.Patch(48000, B, 2)
         build(p)
         p.configure_voices(V)
         for m, f, vals in ov:
             p.set_voice_field(m, f, vals)
-        fr = p.render_channels(T, flags)
+        try:
+            fr = p.render_channels(T, flags)
+        except S.SrackError as e:  # a reverb: the generator does not cover it
+            if flags & 32 and e.code == S.ERR_UNSUPPORTED:
+                continue
+            raise
         n += 1
         ok = np.isfinite(r64) & np.isfinite(fr)
         mask_same = (np.isnan(fr) == np.isnan(ref)).all() and (np.isinf(fr) == np.isinf(ref)).all()
