@@ -651,30 +651,67 @@ SRK_DEV float clamp1(float x)
     return fmaxf(fminf(x, 1.0f), -1.0f);
 }
 
-// filter.rs:61-68 — recompute only when (frequency, res) changed.  kFast folds the polynomials' multiply-adds into fmas
-// (10 instructions instead of 14; matters when an envelope sweeps the cutoff and the coefficients change every sample).
-template <bool kFast = false>
-SRK_DEV void vcf_coeffs(VcfRegs& s, float frequency, float res)
+// filter.rs:61-68, the polynomials.  kFast folds their multiply-adds into fmas (10 instructions instead of 14; matters when an
+// envelope sweeps the cutoff and the coefficients change every sample).
+template <bool kFast>
+SRK_DEV void vcf_polys(float frequency, float res, float& p, float& f, float& qq)
 {
-    const bool changed = frequency != s.freq || res != s.res;
-    if (__builtin_amdgcn_ballot_w64(changed) != 0) {  // wave-uniform skip; lanes whose pair is unchanged keep their coefficients
-        const float q = 1.0f - frequency;
+    const float q = 1.0f - frequency;
+    if (kFast) {
+        p = __builtin_fmaf(0.8f * frequency, q, frequency);
+        f = __builtin_fmaf(p, 2.0f, -1.0f);
+        qq = res * __builtin_fmaf(0.5f * q, __builtin_fmaf(5.6f * q, q, 1.0f - q), 1.0f);
+    } else {
+        p = frequency + 0.8f * frequency * q;
+        f = p * 2.0f - 1.0f;
+        qq = res * (1.0f + 0.5f * q * (1.0f - q + 5.6f * q * q));
+    }
+}
+
+// Lanes whose (frequency, res) pair changed take new coefficients, the others keep theirs (`changed_lanes`: the ballot of `changed`,
+// not zero).  A cutoff swept by an envelope changes in every lane at once: that case, wave-uniform and known before the arithmetic,
+// computes straight into the state instead of into temporaries behind five selects.
+template <bool kFast>
+SRK_DEV void vcf_coeffs_update(VcfRegs& s, bool changed, uint64_t changed_lanes, float frequency, float res)
+{
+    if (changed_lanes == __builtin_amdgcn_ballot_w64(true)) {
+        asm volatile("");  // (keeps the two arms apart: merged, they are the selects again, behind a select of their condition)
+        s.freq = frequency;
+        s.res = res;
+        vcf_polys<kFast>(frequency, res, s.p, s.f, s.q);
+    } else {
         float p, f, qq;
-        if (kFast) {
-            p = __builtin_fmaf(0.8f * frequency, q, frequency);
-            f = __builtin_fmaf(p, 2.0f, -1.0f);
-            qq = res * __builtin_fmaf(0.5f * q, __builtin_fmaf(5.6f * q, q, 1.0f - q), 1.0f);
-        } else {
-            p = frequency + 0.8f * frequency * q;
-            f = p * 2.0f - 1.0f;
-            qq = res * (1.0f + 0.5f * q * (1.0f - q + 5.6f * q * q));
-        }
+        vcf_polys<kFast>(frequency, res, p, f, qq);
         s.freq = changed ? frequency : s.freq;
         s.res = changed ? res : s.res;
         s.p = changed ? p : s.p;
         s.f = changed ? f : s.f;
         s.q = changed ? qq : s.q;
     }
+}
+
+// filter.rs:61-68 — recompute only when (frequency, res) changed.
+template <bool kFast = false>
+SRK_DEV void vcf_coeffs(VcfRegs& s, float frequency, float res)
+{
+    const bool changed = frequency != s.freq || res != s.res;
+    const uint64_t changed_lanes = __builtin_amdgcn_ballot_w64(changed);
+    if (changed_lanes != 0) vcf_coeffs_update<kFast>(s, changed, changed_lanes, frequency, res);  // wave-uniform skip
+}
+
+// The same for a kernel whose `res` cannot change during a launch (a parameter; only the cutoff has a CV): vcf_res_settle, once
+// before the first sample, marks the lanes whose stored coefficients belong to another resonance (a NaN in `freq` differs from
+// every frequency, and vcf_frequency never yields one), so that the per-sample test is the one compare of the frequency.
+SRK_DEV void vcf_res_settle(VcfRegs& s, float res)
+{
+    if (res != s.res) s.freq = __builtin_nanf("");
+}
+template <bool kFast = false>
+SRK_DEV void vcf_coeffs_freq(VcfRegs& s, float frequency, float res)
+{
+    const bool changed = frequency != s.freq;
+    const uint64_t changed_lanes = __builtin_amdgcn_ballot_w64(changed);
+    if (changed_lanes != 0) vcf_coeffs_update<kFast>(s, changed, changed_lanes, frequency, res);
 }
 
 // filter.rs:69-82 — returns lowpass; band/highpass through references (caller stores only live ports).
@@ -753,6 +790,9 @@ SRK_DEV void vcf_run(VcfRegs& s, bool& fin, float input, float& lowpass, float& 
 // (self.freq + cv * self.exp_amt).max(0.0).min(0.9), filter.rs:213
 SRK_DEV float vcf_frequency(float freq, float cv, float exp_amt) { return fminf(fmaxf(freq + cv * exp_amt, 0.0f), 0.9f); }
 SRK_DEV float vcf_resonance(float res) { return fminf(fmaxf(res, 0.0f), 1.0f); }  // filter.rs:214
+// default mode: the two clamps as one v_med3_f32 — the same value for every input, NaN included (max(NaN, 0) = 0 = the smaller of the
+// other two); only a frequency of -0.0 may come out as either zero
+SRK_DEV float vcf_frequency_med3(float freq, float cv, float exp_amt) { return __builtin_amdgcn_fmed3f(freq + cv * exp_amt, 0.0f, 0.9f); }
 
 // ---------------------------------------------------------------------------------------------
 // ADSR — adsr.rs:138-214
@@ -919,6 +959,15 @@ SRK_DEV float vca_step(uint32_t flags, bool negative, float audio, float cv)
 {
     if ((flags & (VCA_HAS_AUDIO | VCA_HAS_CV)) != (VCA_HAS_AUDIO | VCA_HAS_CV)) return zero_f32();  // output.fill(0.0)
     return (negative || cv > 0.0f) ? audio * cv : 0.0f;
+}
+
+// the same with a wave-uniform cv (a control track read through the scalar unit): `cv > 0.0` is decided on the scalar unit from the
+// bit pattern — positive, non-zero, not NaN  <=>  0 < bits <= 0x7f800000
+SRK_DEV float vca_step_uniform(uint32_t flags, bool negative, float audio, float cv)
+{
+    if ((flags & (VCA_HAS_AUDIO | VCA_HAS_CV)) != (VCA_HAS_AUDIO | VCA_HAS_CV)) return zero_f32();
+    const bool cv_pos = (uint32_t)(__float_as_int(cv) - 1) < 0x7f800000u;
+    return (negative || cv_pos) ? audio * cv : 0.0f;
 }
 
 SRK_DEV float mixer_step(uint32_t connected, const float in[4], const float gain[4])
