@@ -436,6 +436,36 @@ SRK_DEV float cosc_step(COsc& o)
     return cosc_sine(o);
 }
 
+// The exact render mode's constant-pitch square / saw behind the same guards (host-proved OSC_CONST_SMALL).  Outside its PolyBLEP
+// windows the reference's own value is -1 / +1 (the two blep terms are 0.0 and 0.0 - 0.0 = 0.0) resp. (pos as f32) * 2 - 1, and its
+// `pos %= 1.0` is the exact v_fract of a sum below 2; a sample with ANY lane inside a window (or a phase outside [0, 1): the guards
+// read it as "near") takes osc_step's literal f64 formulas.  Bit-identical to oscillator.rs:108-158 either way.  Worth it where
+// windows are rare: an LFO in any wave (64 lanes x 4 windows of 3.6e-5: 1 % of the samples), any oscillator of a control unit (one voice).
+template <uint32_t kPort>
+SRK_DEV float cosc_exact_step(COsc& o)
+{
+    const int h = __double2hiint(o.pos);
+    uint64_t near = __builtin_amdgcn_ballot_w64(h <= o.hA) | __builtin_amdgcn_ballot_w64(h >= o.hB);
+    if (kPort == OSC_OUT_SQUARE) near |= __builtin_amdgcn_ballot_w64((uint32_t)(h - o.hQ0) <= o.hQspan);
+    if (near != 0) {
+        OscRegs g;
+        g.pos = o.pos;
+        g.sync_last = false;
+        OscConst k;
+        k.delta = o.delta;
+        k.val = 0.0;
+        k.sr = 0.0;
+        k.inv_dt = 0.0f;
+        float o3[3] = {0.0f, 0.0f, 0.0f};
+        osc_step(OSC_AA | OSC_EXACT | kPort, g, k, 0.0f, 0.0f, o3[0], o3[1], o3[2]);
+        o.pos = g.pos;
+        return kPort == OSC_OUT_SQUARE ? o3[1] : o3[2];
+    }
+    const float y = kPort == OSC_OUT_SQUARE ? (h < 0x3fe00000 ? -1.0f : 1.0f) : (float)o.pos * 2.0f - 1.0f;
+    o.pos = __builtin_amdgcn_fract(o.pos + o.delta);
+    return y;
+}
+
 // ---------------------------------------------------------------------------------------------
 // A sequencer-driven pitch (default mode; host-proved OSC_CV_STEPWISE, PolyBLEP on, no sync, one live port): the carried-
 // phase oscillator between note changes.  When some lane's CV differs from the one its increment was computed for (a wave-
@@ -785,6 +815,16 @@ SRK_DEV void vcf_run(VcfRegs& s, bool& fin, float input, float& lowpass, float& 
         vcf_step<false, false>(s, input, lowpass, bandpass, highpass);
         fin = true;
     }
+}
+
+// The literal ladder behind an input that is known to be finite and small (`bounded`, wave-uniform: e.g. the tile-wise exact saw, whose
+// preconditions bound it by 2): no per-sample look at the input.
+SRK_DEV void vcf_run_bounded(VcfRegs& s, bool& fin, bool bounded, float input, float& lowpass, float& bandpass, float& highpass)
+{
+    if (fin && bounded)
+        vcf_step<false, true>(s, input, lowpass, bandpass, highpass);
+    else
+        vcf_run<false>(s, fin, input, lowpass, bandpass, highpass);
 }
 
 // (self.freq + cv * self.exp_amt).max(0.0).min(0.9), filter.rs:213

@@ -385,7 +385,10 @@ def test_specialised_kernel_source_of_p1_and_p3(S):
     assert "srk_ctl0" in src and "adsr_seg_step" in src and "a.ctl_slots[blockIdx.x]" in src   # the gate -> envelope unit rides along
     assert "rowf(14)" in src and "a.ops[1].par_val[2]" in src                               # per-voice cutoff from its row, uniform exp_amt from the op list
     exact = p.kernel_source(S.RENDER_NO_FUSION | S.RENDER_EXACT_OSC)
-    assert "vcf_run<false>" in exact and "osc_step(" in exact
+    # exact mode: the tile-wise saw with the literal per-sample oscillator behind it, the literal ladder without a look at its (bounded)
+    # input, the sample loop versioned on both preconditions; the gate LFO of the control unit leaves its PolyBLEP windows to osc_step
+    assert "xsaw_tile(" in exact and "osc_step(" in exact and "vcf_run_bounded(" in exact and "if (m0_xs && m1_fin) {" in exact
+    assert "cosc_exact_step<0x10u>" in exact
     # parameter VALUES are not part of the kernel: an edit does not ask for another compilation
     p.set_field(ids["vcf"], S.VCF_RES, 0.7)
     p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut[::-1].copy())
