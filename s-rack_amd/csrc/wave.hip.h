@@ -24,6 +24,13 @@ SRK_DEV uint32_t f64_hi(double d) { return (uint32_t)__double2hiint(d); }
 
 SRK_DEV float readlane_f32(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }  // `lane` wave-uniform
 
+// Do the 32 samples of a control track that start at `p` hold one bit pattern?  (wave-uniform; one load and one compare per tile)
+SRK_DEV bool track_flat(const float* p, int lane)
+{
+    const uint32_t v = ((const uint32_t*)p)[lane & 31];
+    return __builtin_amdgcn_ballot_w64(v != (uint32_t)__builtin_amdgcn_readfirstlane((int)v)) == 0;
+}
+
 struct WaveMap {   // which voices a wave owns
     uint32_t wave0;     // first voice of the wave
     uint32_t n_active;  // real voices in it (lanes >= n_active shadow voice wave0 + n_active - 1: same work, same stores)
