@@ -293,21 +293,21 @@ def cpu_baseline(S, workload, n_samples=48000):
     }
 
 
-def profiled_traffic(kernel_name, workload, V, T):
-    """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC summary (profiles/*_summary.json, written
+def profiled_traffic(kernel_name, workload, flags, V, T):
+    """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC summary (profiles/rNN<tag>_summary.json, written
     by profiles/summarize.py from separate WRITE_SIZE / FETCH_SIZE passes of this very command), or None.  NOT measured in
     this run — a profiler cannot run inside the timed region — and only valid for the default size of the workload."""
-    import glob
+    import glob, re
     if (V, T) != (default_voices(workload), 48000):
         return None
+    tag = {("cfg3", 0): "", ("cfg3", 1): "_exact", ("cfg3", 2): "_special", ("cfg3", 3): "_special_exact", ("p3", 0): "_p3", ("p3", 1): "_p3_exact",
+           ("cfg4", 0): "_cfg4", ("cfg4_b1024", 0): "_cfg4_b1024", ("cfg2", 0): "_cfg2", ("p4", 0): "_p4"}.get((workload, flags))
+    if tag is None:
+        return None
     best = None
-    suffix = {"cfg3": ("_summary.json",), "p3": ("_p3_summary.json",), "cfg4": ("_cfg4_summary.json",), "cfg4_b1024": ("_cfg4_b1024_summary.json",),
-              "cfg2": ("_cfg2_summary.json",), "p4": ("_p4_summary.json",)}[workload]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_summary.json"))):
         base = os.path.basename(path)
-        if workload == "cfg3" and base.count("_") != 1:
-            continue
-        if workload != "cfg3" and not base.endswith(suffix):
+        if not re.fullmatch(r"r\d\d" + re.escape(tag) + r"_summary\.json", base):
             continue
         try:
             d = json.load(open(path))
@@ -412,7 +412,7 @@ def run_rank(args, backend_cls=HipBackend):
         if args.workload == "cfg2":
             out["roofline"]["note"] = ("identical voices: the whole patch is one voice-invariant latency chain evaluated by ONE wave, the frames are "
                                        "a broadcast of its track — a few percent of the HBM roofline by construction (plumbing configuration)")
-        tr = profiled_traffic(kname, args.workload, V, T) if be.name == "hip" and args.flags == 0 and not args.no_frames and not args.no_mix else None
+        tr = profiled_traffic(kname, args.workload, args.flags, V, T) if be.name == "hip" and not args.no_frames and not args.no_mix else None
         if tr:
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
             out["roofline"]["traffic_detail"] = dict(tr, measured_in_this_run=False,

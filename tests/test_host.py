@@ -400,6 +400,15 @@ def test_specialised_kernel_source_of_p1_and_p3(S):
     src3 = q.kernel_source(0)
     assert src3.count("static __device__ __forceinline__ void srk_ctl") == 5 and "steposc_step<0x20u>" in src3 and "emit_track_put" in src3
     assert "seq_advance" in src3 and "readlane_f32(trk" in src3
+    # track values reach the sample function as arguments, fetched a group of samples ahead; a swept cutoff compares the frequency only
+    assert "auto sample = [&](int i, float tk0, float tk1, float tk2, float tk3)" in src3 and "tg0[u] = trk0[t0 + (uint32_t)(i0 + u)]" in src3
+    assert "vcf_res_settle(" in src3 and "vcf_coeffs_freq<true>" in src3 and "vcf_frequency_med3(" in src3 and "vca_step_uniform(" in src3
+    exact3 = q.kernel_source(S.RENDER_EXACT_OSC)
+    # exact mode: the sequenced saw tile-wise wherever its note track is flat over the tile, the literal ladder told so by a scalar;
+    # the clock LFO's square leaves only its PolyBLEP windows to the f64 formulas
+    assert "track_flat(trk0_v + t0, lane)" in exact3 and "xsaw_tile(m1_x, m1_xt, kMixPitch, kMixRows)" in exact3
+    assert "vcf_run_bounded(m2, m2_fin, m1_flat" in exact3 and "vcf_coeffs_freq<false>" in exact3 and "vcf_frequency(" in exact3
+    assert "cosc_exact_step<0x10u>" in exact3
     r = S.Patch(48000, 64, 2)   # the one module the generator leaves to the interpreter
     v, o = r.add_module(S.MOD_FREEVERB), r.add_module(S.MOD_OUTPUT)
     r.connect(v, 0, o, 0)
