@@ -356,6 +356,7 @@ int Builder::build()
             op.kind = OP_NONLIN;
             if (connected(0)) op.flags |= MATH_HAS_IN1;
             if (connected(1)) op.flags |= MATH_HAS_IN2;
+            if (render_flags & SRACK_RENDER_EXACT_OSC) op.flags |= NONLIN_EXACT;
             param(op, NONLIN_P_CONST, m, SRACK_NONLIN_CONSTANT, deferred);
             break;
         case SRACK_MOD_FREEVERB: {  // freeverb.rs + the freeverb crate's Freeverb::new / set_* (restated; see oracle/srack_oracle.c)

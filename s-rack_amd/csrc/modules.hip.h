@@ -1058,10 +1058,67 @@ SRK_DEV float noise_sample(uint64_t key, uint64_t n)
 // except within ~1e-13 of a rounding boundary — as close to libm's powf (itself within ~2^-34 of exact before
 // its final rounding) as any implementation other than libm's own tables gets.  Everything else (zeros,
 // infinities, NaNs, over/underflow) goes to ocml's powf, which implements the C99 special cases libm does.
-SRK_DEV float powf_pos(float x, float b)
+// log2 of a normal positive f32, in f64, absolute error < 1e-15 + the table's rounding (default mode; the exact mode keeps ocml's
+// log2, whose double-double arithmetic costs four times as much): x = 2^e * m, the mantissa's top five bits pick c = 1 + (i + 1/2) / 32
+// with 1 / c and log2(c) from a table, z = m / c - 1 is at most 1 / 64 in size (one fma: m has 24 bits), and
+// log2(1 + z) = z * (a1 + a2 z + ... + a7 z^6) — the Taylor series, whose next term is 6e-16 there — by Estrin's scheme.
+__device__ const uint64_t kLog2Tab[32][2] = {  // {bits(1 / c_i), bits(log2 c_i)}
+    {0x3fef81f81f81f820, 0x3f96e79685c2d22a},
+    {0x3fee9131abf0b767, 0x3fb0eb389fa29f9b},
+    {0x3fedae6076b981db, 0x3fbbc84240adabba},
+    {0x3fecd85689039b0b, 0x3fc32ae9e278ae1a},
+    {0x3fec0e070381c0e0, 0x3fc84c2bd02f03b3},
+    {0x3feb4e81b4e81b4f, 0x3fcd49ee4c325970},
+    {0x3fea98ef606a63be, 0x3fd11307dad30b76},
+    {0x3fe9ec8e951033d9, 0x3fd37124cea4cded},
+    {0x3fe948b0fcd6e9e0, 0x3fd5c01a39fbd688},
+    {0x3fe8acb90f6bf3aa, 0x3fd800a563161c54},
+    {0x3fe8181818181818, 0x3fda33760a7f6051},
+    {0x3fe78a4c8178a4c8, 0x3fdc592fad295b56},
+    {0x3fe702e05c0b8170, 0x3fde726aa1e754d2},
+    {0x3fe6816816816817, 0x3fe03fda8b97997f},
+    {0x3fe6058160581606, 0x3fe140c9faa1e544},
+    {0x3fe58ed2308158ed, 0x3fe23c41d42727c8},
+    {0x3fe51d07eae2f815, 0x3fe3327c6ab49ca7},
+    {0x3fe4afd6a052bf5b, 0x3fe423b07e986aa9},
+    {0x3fe446f86562d9fb, 0x3fe510118708a8f9},
+    {0x3fe3e22cbce4a902, 0x3fe5f7cff41e09af},
+    {0x3fe3813813813814, 0x3fe6db196a76194a},
+    {0x3fe323e34a2b10bf, 0x3fe7ba18f93502e4},
+    {0x3fe2c9fb4d812ca0, 0x3fe894f74b06ef8b},
+    {0x3fe27350b8812735, 0x3fe96bdad2acb5f6},
+    {0x3fe21fb78121fb78, 0x3fea3ee7f38e181f},
+    {0x3fe1cf06ada2811d, 0x3feb0e4126bcc86c},
+    {0x3fe1811811811812, 0x3febda071cc67e6e},
+    {0x3fe135c81135c811, 0x3feca258dca93316},
+    {0x3fe0ecf56be69c90, 0x3fed6753e032ea0f},
+    {0x3fe0a6810a6810a7, 0x3fee29142e0e0140},
+    {0x3fe0624dd2f1a9fc, 0x3feee7b471b3a950},
+    {0x3fe0204081020408, 0x3fefa34e1177c233},
+};
+SRK_DEV double log2_pos_f32(float x)
 {
-    const double y = (double)b * ::log2((double)x);
-    const bool fast = x > 0.0f && x < __builtin_inff() && __builtin_fabs(y) < 126.0;  // NaN x / b / y: false
+    const uint32_t bits = __float_as_uint(x);
+    const int e = (int)(bits >> 23) - 127;
+    const uint32_t i = (bits >> 18) & 31u;
+    const double m = (double)__uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
+    const double inv_c = __longlong_as_double((long long)kLog2Tab[i][0]), log_c = __longlong_as_double((long long)kLog2Tab[i][1]);
+    const double z = __builtin_fma(m, inv_c, -1.0);
+    const double z2 = z * z, z4 = z2 * z2;
+    const double p01 = __builtin_fma(-0.7213475204444817, z, 1.4426950408889634);
+    const double p23 = __builtin_fma(-0.36067376022224085, z, 0.4808983469629878);
+    const double p45 = __builtin_fma(-0.2404491734814939, z, 0.28853900817779266);
+    const double q0 = __builtin_fma(p23, z2, p01);
+    const double q1 = __builtin_fma(0.2060992915555662, z2, p45);
+    const double p = __builtin_fma(q1, z4, q0);
+    return __builtin_fma(z, p, (double)e + log_c);
+}
+
+SRK_DEV float powf_pos(float x, float b, bool exact)
+{
+    // (a subnormal x goes to ocml's powf below, like every other special case)
+    const double y = (double)b * (exact ? ::log2((double)x) : log2_pos_f32(x >= 0x1p-126f ? x : 1.0f));
+    const bool fast = x >= 0x1p-126f && x < __builtin_inff() && __builtin_fabs(y) < 126.0;  // NaN x / b / y: false
     float r = (float)exp2_fast(fast ? y : 0.0);
     if (__builtin_amdgcn_ballot_w64(!fast)) {
         if (!fast) r = ::powf(x, b);
@@ -1074,7 +1131,7 @@ SRK_DEV float nonlin_step(uint32_t flags, float in1, float in2, float constant)
     const float a = (flags & MATH_HAS_IN1) ? in1 : zero_f32();
     const float b = (flags & MATH_HAS_IN2) ? in2 : constant;
     const bool pos = a > 0.0f;
-    const float r = powf_pos(pos ? a : -a, b);
+    const float r = powf_pos(pos ? a : -a, b, (flags & NONLIN_EXACT) != 0);
     return pos ? r : -r;
 }
 

@@ -77,7 +77,8 @@ enum : uint32_t {
     MATH_HAS_IN1 = 1u << 0,
     MATH_HAS_IN2 = 1u << 1,
     MATH_OP_SHIFT = 4,        // bits 4..5 = SRACK_MATH_ADD / SUBTRACT / MULTIPLY
-    // OP_NONLIN: MATH_HAS_IN1 / MATH_HAS_IN2
+    // OP_NONLIN: MATH_HAS_IN1 / MATH_HAS_IN2, and
+    NONLIN_EXACT = 1u << 8,   // exact render mode: ocml's f64 log2 inside the power (default: a table-driven one, modules.hip.h)
     // OP_SAMPLE
     SMP_HAS_GATE = 1u << 0,
     SMP_HAS_CV = 1u << 1,
