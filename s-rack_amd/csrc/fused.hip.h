@@ -8,6 +8,7 @@
 //   mix_reduce_groups/final   deterministic sum of the per-wave partials (no atomics)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "interp.hip.h"
 
@@ -676,6 +677,26 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
     }
 }
 
+// Wave-uniform facts about an FM pair's voices (default mode), from which the kernels below pick their sample loop.  Inactive lanes
+// mirror a real voice (WaveMap::vc), so every lane votes.
+struct FmFacts {
+    bool tame = false;     // both exponents below 1000 in magnitude, both phases in [0, 1), sample rates >= 1: increments finite and >= 0
+    bool small_m = false;  // modulator: |feedback constant| + |val| <= 1/2 (given a fed-back value of magnitude <= 1)
+    bool small_c = false;  // carrier:   |index constant| + |val| <= 1/2
+};
+SRK_DEV FmFacts fm_facts(float c_fb, const dev::OscConst& km, double pos_m, float c_ix, const dev::OscConst& kc, double pos_c)
+{
+    // f32 sums of magnitudes, compared with a margin that covers their rounding and the product's (cv = sine * constant in f32)
+    const float em = __builtin_fabsf(c_fb) + __builtin_fabsf((float)km.val), ec = __builtin_fabsf(c_ix) + __builtin_fabsf((float)kc.val);
+    const bool phases = pos_m >= 0.0 && pos_m < 1.0 && pos_c >= 0.0 && pos_c < 1.0;
+    const bool rates = km.sr >= 1.0 && kc.sr >= 1.0;  // 440 / sr finite
+    FmFacts f;
+    f.tame = __builtin_amdgcn_ballot_w64(!(em < 1000.0f && ec < 1000.0f && phases && rates)) == 0;  // NaNs vote no
+    f.small_m = __builtin_amdgcn_ballot_w64(!(em <= 0.4999f)) == 0;
+    f.small_c = __builtin_amdgcn_ballot_w64(!(ec <= 0.4999f)) == 0;
+    return f;
+}
+
 // ---- fused 2-operator FM with a z^-1 feedback edge (patch P2's shape, buffer_size == 1) --------------------
 //   MATH_FB(in1 = OSC_M.sine delayed by one sample) -> OSC_M.cv ; OSC_M.sine -> MATH_IDX -> OSC_C.cv ; OSC_C.sine -> out
 // The broken edge is a one-sample delay, so the fed-back sine lives in a VGPR ("in-register recurrence").
@@ -724,23 +745,43 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
     float sine_m = 0.0f;
     double pos_m = sm.pos;  // modulator phase after exactly t samples (the loop runs it one sample ahead)
     if (a.T > 0) osc_step(fo, sm, km, fed * c_fb, 0.0f, sine_m, sq, sw);  // modulator of sample 0
+    // What a wave can prove about its own voices once per launch (default mode).  A sine is at most 1 in magnitude, so each oscillator's
+    // exponent cv + val is bounded by |constant| + |val|: below 1000 the increment is finite and positive and the wrap is one v_fract
+    // (OSC_PHASE_TAME); at most 1/2 and 2^x needs no range reduction (OSC_CV_SMALL).  The first modulator step above ran without either:
+    // the ring's initial value is the host's, not a sine.
+    const FmFacts facts = kExact ? FmFacts{} : fm_facts(c_fb, km, sm.pos, c_ix, kc, sc.pos);
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
-        auto sample = [&](int i) {
-            const float cur = sine_m;  // OSC_M.sine[t]: feeds the carrier now and, through the z^-1 ring, the modulator of t+1
-            float out = 0.0f;
-            osc_step(fo_carrier, sc, kc, cur * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
-            pos_m = sm.pos;
-            osc_step(fo, sm, km, cur * c_fb, 0.0f, sine_m, sq, sw);   // modulator of sample t+1 (independent of the carrier)
-            fed = cur;
-            emit_put<kOut>(em, mix_tile, out, i, V);
-        };
-        if (n == kMixRows) {  // straight-line code over several samples: the tail of one sample's chains overlaps the head of the next's
+        auto tile = [&](auto fm_c, auto fc_c, auto whole) {
+            constexpr uint32_t FM = decltype(fm_c)::value, FC = decltype(fc_c)::value;
+            auto sample = [&](int i) {
+                const float cur = sine_m;  // OSC_M.sine[t]: feeds the carrier now and, through the z^-1 ring, the modulator of t+1
+                float out = 0.0f;
+                osc_step(FC, sc, kc, cur * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
+                pos_m = sm.pos;
+                osc_step(FM, sm, km, cur * c_fb, 0.0f, sine_m, sq, sw);   // modulator of sample t+1 (independent of the carrier)
+                fed = cur;
+                emit_put<kOut>(em, mix_tile, out, i, V);
+            };
+            if (decltype(whole)::value) {  // straight-line code over several samples: the tail of one sample's chains overlaps the head of the next's
 #pragma unroll SRK_FM_UNROLL
-            for (int i = 0; i < kMixRows; i++) sample(i);
-        } else {
-            for (int i = 0; i < n; i++) sample(i);
-        }
+                for (int i = 0; i < kMixRows; i++) sample(i);
+            } else {
+                for (int i = 0; i < n; i++) sample(i);
+            }
+        };
+        using std::integral_constant;
+        using std::true_type;
+        using std::false_type;
+        if (n != kMixRows) tile(integral_constant<uint32_t, fo>{}, integral_constant<uint32_t, fo_carrier>{}, false_type{});
+        else if (facts.tame && facts.small_m && facts.small_c)
+            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME | OSC_CV_SMALL>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME | OSC_CV_SMALL>{}, true_type{});
+        else if (facts.tame && facts.small_m)
+            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME | OSC_CV_SMALL>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME>{}, true_type{});
+        else if (facts.tame)
+            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME>{}, true_type{});
+        else
+            tile(integral_constant<uint32_t, fo>{}, integral_constant<uint32_t, fo_carrier>{}, true_type{});
         emit_flush<kOut>(em, mix_tile, t0, n, V);
     }
     sm.pos = pos_m;  // drop the look-ahead step
@@ -811,27 +852,54 @@ __global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRol
     const bool ahead = B >= 2u * (uint32_t)kMixRows;
     float fed[kMixRows];
     load_tile(fed, p0);
+    FmFacts facts = kExact ? FmFacts{} : fm_facts(c_fb, km, sm.pos, c_ix, kc, sc.pos);  // as in render_fm_pair; re-proved below once a tile left them
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
         const bool more = t0 + kMixRows < a.T;
         float nxt[kMixRows];
         if (ahead && more) load_tile(nxt, ring_at(p0 + (uint32_t)kMixRows));
-        auto sample = [&](int i) {
-            float sine_m = 0.0f, out = 0.0f;
-            osc_step(fo, sm, km, fed[i] * c_fb, 0.0f, sine_m, sq, sw);   // modulator of sample t
-            const uint32_t p = p0 + (uint32_t)i < B ? p0 + (uint32_t)i : p0 + (uint32_t)i - B;
-            if (active) ring[(size_t)p * V + voice] = sine_m;
-            osc_step(fo_carrier, sc, kc, sine_m * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
-            emit_put<kOut>(em, mix_tile, out, i, V);
-        };
-        if (n == kMixRows) {
+        auto tile = [&](auto fm_c, auto fc_c, auto whole) {
+            constexpr uint32_t FM = decltype(fm_c)::value, FC = decltype(fc_c)::value;
+            auto sample = [&](int i) {
+                float sine_m = 0.0f, out = 0.0f;
+                osc_step(FM, sm, km, fed[i] * c_fb, 0.0f, sine_m, sq, sw);   // modulator of sample t
+                const uint32_t p = p0 + (uint32_t)i < B ? p0 + (uint32_t)i : p0 + (uint32_t)i - B;
+                if (active) ring[(size_t)p * V + voice] = sine_m;
+                osc_step(FC, sc, kc, sine_m * c_ix, 0.0f, out, sq, sw);      // carrier of sample t
+                emit_put<kOut>(em, mix_tile, out, i, V);
+            };
+            if (decltype(whole)::value) {
 #pragma unroll SRK_FM_UNROLL
-            for (int i = 0; i < kMixRows; i++) sample(i);
-        } else {
+                for (int i = 0; i < kMixRows; i++) sample(i);
+            } else {
 #pragma unroll
-            for (int i = 0; i < kMixRows; i++)
-                if (i < n) sample(i);
+                for (int i = 0; i < kMixRows; i++)
+                    if (i < n) sample(i);
+            }
+        };
+        using std::integral_constant;
+        using std::true_type;
+        using std::false_type;
+        // the ring's first lap holds whatever the host put there (a rack file's saved buffers), not sines: the bound on the exponents
+        // (fm_facts) holds for a tile whose 32 fed-back values are at most 1 in magnitude — one v_max per sample, wave-uniform per tile
+        bool fed_unit = false;
+        if (!kExact && facts.tame && n == kMixRows) {
+            float m = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kMixRows; i++) m = __builtin_fmaxf(m, __builtin_fabsf(fed[i]));
+            // (max skips a NaN, and may: a NaN CV makes the increment and then the phase NaN through either form of 2^x and of the wrap)
+            fed_unit = __builtin_amdgcn_ballot_w64(!(m <= 1.0f)) == 0;
         }
+        if (n != kMixRows) tile(integral_constant<uint32_t, fo>{}, integral_constant<uint32_t, fo_carrier>{}, false_type{});
+        else if (fed_unit && facts.small_m && facts.small_c)
+            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME | OSC_CV_SMALL>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME | OSC_CV_SMALL>{}, true_type{});
+        else if (fed_unit && facts.small_m)
+            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME | OSC_CV_SMALL>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME>{}, true_type{});
+        else if (fed_unit)
+            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME>{}, true_type{});
+        else
+            tile(integral_constant<uint32_t, fo>{}, integral_constant<uint32_t, fo_carrier>{}, true_type{});
+        if (!kExact && !fed_unit) facts = fm_facts(c_fb, km, sm.pos, c_ix, kc, sc.pos);  // the literal forms may have left [0, 1)
         emit_flush<kOut>(em, mix_tile, t0, n, V);
         p0 = ring_at(p0 + (uint32_t)n);
         if (more) {

@@ -90,14 +90,17 @@ struct OscConst {    // per-voice constants, set up once per kernel (or tile)
 // relative accuracy to keep the accumulated phase error of a 1 s render below 1e-7 cycles; this leaves two orders of
 // magnitude.  Evaluated by Estrin's scheme — 8 fma + 3 mul with a dependency depth of 4 instead of Horner's 10: the FM
 // kernels run ONE wave per SIMD, where the length of the per-sample dependency chain, not the instruction count, sets the
-// pace.  Overflow / NaN propagate through ldexp like pow's.
+// pace (8 fma + 2 mul since the degree-8 coefficient joined the f^4 group).  Overflow / NaN propagate through ldexp like pow's.
 // (Measured and dropped: the libm-style form — a 32-entry table of 2^(k/32) from constant memory plus a degree-4 polynomial, 9
 // f64-rate instructions instead of 15.  The table load sits inside the modulator's feedback recurrence and its latency cannot be
 // hidden at one wave per SIMD: config 4 went from 9.4 to 16.5 ms per step.)
+template <bool kReduce = true>
 SRK_DEV double exp2_fast(double x)
 {
-    const double n = __builtin_rint(x);
-    const double f = x - n;
+    // kReduce == false: the caller has proved |x| <= 1/2 (OSC_CV_SMALL), x is its own reduced argument: no rndne / subtract /
+    // cvt_i32 / ldexp, four of the 19 f64-rate instructions of an oscillator's increment.
+    const double n = kReduce ? __builtin_rint(x) : 0.0;
+    const double f = kReduce ? x - n : x;
     const double f2 = f * f;
     const double a01 = __builtin_fma(0.6931471805459332, f, 1.0000000000000004);
     const double a23 = __builtin_fma(0.055504109412108156, f, 0.24022650695814518);
@@ -106,10 +109,9 @@ SRK_DEV double exp2_fast(double x)
     const double f4 = f2 * f2;
     const double b0 = __builtin_fma(a23, f2, a01);
     const double b1 = __builtin_fma(a67, f2, a45);
-    const double f8 = f4 * f4;
-    const double c = __builtin_fma(b1, f4, b0);
-    const double p = __builtin_fma(1.3255179556479267e-06, f8, c);
-    return __builtin_ldexp(p, (int)n);
+    const double b2 = __builtin_fma(1.3255179556479267e-06, f4, b1);  // the degree-8 term rides on f4: no f^8, same depth of 4
+    const double p = __builtin_fma(b2, f4, b0);
+    return kReduce ? __builtin_ldexp(p, (int)n) : p;
 }
 
 // 2^e, correctly rounded (exact render mode).  The reference evaluates `2.0_f64.powf(e)` with the host's libm, whose pow is
@@ -222,15 +224,22 @@ SRK_DEV float poly_blep_sel(float t, float tm1, float inv_dt, bool first, bool s
 // has the reference's own, unbiased, half-ulp error.  That matters because a sine that feeds a pitch CV (FM, vibrato) is
 // INTEGRATED by the next oscillator's phase: an f32 evaluation (6e-8, biased) let config 4 drift to 5e-5 after one second;
 // with this one default mode stays at f32 rounding level.
-SRK_DEV double sine_fold(double pos)  // x in [-1/4, 1/4] with sin(2 pi pos) = -sin(2 pi x)
+// The fold: qn = 1/2 - pos in (-1/2, 1/2] has sin(2 pi pos) = sin(2 pi qn) = sign(qn) sin(2 pi xa) with xa = 1/4 - ||qn| - 1/4| in [0, 1/4].
+// Two f64 additions with |.| source modifiers instead of a reflection, an f64 compare and two selects per lane (14 issue cycles of a
+// sine's ~70: the FM kernels are bound by exactly these).  Both additions are EXACT for every pos in [0, 1): |qn| > 1/4 is Sterbenz's
+// case, and |qn| < 1/8 only happens for pos in (3/8, 5/8), where pos — and with it qn — is a multiple of 2^-54, which 1/4 - |qn| in
+// (1/8, 1/4] can represent.  So xa == |qn| or 1/2 - |qn| exactly, as the reflection gave it.
+SRK_DEV double sine_fold(double pos, uint32_t& sign)  // sign: bit 31 set where the sine is negative (for a pos in [0, 1))
 {
-    const double q = pos - 0.5;                          // [-0.5, 0.5); sin(2 pi pos) = -sin(2 pi q)
-    const double r = __builtin_copysign(0.5, q) - q;     // reflection: sin(2 pi q) = sin(2 pi r) for |q| > 1/4
-    return __builtin_fabs(q) > 0.25 ? r : q;
+    const double qn = 0.5 - pos;
+    sign = (uint32_t)__double2hiint(qn) & 0x80000000u;
+    const double t = __builtin_fabs(qn) - 0.25;
+    return 0.25 - __builtin_fabs(t);
 }
 SRK_DEV float sine_fast(double pos)
 {
-    const double x = sine_fold(pos);
+    uint32_t sign;
+    const double x = sine_fold(pos, sign);
     const double z = x * x;
     const double a01 = __builtin_fma(-41.34170223990684, z, 6.283185307179272);
     const double a23 = __builtin_fma(-76.70584757807868, z, 81.60524914955879);
@@ -240,19 +249,20 @@ SRK_DEV float sine_fast(double pos)
     const double b1 = __builtin_fma(3.6659216216293173, z2, a45);
     const double z4 = z2 * z2;
     const double p = __builtin_fma(b1, z4, b0);
-    return (float)(-(p * x));
+    return __uint_as_float(__float_as_uint((float)(p * x)) ^ sign);  // (xor, not copysign: a phase outside [0, 1) — only a host can store one — folds to a negative x)
 }
 // The same sine for a port whose value cannot reach a pitch input (host-proved, OSC_SINE_LOOSE): nothing integrates its error,
 // so f32 arithmetic after the exact f64 fold is inside the 1e-5 contract (max error 2e-7: a degree-9 polynomial in f32).
 SRK_DEV float sine_loose(double pos)
 {
-    const float x = (float)sine_fold(pos);
+    uint32_t sign;
+    const float x = (float)sine_fold(pos, sign);
     const float z = x * x;
     const float a01 = __builtin_fmaf(-41.34168243408203f, z, 6.2831854820251465f);
     const float a23 = __builtin_fmaf(-76.58116912841797f, z, 81.60247802734375f);
     const float z2 = z * z;
     const float p = __builtin_fmaf(__builtin_fmaf(39.75982666015625f, z2, a23), z2, a01);
-    return -(p * x);
+    return __uint_as_float(__float_as_uint(p * x) ^ sign);
 }
 
 SRK_DEV double wrap01(double x)
@@ -288,7 +298,8 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
         if ((flags & OSC_CV_AUDIO_RATE) || __builtin_amdgcn_ballot_w64(cv != s.seen_cv) != 0) {
             const double e = (double)cv + c.val;
             // exact mode: 440 * 2^e / sr as written; default mode: (440 / sr) * 2^e with the series above
-            s.seen_delta = (flags & OSC_EXACT) ? 440.0 * exp2_cr(e) / c.sr : (440.0 / c.sr) * exp2_fast(e);
+            s.seen_delta = (flags & OSC_EXACT) ? 440.0 * exp2_cr(e) / c.sr
+                           : (440.0 / c.sr) * ((flags & OSC_CV_SMALL) ? exp2_fast<false>(e) : exp2_fast<true>(e));
             s.seen_cv = cv;
         }
         delta = s.seen_delta;
@@ -333,7 +344,9 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
             square = (pos < 0.5 ? -1.0f : 1.0f) - (blep0 - blep1);
         }
     }
-    s.pos = wrap01(pos + delta);
+    // x - floor(x) and v_fract_f64 agree for every finite x >= 0 (the subtraction is exact and below 1; fract's clamp to 1 - 2^-53 never
+    // acts); they part at +inf (NaN against the instruction's own answer), which is why the caller has to have proved the precondition
+    s.pos = (flags & OSC_PHASE_TAME) ? __builtin_amdgcn_fract(pos + delta) : wrap01(pos + delta);
 }
 
 // ---------------------------------------------------------------------------------------------

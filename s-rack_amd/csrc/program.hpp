@@ -60,6 +60,10 @@ enum : uint32_t {
                                   // (2^cv, sine, the rest of the patch) stays in the default arithmetic
     OSC_CONST_SMALL = 1u << 11,   // host-proved, whatever the render mode: no CV, no sync, one live port, PolyBLEP on, every voice's delta < 0.25
                                   // (OSC_CONST_FAST = this and not OSC_EXACT)
+    // the next two are never set by the flattener: a kernel that has PROVED them for a stretch of samples (wave-uniform tests on its
+    // own inputs, see render_fm_pair) passes them as compile-time constants; default mode only
+    OSC_CV_SMALL = 1u << 14,      // |f64(cv) + f64(val)| <= 1/2: 2^x needs no range reduction
+    OSC_PHASE_TAME = 1u << 15,    // 0 <= pos < 1 and the increment is finite and >= 0: `pos %= 1.0` is one v_fract_f64
     // OP_VCF
     VCF_HAS_AUDIO = 1u << 0,
     VCF_HAS_CV = 1u << 1,

@@ -162,6 +162,52 @@ def test_p2_feedback_vs_oracle(S, oracle, B, flags):
     assert np.abs(out[0]).max() > 0.9
 
 
+@pytest.mark.parametrize("flags", [0, 1, 2])
+@pytest.mark.parametrize("B", [1, 64, 1024])
+def test_fm_pair_sample_loops(S, oracle, B, flags):
+    """The fused FM kernels choose their sample loop per wave from what the wave can prove about its 64 voices (default mode): both
+    exponents within 1/2 (no range reduction in 2^x, one-instruction phase wrap), only the modulator's, neither (the wrap alone), or
+    nothing at all — a voice whose feedback gain lets 2^x overflow, after which its phase is NaN as in the reference, and its 63
+    well-behaved neighbours, which take the literal forms with it.  One wave of each, plus a modulator `val` that moves a wave from
+    one class to the next; every voice against the oracle."""
+    T, W = 2500, 64
+    rng = np.random.default_rng(11)
+    beta = np.concatenate([rng.uniform(0.05, 0.45, W), rng.uniform(0.1, 0.4, W), rng.uniform(0.6, 1.8, W), rng.uniform(0.1, 0.4, W),
+                           rng.uniform(0.1, 0.3, W)]).astype(np.float32)
+    index = np.concatenate([rng.uniform(0.05, 0.45, W), rng.uniform(0.5, 1.5, W), rng.uniform(0.5, 2.5, W), rng.uniform(0.5, 1.5, W),
+                            rng.uniform(0.1, 0.3, W)]).astype(np.float32)
+    val_m = np.zeros(5 * W, np.float32)
+    val_m[4 * W:] = rng.uniform(0.25, 0.6, W)           # small constants, but |beta| + |val| passes 1/2 for most of the wave
+    beta[3 * W + 17] = 3.0e4                             # 2^(30000 sin) overflows on the second sample (1500 would not at buffer_size 1: a huge
+                                                         # finite increment is an integer, the phase lands on 0 and the sine starts over)
+    V = 5 * W
+    o = oracle.OraclePatch(48000, B, 2)
+    ids = S.build_p2(o)
+    over = [(ids["mul_fb"], S.MATH_CONSTANT, beta), (ids["mul_idx"], S.MATH_CONSTANT, index), (ids["osc_m"], S.OSC_VAL, val_m)]
+    ref, _ = o.render_batch(V, T, over, threads=8)
+    p = S.Patch(48000, B, 2)
+    S.build_p2(p)
+    p.configure_voices(V)
+    for m, f, v in over:
+        p.set_voice_field(m, f, v)
+    out = p.render_channels(T, flags)
+    if not (flags & 2):
+        assert "kernel=render_fm_pair" in p.info(), p.info()
+    bad = 3 * W + 17
+    assert np.isnan(ref[0][:, bad]).any() and np.isnan(ref[0][-1, bad])
+    np.testing.assert_array_equal(np.isnan(out[0]), np.isnan(ref[0]))
+    ok = ~np.isnan(ref[0])
+    err = np.abs(out[0].astype(np.float64) - ref[0]) / np.maximum(np.abs(ref[0]), 1.0)
+    assert err[ok].max() <= TOL, f"max rel err {err[ok].max():.3e} at {np.unravel_index(np.where(ok, err, 0).argmax(), err.shape)}"
+    # and split in two calls at a point that is no tile border: the proofs are per launch / per tile, the state carries over bit for bit
+    p.configure_voices(V)
+    for m, f, v in over:
+        p.set_voice_field(m, f, v)
+    a = p.render_channels(1001, flags)
+    b = p.render_channels(T - 1001, flags)
+    np.testing.assert_array_equal(bits(np.concatenate([a[0], b[0]])), bits(out[0]))
+
+
 @pytest.mark.parametrize("B", [1, 1024])
 def test_cfg4_golden(S, B):
     z = np.load(os.path.join(GOLD, f"cfg4_p2_b{B}.npz"))

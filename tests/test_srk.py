@@ -316,6 +316,31 @@ def test_loaded_feedback_patch_starts_from_the_saved_buffers(S, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [64, 1024])
+def test_loaded_feedback_ring_with_values_no_sine_has(S, B):
+    """A rack file may hold anything in the saved block of the fed-back port.  The fused FM kernel's short cuts (2^x without range
+    reduction, one-instruction phase wrap) rest on fed-back values of magnitude <= 1, which it checks tile by tile: the first lap of
+    the ring (amplitude 40 here, one value infinite) must take the literal forms, and the render must still follow the reference."""
+    from oracle import oracle as O
+    saved = (np.sin(np.arange(B) * 0.37) * 40.0).astype(np.float32)
+    mods = [output("o", B), osc("c", 0.0, B), {"MathModuleV0": ["idx", buf(B), F32(1.0), "Multiply"]},
+            {"MathModuleV0": ["fb", buf(B), F32(0.3), "Multiply"]}, osc("m", 0.0, B, bufs=[[F32(float(x)) for x in saved], buf(B), buf(B)])]
+    conns = [["m", 0, "fb", 0], ["fb", 0, "m", 0], ["m", 0, "idx", 0], ["idx", 0, "c", 0], ["c", 0, "o", 0], ["c", 0, "o", 1]]
+    p = S.Patch.load_srk(enc([mods, conns, []]), 48000, B, 2)
+    o = O.OraclePatch(48000, B, 2)
+    ids = S.build_p2(o, beta=0.3, index=1.0)
+    o.set_output_buffer(ids["osc_m"], 0, saved)
+    T, V = 3 * B + 100, 70
+    ref, _ = o.render_batch(V, T, [], threads=2)
+    for flags in (4, 5):        # (4: everything per voice — identical voices would otherwise be rendered once, by the control program)
+        p.configure_voices(V)
+        fr = p.render_channels(T, flags)
+        assert "kernel=render_fm_pair_ring" in p.info(), p.info()
+        err = np.abs(fr.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1.0)
+        assert err.max() <= 1e-5, (flags, err.max())
+
+
+@pytest.mark.gpu
 def test_loaded_p1_renders_like_the_api_built_patch(S):
     q = S.Patch.load_srk(p1_file(B=64), 48000, 64, 2)
     q.configure_voices(3)
