@@ -119,8 +119,10 @@ SRK_DEV double exp2_fast(double x)
 // ocml's pow / exp2 are ~1 ulp functions: 19 % of their results differ from the host's in the last bit (tools/powcheck.hip),
 // and although an oscillator's f32 output shows that only rarely, a patch that feeds it back (chaotic FM loops, a clock
 // derived from the saw) then parts from the oracle for good.  So the power is evaluated here in double-double arithmetic
-// (~2^-100 relative) and rounded once: e = n + f, |f| <= 1/2; y = f ln2 (ln2 as hi + lo); exp(y) = (exp(y / 8))^8 with a
-// degree-13 Taylor polynomial (|y / 8| < 0.0434: truncation 2^-99).  Finite results only; the rest goes to ocml's pow.
+// and rounded once: e = n + f, |f| <= 1/2; y = f ln2 (ln2 as hi + lo); the reference evaluation is exp(y) = (exp(y / 8))^8 with
+// a degree-13 Taylor polynomial, every operation double-double (|y / 8| < 0.0434: truncation 2^-99, ~2^-100 overall) — and an
+// evaluation five times cheaper decides the rounding whenever it provably can (exp2_cr below).  Finite results only; the rest
+// goes to ocml's pow.
 struct DD {
     double hi, lo;
 };
@@ -152,11 +154,15 @@ SRK_DEV DD dd_mul_d(DD a, double b)
     const double e = __builtin_fma(a.hi, b, -p) + a.lo * b;
     return dd_fast_two_sum(p, e);
 }
-SRK_DEV double exp2_cr(double e)
+SRK_DEV DD dd_sqr(DD a)
 {
-    if (!(e > -1000.0 && e < 1000.0)) return pow(2.0, e);  // overflow / gradual underflow / NaN: the library's special cases
-    const double n = __builtin_rint(e);
-    const double f = e - n;  // exact
+    const double p = a.hi * a.hi;
+    const double e = __builtin_fma(a.hi + a.hi, a.lo, __builtin_fma(a.hi, a.hi, -p));
+    return dd_fast_two_sum(p, e);
+}
+// 2^f for |f| <= 1/2 as hi + lo, ~2^-100: the reference evaluation every result can fall back on (410 f64-rate instructions)
+SRK_DEV double exp2_cr_taylor(double f)
+{
     // y = f * ln2 / 8
     const DD ln2_8 = {0x1.62e42fefa39efp-4, 0x1.abc9e3b39803fp-59};  // ln 2 / 8 = hi + lo
     const DD y = dd_mul_d(ln2_8, f);
@@ -174,7 +180,43 @@ SRK_DEV double exp2_cr(double e)
     acc = dd_mul(acc, acc);
     acc = dd_mul(acc, acc);
     acc = dd_mul(acc, acc);
-    return __builtin_ldexp(acc.hi + acc.lo, (int)n);
+    return acc.hi + acc.lo;
+}
+// Ziv's strategy: a cheap evaluation with a proved error bound decides the rounding whenever the result is not within that bound of
+// a rounding boundary, which is all but 2^-13.5 of the arguments; only a wave with such a lane (one in 180) pays for the one above.
+// Cheap = exp(y)^64 with y = f ln2 / 64, |y| <= 0.0055:  1 + y + y^2/2 in double-double, y^3 (1/6 + ... + y^5/8!) in plain f64 — that
+// part is below 2^-25, so its five roundings (2^-50.7 relative) and the final sum's cost 2^-76 of the result; truncation (y^9/9!) is
+// 2^-86 — then six double-double squarings, each of which doubles the relative error: 2^-69.5 at the end.  The test uses 2^-67.
+SRK_DEV double exp2_cr(double e)
+{
+    if (!(e > -1000.0 && e < 1000.0)) return pow(2.0, e);  // overflow / gradual underflow / NaN: the library's special cases
+    const double n = __builtin_rint(e);
+    const double f = e - n;  // exact
+    const DD ln2_64 = {0x1.62e42fefa39efp-7, 0x1.abc9e3b39803fp-62};  // ln 2 / 64 = hi + lo
+    const DD y = dd_mul_d(ln2_64, f);
+    const double yh = y.hi;
+    double q = 1.0 / 40320.0;
+    q = __builtin_fma(q, yh, 1.0 / 5040.0);
+    q = __builtin_fma(q, yh, 1.0 / 720.0);
+    q = __builtin_fma(q, yh, 1.0 / 120.0);
+    q = __builtin_fma(q, yh, 1.0 / 24.0);
+    q = __builtin_fma(q, yh, 1.0 / 6.0);
+    const double y2 = yh * yh;
+    const double c3 = (y2 * yh) * q;
+    const double y2l = __builtin_fma(yh + yh, y.lo, __builtin_fma(yh, yh, -y2));  // y^2 = y2 + y2l (y.lo^2 dropped: 2^-120)
+    const DD t = dd_fast_two_sum(1.0, yh);
+    const DD v = dd_fast_two_sum(t.hi, 0.5 * y2);
+    const double rest = ((t.lo + v.lo) + (y.lo + 0.5 * y2l)) + c3;
+    DD a = dd_fast_two_sum(v.hi, rest);
+#pragma unroll
+    for (int k = 0; k < 6; k++) a = dd_sqr(a);
+    const double d = a.hi * 0x1p-67;
+    const double up = a.hi + (a.lo + d), down = a.hi + (a.lo - d);
+    double r = up;
+    if (__builtin_amdgcn_ballot_w64(up != down) != 0) {
+        if (up != down) r = exp2_cr_taylor(f);
+    }
+    return __builtin_ldexp(r, (int)n);
 }
 
 // poly_blep, f64, literally (oscillator.rs:50-67)

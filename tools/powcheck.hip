@@ -22,8 +22,30 @@ __global__ void kraw(const double* e, double* out, int n)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = srack::dev::exp2_cr(e[i]);
 }
+// the Ziv evaluation (exp2_cr) against the reference evaluation it falls back on, bit for bit, over counter-generated arguments:
+// any difference would be an error bound that does not hold
+__global__ void kziv(unsigned long long first, unsigned long long* differ)
+{
+    unsigned long long x = first + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
+    x += 0x9e3779b97f4a7c15ull; x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull; x = (x ^ (x >> 27)) * 0x94d049bb133111ebull; x ^= x >> 31;  // splitmix64
+    // half the arguments are sums of two f32 (what an oscillator sees), half are full doubles in [-12, 12)
+    const double u = (double)(x >> 11) * 0x1p-53;
+    double e = u * 24.0 - 12.0;
+    if (x & 1) e = (double)(float)(u * 12.0 - 6.0) + (double)(float)((double)((x >> 3) & 0xfffff) * 0x1p-20 * 9.0 - 6.0);
+    const double n = __builtin_rint(e), f = e - n;
+    const double ref = __builtin_ldexp(srack::dev::exp2_cr_taylor(f), (int)n), got = srack::dev::exp2_cr(e);
+    if (__double_as_longlong(ref) != __double_as_longlong(got)) atomicAdd(differ, 1ull);
+}
 int main()
 {
+    {
+        unsigned long long *d, h[2] = {0, 0};
+        hipMalloc(&d, 16); hipMemcpy(d, h, 16, hipMemcpyHostToDevice);
+        const unsigned long long per = 1ull << 28;
+        for (int r = 0; r < 4; r++) hipLaunchKernelGGL(kziv, dim3((unsigned)(per / 256)), dim3(256), 0, 0, per * r, d);
+        hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+        printf("exp2_cr (Ziv) against its double-double reference evaluation over %llu arguments: %llu differ\n", 4 * per, h[0]);
+    }
     const int n = 1 << 22;
     std::vector<double> e(n), got(n), got2(n);
     uint64_t s = 12345;
