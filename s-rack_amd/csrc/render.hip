@@ -46,6 +46,7 @@ namespace srack {
 struct Knobs {
     uint32_t want_waves = 1024;  // waves to aim for when there are few voices (one per SIMD)
     uint32_t chunk_max = 4096;   // samples per launch; measured on the headline workload: 4096 -> 13.98, 8192 -> 14.14, 16384 -> 14.8 ms per step
+    uint32_t chunk_first = 1024; // samples of the first chunks of a render with a control program (the control work for them is exposed)
     bool debug_occ = false;
     int high_prio_ctl = 1;       // the control stream is created with the highest priority (its own pool of hardware queues)
     int special_ctl = 1;         // specialised kernels carry the control program's units (0: control program on its own stream)
@@ -64,6 +65,7 @@ static const Knobs& knobs()
         };
         v.want_waves = (uint32_t)num("SRACK_WANT_WAVES", 1, 1 << 20, 1024);
         v.chunk_max = (uint32_t)num("SRACK_CHUNK_MAX", 256, 65536, 4096);
+        v.chunk_first = (uint32_t)num("SRACK_CHUNK_FIRST", 32, 4096, 1024);
         v.debug_occ = getenv("SRACK_DEBUG_OCC") != nullptr;
         v.high_prio_ctl = (int)num("SRACK_CTL_HIGH_PRIO", 0, 1, 1);
         v.special_ctl = (int)num("SRACK_SPECIAL_CTL", 0, 1, 1);
@@ -580,8 +582,8 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     };
     // chunk schedule: short first chunks (only control chunk 0 is exposed), doubling up to kChunkMax
     // With a control pipeline of depth L the first voice chunk waits for L + 1 control launches: those stay short.
-    constexpr uint32_t kChunkFirst = 1024;
     const uint32_t kChunkMax = knobs().chunk_max;
+    const uint32_t kChunkFirst = std::min(knobs().chunk_first, kChunkMax);
     uint32_t max_lag = 0;
     for (int lag : h.prog.ctl_lag) max_lag = std::max(max_lag, (uint32_t)lag);
     std::vector<std::pair<uint32_t, uint32_t>> chunks;       // (t_off, len)
