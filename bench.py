@@ -411,8 +411,9 @@ def run_rank(args, backend_cls=HipBackend):
                         "achieved_kernel": achieved_kernel, "frac_kernel": achieved_kernel / HBM_PEAK_GBS},
             })
         if args.workload == "cfg2":
-            out["roofline"]["note"] = ("identical voices: the whole patch is one voice-invariant latency chain evaluated by ONE wave, the frames are "
-                                       "a broadcast of its track — a few percent of the HBM roofline by construction (plumbing configuration)")
+            out["roofline"]["note"] = ("identical voices: the whole patch is voice-invariant and evaluated once, by a pipeline of one-wave control units (bound by the "
+                                       "ladder filter's 13-deep recurrence, ~65 ns per sample); the frames are a broadcast of its track — a few percent of the HBM "
+                                       "roofline by construction (plumbing configuration)")
         tr = profiled_traffic(kname, args.workload, args.flags, V, T) if be.name == "hip" and not args.no_frames and not args.no_mix else None
         if tr:
             out["roofline"]["traffic"] = tr["bytes_per_launch"]

@@ -57,6 +57,8 @@ SRK_DEV float zero_f32()
 }
 
 // TransitionDetector::is_transition, synth.rs:292-297
+constexpr int kTileRows = 32;  // samples per tile of the tile-wise forms below (wave.hip.h: kMixRows, checked there)
+
 SRK_DEV bool rising_edge(bool& last, float val)
 {
     bool above = val > 0.0f;
@@ -519,6 +521,47 @@ SRK_DEV float cosc_exact_step(COsc& o)
     const float y = kPort == OSC_OUT_SQUARE ? (h < 0x3fe00000 ? -1.0f : 1.0f) : (float)o.pos * 2.0f - 1.0f;
     o.pos = __builtin_amdgcn_fract(o.pos + o.delta);
     return y;
+}
+
+// A constant-pitch oscillator of a CONTROL UNIT (one voice, every lane mirrors it), a tile at a time.  Only the phase is a recurrence —
+// `pos = (pos + delta) % 1.0`, two f64 instructions per sample —, the output of sample j is a function of the phase before it: lane j
+// keeps that phase, and after the tile's last step every lane evaluates ITS sample with the per-sample formulas (osc_step: the exact
+// flavour's are the reference's own, so exact modes stay bit-identical; the default flavour's are the ones a voice kernel uses for a
+// general oscillator).  A lone wave pays ~14 cycles per dependent instruction and ~40 per wave-uniform branch: the sample-by-sample form
+// cost 35 (saw) ... 71 ns (square, a branch per sample) per sample, this one costs the two-instruction recurrence.
+// Returns lane j's sample j (j < n); the caller stores the tile with one coalesced store.
+template <bool kExact>
+SRK_DEV float cosc_tile(uint32_t flags, COsc& o, int n)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    double pos = o.pos, mine = o.pos;
+    // v_fract_f64 is `% 1.0` for 0 <= x < 2 (cosc_advance); a phase outside [0, 1) — only a host can store one — takes the exact mode
+    // through fmod's own path (the default mode has always used the instruction here)
+    const bool tame = !kExact || __builtin_amdgcn_ballot_w64(!(pos >= 0.0 && pos < 1.0 && o.delta >= 0.0 && o.delta < 1.0)) == 0;
+    if (tame && n == kTileRows) {
+#pragma unroll
+        for (int j = 0; j < kTileRows; j++) {
+            mine = lane == j ? pos : mine;
+            pos = __builtin_amdgcn_fract(pos + o.delta);
+        }
+    } else {
+        for (int j = 0; j < n; j++) {
+            mine = lane == j ? pos : mine;
+            pos = tame ? __builtin_amdgcn_fract(pos + o.delta) : fmod1(pos + o.delta);
+        }
+    }
+    o.pos = pos;
+    OscRegs g;
+    g.pos = mine;
+    g.sync_last = false;
+    OscConst k;
+    k.delta = o.delta;
+    k.val = 0.0;
+    k.sr = 0.0;
+    k.inv_dt = o.inv_dt;
+    float y0 = 0.0f, y1 = 0.0f, y2 = 0.0f;
+    osc_step(flags, g, k, 0.0f, 0.0f, y0, y1, y2);
+    return (flags & OSC_OUT_SAW) ? y2 : ((flags & OSC_OUT_SQUARE) ? y1 : y0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1045,6 +1088,50 @@ SRK_DEV float adsr_seg_step(AdsrRegs& s, const AdsrConst& c, AdsrSeg& g, float g
     }
     g.held = out;
     return out;
+}
+
+// The envelope of a CONTROL UNIT (one voice, every lane mirrors it), a tile at a time.  `gate`: lane j holds the gate of sample j.
+// The per-sample form above decides "does this sample leave the segment" with two compares, two ballots and a branch per sample; for one
+// voice the same question has a closed answer per RUN of samples: the gate bits of the whole tile are one ballot, so the first sample
+// whose gate level or edge ends the segment is a count-trailing-zeros away, and the phase cannot reach 1.0 within
+// K = (0.9999 - phase) / inc steps (each rounded step adds at most inc + 2^-24: the margin covers a whole tile).  The run up to there is
+// the segment's own operations and nothing else — phase += inc; out = c0 + c1 * (k0 + k1 * phase): the same f32 operations in the same
+// order as adsr.rs, so the bits are the reference's in every mode — and the sample that ends it goes through adsr_seg_step, which decides
+// as before.  ~100 -> ~20 ns per sample.  Returns lane j's sample j (j < n).
+SRK_DEV float adsr_seg_tile(AdsrRegs& s, const AdsrConst& c, AdsrSeg& g, float gate, int n)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint64_t tile = (1ull << n) - 1ull;  // n <= 32
+    const uint64_t high = __builtin_amdgcn_ballot_w64(gate > 0.0f) & tile;
+    const uint64_t before = (high << 1) | (g.last != 0 ? 1ull : 0ull);  // bit j: sample j's predecessor was high
+    float keep = 0.0f;
+    int i = 0;
+    while (i < n) {
+        const uint64_t ends = ((g.on_high != 0 ? high : 0ull) | (g.on_low != 0 ? ~high : 0ull) | (g.on_edge != 0 ? (high & ~before) : 0ull)) & tile & (~0ull << i);
+        const int by_gate = ends != 0 ? (int)__builtin_ctzll(ends) : n;
+        const float room = (0.9999f - s.phase) * __builtin_amdgcn_rcpf(g.inc);  // inc == 0 (Sustain, None): +inf; NaN / negative: no run
+        const int by_phase = __builtin_amdgcn_readfirstlane(room > 0.0f ? (int)__builtin_fminf(room, 64.0f) : 0);
+        const int run = min(by_gate - i, by_phase);
+        if (run > 0) {
+            float ph = s.phase, out = g.held;
+            for (int k = 0; k < run; k++) {
+                ph = ph + g.inc;
+                const float u = g.k0 + g.k1 * ph;
+                out = g.c0 + g.c1 * u;
+                keep = lane == i + k ? out : keep;
+            }
+            s.phase = ph;
+            g.held = out;
+            i += run;
+            g.last = ((high >> (i - 1)) & 1ull) ? ~0ull : 0ull;
+        }
+        if (i < n) {  // the sample that may end the segment (or only the end of a cautious run): decided as it always was
+            const float y = adsr_seg_step(s, c, g, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gate), i)));
+            keep = lane == i ? y : keep;
+            i++;
+        }
+    }
+    return keep;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -63,6 +63,7 @@ SRK_DEV WaveMap wave_map(const Args& a, int lane)
 }  // namespace dev
 
 constexpr int kMixRows = 32;
+static_assert(kMixRows == dev::kTileRows, "the tile-wise module forms (modules.hip.h) assume the mix tile's length");
 constexpr int kMixPitch = 68;  // floats per LDS row of the mix tile: 64 lanes + 4 of padding (see emit_flush)
 constexpr int kMixTile = kMixRows * kMixPitch;
 
