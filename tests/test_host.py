@@ -382,13 +382,14 @@ def test_specialised_kernel_source_of_p1_and_p3(S):
     src = p.kernel_source(S.RENDER_NO_FUSION)
     assert 'extern "C" __global__' in src and "srk_voice(KernelArgs a)" in src
     assert "cosc_step<0x20u>" in src and "vcf_run<true>" in src and "emit_put<KOUT>" in src  # the carried-phase saw, the default-mode ladder
-    assert "srk_ctl0" in src and "adsr_seg_step" in src and "a.ctl_slots[blockIdx.x]" in src   # the gate -> envelope unit rides along
+    assert "srk_ctl0" in src and "a.ctl_slots[blockIdx.x]" in src                               # the gate -> envelope unit rides along,
+    assert "cosc_tile<false>(" in src and "adsr_seg_tile(" in src and "sample(lane);" in src     # evaluated across lanes: lane j = sample j of the tile
     assert "rowf(14)" in src and "a.ops[1].par_val[2]" in src                               # per-voice cutoff from its row, uniform exp_amt from the op list
     exact = p.kernel_source(S.RENDER_NO_FUSION | S.RENDER_EXACT_OSC)
     # exact mode: the tile-wise saw with the literal per-sample oscillator behind it, the literal ladder without a look at its (bounded)
     # input, the sample loop versioned on both preconditions; the gate LFO of the control unit leaves its PolyBLEP windows to osc_step
     assert "xsaw_tile(" in exact and "osc_step(" in exact and "vcf_run_bounded(" in exact and "if (m0_xs && m1_fin) {" in exact
-    assert "cosc_exact_step<0x10u>" in exact
+    assert "cosc_tile<true>(" in exact and "adsr_seg_tile(" in exact                            # (the exact flavour of the same unit)
     # parameter VALUES are not part of the kernel: an edit does not ask for another compilation
     p.set_field(ids["vcf"], S.VCF_RES, 0.7)
     p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut[::-1].copy())
@@ -408,7 +409,7 @@ def test_specialised_kernel_source_of_p1_and_p3(S):
     # the clock LFO's square leaves only its PolyBLEP windows to the f64 formulas
     assert "track_flat(trk0_v + t0, lane)" in exact3 and "xsaw_tile(m1_x, m1_xt, kMixPitch, kMixRows)" in exact3
     assert "vcf_run_bounded(m2, m2_fin, m1_flat" in exact3 and "vcf_coeffs_freq<false>" in exact3 and "vcf_frequency(" in exact3
-    assert "cosc_exact_step<0x10u>" in exact3
+    assert "cosc_tile<true>(" in exact3                                                         # the clock: a unit evaluated across lanes
     r = S.Patch(48000, 64, 2)   # the one module the generator leaves to the interpreter
     v, o = r.add_module(S.MOD_FREEVERB), r.add_module(S.MOD_OUTPUT)
     r.connect(v, 0, o, 0)
