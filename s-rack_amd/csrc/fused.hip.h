@@ -31,9 +31,9 @@ struct CtlWork {
     uint32_t port;     // OSC_OUT_* of the gate oscillator, | OSC_EXACT in the exact render mode
 };
 
-// kExact: a sample inside a PolyBLEP window takes the reference's f64 formulas (osc_step with OSC_EXACT) instead of the f32
-// ones.  Outside the windows the square is exactly -1 / +1 in the reference too, the phase recurrence is the same f64 add and
-// exact wrap, and the segmented envelope performs adsr.rs's own operations: the speculative groups serve both modes.
+// kExact: the oscillator's outputs are the reference's f64 formulas (osc_step with OSC_EXACT) instead of the default mode's f32
+// PolyBLEP.  The phase recurrence is the same f64 add and exact wrap either way, and the segmented envelope performs adsr.rs's own
+// operations in both modes.
 template <uint32_t kOscPort, bool kExact>
 SRK_DEV void ctl_gate_env_body(const CtlWork& a)
 {
@@ -57,69 +57,16 @@ SRK_DEV void ctl_gate_env_body(const CtlWork& a)
     AdsrSeg seg;
     adsr_seg_enter(sd, kd, seg);
 
-    // Four samples at a time on the assumption that nothing happens in them: the square stays outside its PolyBLEP
-    // windows (so it is exactly -1/+1) and the envelope stays in its segment.  One scalar test per group instead
-    // of two per sample; when the assumption fails the group is redone one sample at a time (cosc / adsr_seg).
-    float out[4];
-    auto try_group = [&]() -> bool {
-        double pos = cl.pos;
-        float ph = sd.phase;
-        uint64_t last = seg.last, bad = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int hw = __double2hiint(pos);
-            bad |= __builtin_amdgcn_ballot_w64(hw <= cl.hA) | __builtin_amdgcn_ballot_w64(hw >= cl.hB) |
-                   __builtin_amdgcn_ballot_w64((uint32_t)(hw - cl.hQ0) <= cl.hQspan);
-            const uint64_t high = __builtin_amdgcn_ballot_w64(hw >= 0x3fe00000);  // square = +1 > 0  <=>  pos >= 0.5
-            pos = __builtin_amdgcn_fract(pos + cl.delta);
-            ph = ph + seg.inc;
-            bad |= __builtin_amdgcn_ballot_w64(ph >= 1.0f) | (high & seg.on_high) | (~high & seg.on_low) | (high & ~last & seg.on_edge);
-            last = high;
-            out[q] = seg.c0 + seg.c1 * (seg.k0 + seg.k1 * ph);
-        }
-        if (bad != 0) return false;
-        cl.pos = pos;
-        sd.phase = ph;
-        seg.last = last;
-        seg.held = out[3];
-        return true;
-    };
-
-    for (uint32_t t0 = 0; t0 < a.T; t0 += 64) {
-        const int n = (int)min(64u, a.T - t0);
-        float keep_v = 0.0f;  // lane j keeps sample t0 + j
-        int j = 0;
-        while (j < n) {
-            if (kOscPort == OSC_OUT_SQUARE && j + 4 <= n && try_group()) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) keep_v = lane == j + q ? out[q] : keep_v;
-                j += 4;
-                continue;
-            }
-            const int stop = min(n, j + 4);
-            for (; j < stop; j++) {
-                float gate;
-                if (kExact) {
-                    OscRegs g;
-                    g.pos = cl.pos;
-                    g.sync_last = false;
-                    OscConst kc;
-                    kc.delta = cl.delta;
-                    kc.val = 0.0;
-                    kc.sr = 0.0;
-                    kc.inv_dt = 0.0f;
-                    float o3[3] = {0.0f, 0.0f, 0.0f};
-                    osc_step(OSC_AA | OSC_EXACT | kOscPort, g, kc, 0.0f, 0.0f, o3[0], o3[1], o3[2]);
-                    gate = kOscPort == OSC_OUT_SINE ? o3[0] : (kOscPort == OSC_OUT_SQUARE ? o3[1] : o3[2]);
-                    cl.pos = g.pos;
-                } else {
-                    gate = cosc_step<kOscPort>(cl);
-                }
-                const float env = adsr_seg_step(sd, kd, seg, gate);
-                keep_v = lane == j ? env : keep_v;
-            }
-        }
-        if (lane < n) track[t0 + lane] = keep_v;
+    // One voice on one wave is a latency chain, so the block works a tile at a time across lanes (modules.hip.h): the oscillator runs only
+    // its two-instruction phase recurrence per sample and lane j evaluates sample j's output; the envelope takes whole runs of samples
+    // between the events that can end its segment.  55 ns per sample where the sample-by-sample form (four-sample speculative groups)
+    // took 102 — it is the first chunk's track that nothing hides.
+    constexpr uint32_t osc_flags = OSC_AA | kOscPort | (kExact ? OSC_EXACT : 0u);
+    for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
+        const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+        const float gate = cosc_tile<kExact>(osc_flags, cl, n);
+        const float env = adsr_seg_tile(sd, kd, seg, gate, n);
+        if (lane < n) track[t0 + lane] = env;
     }
     adsr_seg_flush(sd, seg);
     if (lane == 0) {
