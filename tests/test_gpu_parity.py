@@ -142,6 +142,46 @@ def test_cfg2_identical_voices(S, oracle):
     assert_close(mix[0] / V, ref, tol=2e-5)
 
 
+# ---- control units evaluated across lanes (voice-invariant modules of a specialised kernel) --------------------------------
+@pytest.mark.parametrize("gate_port", [1, 2, 0])                                # square, saw, sine as the envelope's gate
+@pytest.mark.parametrize("env", [(0.0, 0.0, 0.5, 0.0), (1e-4, 2e-4, 0.3, 1e-4), (0.01, 0.1, 0.5, 0.2), (5.0, 5.0, 1.0, 5.0)])
+@pytest.mark.parametrize("lfo_val", [-2.0, 3.0, 5.4])
+def test_control_units_across_lanes(S, oracle, lfo_val, env, gate_port):
+    """Identical voices: every module is voice-invariant and lands in a co-scheduled control unit, where lane j evaluates sample j of a
+    tile — the oscillators as a phase recurrence + per-lane outputs, the envelope in runs between the events that can end its segment,
+    the VCA across lanes, the filter sample by sample.  Envelopes with zero-length segments (infinite increments: a segment per sample),
+    very short and very long ones; a gate that toggles every few samples (3520 Hz) and one above a quarter cycle per sample (the
+    oscillator then has no tile-wise form and its unit falls back); a render length with a ragged last tile, and the same render split at
+    a sample that is no tile border.  Exact mode bit for bit, default mode inside the contract."""
+    T, V = 5000 + 13, 70
+    def build(g):
+        ids = S.build_p1(g, lfo_val=lfo_val)
+        for f, v in zip((S.ADSR_A_SEC, S.ADSR_D_SEC, S.ADSR_S_VAL, S.ADSR_R_SEC), env):
+            g.set_field(ids["adsr"], f, v)
+        g.disconnect(ids["adsr"], 0)
+        g.connect(ids["osc_lfo"], gate_port, ids["adsr"], 0)
+        return ids
+    o = oracle.OraclePatch(48000, 1024, 2)
+    build(o)
+    ref = o.render(T)[0]
+    assert np.abs(ref).max() > 1e-3
+    for flags in (33, 32):
+        p = S.Patch(48000, 1024, 2)
+        build(p)
+        p.configure_voices(V)
+        out = p.render_channels(T, flags)[0]
+        assert "kernel=render_specialized" in p.info() and "ctl[" in p.info(), p.info()
+        assert (out == out[:, :1]).all()
+        if flags & 1:
+            np.testing.assert_array_equal(bits(out[:, 0]), bits(ref))
+        elif gate_port == 1:   # (a saw or sine gate is a threshold on an approximated value: default mode may move an edge by a sample)
+            assert_close(out[:, 0], ref)
+        p.configure_voices(V)
+        a = p.render_channels(1777, flags)[0]
+        b = p.render_channels(T - 1777, flags)[0]
+        np.testing.assert_array_equal(bits(np.concatenate([a, b])), bits(out))
+
+
 # ---- FM patch with a feedback edge (config 4) ---------------------------------------------------------
 @pytest.mark.parametrize("flags", [0, 1])
 @pytest.mark.parametrize("B", [1, 7, 16, 64, 1024])
