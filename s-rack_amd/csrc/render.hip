@@ -596,7 +596,11 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         }
     } else {  // no control program to overlap with, but short launches still win: the waves of a launch stay within a few
               // samples of each other, so their frame rows land in the same DRAM pages (FM pair 13.2 -> 9.9 ms per step)
-        for (uint32_t t_off = 0; t_off < T; t_off += kChunkMax) chunks.emplace_back(t_off, std::min(kChunkMax, T - t_off));
+        // The z^-1 FM pair (one wave per SIMD at config 4's 65 536 voices, no ring traffic) wants them shorter still: 2048 samples 7.26 ms per
+        // step, 4096 7.39, 1536 7.31, 1024 7.43, 8192 7.85 (tools/ab_env.sh, one box); its ring variant and the flagship are flat from 3072 to 6144.
+        const bool fm_z1 = P.fused == FUSED_FM_PAIR && P.fused_variant == 0 && !(flags & (SRACK_RENDER_NO_FUSION | SRACK_RENDER_EXACT_OSC));
+        const uint32_t len = fm_z1 ? std::min(kChunkMax, 2048u) : kChunkMax;
+        for (uint32_t t_off = 0; t_off < T; t_off += len) chunks.emplace_back(t_off, std::min(len, T - t_off));
     }
     const uint32_t n_chunks = (uint32_t)chunks.size();
     auto get_event = [&](hipEvent_t& e) -> int {
