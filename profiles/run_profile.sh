@@ -12,8 +12,6 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu ${2:-}"
-# the un-profiled bench line of the same configuration (more steps; cpu_baseline only for the headline tag)
-python $ROOT/bench.py --steps 10 --warmup 3 ${3:---no-cpu} ${2:-} > $ROOT/profiles/${TAG}_bench.json 2> $OUT/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq.log 2>&1
@@ -22,4 +20,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_rd -o pmc -- $BENCH > $OUT
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE -d $OUT/pmc_mem -o pmc -- $BENCH > $OUT/pmc_mem.log 2>&1
 cd $ROOT
 python profiles/summarize.py $TAG > $OUT/summary.log 2>&1
+# the un-profiled bench line of the same configuration (more steps; cpu_baseline only for the headline tag) — AFTER the summary exists:
+# bench.py looks the per-launch HBM traffic up in it (roofline.traffic, measured_in_this_run: false)
+python bench.py --steps 10 --warmup 3 ${3:---no-cpu} ${2:-} > profiles/${TAG}_bench.json 2> $OUT/bench.err
 tail -40 $OUT/summary.log
