@@ -744,6 +744,149 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
     }
 }
 
+// ---- the z^-1 FM pair on TWO waves per 64 voices ------------------------------------------------------------------------------
+// The carrier is not part of the feedback loop: it only consumes the modulator's sine.  Wave 0 of the workgroup runs the modulators of
+// its 64 voices (the recurrence), wave 1 their carriers, frames and mix; the sines cross through a double-buffered LDS tile, one
+// barrier per 32 samples: while the carrier wave works on tile k - 1 the modulator wave produces tile k.  65 536 voices are then 2048
+// waves — two per SIMD instead of one, each with half the f64 work — and the other wave's instructions fill the gaps a lone wave's
+// dependent chains leave.  Same arithmetic, same proofs per wave (each about its own oscillator) as render_fm_pair; results are
+// bit-identical to it.  MEASURED (config 4, one box, tools/ab_env.sh SRACK_FM_SPLIT "0 1"): exact mode 55.4 -> 44.0 ms per step — its
+// correctly rounded 2^cv, library sine and division are long serial chains behind wave-uniform branches —, default mode 7.29 -> 7.57:
+// render_fm_pair already interleaves its four chains by hand, and the LDS hand-over and the barrier only add to it (swapping the two
+// jobs in every other workgroup, by any bit of its index, to balance the SIMDs: 7.6 - 7.8).  So the launch code takes this kernel in
+// exact mode only.
+struct OscFacts {
+    bool tame = false, small = false;  // as FmFacts, for one oscillator
+};
+SRK_DEV OscFacts fm_osc_facts(float gain, const dev::OscConst& k, double pos)
+{
+    const float e = __builtin_fabsf(gain) + __builtin_fabsf((float)k.val);
+    OscFacts f;
+    f.tame = __builtin_amdgcn_ballot_w64(!(e < 1000.0f && pos >= 0.0 && pos < 1.0 && k.sr >= 1.0)) == 0;
+    f.small = __builtin_amdgcn_ballot_w64(!(e <= 0.4999f)) == 0;
+    return f;
+}
+template <bool kExact, int kOut>
+__global__ __launch_bounds__(128) void render_fm_pair_split(KernelArgs a, ChainRoles r)
+{
+    using namespace dev;
+    using std::integral_constant;
+    __shared__ __attribute__((aligned(16))) float mix_tile[kMixTile];
+    __shared__ float sines[2][kMixRows * 64];
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool carrier = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
+    const bool active = wm.active;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+    auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+    const DevOp& oscop = a.ops[carrier ? r.osc_a : r.osc_l];   // this wave's oscillator (roles as in render_fm_pair)
+    const DevOp& mulop = a.ops[carrier ? r.vca : r.adsr];      // the Multiply in front of its CV: x index / x feedback gain
+    const int plane = a.ops[r.out].aux;
+    const int ring_row = r.track;
+
+    constexpr uint32_t fo = OSC_HAS_CV | OSC_CV_AUDIO_RATE | OSC_AA | OSC_OUT_SINE | (kExact ? OSC_EXACT : 0u);
+    constexpr uint32_t fo_carrier = fo | OSC_SINE_LOOSE;
+    OscRegs s;
+    OscConst k;
+    s.pos = make_f64(row(oscop.state_row + OSC_S_POS_LO), row(oscop.state_row + OSC_S_POS_HI));
+    s.sync_last = false;
+    k.sr = oscop.sample_rate;
+    k.val = (double)parv(oscop, OSC_P_VAL);
+    k.delta = 0.0;
+    k.inv_dt = 0.0f;
+    const float gain = parv(mulop, MATH_P_CONST);
+    float fed = __uint_as_float(row(ring_row));  // (modulator wave) OSC_M.sine of the previous tick
+    Emit em = make_emit(a, plane, lane);         // (carrier wave)
+    float sq = 0.0f, sw = 0.0f;
+    OscFacts facts = kExact ? OscFacts{} : fm_osc_facts(gain, k, s.pos);
+
+    const uint32_t n_tiles = (a.T + (uint32_t)kMixRows - 1u) / (uint32_t)kMixRows;
+    for (uint32_t kt = 0; kt <= n_tiles; kt++) {
+        if (!carrier) {
+            if (kt < n_tiles) {
+                const uint32_t t0 = kt * (uint32_t)kMixRows;
+                const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+                float* const dst = sines[kt & 1u] + lane;
+                // the tile's first fed-back value is the host's at the start of a launch, a sine afterwards: the bound is checked where it enters
+                const bool proved = !kExact && facts.tame && n == kMixRows && __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(fed) <= 1.0f)) == 0;
+                auto tile = [&](auto flags_c) {
+                    constexpr uint32_t F = decltype(flags_c)::value;
+#pragma unroll SRK_FM_UNROLL
+                    for (int i = 0; i < kMixRows; i++) {
+                        float sine = 0.0f;
+                        osc_step(F, s, k, fed * gain, 0.0f, sine, sq, sw);
+                        fed = sine;
+                        dst[i * 64] = sine;
+                    }
+                };
+                if (proved && facts.small)
+                    tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME | OSC_CV_SMALL>{});
+                else if (proved)
+                    tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME>{});
+                else if (n == kMixRows)
+                    tile(integral_constant<uint32_t, fo>{});
+                else
+                    for (int i = 0; i < n; i++) {
+                        float sine = 0.0f;
+                        osc_step(fo, s, k, fed * gain, 0.0f, sine, sq, sw);
+                        fed = sine;
+                        dst[i * 64] = sine;
+                    }
+                if (!kExact && !proved) facts = fm_osc_facts(gain, k, s.pos);  // the literal forms may have left [0, 1)
+            }
+        } else if (kt > 0) {
+            const uint32_t t0 = (kt - 1u) * (uint32_t)kMixRows;
+            const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+            const float* const src = sines[(kt - 1u) & 1u] + lane;
+            float in[kMixRows];
+#pragma unroll
+            for (int i = 0; i < kMixRows; i++) in[i] = src[i * 64];  // (rows past a short last tile: stale, unused)
+            bool proved = false;
+            if (!kExact && facts.tame && n == kMixRows) {  // a sine from a phase outside [0, 1) is not bounded by 1: look
+                float m = 0.0f;
+#pragma unroll
+                for (int i = 0; i < kMixRows; i++) m = __builtin_fmaxf(m, __builtin_fabsf(in[i]));
+                proved = __builtin_amdgcn_ballot_w64(!(m <= 1.0f)) == 0;
+            }
+            auto tile = [&](auto flags_c) {
+                constexpr uint32_t F = decltype(flags_c)::value;
+#pragma unroll SRK_FM_UNROLL
+                for (int i = 0; i < kMixRows; i++) {
+                    float out = 0.0f;
+                    osc_step(F, s, k, in[i] * gain, 0.0f, out, sq, sw);
+                    emit_put<kOut>(em, mix_tile, out, i, V);
+                }
+            };
+            if (proved && facts.small)
+                tile(integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME | OSC_CV_SMALL>{});
+            else if (proved)
+                tile(integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME>{});
+            else if (n == kMixRows)
+                tile(integral_constant<uint32_t, fo_carrier>{});
+            else {
+#pragma unroll
+                for (int i = 0; i < kMixRows; i++)
+                    if (i < n) {
+                        float out = 0.0f;
+                        osc_step(fo_carrier, s, k, in[i] * gain, 0.0f, out, sq, sw);
+                        emit_put<kOut>(em, mix_tile, out, i, V);
+                    }
+            }
+            if (!kExact && !proved) facts = fm_osc_facts(gain, k, s.pos);
+            emit_flush<kOut, false>(em, mix_tile, t0, n, V);
+        }
+        __syncthreads();  // tile kt is complete and visible; the carrier is done with the buffer tile kt + 1 will overwrite
+    }
+    if (active) {
+        put(oscop.state_row + OSC_S_POS_LO, f64_lo(s.pos));
+        put(oscop.state_row + OSC_S_POS_HI, f64_hi(s.pos));
+        put(oscop.state_row + OSC_S_SYNC_LAST, 0u);
+        if (!carrier) put(ring_row, __float_as_uint(fed));
+    }
+}
+
 // ---- the same FM pair with the app's default delay: buffer_size >= 32, the ring in HBM ---------------------------------
 // The modulator of sample t reads what it produced buffer_size samples ago (ring[(n0 + t) mod B], [B][V] f32, voice-
 // minor) and overwrites it.  A 32-sample tile's reads were all written before the tile began (B >= 32), so they are

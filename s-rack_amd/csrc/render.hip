@@ -50,6 +50,7 @@ struct Knobs {
     bool debug_occ = false;
     int high_prio_ctl = 1;       // the control stream is created with the highest priority (its own pool of hardware queues)
     int special_ctl = 1;         // specialised kernels carry the control program's units (0: control program on its own stream)
+    int fm_split = 1;            // exact mode: the z^-1 FM pair on two waves per 64 voices (modulators / carriers); 0: one wave does both
 };
 static const Knobs& knobs()
 {
@@ -69,6 +70,7 @@ static const Knobs& knobs()
         v.debug_occ = getenv("SRACK_DEBUG_OCC") != nullptr;
         v.high_prio_ctl = (int)num("SRACK_CTL_HIGH_PRIO", 0, 1, 1);
         v.special_ctl = (int)num("SRACK_SPECIAL_CTL", 0, 1, 1);
+        v.fm_split = (int)num("SRACK_FM_SPLIT", 0, 1, 1);
         return v;
     }();
     return k;
@@ -426,6 +428,8 @@ static void launch_fm_pair2(bool exact, int out_mode, const KernelArgs& ka, cons
     do {                                                                                               \
         if (kRing)                                                                                     \
             hipLaunchKernelGGL((render_fm_pair_ring<E, O>), grid, dim3(64), 0, st, ka, roles);         \
+        else if ((E) && knobs().fm_split) /* exact mode only: measured, see the kernel's comment */    \
+            hipLaunchKernelGGL((render_fm_pair_split<E, O>), grid, dim3(128), 0, st, ka, roles);       \
         else                                                                                           \
             hipLaunchKernelGGL((render_fm_pair<E, O>), grid, dim3(64), 0, st, ka, roles);              \
     } while (0)

@@ -104,7 +104,9 @@ SRK_DEV void emit_rebase(Emit& e)  // point the descriptor at frame_row; a tile 
     e.soff = 0u;
 }
 
-template <int kOut>
+// kBarrier = false: the caller's workgroup has other waves that do not take part (render_fm_pair_split); the tile is this wave's
+// own, and one wave's LDS writes and reads stay in program order.
+template <int kOut, bool kBarrier = true>
 SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n, uint32_t V)  // the tile holds samples t0 .. t0+n-1
 {
     const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
@@ -116,7 +118,7 @@ SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n, uint32_t V
     if (!mix) return;
     if (!e.full_wave && (uint32_t)e.lane >= e.n_active)  // shadow lanes contribute nothing to the mix
         for (int r = 0; r < kMixRows; r++) mix_tile[r * kMixPitch + e.lane] = 0.0f;
-    __syncthreads();
+    if (kBarrier) __syncthreads();
     // lane l sums half (l >> 5) of row (l & 31) with eight 16-byte reads; row pitch 68 floats = 272 B keeps them 16-B aligned and
     // spreads the 16 lanes of a ds_read_b128 group (rows r .. r+15) over all 64 banks (bank = 4 r + 4 q mod 64)
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -127,7 +129,7 @@ SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n, uint32_t V
     float sum = (acc.x + acc.y) + (acc.z + acc.w);
     sum += __shfl_xor(sum, 32);
     if (e.lane < n) e.mp[t0 + e.lane] = sum;
-    __syncthreads();
+    if (kBarrier) __syncthreads();
 }
 
 // A plane that carries a control track unchanged (every voice plays the same sample): the frames are a broadcast store of a
