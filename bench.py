@@ -47,12 +47,13 @@ BYTES_PER_VOICE_SAMPLE = 4   # one f32 frame per voice per sample per distinct o
 # (the spec's 78.6 TFLOP/s counts an FMA as two).
 F64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
 # f64-rate VALU instructions per voice-sample in the loop body that render_fm_pair<false, 3> runs for BASELINE config 4's draw
-# (feedback gain 0.1 ... 0.4, index 0.5 ... 1.5: every wave proves "modulator exponent within 1/2, increments finite" and takes the
-# loop without the modulator's range reduction and with one-instruction phase wraps): 52, counted in the gfx950 ISA
-# (tools/disasm.sh; the mix is in DESIGN.md section 4.  The literal loop — nothing proved — has 58, round 2's first kernel had 60).
-# tools/ubench.hip measures the pipe itself: v_fma_f64 saturates at 33.3 T lane-ops/s on this part (8 waves per SIMD), and ONE
-# wave per SIMD — all that 65 536 voices give — reaches 25-30 T with 4-8 independent chains.
-FM_PAIR_F64_OPS = {"render_fm_pair": 52, "render_fm_pair_ring": 52}
+# (feedback gain 0.1 ... 0.4, index 0.5 ... 1.5: every wave proves "increments finite, modulator CV within 1/2, carrier CV within 2"
+# and takes the loop with val folded into a per-voice scale, no range reduction in the modulator's 2^x, (2^(cv/4))^4 in the carrier's and
+# one-instruction phase wraps): 48, counted in the gfx950 ISA (tools/disasm.sh; the mix is in DESIGN.md section 4.  The literal loop —
+# nothing proved — has 58, round 2's first kernel had 60).  tools/ubench.hip measures the pipe itself: v_fma_f64 saturates at
+# 33.3 T lane-ops/s on this part (8 waves per SIMD), and ONE wave per SIMD — all that 65 536 voices give — reaches 25-30 T with 4-8
+# independent chains.
+FM_PAIR_F64_OPS = {"render_fm_pair": 48, "render_fm_pair_ring": 48}
 F64_LANE_OPS_MEASURED = 33.3e12
 
 WORKLOADS = ("cfg3", "cfg2", "cfg4", "cfg4_b1024", "p3", "p4")

@@ -625,23 +625,49 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
 }
 
 // Wave-uniform facts about an FM pair's voices (default mode), from which the kernels below pick their sample loop.  Inactive lanes
-// mirror a real voice (WaveMap::vc), so every lane votes.
+// mirror a real voice (WaveMap::vc), so every lane votes.  In the proved loops the increment is scale * 2^cv with scale = 440 / sr * 2^val
+// per voice (OSC_VAL_FOLDED), so what matters is |cv| <= |gain| (the fed-back value is a sine: at most 1, checked where it enters).
 struct FmFacts {
-    bool tame = false;     // both exponents below 1000 in magnitude, both phases in [0, 1), sample rates >= 1: increments finite and >= 0
-    bool small_m = false;  // modulator: |feedback constant| + |val| <= 1/2 (given a fed-back value of magnitude <= 1)
-    bool small_c = false;  // carrier:   |index constant| + |val| <= 1/2
+    bool tame = false;  // gains and vals below 1000 in magnitude, both phases in [0, 1), sample rates >= 1: increments finite and >= 0
+    int mod = 0, car = 0;  // per oscillator: 2 = |gain| <= 1/2 (no range reduction), 1 = |gain| <= 2 ((2^(cv/4))^4), 0 = range reduction
 };
+SRK_DEV int fm_gain_class(float gain)
+{
+    const float g = __builtin_fabsf(gain);  // the margins cover the f32 product cv = sine * gain
+    if (__builtin_amdgcn_ballot_w64(!(g <= 0.4999f)) == 0) return 2;
+    if (__builtin_amdgcn_ballot_w64(!(g <= 1.9999f)) == 0) return 1;
+    return 0;
+}
 SRK_DEV FmFacts fm_facts(float c_fb, const dev::OscConst& km, double pos_m, float c_ix, const dev::OscConst& kc, double pos_c)
 {
-    // f32 sums of magnitudes, compared with a margin that covers their rounding and the product's (cv = sine * constant in f32)
-    const float em = __builtin_fabsf(c_fb) + __builtin_fabsf((float)km.val), ec = __builtin_fabsf(c_ix) + __builtin_fabsf((float)kc.val);
+    const bool sizes = __builtin_fabsf(c_fb) < 1000.0f && __builtin_fabsf(c_ix) < 1000.0f && __builtin_fabs(km.val) < 1000.0 && __builtin_fabs(kc.val) < 1000.0;
     const bool phases = pos_m >= 0.0 && pos_m < 1.0 && pos_c >= 0.0 && pos_c < 1.0;
     const bool rates = km.sr >= 1.0 && kc.sr >= 1.0;  // 440 / sr finite
     FmFacts f;
-    f.tame = __builtin_amdgcn_ballot_w64(!(em < 1000.0f && ec < 1000.0f && phases && rates)) == 0;  // NaNs vote no
-    f.small_m = __builtin_amdgcn_ballot_w64(!(em <= 0.4999f)) == 0;
-    f.small_c = __builtin_amdgcn_ballot_w64(!(ec <= 0.4999f)) == 0;
+    f.tame = __builtin_amdgcn_ballot_w64(!(sizes && phases && rates)) == 0;  // NaNs vote no
+    f.mod = fm_gain_class(c_fb);
+    f.car = fm_gain_class(c_ix);
     return f;
+}
+// the proved sample loops: tile(modulator flags, carrier flags) for the facts' classes
+template <uint32_t kMod, uint32_t kCar, class Tile>
+SRK_DEV void fm_proved_tile(const FmFacts& f, Tile&& tile)
+{
+    using std::integral_constant;
+    constexpr uint32_t P = OSC_PHASE_TAME | OSC_VAL_FOLDED;
+    auto with_car = [&](auto m) {
+        constexpr uint32_t M = kMod | P | decltype(m)::value;
+        if (f.car == 2)
+            tile(integral_constant<uint32_t, M>{}, integral_constant<uint32_t, kCar | P | OSC_CV_SMALL>{});
+        else if (f.car == 1)
+            tile(integral_constant<uint32_t, M>{}, integral_constant<uint32_t, kCar | P | OSC_CV_QUAD>{});
+        else
+            tile(integral_constant<uint32_t, M>{}, integral_constant<uint32_t, kCar | P>{});
+    };
+    if (f.mod == 2)  // (a feedback gain between 1/2 and 2 takes the range reduction: three more copies of every loop for one more instruction pair)
+        with_car(integral_constant<uint32_t, OSC_CV_SMALL>{});
+    else
+        with_car(integral_constant<uint32_t, 0u>{});
 }
 
 // ---- fused 2-operator FM with a z^-1 feedback edge (patch P2's shape, buffer_size == 1) --------------------
@@ -683,6 +709,10 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
     kc = km;
     kc.sr = ocr.sample_rate;
     kc.val = (double)parv(ocr, OSC_P_VAL);
+    if (!kExact) {  // (the proved loops: OSC_VAL_FOLDED)
+        km.scale = (440.0 / km.sr) * exp2(km.val);
+        kc.scale = (440.0 / kc.sr) * exp2(kc.val);
+    }
     // both MATH modules are Multiply by a constant (host-checked): in1 * constant (math.rs:152)
     const float c_fb = parv(ofb, MATH_P_CONST), c_ix = parv(oix, MATH_P_CONST);
     float fed = __uint_as_float(row(ring_row));  // OSC_M.sine of the previous tick (0.0 before the first)
@@ -691,12 +721,20 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
     float sq = 0.0f, sw = 0.0f;
     float sine_m = 0.0f;
     double pos_m = sm.pos;  // modulator phase after exactly t samples (the loop runs it one sample ahead)
-    if (a.T > 0) osc_step(fo, sm, km, fed * c_fb, 0.0f, sine_m, sq, sw);  // modulator of sample 0
     // What a wave can prove about its own voices once per launch (default mode).  A sine is at most 1 in magnitude, so each oscillator's
-    // exponent cv + val is bounded by |constant| + |val|: below 1000 the increment is finite and positive and the wrap is one v_fract
-    // (OSC_PHASE_TAME); at most 1/2 and 2^x needs no range reduction (OSC_CV_SMALL).  The first modulator step above ran without either:
-    // the ring's initial value is the host's, not a sine.
+    // CV is bounded by its gain: below 1000 (and |val| too) the increment is finite and positive and the wrap is one v_fract
+    // (OSC_PHASE_TAME); at most 2 and 2^cv is (2^(cv/4))^4, at most 1/2 and it needs no range reduction at all (fm_facts).  The folded
+    // val and the squarings round differently from the literal form (1e-16), so a launch is proved as a whole or not at all — the first
+    // modulator step and a ragged last tile included: a render must not depend on where it was split.  The one value that is not a
+    // sine is the ring's initial one (the host's): checked here.
     const FmFacts facts = kExact ? FmFacts{} : fm_facts(c_fb, km, sm.pos, c_ix, kc, sc.pos);
+    const bool proved = !kExact && facts.tame && __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(fed) <= 1.0f)) == 0;
+    if (a.T > 0) {  // modulator of sample 0
+        if (proved)
+            fm_proved_tile<fo, fo_carrier>(facts, [&](auto m, auto) { osc_step(decltype(m)::value, sm, km, fed * c_fb, 0.0f, sine_m, sq, sw); });
+        else
+            osc_step(fo, sm, km, fed * c_fb, 0.0f, sine_m, sq, sw);
+    }
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
         auto tile = [&](auto fm_c, auto fc_c, auto whole) {
@@ -720,15 +758,14 @@ __global__ __launch_bounds__(64) void render_fm_pair(KernelArgs a, ChainRoles r)
         using std::integral_constant;
         using std::true_type;
         using std::false_type;
-        if (n != kMixRows) tile(integral_constant<uint32_t, fo>{}, integral_constant<uint32_t, fo_carrier>{}, false_type{});
-        else if (facts.tame && facts.small_m && facts.small_c)
-            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME | OSC_CV_SMALL>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME | OSC_CV_SMALL>{}, true_type{});
-        else if (facts.tame && facts.small_m)
-            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME | OSC_CV_SMALL>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME>{}, true_type{});
-        else if (facts.tame)
-            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME>{}, true_type{});
-        else
+        if (proved && n == kMixRows)
+            fm_proved_tile<fo, fo_carrier>(facts, [&](auto m, auto c) { tile(m, c, true_type{}); });
+        else if (proved)
+            fm_proved_tile<fo, fo_carrier>(facts, [&](auto m, auto c) { tile(m, c, false_type{}); });
+        else if (n == kMixRows)
             tile(integral_constant<uint32_t, fo>{}, integral_constant<uint32_t, fo_carrier>{}, true_type{});
+        else
+            tile(integral_constant<uint32_t, fo>{}, integral_constant<uint32_t, fo_carrier>{}, false_type{});
         emit_flush<kOut>(em, mix_tile, t0, n, V);
     }
     sm.pos = pos_m;  // drop the look-ahead step
@@ -927,6 +964,10 @@ __global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRol
     kc = km;
     kc.sr = ocr.sample_rate;
     kc.val = (double)parv(ocr, OSC_P_VAL);
+    if (!kExact) {
+        km.scale = (440.0 / km.sr) * exp2(km.val);
+        kc.scale = (440.0 / kc.sr) * exp2(kc.val);
+    }
     const float c_fb = parv(ofb, MATH_P_CONST), c_ix = parv(oix, MATH_P_CONST);
 
     Emit em = make_emit(a, plane, lane);
@@ -970,25 +1011,25 @@ __global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRol
         using std::integral_constant;
         using std::true_type;
         using std::false_type;
-        // the ring's first lap holds whatever the host put there (a rack file's saved buffers), not sines: the bound on the exponents
-        // (fm_facts) holds for a tile whose 32 fed-back values are at most 1 in magnitude — one v_max per sample, wave-uniform per tile
+        // the ring's first lap holds whatever the host put there (a rack file's saved buffers), not sines: the bound on the CVs (fm_facts)
+        // holds for a tile whose fed-back values are at most 1 in magnitude — one v_max per sample, wave-uniform per tile.  (A ragged
+        // last tile takes the same arithmetic as a whole one: a render must not depend on where it was split.)
         bool fed_unit = false;
-        if (!kExact && facts.tame && n == kMixRows) {
+        if (!kExact && facts.tame) {
             float m = 0.0f;
 #pragma unroll
-            for (int i = 0; i < kMixRows; i++) m = __builtin_fmaxf(m, __builtin_fabsf(fed[i]));
+            for (int i = 0; i < kMixRows; i++) m = __builtin_fmaxf(m, i < n ? __builtin_fabsf(fed[i]) : 0.0f);
             // (max skips a NaN, and may: a NaN CV makes the increment and then the phase NaN through either form of 2^x and of the wrap)
             fed_unit = __builtin_amdgcn_ballot_w64(!(m <= 1.0f)) == 0;
         }
-        if (n != kMixRows) tile(integral_constant<uint32_t, fo>{}, integral_constant<uint32_t, fo_carrier>{}, false_type{});
-        else if (fed_unit && facts.small_m && facts.small_c)
-            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME | OSC_CV_SMALL>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME | OSC_CV_SMALL>{}, true_type{});
-        else if (fed_unit && facts.small_m)
-            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME | OSC_CV_SMALL>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME>{}, true_type{});
+        if (fed_unit && n == kMixRows)
+            fm_proved_tile<fo, fo_carrier>(facts, [&](auto m, auto c) { tile(m, c, true_type{}); });
         else if (fed_unit)
-            tile(integral_constant<uint32_t, fo | OSC_PHASE_TAME>{}, integral_constant<uint32_t, fo_carrier | OSC_PHASE_TAME>{}, true_type{});
-        else
+            fm_proved_tile<fo, fo_carrier>(facts, [&](auto m, auto c) { tile(m, c, false_type{}); });
+        else if (n == kMixRows)
             tile(integral_constant<uint32_t, fo>{}, integral_constant<uint32_t, fo_carrier>{}, true_type{});
+        else
+            tile(integral_constant<uint32_t, fo>{}, integral_constant<uint32_t, fo_carrier>{}, false_type{});
         if (!kExact && !fed_unit) facts = fm_facts(c_fb, km, sm.pos, c_ix, kc, sc.pos);  // the literal forms may have left [0, 1)
         emit_flush<kOut>(em, mix_tile, t0, n, V);
         p0 = ring_at(p0 + (uint32_t)n);

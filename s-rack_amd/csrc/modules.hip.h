@@ -85,6 +85,7 @@ struct OscConst {    // per-voice constants, set up once per kernel (or tile)
     double val;      // f64(val) when CV is connected
     double sr;       // f64(sample_rate)
     float inv_dt;    // 1 / f32(delta) for the f32 PolyBLEP (constant pitch)
+    double scale = 0.0;  // 440 / sr * 2^val, only where a kernel passes OSC_VAL_FOLDED
 };
 
 // 2^x in f64 for the CV path of the default mode: x = n + f, |f| <= 1/2, a degree-8 polynomial for 2^f (Chebyshev
@@ -340,10 +341,22 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
     if (flags & OSC_HAS_CV) {
         // 440 * 2^(f64(cv) + f64(val)) / f64(sample_rate), per sample (oscillator.rs:45,132)
         if ((flags & OSC_CV_AUDIO_RATE) || __builtin_amdgcn_ballot_w64(cv != s.seen_cv) != 0) {
-            const double e = (double)cv + c.val;
-            // exact mode: 440 * 2^e / sr as written; default mode: (440 / sr) * 2^e with the series above
-            s.seen_delta = (flags & OSC_EXACT) ? 440.0 * exp2_cr(e) / c.sr
-                           : (440.0 / c.sr) * ((flags & OSC_CV_SMALL) ? exp2_fast<false>(e) : exp2_fast<true>(e));
+            if (!(flags & OSC_EXACT) && (flags & OSC_VAL_FOLDED)) {  // (a kernel that proved a bound on |cv|: see the flags)
+                double p;
+                if (flags & OSC_CV_QUAD) {
+                    p = exp2_fast<false>((double)(cv * 0.25f));
+                    p = p * p;
+                    p = p * p;
+                } else {
+                    p = (flags & OSC_CV_SMALL) ? exp2_fast<false>((double)cv) : exp2_fast<true>((double)cv);
+                }
+                s.seen_delta = c.scale * p;
+            } else {
+                const double e = (double)cv + c.val;
+                // exact mode: 440 * 2^e / sr as written; default mode: (440 / sr) * 2^e with the series above
+                s.seen_delta = (flags & OSC_EXACT) ? 440.0 * exp2_cr(e) / c.sr
+                               : (440.0 / c.sr) * ((flags & OSC_CV_SMALL) ? exp2_fast<false>(e) : exp2_fast<true>(e));
+            }
             s.seen_cv = cv;
         }
         delta = s.seen_delta;

@@ -62,8 +62,12 @@ enum : uint32_t {
                                   // (OSC_CONST_FAST = this and not OSC_EXACT)
     // the next two are never set by the flattener: a kernel that has PROVED them for a stretch of samples (wave-uniform tests on its
     // own inputs, see render_fm_pair) passes them as compile-time constants; default mode only
-    OSC_CV_SMALL = 1u << 14,      // |f64(cv) + f64(val)| <= 1/2: 2^x needs no range reduction
+    OSC_CV_SMALL = 1u << 14,      // |f64(cv) + f64(val)| <= 1/2 (|cv| <= 1/2 with OSC_VAL_FOLDED): 2^x needs no range reduction
     OSC_PHASE_TAME = 1u << 15,    // 0 <= pos < 1 and the increment is finite and >= 0: `pos %= 1.0` is one v_fract_f64
+    OSC_VAL_FOLDED = 1u << 16,    // the increment is OscConst::scale * 2^cv with scale = 440 / sr * 2^val computed once per launch (2^(cv + val) =
+                                  // 2^val 2^cv: one rounding more than the sum's, 1e-16 against the polynomial's 1e-12), so the bound is on |cv| alone
+    OSC_CV_QUAD = 1u << 17,       // with OSC_VAL_FOLDED, |cv| <= 2: 2^cv = (2^(cv / 4))^4 — cv / 4 is exact in f32 and needs no range reduction; two
+                                  // squarings instead of v_rndne, subtract, v_cvt_i32 and v_ldexp (the relative error is four times the polynomial's)
     // OP_VCF
     VCF_HAS_AUDIO = 1u << 0,
     VCF_HAS_CV = 1u << 1,

@@ -429,7 +429,7 @@ static void launch_fm_pair2(bool exact, int out_mode, const KernelArgs& ka, cons
         if (kRing)                                                                                     \
             hipLaunchKernelGGL((render_fm_pair_ring<E, O>), grid, dim3(64), 0, st, ka, roles);         \
         else if ((E) && knobs().fm_split) /* exact mode only: measured, see the kernel's comment */    \
-            hipLaunchKernelGGL((render_fm_pair_split<E, O>), grid, dim3(128), 0, st, ka, roles);       \
+            hipLaunchKernelGGL((render_fm_pair_split<true, 0>), grid, dim3(128), 0, st, ka, roles);    \
         else                                                                                           \
             hipLaunchKernelGGL((render_fm_pair<E, O>), grid, dim3(64), 0, st, ka, roles);              \
     } while (0)
