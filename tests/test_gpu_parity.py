@@ -206,21 +206,23 @@ def test_p2_feedback_vs_oracle(S, oracle, B, flags):
 @pytest.mark.parametrize("B", [1, 64, 1024])
 def test_fm_pair_sample_loops(S, oracle, B, flags):
     """The fused FM kernels choose their sample loop per wave from what the wave can prove about its 64 voices (default mode): both
-    exponents within 1/2 (no range reduction in 2^x, one-instruction phase wrap), only the modulator's, neither (the wrap alone), or
-    nothing at all — a voice whose feedback gain lets 2^x overflow, after which its phase is NaN as in the reference, and its 63
+    CVs within 1/2 (no range reduction in 2^x, one-instruction phase wrap), the carrier's within two octaves ((2^(cv/4))^4), beyond
+    (range reduction), or nothing at all — a voice whose feedback gain lets 2^x overflow, after which its phase is NaN as in the reference, and its 63
     well-behaved neighbours, which take the literal forms with it.  One wave of each, plus a modulator `val` that moves a wave from
     one class to the next; every voice against the oracle."""
     T, W = 2500, 64
     rng = np.random.default_rng(11)
     beta = np.concatenate([rng.uniform(0.05, 0.45, W), rng.uniform(0.1, 0.4, W), rng.uniform(0.6, 1.8, W), rng.uniform(0.1, 0.4, W),
-                           rng.uniform(0.1, 0.3, W)]).astype(np.float32)
+                           rng.uniform(0.1, 0.3, W), rng.uniform(0.6, 1.8, W), rng.uniform(0.6, 1.8, W), rng.uniform(0.1, 0.4, W)]).astype(np.float32)
     index = np.concatenate([rng.uniform(0.05, 0.45, W), rng.uniform(0.5, 1.5, W), rng.uniform(0.5, 2.5, W), rng.uniform(0.5, 1.5, W),
-                            rng.uniform(0.1, 0.3, W)]).astype(np.float32)
-    val_m = np.zeros(5 * W, np.float32)
-    val_m[4 * W:] = rng.uniform(0.25, 0.6, W)           # small constants, but |beta| + |val| passes 1/2 for most of the wave
+                            rng.uniform(0.1, 0.3, W), rng.uniform(0.1, 0.4, W), rng.uniform(0.6, 1.9, W), rng.uniform(2.1, 3.0, W)]).astype(np.float32)
+    # (waves 5 - 7: the remaining pairings of the per-oscillator classes — modulator with a range reduction beside a carrier without one or
+    # with the two-octave form, and a small modulator beside a carrier whose index passes two octaves)
+    val_m = np.zeros(8 * W, np.float32)
+    val_m[4 * W:5 * W] = rng.uniform(0.25, 0.6, W)      # a per-voice pitch offset: folded into the voice's scale in the proved loops
     beta[3 * W + 17] = 3.0e4                             # 2^(30000 sin) overflows on the second sample (1500 would not at buffer_size 1: a huge
                                                          # finite increment is an integer, the phase lands on 0 and the sine starts over)
-    V = 5 * W
+    V = 8 * W
     o = oracle.OraclePatch(48000, B, 2)
     ids = S.build_p2(o)
     over = [(ids["mul_fb"], S.MATH_CONSTANT, beta), (ids["mul_idx"], S.MATH_CONSTANT, index), (ids["osc_m"], S.OSC_VAL, val_m)]
