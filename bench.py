@@ -20,6 +20,11 @@ when WORLD_SIZE is not set — bench.py starts the N ranks itself (one per devic
 The control plane (barrier, max over ranks, handing the RCCL unique id around) is torch.distributed/gloo on CPU tensors;
 the data path never touches it.
 
+The default run (cfg3, 1 GPU, default sizes) ALSO times the other two single-GPU BASELINE configurations after the headline
+steps — config 2 (4 096 identical voices) and config 4 (P2 FM pair, buffer_size 1, 65 536 voices), SIDE_STEPS steps each after one
+warm-up, same bracketing (device sync both sides) — and carries them on the same line: flat scalars `cfg2_*` / `cfg4_*` inside
+`roofline`, full detail under `configs`.  metric / value / config / roofline.frac stay the headline's.  `--no-side-configs` skips them.
+
 Prints ONE JSON line (rank 0): metric/value/unit per the driver's contract, plus
   roofline     — achieved = algorithmic bytes of a step / step time (4 B x planes x V x T / t_render, per GPU),
                  peak 8 TB/s HBM; `frac_kernel` is the same for the dominant kernel alone (HIP events on the kernel's own
@@ -135,6 +140,15 @@ class ControlPlane:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather(self, x):
+        """every rank's x, in rank order, on every rank"""
+        if not self.dist:
+            return [x]
+        import torch
+        out = [torch.zeros(1, dtype=torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(out, torch.tensor([x], dtype=torch.float64))
+        return [float(t.item()) for t in out]
+
     def bcast_bytes(self, payload, n):
         """rank 0's `payload` (n bytes) on every rank"""
         if not self.dist:
@@ -171,48 +185,10 @@ class HipBackend:
         self.dev = torch.device("cuda", local_rank)
         if S.lib.srack_device_set(local_rank) != 0:  # the library renders on the calling thread's current device: say it in its own words too
             raise SystemExit("srack_device_set(%d): %s" % (local_rank, S.lib.srack_last_error().decode(errors="replace")))
-        self.args, self.world, self.rank = args, world, rank
+        self.args, self.world, self.rank, self.local_rank = args, world, rank, local_rank
         V, T, C = args.voices, args.samples, 2
-        w = args.workload
-        B = 1 if w == "cfg4" else 1024
-        p = self.p = S.Patch(48000, B, C)
-        first = rank * V  # global voice index => same draw as the 1-GPU run of the same voices
-        if w in ("cfg3", "cfg2"):
-            ids = S.build_p1(p)
-            p.configure_voices(V)
-            if w == "cfg3":
-                det, cut = S.p1_voice_params(V, first_voice=first)
-                p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
-                p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
-                self.what = ("BASELINE config 3 per GPU (config 5 at 8 GPUs): patch P1 saw VCO->ladder VCF->ADSR->VCA, "
-                             f"{V} voices/GPU with per-voice randomised detune/cutoff")
-            else:
-                self.what = (f"BASELINE config 2: patch P1, {V} IDENTICAL voices (every module is voice-invariant: one wave evaluates the patch "
-                             "once — a latency chain — and the frames are a broadcast)")
-        elif w in ("cfg4", "cfg4_b1024"):
-            ids = S.build_p2(p)
-            p.configure_voices(V)
-            beta, index = S.p2_voice_params(V, first_voice=first)
-            p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, beta)
-            p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
-            self.what = (f"BASELINE config 4: patch P2 2-op FM with a feedback edge, {V} voices with per-voice feedback / index, "
-                         f"buffer_size {B} (" + ("z^-1 feedback in a register" if B == 1 else "the app's block size: the feedback delay is a ring in HBM") + ")")
-        elif w == "p4":
-            ids = S.build_p4(p)
-            p.configure_voices(V)
-            depth, expo = S.p4_voice_params(V, first_voice=first)
-            p.set_voice_field(ids["depth"], S.MATH_CONSTANT, depth)
-            p.set_voice_field(ids["shaper"], S.NONLIN_CONSTANT, expo)
-            self.what = ("patch P4 (diagnostic): clock -> sample player with per-voice vibrato depth -> sign-preserving waveshaper with a per-voice "
-                         f"exponent, raw sample on channel 2, {V} voices/GPU")
-        else:
-            ids = S.build_p3(p)
-            p.configure_voices(V)
-            u0, u1 = S.voice_uniform(V, 0, first_voice=first), S.voice_uniform(V, 1, first_voice=first)
-            p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, (u0 * np.float32(2.5) - np.float32(2.0)).astype(np.float32))
-            p.set_voice_field(ids["vcf"], S.VCF_FREQ, (np.float32(0.05) + u1 * np.float32(0.35)).astype(np.float32))
-            self.what = ("patch P3 (diagnostic): clock -> grid + pattern sequencers -> per-voice transposed saw VCO -> VCF swept by an "
-                         f"envelope -> VCA, raw gate on channel 2, {V} voices/GPU with per-voice transpose/cutoff")
+        p, self.what, B = self.make_patch()
+        self.p = p
         self.buffer_size = B
         self.n_planes, _ = p.planes()
         self.frames = None if args.no_frames else torch.empty((self.n_planes, T, V), dtype=torch.float32, device=self.dev)
@@ -225,6 +201,78 @@ class HipBackend:
             uid = cp.bcast_bytes(S.MixComm.unique_id() if rank == 0 else None, S.DIST_ID_BYTES)
             self.comm = S.MixComm(uid, world, rank)
             self.ranks_seen = self.comm.count()
+
+    def make_patch(self):
+        """This rank's shard of the workload as a fresh patch: (patch, description, buffer_size).  Voices are drawn by GLOBAL voice index
+        (rank * V + v), so a shard is the same voices whatever the number of ranks."""
+        S, args = self.S, self.args
+        V = args.voices
+        w = args.workload
+        B = 1 if w == "cfg4" else 1024
+        p = S.Patch(48000, B, 2)
+        first = self.rank * V  # global voice index => same draw as the 1-GPU run of the same voices
+        if w in ("cfg3", "cfg2"):
+            ids = S.build_p1(p)
+            p.configure_voices(V)
+            if w == "cfg3":
+                det, cut = S.p1_voice_params(V, first_voice=first)
+                p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+                p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+                what = ("BASELINE config 3 per GPU (config 5 at 8 GPUs): patch P1 saw VCO->ladder VCF->ADSR->VCA, "
+                        f"{V} voices/GPU with per-voice randomised detune/cutoff")
+            else:
+                what = (f"BASELINE config 2: patch P1, {V} IDENTICAL voices (every module is voice-invariant: one wave evaluates the patch "
+                        "once — a latency chain — and the frames are a broadcast)")
+        elif w in ("cfg4", "cfg4_b1024"):
+            ids = S.build_p2(p)
+            p.configure_voices(V)
+            beta, index = S.p2_voice_params(V, first_voice=first)
+            p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, beta)
+            p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
+            what = (f"BASELINE config 4: patch P2 2-op FM with a feedback edge, {V} voices with per-voice feedback / index, "
+                    f"buffer_size {B} (" + ("z^-1 feedback in a register" if B == 1 else "the app's block size: the feedback delay is a ring in HBM") + ")")
+        elif w == "p4":
+            ids = S.build_p4(p)
+            p.configure_voices(V)
+            depth, expo = S.p4_voice_params(V, first_voice=first)
+            p.set_voice_field(ids["depth"], S.MATH_CONSTANT, depth)
+            p.set_voice_field(ids["shaper"], S.NONLIN_CONSTANT, expo)
+            what = ("patch P4 (diagnostic): clock -> sample player with per-voice vibrato depth -> sign-preserving waveshaper with a per-voice "
+                    f"exponent, raw sample on channel 2, {V} voices/GPU")
+        else:
+            ids = S.build_p3(p)
+            p.configure_voices(V)
+            u0, u1 = S.voice_uniform(V, 0, first_voice=first), S.voice_uniform(V, 1, first_voice=first)
+            p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, (u0 * np.float32(2.5) - np.float32(2.0)).astype(np.float32))
+            p.set_voice_field(ids["vcf"], S.VCF_FREQ, (np.float32(0.05) + u1 * np.float32(0.35)).astype(np.float32))
+            what = ("patch P3 (diagnostic): clock -> grid + pattern sequencers -> per-voice transposed saw VCO -> VCF swept by an "
+                    f"envelope -> VCA, raw gate on channel 2, {V} voices/GPU with per-voice transpose/cutoff")
+        return p, what, B
+
+    def dump(self, directory):
+        """Test hook (SRACK_BENCH_DUMP, tests/test_gpu_dist.py): a CHECKED render beside the timed ones.  A fresh patch of this rank's
+        shard is rendered from sample 0 through the same entry points and the same communicator; what a checker needs is left in
+        `directory`/rank<r>.npz: the device this rank rendered on, sampled voices' frames (first and last of the shard among them), the
+        f64 sum over all of the shard's voices, the partial mix, and — rank 0 — the mix after the RCCL reduce."""
+        torch, a = self.torch, self.args
+        V, T = a.voices, a.samples
+        p, _, _ = self.make_patch()
+        frames = torch.empty((self.n_planes, T, V), dtype=torch.float32, device=self.dev)
+        mix = torch.empty((2, T), dtype=torch.float32, device=self.dev)
+        p.render_raw(T, frames.data_ptr(), mix.data_ptr(), a.flags, self.stream.cuda_stream)
+        self.sync()
+        partial = mix.cpu().numpy().copy()
+        reduced = None
+        if self.comm is not None:
+            self.comm.reduce_mix(mix.data_ptr(), mix.numel(), 0, self.stream.cuda_stream)
+            self.sync()
+            reduced = mix.cpu().numpy()
+        idx = np.unique(np.concatenate([[0, V - 1], np.linspace(0, V - 1, 6).astype(np.int64)]))
+        hip_device, bus = self.S.device_get()  # the device the LIBRARY renders on, in its own words
+        np.savez(os.path.join(directory, f"rank{self.rank}.npz"), rank=self.rank, world=self.world, local_rank=self.local_rank, hip_device=hip_device,
+                 pci_bus_id=bus, ranks_seen=self.ranks_seen, voices=idx, frames=frames[:, :, torch.from_numpy(idx).to(self.dev)].cpu().numpy(),
+                 frames_sum_f64=frames.double().sum(dim=2).cpu().numpy(), frames_abs_sum_f64=frames.double().abs().sum(dim=2).cpu().numpy(),
+                 partial_mix=partial, reduced_mix=reduced if reduced is not None else partial, planes=np.array(p.planes()[1]), info=p.info())
 
     def step(self):
         a = self.args
@@ -249,6 +297,7 @@ class HipBackend:
         if self.comm is not None:
             self.sync()
             self.comm.destroy()
+            self.comm = None
 
 
 def cpu_baseline(S, workload, n_samples=48000):
@@ -295,6 +344,47 @@ def cpu_baseline(S, workload, n_samples=48000):
     }
 
 
+SIDE_CONFIGS = ("cfg2", "cfg4")   # BASELINE.json configs[1] and configs[3]: the other single-GPU configurations
+SIDE_STEPS, SIDE_WARMUP = 5, 1
+
+
+def side_config(args, workload):
+    """One of the other single-GPU BASELINE configurations, timed like the headline: SIDE_WARMUP untimed steps, then exactly SIDE_STEPS
+    steps between two device syncs; the dominant kernel by HIP events beside it.  Returns the figures of its own bench line."""
+    a = argparse.Namespace(**vars(args))
+    a.workload, a.voices, a.flags, a.force_dist, a.no_frames, a.no_mix = workload, default_voices(workload), 0, False, False, False
+    be = HipBackend(a, 1, 0, int(os.environ.get("LOCAL_RANK", "0")), None)
+    try:
+        for _ in range(SIDE_WARMUP):
+            be.step()
+        be.sync()
+        be.arm_kernel_timer()
+        t0 = time.perf_counter()
+        for _ in range(SIDE_STEPS):
+            be.step()
+        be.sync()
+        step_s = (time.perf_counter() - t0) / SIDE_STEPS
+        kernel_ms, n_launch = be.kernel_ms()
+        V, T = a.voices, a.samples
+        info = be.info()
+        kname = info.split("kernel=")[-1] if "kernel=" in info else ""
+        launches = max(1, n_launch // SIDE_STEPS)
+        bytes_per_step = BYTES_PER_VOICE_SAMPLE * be.n_planes * V * T
+        out = {"workload": be.what, "voices": V, "samples_per_step": T, "buffer_size": be.buffer_size, "steps": SIDE_STEPS, "warmup": SIDE_WARMUP,
+               "ms_per_step": step_s * 1e3, "voice_samples_per_s": V * T / step_s,
+               "frac_hbm": bytes_per_step / step_s / 1e9 / HBM_PEAK_GBS, "kernel": kname, "kernel_ms": kernel_ms, "launches_per_step": launches,
+               "frac_hbm_kernel": (bytes_per_step / launches / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms > 0 else 0.0, "program": info}
+        ops = FM_PAIR_F64_OPS.get(kname)
+        if ops:
+            out.update({"f64_ops_per_voice_sample": ops, "frac_valu_f64": ops * V * T / step_s / F64_LANE_OPS_PEAK,
+                        "frac_of_measured_f64_rate": ops * V * T / step_s / F64_LANE_OPS_MEASURED})
+        return out
+    finally:
+        be.close()
+        be.frames = be.mix = be.p = None
+        be.torch.cuda.empty_cache()
+
+
 def profiled_traffic(kernel_name, workload, flags, V, T):
     """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC summary (profiles/rNN<tag>_summary.json, written
     by profiles/summarize.py from separate WRITE_SIZE / FETCH_SIZE passes of this very command), or None.  NOT measured in
@@ -303,7 +393,7 @@ def profiled_traffic(kernel_name, workload, flags, V, T):
     if (V, T) != (default_voices(workload), 48000):
         return None
     tag = {("cfg3", 0): "", ("cfg3", 1): "_exact", ("cfg3", 2): "_special", ("cfg3", 3): "_special_exact", ("p3", 0): "_p3", ("p3", 1): "_p3_exact",
-           ("cfg4", 0): "_cfg4", ("cfg4_b1024", 0): "_cfg4_b1024", ("cfg2", 0): "_cfg2", ("p4", 0): "_p4"}.get((workload, flags))
+           ("cfg4", 0): "_cfg4", ("cfg4", 2): "_cfg4_special", ("cfg4_b1024", 0): "_cfg4_b1024", ("cfg4_b1024", 2): "_cfg4_b1024_special", ("cfg2", 0): "_cfg2", ("p4", 0): "_p4"}.get((workload, flags))
     if tag is None:
         return None
     best = None
@@ -316,10 +406,12 @@ def profiled_traffic(kernel_name, workload, flags, V, T):
         except (OSError, ValueError):
             continue
         for name, v in d.get("derived", {}).items():
-            # (a kernel specialised at run time appears under its entry point's name in the profiler)
+            # (a kernel specialised at run time appears under its entry point's name in the profiler; its control-only launches are a group
+            # of their own — same name, another grid —: the voice launches are the group that moves the bytes)
             if kernel_name and (kernel_name in name or (kernel_name == "render_specialized" and name.startswith("srk_voice"))) and "hbm_traffic_bytes" in v:
-                best = {"bytes_per_launch": v["hbm_traffic_bytes"], "write": v.get("hbm_write_bytes"),
-                        "read_corrected": v.get("hbm_read_bytes_gfx950_corrected"), "source": "profiles/" + base}
+                if best is None or best["source"] != "profiles/" + base or v["hbm_traffic_bytes"] > best["bytes_per_launch"]:
+                    best = {"bytes_per_launch": v["hbm_traffic_bytes"], "write": v.get("hbm_write_bytes"),
+                            "read_corrected": v.get("hbm_read_bytes_gfx950_corrected"), "source": "profiles/" + base}
     return best
 
 
@@ -352,8 +444,12 @@ def run_rank(args, backend_cls=HipBackend):
         be.step()
     host_enqueue = time.perf_counter() - t0  # host time to enqueue K steps (diagnostic: is the host the bottleneck?)
     fence()
-    elapsed = cp.max(time.perf_counter() - t0)
+    mine = time.perf_counter() - t0
+    elapsed = cp.max(mine)
+    per_rank_ms = [x / args.steps * 1e3 for x in cp.gather(mine)]
     kernel_ms, n_launch = be.kernel_ms()
+    if os.environ.get("SRACK_BENCH_DUMP") and hasattr(be, "dump"):
+        be.dump(os.environ["SRACK_BENCH_DUMP"])
 
     out = None
     if rank == 0:
@@ -380,6 +476,7 @@ def run_rank(args, backend_cls=HipBackend):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "ranks_seen": getattr(be, "ranks_seen", world),
+            "per_rank_ms_per_step": per_rank_ms,
             "config": {
                 "workload": be.what + f", {T} samples/step @48 kHz, f32 frames [{n_planes}][T][V] in HBM + stereo mix-down"
                             + (" + RCCL reduce of the [2][T] mix (srack_dist_reduce_mix)" if getattr(be, "comm", None) is not None else ""),
@@ -420,6 +517,26 @@ def run_rank(args, backend_cls=HipBackend):
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
             out["roofline"]["traffic_detail"] = dict(tr, measured_in_this_run=False,
                                                      note="rocprofv3 PMC passes of this command (profiles/run_profile.sh); a profiler cannot run inside the timed region")
+        if world > 1:  # a straggler shows here (the value is paced by the slowest rank)
+            print("[bench] ms per step by rank: " + " ".join(f"{r}:{m:.3f}" for r, m in enumerate(per_rank_ms)), file=sys.stderr, flush=True)
+        if (world == 1 and be.name == "hip" and args.workload == "cfg3" and not args.no_side_configs and args.flags == 0 and not args.no_frames
+                and not args.no_mix and (V, T) == (default_voices("cfg3"), 48000)):
+            # the other single-GPU BASELINE configurations on the same line (the headline's buffers are released first)
+            be.close()
+            be.frames = be.mix = be.p = None
+            be.torch.cuda.empty_cache()
+            out["configs"] = {}
+            for w in SIDE_CONFIGS:
+                c = out["configs"][w] = side_config(args, w)
+                rf = out["roofline"]
+                rf[w + "_ms_per_step"] = c["ms_per_step"]
+                rf[w + "_voice_samples_per_s"] = c["voice_samples_per_s"]
+                rf[w + "_frac_hbm"] = c["frac_hbm"]
+                rf[w + "_kernel_ms"] = c["kernel_ms"]
+                rf[w + "_launches_per_step"] = c["launches_per_step"]
+                if "frac_valu_f64" in c:
+                    rf[w + "_frac_valu_f64"] = c["frac_valu_f64"]
+                    rf[w + "_f64_ops_per_voice_sample"] = c["f64_ops_per_voice_sample"]
         if world == 1 and not args.no_cpu and args.workload not in ("p3", "p4") and be.name == "hip":
             out["cpu_baseline"] = cpu_baseline(be.S, args.workload)
     be.close()
@@ -439,6 +556,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-frames", action="store_true", help="mix only (diagnostic; not the metric)")
     ap.add_argument("--no-mix", action="store_true", help="frames only (diagnostic; not the metric)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip configs 2 and 4 after the headline steps of the default run")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the RCCL communicator and run the mix reduce even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     args = ap.parse_args(argv)

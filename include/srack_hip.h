@@ -341,6 +341,9 @@ int srack_voices_get_field(srack_patch* p, int module, int field, double* values
 /* ---- device helpers for hosts without a HIP binding ---------------------------------------- */
 int srack_device_count(int* n);
 int srack_device_set(int device);
+/* The calling thread's current device — the one srack_render launches on — and its PCI bus id ("0000:05:00.0"), so that a
+ * multi-rank host can check that its ranks really are on different GPUs.  Either pointer may be NULL. */
+int srack_device_get(int* device, char* pci_bus_id, size_t cap);
 int srack_device_alloc(void** d_ptr, size_t bytes);
 int srack_device_free(void* d_ptr);
 int srack_device_to_host(void* h_dst, const void* d_src, size_t bytes, void* stream);

@@ -42,6 +42,7 @@ mod ffi {
         pub fn srack_device_free(d_ptr: *mut c_void) -> c_int;
         pub fn srack_device_to_host(h_dst: *mut c_void, d_src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
         pub fn srack_device_set(device: c_int) -> c_int;
+        pub fn srack_device_get(device: *mut c_int, pci_bus_id: *mut c_char, cap: usize) -> c_int;
         pub fn srack_render_reserve(p: *mut SrackPatch, n_samples: u32, want_mix: c_int, flags: u32) -> c_int;
         pub fn srack_dist_unique_id(id_out: *mut u8) -> c_int;
         pub fn srack_dist_init(id: *const u8, n_ranks: c_int, rank: c_int, comm_out: *mut *mut c_void) -> c_int;

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "srack_patch_set_module_position", "srack_patch_get_module_position", "srack_patch_set_output_buffer", "srack_patch_set_noise_seed", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
     "srack_patch_plan", "srack_patch_plan_list", "srack_patch_removed_edges", "srack_patch_delayed_edges",
     "srack_voices_configure", "srack_voices_set_field_f32", "srack_voices_set_field_f64", "srack_render_planes", "srack_render", "srack_render_reserve",
-    "srack_render_info", "srack_render_kernel_source", "srack_render_kernel_compile", "srack_render_kernel_ms", "srack_voices_get_field", "srack_device_count", "srack_device_set",
+    "srack_render_info", "srack_render_kernel_source", "srack_render_kernel_compile", "srack_render_kernel_ms", "srack_voices_get_field", "srack_device_count", "srack_device_set", "srack_device_get",
     "srack_device_alloc", "srack_device_free", "srack_device_to_host", "srack_device_sync",
     "srack_dist_unique_id", "srack_dist_init", "srack_dist_comm_count", "srack_dist_destroy", "srack_dist_reduce_mix",
 ]
@@ -89,6 +89,7 @@ def _load():
     L.srack_voices_get_field.argtypes = [vp, i32, i32, dp]
     L.srack_device_count.argtypes = [ip]
     L.srack_device_set.argtypes = [i32]
+    L.srack_device_get.argtypes = [ip, C.c_char_p, sz]
     L.srack_device_alloc.argtypes = [C.POINTER(vp), sz]
     L.srack_device_free.argtypes = [vp]
     L.srack_device_to_host.argtypes = [vp, vp, sz, vp]
@@ -114,6 +115,13 @@ def device_count():
     n = C.c_int(0)
     lib.srack_device_count(C.byref(n))
     return n.value
+
+
+def device_get():
+    """(current device of this thread — the one a render launches on —, its PCI bus id)"""
+    d, bus = C.c_int(-1), C.create_string_buffer(64)
+    _check(lib.srack_device_get(C.byref(d), bus, 64))
+    return d.value, bus.value.decode(errors="replace")
 
 
 DIST_ID_BYTES = 128

@@ -1,6 +1,7 @@
 // capi.cpp — the extern "C" boundary declared in include/srack_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -564,10 +565,12 @@ int srack_render_kernel_source(srack_patch* p, uint32_t flags, char* buf, size_t
             set_error("render_kernel_source: call srack_voices_configure first");
             return SRACK_ERR_STATE;
         }
-        int rc = ensure_program(p->h, flags);
+        FlatPair scratch;
+        const FlatPair* prog = nullptr;
+        int rc = peek_program(p->h, flags, scratch, &prog);
         if (rc != SRACK_OK) return rc;
         std::string src;
-        rc = jit_source(p->h.prog, 3, jit_ctl_supported(p->h.prog), src);
+        rc = jit_source(*prog, 3, jit_ctl_supported(*prog), src);
         if (rc != SRACK_OK) return rc;
         if (buf && cap) {
             std::strncpy(buf, src.c_str(), cap - 1);
@@ -585,9 +588,11 @@ int srack_render_kernel_compile(srack_patch* p, uint32_t flags)
             set_error("render_kernel_compile: call srack_voices_configure first");
             return SRACK_ERR_STATE;
         }
-        int rc = ensure_program(p->h, flags);
+        FlatPair scratch;
+        const FlatPair* prog = nullptr;
+        int rc = peek_program(p->h, flags, scratch, &prog);
         if (rc != SRACK_OK) return rc;
-        return jit_compile_only(p->h.prog, 3, jit_ctl_supported(p->h.prog));
+        return jit_compile_only(*prog, 3, jit_ctl_supported(*prog));
     });
 }
 
@@ -679,6 +684,20 @@ int srack_device_set(int device)
 {
     return guarded([&]() -> int {
         HIP_TRY_C(hipSetDevice(device));
+        return SRACK_OK;
+    });
+}
+
+int srack_device_get(int* device, char* pci_bus_id, size_t cap)
+{
+    return guarded([&]() -> int {
+        int dev = -1;
+        HIP_TRY_C(hipGetDevice(&dev));
+        if (device) *device = dev;
+        if (pci_bus_id && cap > 0) {
+            pci_bus_id[0] = 0;
+            HIP_TRY_C(hipDeviceGetPCIBusId(pci_bus_id, (int)std::min<size_t>(cap, 1u << 20), dev));
+        }
         return SRACK_OK;
     });
 }

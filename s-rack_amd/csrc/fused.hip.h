@@ -628,7 +628,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
 // mirror a real voice (WaveMap::vc), so every lane votes.  In the proved loops the increment is scale * 2^cv with scale = 440 / sr * 2^val
 // per voice (OSC_VAL_FOLDED), so what matters is |cv| <= |gain| (the fed-back value is a sine: at most 1, checked where it enters).
 struct FmFacts {
-    bool tame = false;  // gains and vals below 1000 in magnitude, both phases in [0, 1), sample rates >= 1: increments finite and >= 0
+    bool tame = false;  // |gain| + |val| below 1000 per oscillator, both phases in [0, 1), sample rates >= 1: increments finite and >= 0
     int mod = 0, car = 0;  // per oscillator: 2 = |gain| <= 1/2 (no range reduction), 1 = |gain| <= 2 ((2^(cv/4))^4), 0 = range reduction
 };
 SRK_DEV int fm_gain_class(float gain)
@@ -640,7 +640,9 @@ SRK_DEV int fm_gain_class(float gain)
 }
 SRK_DEV FmFacts fm_facts(float c_fb, const dev::OscConst& km, double pos_m, float c_ix, const dev::OscConst& kc, double pos_c)
 {
-    const bool sizes = __builtin_fabsf(c_fb) < 1000.0f && __builtin_fabsf(c_ix) < 1000.0f && __builtin_fabs(km.val) < 1000.0 && __builtin_fabs(kc.val) < 1000.0;
+    // the exponent of an increment is val + cv with |cv| <= |gain|: the SUM has to stay clear of 2^x's overflow (val = 600 with gain = 600 would
+    // not), and then scale = 440 / sr * 2^val and scale * 2^cv are finite too
+    const bool sizes = (double)__builtin_fabsf(c_fb) + __builtin_fabs(km.val) < 1000.0 && (double)__builtin_fabsf(c_ix) + __builtin_fabs(kc.val) < 1000.0;
     const bool phases = pos_m >= 0.0 && pos_m < 1.0 && pos_c >= 0.0 && pos_c < 1.0;
     const bool rates = km.sr >= 1.0 && kc.sr >= 1.0;  // 440 / sr finite
     FmFacts f;

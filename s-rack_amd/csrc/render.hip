@@ -145,10 +145,34 @@ PatchHandle::~PatchHandle()
     device_release(dev_old);
 }
 
+// SPECIALIZE / NO_SPECIALIZE choose a kernel for the SAME flattened program: they are not part of the program's identity.  (A host that
+// reserves with flags 0 and renders with SPECIALIZE, or toggles the bit between renders, must not re-flatten — that would restart every
+// voice and throw the reserved scratch and the compiled kernel away.)
+constexpr uint32_t kLaunchPolicyFlags = SRACK_RENDER_SPECIALIZE | SRACK_RENDER_NO_SPECIALIZE;
+
+static bool program_current(const PatchHandle& h, uint32_t flags)
+{
+    return h.prog_valid && h.prog_graph_revision == h.graph.revision && h.prog_voices_revision == h.voices_revision && h.prog_flags == (flags & ~kLaunchPolicyFlags);
+}
+
+// The program `flags` would render, WITHOUT touching the handle: the handle's own when it is current, else a flatten of a copy of the
+// graph into `scratch` (srack_render_kernel_source / _compile are diagnostics: they must not restart the voices of a running patch).
+int peek_program(PatchHandle& h, uint32_t flags, FlatPair& scratch, const FlatPair** out)
+{
+    if (program_current(h, flags)) {
+        *out = &h.prog;
+        return SRACK_OK;
+    }
+    Graph g = h.graph;
+    const int rc = flatten(g, h.n_voices, h.overrides, (flags & ~kLaunchPolicyFlags) | (h.keep_state ? kFlattenEvalAll : 0u), scratch);
+    *out = &scratch;
+    return rc;
+}
+
 int ensure_program(PatchHandle& h, uint32_t flags)
 {
-    if (h.prog_valid && h.prog_graph_revision == h.graph.revision && h.prog_voices_revision == h.voices_revision && h.prog_flags == flags)
-        return SRACK_OK;
+    if (program_current(h, flags)) return SRACK_OK;
+    flags &= ~kLaunchPolicyFlags;
     // srack_patch_keep_state: what the modules hold on the device becomes the state the re-flattened program starts from —
     // per voice for the modules of the voice program (a per-voice override of the state field), once for a module the control
     // program evaluates (it stays voice-invariant: the field itself).  Rings and reverb lines are not carried.
@@ -876,7 +900,8 @@ int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_
         rc = upload_program(h);
         if (rc != SRACK_OK) return rc;
     }
-    flags = h.prog.effective_flags;  // e.g. the exact oscillator forced for a patch whose approximated ports drive a pitch
+    // e.g. the exact oscillator forced for a patch whose approximated ports drive a pitch; the kernel choice stays this call's
+    flags = h.prog.effective_flags | (flags & kLaunchPolicyFlags);
     constexpr uint32_t kSegment = 65536;
     for (uint32_t t = 0; t < n_samples && rc == SRACK_OK; t += kSegment)
         rc = render_segment(h, n_samples, t, std::min(kSegment, n_samples - t), d_frames, d_mix, flags, (hipStream_t)stream);
@@ -905,7 +930,7 @@ int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t f
     if (h.prog.n_tracks > 0 && (rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
     const JitKernel* special = nullptr;  // compile now what the first render would otherwise compile (frames + mix, or frames only)
     bool special_ctl = false;
-    if ((rc = resolve_specialized(h, h.prog.effective_flags, want_mix ? 3 : 1, &special, &special_ctl)) != SRACK_OK) return rc;
+    if ((rc = resolve_specialized(h, h.prog.effective_flags | (flags & kLaunchPolicyFlags), want_mix ? 3 : 1, &special, &special_ctl)) != SRACK_OK) return rc;
     return SRACK_OK;
 }
 

@@ -48,6 +48,8 @@ struct PatchHandle {
 // (Re)flatten when the graph, the voices or the flags changed since the last render; a re-flatten
 // resets the device voice state to the modules' fields (like re-loading the patch).
 int ensure_program(PatchHandle& h, uint32_t flags);
+// The program `flags` would render, without touching the handle (its own if current, else flattened from a copy into `scratch`).
+int peek_program(PatchHandle& h, uint32_t flags, FlatPair& scratch, const FlatPair** out);
 
 int device_render(PatchHandle& h, uint32_t n_samples, float* d_frames, float* d_mix, uint32_t flags, void* stream);
 int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t flags);
