@@ -58,7 +58,10 @@ F64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
 # nothing proved — has 58, round 2's first kernel had 60).  tools/ubench.hip measures the pipe itself: v_fma_f64 saturates at
 # 33.3 T lane-ops/s on this part (8 waves per SIMD), and ONE wave per SIMD — all that 65 536 voices give — reaches 25-30 T with 4-8
 # independent chains.
-FM_PAIR_F64_OPS = {"render_fm_pair": 48, "render_fm_pair_ring": 48}
+FM_PAIR_F64_OPS = {"render_fm_pair": 48, "render_fm_pair_ring": 48,
+                   # config 4 through the kernel specialised at run time (the default since round 3): the generator's vote picks the same loop —
+                   # modulator small, carrier (2^(cv/4))^4 — and tools/disasm_jit.py p2 counts the same 384 f64-rate instructions per 8 samples
+                   "render_specialized": 48}
 F64_LANE_OPS_MEASURED = 33.3e12
 
 WORKLOADS = ("cfg3", "cfg2", "cfg4", "cfg4_b1024", "p3", "p4")
@@ -374,7 +377,7 @@ def side_config(args, workload):
                "ms_per_step": step_s * 1e3, "voice_samples_per_s": V * T / step_s,
                "frac_hbm": bytes_per_step / step_s / 1e9 / HBM_PEAK_GBS, "kernel": kname, "kernel_ms": kernel_ms, "launches_per_step": launches,
                "frac_hbm_kernel": (bytes_per_step / launches / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms > 0 else 0.0, "program": info}
-        ops = FM_PAIR_F64_OPS.get(kname)
+        ops = FM_PAIR_F64_OPS.get(kname) if workload == "cfg4" or kname != "render_specialized" else None
         if ops:
             out.update({"f64_ops_per_voice_sample": ops, "frac_valu_f64": ops * V * T / step_s / F64_LANE_OPS_PEAK,
                         "frac_of_measured_f64_rate": ops * V * T / step_s / F64_LANE_OPS_MEASURED})
@@ -497,7 +500,7 @@ def run_rank(args, backend_cls=HipBackend):
                 "traffic": None,
             },
         }
-        if args.workload in ("cfg4", "cfg4_b1024") and FM_PAIR_F64_OPS.get(kname):
+        if args.workload in ("cfg4", "cfg4_b1024") and FM_PAIR_F64_OPS.get(kname) and not (kname == "render_specialized" and args.workload != "cfg4"):
             ops = FM_PAIR_F64_OPS[kname]
             lane_ops = ops * V * T / step_s
             out["roofline"].update({

@@ -338,6 +338,27 @@ int srack_render_kernel_ms(srack_patch* p, double* avg_ms, int* n_launches, int 
 /* Read back one field of every voice's state after a render (host buffer, n_voices doubles). */
 int srack_voices_get_field(srack_patch* p, int module, int field, double* values);
 
+/* ---- the cache of run-time specialised kernels ------------------------------------------------------------
+ * A general patch (anything the hand-matched kernels do not cover) renders through a kernel compiled for its STRUCTURE with hiprtc
+ * the first time that structure is seen (0.3 - 2 s).  Code objects are kept in memory (the last SRACK_KERNEL_CACHE_MAX structures,
+ * default 64, least recently used first out; a module is unloaded once no patch renders with it) and ON DISK, so the next start of
+ * the host — and every other rank of a multi-GPU job — loads instead of compiling (ranks starting together serialise on a file
+ * lock: one compiles).  The directory: srack_kernel_cache_set_dir(path); "off" disables the disk level; NULL restores the default
+ * resolution — $SRACK_KERNEL_CACHE_DIR, else `.srack_kernel_cache` next to this library if writable, else $XDG_CACHE_HOME/srack_hip
+ * or ~/.cache/srack_hip.  srack_render_info names where a patch's kernel came from: jit=compiled(N ms) | disk-cache | memory-cache |
+ * unavailable(reason).  No counterpart in the reference (its modules are compiled Rust, src/synth.rs:300-317). */
+typedef struct srack_kernel_cache_info {
+    uint64_t compiled;               /* hiprtc compilations by this process */
+    uint64_t disk_hits, memory_hits;
+    uint64_t modules_loaded;
+    uint64_t code_evictions, module_evictions;
+    uint64_t resident_code_objects, resident_modules;
+    double compile_ms;               /* total hiprtc time */
+    char directory[512];             /* the disk cache in use; "" = none */
+} srack_kernel_cache_info;
+int srack_kernel_cache_set_dir(const char* dir);
+int srack_kernel_cache_stats(srack_kernel_cache_info* out);
+
 /* ---- device helpers for hosts without a HIP binding ---------------------------------------- */
 int srack_device_count(int* n);
 int srack_device_set(int device);

@@ -48,10 +48,16 @@ def bench_line(path):
 
 
 def dispatches(con):
-    """[(name, grid, start_ns, end_ns, dispatch_id)] in start order"""
+    """[(name, grid class, start_ns, end_ns, dispatch_id)] in start order.  The grid class of a launch is the largest grid its kernel is
+    ever launched with ("voice launches": the co-scheduled control blocks add one or a few workgroups to some of them, which is not
+    another kind of launch) or, for a launch of less than half that, its own grid (a specialised kernel's control-only launches)."""
     q = ("select S.display_name, K.grid_size_x * K.grid_size_y * K.grid_size_z, K.start, K.end, K.dispatch_id from rocpd_kernel_dispatch K "
          "join rocpd_info_kernel_symbol S on S.id = K.kernel_id and S.guid = K.guid order by K.start, K.dispatch_id")
-    return [(str(n), int(g), int(s), int(e), int(d)) for n, g, s, e, d in con.execute(q)]
+    rows = [(str(n), int(g), int(s), int(e), int(d)) for n, g, s, e, d in con.execute(q)]
+    biggest = {}
+    for n, g, _, _, _ in rows:
+        biggest[n] = max(biggest.get(n, 0), g)
+    return [(n, biggest[n] if 2 * g > biggest[n] else g, s, e, d) for n, g, s, e, d in rows]
 
 
 def step_period(keys, n_steps):

@@ -27,10 +27,17 @@ ABI_SYMBOLS = [
     "srack_patch_set_module_position", "srack_patch_get_module_position", "srack_patch_set_output_buffer", "srack_patch_set_noise_seed", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
     "srack_patch_plan", "srack_patch_plan_list", "srack_patch_removed_edges", "srack_patch_delayed_edges",
     "srack_voices_configure", "srack_voices_set_field_f32", "srack_voices_set_field_f64", "srack_render_planes", "srack_render", "srack_render_reserve",
-    "srack_render_info", "srack_render_kernel_source", "srack_render_kernel_compile", "srack_render_kernel_ms", "srack_voices_get_field", "srack_device_count", "srack_device_set", "srack_device_get",
+    "srack_render_info", "srack_render_kernel_source", "srack_render_kernel_compile", "srack_render_kernel_ms", "srack_voices_get_field", "srack_kernel_cache_set_dir", "srack_kernel_cache_stats", "srack_device_count", "srack_device_set", "srack_device_get",
     "srack_device_alloc", "srack_device_free", "srack_device_to_host", "srack_device_sync",
     "srack_dist_unique_id", "srack_dist_init", "srack_dist_comm_count", "srack_dist_destroy", "srack_dist_reduce_mix",
 ]
+
+
+class KernelCacheInfo(C.Structure):
+    """srack_kernel_cache_info (include/srack_hip.h)"""
+    _fields_ = [("compiled", C.c_uint64), ("disk_hits", C.c_uint64), ("memory_hits", C.c_uint64), ("modules_loaded", C.c_uint64),
+                ("code_evictions", C.c_uint64), ("module_evictions", C.c_uint64), ("resident_code_objects", C.c_uint64),
+                ("resident_modules", C.c_uint64), ("compile_ms", C.c_double), ("directory", C.c_char * 512)]
 
 
 class SrackError(RuntimeError):
@@ -87,6 +94,8 @@ def _load():
     L.srack_render_kernel_source.argtypes = [vp, u32, C.c_char_p, sz]
     L.srack_render_kernel_compile.argtypes = [vp, u32]
     L.srack_voices_get_field.argtypes = [vp, i32, i32, dp]
+    L.srack_kernel_cache_set_dir.argtypes = [C.c_char_p]
+    L.srack_kernel_cache_stats.argtypes = [C.POINTER(KernelCacheInfo)]
     L.srack_device_count.argtypes = [ip]
     L.srack_device_set.argtypes = [i32]
     L.srack_device_get.argtypes = [ip, C.c_char_p, sz]
@@ -115,6 +124,19 @@ def device_count():
     n = C.c_int(0)
     lib.srack_device_count(C.byref(n))
     return n.value
+
+
+def kernel_cache_set_dir(path):
+    """The disk level of the specialised-kernel cache: a directory, "off", or None for the default resolution."""
+    _check(lib.srack_kernel_cache_set_dir(None if path is None else os.fsencode(path)))
+
+
+def kernel_cache_stats():
+    st = KernelCacheInfo()
+    _check(lib.srack_kernel_cache_stats(C.byref(st)))
+    d = {k: getattr(st, k) for k, _ in KernelCacheInfo._fields_}
+    d["directory"] = st.directory.decode(errors="replace")
+    return d
 
 
 def device_get():

@@ -548,6 +548,8 @@ int srack_render_info(srack_patch* p, char* buf, size_t cap)
         if (rc != SRACK_OK) return rc;
         std::string s = p->h.prog.description;
         const char* k = device_kernel_name(p->h);
+        // (the kernel's name stays LAST: hosts and tests read it with split("kernel="))
+        s += device_jit_note(p->h);
         if (k && *k) s += std::string(" kernel=") + k;
         if (buf && cap) {
             std::strncpy(buf, s.c_str(), cap - 1);
@@ -572,6 +574,7 @@ int srack_render_kernel_source(srack_patch* p, uint32_t flags, char* buf, size_t
         std::string src;
         rc = jit_source(*prog, 3, jit_ctl_supported(*prog), src);
         if (rc != SRACK_OK) return rc;
+        src = "// for: " + prog->description + "\n" + src;  // (for the reader; not part of what is compiled and cached)
         if (buf && cap) {
             std::strncpy(buf, src.c_str(), cap - 1);
             buf[cap - 1] = 0;
@@ -667,6 +670,35 @@ bool read_device_state(PatchHandle& h, int module, int field, std::vector<double
 }
 }  // namespace srack
 }  // extern "C++"
+
+// ---- the kernel cache (jit.cpp) ---------------------------------------------------------------------
+int srack_kernel_cache_set_dir(const char* dir)
+{
+    return guarded([&]() -> int { return jit_cache_set_dir(dir); });
+}
+
+int srack_kernel_cache_stats(srack_kernel_cache_info* out)
+{
+    return guarded([&]() -> int {
+        if (!out) {
+            set_error("srack_kernel_cache_stats: out is null");
+            return SRACK_ERR_INVALID;
+        }
+        const JitCacheStats st = jit_cache_stats();
+        std::memset(out, 0, sizeof *out);
+        out->compiled = st.compiled;
+        out->disk_hits = st.disk_hits;
+        out->memory_hits = st.memory_hits;
+        out->modules_loaded = st.modules_loaded;
+        out->code_evictions = st.code_evictions;
+        out->module_evictions = st.module_evictions;
+        out->resident_code_objects = st.resident_code_objects;
+        out->resident_modules = st.resident_modules;
+        out->compile_ms = st.compile_ms;
+        std::snprintf(out->directory, sizeof out->directory, "%s", st.directory);
+        return SRACK_OK;
+    });
+}
 
 // ---- device helpers -------------------------------------------------------------------------------
 int srack_device_count(int* n)

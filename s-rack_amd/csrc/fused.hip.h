@@ -631,13 +631,7 @@ struct FmFacts {
     bool tame = false;  // |gain| + |val| below 1000 per oscillator, both phases in [0, 1), sample rates >= 1: increments finite and >= 0
     int mod = 0, car = 0;  // per oscillator: 2 = |gain| <= 1/2 (no range reduction), 1 = |gain| <= 2 ((2^(cv/4))^4), 0 = range reduction
 };
-SRK_DEV int fm_gain_class(float gain)
-{
-    const float g = __builtin_fabsf(gain);  // the margins cover the f32 product cv = sine * gain
-    if (__builtin_amdgcn_ballot_w64(!(g <= 0.4999f)) == 0) return 2;
-    if (__builtin_amdgcn_ballot_w64(!(g <= 1.9999f)) == 0) return 1;
-    return 0;
-}
+using dev::fm_gain_class;  // modules.hip.h: shared with the kernels specialised at run time
 SRK_DEV FmFacts fm_facts(float c_fb, const dev::OscConst& km, double pos_m, float c_ix, const dev::OscConst& kc, double pos_c)
 {
     // the exponent of an increment is val + cv with |cv| <= |gain|: the SUM has to stay clear of 2^x's overflow (val = 600 with gain = 600 would

@@ -1,5 +1,7 @@
 // jit.hpp — voice kernels specialised for one flattened program at run time (jit.cpp).
 #pragma once
+#include <cstdint>
+#include <memory>
 #include <string>
 
 #include "flatten.hpp"
@@ -9,9 +11,25 @@ namespace srack {
 
 constexpr int kMixRowsHost = 32;  // = kMixRows of wave.hip.h: samples per tile of the specialised and the fused kernels
 
-struct JitKernel {
+struct JitKernel {  // a loaded module: shared between the process-wide cache and every patch that renders with it
     void* module = nullptr;    // hipModule_t
     void* function = nullptr;  // hipFunction_t
+    JitKernel() = default;
+    JitKernel(const JitKernel&) = delete;
+    JitKernel& operator=(const JitKernel&) = delete;
+    ~JitKernel();              // hipModuleUnload, once the last owner lets go
+};
+
+struct JitFetchInfo {  // how one kernel was come by
+    int how = 0;              // 0: this process had it (memory), 1: the disk cache, 2: compiled now
+    double compile_ms = 0.0;  // hiprtc time when how == 2
+};
+
+struct JitCacheStats {  // process-wide, since start (srack_kernel_cache_stats)
+    uint64_t compiled = 0, disk_hits = 0, memory_hits = 0, modules_loaded = 0, code_evictions = 0, module_evictions = 0;
+    uint64_t resident_code_objects = 0, resident_modules = 0;
+    double compile_ms = 0.0;
+    char directory[512] = {0};  // the disk cache in use ("" = none)
 };
 
 // Can the generator express this program?  (`why` names the first obstacle.)
@@ -23,8 +41,11 @@ bool jit_ctl_supported(const FlatPair& pair, std::string* why = nullptr);
 int jit_source(const FlatPair& pair, int out_mode, bool with_ctl, std::string& src);
 // Generate + compile for the current device's architecture (gfx950 when the process has no device); nothing is loaded.
 int jit_compile_only(const FlatPair& pair, int out_mode, bool with_ctl);
-// Generate, compile (cached per source) and load on the current device (cached per device).
-int jit_get(const FlatPair& pair, int out_mode, bool with_ctl, const JitKernel** out);
+// Generate, fetch the code object (memory -> disk -> hiprtc; jit.cpp "the kernel cache") and load it on the current device.
+int jit_get(const FlatPair& pair, int out_mode, bool with_ctl, std::shared_ptr<const JitKernel>* out, JitFetchInfo* how = nullptr);
+// The disk cache's directory: a path, "off", or nullptr for the default resolution (SRACK_KERNEL_CACHE_DIR, next to the library, ~/.cache).
+int jit_cache_set_dir(const char* dir);
+JitCacheStats jit_cache_stats();
 int jit_launch(const JitKernel& k, const KernelArgs& ka, uint32_t n_blocks, void* stream);
 
 }  // namespace srack

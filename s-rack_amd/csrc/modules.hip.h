@@ -406,6 +406,28 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
     s.pos = (flags & OSC_PHASE_TAME) ? __builtin_amdgcn_fract(pos + delta) : wrap01(pos + delta);
 }
 
+// ---- what a WAVE can prove about an oscillator's pitch CV once per launch (default mode) ---------------------------------------------
+// A CV whose magnitude is bounded for the whole launch — a sine through a gain: |cv| <= |gain| — lets the sample loop drop work
+// (render_fm_pair in fused.hip.h; the kernels specialised at run time, jit.cpp): every lane votes with its own bound.
+//   2: |cv| <= 1/2  2^cv needs no range reduction (OSC_CV_SMALL)   1: |cv| <= 2  2^cv = (2^(cv / 4))^4 (OSC_CV_QUAD)   0: neither
+SRK_DEV int fm_gain_class(float bound)
+{
+    const float g = __builtin_fabsf(bound);  // the margins cover the f32 roundings of the products and sums the bound stands for
+    if (__builtin_amdgcn_ballot_w64(!(g <= 0.4999f)) == 0) return 2;
+    if (__builtin_amdgcn_ballot_w64(!(g <= 1.9999f)) == 0) return 1;
+    return 0;
+}
+// A compile-time class per versioned oscillator of a specialised kernel: 0 nothing proved (the literal forms), 1 increments finite and
+// phase in [0, 1) (one-instruction wrap, val folded into a per-launch scale), 2 = 1 and |cv| <= 2, 3 = 1 and |cv| <= 1/2.
+template <uint32_t kValue>
+struct UC {
+    static constexpr uint32_t value = kValue;
+};
+constexpr uint32_t fm_class_flags(uint32_t cls)
+{
+    return cls == 0u ? 0u : (OSC_PHASE_TAME | OSC_VAL_FOLDED | (cls == 3u ? OSC_CV_SMALL : cls == 2u ? OSC_CV_QUAD : 0u));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Constant-pitch, unsynced oscillator — the hot special case (no CV, no sync, delta < 0.25).
 // Same phase recurrence as osc_step (bit-identical pos); the per-sample work is cut down by

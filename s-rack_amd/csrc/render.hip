@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <string>
 #include <vector>
 
 #include "fused.hip.h"
@@ -109,8 +111,9 @@ struct DeviceState {
     size_t mixgroup_bytes = 0;
     float* d_tracks = nullptr;
     size_t tracks_bytes = 0;
-    const JitKernel* jit[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the specialised voice kernel per output mode (1 frames, 2 mix, 3 both, 4 neither)
+    std::shared_ptr<const JitKernel> jit[5];  // the specialised voice kernel per output mode (1 frames, 2 mix, 3 both, 4 neither), co-owned with the cache
     bool jit_failed = false;  // specialisation was tried by default and is not available: the interpreter renders
+    std::string jit_note;     // for srack_render_info: how the kernel was come by (compiled in N ms / disk cache / memory), or why there is none
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timings;  // (start, stop) pairs of the dominant kernel, not yet read
     std::vector<hipEvent_t> pool;
     const char* kernel_name = "";
@@ -496,10 +499,24 @@ static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_
 // The general path: a kernel specialised for the program (jit.cpp), or the tile interpreter.  Specialising costs a compilation
 // (~1 s) the first time a program structure is seen, so by default it is reserved for renders wide enough to repay it.
 constexpr uint32_t kSpecializeMinVoices = 4096;
-// Which programs take a specialised kernel: those no hand-written kernel matches, and two shapes whose hand-written kernels the
-// specialised ones outrun on MI355X (P1 with everything per voice: 21.2 -> 18.1 ms per step; the sequencer-driven chain P3:
-// 29.5 -> 24.5).  The flagship track kernel and the FM pair keep their hand-written kernels.
-static bool specializable_shape(int fused) { return fused == FUSED_NONE || fused == FUSED_VOICE_CHAIN || fused == FUSED_VOICE_CHAIN_SEQ; }
+// Which programs take a specialised kernel: those no hand-written kernel matches, and the shapes whose hand-written kernels the
+// specialised ones outrun or tie on MI355X (P1 with everything per voice: 21.2 -> 18.1 ms per step; the sequencer-driven chain P3:
+// 29.5 -> 24.5; since round 3 the z^-1 FM pair in default mode: the generator derives what render_fm_pair proves by hand — bounded pitch
+// CVs, the wave's vote, a loop copy per class: the same 48 f64-rate instructions per voice-sample in the ISA — and config 4 runs 7.26 -
+// 7.28 ms per step through it against 7.46 - 7.49 on the same box).  The flagship track kernel keeps its hand-written form (fixed-point
+// phase), so do the FM pair's ring variant (per-tile votes on what the ring hands over) and its exact-mode two-wave split.
+// SRACK_FM_FUSED=1 (tools/) keeps render_fm_pair for A/B runs.
+static bool specializable_shape(const FlatProgram& P, uint32_t flags)
+{
+    if (P.fused == FUSED_FM_PAIR) {
+        static const bool keep_fused = [] {
+            const char* e = getenv("SRACK_FM_FUSED");
+            return e && e[0] == '1';
+        }();
+        return P.fused_variant == 0 && !(flags & SRACK_RENDER_EXACT_OSC) && !keep_fused;
+    }
+    return P.fused == FUSED_NONE || P.fused == FUSED_VOICE_CHAIN || P.fused == FUSED_VOICE_CHAIN_SEQ;
+}
 
 static int resolve_specialized(PatchHandle& h, uint32_t flags, int out_mode, const JitKernel** out, bool* with_ctl)
 {
@@ -507,21 +524,32 @@ static int resolve_specialized(PatchHandle& h, uint32_t flags, int out_mode, con
     *with_ctl = false;
     const FlatProgram& P = h.prog.voice;
     DeviceState* d = h.dev;
-    if (!specializable_shape(P.fused) || (flags & SRACK_RENDER_NO_SPECIALIZE) || P.ops.empty()) return SRACK_OK;
+    if (!specializable_shape(P, flags) || (flags & SRACK_RENDER_NO_SPECIALIZE) || P.ops.empty()) return SRACK_OK;
     const bool forced = (flags & SRACK_RENDER_SPECIALIZE) != 0;
     if (!forced && (P.n_voices < kSpecializeMinVoices || d->jit_failed || !jit_supported(P))) return SRACK_OK;
     // the control program's units ride along in the same launches whenever the generator covers them all
     const bool ctl = h.prog.n_tracks > 0 && knobs().special_ctl && jit_ctl_supported(h.prog);
     if (!d->jit[out_mode]) {
-        const int rc = jit_get(h.prog, out_mode, ctl, &d->jit[out_mode]);
+        JitFetchInfo how;
+        const int rc = jit_get(h.prog, out_mode, ctl, &d->jit[out_mode], &how);
         if (rc != SRACK_OK) {
             if (forced) return rc;  // asked for explicitly: fail loudly
+            d->jit_note = std::string(" jit=unavailable(") + last_error() + ")";
+            if (d->jit_note.size() > 160) d->jit_note = d->jit_note.substr(0, 157) + "...)";
+            for (char& c : d->jit_note)
+                if (c == '\n') c = ' ';
             fprintf(stderr, "[srack] no specialised kernel for this program (%s): rendering through the pre-built kernels\n", last_error());
             d->jit_failed = true;
             return SRACK_OK;
         }
+        char note[96];
+        if (how.how == 2)
+            std::snprintf(note, sizeof note, " jit=compiled(%.0f ms)", how.compile_ms);
+        else
+            std::snprintf(note, sizeof note, " jit=%s", how.how == 1 ? "disk-cache" : "memory-cache");
+        d->jit_note = note;
     }
-    *out = d->jit[out_mode];
+    *out = d->jit[out_mode].get();
     *with_ctl = ctl;
     return SRACK_OK;
 }
@@ -608,6 +636,12 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         return CtlWork{d->ctl[0].d_ops, d->ctl[0].d_table, d->d_tracks + (size_t)Cp.ops[2].aux * T + t_off, len,
                        Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_EXACT)};
     };
+    const JitKernel* special = nullptr;  // a kernel specialised for this program (jit.cpp), if the program takes one
+    bool special_ctl = false;            // ... with the control program's units as extra blocks of every launch
+    {
+        const int om = (d_frames ? 1 : 0) | (d_mix ? 2 : 0);
+        if ((rc = resolve_specialized(h, flags, om ? om : 4, &special, &special_ctl)) != SRACK_OK) return rc;
+    }
     // chunk schedule: short first chunks (only control chunk 0 is exposed), doubling up to kChunkMax
     // With a control pipeline of depth L the first voice chunk waits for L + 1 control launches: those stay short.
     const uint32_t kChunkMax = knobs().chunk_max;
@@ -626,8 +660,11 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
               // samples of each other, so their frame rows land in the same DRAM pages (FM pair 13.2 -> 9.9 ms per step)
         // The z^-1 FM pair (one wave per SIMD at config 4's 65 536 voices, no ring traffic) wants them shorter still: 2048 samples 7.26 ms per
         // step, 4096 7.39, 1536 7.31, 1024 7.43, 8192 7.85 (tools/ab_env.sh, one box); its ring variant and the flagship are flat from 3072 to 6144.
+        // A specialised kernel without rings in HBM at one wave per SIMD or fewer is in the same position (config 4 through the general
+        // path: 7.36 - 7.46 ms per step at 4096, 7.26 - 7.28 at 2048, two rounds on one box).
         const bool fm_z1 = P.fused == FUSED_FM_PAIR && P.fused_variant == 0 && !(flags & (SRACK_RENDER_NO_FUSION | SRACK_RENDER_EXACT_OSC));
-        const uint32_t len = fm_z1 ? std::min(kChunkMax, 2048u) : kChunkMax;
+        const bool lone_waves = special && P.hdr.n_rings == 0 && n_waves <= 1024 && !(flags & SRACK_RENDER_EXACT_OSC);
+        const uint32_t len = (fm_z1 || lone_waves) ? std::min(kChunkMax, 2048u) : kChunkMax;
         for (uint32_t t_off = 0; t_off < T; t_off += len) chunks.emplace_back(t_off, std::min(len, T - t_off));
     }
     const uint32_t n_chunks = (uint32_t)chunks.size();
@@ -642,12 +679,6 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     };
 
     if (has_ctl && (rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
-    const JitKernel* special = nullptr;  // a kernel specialised for this program (jit.cpp), if the program takes one
-    bool special_ctl = false;            // ... with the control program's units as extra blocks of every launch
-    {
-        const int om = (d_frames ? 1 : 0) | (d_mix ? 2 : 0);
-        if ((rc = resolve_specialized(h, flags, om ? om : 4, &special, &special_ctl)) != SRACK_OK) return rc;
-    }
     // One argument block per (launch, control unit): launch j runs unit s on chunk j - lag[s]; chunk c is complete after launch
     // c + max_lag.  (A control program that was not cut into units is one unit with lag 0.)
     auto stage_args = [&](uint32_t s, uint32_t k) {
@@ -976,5 +1007,6 @@ int device_read_rows(PatchHandle& h, int ctl_stage, int first_row, int n_rows, u
 }
 
 const char* device_kernel_name(const PatchHandle& h) { return h.dev ? h.dev->kernel_name : ""; }
+std::string device_jit_note(const PatchHandle& h) { return h.dev ? h.dev->jit_note : std::string(); }
 
 }  // namespace srack

@@ -59,5 +59,6 @@ int device_read_rows(PatchHandle& h, int ctl_stage /* -1: the voice program */, 
 bool read_device_state(PatchHandle& h, int module, int field, std::vector<double>& values);
 void device_release(DeviceState* d);
 const char* device_kernel_name(const PatchHandle& h);
+std::string device_jit_note(const PatchHandle& h);  // " jit=compiled(1834 ms)" / " jit=disk-cache" / " jit=memory-cache" / " jit=unavailable(why)" / ""
 
 }  // namespace srack

@@ -22,7 +22,8 @@ import srack_pkg
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-V_PER_RANK, T = 8192, 6000   # 128 waves per rank through the flagship kernel; three launches (1024 + 2048 + 2928 samples) and a ragged tile
+V_PER_RANK, T = 8192, 18000  # 128 waves per rank through the flagship kernel; six launches and a ragged tile; P1's gate LFO (1.72 Hz) first
+                             # rises at sample 13 964: the render holds silence, an attack and most of a decay
 
 
 @pytest.fixture(scope="module")

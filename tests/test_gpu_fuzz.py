@@ -65,13 +65,18 @@ def test_random_patch_matches_oracle(seed, noise, oracle, monkeypatch):
 DEFAULT_FLAGS = (0, 2, 4)          # fused / general path (interpreter at this size) / everything per voice
 DEFAULT_SPECIAL = 34               # the general path through a kernel specialised at run time (a compilation: every third seed)
 KNOWN_CHAOTIC = {
-    # (seed, noise): reason
+    # (seed, noise): reason — none of the pinned seeds (0 ... 159, the seven soak finds, 0 ... 39 of the noise family) is chaotic since the
+    # flattener gives producers that reach a pitch the exact PolyBLEP / the literal ladder; these three are what
+    # tools/fuzz_soak_default.py finds in seeds 700 ... 759 and 1400 ... 1499 (480 renders, 9 outside the band, all three modes alike):
+    (725, False): "feedback loop through a sync input: one sample's 1e-7 moves an edge, the phases part for good (also parts in exact mode under tools/fuzz_soak_cfg.py)",
+    (1459, False): "filter <-> mixer loop with a per-voice mixer gain above 1 whose cutoff a square wave slams between two values: chaotic in one voice of 67",
+    (1473, False): "feedback through a pitch input: parts from the oracle in exact mode as well (the last bit of 2^cv against glibc's, iterated)",
 }
 
 
 def _default_cases():
     cases = []
-    for s, noise in [(s, False) for s in list(range(160)) + [707, 774, 780, 867, 944, 1000, 1157]] + [(s, True) for s in range(40)]:
+    for s, noise in [(s, False) for s in list(range(160)) + [707, 725, 774, 780, 867, 944, 1000, 1157, 1459, 1473]] + [(s, True) for s in range(40)]:
         why = KNOWN_CHAOTIC.get((s, noise))
         cases.append(pytest.param(s, noise, marks=pytest.mark.xfail(strict=True, reason=why)) if why else pytest.param(s, noise))
     return cases

@@ -419,6 +419,43 @@ def test_specialised_kernel_source_of_p1_and_p3(S):
     assert e.value.code == S.ERR_UNSUPPORTED
 
 
+def test_specialised_kernel_versions_oscillators_with_a_bounded_cv(S):
+    """What render_fm_pair proves by hand the generator derives for any program: an oscillator whose pitch CV is a bounded value — a sine
+    through a gain, here P2's two operators — gets the per-wave vote and a copy of the sample loop per class (jit.cpp, analyze)."""
+    p = S.Patch(48000, 1, 2)
+    ids = S.build_p2(p)
+    p.configure_voices(128)
+    beta, index = S.p2_voice_params(128)
+    p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, beta)
+    p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
+    src = p.kernel_source(S.RENDER_NO_FUSION)
+    # both operators: |cv| <= 1 x |gain|; the modulator's bound rests on the z^-1 ring's stored value being a sine's too
+    assert "const float fm_b0 = (1.0f * __builtin_fabsf(m1_c));" in src and "const float fm_b1 = (1.0f * __builtin_fabsf(m4_c));" in src
+    assert "fm_lane = fm_lane && __builtin_fabsf(ring6) <= 1.0f;" in src and "m2.pos >= 0.0 && m2.pos < 1.0" in src and "m5.pos >= 0.0 && m5.pos < 1.0" in src
+    assert "auto fm_run = [&](auto fm_c0, auto fm_c1) {" in src and "| kFm0), m2, m2_k" in src and "| kFm1), m5, m5_k" in src
+    assert src.count("fm_run(UC<") == 10  # nothing proved + 3 x 3 classes
+    assert "m2_k.scale = (440.0 / m2_k.sr) * exp2(m2_k.val);" in src
+    assert "osc_step((0x10du | kFm0)" in src and "osc_step((0x110du | kFm1)" in src  # OSC_CV_AUDIO_RATE: no compare with the last CV; the carrier's loose sine
+    # exact mode proves nothing (bit-identical arithmetic), but an audio-rate CV is still not compared with the previous one
+    exact = p.kernel_source(S.RENDER_NO_FUSION | S.RENDER_EXACT_OSC)
+    assert "fm_run" not in exact and "osc_step(0x14du, m2" in exact
+    # the app's block size: the ring lives in HBM, whose contents no launch-time vote can vouch for — the modulator keeps the literal forms,
+    # and with it the carrier (a sine is only bounded by 1 while its phase provably stays in [0, 1))
+    q = S.Patch(48000, 1024, 2)
+    qi = S.build_p2(q)
+    q.configure_voices(128)
+    q.set_voice_field(qi["mul_fb"], S.MATH_CONSTANT, beta)
+    q.set_voice_field(qi["mul_idx"], S.MATH_CONSTANT, index)
+    ring = q.kernel_source(S.RENDER_NO_FUSION)
+    assert "fm_run" not in ring and "osc_step(0x10du, m2" in ring and "osc_step(0x110du, m5" in ring
+    # a sequencer's note is stepwise and of any size: no vote, the carried-phase oscillator as before
+    r = S.Patch(48000, 1024, 2)
+    ri = S.build_p3(r)
+    r.configure_voices(70)
+    r.set_voice_field(ri["transpose"], S.MATH_CONSTANT, np.linspace(-1, 0, 70).astype(np.float32))
+    assert "fm_run" not in r.kernel_source(0)
+
+
 @pytest.mark.skipif(not _have_hiprtc(), reason="no libhiprtc on this host")
 def test_specialised_kernels_compile_for_gfx950(S):
     """hiprtc cross-compiles without a GPU: the generated source of the BASELINE patches and of a few random ones (rings of every
@@ -451,3 +488,84 @@ def test_specialised_kernels_compile_for_gfx950(S):
         except S.SrackError as e:
             assert e.code == S.ERR_UNSUPPORTED, str(e)[:2000]
     assert n >= 9
+
+
+# ---- the cache of specialised kernels (jit.cpp): memory (bounded) over disk (persistent) over hiprtc -----------------------------------
+_CACHE_PROBE = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["SRACK_ROOT"])
+import numpy as np
+import srack_pkg
+S = srack_pkg.load()
+def chain(ops):   # oscillator -> one Math module per entry of `ops` -> output: the op sequence IS the program's structure
+    p = S.Patch(48000, 64, 2)
+    o = p.add_module(S.MOD_OSCILLATOR)
+    prev = o
+    for k in ops:
+        m = p.add_module(S.MOD_MATH)
+        p.set_field(m, S.MATH_OPERATION, k)
+        p.connect(prev, 2 if prev == o else 0, m, 0)
+        prev = m
+    out = p.add_module(S.MOD_OUTPUT)
+    p.connect(prev, 2 if prev == o else 0, out, 0)
+    p.configure_voices(64)
+    p.set_voice_field(o, S.OSC_VAL, np.linspace(-1, 1, 64).astype(np.float32))
+    return p
+for spec in json.loads(os.environ["SRACK_PROBE_SPECS"]):
+    chain(spec).kernel_compile(S.RENDER_NO_FUSION)
+print(json.dumps(S.kernel_cache_stats()))
+"""
+
+
+def _cache_probe(specs, cache_dir, extra_env=None, wait=True):
+    import json, subprocess, sys
+    env = dict(os.environ, SRACK_ROOT=ROOT, SRACK_PROBE_SPECS=json.dumps(specs), SRACK_KERNEL_CACHE_DIR=str(cache_dir), **(extra_env or {}))
+    pr = subprocess.Popen([sys.executable, "-c", _CACHE_PROBE], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if not wait:
+        return pr
+    out, err = pr.communicate(timeout=600)
+    assert pr.returncode == 0, err[-3000:]
+    return json.loads(out.strip().splitlines()[-1])
+
+
+@pytest.mark.skipif(not _have_hiprtc(), reason="no libhiprtc on this host")
+def test_kernel_cache_persists_across_processes(tmp_path):
+    """The second start of a host finds its kernels on disk: no hiprtc call.  The key is the program's structure — parameter values
+    and the voice count do not enter —, the architecture, the hiprtc version and the device headers this library embeds."""
+    first = _cache_probe([[0], [1, 2]], tmp_path)
+    assert first["compiled"] == 2 and first["disk_hits"] == 0 and first["directory"] == str(tmp_path) and first["compile_ms"] > 0
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 2 and not [f for f in os.listdir(tmp_path) if f.endswith(".lock")]
+    second = _cache_probe([[0], [1, 2], [0]], tmp_path)
+    assert second["compiled"] == 0 and second["disk_hits"] == 2 and second["memory_hits"] == 1
+    # a damaged file is not trusted: recompiled and rewritten
+    victim = sorted(f for f in os.listdir(tmp_path) if f.endswith(".hsaco"))[0]
+    with open(os.path.join(tmp_path, victim), "r+b") as f:
+        f.seek(200)
+        f.write(b"\x00garbage\x00")
+    third = _cache_probe([[0], [1, 2]], tmp_path)
+    assert third["compiled"] == 1 and third["disk_hits"] == 1
+    off = _cache_probe([[0]], "off")
+    assert off["compiled"] == 1 and off["directory"] == ""
+
+
+@pytest.mark.skipif(not _have_hiprtc(), reason="no libhiprtc on this host")
+def test_kernel_cache_is_bounded_in_memory(tmp_path):
+    """A long-running host that keeps re-patching: the process keeps the last SRACK_KERNEL_CACHE_MAX structures, not all of them."""
+    specs = [[a, b] for a in range(3) for b in range(3)] + [[0, 0]]   # nine structures, then the first again
+    st = _cache_probe(specs, "off", {"SRACK_KERNEL_CACHE_MAX": "4"})
+    assert st["resident_code_objects"] == 4 and st["code_evictions"] == 6 and st["compiled"] == 10  # [0, 0] had been evicted: compiled again
+    st = _cache_probe(specs, tmp_path, {"SRACK_KERNEL_CACHE_MAX": "4"})
+    assert st["resident_code_objects"] == 4 and st["compiled"] == 9 and st["disk_hits"] == 1          # ... or fetched from the disk level
+
+
+@pytest.mark.skipif(not _have_hiprtc(), reason="no libhiprtc on this host")
+def test_ranks_starting_together_compile_once(tmp_path):
+    """Every rank of a multi-GPU job needs the same kernel at the same moment: one compiles (a per-kernel file lock), the others read."""
+    import json
+    procs = [_cache_probe([[2, 1, 0, 2]], tmp_path, wait=False) for _ in range(3)]
+    stats = []
+    for pr in procs:
+        out, err = pr.communicate(timeout=600)
+        assert pr.returncode == 0, err[-3000:]
+        stats.append(json.loads(out.strip().splitlines()[-1]))
+    assert sum(s["compiled"] for s in stats) == 1 and sum(s["disk_hits"] for s in stats) == 2
