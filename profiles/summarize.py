@@ -168,8 +168,10 @@ def main():
             if line["roofline"]["kernel_ms"] > 0 and abs(tr["dominant_launches_per_step"] - line["roofline"]["launches_per_step"]) < 0.5:
                 rel = tr["dominant_mean_ms"] / line["roofline"]["kernel_ms"] - 1.0
                 tr["trace_vs_hip_events"] = rel
-                check("rocprof mean duration of the dominant kernel vs HIP events of the same run, within 2 %", abs(rel) <= 0.02,
-                      f'{tr["dominant_mean_ms"]:.4f} ms vs {line["roofline"]["kernel_ms"]:.4f} ms ({rel:+.2%})')
+                # (an event pair brackets the dispatch, launch latency included: a few microseconds, which is more than 2 % of a 0.2 ms kernel)
+                gap_us = (line["roofline"]["kernel_ms"] - tr["dominant_mean_ms"]) * 1e3
+                check("rocprof mean duration of the dominant kernel vs HIP events of the same run, within 2 % (or 8 us of launch latency)",
+                      abs(rel) <= 0.02 or 0.0 <= gap_us <= 8.0, f'{tr["dominant_mean_ms"]:.4f} ms vs {line["roofline"]["kernel_ms"]:.4f} ms ({rel:+.2%}, {gap_us:+.1f} us)')
             with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
                 w = csv.writer(f)
                 w.writerow(["Kernel [grid]", "LaunchesPerStep", "MedianMs", "MeanMs", "MinMs", "MaxMs", "SumMsPerStep"])

@@ -837,7 +837,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         roles.osc_a = 5;
         roles.out = 6;
         roles.track = P.ops[0].aux;  // the ring's state row
-        d->kernel_name = P.fused_variant == 1 ? "render_fm_pair_ring" : "render_fm_pair";
+        if (!special) d->kernel_name = P.fused_variant == 1 ? "render_fm_pair_ring" : "render_fm_pair";
     }
     for (uint32_t k = 0; k < n_chunks; k++) {
         const uint32_t t_off = chunks[k].first, len = chunks[k].second;
