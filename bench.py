@@ -61,7 +61,11 @@ F64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
 FM_PAIR_F64_OPS = {"render_fm_pair": 48, "render_fm_pair_ring": 48,
                    # config 4 through the kernel specialised at run time (the default since round 3): the generator's vote picks the same loop —
                    # modulator small, carrier (2^(cv/4))^4 — and tools/disasm_jit.py p2 counts the same 384 f64-rate instructions per 8 samples
-                   "render_specialized": 48}
+                   "render_specialized": 48,
+                   # the time-parallel pair (buffer_size 256 ... 1024): 809 f64-rate instructions per 16 samples and lane in the copy config 4's draw
+                   # takes (tools/disasm.sh ... render_fm_pair_block: 538 between the two barriers of a chunk, 271 after) — the same polynomials, two
+                   # additions and a fract per phase instead of one and one, the slice scan, less the carrier sine's f64 fold
+                   "render_fm_pair_block": 50.6}
 F64_LANE_OPS_MEASURED = 33.3e12
 
 WORKLOADS = ("cfg3", "cfg2", "cfg4", "cfg4_b1024", "p3", "p4")

@@ -1090,6 +1090,356 @@ __global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRol
     }
 }
 
+// ---- the same FM pair, TIME-PARALLEL: buffer_size 256 ... 1024, the ring in LDS (round 3) ----------------------------------------------
+// With a delay of B samples the modulator's pitch CV for the next B samples is already in the ring: beta * sine[t - B].  So for a
+// chunk of L <= B samples every modulator increment is known up front, and the modulator's phase at sample i is a PREFIX SUM of
+// increments (mod 1) instead of a recurrence: pos[i] = frac(pos[0] + sum_{j<i} delta[j]).  Its sines then follow independently,
+// the carrier's increments from them, the carrier's phases by a second prefix sum.  Nothing in a chunk waits for its own past.
+//   * One workgroup of 512 threads owns 32 voices for the whole launch: lane (g, s) = voice g of the 32, time slice s of 16.  A chunk
+//     is 256 samples; slice s holds samples [16 s, 16 s + 16) of it: 16 increments in registers, a local prefix, the 16 slice totals
+//     exchanged through LDS (two barriers per chunk), every lane adds the totals below its own.
+//   * 2048 workgroups x 8 waves instead of 1024 lone waves: two waves per SIMD, each with 16 independent evaluations of 2^x and of
+//     the sine in flight — the z^-1 kernel's one wave per SIMD is bound by the latency of its own dependency chains (NOTES.md section 4).
+//   * The ring ([B][32] f32 = 128 KB at the app's buffer_size 1024) lives in LDS for the whole launch: loaded from HBM once, stored back
+//     once.  render_fm_pair_ring reads and writes it in HBM every sample (8 B per voice-sample: 3.0 x the algorithmic bytes); here the
+//     launch is the whole render segment and the ring costs 8 B per voice and B samples of it.
+//   * Frames leave as 128-byte rows per (sample, workgroup): a wave stores two of them per instruction (its two slices).
+//   * Arithmetic: the proved per-oscillator loops of render_fm_pair (modules.hip.h, fm_class_flags: scale * 2^cv with val folded, no
+//     range reduction for |cv| <= 1/2, (2^(cv/4))^4 for |cv| <= 2, one-instruction wrap), voted per workgroup and launch; the literal
+//     forms otherwise.  Default mode only: a prefix sum associates differently from the reference's recurrence — 1e-16 in a phase, nine
+//     orders below the contract, but not bit-identical, and a render split between calls sums in other groups than an unsplit one.
+// Reference: oscillator.rs:43-48,132-153 (the two oscillators), math.rs:152 (the two gains), synth.rs:164-192 (which edge is delayed).
+constexpr int kBlkVoices = 32, kBlkSlices = 16, kBlkPer = 16, kBlkChunk = kBlkSlices * kBlkPer;  // 256 samples per chunk
+SRK_DEV size_t fm_block_lds_bytes(uint32_t B) { return sizeof(float) * B * kBlkVoices + sizeof(double) * 2 * kBlkSlices * kBlkVoices + 16; }
+
+// The polynomials' coefficients as REGISTERS.  A VOP3 f64 fma cannot take a 64-bit literal, and with sixteen evaluations in flight the
+// compiler rematerialised every coefficient at every use (s_mov + v_mov: a fifth of the chunk's instructions).  Loaded once per launch and
+// made opaque, they stay where they are; the operations are exp2_fast's and sine_fast's own (modules.hip.h), bit for bit.
+struct BlkConsts {
+    double e[9];  // 2^f, degree 8
+    double q[7];  // sin(2 pi x) / x in x^2, degree 6
+};
+SRK_DEV void blk_consts_load(BlkConsts& K)
+{
+    const double e[9] = {1.0000000000000004, 0.6931471805459332, 0.24022650695814518, 0.055504109412108156, 0.009618129159053034,
+                         0.0013333450563173552, 0.00015403456082633648, 1.5310080611926545e-05, 1.3255179556479267e-06};
+    const double q[7] = {6.283185307179272, -41.34170223990684, 81.60524914955879, -76.70584757807868, 42.05813586028645, -15.081496425342264, 3.6659216216293173};
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        K.e[i] = e[i];
+        asm volatile("" : "+v"(K.e[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        K.q[i] = q[i];
+        asm volatile("" : "+v"(K.q[i]));
+    }
+}
+template <bool kReduce>
+SRK_DEV double blk_exp2(const BlkConsts& K, double x)  // == dev::exp2_fast<kReduce>(x)
+{
+    const double n = kReduce ? __builtin_rint(x) : 0.0;
+    const double f = kReduce ? x - n : x;
+    const double f2 = f * f;
+    const double a01 = __builtin_fma(K.e[1], f, K.e[0]);
+    const double a23 = __builtin_fma(K.e[3], f, K.e[2]);
+    const double a45 = __builtin_fma(K.e[5], f, K.e[4]);
+    const double a67 = __builtin_fma(K.e[7], f, K.e[6]);
+    const double f4 = f2 * f2;
+    const double b0 = __builtin_fma(a23, f2, a01);
+    const double b1 = __builtin_fma(a67, f2, a45);
+    const double b2 = __builtin_fma(K.e[8], f4, b1);
+    const double p = __builtin_fma(b2, f4, b0);
+    return kReduce ? __builtin_ldexp(p, (int)n) : p;
+}
+SRK_DEV float blk_sine(const BlkConsts& K, double pos)  // == dev::sine_fast(pos)
+{
+    uint32_t sign;
+    const double x = dev::sine_fold(pos, sign);
+    const double z = x * x;
+    const double a01 = __builtin_fma(K.q[1], z, K.q[0]);
+    const double a23 = __builtin_fma(K.q[3], z, K.q[2]);
+    const double a45 = __builtin_fma(K.q[5], z, K.q[4]);
+    const double z2 = z * z;
+    const double b0 = __builtin_fma(a23, z2, a01);
+    const double b1 = __builtin_fma(K.q[6], z2, a45);
+    const double z4 = z2 * z2;
+    const double p = __builtin_fma(b1, z4, b0);
+    return __uint_as_float(__float_as_uint((float)(p * x)) ^ sign);
+}
+// The carrier's sine — it only feeds the OutputModule (the matched shape), nothing integrates it — folded in f32: the phase's 6e-8 of
+// f32 rounding is 4e-7 of sine, beside the polynomial's 2e-7 (sine_loose folds in f64: three f64-rate instructions more per sample).
+SRK_DEV float blk_sine_loose(double pos)
+{
+    const float qn = 0.5f - (float)pos;
+    const uint32_t sign = __float_as_uint(qn) & 0x80000000u;
+    const float x = 0.25f - __builtin_fabsf(__builtin_fabsf(qn) - 0.25f);
+    const float z = x * x;
+    const float a01 = __builtin_fmaf(-41.34168243408203f, z, 6.2831854820251465f);
+    const float a23 = __builtin_fmaf(-76.58116912841797f, z, 81.60247802734375f);
+    const float z2 = z * z;
+    const float p = __builtin_fmaf(__builtin_fmaf(39.75982666015625f, z2, a23), z2, a01);
+    return __uint_as_float(__float_as_uint(p * x) ^ sign);
+}
+// the phase increment of one sample, as osc_step spells it for the proved flags (default mode)
+template <uint32_t kFlags>
+SRK_DEV double fm_increment(const BlkConsts& K, const dev::OscConst& c, float cv)
+{
+    static_assert((kFlags & OSC_VAL_FOLDED) != 0, "the time-parallel pair runs proved loops only");
+    double p;
+    if (kFlags & OSC_CV_QUAD) {
+        p = blk_exp2<false>(K, (double)(cv * 0.25f));
+        p = p * p;
+        p = p * p;
+    } else {
+        p = (kFlags & OSC_CV_SMALL) ? blk_exp2<false>(K, (double)cv) : blk_exp2<true>(K, (double)cv);
+    }
+    return c.scale * p;
+}
+// lane i's value from lane i ^ kMask of its row of 16, through the DPP network (no LDS crossbar): the masks a halving butterfly over 16
+// lanes can use are 1 and 2 (quad permutes), 7 (row_half_mirror: i <-> 7 - i) and 15 (row_mirror: i <-> 15 - i) — together they span the row
+template <int kMask>
+SRK_DEV float row_xchg(float v)
+{
+    constexpr int ctrl = kMask == 1 ? 0xB1 : kMask == 2 ? 0x4E : kMask == 7 ? 0x141 : 0x140;
+    static_assert(kMask == 1 || kMask == 2 || kMask == 7 || kMask == 15, "not a single DPP control");
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false));
+}
+
+// (two waves per SIMD is all the LDS allows — one workgroup per CU —, so the kernel may as well use their 256 registers each: the
+// sixteen evaluations per lane and the polynomials' constants stay in registers instead of being rematerialised)
+template <int kOut>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void render_fm_pair_block(KernelArgs a, ChainRoles r)
+{
+    using namespace dev;
+    extern __shared__ __attribute__((aligned(16))) float blk_lds[];
+    const uint32_t B = (uint32_t)a.prog.buffer_size, V = a.V;
+    float* const ring_l = blk_lds;                                                   // [B][32]
+    double* const sums = (double*)(blk_lds + (size_t)B * kBlkVoices);                 // [2][16][32]: per oscillator, per slice, per voice
+    uint32_t* const flag = (uint32_t*)(sums + 2 * kBlkSlices * kBlkVoices);
+    const int tid = (int)threadIdx.x, g = tid & 31, s = tid >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave holds slices 2 w and 2 w + 1 of all 32 voices
+    const bool odd = (s & 1) != 0;
+    const uint32_t voice0 = (blockIdx.x - a.block0) * (uint32_t)kBlkVoices;
+    const uint32_t n_act = min((uint32_t)kBlkVoices, V - voice0);
+    const bool active = (uint32_t)g < n_act;
+    const uint32_t voice = voice0 + (uint32_t)g, vc = active ? voice : voice0 + n_act - 1u;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+
+    const DevOp& ofb = a.ops[r.adsr];    // roles as in render_fm_pair_ring
+    const DevOp& om = a.ops[r.osc_l];
+    const DevOp& oix = a.ops[r.vca];
+    const DevOp& ocr = a.ops[r.osc_a];
+    const int plane = a.ops[r.out].aux;
+    float* const ring = a.rings + (size_t)r.track * B * V;
+
+    constexpr uint32_t fo = OSC_HAS_CV | OSC_CV_AUDIO_RATE | OSC_AA | OSC_OUT_SINE;
+    constexpr uint32_t fo_carrier = fo | OSC_SINE_LOOSE;
+    OscConst km, kc;
+    double pos_m = make_f64(row(om.state_row + OSC_S_POS_LO), row(om.state_row + OSC_S_POS_HI));
+    double pos_c = make_f64(row(ocr.state_row + OSC_S_POS_LO), row(ocr.state_row + OSC_S_POS_HI));
+    km.sr = om.sample_rate;
+    km.val = (double)parv(om, OSC_P_VAL);
+    km.delta = 0.0;
+    km.inv_dt = 0.0f;
+    kc = km;
+    kc.sr = ocr.sample_rate;
+    kc.val = (double)parv(ocr, OSC_P_VAL);
+    km.scale = (440.0 / km.sr) * exp2(km.val);
+    kc.scale = (440.0 / kc.sr) * exp2(kc.val);
+    const float c_fb = parv(ofb, MATH_P_CONST), c_ix = parv(oix, MATH_P_CONST);
+    BlkConsts K;
+    blk_consts_load(K);
+
+    // the ring: HBM -> LDS, looking at every value on the way (the host's may be anything; a sine is at most 1)
+    if (tid == 0) *flag = 0u;
+    __syncthreads();
+    bool unit = true;
+    for (uint32_t p = (uint32_t)s; p < B; p += (uint32_t)kBlkSlices) {
+        const float x = ring[(size_t)p * V + vc];
+        ring_l[p * kBlkVoices + (uint32_t)g] = x;
+        unit = unit && __builtin_fabsf(x) <= 1.0f;
+    }
+    if (!unit) atomicOr(flag, 1u);
+    __syncthreads();
+    // every wave holds all 32 voices (two slices of each): its ballots speak for the workgroup
+    const FmFacts facts = fm_facts(c_fb, km, pos_m, c_ix, kc, pos_c);
+    // A prefix sum adds a chunk's increments BEFORE it wraps: fine while they are of ordinary size (256 x 2^20 cycles still leaves 2^-24 of
+    // a cycle), wrong for the huge ones a gain of hundreds of octaves produces — the recurrence wraps after every step and carries on from
+    // the fraction, a sum would swallow every later increment.  A workgroup with such a voice (or with host values above 1 in its ring, or
+    // a phase outside [0, 1)) renders through the recurrence itself, below: one lane per voice, the literal forms, as render_fm_pair_ring.
+    const double biggest = __builtin_fmax(km.scale * exp2((double)__builtin_fabsf(c_fb)), kc.scale * exp2((double)__builtin_fabsf(c_ix)));
+    const bool sane = facts.tame && *flag == 0u && __builtin_amdgcn_ballot_w64(!(biggest <= 1048576.0)) == 0;
+    uint32_t p0 = (uint32_t)(a.n0 % B);
+    const uint32_t i0 = (uint32_t)s * (uint32_t)kBlkPer;  // this lane's first sample of a chunk
+    float* const frame_base = a.frames ? a.frames + (size_t)plane * a.plane_stride + voice0 : nullptr;
+    float* const mp = a.mixpart ? a.mixpart + ((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride : nullptr;
+    const bool frames = kOut == 0 ? frame_base != nullptr : (kOut & 1) != 0;
+    const bool mix = kOut == 0 ? mp != nullptr : (kOut & 2) != 0;
+
+    // Where a lane's slice starts: the phase at the chunk's first sample + the totals of the slices below it.  The 16 slice totals of a
+    // voice sit in 8 waves, two per wave: each wave leaves one total per voice (its two slices') in LDS, a lane adds the waves below
+    // its own — a wave-uniform count: scalar branches, no selects — and the odd slice its even neighbour's, 32 lanes away.
+    auto slice_base = [&](int osc, double mine, double start, double& base, double& total) {
+        const double pair = mine + __shfl_xor(mine, 32);
+        if (!odd) sums[(osc * 8 + w) * kBlkVoices + g] = pair;
+        __syncthreads();
+        base = start;
+        total = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < 8; w2++) {
+            const double v = sums[(osc * 8 + w2) * kBlkVoices + g];
+            total += v;
+            if (w2 < w) base += v;
+        }
+        if (odd) base += pair - mine;  // (the even neighbour's total; exact enough: the same additions in another order are not bit-identical anyway)
+    };
+
+    auto run = [&](auto fm_c, auto fc_c) {
+        constexpr uint32_t FM = decltype(fm_c)::value, FC = decltype(fc_c)::value;
+        auto chunk = [&](uint32_t t0, uint32_t n, auto fast_c) {
+            // kFast: all 256 samples are the render's, every slice's 16 ring rows are contiguous (no wrap inside a slice: the ring's position
+            // and length are multiples of 16) and all 32 voices are real — no masks, no selects, ring addresses as instruction offsets
+            constexpr bool kFast = decltype(fast_c)::value;
+            uint32_t idx[kBlkPer];
+            double pre[kBlkPer];
+            // ---- modulator: increments from what the ring holds, local prefix ----
+            double acc = 0.0;
+            if (kFast) {
+                uint32_t p = p0 + i0;
+                p = p >= B ? p - B : p;
+                const uint32_t first = p * (uint32_t)kBlkVoices + (uint32_t)g;
+#pragma unroll
+                for (int k = 0; k < kBlkPer; k++) idx[k] = first + (uint32_t)(k * kBlkVoices);
+            } else {
+#pragma unroll
+                for (int k = 0; k < kBlkPer; k++) {
+                    uint32_t p = p0 + i0 + (uint32_t)k;
+                    p = p >= B ? p - B : p;
+                    idx[k] = p * (uint32_t)kBlkVoices + (uint32_t)g;
+                }
+            }
+            float fed[kBlkPer];
+#pragma unroll
+            for (int k = 0; k < kBlkPer; k++) fed[k] = ring_l[idx[k]];
+#pragma unroll
+            for (int k = 0; k < kBlkPer; k++) {
+                double d = fm_increment<FM>(K, km, fed[k] * c_fb);
+                if (!kFast) {
+                    asm("" : "+v"(d));  // (computed in every lane: a select, not sixteen branches that would fence the evaluations off from each other)
+                    d = i0 + (uint32_t)k < n ? d : 0.0;
+                }
+                pre[k] = acc;
+                acc += d;
+            }
+            double base, total;
+            slice_base(0, acc, pos_m, base, total);
+            pos_m = __builtin_amdgcn_fract(pos_m + total);
+            // ---- modulator sines -> ring; carrier increments, local prefix ----
+            acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < kBlkPer; k++) {
+                const double pm = __builtin_amdgcn_fract(base + pre[k]);
+                const float sine = blk_sine(K, pm);
+                double d = fm_increment<FC>(K, kc, sine * c_ix);
+                if (kFast) {
+                    ring_l[idx[k]] = sine;
+                } else {
+                    asm("" : "+v"(d));
+                    const bool live = i0 + (uint32_t)k < n;
+                    if (live) ring_l[idx[k]] = sine;
+                    d = live ? d : 0.0;
+                }
+                pre[k] = acc;
+                acc += d;
+            }
+            slice_base(1, acc, pos_c, base, total);
+            pos_c = __builtin_amdgcn_fract(pos_c + total);
+            // ---- carrier sines: frames and the workgroup's mix partial ----
+            float out[kBlkPer];
+#pragma unroll
+            for (int k = 0; k < kBlkPer; k++) out[k] = blk_sine_loose(__builtin_amdgcn_fract(base + pre[k]));
+            if (frames && (kFast || active)) {
+                // one descriptor per wave and chunk: its two slices' first rows; lane offset = voice (+ 16 rows for the odd slice), scalar offset = row k
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(frame_base + (size_t)(t0 + (uint32_t)w * 2u * (uint32_t)kBlkPer) * V, 0, 0x7fffffff, 0x00020000);
+                const uint32_t voff = ((uint32_t)g + (odd ? (uint32_t)kBlkPer * V : 0u)) * 4u;
+#pragma unroll
+                for (int k = 0; k < kBlkPer; k++)
+                    if (kFast || i0 + (uint32_t)k < n) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[k]), rsrc, (int)voff, (int)((uint32_t)k * V * 4u), SRK_FRAME_AUX);
+            }
+            if (mix) {
+                // sum over the 32 voices of each of this slice's 16 samples: a halving butterfly — 16 -> 8 -> 4 -> 2 -> 1 values per lane
+                // while the lanes pair up (i ^ 15, i ^ 7, i ^ 2, i ^ 1: single DPP controls) — then the two rows of 16 lanes: lane g ends with sample (g & 15)
+                float v[kBlkPer];
+#pragma unroll
+                for (int k = 0; k < kBlkPer; k++) v[k] = (kFast || active) ? out[k] : 0.0f;
+                auto halve = [&](auto mask_c, int bit, int h) {  // lanes i and i ^ mask share the work: the one with `bit` set keeps the upper half
+                    const bool up = (g & bit) != 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (j < h) {
+                            const float send = up ? v[j] : v[j + h], keep = up ? v[j + h] : v[j];
+                            v[j] = keep + row_xchg<decltype(mask_c)::value>(send);
+                        }
+                };
+                halve(std::integral_constant<int, 15>{}, 8, 8);
+                halve(std::integral_constant<int, 7>{}, 4, 4);
+                halve(std::integral_constant<int, 2>{}, 2, 2);
+                halve(std::integral_constant<int, 1>{}, 1, 1);
+                const float sum = v[0] + __shfl_xor(v[0], 16);
+                if (g < kBlkPer && (kFast || i0 + (uint32_t)g < n)) mp[t0 + i0 + (uint32_t)g] = sum;
+            }
+            p0 += n;
+            p0 = p0 >= B ? p0 - B : p0;
+        };
+        const bool fast = (B % (uint32_t)kBlkPer) == 0u && (p0 % (uint32_t)kBlkPer) == 0u && n_act == (uint32_t)kBlkVoices;  // (uniform; p0 stays a multiple of 16 over full chunks)
+        uint32_t t0 = 0;
+        if (fast)
+            for (; t0 + (uint32_t)kBlkChunk <= a.T; t0 += (uint32_t)kBlkChunk) chunk(t0, (uint32_t)kBlkChunk, std::true_type{});
+        for (; t0 < a.T; t0 += (uint32_t)kBlkChunk) chunk(t0, min((uint32_t)kBlkChunk, a.T - t0), std::false_type{});
+    };
+    if (sane) {
+        fm_proved_tile<fo, fo_carrier>(facts, [&](auto m, auto c) { run(m, c); });
+    } else if (s == 0) {  // the recurrence, sample by sample, one lane per voice (the other fifteen slices have nothing to do in this launch)
+        OscRegs sm, sc;
+        sm.pos = pos_m;
+        sc.pos = pos_c;
+        sm.sync_last = sc.sync_last = false;
+        float sq = 0.0f, sw = 0.0f;
+        for (uint32_t t = 0; t < a.T; t++) {
+            const uint32_t at = p0 * (uint32_t)kBlkVoices + (uint32_t)g;
+            float sine_m = 0.0f, out = 0.0f;
+            osc_step(fo, sm, km, ring_l[at] * c_fb, 0.0f, sine_m, sq, sw);
+            ring_l[at] = sine_m;
+            osc_step(fo_carrier, sc, kc, sine_m * c_ix, 0.0f, out, sq, sw);
+            if (frames && active) frame_base[(size_t)t * V + (uint32_t)g] = out;
+            if (mix) {
+                float v = active ? out : 0.0f;
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+                if (g == 0) mp[t] = v;
+            }
+            p0 = p0 + 1u == B ? 0u : p0 + 1u;
+        }
+        pos_m = sm.pos;
+        pos_c = sc.pos;
+    }
+    __syncthreads();  // the last chunk's ring writes
+    if (active) {
+        for (uint32_t p = (uint32_t)s; p < B; p += (uint32_t)kBlkSlices) ring[(size_t)p * V + voice] = ring_l[p * kBlkVoices + (uint32_t)g];
+        if (s == 0) {
+            auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+            put(om.state_row + OSC_S_POS_LO, f64_lo(pos_m));
+            put(om.state_row + OSC_S_POS_HI, f64_hi(pos_m));
+            put(om.state_row + OSC_S_SYNC_LAST, 0u);
+            put(ocr.state_row + OSC_S_POS_LO, f64_lo(pos_c));
+            put(ocr.state_row + OSC_S_POS_HI, f64_hi(pos_c));
+            put(ocr.state_row + OSC_S_SYNC_LAST, 0u);
+        }
+    }
+}
+
 // ---- mix-down, passes 2 and 3: mix[c][i] = sum over waves of mixpart[plane(c)][w][i] ---------------------------
 // Deterministic (fixed order, no atomics).  Pass 2 splits the waves into kMixSplit groups so that enough loads
 // are in flight to stream the partials at HBM rate: block (x, y) sums group y for 256 consecutive samples into

@@ -53,6 +53,8 @@ struct Knobs {
     int high_prio_ctl = 1;       // the control stream is created with the highest priority (its own pool of hardware queues)
     int special_ctl = 1;         // specialised kernels carry the control program's units (0: control program on its own stream)
     int fm_split = 1;            // exact mode: the z^-1 FM pair on two waves per 64 voices (modulators / carriers); 0: one wave does both
+    int fm_block = 1;            // default mode, buffer_size 256 ... 1024: the time-parallel FM pair with its ring in LDS; 0: render_fm_pair_ring
+    uint32_t fm_block_chunk = 65536;  // ... its launch length: the ring is loaded and stored once per launch, so the whole segment by default
 };
 static const Knobs& knobs()
 {
@@ -73,6 +75,8 @@ static const Knobs& knobs()
         v.high_prio_ctl = (int)num("SRACK_CTL_HIGH_PRIO", 0, 1, 1);
         v.special_ctl = (int)num("SRACK_SPECIAL_CTL", 0, 1, 1);
         v.fm_split = (int)num("SRACK_FM_SPLIT", 0, 1, 1);
+        v.fm_block = (int)num("SRACK_FM_BLOCK", 0, 1, 1);
+        v.fm_block_chunk = (uint32_t)num("SRACK_FM_BLOCK_CHUNK", 256, 65536, 65536);
         return v;
     }();
     return k;
@@ -473,6 +477,38 @@ static void launch_fm_pair2(bool exact, int out_mode, const KernelArgs& ka, cons
 #undef SRK_FM
 }
 
+// The FM pair with a delay of 256 ... 1024 samples in default mode: time-parallel, 32 voices per 512-thread workgroup, ring in LDS.
+static bool fm_block_shape(const FlatProgram& P, uint32_t flags)
+{
+    return P.fused == FUSED_FM_PAIR && P.fused_variant == 1 && !(flags & (SRACK_RENDER_EXACT_OSC | SRACK_RENDER_NO_FUSION)) && knobs().fm_block &&
+           P.hdr.buffer_size >= kBlkChunk && P.hdr.buffer_size <= 1024;
+}
+
+static int launch_fm_block(int out_mode, const KernelArgs& ka, const ChainRoles& roles, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * (size_t)ka.prog.buffer_size * kBlkVoices + sizeof(double) * 2 * kBlkSlices * kBlkVoices + 16;
+    const dim3 grid(ka.n_waves), block(kBlkVoices * kBlkSlices);
+#define SRK_BLK(O)                                                                                                              \
+    do {                                                                                                                        \
+        static bool raised = false; /* more than 64 KB of dynamic LDS has to be asked for, once per kernel */                  \
+        if (!raised) {                                                                                                          \
+            HIP_TRY(hipFuncSetAttribute((const void*)render_fm_pair_block<O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            raised = true;                                                                                                      \
+        }                                                                                                                       \
+        hipLaunchKernelGGL((render_fm_pair_block<O>), grid, block, lds, st, ka, roles);                                         \
+    } while (0)
+    if (out_mode == 3)
+        SRK_BLK(3);
+    else if (out_mode == 1)
+        SRK_BLK(1);
+    else if (out_mode == 2)
+        SRK_BLK(2);
+    else
+        SRK_BLK(0);
+#undef SRK_BLK
+    return SRACK_OK;
+}
+
 static void launch_fm_pair(bool ring, bool exact, int out_mode, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
 {
     if (ring)
@@ -602,7 +638,8 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     // With few voices, half- or quarter-filled waves double / quadruple the number of waves: a VALU instruction
     // costs the same for 16 lanes as for 64, so this only pays while SIMDs would otherwise sit idle (VALU-bound
     // kernels: up to one wave per SIMD) or while waves are latency-bound (FM pair, interpreter: up to four).
-    const uint32_t lanes = lanes_per_wave(V);
+    const bool fm_block = fm_block_shape(P, flags);  // 32 voices per workgroup, whatever the voice count
+    const uint32_t lanes = fm_block ? (uint32_t)kBlkVoices : lanes_per_wave(V);
     const uint32_t n_waves = (V + lanes - 1) / lanes;
 
     if (P.hdr.n_planes == 0) {  // nothing reaches the output: silence (output.rs:55)
@@ -664,7 +701,8 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         // path: 7.36 - 7.46 ms per step at 4096, 7.26 - 7.28 at 2048, two rounds on one box).
         const bool fm_z1 = P.fused == FUSED_FM_PAIR && P.fused_variant == 0 && !(flags & (SRACK_RENDER_NO_FUSION | SRACK_RENDER_EXACT_OSC));
         const bool lone_waves = special && P.hdr.n_rings == 0 && n_waves <= 1024 && !(flags & SRACK_RENDER_EXACT_OSC);
-        const uint32_t len = (fm_z1 || lone_waves) ? std::min(kChunkMax, 2048u) : kChunkMax;
+        // (the time-parallel FM pair keeps its ring in LDS for a launch and moves it to and from HBM at the ends: one launch per segment)
+        const uint32_t len = fm_block ? knobs().fm_block_chunk : (fm_z1 || lone_waves) ? std::min(kChunkMax, 2048u) : kChunkMax;
         for (uint32_t t_off = 0; t_off < T; t_off += len) chunks.emplace_back(t_off, std::min(len, T - t_off));
     }
     const uint32_t n_chunks = (uint32_t)chunks.size();
@@ -837,7 +875,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         roles.osc_a = 5;
         roles.out = 6;
         roles.track = P.ops[0].aux;  // the ring's state row
-        if (!special) d->kernel_name = P.fused_variant == 1 ? "render_fm_pair_ring" : "render_fm_pair";
+        if (!special) d->kernel_name = fm_block ? "render_fm_pair_block" : P.fused_variant == 1 ? "render_fm_pair_ring" : "render_fm_pair";
     }
     for (uint32_t k = 0; k < n_chunks; k++) {
         const uint32_t t_off = chunks[k].first, len = chunks[k].second;
@@ -882,6 +920,8 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         } else if (seq_chain) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             launch_seq(seq_port, out_mode, ka, seq, dim3(n_waves), st);
+        } else if (fm_pair && fm_block) {
+            if ((rc = launch_fm_block((ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0), ka, roles, st)) != SRACK_OK) return rc;
         } else if (fm_pair) {
             const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
             launch_fm_pair(P.fused_variant == 1, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, ka, roles, dim3(n_waves), st);
@@ -953,7 +993,7 @@ int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t f
     DeviceState* d = h.dev;
     const FlatProgram& P = h.prog.voice;
     const uint32_t T = std::min(n_samples, 65536u);  // one segment
-    const uint32_t lanes = lanes_per_wave(P.n_voices), n_waves = (P.n_voices + lanes - 1) / lanes;
+    const uint32_t lanes = fm_block_shape(P, h.prog.effective_flags) ? (uint32_t)kBlkVoices : lanes_per_wave(P.n_voices), n_waves = (P.n_voices + lanes - 1) / lanes;
     if (want_mix && P.hdr.n_planes > 0) {
         if ((rc = grow(d->d_mixpart, d->mixpart_bytes, sizeof(float) * (size_t)P.hdr.n_planes * n_waves * T)) != SRACK_OK) return rc;
         if ((rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * T)) != SRACK_OK) return rc;

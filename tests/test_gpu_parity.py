@@ -247,7 +247,16 @@ def test_fm_pair_sample_loops(S, oracle, B, flags):
         p.set_voice_field(m, f, v)
     a = p.render_channels(1001, flags)
     b = p.render_channels(T - 1001, flags)
-    np.testing.assert_array_equal(bits(np.concatenate([a[0], b[0]])), bits(out[0]))
+    if "kernel=render_fm_pair_block" in p.info():
+        # the time-parallel pair (buffer_size 256 ... 1024, default mode): a phase is a prefix sum over 256-sample chunks counted from the
+        # launch's first sample, so a split render adds the same increments in other groups — 1e-16 in a phase, an occasional last bit of an
+        # f32 sample, never a different NaN
+        ab = np.concatenate([a[0], b[0]])
+        np.testing.assert_array_equal(np.isnan(ab), np.isnan(out[0]))
+        fin = ~np.isnan(ab)
+        assert np.abs(ab[fin].astype(np.float64) - out[0][fin]).max() <= 4e-7 and (bits(ab) != bits(out[0])).mean() < 1e-3
+    else:
+        np.testing.assert_array_equal(bits(np.concatenate([a[0], b[0]])), bits(out[0]))
 
 
 @pytest.mark.parametrize("B", [1, 1024])
@@ -489,7 +498,9 @@ def test_cfg3_exactly_as_benchmarked(S, oracle):
     assert (np.abs(mix[0].astype(np.float64) - own) <= 1e-5 * np.maximum(scale, 1.0)).all() and np.array_equal(mix[0], mix[1])
 
 
-@pytest.mark.parametrize("B,kernel", [(1, "render_fm_pair"), (1024, "render_fm_pair")])
+# (since round 3 the kernels bench.py times for this patch: buffer_size 1 — the kernel specialised at run time, whose generator derives
+# the bounded pitch CVs render_fm_pair proves by hand; buffer_size 1024 — the time-parallel pair with its ring in LDS)
+@pytest.mark.parametrize("B,kernel", [(1, "render_specialized"), (1024, "render_fm_pair_block")])
 def test_cfg4_exactly_as_benchmarked(S, oracle, B, kernel):
     """BASELINE config 4 at full size, the workload `bench.py --workload cfg4` (and cfg4_b1024) times: 65 536 voices x 48 000
     samples of the 2-operator FM patch with its feedback edge, per-voice feedback / index (12.6 GB of frames, kept on the device),

@@ -1,0 +1,21 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out/r3h
+mkdir -p $OUT
+export TMPDIR=/tmp
+( timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_srk.py -m gpu -q -k "fm or cfg4 or p2 or ring or keep_state" ) > $OUT/pytest_fm.log 2>&1; grep -E "passed|failed|Error|assert" $OUT/pytest_fm.log | tail -8 | cut -c1-300
+line() { python - "$1" "$2" <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d["roofline"]
+    print("   %-28s ms/step %.3f  kernel %s x%d %.4f ms" % (sys.argv[2], d["ms_per_step"], r["kernel"], r["launches_per_step"], r["kernel_ms"]))
+except Exception as e: print("   parse failed", sys.argv[1], e, open(sys.argv[1].replace('.json','.err')).read()[-600:])
+PY
+}
+run() { name=$1; args=$2; shift; shift; env "$@" timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu --workload cfg4_b1024 $args > $OUT/$name.json 2> $OUT/$name.err; line $OUT/$name.json $name; }
+for round in 1 2; do
+run ring "" SRACK_FM_BLOCK=0
+run block_full "" A=1
+run block_noframes "--no-frames" A=1
+run block_nomix "--no-mix" A=1
+done
