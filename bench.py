@@ -54,7 +54,7 @@ F64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
 # f64-rate VALU instructions per voice-sample in the loop body that render_fm_pair<false, 3> runs for BASELINE config 4's draw
 # (feedback gain 0.1 ... 0.4, index 0.5 ... 1.5: every wave proves "increments finite, modulator CV within 1/2, carrier CV within 2"
 # and takes the loop with val folded into a per-voice scale, no range reduction in the modulator's 2^x, (2^(cv/4))^4 in the carrier's and
-# one-instruction phase wraps): 48, counted in the gfx950 ISA (tools/disasm.sh; the mix is in DESIGN.md section 4.  The literal loop —
+# one-instruction phase wraps): 48, counted in the gfx950 ISA (tools/disasm.sh; the mix is in NOTES.md section 4.  The literal loop —
 # nothing proved — has 58, round 2's first kernel had 60).  tools/ubench.hip measures the pipe itself: v_fma_f64 saturates at
 # 33.3 T lane-ops/s on this part (8 waves per SIMD), and ONE wave per SIMD — all that 65 536 voices give — reaches 25-30 T with 4-8
 # independent chains.
@@ -490,7 +490,7 @@ def run_rank(args, backend_cls=HipBackend):
                 "name": args.workload, "voices_per_gpu": V, "samples_per_step": T, "buffer_size": getattr(be, "buffer_size", 1024),
                 "render_flags": args.flags, "backend": be.name,
                 "arithmetic": "f32 wires and modules; oscillator phase accumulator 64-bit: f64 as the reference, 2^-64 fixed point in the "
-                              "default-mode fused saw kernel (DESIGN.md section 3)",
+                              "default-mode fused saw kernel (DESIGN.md section 5)",
                 "frames_written": not args.no_frames, "mix_down": not args.no_mix, "program": info,
             },
             "roofline": {

@@ -1068,7 +1068,7 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             }
         }
         // A filter inside ANY feedback loop iterates its own rounding too: the fma-contracted ladder stays within 1e-5 of the reference while
-        // its differences die out (a damped recurrence, section 2 of DESIGN.md), not when a loop feeds them back in — through a mixer into
+        // its differences die out (a damped recurrence, section 2 of NOTES.md), not when a loop feeds them back in — through a mixer into
         // its own input, or through a gate that restarts a sample player (random patches of that kind left the band after a few thousand
         // samples).  Such a filter runs the literal ladder.
         for (int m = 0; m < n_mod; m++) {

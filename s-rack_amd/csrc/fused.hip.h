@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(64) void render_fm_pair_ring(KernelArgs a, ChainRol
         for (int i = 0; i < kMixRows; i++) dst[i] = ring[(size_t)ring_at(first + (uint32_t)i) * V + vc];
     };
     // With buffer_size >= 64 the NEXT tile's 32 values are older than this tile too: they are fetched while this tile computes
-    // (one wave per SIMD at 65 536 voices: nobody else hides the 32 loads' latency; the app's 1024: 12.7 -> see DESIGN section 4).
+    // (one wave per SIMD at 65 536 voices: nobody else hides the 32 loads' latency; the app's 1024: 12.7 -> see NOTES.md section 4).
     const bool ahead = B >= 2u * (uint32_t)kMixRows;
     float fed[kMixRows];
     load_tile(fed, p0);

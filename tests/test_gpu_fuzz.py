@@ -60,13 +60,13 @@ def test_random_patch_matches_oracle(seed, noise, oracle, monkeypatch):
 # the denominator).  Default arithmetic is 1e-7-accurate, not bit-identical: the f32 PolyBLEP, the fma-contracted ladder, the polynomial
 # 2^cv and sine.  A patch that ITERATES such a value — feedback through a pitch or a sync input, a sample-player read index that truncates
 # the other way, a ladder at resonance > 0.9 inside a loop — is chaotic: any 1e-7 grows without bound, and no implementation that is
-# not bit-identical to the host libm stays within 1e-5 on it.  Those patches are listed here, one line each, as
+# not bit-identical to the host libm stays within 1e-5 on it (NOTES.md section 2 has the soaks).  Those patches are listed here, one line each, as
 # strict xfails: if one starts passing, or another starts failing, the suite says so.
 DEFAULT_FLAGS = (0, 2, 4)          # fused / general path (interpreter at this size) / everything per voice
 DEFAULT_SPECIAL = 34               # the general path through a kernel specialised at run time (a compilation: every third seed)
 KNOWN_CHAOTIC = {
     # (seed, noise): reason — none of the pinned seeds (0 ... 159, the seven soak finds, 0 ... 39 of the noise family) is chaotic since the
-    # flattener gives producers that reach a pitch the exact PolyBLEP / the literal ladder; these three are what
+    # flattener gives producers that reach a pitch the exact PolyBLEP / the literal ladder (NOTES.md section 2 has the soaks); these three are what
     # tools/fuzz_soak_default.py finds in seeds 700 ... 759 and 1400 ... 1499 (480 renders, 9 outside the band, all three modes alike):
     (725, False): "feedback loop through a sync input: one sample's 1e-7 moves an edge, the phases part for good (also parts in exact mode under tools/fuzz_soak_cfg.py)",
     (1459, False): "filter <-> mixer loop with a per-voice mixer gain above 1 whose cutoff a square wave slams between two values: chaotic in one voice of 67",
