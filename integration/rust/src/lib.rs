@@ -17,6 +17,21 @@ pub struct SrackPatch {
 #[allow(non_camel_case_types)]
 mod ffi {
     use super::*;
+    /// `srack_kernel_cache_info` (include/srack_hip.h)
+    #[repr(C)]
+    pub struct SrackKernelCacheInfo {
+        pub compiled: u64,
+        pub disk_hits: u64,
+        pub memory_hits: u64,
+        pub modules_loaded: u64,
+        pub code_evictions: u64,
+        pub module_evictions: u64,
+        pub resident_code_objects: u64,
+        pub resident_modules: u64,
+        pub compile_ms: f64,
+        pub directory: [c_char; 512],
+    }
+
     extern "C" {
         pub fn srack_abi_version() -> c_int;
         pub fn srack_last_error() -> *const c_char;
@@ -43,6 +58,8 @@ mod ffi {
         pub fn srack_device_to_host(h_dst: *mut c_void, d_src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
         pub fn srack_device_set(device: c_int) -> c_int;
         pub fn srack_device_get(device: *mut c_int, pci_bus_id: *mut c_char, cap: usize) -> c_int;
+        pub fn srack_kernel_cache_set_dir(dir: *const c_char) -> c_int;
+        pub fn srack_kernel_cache_stats(out: *mut SrackKernelCacheInfo) -> c_int;
         pub fn srack_render_reserve(p: *mut SrackPatch, n_samples: u32, want_mix: c_int, flags: u32) -> c_int;
         pub fn srack_dist_unique_id(id_out: *mut u8) -> c_int;
         pub fn srack_dist_init(id: *const u8, n_ranks: c_int, rank: c_int, comm_out: *mut *mut c_void) -> c_int;
