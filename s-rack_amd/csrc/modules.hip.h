@@ -1067,6 +1067,20 @@ SRK_DEV float adsr_step(uint32_t flags, AdsrRegs& s, const AdsrConst& c, float g
     return out;
 }
 
+// What an envelope can reach, for the kernels that version an oscillator on a bound of its pitch CV (jit.cpp, analyze): every output is a
+// convex combination of values already in the hull of {0, 1, s_val, r_val, from_a_val} — Attack r + (1 - r) phase, Decay s + (1 - s)(1 -
+// phase), Sustain s, Release s (1 - phase), each with 0 <= phase < 1 — provided the three increments are not negative (a negative time
+// constant would run a phase below 0) and the stored phase is a phase.
+SRK_DEV float adsr_bound(const AdsrRegs& s, const AdsrConst& c)
+{
+    return __builtin_fmaxf(__builtin_fmaxf(1.0f, __builtin_fabsf(c.s_val)), __builtin_fmaxf(__builtin_fabsf(s.r_val), __builtin_fabsf(s.from_a_val)));
+}
+SRK_DEV bool adsr_tame(const AdsrRegs& s, const AdsrConst& c)
+{
+    return c.inc_a >= 0.0f && c.inc_d >= 0.0f && c.inc_r >= 0.0f && s.phase >= 0.0f && s.phase <= 1.0f && __builtin_fabsf(c.s_val) < 1.0e30f &&
+           __builtin_fabsf(s.r_val) < 1.0e30f && __builtin_fabsf(s.from_a_val) < 1.0e30f;
+}
+
 // Segmented ADSR: between mode changes the envelope is  phase += inc; out = c0 + c1 * u  with
 // u = phase (Attack) or 1 - phase, and (inc, c0, c1) fixed — the same f32 operations adsr_step
 // performs for that mode, so the bits are identical.  A sample that may change the mode

@@ -448,6 +448,17 @@ def test_specialised_kernel_versions_oscillators_with_a_bounded_cv(S):
     q.set_voice_field(qi["mul_idx"], S.MATH_CONSTANT, index)
     ring = q.kernel_source(S.RENDER_NO_FUSION)
     assert "fm_run" not in ring and "osc_step(0x10du, m2" in ring and "osc_step(0x110du, m5" in ring
+    # an envelope on the index: the bound is the envelope's hull times the gains, its time constants join the vote
+    e = S.Patch(48000, 1024, 2)
+    lfo, env, om, vca, idx, oc, out = (e.add_module(t) for t in (S.MOD_OSCILLATOR, S.MOD_ADSR, S.MOD_OSCILLATOR, S.MOD_VCA, S.MOD_MATH, S.MOD_OSCILLATOR, S.MOD_OUTPUT))
+    e.set_field(idx, S.MATH_OPERATION, 2)
+    for a_, ap, b_, bp in ((lfo, 1, env, 0), (om, 0, vca, 0), (env, 0, vca, 1), (vca, 0, idx, 0), (idx, 0, oc, 0), (oc, 0, out, 0)):
+        e.connect(a_, ap, b_, bp)
+    e.configure_voices(64)
+    for m_, f_ in ((idx, S.MATH_CONSTANT), (env, S.ADSR_S_VAL), (om, S.OSC_VAL)):
+        e.set_voice_field(m_, f_, np.linspace(0.1, 0.9, 64).astype(np.float32))
+    esrc = e.kernel_source(S.RENDER_NO_FUSION)
+    assert "adsr_bound(m0, m0_k)) * __builtin_fabsf(m3_c));" in esrc and "fm_lane = fm_lane && adsr_tame(m0, m0_k);" in esrc and esrc.count("fm_run(UC<") == 4
     # a sequencer's note is stepwise and of any size: no vote, the carried-phase oscillator as before
     r = S.Patch(48000, 1024, 2)
     ri = S.build_p3(r)

@@ -59,11 +59,11 @@ for seed in range(lo, hi):
     extra["p1"] = dict(res=round(res, 3), exp=round(expa, 3), neg=neg, port_a=port_a, port_f=port_f, adsr=[round(x, 4) for x in ad], lfo=round(lfo, 2))
     check("p1", seed, sr, B, V, T, p1, lambda ids: [(ids["osc_a"], S.OSC_VAL, det), (ids["vcf"], S.VCF_FREQ, cut)], (0, 1, 4, 5, 2))
     # ---- P2
-    B2 = int(r.choice([1, 32, 64, 1024]))
+    B2 = int(r.choice([1, 32, 64, 256, 512, 1024]))  # (256 ... 1024, default mode: the time-parallel pair)
     beta0, index0 = float(np.float32(r.uniform(0, 0.6))), float(np.float32(r.uniform(0, 2)))
     def p2(g): return S.build_p2(g, beta=beta0, index=index0)
     bet = r.uniform(0, 0.6, V).astype(np.float32); idx = r.uniform(0, 2, V).astype(np.float32); pitch = r.uniform(-2, 2, V).astype(np.float32)
-    check("p2", seed, sr, B2, V, min(T, 2500), p2, lambda ids: [(ids["mul_fb"], S.MATH_CONSTANT, bet), (ids["mul_idx"], S.MATH_CONSTANT, idx), (ids["osc_c"], S.OSC_VAL, pitch)], (0, 1, 2))
+    check("p2", seed, sr, B2, V, min(T, 2500), p2, lambda ids: [(ids["mul_fb"], S.MATH_CONSTANT, bet), (ids["mul_idx"], S.MATH_CONSTANT, idx), (ids["osc_c"], S.OSC_VAL, pitch)], (0, 1, 2, 34))  # 34: the z^-1 pair through the specialised kernel (the wave's vote over this parameter space)
     # ---- P3
     clock, length = float(np.float32(r.uniform(-7, -1.5))), int(r.integers(1, 17))
     def p3(g):
