@@ -283,8 +283,17 @@ class HipBackend:
 
     def step(self):
         a = self.args
-        self.p.render_raw(a.samples, self.frames.data_ptr() if self.frames is not None else None, None if a.no_mix else self.mix.data_ptr(),
-                          a.flags, self.stream.cuda_stream)
+        if a.block:  # diagnostic: the step as the app's tick loop would drive it — one call per `block` samples (main.rs:59-63)
+            V, T, st = a.voices, a.samples, self.stream.cuda_stream
+            if self.n_planes > 1 and self.frames is not None:
+                raise SystemExit("--block: frames of a multi-plane patch are [planes][n][V] per call (use --no-frames)")
+            for t in range(0, T, a.block):
+                n = min(a.block, T - t)
+                self.p.render_raw(n, self.frames.data_ptr() + 4 * t * V if self.frames is not None else None,
+                                  None if a.no_mix else self.mix.data_ptr() + 4 * 2 * t, a.flags, st)  # this call's mix is [2][n] at 2 * t
+        else:
+            self.p.render_raw(a.samples, self.frames.data_ptr() if self.frames is not None else None, None if a.no_mix else self.mix.data_ptr(),
+                              a.flags, self.stream.cuda_stream)
         if self.comm is not None and not a.no_mix:
             self.comm.reduce_mix(self.mix.data_ptr(), self.mix.numel(), 0, self.stream.cuda_stream)  # RCCL over xGMI: [2][T] f32 partial mixes
 
@@ -488,7 +497,7 @@ def run_rank(args, backend_cls=HipBackend):
                 "workload": be.what + f", {T} samples/step @48 kHz, f32 frames [{n_planes}][T][V] in HBM + stereo mix-down"
                             + (" + RCCL reduce of the [2][T] mix (srack_dist_reduce_mix)" if getattr(be, "comm", None) is not None else ""),
                 "name": args.workload, "voices_per_gpu": V, "samples_per_step": T, "buffer_size": getattr(be, "buffer_size", 1024),
-                "render_flags": args.flags, "backend": be.name,
+                "render_flags": args.flags, "backend": be.name, "samples_per_call": args.block or T,
                 "arithmetic": "f32 wires and modules; oscillator phase accumulator 64-bit: f64 as the reference, 2^-64 fixed point in the "
                               "default-mode fused saw kernel (DESIGN.md section 5)",
                 "frames_written": not args.no_frames, "mix_down": not args.no_mix, "program": info,
@@ -526,7 +535,7 @@ def run_rank(args, backend_cls=HipBackend):
                                                      note="rocprofv3 PMC passes of this command (profiles/run_profile.sh); a profiler cannot run inside the timed region")
         if world > 1:  # a straggler shows here (the value is paced by the slowest rank)
             print("[bench] ms per step by rank: " + " ".join(f"{r}:{m:.3f}" for r, m in enumerate(per_rank_ms)), file=sys.stderr, flush=True)
-        if (world == 1 and be.name == "hip" and args.workload == "cfg3" and not args.no_side_configs and args.flags == 0 and not args.no_frames
+        if (world == 1 and be.name == "hip" and args.workload == "cfg3" and not args.no_side_configs and args.flags == 0 and not args.block and not args.no_frames
                 and not args.no_mix and (V, T) == (default_voices("cfg3"), 48000)):
             # the other single-GPU BASELINE configurations on the same line (the headline's buffers are released first)
             be.close()
@@ -564,6 +573,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-mix", action="store_true", help="frames only (diagnostic; not the metric)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-side-configs", action="store_true", help="skip configs 2 and 4 after the headline steps of the default run")
+    ap.add_argument("--block", type=int, default=0,
+                    help="diagnostic: render each step in calls of this many samples (the app's tick loop: one call per buffer_size), not in one call")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the RCCL communicator and run the mix reduce even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     args = ap.parse_args(argv)
