@@ -537,6 +537,17 @@ def run_rank(args, backend_cls=HipBackend):
             print("[bench] ms per step by rank: " + " ".join(f"{r}:{m:.3f}" for r, m in enumerate(per_rank_ms)), file=sys.stderr, flush=True)
         if (world == 1 and be.name == "hip" and args.workload == "cfg3" and not args.no_side_configs and args.flags == 0 and not args.block and not args.no_frames
                 and not args.no_mix and (V, T) == (default_voices("cfg3"), 48000)):
+            # the same workload driven the way the reference's audio callback drives `execute` — one call per buffer_size samples
+            # (main.rs:59-63) — instead of one call per second of audio: what a host that ticks pays (tick sessions)
+            be.args.block = 1024
+            be.step()
+            be.sync()
+            t_tick = time.perf_counter()
+            for _ in range(SIDE_STEPS):
+                be.step()
+            be.sync()
+            out["roofline"]["cfg3_ticked_1024_ms_per_step"] = (time.perf_counter() - t_tick) / SIDE_STEPS * 1e3
+            be.args.block = 0
             # the other single-GPU BASELINE configurations on the same line (the headline's buffers are released first)
             be.close()
             be.frames = be.mix = be.p = None

@@ -29,6 +29,8 @@ struct CtlWork {
     float* track;      // this chunk's first sample of the envelope track
     uint32_t T;        // samples to produce (0: nothing to do)
     uint32_t port;     // OSC_OUT_* of the gate oscillator, | OSC_EXACT in the exact render mode
+    uint32_t* table_out;  // where the state goes (a tick session, render.hip: another copy of the table; null: in place) ...
+    uint32_t n_rows;      // ... and how many rows the table has
 };
 
 // kExact: the oscillator's outputs are the reference's f64 formulas (osc_step with OSC_EXACT) instead of the default mode's f32
@@ -69,15 +71,20 @@ SRK_DEV void ctl_gate_env_body(const CtlWork& a)
         if (lane < n) track[t0 + lane] = env;
     }
     adsr_seg_flush(sd, seg);
+    uint32_t* const tout = a.table_out ? a.table_out : a.table;
+    if (a.table_out) {  // the rows this block does not rewrite travel with the state (lane r's store, then lane 0's below: fenced)
+        for (uint32_t rr = (uint32_t)lane; rr < a.n_rows; rr += 64u) a.table_out[rr] = a.table[rr];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
     if (lane == 0) {
-        a.table[ol.state_row + OSC_S_POS_LO] = f64_lo(cl.pos);
-        a.table[ol.state_row + OSC_S_POS_HI] = f64_hi(cl.pos);
-        a.table[ol.state_row + OSC_S_SYNC_LAST] = 0u;
-        a.table[od.state_row + ADSR_S_PHASE] = __float_as_uint(sd.phase);
-        a.table[od.state_row + ADSR_S_MODE] = (uint32_t)sd.mode;
-        a.table[od.state_row + ADSR_S_R_VAL] = __float_as_uint(sd.r_val);
-        a.table[od.state_row + ADSR_S_FROM_A] = __float_as_uint(sd.from_a_val);
-        a.table[od.state_row + ADSR_S_GATE_LAST] = sd.gate_last ? 1u : 0u;
+        tout[ol.state_row + OSC_S_POS_LO] = f64_lo(cl.pos);
+        tout[ol.state_row + OSC_S_POS_HI] = f64_hi(cl.pos);
+        tout[ol.state_row + OSC_S_SYNC_LAST] = 0u;
+        tout[od.state_row + ADSR_S_PHASE] = __float_as_uint(sd.phase);
+        tout[od.state_row + ADSR_S_MODE] = (uint32_t)sd.mode;
+        tout[od.state_row + ADSR_S_R_VAL] = __float_as_uint(sd.r_val);
+        tout[od.state_row + ADSR_S_FROM_A] = __float_as_uint(sd.from_a_val);
+        tout[od.state_row + ADSR_S_GATE_LAST] = sd.gate_last ? 1u : 0u;
     }
 }
 

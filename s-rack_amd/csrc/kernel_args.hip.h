@@ -29,6 +29,10 @@ struct KernelArgs {
     // Kernels specialised at run time only (jit.cpp): blocks [0, block0) of a launch are the control program's units, block b
     // running unit b on the chunk ctl_slots[b] describes (T == 0: nothing to do in this launch).
     const KernelArgs* ctl_slots;
+    // A control unit inside a tick session (render.hip, TickSession): the state this chunk leaves behind goes to another copy of the
+    // table than the one it was read from, so that a chunk computed ahead of the host's next call never overwrites what the patch
+    // holds as of the last rendered sample.  Null: in place.
+    uint32_t* table_out;
 };
 
 struct ChainRoles {  // op indices of the fused voice chain (osc_l / adsr unused in the track variant)

@@ -55,6 +55,10 @@ struct Knobs {
     int fm_split = 1;            // exact mode: the z^-1 FM pair on two waves per 64 voices (modulators / carriers); 0: one wave does both
     int fm_block = 1;            // default mode, buffer_size 256 ... 1024: the time-parallel FM pair with its ring in LDS; 0: render_fm_pair_ring
     uint32_t fm_block_chunk = 65536;  // ... its launch length: the ring is loaded and stored once per launch, so the whole segment by default
+    uint32_t fm_block_min = 4096;     // ... and the shortest call it takes: a host that ticks block by block (one call per buffer_size samples) would move
+                                      // the ring between HBM and LDS every call — config 4 at buffer_size 1024, 47 calls of 1024: 18.2 ms against 7.5 in one
+                                      // call and 10.5 through render_fm_pair_ring; calls of 4096: 9.9 — so short calls keep the ring kernel
+    int tick = 1;                     // calls of one chunk keep the control program running ahead across calls (TickSession below); 0: every call starts it afresh
 };
 static const Knobs& knobs()
 {
@@ -77,6 +81,8 @@ static const Knobs& knobs()
         v.fm_split = (int)num("SRACK_FM_SPLIT", 0, 1, 1);
         v.fm_block = (int)num("SRACK_FM_BLOCK", 0, 1, 1);
         v.fm_block_chunk = (uint32_t)num("SRACK_FM_BLOCK_CHUNK", 256, 65536, 65536);
+        v.fm_block_min = (uint32_t)num("SRACK_FM_BLOCK_MIN", 1, 65536, 4096);
+        v.tick = (int)num("SRACK_TICK", 0, 1, 1);
         return v;
     }();
     return k;
@@ -103,7 +109,35 @@ struct DevProg {  // device copy of one FlatProgram
     }
 };
 
+// A host that ticks block by block — one srack_render call per buffer_size samples, the reference's own loop (main.rs:59-63) — renders
+// one chunk per call.  Treated as separate renders, every call would first wait for its chunk's control tracks: the control program's
+// units are one-wave latency chains, hidden only behind the voice kernels of EARLIER chunks (P1, 1024-sample calls: 14.3 ms per
+// second of audio against 11.1 in one call; the sequencer patch P3: 28.6 against 18.0).  A tick session keeps the control program
+// running ahead ACROSS calls: the voice launch of call c carries, as its first blocks, the units' work on the chunks of the calls to
+// come (unit s, `lag[s]` launches behind the first unit, is 1 + max_lag - lag[s] chunks ahead of the voices), on the guess that the
+// next call continues this one — same program, same length, same stream.  What is computed ahead must not touch what the patch holds
+// as of the last rendered sample (a host may read state back, edit the patch, or ask for another length next): the units' state
+// moves through a ring of R = max_lag + 2 copies of their tables (chunk x reads copy x % R — the table itself for x = 0 — and writes
+// copy (x + 1) % R), the tracks through a ring of R chunk buffers.  Ending a session (another length, an edit, a state read-back)
+// copies the state as of the last rendered chunk into the tables and forgets the rest.  Sample for sample the units do what they
+// would do in separate calls of the same length, so a session changes no bit of any render.
+struct TickSession {
+    bool on = false;
+    uint32_t L = 0;          // samples per call
+    uint32_t R = 0;          // depth of the rings
+    uint64_t c = 0;          // calls (= chunks) rendered
+    uint64_t n0 = 0;         // absolute index of the session's first sample
+    hipStream_t st = nullptr;
+    float* d_ring = nullptr;           // [R][n_tracks][L] control tracks
+    size_t ring_bytes = 0;
+    std::vector<uint32_t*> d_copies;   // per unit: [R][words] copies of its table
+    std::vector<size_t> words;
+    uint64_t slots_base = 0;           // argument blocks of the carried launches of calls [slots_base, slots_base + kTickBatch) are on the device
+};
+constexpr uint32_t kTickBatch = 256;
+
 struct DeviceState {
+    TickSession tick;
     DevProg voice;
     std::vector<DevProg> ctl;  // one per control stage
     KernelArgs* d_stage_slots = nullptr;  // [launches][stages] argument blocks of the staged control pipeline
@@ -135,6 +169,8 @@ void device_release(DeviceState* d)
     (void)hipFree(d->d_mixpart);
     (void)hipFree(d->d_mixgroup);
     (void)hipFree(d->d_tracks);
+    (void)hipFree(d->tick.d_ring);
+    for (uint32_t* c : d->tick.d_copies) (void)hipFree(c);
     for (auto& p : d->timings) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -176,9 +212,26 @@ int peek_program(PatchHandle& h, uint32_t flags, FlatPair& scratch, const FlatPa
     return rc;
 }
 
+// The state as of the last rendered sample goes back into the units' tables (on the session's stream); what was computed ahead is dropped.
+static int tick_end(PatchHandle& h)
+{
+    DeviceState* d = h.dev;
+    if (!d || !d->tick.on) return SRACK_OK;
+    TickSession& k = d->tick;
+    k.on = false;
+    for (size_t s2 = 0; s2 < k.d_copies.size(); s2++)
+        if (k.words[s2] > 0)  // chunk c - 1 left its state in copy c % R
+            HIP_TRY(hipMemcpyAsync(d->ctl[s2].d_table, k.d_copies[s2] + (size_t)(k.c % k.R) * k.words[s2], sizeof(uint32_t) * k.words[s2], hipMemcpyDeviceToDevice, k.st));
+    return SRACK_OK;
+}
+
 int ensure_program(PatchHandle& h, uint32_t flags)
 {
     if (program_current(h, flags)) return SRACK_OK;
+    {  // the program is about to be replaced: what it holds is read back (keep_state) or dropped — as of the last rendered sample either way
+        const int rc_tick = tick_end(h);
+        if (rc_tick != SRACK_OK) return rc_tick;
+    }
     flags &= ~kLaunchPolicyFlags;
     // srack_patch_keep_state: what the modules hold on the device becomes the state the re-flattened program starts from —
     // per voice for the modules of the voice program (a per-voice override of the state field), once for a module the control
@@ -478,9 +531,9 @@ static void launch_fm_pair2(bool exact, int out_mode, const KernelArgs& ka, cons
 }
 
 // The FM pair with a delay of 256 ... 1024 samples in default mode: time-parallel, 32 voices per 512-thread workgroup, ring in LDS.
-static bool fm_block_shape(const FlatProgram& P, uint32_t flags)
+static bool fm_block_shape(const FlatProgram& P, uint32_t flags, uint32_t n_samples)
 {
-    return P.fused == FUSED_FM_PAIR && P.fused_variant == 1 && !(flags & (SRACK_RENDER_EXACT_OSC | SRACK_RENDER_NO_FUSION)) && knobs().fm_block &&
+    return n_samples >= knobs().fm_block_min && P.fused == FUSED_FM_PAIR && P.fused_variant == 1 && !(flags & (SRACK_RENDER_EXACT_OSC | SRACK_RENDER_NO_FUSION)) && knobs().fm_block &&
            P.hdr.buffer_size >= kBlkChunk && P.hdr.buffer_size <= 1024;
 }
 
@@ -594,7 +647,7 @@ static void launch_ctl(const FlatProgram& Cp, const KernelArgs& kc, hipStream_t 
 {
     if (Cp.fused == FUSED_CTL_GATE_ENV) {
         CtlWork w{kc.ops, kc.table, kc.frames + (size_t)Cp.ops[2].aux * kc.plane_stride, kc.T,
-                  Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_EXACT)};
+                  Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_EXACT), nullptr, 0u};
         hipLaunchKernelGGL(render_ctl_gate_env, dim3(1), dim3(64), 0, st, w);
     } else if (Cp.fused == FUSED_FM_PAIR) {
         ChainRoles roles{};
@@ -638,7 +691,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     // With few voices, half- or quarter-filled waves double / quadruple the number of waves: a VALU instruction
     // costs the same for 16 lanes as for 64, so this only pays while SIMDs would otherwise sit idle (VALU-bound
     // kernels: up to one wave per SIMD) or while waves are latency-bound (FM pair, interpreter: up to four).
-    const bool fm_block = fm_block_shape(P, flags);  // 32 voices per workgroup, whatever the voice count
+    const bool fm_block = fm_block_shape(P, flags, T);  // 32 voices per workgroup, whatever the voice count
     const uint32_t lanes = fm_block ? (uint32_t)kBlkVoices : lanes_per_wave(V);
     const uint32_t n_waves = (V + lanes - 1) / lanes;
 
@@ -671,7 +724,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     auto ctl_work = [&](uint32_t t_off, uint32_t len) {
         const FlatProgram& Cp = h.prog.ctl[0];
         return CtlWork{d->ctl[0].d_ops, d->ctl[0].d_table, d->d_tracks + (size_t)Cp.ops[2].aux * T + t_off, len,
-                       Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_EXACT)};
+                       Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_EXACT), nullptr, 0u};
     };
     const JitKernel* special = nullptr;  // a kernel specialised for this program (jit.cpp), if the program takes one
     bool special_ctl = false;            // ... with the control program's units as extra blocks of every launch
@@ -685,8 +738,20 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     const uint32_t kChunkFirst = std::min(knobs().chunk_first, kChunkMax);
     uint32_t max_lag = 0;
     for (int lag : h.prog.ctl_lag) max_lag = std::max(max_lag, (uint32_t)lag);
+    // A call of one chunk whose control program runs as blocks of the voice launches is (the start of) a tick session (TickSession):
+    // everything the units hold must live in their tables (no rings in HBM, no reverb lines — those have no copies to move through).
+    bool tick = knobs().tick && has_ctl && (co_ctl || (special && special_ctl)) && t_seg == 0 && T_total == T && T <= kChunkMax;
+    for (const FlatProgram& Cp : h.prog.ctl) tick = tick && Cp.hdr.n_rings == 0 && Cp.fv_rows == 0;
+    TickSession& tk = d->tick;
+    if (tk.on && !(tick && tk.L == T && tk.st == st && tk.n0 + tk.c * (uint64_t)T == h.samples_rendered)) {  // not the call the session guessed
+        const hipStream_t was_on = tk.st;
+        if ((rc = tick_end(h)) != SRACK_OK) return rc;
+        if (was_on != st) HIP_TRY(hipStreamSynchronize(was_on));
+    }
     std::vector<std::pair<uint32_t, uint32_t>> chunks;       // (t_off, len)
-    if (has_ctl) {
+    if (tick) {
+        chunks.emplace_back(0u, T);
+    } else if (has_ctl) {
         uint32_t k = 0;
         for (uint32_t t_off = 0, len = kChunkFirst; t_off < T; t_off += len, k++) {
             if (k > max_lag) len = std::min(len * 2, kChunkMax);
@@ -759,7 +824,95 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         HIP_TRY(hipMemcpyAsync(d->d_stage_slots, d->h_stage_slots.data(), bytes, hipMemcpyHostToDevice, on));
         return SRACK_OK;
     };
-    if (special && special_ctl) {
+    // ---- tick session: argument blocks of unit s2 on chunk x, and the launches that start a session ----
+    const uint32_t n_tracks = (uint32_t)h.prog.n_tracks;
+    auto tick_tracks = [&](uint64_t x) { return tk.d_ring + (size_t)(x % tk.R) * n_tracks * tk.L; };
+    auto tick_table = [&](uint32_t s2, uint64_t x) -> uint32_t* {  // the copy chunk x reads (x = 0: the table itself) / chunk x - 1 wrote
+        if (tk.words[s2] == 0) return nullptr;
+        return x == 0 ? d->ctl[s2].d_table : tk.d_copies[s2] + (size_t)(x % tk.R) * tk.words[s2];
+    };
+    auto tick_unit_args = [&](uint32_t s2, uint64_t x) {
+        KernelArgs kc{};
+        kc.ops = d->ctl[s2].d_ops;
+        kc.prog = h.prog.ctl[s2].hdr;
+        kc.table = tick_table(s2, x);
+        kc.table_out = tick_table(s2, x + 1);
+        kc.seqtab = d->ctl[s2].d_seqtab;
+        kc.frames = tick_tracks(x);
+        kc.tracks = kc.frames;
+        kc.plane_stride = tk.L;
+        kc.t_stride = tk.L;
+        kc.V = 1;
+        kc.T = tk.L;
+        kc.n_waves = 1;
+        kc.lanes = 64;
+        kc.n0 = tk.n0 + x * tk.L;
+        kc.block0 = s2;
+        return kc;
+    };
+    auto tick_work = [&](uint64_t x) {  // the fused gate -> envelope control program on chunk x
+        const FlatProgram& Cp = h.prog.ctl[0];
+        return CtlWork{d->ctl[0].d_ops, tick_table(0, x), tick_tracks(x) + (size_t)Cp.ops[2].aux * tk.L, tk.L,
+                       Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_EXACT), tick_table(0, x + 1), (uint32_t)Cp.hdr.n_rows};
+    };
+    // global launch g of the session runs unit s2 on chunk g - lag[s2]: launches 0 .. max_lag run alone when the session starts (they
+    // complete chunk 0), launch max_lag + 1 + i rides on the voice launch of call i.  The device holds the first ones and a batch of the others.
+    auto tick_upload_slots = [&](uint64_t base) -> int {
+        const uint32_t fill = max_lag + 1;
+        d->h_stage_slots.assign((size_t)(fill + kTickBatch) * n_stages, KernelArgs{});
+        for (uint32_t s2 = 0; s2 < n_stages; s2++) {
+            const uint32_t lag = (uint32_t)h.prog.ctl_lag[s2];
+            if (base == 0)
+                for (uint32_t g = lag; g < fill; g++) d->h_stage_slots[(size_t)g * n_stages + s2] = tick_unit_args(s2, g - lag);
+            for (uint32_t i = 0; i < kTickBatch; i++) d->h_stage_slots[(size_t)(fill + i) * n_stages + s2] = tick_unit_args(s2, base + i + fill - lag);
+        }
+        const size_t bytes = sizeof(KernelArgs) * d->h_stage_slots.size();
+        if (bytes > d->stage_slots_cap) {
+            (void)hipFree(d->d_stage_slots);
+            d->d_stage_slots = nullptr;
+            d->stage_slots_cap = 0;
+            HIP_TRY(hipMalloc(&d->d_stage_slots, bytes));
+            d->stage_slots_cap = bytes;
+        }
+        HIP_TRY(hipMemcpyAsync(d->d_stage_slots, d->h_stage_slots.data(), bytes, hipMemcpyHostToDevice, st));
+        tk.slots_base = base;
+        return SRACK_OK;
+    };
+    if (tick && !tk.on) {  // a session starts: its first chunk's control work is exposed, like any render's
+        const uint32_t R = max_lag + 2;
+        if ((rc = grow(tk.d_ring, tk.ring_bytes, sizeof(float) * (size_t)R * n_tracks * T)) != SRACK_OK) return rc;
+        if (tk.d_copies.empty()) {
+            tk.d_copies.assign(n_stages, nullptr);
+            tk.words.assign(n_stages, 0);
+            for (uint32_t s2 = 0; s2 < n_stages; s2++) {
+                tk.words[s2] = h.prog.ctl[s2].table.size();
+                if (tk.words[s2] > 0) HIP_TRY(hipMalloc(&tk.d_copies[s2], sizeof(uint32_t) * tk.words[s2] * R));
+            }
+        }
+        tk.on = true;
+        tk.L = T;
+        tk.R = R;
+        tk.c = 0;
+        tk.n0 = h.samples_rendered;
+        tk.st = st;
+        if (co_ctl) {
+            hipLaunchKernelGGL(render_ctl_gate_env, dim3(1), dim3(64), 0, st, tick_work(0));
+            HIP_TRY(hipGetLastError());
+        } else {
+            if ((rc = tick_upload_slots(0)) != SRACK_OK) return rc;
+            for (uint32_t g = 0; g <= max_lag; g++) {
+                KernelArgs kp{};
+                kp.block0 = n_stages;
+                kp.ctl_slots = d->d_stage_slots + (size_t)g * n_stages;
+                if ((rc = jit_launch(*special, kp, n_stages, st)) != SRACK_OK) return rc;
+            }
+        }
+    } else if (tick && !co_ctl && tk.c >= tk.slots_base + kTickBatch) {
+        if ((rc = tick_upload_slots(tk.c)) != SRACK_OK) return rc;
+    }
+    if (tick) {
+        // (below: the voice launch of this call, with the units' next launch as its first blocks)
+    } else if (special && special_ctl) {
         // Co-scheduled control units: everything on the caller's stream.  Launches 0 .. max_lag of the control pipeline run alone
         // (they complete chunk 0: the only exposed control work, kept short by the 1024-sample first chunks); voice launch k then
         // carries control launch k + max_lag + 1 as its first blocks, which completes chunk k + 1 while chunk k is consumed.
@@ -888,7 +1041,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         ka.fv = d->voice.d_fv;
         ka.frames = d_frames ? d_frames + (size_t)t_off * V : nullptr;
         ka.mixpart = d_mix ? d->d_mixpart + t_off : nullptr;
-        ka.tracks = has_ctl ? d->d_tracks + t_off : nullptr;
+        ka.tracks = tick ? tick_tracks(tk.c) : has_ctl ? d->d_tracks + t_off : nullptr;
         ka.plane_stride = (uint64_t)T_total * V;
         ka.t_stride = T;
         ka.V = V;
@@ -897,12 +1050,18 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         ka.lanes = lanes;
         ka.n0 = h.samples_rendered + t_off;
         CtlWork co{};
-        if (co_ctl && k + 1 < n_chunks) {  // this launch's block 0 prepares the next chunk's track
+        if (tick && co_ctl) {  // block 0: the track of the chunk the next call is expected to ask for
+            co = tick_work(tk.c + 1);
+            ka.block0 = 1;
+        } else if (tick) {
+            ka.block0 = n_stages;
+            ka.ctl_slots = d->d_stage_slots + (size_t)(max_lag + 1 + (tk.c - tk.slots_base)) * n_stages;
+        } else if (co_ctl && k + 1 < n_chunks) {  // this launch's block 0 prepares the next chunk's track
             co = ctl_work(chunks[k + 1].first, chunks[k + 1].second);
             ka.block0 = 1;
         }
         if (has_ctl && !co_ctl && !(special && special_ctl)) HIP_TRY(hipStreamWaitEvent(st, d->ev_chunk[k], 0));
-        if (special && special_ctl && k + max_lag + 1 < n_ctl_launch) {  // this launch's first blocks: the control units' next launch
+        if (!tick && special && special_ctl && k + max_lag + 1 < n_ctl_launch) {  // this launch's first blocks: the control units' next launch
             ka.block0 = n_stages;
             ka.ctl_slots = d->d_stage_slots + (size_t)(k + max_lag + 1) * n_stages;
         }
@@ -956,6 +1115,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         HIP_TRY(hipGetLastError());
     }
     h.samples_rendered += T;
+    if (tick) tk.c++;
     return SRACK_OK;
 }
 
@@ -993,7 +1153,7 @@ int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t f
     DeviceState* d = h.dev;
     const FlatProgram& P = h.prog.voice;
     const uint32_t T = std::min(n_samples, 65536u);  // one segment
-    const uint32_t lanes = fm_block_shape(P, h.prog.effective_flags) ? (uint32_t)kBlkVoices : lanes_per_wave(P.n_voices), n_waves = (P.n_voices + lanes - 1) / lanes;
+    const uint32_t lanes = fm_block_shape(P, h.prog.effective_flags, T) ? (uint32_t)kBlkVoices : lanes_per_wave(P.n_voices), n_waves = (P.n_voices + lanes - 1) / lanes;
     if (want_mix && P.hdr.n_planes > 0) {
         if ((rc = grow(d->d_mixpart, d->mixpart_bytes, sizeof(float) * (size_t)P.hdr.n_planes * n_waves * T)) != SRACK_OK) return rc;
         if ((rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * T)) != SRACK_OK) return rc;
@@ -1038,6 +1198,8 @@ int device_read_rows(PatchHandle& h, int ctl_stage, int first_row, int n_rows, u
     const size_t V = P.n_voices;
     const uint32_t* d_table = h.dev ? (ctl_stage >= 0 ? h.dev->ctl[(size_t)ctl_stage].d_table : h.dev->voice.d_table) : nullptr;
     if (d_table) {
+        const int rc_tick = tick_end(h);
+        if (rc_tick != SRACK_OK) return rc_tick;
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(host_dst, d_table + (size_t)first_row * V, sizeof(uint32_t) * V * (size_t)n_rows, hipMemcpyDeviceToHost));
     } else {  // nothing rendered yet: the initial table

@@ -210,7 +210,8 @@ def test_fm_pair_sample_loops(S, oracle, B, flags):
     (range reduction), or nothing at all — a voice whose feedback gain lets 2^x overflow, after which its phase is NaN as in the reference, and its 63
     well-behaved neighbours, which take the literal forms with it.  One wave of each, plus a modulator `val` that moves a wave from
     one class to the next; every voice against the oracle."""
-    T, W = 2500, 64
+    # (buffer_size 1024: the time-parallel pair takes calls of 4096 samples and more — shorter ones keep the ring kernel, see below)
+    T, W, cut = (9000, 64, 4501) if B == 1024 else (2500, 64, 1001)
     rng = np.random.default_rng(11)
     beta = np.concatenate([rng.uniform(0.05, 0.45, W), rng.uniform(0.1, 0.4, W), rng.uniform(0.6, 1.8, W), rng.uniform(0.1, 0.4, W),
                            rng.uniform(0.1, 0.3, W), rng.uniform(0.6, 1.8, W), rng.uniform(0.6, 1.8, W), rng.uniform(0.1, 0.4, W)]).astype(np.float32)
@@ -245,8 +246,10 @@ def test_fm_pair_sample_loops(S, oracle, B, flags):
     p.configure_voices(V)
     for m, f, v in over:
         p.set_voice_field(m, f, v)
-    a = p.render_channels(1001, flags)
-    b = p.render_channels(T - 1001, flags)
+    a = p.render_channels(cut, flags)
+    b = p.render_channels(T - cut, flags)
+    if B == 1024 and flags == 0:
+        assert "kernel=render_fm_pair_block" in p.info(), p.info()
     if "kernel=render_fm_pair_block" in p.info():
         # the time-parallel pair (buffer_size 256 ... 1024, default mode): a phase is a prefix sum over 256-sample chunks counted from the
         # launch's first sample, so a split render adds the same increments in other groups — 1e-16 in a phase, an occasional last bit of an

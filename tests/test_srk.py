@@ -330,7 +330,7 @@ def test_loaded_feedback_ring_with_values_no_sine_has(S, B):
     o = O.OraclePatch(48000, B, 2)
     ids = S.build_p2(o, beta=0.3, index=1.0)
     o.set_output_buffer(ids["osc_m"], 0, saved)
-    T, V = 3 * B + 100, 70
+    T, V = (4 if B == 1024 else 3) * B + 100, 70   # (the time-parallel pair takes calls of 4096 samples and more)
     ref, _ = o.render_batch(V, T, [], threads=2)
     for flags in (4, 5):        # (4: everything per voice — identical voices would otherwise be rendered once, by the control program)
         p.configure_voices(V)
