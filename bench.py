@@ -44,6 +44,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: without this RCCL across processes fails in hipIpcGetMemHandle (set before HIP starts in
+# any rank, whoever launched it — a launcher's environment usually has it already)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured streaming ceiling ~6290
 HBM_STREAM_GBS = 6290.0

@@ -6,6 +6,7 @@ with the CPU oracle (test infrastructure standing in for the GPU), draws its per
 like bench.py does, reduces the [2][T] partial mix to rank 0 over torch.distributed (gloo on CPU, RCCL on
 the GPU box) and rank 0 compares with the single-process render of all voices.
 """
+import json
 import os
 import sys
 
@@ -132,6 +133,29 @@ def test_bench_under_an_external_launcher(tmp_path):
     rc = bench.launch_ranks(2, cmd, env=env, timeout=240)  # stands in for torch.distributed.run: same environment contract
     assert rc == 0
     assert sorted(os.listdir(tmp_path)) == ["steps.0", "steps.1"]  # two ranks, not four
+
+
+def test_bench_under_torch_distributed_run(tmp_path):
+    """The driver's command, literally: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` — here with the CPU backend standing in and N = 2."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SRACK_TEST_STEPS_OUT=str(tmp_path / "steps"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "bench_cpu_rank.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--voices", "4", "--samples", "600", "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and len(out["per_rank_ms_per_step"]) == 2
+    assert abs(out["value"] - 2 * 4 * 600 / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    assert sorted(os.listdir(tmp_path)) == ["steps.0", "steps.1"] and open(str(tmp_path / "steps") + ".1").read() == "3"
 
 
 def test_bench_single_rank_needs_no_rendezvous(tmp_path):
