@@ -77,3 +77,17 @@ def test_a_tick_session_changes_no_bit(oracle, tmp_path, scenario, flags):
                     checked += 1
         n += op[1]
     assert checked > 0 and np.abs(ref).max() > 0.05
+
+
+def test_two_patches_on_two_streams(tmp_path):
+    """Two patches ticking on two non-default streams, their calls interleaved and unsynchronised (each with a session of its own),
+    one of them changing stream mid-way: bit for bit what each renders alone on the null stream."""
+    out = os.path.join(tmp_path, "streams.npz")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stream_driver.py"), out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(out)
+    for k in range(2):
+        assert np.abs(d[f"alone_fr{k}"]).max() > 0.05
+        np.testing.assert_array_equal(bits(d[f"both_fr{k}"]), bits(d[f"alone_fr{k}"]), err_msg=f"frames of patch {k}")
+        np.testing.assert_array_equal(bits(d[f"both_mx{k}"]), bits(d[f"alone_mx{k}"]), err_msg=f"mix of patch {k}")
+    assert "kernel=render_voice_chain_track" in str(d["info0"]) and "kernel=render_specialized" in str(d["info1"])
