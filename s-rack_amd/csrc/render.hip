@@ -743,6 +743,12 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     bool tick = knobs().tick && has_ctl && (co_ctl || (special && special_ctl)) && t_seg == 0 && T_total == T && T <= kChunkMax;
     for (const FlatProgram& Cp : h.prog.ctl) tick = tick && Cp.hdr.n_rings == 0 && Cp.fv_rows == 0;
     TickSession& tk = d->tick;
+    // (a call that fails part-way — a launch error — must not leave a session behind whose bookkeeping is a call ahead of the device)
+    struct TickGuard {
+        TickSession& t;
+        bool done = false;
+        ~TickGuard() { if (!done) t.on = false; }
+    } tick_guard{tk};
     if (tk.on && !(tick && tk.L == T && tk.st == st && tk.n0 + tk.c * (uint64_t)T == h.samples_rendered)) {  // not the call the session guessed
         const hipStream_t was_on = tk.st;
         if ((rc = tick_end(h)) != SRACK_OK) return rc;
@@ -1116,6 +1122,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     }
     h.samples_rendered += T;
     if (tick) tk.c++;
+    tick_guard.done = true;
     return SRACK_OK;
 }
 
