@@ -132,9 +132,10 @@ struct TickSession {
     size_t ring_bytes = 0;
     std::vector<uint32_t*> d_copies;   // per unit: [R][words] copies of its table
     std::vector<size_t> words;
-    uint64_t slots_base = 0;           // argument blocks of the carried launches of calls [slots_base, slots_base + kTickBatch) are on the device
+    uint64_t slots_base = 0;           // argument blocks of the carried launches of calls [slots_base, slots_base + slots_n) are on the device
+    uint32_t slots_n = 0;
 };
-constexpr uint32_t kTickBatch = 256;
+constexpr uint32_t kTickBatch = 256, kTickFirstBatch = 8;  // (a session that the very next call ends should not have uploaded much)
 
 struct DeviceState {
     TickSession tick;
@@ -864,13 +865,13 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     // global launch g of the session runs unit s2 on chunk g - lag[s2]: launches 0 .. max_lag run alone when the session starts (they
     // complete chunk 0), launch max_lag + 1 + i rides on the voice launch of call i.  The device holds the first ones and a batch of the others.
     auto tick_upload_slots = [&](uint64_t base) -> int {
-        const uint32_t fill = max_lag + 1;
-        d->h_stage_slots.assign((size_t)(fill + kTickBatch) * n_stages, KernelArgs{});
+        const uint32_t fill = max_lag + 1, batch = base == 0 ? kTickFirstBatch : kTickBatch;
+        d->h_stage_slots.assign((size_t)(fill + batch) * n_stages, KernelArgs{});
         for (uint32_t s2 = 0; s2 < n_stages; s2++) {
             const uint32_t lag = (uint32_t)h.prog.ctl_lag[s2];
             if (base == 0)
                 for (uint32_t g = lag; g < fill; g++) d->h_stage_slots[(size_t)g * n_stages + s2] = tick_unit_args(s2, g - lag);
-            for (uint32_t i = 0; i < kTickBatch; i++) d->h_stage_slots[(size_t)(fill + i) * n_stages + s2] = tick_unit_args(s2, base + i + fill - lag);
+            for (uint32_t i = 0; i < batch; i++) d->h_stage_slots[(size_t)(fill + i) * n_stages + s2] = tick_unit_args(s2, base + i + fill - lag);
         }
         const size_t bytes = sizeof(KernelArgs) * d->h_stage_slots.size();
         if (bytes > d->stage_slots_cap) {
@@ -882,6 +883,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         }
         HIP_TRY(hipMemcpyAsync(d->d_stage_slots, d->h_stage_slots.data(), bytes, hipMemcpyHostToDevice, st));
         tk.slots_base = base;
+        tk.slots_n = batch;
         return SRACK_OK;
     };
     if (tick && !tk.on) {  // a session starts: its first chunk's control work is exposed, like any render's
@@ -913,7 +915,7 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
                 if ((rc = jit_launch(*special, kp, n_stages, st)) != SRACK_OK) return rc;
             }
         }
-    } else if (tick && !co_ctl && tk.c >= tk.slots_base + kTickBatch) {
+    } else if (tick && !co_ctl && tk.c >= tk.slots_base + tk.slots_n) {
         if ((rc = tick_upload_slots(tk.c)) != SRACK_OK) return rc;
     }
     if (tick) {
