@@ -5,9 +5,11 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <random>
+#include <vector>
 
 #include "../../include/srack.hpp"
 
@@ -154,16 +156,100 @@ static int one_rank_mix_comm()
     return 0;
 }
 
+// The audio callback of src/main.rs:59-90, transliterated: cpal hands over an interleaved `data: &mut [f32]` of whatever length it likes;
+// whenever the staging buffers run dry (`src_buf_idx == 0` at a frame boundary) the callback runs `synth::execute(&plan)` — here one
+// srack_render of buffer_size samples, the mix standing in for OutputModule::bufs — copies the channels out and goes on interleaving.
+// A host that ticks like this must hear exactly what one long render gives (the library keeps its control program running ahead
+// across such calls: a tick session).
+static int audio_callback(uint32_t n_voices)
+{
+    AudioConfig ac;
+    ac.sample_rate = 48000;
+    ac.buffer_size = 256;
+    ac.channels = 2;
+    auto build = [&](Workspace& ws) {  // P1: saw VCO -> ladder -> VCA, envelope gated by an LFO square (a fast one: 110 Hz)
+        SharedSynthModule osc = ws.add(ModuleType::Oscillator), lfo = ws.add(ModuleType::Oscillator), vcf = ws.add(ModuleType::MoogFilter);
+        SharedSynthModule adsr = ws.add(ModuleType::ADSR), vca = ws.add(ModuleType::VCA), out = ws.add(ModuleType::Output);
+        lfo.set(SRACK_OSC_VAL, -2.0);
+        adsr.set(SRACK_ADSR_A_SEC, 0.001);
+        adsr.set(SRACK_ADSR_D_SEC, 0.002);
+        adsr.set(SRACK_ADSR_S_VAL, 0.5);
+        adsr.set(SRACK_ADSR_R_SEC, 0.002);
+        if (!vcf.set_input(0, osc, SRACK_OSC_OUT_SAW) || !adsr.set_input(0, lfo, SRACK_OSC_OUT_SQUARE) || !vca.set_input(0, vcf, 0) ||
+            !vca.set_input(1, adsr, 0) || !out.set_input(0, vca, 0) || !out.set_input(1, vca, 0))
+            throw Error(SRACK_ERR_PORT, "set_input");
+        ws.configure_voices(n_voices);
+        if (n_voices > 1) {
+            std::vector<float> val(n_voices);
+            for (uint32_t v = 0; v < n_voices; v++) val[v] = -0.5f + (float)v / (float)n_voices;
+            ws.check(srack_voices_set_field_f32(ws.handle(), osc.index(), SRACK_OSC_VAL, val.data()));
+        }
+    };
+    const size_t channels = ac.channels, buffer_size = ac.buffer_size;
+    const size_t lens[] = {512, 2 * 256, 2 * 100, 2 * 733, 2 * 1, 2 * 1024, 2 * 256, 2 * 256, 2 * 77};  // data.len() per callback (frames x channels)
+    size_t total = 0;
+    for (size_t n : lens) total += n;
+    // --- the ticking host ---
+    Workspace ws(ac);
+    build(ws);
+    float* d_mix = nullptr;
+    ws.check(srack_device_alloc((void**)&d_mix, channels * buffer_size * sizeof(float)));
+    std::vector<std::vector<float>> src_buf(channels, std::vector<float>(buffer_size, 0.0f));
+    std::vector<float> bufs(channels * buffer_size), heard;
+    size_t src_buf_idx = 0, executes = 0;
+    for (size_t n : lens) {
+        std::vector<float> data(n);
+        for (size_t out_idx = 0; out_idx < data.size(); out_idx++) {
+            if (src_buf_idx == 0 && out_idx % channels == 0) {
+                ws.execute_batch((uint32_t)buffer_size, nullptr, d_mix);  // synth::execute(&plan)
+                executes++;
+                ws.check(srack_device_to_host(bufs.data(), d_mix, bufs.size() * sizeof(float), nullptr));
+                ws.check(srack_device_sync(nullptr));
+                for (size_t c = 0; c < channels; c++) std::copy(bufs.begin() + c * buffer_size, bufs.begin() + (c + 1) * buffer_size, src_buf[c].begin());
+            }
+            data[out_idx] = src_buf[out_idx % channels][src_buf_idx];
+            if (out_idx % channels == channels - 1) {
+                src_buf_idx += 1;
+                if (src_buf_idx >= buffer_size) src_buf_idx = 0;
+            }
+        }
+        heard.insert(heard.end(), data.begin(), data.end());
+    }
+    srack_device_free(d_mix);
+    // --- one long render of as many blocks ---
+    Workspace whole(ac);
+    build(whole);
+    const size_t T = executes * buffer_size;
+    float* d_all = nullptr;
+    whole.check(srack_device_alloc((void**)&d_all, channels * T * sizeof(float)));
+    whole.execute_batch((uint32_t)T, nullptr, d_all);
+    std::vector<float> all(channels * T);
+    whole.check(srack_device_to_host(all.data(), d_all, all.size() * sizeof(float), nullptr));
+    whole.check(srack_device_sync(nullptr));
+    srack_device_free(d_all);
+    REQUIRE(heard.size() == total && total / channels <= T);
+    float peak = 0.0f;
+    for (size_t i = 0; i < heard.size(); i++) {
+        const float want = all[(i % channels) * T + i / channels];
+        REQUIRE(std::memcmp(&heard[i], &want, sizeof(float)) == 0);  // bit for bit
+        peak = std::fmax(peak, std::fabs(want));
+    }
+    REQUIRE(peak > 0.05f * (float)(n_voices > 1 ? 8 : 1));
+    std::printf("audio_callback ok (%zu executes, %zu frames, peak %.3f)\n", executes, total / channels, (double)peak);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     try {
         if (argc > 1 && !std::strcmp(argv[1], "topo")) return topological_sort();
         if (argc > 1 && !std::strcmp(argv[1], "dco")) return produces_440();
         if (argc > 1 && !std::strcmp(argv[1], "dist")) return one_rank_mix_comm();
+        if (argc > 1 && !std::strcmp(argv[1], "callback")) return audio_callback(argc > 2 ? (uint32_t)std::atoi(argv[2]) : 1u);
     } catch (const Error& e) {
         std::printf("srack::Error %d: %s\n", e.code, e.what());
         return 2;
     }
-    std::printf("usage: test_mirror topo|dco|dist\n");
+    std::printf("usage: test_mirror topo|dco|dist|callback [voices]\n");
     return 3;
 }

@@ -38,3 +38,15 @@ def test_one_rank_mix_comm_cpp(mirror_bin):
     r = subprocess.run([mirror_bin, "dist"], capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "one_rank_mix_comm ok" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("voices", [1, 300, 5000])
+def test_audio_callback_cpp(mirror_bin, voices):
+    """The reference's audio callback (src/main.rs:59-90) transliterated onto the C++ mirror: `execute` once per buffer_size frames
+    whenever the staging buffers run dry, interleave into a `data` slice of whatever length the device asks for — bit for bit what
+    one long render gives (1 voice: the reference's own case; 300 and 5000: per-voice pitch, the flagship kernel with its co-scheduled
+    control block, i.e. a tick session from the second execute on)."""
+    r = subprocess.run([mirror_bin, "callback", str(voices)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "audio_callback ok" in r.stdout
