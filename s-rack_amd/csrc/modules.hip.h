@@ -1290,13 +1290,42 @@ __device__ const uint64_t kLog2Tab[32][2] = {  // {bits(1 / c_i), bits(log2 c_i)
     {0x3fe0624dd2f1a9fc, 0x3feee7b471b3a950},
     {0x3fe0204081020408, 0x3fefa34e1177c233},
 };
-SRK_DEV double log2_pos_f32(float x)
+// (pow2f_libm's table, below: tab[i] = bits(2^(i/32)) - (i << 47))
+__device__ const uint64_t kExp2fTab[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b, 0x3fef54873168b9aa,
+    0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
+    0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74,
+    0x3feea11473eb0187, 0x3feea589994cce13, 0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+    0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+    0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
+};
+// (The tables of this section, as a kernel reaches them.  A lane's index is its own: through the global pointer that is a gather for the
+// vector-memory pipe — 16 cycles of its address unit per wave and load at best, shared by the CU's four SIMDs; P4, with three such
+// loads per voice-sample, was bound by exactly that (rocprofv3: 94 VALU instructions in 677 SIMD cycles per wave-sample, the same at
+// two and at four waves per SIMD).  A kernel generated for a patch copies the tables into LDS once per launch and passes LDS pointers:
+// ds_read_b64 / b128 with per-lane addresses.)
+typedef __attribute__((address_space(3))) const uint64_t LdsTab;
+struct GlobalTables {
+    SRK_DEV uint64_t exp2f(uint32_t i) const { return kExp2fTab[i]; }
+    SRK_DEV uint64_t log2_inv_c(uint32_t i) const { return kLog2Tab[i][0]; }
+    SRK_DEV uint64_t log2_c(uint32_t i) const { return kLog2Tab[i][1]; }
+};
+struct LdsTables {
+    LdsTab* exp2f_tab;  // [32]
+    LdsTab* log2_tab;   // [32][2]
+    SRK_DEV uint64_t exp2f(uint32_t i) const { return exp2f_tab[i]; }
+    SRK_DEV uint64_t log2_inv_c(uint32_t i) const { return log2_tab[2u * i]; }
+    SRK_DEV uint64_t log2_c(uint32_t i) const { return log2_tab[2u * i + 1u]; }
+};
+
+template <class Tab = GlobalTables>
+SRK_DEV double log2_pos_f32(float x, const Tab tab = Tab{})
 {
     const uint32_t bits = __float_as_uint(x);
     const int e = (int)(bits >> 23) - 127;
     const uint32_t i = (bits >> 18) & 31u;
     const double m = (double)__uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
-    const double inv_c = __longlong_as_double((long long)kLog2Tab[i][0]), log_c = __longlong_as_double((long long)kLog2Tab[i][1]);
+    const double inv_c = __longlong_as_double((long long)tab.log2_inv_c(i)), log_c = __longlong_as_double((long long)tab.log2_c(i));
     const double z = __builtin_fma(m, inv_c, -1.0);
     const double z2 = z * z, z4 = z2 * z2;
     const double p01 = __builtin_fma(-0.7213475204444817, z, 1.4426950408889634);
@@ -1308,10 +1337,11 @@ SRK_DEV double log2_pos_f32(float x)
     return __builtin_fma(z, p, (double)e + log_c);
 }
 
-SRK_DEV float powf_pos(float x, float b, bool exact)
+template <class Tab = GlobalTables>
+SRK_DEV float powf_pos(float x, float b, bool exact, const Tab tab = Tab{})
 {
     // (a subnormal x goes to ocml's powf below, like every other special case)
-    const double y = (double)b * (exact ? ::log2((double)x) : log2_pos_f32(x >= 0x1p-126f ? x : 1.0f));
+    const double y = (double)b * (exact ? ::log2((double)x) : log2_pos_f32(x >= 0x1p-126f ? x : 1.0f, tab));
     const bool fast = x >= 0x1p-126f && x < __builtin_inff() && __builtin_fabs(y) < 126.0;  // NaN x / b / y: false
     float r = (float)exp2_fast(fast ? y : 0.0);
     if (__builtin_amdgcn_ballot_w64(!fast)) {
@@ -1320,12 +1350,13 @@ SRK_DEV float powf_pos(float x, float b, bool exact)
     return r;
 }
 
-SRK_DEV float nonlin_step(uint32_t flags, float in1, float in2, float constant)
+template <class Tab = GlobalTables>
+SRK_DEV float nonlin_step(uint32_t flags, float in1, float in2, float constant, const Tab tab = Tab{})
 {
     const float a = (flags & MATH_HAS_IN1) ? in1 : zero_f32();
     const float b = (flags & MATH_HAS_IN2) ? in2 : constant;
     const bool pos = a > 0.0f;
-    const float r = powf_pos(pos ? a : -a, b, (flags & NONLIN_EXACT) != 0);
+    const float r = powf_pos(pos ? a : -a, b, (flags & NONLIN_EXACT) != 0, tab);
     return pos ? r : -r;
 }
 
@@ -1338,16 +1369,9 @@ SRK_DEV float nonlin_step(uint32_t flags, float in1, float in2, float constant)
 // (tab[i] = bits(2^(i/32)) - (i << 47)), 2^r by the cubic below, one rounding to f32.  Checked against glibc
 // 2.35's powf on 2e8 random arguments in [-20, 20) with zero mismatches (tests/test_oracle.py holds the
 // CPU-side check of this same formula); the read position it scales is an INDEX, hence bit-exactness.
-__device__ const uint64_t kExp2fTab[32] = {
-    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b, 0x3fef54873168b9aa,
-    0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
-    0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74,
-    0x3feea11473eb0187, 0x3feea589994cce13, 0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
-    0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
-    0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
-};
 
-SRK_DEV float pow2f_libm(float y)
+template <class Tab = GlobalTables>
+SRK_DEV float pow2f_libm(float y, const Tab tab = Tab{})
 {
     if (y != y) return y + 2.0f;                  // NaN
     if (y >= 128.0f) return __builtin_inff();     // f64(y) > 0x1.fffffffd1d571p+6: overflow (covers +inf)
@@ -1358,7 +1382,7 @@ SRK_DEV float pow2f_libm(float y)
     const uint64_t ki = (uint64_t)__double_as_longlong(kd);
     kd -= shift;
     const double r = xd - kd;
-    const uint64_t t = kExp2fTab[ki & 31u] + (ki << 47);
+    const uint64_t t = tab.exp2f((uint32_t)ki & 31u) + (ki << 47);
     const double s = __longlong_as_double((long long)t);
     const double z = 0x1.c6af84b912394p-5 * r + 0x1.ebfce50fac4f3p-3;
     const double r2 = r * r;
@@ -1413,7 +1437,8 @@ struct SmpRegs {
 // One sample of the position state machine; returns the index read this sample.  `ratio` =
 // wavebox.sample_rate / self.sample_rate (f32 divide, loop-invariant).  `as usize` saturates and maps NaN to 0;
 // the clamp below does the same within u32 (wave lengths are < 2^31, so any index >= 2^32 is out of range anyway).
-SRK_DEV uint32_t sample_advance(uint32_t flags, SmpRegs& s, float ratio, uint32_t n_wave, float gate, float cv)
+template <class Tab = GlobalTables>
+SRK_DEV uint32_t sample_advance(uint32_t flags, SmpRegs& s, float ratio, uint32_t n_wave, float gate, float cv, const Tab tab = Tab{})
 {
     if (rising_edge(s.gate_last, (flags & SMP_HAS_GATE) ? gate : 0.0f)) {
         s.pos = 0.0f;
@@ -1425,7 +1450,7 @@ SRK_DEV uint32_t sample_advance(uint32_t flags, SmpRegs& s, float ratio, uint32_
         s.playing = false;
         idx = 0u;
     }
-    if (s.playing) s.pos += (flags & SMP_HAS_CV) ? ratio * pow2f_libm(cv) : ratio * 1.0f;
+    if (s.playing) s.pos += (flags & SMP_HAS_CV) ? ratio * pow2f_libm(cv, tab) : ratio * 1.0f;
     return idx;
 }
 

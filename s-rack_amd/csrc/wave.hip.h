@@ -132,6 +132,51 @@ SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n, uint32_t V
     if (kBarrier) __syncthreads();
 }
 
+// Several planes, ONE tile (kernels generated for patches with two or more planes fed by wires, default mode): a tile per plane is
+// 8.7 KB of LDS each, and two of them already hold a CU to eight one-wave workgroups — two waves per SIMD, which leaves dependent
+// arithmetic (P4's two powers per sample) half the issue slots (rocprofv3: VALU busy 50 % at two and at "four" waves per SIMD, the
+// latter running in two rounds).  Plane j owns rows [j, j + 1) * kRows of the one tile, kRows = 32 / (planes, rounded up to a power of
+// two); after the last plane's sample that fills them — every kRows samples — ONE pass sums all 32 rows exactly as emit_flush does (same
+// reads, same additions: a plane's mix is bit for bit what its own tile gave) and lane r + j kRows stores row r of plane j.
+template <int kOut>
+SRK_DEV void emit_put_rows(Emit& e, float* rows, float o, int r, uint32_t V)  // rows = this plane's rows of the tile, r = i mod kRows
+{
+    const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
+    const bool mix = kOut == 0 ? e.has_mix : (kOut & 2) != 0;
+    if (frames) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), e.rsrc, e.lane_c * 4, (int)e.soff, SRK_FRAME_AUX);
+        e.soff += V * 4u;
+    }
+    if (mix) rows[r * kMixPitch + e.lane] = o;
+}
+template <int kRows>
+SRK_DEV void emit_rows_flush(const Emit& e, float* tile, float* mp_lane, uint32_t t_first, int n_valid)  // mp_lane: the mixpart row of the plane lane & 31 belongs to (or null)
+{
+    static_assert(kRows == 16 || kRows == 8 || kRows == 4, "rows per plane");
+    if (!e.full_wave && (uint32_t)e.lane >= e.n_active)
+        for (int r = 0; r < kMixRows; r++) tile[r * kMixPitch + e.lane] = 0.0f;
+    __syncthreads();
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* p = (const f4*)(tile + (e.lane & 31) * kMixPitch + (e.lane >> 5) * 32);
+    f4 acc = p[0];
+#pragma unroll
+    for (int q = 1; q < 8; q++) acc += p[q];
+    float sum = (acc.x + acc.y) + (acc.z + acc.w);
+    sum += __shfl_xor(sum, 32);
+    const int r = e.lane & (kRows - 1);
+    if (e.lane < 32 && r < n_valid && mp_lane) mp_lane[t_first + (uint32_t)r] = sum;
+    __syncthreads();
+}
+template <int kOut>
+SRK_DEV void emit_rows_end(Emit& e, int n, uint32_t V)  // end of a 32-sample tile: the mix is already out; the frame descriptor moves on
+{
+    const bool frames = kOut == 0 ? e.has_frames : (kOut & 1) != 0;
+    if (frames) {
+        e.frame_row += (size_t)n * V;
+        emit_rebase(e);
+    }
+}
+
 // ---- experiment (round 3, -DSRK_MIX_MFMA=1): the mix-down's cross-lane sum on the matrix pipe --------------------------------------
 // v_mfma_f32_16x16x4_f32 is exact f32 (a k-ordered fmaf chain) and runs beside the VALU.  With the sample as the A operand
 // (A[i][k] = lane 16 k + i) and a one-hot column selector as B (B[k][j] = [j == t mod 16]), sample t adds its four-lane partial sums
