@@ -77,6 +77,7 @@ struct Analysis {  // whole-graph facts shared by both programs
     std::vector<char> in_ctl;
     std::vector<int> stage;                          // per module: control stage (>= 0) or -1 = voice program
     std::vector<char> sine_loose;                    // per oscillator: its sine port cannot reach a pitch input (OSC_SINE_LOOSE)
+    std::vector<char> nonlin_loose;                  // per NonLinear module: its output cannot reach a pitch input or a threshold (NONLIN_LOOSE)
     std::vector<char> exact_src;                     // per oscillator / filter, default mode: an approximated output of it can reach a pitch input
                                                      // (OSC_EXACT_BLEP / VCF_LITERAL)
     std::vector<std::pair<int, int>> tracks;         // (module, port) exported by a control stage
@@ -357,6 +358,7 @@ int Builder::build()
             if (connected(0)) op.flags |= MATH_HAS_IN1;
             if (connected(1)) op.flags |= MATH_HAS_IN2;
             if (render_flags & SRACK_RENDER_EXACT_OSC) op.flags |= NONLIN_EXACT;
+            else if (A.nonlin_loose[(size_t)m]) op.flags |= NONLIN_LOOSE;
             param(op, NONLIN_P_CONST, m, SRACK_NONLIN_CONSTANT, deferred);
             break;
         case SRACK_MOD_FREEVERB: {  // freeverb.rs + the freeverb crate's Freeverb::new / set_* (restated; see oracle/srack_oracle.c)
@@ -1037,6 +1039,15 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                     std::vector<uint32_t> from((size_t)n_mod, 0u);
                     from[(size_t)m] = 1u;
                     A.sine_loose[(size_t)m] = !reaches_pitch(from, true);
+                }
+        // The same for a NonLinear module's power: through the f32 transcendental unit where nothing integrates the result (modules.hip.h, powf_pos)
+        A.nonlin_loose.assign((size_t)n_mod, 0);
+        if (!(render_flags & SRACK_RENDER_EXACT_OSC) && !getenv("SRACK_NONLIN_F64"))
+            for (int m = 0; m < n_mod; m++)
+                if (A.live[(size_t)m] && g.modules[(size_t)m].type == SRACK_MOD_NONLINEAR) {
+                    std::vector<uint32_t> from((size_t)n_mod, 0u);
+                    from[(size_t)m] = 1u;
+                    A.nonlin_loose[(size_t)m] = !reaches_pitch(from, true);
                 }
       A.exact_src.assign((size_t)n_mod, 0);
       if (!(render_flags & SRACK_RENDER_EXACT_OSC)) {

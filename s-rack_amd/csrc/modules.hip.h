@@ -1350,13 +1350,27 @@ SRK_DEV float powf_pos(float x, float b, bool exact, const Tab tab = Tab{})
     return r;
 }
 
+// NONLIN_LOOSE (the flattener: nothing integrates or thresholds this module's output): x^b = 2^(b log2 x) through v_log_f32 / v_exp_f32 —
+// one ulp each, i.e. a relative error of about 1.3e-7 |b log2 x|; taken while |b log2 x| < 32 (4e-6), everything else as powf_pos.
+template <class Tab = GlobalTables>
+SRK_DEV float powf_pos_loose(float x, float b, const Tab tab = Tab{})
+{
+    const float y = b * __builtin_amdgcn_logf(x >= 0x1p-126f ? x : 1.0f);
+    const bool fast = x >= 0x1p-126f && x < __builtin_inff() && __builtin_fabsf(y) < 32.0f;  // NaN x / b / y: false
+    float r = __builtin_amdgcn_exp2f(fast ? y : 0.0f);
+    if (__builtin_amdgcn_ballot_w64(!fast)) {
+        if (!fast) r = powf_pos(x, b, false, tab);
+    }
+    return r;
+}
+
 template <class Tab = GlobalTables>
 SRK_DEV float nonlin_step(uint32_t flags, float in1, float in2, float constant, const Tab tab = Tab{})
 {
     const float a = (flags & MATH_HAS_IN1) ? in1 : zero_f32();
     const float b = (flags & MATH_HAS_IN2) ? in2 : constant;
     const bool pos = a > 0.0f;
-    const float r = powf_pos(pos ? a : -a, b, (flags & NONLIN_EXACT) != 0, tab);
+    const float r = (flags & NONLIN_LOOSE) ? powf_pos_loose(pos ? a : -a, b, tab) : powf_pos(pos ? a : -a, b, (flags & NONLIN_EXACT) != 0, tab);
     return pos ? r : -r;
 }
 

@@ -87,6 +87,8 @@ enum : uint32_t {
     MATH_OP_SHIFT = 4,        // bits 4..5 = SRACK_MATH_ADD / SUBTRACT / MULTIPLY
     // OP_NONLIN: MATH_HAS_IN1 / MATH_HAS_IN2, and
     NONLIN_EXACT = 1u << 8,   // exact render mode: ocml's f64 log2 inside the power (default: a table-driven one, modules.hip.h)
+    NONLIN_LOOSE = 1u << 9,   // host-proved, default mode only: the output can reach neither a pitch input nor a threshold, so nothing integrates or
+                              // amplifies its rounding — the power goes through the f32 transcendental unit (v_log_f32, v_exp_f32: 1e-7 |b log2 x|)
     // OP_SAMPLE
     SMP_HAS_GATE = 1u << 0,
     SMP_HAS_CV = 1u << 1,

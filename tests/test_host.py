@@ -580,3 +580,29 @@ def test_ranks_starting_together_compile_once(tmp_path):
         assert pr.returncode == 0, err[-3000:]
         stats.append(json.loads(out.strip().splitlines()[-1]))
     assert sum(s["compiled"] for s in stats) == 1 and sum(s["disk_hits"] for s in stats) == 2
+
+
+def test_nonlinear_takes_the_f32_power_only_where_nothing_integrates_it(S):
+    """NONLIN_LOOSE (program.hpp): the flattener proves that a NonLinear module's output can reach neither a pitch input nor a threshold —
+    P4's shaper feeds the OutputModule only — before the default mode's power goes through v_log_f32 / v_exp_f32; a shaper in front of an
+    oscillator's CV, or of an envelope's gate, keeps the f64 power, and the exact mode never takes it."""
+    import re
+
+    def nonlin_flags(p, flags=0):
+        src = p.kernel_source(flags | S.RENDER_NO_UNIFORM_HOIST)
+        return [int(x, 16) for x in re.findall(r"nonlin_step\((0x[0-9a-f]+)u", src)]
+
+    p = S.Patch(48000, 1024, 2)
+    S.build_p4(p)
+    p.configure_voices(8)
+    assert [f & 0x200 for f in nonlin_flags(p)] == [0x200]
+    assert [f & 0x300 for f in nonlin_flags(p, S.RENDER_EXACT_OSC)] == [0x100]            # NONLIN_EXACT
+    for sink_type, sink_port in ((S.MOD_OSCILLATOR, 0), (S.MOD_ADSR, 0)):                  # a pitch CV; a gate (a threshold)
+        q = S.Patch(48000, 1024, 2)
+        osc, shaper, sink, out = q.add_module(S.MOD_OSCILLATOR), q.add_module(S.MOD_NONLINEAR), q.add_module(sink_type), q.add_module(S.MOD_OUTPUT)
+        q.connect(osc, S.OSC_OUT_SINE, shaper, 0)
+        q.connect(shaper, 0, sink, sink_port)
+        q.connect(sink, 0, out, 0)
+        q.connect(shaper, 0, out, 1)
+        q.configure_voices(8)
+        assert [f & 0x200 for f in nonlin_flags(q)] == [0], sink_type
