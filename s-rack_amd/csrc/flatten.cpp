@@ -1191,7 +1191,83 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             for (const InputRef& in : g.modules[(size_t)m].in)
                 if (in.src >= 0 && A.in_ctl[(size_t)in.src] && pos[(size_t)in.src] > pos[(size_t)m]) feedback = true;
         }
-        if (n_ctl >= kMinModulesToSplit && !feedback) {
+        if (n_ctl >= kMinModulesToSplit && feedback && !getenv("SRACK_CTL_ONE_UNIT_ON_FEEDBACK")) {
+            // Feedback inside the control sub-graph: the modules of a cycle must share a unit (the delayed edge is a ring inside it), everything
+            // else is pipelined as without feedback — units are the strongly connected components of the control sub-graph (Tarjan; a wire is
+            // an edge whether the planner delayed it or not).  Until round 3 one such edge kept the WHOLE control program one unit: one lane's
+            // latency chain through all its modules, 0.6 - 1.4 us per sample on random patches (NOTES R3.10).
+            std::vector<int> index((size_t)n_mod, -1), low((size_t)n_mod, 0), comp((size_t)n_mod, -1), stack;
+            std::vector<char> on_stack((size_t)n_mod, 0);
+            int counter = 0, n_comp = 0;
+            std::vector<std::vector<int>> sinks_of((size_t)n_mod);
+            for (int m = 0; m < n_mod; m++)
+                if (A.in_ctl[(size_t)m])
+                    for (const InputRef& in : g.modules[(size_t)m].in)
+                        if (in.src >= 0 && A.in_ctl[(size_t)in.src]) sinks_of[(size_t)in.src].push_back(m);
+            struct Frame { int v; size_t next; };
+            for (int root = 0; root < n_mod; root++) {
+                if (!A.in_ctl[(size_t)root] || index[(size_t)root] >= 0) continue;
+                std::vector<Frame> call{{root, 0}};
+                index[(size_t)root] = low[(size_t)root] = counter++;
+                stack.push_back(root);
+                on_stack[(size_t)root] = 1;
+                while (!call.empty()) {
+                    Frame& f = call.back();
+                    if (f.next < sinks_of[(size_t)f.v].size()) {
+                        const int w = sinks_of[(size_t)f.v][f.next++];
+                        if (index[(size_t)w] < 0) {
+                            index[(size_t)w] = low[(size_t)w] = counter++;
+                            stack.push_back(w);
+                            on_stack[(size_t)w] = 1;
+                            call.push_back({w, 0});
+                        } else if (on_stack[(size_t)w]) {
+                            low[(size_t)f.v] = std::min(low[(size_t)f.v], index[(size_t)w]);
+                        }
+                    } else {
+                        const int v = f.v;
+                        if (low[(size_t)v] == index[(size_t)v]) {
+                            for (;;) {
+                                const int w = stack.back();
+                                stack.pop_back();
+                                on_stack[(size_t)w] = 0;
+                                comp[(size_t)w] = n_comp;
+                                if (w == v) break;
+                            }
+                            n_comp++;
+                        }
+                        call.pop_back();
+                        if (!call.empty()) low[(size_t)call.back().v] = std::min(low[(size_t)call.back().v], low[(size_t)v]);
+                    }
+                }
+            }
+            if (n_comp >= 2) {  // (one component: the whole control program is one cycle — nothing to pipeline)
+                std::vector<int> unit_of_comp((size_t)n_comp, -1);
+                unit_lag.clear();
+                for (int m : g.plan.order) {  // units numbered by first appearance in the plan
+                    if (!A.in_ctl[(size_t)m]) continue;
+                    int& u = unit_of_comp[(size_t)comp[(size_t)m]];
+                    if (u < 0) {
+                        u = (int)unit_lag.size();
+                        unit_lag.push_back(0);
+                    }
+                    A.stage[(size_t)m] = u;
+                }
+                for (bool changed = true; changed;) {  // depths over the condensation (a DAG): a unit trails every unit it reads by one chunk
+                    changed = false;
+                    for (int m = 0; m < n_mod; m++) {
+                        if (!A.in_ctl[(size_t)m]) continue;
+                        for (const InputRef& in : g.modules[(size_t)m].in) {
+                            if (in.src < 0 || !A.in_ctl[(size_t)in.src] || A.stage[(size_t)in.src] == A.stage[(size_t)m]) continue;
+                            const int need = unit_lag[(size_t)A.stage[(size_t)in.src]] + 1;
+                            if (unit_lag[(size_t)A.stage[(size_t)m]] < need) {
+                                unit_lag[(size_t)A.stage[(size_t)m]] = need;
+                                changed = true;
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (n_ctl >= kMinModulesToSplit && !feedback) {
             unit_lag.clear();
             for (int m : g.plan.order) {  // plan order: every non-delayed source comes first
                 if (!A.in_ctl[(size_t)m]) continue;
@@ -1201,6 +1277,8 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                 A.stage[(size_t)m] = (int)unit_lag.size();
                 unit_lag.push_back(depth);
             }
+        }
+        if (unit_lag.size() > 1) {
             for (int m : g.plan.order) {  // wires between units travel as tracks too
                 if (!A.in_ctl[(size_t)m]) continue;
                 for (const InputRef& in : g.modules[(size_t)m].in)
