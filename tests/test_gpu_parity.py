@@ -6,6 +6,7 @@ The f32 modules are bit-exact by construction; with SRACK_RENDER_EXACT_OSC the o
 square are too, so chains that use only those ports are compared bit for bit in that mode.
 """
 import os
+import re
 
 import numpy as np
 import pytest
@@ -847,6 +848,59 @@ def test_p4_default_mode_index_slips_are_rare(S, oracle):
     assert same.mean() > 0.999
     err = np.abs(fr[0].astype(np.float64) - ref[0]) / np.maximum(np.abs(ref[0]), 1.0)
     assert (err[same] <= TOL).all()
+
+
+def test_p4_exactly_as_benchmarked(S, oracle):
+    """`bench.py --workload p4` at full size (SURVEY 8(f4)'s modules): 131 072 voices x 48 000 samples, two planes (50 GB of frames, kept on
+    the device), default mode — the specialised kernel with the planes' shared mix tile and NonLinear's power through the f32
+    transcendental unit.  34 sampled voices against the oracle for the whole second: the raw sample plane bit for bit but for the rare
+    index slips of the default mode's f32 LFO sine (< 0.1 % of the samples), the shaper within the contract wherever the player read
+    the same sample; both mixes against f64 sums of all the frames."""
+    import ctypes as C
+    V, T = 131072, 48000
+    depth, expo = S.p4_voice_params(V)
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p4(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["depth"], S.MATH_CONSTANT, depth)
+    p.set_voice_field(ids["shaper"], S.NONLIN_CONSTANT, expo)
+    assert p.planes() == (2, [0, 1])
+    d_fr, d_mx = C.c_void_p(), C.c_void_p()
+    assert S.lib.srack_device_alloc(C.byref(d_fr), 2 * T * V * 4) == 0 and S.lib.srack_device_alloc(C.byref(d_mx), 2 * T * 4) == 0
+    try:
+        p.render_raw(T, d_fr, d_mx, 0, None)
+        assert S.lib.srack_device_sync(None) == 0
+        assert "kernel=render_specialized" in p.info()
+        src = p.kernel_source(0)
+        assert "emit_rows_flush<16>" in src and re.search(r"nonlin_step\(0x[0-9a-f]*2[0-9a-f]{2}u", src)   # the shared tile; NONLIN_LOOSE (0x200)
+        pick = np.unique(np.concatenate([np.arange(0, V, 4099), [0, 63, 64, V - 65, V - 64, V - 1]]))
+        got = np.empty((2, T, len(pick)), dtype=np.float32)
+        own, scale = np.empty((2, T)), np.empty((2, T))
+        rows = 1024
+        buf = np.empty((rows, V), dtype=np.float32)
+        for plane in range(2):
+            for t0 in range(0, T, rows):
+                n = min(rows, T - t0)
+                assert S.lib.srack_device_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + (plane * T + t0) * V * 4), n * V * 4, None) == 0
+                assert S.lib.srack_device_sync(None) == 0
+                got[plane, t0:t0 + n] = buf[:n, pick]
+                own[plane, t0:t0 + n] = buf[:n].sum(axis=1, dtype=np.float64)
+                scale[plane, t0:t0 + n] = np.abs(buf[:n]).sum(axis=1, dtype=np.float64)
+        mix = np.empty((2, T), dtype=np.float32)
+        assert S.lib.srack_device_to_host(mix.ctypes.data_as(C.c_void_p), d_mx, mix.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
+    finally:
+        S.lib.srack_device_free(d_fr)
+        S.lib.srack_device_free(d_mx)
+    o = oracle.OraclePatch(48000, 1024, 2)
+    S.build_p4(o)
+    ref, _ = o.render_batch(len(pick), T, [(ids["depth"], S.MATH_CONSTANT, depth[pick]), (ids["shaper"], S.NONLIN_CONSTANT, expo[pick])], threads=8)
+    same = bits(got[1]) == bits(ref[1])
+    assert same.mean() > 0.999, same.mean()
+    err = np.abs(got[0].astype(np.float64) - ref[0]) / np.maximum(np.abs(ref[0]), 1.0)
+    assert (err[same] <= TOL).all(), err[same].max()
+    assert np.abs(got[1]).max() > 0.3
+    for plane in range(2):
+        assert (np.abs(mix[plane].astype(np.float64) - own[plane]) <= 1e-5 * np.maximum(scale[plane], 1.0)).all(), plane
 
 
 @pytest.mark.parametrize("B", [1, 64])
