@@ -725,6 +725,62 @@ def test_p3_sequencers_vs_oracle(S, oracle, flags):
     assert (steps == steps[0]).all() and 0 <= steps[0] < 8
 
 
+def test_p3_exactly_as_benchmarked(S, oracle):
+    """`bench.py --workload p3` at full size (the sequencers as control tracks): 262 144 voices x 48 000 samples, two planes
+    (100 GB of frames, kept on the device), default mode — the specialised kernel with five control units on its launches.  Sampled voices
+    against the oracle over the whole second (plane 1, the raw pattern gate, exactly); plane 0's mix against the f64 sum of all its frames,
+    plane 1's against voices x gate."""
+    import ctypes as C
+    V, T = 262144, 48000
+    u0, u1 = S.voice_uniform(V, 0), S.voice_uniform(V, 1)
+    transpose = (u0 * np.float32(2.5) - np.float32(2.0)).astype(np.float32)   # bench.py's draw
+    cut = (np.float32(0.05) + u1 * np.float32(0.35)).astype(np.float32)
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p3(p)
+    p.configure_voices(V)
+    p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, transpose)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    assert p.planes() == (2, [0, 1])
+    d_fr, d_mx = C.c_void_p(), C.c_void_p()
+    assert S.lib.srack_device_alloc(C.byref(d_fr), 2 * T * V * 4) == 0 and S.lib.srack_device_alloc(C.byref(d_mx), 2 * T * 4) == 0
+    try:
+        p.render_raw(T, d_fr, d_mx, 0, None)
+        assert S.lib.srack_device_sync(None) == 0
+        assert "kernel=render_specialized" in p.info() and p.info().count("ctl[") == 5
+        pick = np.unique(np.concatenate([np.arange(0, V, 8209), [0, 63, 64, V - 65, V - 64, V - 1]]))
+        got = np.empty((2, T, len(pick)), dtype=np.float32)
+        own, scale = np.empty(T), np.empty(T)
+        rows = 1024
+        buf = np.empty((rows, V), dtype=np.float32)
+        for t0 in range(0, T, rows):   # plane 0 in full (50 GB over PCIe), plane 1 (every voice the same gate) at the sampled voices
+            n = min(rows, T - t0)
+            assert S.lib.srack_device_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + t0 * V * 4), n * V * 4, None) == 0
+            assert S.lib.srack_device_sync(None) == 0
+            got[0, t0:t0 + n] = buf[:n, pick]
+            own[t0:t0 + n] = buf[:n].sum(axis=1, dtype=np.float64)
+            scale[t0:t0 + n] = np.abs(buf[:n]).sum(axis=1, dtype=np.float64)
+        row = np.empty(V, dtype=np.float32)
+        for t in range(0, T, 997):   # plane 1: whole rows at a stride (every voice must carry the same gate)
+            assert S.lib.srack_device_to_host(row.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + ((T + t) * V) * 4), V * 4, None) == 0
+            assert S.lib.srack_device_sync(None) == 0
+            assert (row == row[0]).all(), t
+            got[1, t] = row[pick]
+        mix = np.empty((2, T), dtype=np.float32)
+        assert S.lib.srack_device_to_host(mix.ctypes.data_as(C.c_void_p), d_mx, mix.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
+    finally:
+        S.lib.srack_device_free(d_fr)
+        S.lib.srack_device_free(d_mx)
+    o = oracle.OraclePatch(48000, 1024, 2)
+    S.build_p3(o)
+    ref, _ = o.render_batch(len(pick), T, [(ids["transpose"], S.MATH_CONSTANT, transpose[pick]), (ids["vcf"], S.VCF_FREQ, cut[pick])], threads=8)
+    assert assert_close(got[0], ref[0]) < 5e-6
+    at = np.arange(0, T, 997)
+    np.testing.assert_array_equal(got[1][at], ref[1][at])   # the raw gate: exactly 0.0 / 1.0 / the clock's square
+    assert np.abs(got[0]).max() > 0.1 and ref[1].max() > 0.5
+    assert (np.abs(mix[0].astype(np.float64) - own) <= 1e-5 * np.maximum(scale, 1.0)).all()
+    assert (np.abs(mix[1].astype(np.float64) - V * ref[1][:, 0].astype(np.float64)) <= 1e-5 * np.maximum(V * np.abs(ref[1][:, 0]), 1.0)).all()
+
+
 @pytest.mark.parametrize("flags", [pytest.param(0, id="fused"), pytest.param(2, id="interp")])
 def test_p3_extreme_transpose_takes_the_literal_oscillator(S, oracle, flags):
     """Notes whose phase increment reaches a quarter cycle (>= 12 kHz at 48 kHz) leave the carried-phase form: lanes on both
