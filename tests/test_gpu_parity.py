@@ -128,19 +128,24 @@ def test_p1_voices_vs_oracle_and_mix(S, oracle, V, flags):
     np.testing.assert_array_equal(mix[0], mix[1])
 
 
-def test_cfg2_identical_voices(S, oracle):
-    """config 2: 4096 identical voices, same patch — every column equals the 1-voice oracle render."""
-    T, V = 4096, 4096
+@pytest.mark.parametrize("lfo_val", [pytest.param(-8.0, id="as-benchmarked"), pytest.param(-2.0, id="fast-gate")])
+def test_cfg2_identical_voices(S, oracle, lfo_val):
+    """config 2 at full size — 4096 identical voices, the whole second (BASELINE's gate LFO at 1.72 Hz first rises at sample 13 964; a
+    110 Hz gate beside it keeps the envelope busy throughout): every column equals the 1-voice oracle render, the kernel is the one
+    `bench.py` times for config 2 (five control units + a broadcast)."""
+    T, V = 48000, 4096
     o = oracle.OraclePatch(48000, 1024, 2)
-    S.build_p1(o, lfo_val=-2.0)
-    ref = o.render(T)[0]
+    S.build_p1(o, lfo_val=lfo_val)
+    ref = np.concatenate([o.render(1024)[0] for _ in range(47)])[:T]   # 47 ticks of buffer_size samples, truncated: SURVEY 8(a1)
     p = S.Patch(48000, 1024, 2)
-    S.build_p1(p, lfo_val=-2.0)
+    S.build_p1(p, lfo_val=lfo_val)
     p.configure_voices(V)
     fr, mix = p.render(T)
+    assert "kernel=render_specialized" in p.info() and p.info().count("ctl[") == 5, p.info()
     assert (fr[0] == fr[0][:, :1]).all()
     assert_close(fr[0][:, 0], ref)
     assert_close(mix[0] / V, ref, tol=2e-5)
+    assert np.abs(ref).max() > 0.05
 
 
 # ---- control units evaluated across lanes (voice-invariant modules of a specialised kernel) --------------------------------
