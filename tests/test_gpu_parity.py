@@ -513,6 +513,56 @@ def test_full_size_voices_short_render(S, oracle):
     assert (np.abs(mix[0] - own) <= 1e-5 * np.maximum(scale, 1.0)).all()
 
 
+def test_cfg3_ticked_as_benchmarked(S):
+    """`cfg3_ticked_1024_ms_per_step` on the bench line, checked: config 3 at full size driven the way the reference's audio callback drives
+    `execute` — 47 calls of 1024 samples (a tick session: the control track of call c + 1 is computed under the voices of call c) —
+    against the same second in ONE call, on the device: whole frame rows at a stride and both mixes, bit for bit."""
+    import ctypes as C
+    V, T, L = 262144, 48000, 1024
+    det, cut = S.p1_voice_params(V)
+
+    def patch():
+        p = S.Patch(48000, 1024, 2)
+        ids = S.build_p1(p)
+        p.configure_voices(V)
+        p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+        p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+        return p
+
+    bufs = [C.c_void_p() for _ in range(4)]
+    for b, n in zip(bufs, (T * V * 4, T * V * 4, 2 * T * 4, 2 * T * 4)):
+        assert S.lib.srack_device_alloc(C.byref(b), n) == 0
+    fr_one, fr_tick, mx_one, mx_tick = bufs
+    try:
+        one = patch()
+        one.render_raw(T, fr_one, mx_one, 0, None)
+        tick = patch()
+        for t in range(0, T, L):   # a call's mix is [2][n] of its own: at 2 t floats into the buffer
+            n = min(L, T - t)
+            tick.render_raw(n, C.c_void_p(fr_tick.value + t * V * 4), C.c_void_p(mx_tick.value + 2 * t * 4), 0, None)
+        assert S.lib.srack_device_sync(None) == 0
+        assert "kernel=render_voice_chain_track" in tick.info()
+        a, b = np.empty(V, dtype=np.float32), np.empty(V, dtype=np.float32)
+        loud = 0.0
+        for t in list(range(0, T, 89)) + [1023, 1024, 1025, T - 897, T - 896, T - 1]:
+            for dst, src in ((a, fr_one), (b, fr_tick)):
+                assert S.lib.srack_device_to_host(dst.ctypes.data_as(C.c_void_p), C.c_void_p(src.value + t * V * 4), V * 4, None) == 0
+            assert S.lib.srack_device_sync(None) == 0
+            np.testing.assert_array_equal(bits(a), bits(b), err_msg=f"row {t}")
+            loud = max(loud, float(np.abs(a).max()))
+        assert loud > 0.05
+        m1, m2 = np.empty((2, T), dtype=np.float32), np.empty(2 * T, dtype=np.float32)
+        assert S.lib.srack_device_to_host(m1.ctypes.data_as(C.c_void_p), mx_one, m1.nbytes, None) == 0
+        assert S.lib.srack_device_to_host(m2.ctypes.data_as(C.c_void_p), mx_tick, m2.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
+        for t in range(0, T, L):
+            n = min(L, T - t)
+            blk = m2[2 * t:2 * t + 2 * n].reshape(2, n)
+            np.testing.assert_array_equal(bits(blk), bits(m1[:, t:t + n]), err_msg=f"mix of the call at {t}")
+    finally:
+        for b in bufs:
+            S.lib.srack_device_free(b)
+
+
 def test_cfg3_exactly_as_benchmarked(S, oracle):
     """BASELINE config 3 at full size, the very workload bench.py times: 262 144 voices x 48 000 samples (50 GB of frames,
     kept on the device), default mode.  67 sampled voices against the oracle for the whole second, and the stereo mix
