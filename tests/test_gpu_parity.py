@@ -513,6 +513,48 @@ def test_full_size_voices_short_render(S, oracle):
     assert (np.abs(mix[0] - own) <= 1e-5 * np.maximum(scale, 1.0)).all()
 
 
+def test_two_million_voices_on_one_gpu(S, oracle):
+    """Maximum sizes: config 5's 2 097 152 voices as ONE patch on one GPU (2048 samples: 17 GB of frames), first / last / sampled
+    voices against the oracle, the mix against f64 sums of whole frame rows; and the limit itself (2^24 voices: a tile of 32 frame
+    rows must fit a 31-bit buffer offset) is refused with an error, not rendered wrongly."""
+    import ctypes as C
+    V, T = 2097152, 2048
+    det, cut = S.p1_voice_params(V)
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p1(p, adsr="finite", lfo_val=-2.0)
+    p.configure_voices(V)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    d_fr, d_mx = C.c_void_p(), C.c_void_p()
+    assert S.lib.srack_device_alloc(C.byref(d_fr), T * V * 4) == 0 and S.lib.srack_device_alloc(C.byref(d_mx), 2 * T * 4) == 0
+    try:
+        p.render_raw(T, d_fr, d_mx, 0, None)
+        assert S.lib.srack_device_sync(None) == 0
+        assert "kernel=render_voice_chain_track" in p.info()
+        pick = np.unique(np.concatenate([np.arange(0, V, 52429), [0, 63, 64, V - 65, V - 64, V - 1]]))
+        ts = np.unique(np.concatenate([np.arange(0, T, 16), [31, 32, 1023, 1024, T - 1]]))
+        row = np.empty(V, dtype=np.float32)
+        got, own, scale = np.empty((len(ts), len(pick)), dtype=np.float32), np.empty(len(ts)), np.empty(len(ts))
+        for k, t in enumerate(ts):
+            assert S.lib.srack_device_to_host(row.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + int(t) * V * 4), V * 4, None) == 0
+            got[k], own[k], scale[k] = row[pick], row.sum(dtype=np.float64), np.abs(row).sum(dtype=np.float64)
+        mix = np.empty((2, T), dtype=np.float32)
+        assert S.lib.srack_device_to_host(mix.ctypes.data_as(C.c_void_p), d_mx, mix.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
+    finally:
+        S.lib.srack_device_free(d_fr)
+        S.lib.srack_device_free(d_mx)
+    o = oracle.OraclePatch(48000, 1024, 2)
+    S.build_p1(o, adsr="finite", lfo_val=-2.0)
+    ref, _ = o.render_batch(len(pick), T, [(ids["osc_a"], S.OSC_VAL, det[pick]), (ids["vcf"], S.VCF_FREQ, cut[pick])], threads=8)
+    assert_close(got, ref[0][ts])
+    assert np.abs(ref).max() > 0.3
+    assert (np.abs(mix[0][ts].astype(np.float64) - own) <= 1e-5 * np.maximum(scale, 1.0)).all() and np.array_equal(mix[0], mix[1])
+    q = S.Patch(48000, 1024, 2)
+    S.build_p1(q)
+    with pytest.raises(S.SrackError):
+        q.configure_voices((1 << 24) + 1)
+
+
 def test_cfg3_ticked_as_benchmarked(S):
     """`cfg3_ticked_1024_ms_per_step` on the bench line, checked: config 3 at full size driven the way the reference's audio callback drives
     `execute` — 47 calls of 1024 samples (a tick session: the control track of call c + 1 is computed under the voices of call c) —
