@@ -132,7 +132,8 @@ SRK_DEV void emit_flush(Emit& e, float* mix_tile, uint32_t t0, int n, uint32_t V
     if (kBarrier) __syncthreads();
 }
 
-// Several planes, ONE tile (kernels generated for patches with two or more planes fed by wires, default mode): a tile per plane is
+// Several planes, ONE tile (kernels generated for patches with two or more planes fed by wires, unless a tile-wise exact saw borrows a
+// plane's tile — jit.cpp): a tile per plane is
 // 8.7 KB of LDS each, and two of them already hold a CU to eight one-wave workgroups — two waves per SIMD, which leaves dependent
 // arithmetic (P4's two powers per sample) half the issue slots (rocprofv3: VALU busy 50 % at two and at "four" waves per SIMD, the
 // latter running in two rounds).  Plane j owns rows [j, j + 1) * kRows of the one tile, kRows = 32 / (planes, rounded up to a power of
