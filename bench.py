@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py — voice-samples/sec of the batch render on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg4_b1024|p3|p4] [--flags F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg3_poly|cfg2|cfg4|cfg4_b1024|p3|p4] [--flags F]
 
 Workloads (BASELINE.json `configs`; SURVEY 8(d) spells them out):
     cfg3 (default; = config 5 at 8 GPUs)  patch P1 saw VCO -> ladder VCF -> VCA, ADSR gated by an LFO square; 262 144 voices per GPU,
                  per-voice randomised detune / cutoff — the configuration the metric is quoted on
+    cfg3_poly    the same patch and voice count with NOTHING voice-invariant: per-voice gate-LFO rate and per-voice envelope times on top of
+                 detune / cutoff (every voice its own notes: real polyphony) — the whole of P1 evaluated per voice, one voice per lane
     cfg2         the same patch, 4 096 IDENTICAL voices (plumbing: everything is voice-invariant, one latency chain)
     cfg4         patch P2, 2-operator FM with a feedback edge, 65 536 voices, buffer_size 1 (z^-1 held in a register)
     cfg4_b1024   the same at the app's buffer_size 1024 (the feedback delay is a ring in HBM)
@@ -20,10 +22,11 @@ when WORLD_SIZE is not set — bench.py starts the N ranks itself (one per devic
 The control plane (barrier, max over ranks, handing the RCCL unique id around) is torch.distributed/gloo on CPU tensors;
 the data path never touches it.
 
-The default run (cfg3, 1 GPU, default sizes) ALSO times the other two single-GPU BASELINE configurations after the headline
-steps — config 2 (4 096 identical voices) and config 4 (P2 FM pair, buffer_size 1, 65 536 voices), SIDE_STEPS steps each after one
-warm-up, same bracketing (device sync both sides) — and carries them on the same line: flat scalars `cfg2_*` / `cfg4_*` inside
-`roofline`, full detail under `configs`.  metric / value / config / roofline.frac stay the headline's.  `--no-side-configs` skips them.
+The default run (cfg3, 1 GPU, default sizes) ALSO times, after the headline steps, the headline workload in the exact render mode
+(`cfg3_exact`: the reference's own arithmetic, bit for bit), the fully per-voice variant (`cfg3_poly`) and the other two single-GPU
+BASELINE configurations — config 2 (4 096 identical voices) and config 4 (P2 FM pair, buffer_size 1, 65 536 voices) —, SIDE_STEPS steps
+each after one warm-up, same bracketing (device sync both sides), and carries them on the same line: flat scalars `cfg3_exact_*` /
+`cfg3_poly_*` / `cfg2_*` / `cfg4_*` inside `roofline`, full detail under `configs`.  metric / value / config / roofline.frac stay the headline's.  `--no-side-configs` skips them.
 
 Prints ONE JSON line (rank 0): metric/value/unit per the driver's contract, plus
   roofline     — achieved = algorithmic bytes of a step / step time (4 B x planes x V x T / t_render, per GPU),
@@ -71,7 +74,7 @@ FM_PAIR_F64_OPS = {"render_fm_pair": 48, "render_fm_pair_ring": 48,
                    "render_fm_pair_block": 50.6}
 F64_LANE_OPS_MEASURED = 33.3e12
 
-WORKLOADS = ("cfg3", "cfg2", "cfg4", "cfg4_b1024", "p3", "p4")
+WORKLOADS = ("cfg3", "cfg3_poly", "cfg2", "cfg4", "cfg4_b1024", "p3", "p4")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -221,7 +224,14 @@ class HipBackend:
         B = 1 if w == "cfg4" else 1024
         p = S.Patch(48000, B, 2)
         first = self.rank * V  # global voice index => same draw as the 1-GPU run of the same voices
-        if w in ("cfg3", "cfg2"):
+        if w == "cfg3_poly":
+            ids = S.build_p1(p)
+            p.configure_voices(V)
+            for m, f, v in S.p1_poly_overrides(ids, S.p1_poly_voice_params(V, first_voice=first)):
+                p.set_voice_field(m, f, v)
+            what = (f"config 3's patch and size with nothing voice-invariant: P1, {V} voices/GPU with per-voice detune / cutoff / gate-LFO rate "
+                    "(1.7 ... 13.8 Hz) / envelope times — saw VCO, gate LFO, ladder VCF, ADSR and VCA all evaluated per voice")
+        elif w in ("cfg3", "cfg2"):
             ids = S.build_p1(p)
             p.configure_voices(V)
             if w == "cfg3":
@@ -320,8 +330,9 @@ class HipBackend:
 
 
 def cpu_baseline(S, workload, n_samples=48000):
-    """The oracle timed on this host: `cores` threads x a few voices x 1 s of the workload's patch (about 10-30 s of CPU work
-    in total across cores; wall time a few seconds)."""
+    """The oracle timed on this host: B1 — `cores` threads x a few voices x 1 s of the workload's patch, best of 3 (the
+    `value`: about 10-30 s of CPU work in total across cores, wall time a few seconds) — and B0 — ONE voice on ONE thread, the faithful analogue
+    of the reference's single audio thread (main.rs:59-63), best of 5."""
     from oracle import oracle as O
     O.build()
     cores = os.cpu_count() or 1
@@ -335,6 +346,10 @@ def cpu_baseline(S, workload, n_samples=48000):
         beta, index = S.p2_voice_params(V)
         ov = [(ids["mul_fb"], S.MATH_CONSTANT, beta), (ids["mul_idx"], S.MATH_CONSTANT, index)]
         patch = "P2 (cfg4 draw)"
+    elif workload == "cfg3_poly":
+        ids = S.build_p1(g)
+        ov = S.p1_poly_overrides(ids, S.p1_poly_voice_params(V))
+        patch = "P1 (cfg3_poly draw)"
     else:
         ids = S.build_p1(g)
         det, cut = S.p1_voice_params(V)
@@ -348,30 +363,34 @@ def cpu_baseline(S, workload, n_samples=48000):
         dt = time.perf_counter() - t
         best = dt if best is None else min(best, dt)
     single = None
-    for _ in range(3):
+    for _ in range(5):  # B0: one voice, one thread, best of 5
         t = time.perf_counter()
-        g.render_batch(voices_per_core, n_samples, [(m, f, v[:voices_per_core]) for m, f, v in ov], frames=False, mix=True, threads=1)
+        g.render_batch(1, n_samples, [(m, f, v[:1]) for m, f, v in ov], frames=False, mix=True, threads=1)
         dt1 = time.perf_counter() - t
         single = dt1 if single is None else min(single, dt1)
     return {
         "value": V * n_samples / best, "unit": "voice-samples/s", "cores": cores, "kind": "port",
-        "sample": f"{V} voices x {n_samples} samples of patch {patch}, buffer_size {B}, {cores} threads, best of 3",
-        "single_thread_value": voices_per_core * n_samples / single,
-        "single_thread_sample": f"{voices_per_core} voices x {n_samples} samples, 1 thread, best of 3",
+        "sample": f"B1: {V} voices x {n_samples} samples of patch {patch}, buffer_size {B}, {cores} threads, best of 3",
+        "per_core_value": V * n_samples / best / cores,
+        "single_thread_value": n_samples / single,
+        "single_thread_sample": f"B0 (BASELINE.md section 2): 1 voice x {n_samples} samples, 1 thread, best of 5",
+        "single_thread_x_realtime": n_samples / single / 48000.0,
         "note": "C restatement of the reference tick (oracle/srack_oracle.c); the Rust reference cannot be built here. "
                 "Omits the reference's per-block RwLock/Arc/Vec overhead, so it is a slightly optimistic stand-in.",
     }
 
 
-SIDE_CONFIGS = ("cfg2", "cfg4")   # BASELINE.json configs[1] and configs[3]: the other single-GPU configurations
+# (name on the line, workload, render flags): the headline in the exact render mode (the reference's arithmetic bit for bit), the fully
+# per-voice variant of the headline, and BASELINE.json configs[1] and configs[3] — the other single-GPU configurations
+SIDE_CONFIGS = (("cfg3_exact", "cfg3", 1), ("cfg3_poly", "cfg3_poly", 0), ("cfg2", "cfg2", 0), ("cfg4", "cfg4", 0))
 SIDE_STEPS, SIDE_WARMUP = 5, 1
 
 
-def side_config(args, workload):
-    """One of the other single-GPU BASELINE configurations, timed like the headline: SIDE_WARMUP untimed steps, then exactly SIDE_STEPS
+def side_config(args, workload, flags=0):
+    """Another single-GPU configuration, timed like the headline: SIDE_WARMUP untimed steps, then exactly SIDE_STEPS
     steps between two device syncs; the dominant kernel by HIP events beside it.  Returns the figures of its own bench line."""
     a = argparse.Namespace(**vars(args))
-    a.workload, a.voices, a.flags, a.force_dist, a.no_frames, a.no_mix = workload, default_voices(workload), 0, False, False, False
+    a.workload, a.voices, a.flags, a.force_dist, a.no_frames, a.no_mix = workload, default_voices(workload), flags, False, False, False
     be = HipBackend(a, 1, 0, int(os.environ.get("LOCAL_RANK", "0")), None)
     try:
         for _ in range(SIDE_WARMUP):
@@ -389,7 +408,8 @@ def side_config(args, workload):
         kname = info.split("kernel=")[-1] if "kernel=" in info else ""
         launches = max(1, n_launch // SIDE_STEPS)
         bytes_per_step = BYTES_PER_VOICE_SAMPLE * be.n_planes * V * T
-        out = {"workload": be.what, "voices": V, "samples_per_step": T, "buffer_size": be.buffer_size, "steps": SIDE_STEPS, "warmup": SIDE_WARMUP,
+        out = {"workload": be.what, "render_flags": flags, "arithmetic": arithmetic_note(flags), "voices": V, "samples_per_step": T, "buffer_size": be.buffer_size,
+               "steps": SIDE_STEPS, "warmup": SIDE_WARMUP,
                "ms_per_step": step_s * 1e3, "voice_samples_per_s": V * T / step_s,
                "frac_hbm": bytes_per_step / step_s / 1e9 / HBM_PEAK_GBS, "kernel": kname, "kernel_ms": kernel_ms, "launches_per_step": launches,
                "frac_hbm_kernel": (bytes_per_step / launches / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms > 0 else 0.0, "program": info}
@@ -412,7 +432,7 @@ def profiled_traffic(kernel_name, workload, flags, V, T):
     if (V, T) != (default_voices(workload), 48000):
         return None
     tag = {("cfg3", 0): "", ("cfg3", 1): "_exact", ("cfg3", 2): "_special", ("cfg3", 3): "_special_exact", ("p3", 0): "_p3", ("p3", 1): "_p3_exact",
-           ("cfg4", 0): "_cfg4", ("cfg4", 2): "_cfg4_special", ("cfg4_b1024", 0): "_cfg4_b1024", ("cfg4_b1024", 2): "_cfg4_b1024_special", ("cfg2", 0): "_cfg2", ("p4", 0): "_p4"}.get((workload, flags))
+           ("cfg4", 0): "_cfg4", ("cfg4", 2): "_cfg4_special", ("cfg4_b1024", 0): "_cfg4_b1024", ("cfg4_b1024", 2): "_cfg4_b1024_special", ("cfg2", 0): "_cfg2", ("p4", 0): "_p4", ("cfg3_poly", 0): "_poly"}.get((workload, flags))
     if tag is None:
         return None
     best = None
@@ -434,8 +454,21 @@ def profiled_traffic(kernel_name, workload, flags, V, T):
     return best
 
 
+def arithmetic_note(flags):
+    """What the render mode computes in, where it is not the reference's own operation sequence."""
+    if flags & 1:
+        return ("exact mode: the reference's operations one by one — f64 phase / 2^cv (correctly rounded) / PolyBLEP with its f64 division, the ladder "
+                "uncontracted with min/max clamps; frames bit-identical to the CPU tick (oscillator.rs:108-158, filter.rs:58-92)")
+    return ("default mode, within the 1e-5 contract but NOT the reference's arithmetic everywhere: PolyBLEP evaluated in f32 (reference: f64, "
+            "oscillator.rs:50-67); the ladder with one product of each a*b - c*d folded into an fma and v_med3 clamps (reference: uncontracted, "
+            "min/max, filter.rs:69-89); the audio saw's phase accumulator in 2^-64 fixed point where the flattener proves nothing integrates it "
+            "(reference: f64 with fmod; gate-producing oscillators keep the f64 phase); 2^cv and sine by polynomials (1e-12) where a pitch CV is connected. "
+            "ADSR, VCA, mixer, math, sequencers: the reference's f32 operations in its order, bit-identical in every mode. "
+            "`cfg3_exact_*` on this line is the same workload in the reference's own arithmetic")
+
+
 def default_voices(workload):
-    return {"cfg3": 262144, "p3": 262144, "p4": 131072, "cfg2": 4096, "cfg4": 65536, "cfg4_b1024": 65536}[workload]
+    return {"cfg3": 262144, "cfg3_poly": 262144, "p3": 262144, "p4": 131072, "cfg2": 4096, "cfg4": 65536, "cfg4_b1024": 65536}[workload]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -501,8 +534,7 @@ def run_rank(args, backend_cls=HipBackend):
                             + (" + RCCL reduce of the [2][T] mix (srack_dist_reduce_mix)" if getattr(be, "comm", None) is not None else ""),
                 "name": args.workload, "voices_per_gpu": V, "samples_per_step": T, "buffer_size": getattr(be, "buffer_size", 1024),
                 "render_flags": args.flags, "backend": be.name, "samples_per_call": args.block or T,
-                "arithmetic": "f32 wires and modules; oscillator phase accumulator 64-bit: f64 as the reference, 2^-64 fixed point in the "
-                              "default-mode fused saw kernel (DESIGN.md section 5)",
+                "arithmetic": arithmetic_note(args.flags),
                 "frames_written": not args.no_frames, "mix_down": not args.no_mix, "program": info,
             },
             "roofline": {
@@ -556,12 +588,13 @@ def run_rank(args, backend_cls=HipBackend):
             be.frames = be.mix = be.p = None
             be.torch.cuda.empty_cache()
             out["configs"] = {}
-            for w in SIDE_CONFIGS:
-                c = out["configs"][w] = side_config(args, w)
+            for w, wl, fl in SIDE_CONFIGS:
+                c = out["configs"][w] = side_config(args, wl, fl)
                 rf = out["roofline"]
                 rf[w + "_ms_per_step"] = c["ms_per_step"]
                 rf[w + "_voice_samples_per_s"] = c["voice_samples_per_s"]
                 rf[w + "_frac_hbm"] = c["frac_hbm"]
+                rf[w + "_frac_hbm_kernel"] = c["frac_hbm_kernel"]
                 rf[w + "_kernel_ms"] = c["kernel_ms"]
                 rf[w + "_launches_per_step"] = c["launches_per_step"]
                 if "frac_valu_f64" in c:

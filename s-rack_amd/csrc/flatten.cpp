@@ -77,6 +77,7 @@ struct Analysis {  // whole-graph facts shared by both programs
     std::vector<char> in_ctl;
     std::vector<int> stage;                          // per module: control stage (>= 0) or -1 = voice program
     std::vector<char> sine_loose;                    // per oscillator: its sine port cannot reach a pitch input (OSC_SINE_LOOSE)
+    std::vector<char> saw_fixed;                     // per oscillator, default mode: its saw can reach neither a pitch input nor a threshold (OSC_FIXED_PHASE where the pitch is constant)
     std::vector<char> nonlin_loose;                  // per NonLinear module: its output cannot reach a pitch input or a threshold (NONLIN_LOOSE)
     std::vector<char> exact_src;                     // per oscillator / filter, default mode: an approximated output of it can reach a pitch input
                                                      // (OSC_EXACT_BLEP / VCF_LITERAL)
@@ -670,6 +671,37 @@ int Builder::build()
     out.table.resize((size_t)H.n_rows * V);
     for (int r = 0; r < H.n_rows; r++) std::memcpy(&out.table[(size_t)r * V], rows[(size_t)r].data(), sizeof(uint32_t) * V);
 
+    // Default mode, a voice program's constant-pitch saw that nothing integrates or thresholds (A.saw_fixed): every kernel keeps its phase in
+    // 64-bit fixed point (modules.hip.h, FOsc — three integer-rate instructions per sample where the f64 accumulator takes three at half
+    // rate or less).  State and increment change representation here, once: phase * 2^64 as u64 in the same two rows.
+    if (!is_ctl && !A.saw_fixed.empty())
+        for (DevOp& osc : out.ops) {
+            if (osc.kind != OP_OSC || !(osc.flags & OSC_CONST_FAST) || (osc.flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW)) != OSC_OUT_SAW || !A.saw_fixed[(size_t)osc.module]) continue;
+            auto to_fixed = [](double x) {  // x in [0, 1): exact whenever x has no bits below 2^-64
+                const double y = std::ldexp(x - std::floor(x), 64);
+                return y >= 18446744073709551616.0 ? ~0ull : (uint64_t)y;
+            };
+            auto convert_rows = [&](int lo_row) {
+                uint32_t* lo = &out.table[(size_t)lo_row * V];
+                uint32_t* hi = &out.table[(size_t)(lo_row + 1) * V];
+                for (uint32_t v = 0; v < V; v++) {
+                    const uint64_t bits = ((uint64_t)hi[v] << 32) | lo[v];
+                    double d;
+                    std::memcpy(&d, &bits, 8);
+                    const uint64_t f = to_fixed(d);
+                    lo[v] = (uint32_t)f;
+                    hi[v] = (uint32_t)(f >> 32);
+                }
+            };
+            osc.flags |= OSC_FIXED_PHASE;
+            convert_rows(osc.state_row + OSC_S_POS_LO);
+            if (osc.delta_row >= 0) {
+                convert_rows(osc.delta_row);
+            } else {
+                const uint64_t f = to_fixed(osc.delta);
+                std::memcpy(&osc.delta, &f, 8);
+            }
+        }
     if (!(render_flags & SRACK_RENDER_NO_FUSION)) match_fused(!rings.empty());
     if (is_ctl && !(render_flags & SRACK_RENDER_NO_FUSION) && rings.empty() && H.n_ops == 3 && out.ops[0].kind == OP_OSC &&
         out.ops[1].kind == OP_ADSR && out.ops[2].kind == OP_OUT && (out.ops[0].flags & OSC_CONST_SMALL) && (out.ops[1].flags & ADSR_HAS_GATE) &&
@@ -793,35 +825,7 @@ void Builder::match_fused(bool has_rings)
         ok = A.in_ctl[(size_t)src_of(vca->module, 1).src] && vca->in_slot[1] >= kTrackSlot;
         if (ok) {
             out.fused = FUSED_VOICE_CHAIN_TRACK;
-            // Default mode, saw port: the kernel keeps the oscillator phase in 64-bit fixed point (modules.hip.h, FOsc).
-            // State and increment change representation here, once: phase * 2^64 as u64 in the same two rows.
-            DevOp& osc = out.ops[(size_t)out.op_of_module[(size_t)src_of(vcf->module, 0).src]];
-            if ((osc.flags & OSC_OUT_SAW) && !(osc.flags & OSC_EXACT)) {
-                auto to_fixed = [](double x) {  // x in [0, 1): exact whenever x has no bits below 2^-64
-                    const double y = std::ldexp(x - std::floor(x), 64);
-                    return y >= 18446744073709551616.0 ? ~0ull : (uint64_t)y;
-                };
-                auto convert_rows = [&](int lo_row) {
-                    uint32_t* lo = &out.table[(size_t)lo_row * V];
-                    uint32_t* hi = &out.table[(size_t)(lo_row + 1) * V];
-                    for (uint32_t v = 0; v < V; v++) {
-                        const uint64_t bits = ((uint64_t)hi[v] << 32) | lo[v];
-                        double d;
-                        std::memcpy(&d, &bits, 8);
-                        const uint64_t f = to_fixed(d);
-                        lo[v] = (uint32_t)f;
-                        hi[v] = (uint32_t)(f >> 32);
-                    }
-                };
-                osc.flags |= OSC_FIXED_PHASE;
-                convert_rows(osc.state_row + OSC_S_POS_LO);
-                if (osc.delta_row >= 0) {
-                    convert_rows(osc.delta_row);
-                } else {
-                    const uint64_t f = to_fixed(osc.delta);
-                    std::memcpy(&osc.delta, &f, 8);
-                }
-            }
+            // (default mode, saw port: the oscillator's phase is in 64-bit fixed point — OSC_FIXED_PHASE, set above for every kernel)
         }
     }
 }
@@ -1048,6 +1052,17 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                     std::vector<uint32_t> from((size_t)n_mod, 0u);
                     from[(size_t)m] = 1u;
                     A.nonlin_loose[(size_t)m] = !reaches_pitch(from, true);
+                }
+        // A saw whose value nobody integrates (a pitch input) or thresholds (a gate, a sync, a clock, a VCA's CV) may run its phase in 2^-64
+        // fixed point (modules.hip.h, FOsc): the two accumulators differ by 1e-14 after a second, far below f32 resolution at the output —
+        // but enough to move a zero crossing by a sample once in 1e10 crossings, which a threshold would turn into an event.
+        A.saw_fixed.assign((size_t)n_mod, 0);
+        if (!(render_flags & SRACK_RENDER_EXACT_OSC) && !(getenv("SRACK_NO_FIXED_SAW") && getenv("SRACK_NO_FIXED_SAW")[0] == '1'))
+            for (int m = 0; m < n_mod; m++)
+                if (A.live[(size_t)m] && g.modules[(size_t)m].type == SRACK_MOD_OSCILLATOR && (A.port_live[(size_t)m] & 7u) == 4u) {
+                    std::vector<uint32_t> from((size_t)n_mod, 0u);
+                    from[(size_t)m] = 4u;
+                    A.saw_fixed[(size_t)m] = !reaches_pitch(from, true);
                 }
       A.exact_src.assign((size_t)n_mod, 0);
       if (!(render_flags & SRACK_RENDER_EXACT_OSC)) {

@@ -179,15 +179,27 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
     Emit em = make_emit(a, plane, lane);
 
     COsc ca, cl;
+    FOsc fa_osc;
+    // default mode, a saw nothing integrates or thresholds: the host stored its phase and increment as value * 2^64 (OSC_FIXED_PHASE; wave-uniform)
+    const bool fixed_a = !kExact && kOscAPort == OSC_OUT_SAW && (oa.flags & OSC_FIXED_PHASE) != 0;
+    uint32_t fix_lo = 0u, fix_hi = 0u;  // ... its phase after exactly t samples
     AdsrSeg seg;
     float x = 0.0f, gate = 0.0f;
     double pos_a = sa.pos, pos_l = sl.pos;  // oscillator phases after exactly t samples (the loop runs one sample ahead)
     if (!kExact) {
-        cosc_init(ca, sa.pos, ka.delta);
+        if (fixed_a) {
+            const uint64_t dbits = (uint64_t)__double_as_longlong(oa.delta);
+            fosc_init(fa_osc, row(oa.state_row + OSC_S_POS_LO), row(oa.state_row + OSC_S_POS_HI), oa.delta_row >= 0 ? row(oa.delta_row) : (uint32_t)dbits,
+                      oa.delta_row >= 0 ? row(oa.delta_row + 1) : (uint32_t)(dbits >> 32));
+            fix_lo = fa_osc.lo;
+            fix_hi = fa_osc.hi;
+        } else {
+            cosc_init(ca, sa.pos, ka.delta);
+        }
         cosc_init(cl, sl.pos, kl.delta);
         adsr_seg_enter(sd, kd, seg);
         if (a.T > 0) {  // software pipeline: the oscillators of sample t+1 are evaluated beside the filter of sample t
-            x = cosc_step<kOscAPort>(ca);
+            x = fixed_a ? fosc_saw(fa_osc) : cosc_step<kOscAPort>(ca);
             gate = cosc_step<kOscLPort>(cl);
         }
     }
@@ -208,9 +220,15 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
             vcf_run<!kExact>(sv, sv_fin, x, lp, bp, hp);
             const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
             if (!kExact) {  // next sample's oscillators: same basic block as the filter chain above => they interleave
-                pos_a = ca.pos;
                 pos_l = cl.pos;
-                x_next = cosc_step<kOscAPort>(ca);
+                if (fixed_a) {
+                    fix_lo = fa_osc.lo;
+                    fix_hi = fa_osc.hi;
+                    x_next = fosc_saw(fa_osc);
+                } else {
+                    pos_a = ca.pos;
+                    x_next = cosc_step<kOscAPort>(ca);
+                }
                 gate_next = cosc_step<kOscLPort>(cl);
             }
             if (kExact)
@@ -235,8 +253,8 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
 
     if (active) {
         auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
-        put(oa.state_row + OSC_S_POS_LO, f64_lo(sa.pos));
-        put(oa.state_row + OSC_S_POS_HI, f64_hi(sa.pos));
+        put(oa.state_row + OSC_S_POS_LO, fixed_a ? fix_lo : f64_lo(sa.pos));
+        put(oa.state_row + OSC_S_POS_HI, fixed_a ? fix_hi : f64_hi(sa.pos));
         put(oa.state_row + OSC_S_SYNC_LAST, sa.sync_last ? 1u : 0u);
         put(ol.state_row + OSC_S_POS_LO, f64_lo(sl.pos));
         put(ol.state_row + OSC_S_POS_HI, f64_hi(sl.pos));

@@ -159,11 +159,23 @@ __device__ __noinline__ void tile_osc_const(const Ctx c_v, COp& op_v)
     const Ctx c = uniform_ctx(c_v);
     COp& op = uniform_op(op_v);
     const uint32_t fl = op.flags;
+    const Port w[1] = {out_port(c, op.out_slot[(fl & OSC_OUT_SAW) ? 2 : (fl & OSC_OUT_SQUARE) ? 1 : 0])};
+    const Port none[1] = {w[0]};  // no input: the dummy read goes to the op's own output row
+    if (fl & OSC_FIXED_PHASE) {  // (host-set: default mode, saw only) phase and increment rows hold value * 2^64 (modules.hip.h, FOsc)
+        const int sr = op.state_row;
+        const uint64_t dbits = (uint64_t)__double_as_longlong(op.delta);
+        FOsc fo;
+        fosc_init(fo, ROW(sr + OSC_S_POS_LO), ROW(sr + OSC_S_POS_HI), op.delta_row >= 0 ? ROW(op.delta_row) : (uint32_t)dbits,
+                  op.delta_row >= 0 ? ROW(op.delta_row + 1) : (uint32_t)(dbits >> 32));
+        tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = fosc_saw(fo); });
+        ROW(sr + OSC_S_POS_LO) = fo.lo;
+        ROW(sr + OSC_S_POS_HI) = fo.hi;
+        ROW(sr + OSC_S_SYNC_LAST) = 0u;
+        return;
+    }
     const OscSetup u = osc_setup(c, op);
     COsc o;
     cosc_init(o, u.s.pos, u.k.delta);
-    const Port w[1] = {out_port(c, op.out_slot[(fl & OSC_OUT_SAW) ? 2 : (fl & OSC_OUT_SQUARE) ? 1 : 0])};
-    const Port none[1] = {w[0]};  // no input: the dummy read goes to the op's own output row
     if (fl & OSC_OUT_SAW)
         tile_run<1, 1>(c, none, w, [&](const float*, float* y) { y[0] = cosc_saw(o); });
     else if (fl & OSC_OUT_SQUARE)

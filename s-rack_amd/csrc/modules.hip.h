@@ -328,6 +328,23 @@ SRK_DEV double fmod1(double x)
     return r;
 }
 
+// A square is what gates are made of (an LFO into an envelope, a clock into a sequencer): the consumer looks at `value > 0.0` only.  The
+// f32 PolyBLEP is within 1e-7 of the reference's value — but just after the rising edge the reference's value is a tiny POSITIVE number
+// (2x - x^2 with x = (pos - 0.5) / dt) which f32 rounds to exactly 0.0 for x < 1.5e-8: the gate would open a sample late, and an
+// envelope a sample late is an error of one increment (1e-2), not 1e-7.  One edge in 7e7 — but the metric's configuration has millions of
+// edges per second of audio.  So a value this close to zero (any lane: a wave-uniform branch, taken about once per 1e5 in-window samples)
+// is re-evaluated with the reference's own f64 operations (oscillator.rs:50-67,135-142): same sign, same bits.
+SRK_DEV float square_sign_safe(float sq, double pos, double delta)
+{
+    const bool tiny = __builtin_fabsf(sq) < 2.0e-6f;
+    if (__builtin_amdgcn_ballot_w64(tiny) != 0) {
+        if (tiny) {
+            sq = (pos < 0.5 ? -1.0f : 1.0f) - (float)(poly_blep_exact(pos, delta) - poly_blep_exact(fmod1(pos + 0.5), delta));
+        }
+    }
+    return sq;
+}
+
 SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, float sync, float& sine, float& square, float& saw)
 {
     if (flags & OSC_HAS_SYNC) {
@@ -399,6 +416,7 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
                 blep1 = poly_blep_sel((float)p2, (float)(p2 - 1.0), inv_dt, p2 < delta, p2 > upper);
             }
             square = (pos < 0.5 ? -1.0f : 1.0f) - (blep0 - blep1);
+            if (flags & OSC_AA) square = square_sign_safe(square, pos, delta);
         }
     }
     // x - floor(x) and v_fract_f64 agree for every finite x >= 0 (the subtraction is exact and below 1; fract's clamp to 1 - 2^-53 never
@@ -504,7 +522,7 @@ SRK_DEV float cosc_square(COsc& o)
         double p2 = pos + 0.5;
         p2 = p2 >= 1.0 ? p2 - 1.0 : p2;
         const float blep1 = poly_blep_fast((float)p2, (float)(p2 - 1.0), o.inv_dt);
-        sq = sq - (blep0 - blep1);
+        sq = square_sign_safe(sq - (blep0 - blep1), pos, o.delta);
     }
     bool wrapped;
     o.pos = cosc_advance(o, wrapped);
@@ -526,6 +544,62 @@ SRK_DEV float cosc_step(COsc& o)
     if (kPort == OSC_OUT_SAW) return cosc_saw(o);
     if (kPort == OSC_OUT_SQUARE) return cosc_square(o);
     return cosc_sine(o);
+}
+
+// ---- quiet groups (kernels specialised at run time, jit.cpp) --------------------------------------------------------------------------
+// A gate LFO and the envelope behind it are event machines: between a voice's events — the LFO inside a PolyBLEP window (its only chance
+// to change sign), the envelope's phase reaching 1, a gate level or edge that ends the segment — their per-sample work is
+// `pos = fract(pos + delta)` and `phase += inc; out = c0 + c1 * (k0 + k1 * phase)`.  The per-sample forms (cosc_square, adsr_seg_step) ask
+// "does any lane have an event NOW" every sample: three compares and two ballots for the LFO, two compares, two ballots, six scalar
+// operations and a branch for the envelope, and the branch's cold arm costs the hot one a dozen register moves.  With every voice on
+// its own clock (real polyphony: nothing is voice-invariant) that questioning is a third of the kernel.  A group of kQuietGroup samples
+// asks ONCE, ahead: can any lane have an event within the group?  If not (two groups in three at 64 independent voices), the group
+// runs the event-free forms below — the same operations on the same values in the same order as the per-sample forms' hot paths, so
+// every bit of state and output is what they would have produced.
+#ifndef SRK_QUIET_GROUP
+#define SRK_QUIET_GROUP 8
+#endif
+constexpr int kQuietGroup = SRK_QUIET_GROUP;
+
+struct COscQuiet {
+    int hBq, hQ0q;      // guards on hi32(pos) like COsc's hB / hQ0, moved down by the phase a group covers
+    uint32_t hQspanq;
+};
+
+SRK_DEV void cosc_quiet_init(const COsc& o, COscQuiet& q)
+{
+    const double g = __builtin_fmin(o.delta * (1.0 + 9.5367431640625e-07) + 1e-300, 0.25);  // cosc_init's window half-width
+    const double w = g + (double)kQuietGroup * o.delta * (1.0 + 9.5367431640625e-07);        // ... plus the phase the group's samples cover
+    if (w < 0.24) {
+        q.hBq = __double2hiint(1.0 - w);
+        q.hQ0q = __double2hiint(0.5 - w);
+        q.hQspanq = (uint32_t)(__double2hiint(0.5 + g) - q.hQ0q);
+    } else {  // fast oscillators (and a NaN increment): never quiet
+        q.hBq = (int)0x80000000;
+        q.hQ0q = 0;
+        q.hQspanq = 0u;
+    }
+}
+
+// this lane's square oscillator stays outside every PolyBLEP window for the next kQuietGroup samples: its value is the level of its
+// phase's half, -1.0 or +1.0 exactly (both blep terms are 0.0, as in cosc_square's hot path), and does not change within the group
+SRK_DEV bool cosc_square_quiet(const COsc& o, const COscQuiet& q)
+{
+    const int h = __double2hiint(o.pos);
+    return !(h <= o.hA || h >= q.hBq || (uint32_t)(h - q.hQ0q) <= q.hQspanq);
+}
+// ... and for ONE sample (a group that is not quiet as a whole is walked sample by sample: the event-free form for every sample no lane
+// has an event in — cosc_square's own `near` test —, the per-sample form for the others)
+SRK_DEV bool cosc_square_calm(const COsc& o)
+{
+    const int h = __double2hiint(o.pos);
+    return !(h <= o.hA || h >= o.hB || (uint32_t)(h - o.hQ0) <= o.hQspan);
+}
+SRK_DEV float cosc_square_level(const COsc& o) { return __double2hiint(o.pos) < 0x3fe00000 ? -1.0f : 1.0f; }
+SRK_DEV void cosc_quiet_step(COsc& o)
+{
+    bool wrapped;
+    o.pos = cosc_advance(o, wrapped);
 }
 
 // The exact render mode's constant-pitch square / saw behind the same guards (host-proved OSC_CONST_SMALL).  Outside its PolyBLEP
@@ -1138,6 +1212,35 @@ SRK_DEV float adsr_seg_step(AdsrRegs& s, const AdsrConst& c, AdsrSeg& g, float g
         const float u = g.k0 + g.k1 * ph;
         out = g.c0 + g.c1 * u;
     }
+    g.held = out;
+    return out;
+}
+
+// Quiet groups (see cosc_quiet_init): no lane leaves its segment during the next kQuietGroup samples, given that its gate holds the value
+// `gate` for all of them (a group-constant gate: a quiet square oscillator's level).  Wave-uniform part: the gate's level or edge ends no
+// lane's segment — adsr_seg_step's own mask, evaluated once; a constant gate has its only possible edge at the group's first sample.
+// Per-lane part: the phase stays below 1 — each of the group's rounded additions adds at most inc + 2^-24 (an infinite or NaN increment
+// says no).  `m_high` returns the gate's level mask: what adsr_seg_step would leave in g.last after every one of the group's samples.
+SRK_DEV bool adsr_seg_quiet(const AdsrRegs& s, const AdsrSeg& g, float gate, uint64_t& m_high)
+{
+    m_high = __builtin_amdgcn_ballot_w64(gate > 0.0f);
+    const uint64_t m_leave = (m_high & g.on_high) | (~m_high & g.on_low) | (m_high & ~g.last & g.on_edge);
+    return m_leave == 0 && s.phase + (float)kQuietGroup * g.inc <= 0.9999f;
+}
+// the same question for ONE sample: adsr_seg_step's own test (m_leave == 0, i.e. no lane's phase reaches 1 and no gate level or edge ends
+// a segment), asked ahead of the sample for a gate that is known before the envelope's turn
+SRK_DEV bool adsr_seg_calm(const AdsrRegs& s, const AdsrSeg& g, float gate, uint64_t& m_high)
+{
+    m_high = __builtin_amdgcn_ballot_w64(gate > 0.0f);
+    const uint64_t m_leave = (m_high & g.on_high) | (~m_high & g.on_low) | (m_high & ~g.last & g.on_edge);
+    return m_leave == 0 && !(s.phase + g.inc >= 1.0f);
+}
+// one sample of such a group: adsr_seg_step's hot path without its questions (the caller sets g.last = m_high after the group)
+SRK_DEV float adsr_seg_quiet_step(AdsrRegs& s, AdsrSeg& g)
+{
+    s.phase = s.phase + g.inc;
+    const float u = g.k0 + g.k1 * s.phase;
+    const float out = g.c0 + g.c1 * u;
     g.held = out;
     return out;
 }

@@ -217,6 +217,28 @@ def p1_voice_params(n_voices, seed=SEED, first_voice=0):
     return detune.astype(np.float32), cutoff.astype(np.float32)
 
 
+def p1_poly_voice_params(n_voices, seed=SEED, first_voice=0):
+    """cfg3_poly: config 3's draw (detune, cutoff) plus a per-voice gate LFO rate and per-voice envelope times, so that NOTHING of P1 is
+    voice-invariant (every voice has its own gate pattern and envelope: real polyphony).  OSC_LFO.val = -8 + U(0, 3) octaves
+    (1.72 ... 13.75 Hz: one to thirteen notes in the second), ADSR a_sec = U(0.002, 0.05), d_sec = U(0.05, 0.3), s_val = U(0.2, 0.8),
+    r_sec = U(0.05, 0.4).  Draw k >= 2 comes from the same counter-based generator under seed + 0x1000 * (k // 2), so that no two draws
+    of neighbouring voices coincide.  -> dict name -> f32[n_voices]."""
+    u = [voice_uniform(n_voices, k % 2, seed + 0x1000 * (k // 2), first_voice) for k in range(7)]
+    f = np.float32
+    detune, cutoff = p1_voice_params(n_voices, seed, first_voice)
+    return dict(detune=detune, cutoff=cutoff,
+                lfo_val=(f(-8.0) + u[2] * f(3.0)).astype(f),
+                a_sec=(f(0.002) + u[3] * f(0.048)).astype(f), d_sec=(f(0.05) + u[4] * f(0.25)).astype(f),
+                s_val=(f(0.2) + u[5] * f(0.6)).astype(f), r_sec=(f(0.05) + u[6] * f(0.35)).astype(f))
+
+
+def p1_poly_overrides(ids, pv):
+    """the (module, field, values) list of p1_poly_voice_params' draw, for Patch.set_voice_field / OraclePatch.render_batch"""
+    return [(ids["osc_a"], OSC_VAL, pv["detune"]), (ids["vcf"], VCF_FREQ, pv["cutoff"]), (ids["osc_lfo"], OSC_VAL, pv["lfo_val"]),
+            (ids["adsr"], ADSR_A_SEC, pv["a_sec"]), (ids["adsr"], ADSR_D_SEC, pv["d_sec"]), (ids["adsr"], ADSR_S_VAL, pv["s_val"]),
+            (ids["adsr"], ADSR_R_SEC, pv["r_sec"])]
+
+
 def p2_voice_params(n_voices, seed=SEED, first_voice=0):
     """cfg4 per-voice randomisation: feedback beta = U(0.1, 0.4), index = U(0.5, 1.5)."""
     u0 = voice_uniform(n_voices, 0, seed, first_voice)

@@ -648,6 +648,93 @@ def test_cfg3_exactly_as_benchmarked(S, oracle):
     assert (np.abs(mix[0].astype(np.float64) - own) <= 1e-5 * np.maximum(scale, 1.0)).all() and np.array_equal(mix[0], mix[1])
 
 
+def test_cfg3_poly_exactly_as_benchmarked(S, oracle):
+    """The fully per-voice variant of config 3 at full size, the workload `bench.py --workload cfg3_poly` (and the default line's
+    `cfg3_poly_*`) times: 262 144 voices x 48 000 samples of P1 with per-voice detune, cutoff, gate-LFO rate and envelope times (nothing is
+    voice-invariant: every voice has its own notes), default mode.  Sampled voices against the oracle for the whole second — a gate edge
+    one sample off would be an error of an envelope increment, 1e-2 — and the mix against an f64 sum of all the frames."""
+    import ctypes as C
+    V, T = 262144, 48000
+    pv = S.p1_poly_voice_params(V)
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p1(p)
+    p.configure_voices(V)
+    for m, f, v in S.p1_poly_overrides(ids, pv):
+        p.set_voice_field(m, f, v)
+    d_fr, d_mx = C.c_void_p(), C.c_void_p()
+    assert S.lib.srack_device_alloc(C.byref(d_fr), T * V * 4) == 0 and S.lib.srack_device_alloc(C.byref(d_mx), 2 * T * 4) == 0
+    try:
+        p.render_raw(T, d_fr, d_mx, 0, None)
+        assert S.lib.srack_device_sync(None) == 0
+        assert "kernel=render_specialized" in p.info() and "ctl[" not in p.info(), p.info()   # nothing hoisted: no control program
+        pick = np.unique(np.concatenate([np.arange(0, V, 2731), [0, 63, 64, V - 65, V - 64, V - 1]]))
+        got = np.empty((T, len(pick)), dtype=np.float32)
+        own, scale = np.empty(T), np.empty(T)
+        rows = 256
+        buf = np.empty((rows, V), dtype=np.float32)
+        for t0 in range(0, T, rows):
+            n = min(rows, T - t0)
+            assert S.lib.srack_device_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + t0 * V * 4), n * V * 4, None) == 0
+            assert S.lib.srack_device_sync(None) == 0
+            got[t0:t0 + n] = buf[:n, pick]
+            own[t0:t0 + n] = buf[:n].sum(axis=1, dtype=np.float64)
+            scale[t0:t0 + n] = np.abs(buf[:n]).sum(axis=1, dtype=np.float64)
+        mix = np.empty((2, T), dtype=np.float32)
+        assert S.lib.srack_device_to_host(mix.ctypes.data_as(C.c_void_p), d_mx, mix.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
+    finally:
+        S.lib.srack_device_free(d_fr)
+        S.lib.srack_device_free(d_mx)
+    o = oracle.OraclePatch(48000, 1024, 2)
+    S.build_p1(o)
+    ref, _ = o.render_batch(len(pick), T, [(m, f, v[pick]) for m, f, v in S.p1_poly_overrides(ids, pv)], threads=8)
+    assert assert_close(got, ref[0]) < 2e-6
+    assert np.abs(got).max() > 0.1
+    assert (np.abs(mix[0].astype(np.float64) - own) <= 1e-5 * np.maximum(scale, 1.0)).all() and np.array_equal(mix[0], mix[1])
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 16, 32 | 2])
+@pytest.mark.parametrize("V,T", [(192, 48000), (4096 + 37, 6000)])
+def test_cfg3_poly_modes(S, oracle, flags, V, T):
+    """cfg3_poly's patch through every render mode (default / exact, the fused kernel, the specialised kernel, the interpreter), a ragged
+    last wave, a whole second at the small size (several notes per voice, every envelope segment): exact modes bit for bit, default modes
+    within the contract — and the envelope alone (a second patch: ADSR straight to the output) bit for bit in EVERY mode, gate edges included."""
+    pv = S.p1_poly_voice_params(V)
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p1(p)
+    p.configure_voices(V)
+    ov = S.p1_poly_overrides(ids, pv)
+    for m, f, v in ov:
+        p.set_voice_field(m, f, v)
+    fr, mix = p.render(T, flags=flags)
+    o = oracle.OraclePatch(48000, 1024, 2)
+    S.build_p1(o)
+    ref, _ = o.render_batch(V, T, ov, threads=8)
+    if flags & 1:
+        np.testing.assert_array_equal(bits(fr[0]), bits(ref[0]))
+    else:
+        assert assert_close(fr[0], ref[0]) < 2e-6
+    assert np.abs(fr[0]).max() > 0.1
+    # the envelope by itself: LFO square -> ADSR -> OUT
+    q = S.Patch(48000, 1024, 2)
+    lfo, adsr, out = q.add_module(S.MOD_OSCILLATOR), q.add_module(S.MOD_ADSR), q.add_module(S.MOD_OUTPUT)
+    q.connect(lfo, S.OSC_OUT_SQUARE, adsr, 0)
+    q.connect(adsr, 0, out, 0)
+    q.configure_voices(V)
+    ov2 = [(lfo, S.OSC_VAL, pv["lfo_val"]), (adsr, S.ADSR_A_SEC, pv["a_sec"]), (adsr, S.ADSR_D_SEC, pv["d_sec"]), (adsr, S.ADSR_S_VAL, pv["s_val"]),
+           (adsr, S.ADSR_R_SEC, pv["r_sec"])]
+    for m, f, v in ov2:
+        q.set_voice_field(m, f, v)
+    env, _ = q.render(T, flags=flags)
+    o2 = oracle.OraclePatch(48000, 1024, 2)
+    for t in (S.MOD_OSCILLATOR, S.MOD_ADSR, S.MOD_OUTPUT):
+        o2.add_module(t)
+    o2.connect(lfo, S.OSC_OUT_SQUARE, adsr, 0)
+    o2.connect(adsr, 0, out, 0)
+    ref2, _ = o2.render_batch(V, T, ov2, threads=8)
+    np.testing.assert_array_equal(bits(env[0]), bits(ref2[0]))
+    assert env[0].max() > 0.9
+
+
 # (since round 3 the kernels bench.py times for this patch: buffer_size 1 — the kernel specialised at run time, whose generator derives
 # the bounded pitch CVs render_fm_pair proves by hand; buffer_size 1024 — the time-parallel pair with its ring in LDS)
 @pytest.mark.parametrize("B,kernel", [(1, "render_specialized"), (1024, "render_fm_pair_block")])

@@ -381,7 +381,7 @@ def test_specialised_kernel_source_of_p1_and_p3(S):
     p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
     src = p.kernel_source(S.RENDER_NO_FUSION)
     assert 'extern "C" __global__' in src and "srk_voice(KernelArgs a)" in src
-    assert "cosc_step<0x20u>" in src and "vcf_run<true>" in src and "emit_put<KOUT>" in src  # the carried-phase saw, the default-mode ladder
+    assert "fosc_saw(m0)" in src and "vcf_run<true>" in src and "emit_put<KOUT>" in src  # the carried-phase saw (fixed-point phase: nothing integrates it), the default-mode ladder
     assert "srk_ctl0" in src and "a.ctl_slots[blockIdx.x]" in src                               # the gate -> envelope unit rides along,
     assert "cosc_tile<false>(" in src and "adsr_seg_tile(" in src and "sample(lane);" in src     # evaluated across lanes: lane j = sample j of the tile
     assert "rowf(14)" in src and "a.ops[1].par_val[2]" in src                               # per-voice cutoff from its row, uniform exp_amt from the op list

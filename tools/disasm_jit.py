@@ -1,4 +1,4 @@
-"""tools/disasm_jit.py <p1|p2|p2_b1024|p3|p4> [flags] [out.s] — the kernel specialised for a BASELINE patch (hiprtc cross-compiles for gfx950 without a
+"""tools/disasm_jit.py <p1|poly|p2|p2_b1024|p3|p4> [flags] [out.s] — the kernel specialised for a BASELINE patch (hiprtc cross-compiles for gfx950 without a
 GPU), disassembled, with an instruction histogram per loop: the ISA counts quoted for the general path.  The code object is
 taken out of a scratch disk cache (jit.cpp: 24 bytes of header, then the ELF)."""
 import collections, os, re, subprocess, sys, tempfile
@@ -15,6 +15,9 @@ p = S.Patch(48000, 1 if what == "p2" else 1024, 2)
 if what == "p1":
     ids = S.build_p1(p); p.configure_voices(V); det, cut = S.p1_voice_params(V)
     p.set_voice_field(ids["osc_a"], S.OSC_VAL, det); p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+elif what == "poly":
+    ids = S.build_p1(p); p.configure_voices(V)
+    for m, f, v in S.p1_poly_overrides(ids, S.p1_poly_voice_params(V)): p.set_voice_field(m, f, v)
 elif what in ("p2", "p2_b1024"):
     ids = S.build_p2(p); p.configure_voices(V); beta, index = S.p2_voice_params(V)
     p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, beta); p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
