@@ -99,3 +99,48 @@ def test_second_start_of_a_host_compiles_nothing(tmp_path):
     second = run(_P3, tmp_path)
     assert second["compiled"] == 0 and second["disk_hits"] == 1 and "jit=disk-cache" in second["info"]
     assert second["checksum"] == first["checksum"] and first["checksum"] > 0  # the same kernel, to the bit
+
+
+_BASELINE = r"""
+import json, os, sys
+if os.environ.get("SRACK_IMPORT_TORCH_FIRST") == "1":
+    import torch   # bench.py's order: the process then runs on the HIP runtime (and hiprtc) of torch's wheel, not the image's
+sys.path.insert(0, os.environ["SRACK_ROOT"])
+import numpy as np
+import srack_pkg
+S = srack_pkg.load()
+V, out = 4096, {}
+def poly(ids):
+    return S.p1_poly_overrides(ids, S.p1_poly_voice_params(V))
+def fm(ids):
+    beta, index = S.p2_voice_params(V)
+    return [(ids["mul_fb"], S.MATH_CONSTANT, beta), (ids["mul_idx"], S.MATH_CONSTANT, index)]
+for name, B, build_patch, per_voice in (("cfg2", 1024, S.build_p1, lambda ids: []), ("cfg3_poly", 1024, S.build_p1, poly), ("cfg4", 1, S.build_p2, fm)):
+    p = S.Patch(48000, B, 2)
+    ids = build_patch(p)
+    p.configure_voices(V)
+    for m, f, v in per_voice(ids):
+        p.set_voice_field(m, f, v)
+    fr, mix = p.render(1024)
+    out[name] = p.info()
+st = S.kernel_cache_stats()
+st["info"] = out
+print(json.dumps(st))
+"""
+
+
+@pytest.mark.parametrize("torch_first", [False, True])
+def test_kernels_of_the_baseline_configurations_come_prebuilt(torch_first):
+    """`__graft_entry__.build()` pre-compiles the kernels the BASELINE configurations' default renders use (configs 2 and 4, cfg3_poly) into
+    the in-tree disk cache that ships with the library — once per HIP runtime a process may run on: the image's, and the one torch's
+    wheel brings when torch is imported first (bench.py's order; round 3's driver line said `jit=compiled` because only the former had
+    been built).  A FRESH process of either kind renders them without compiling anything."""
+    e = dict(os.environ, SRACK_ROOT=ROOT, SRACK_IMPORT_TORCH_FIRST="1" if torch_first else "0")
+    e.pop("SRACK_KERNEL_CACHE_DIR", None)   # the default resolution: next to the library
+    r = subprocess.run([sys.executable, "-c", _BASELINE], env=e, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-4000:]
+    st = json.loads(r.stdout.strip().splitlines()[-1])
+    assert st["directory"].endswith(".srack_kernel_cache"), st["directory"]
+    for name, info in st["info"].items():
+        assert "kernel=render_specialized" in info and "jit=disk-cache" in info, (name, info)
+    assert st["compiled"] == 0, st

@@ -25,5 +25,12 @@ case ${1:-} in
       for round in 1 2 3; do for v in $vals; do
         env $var=$v timeout 600 python bench.py --no-cpu --no-side-configs "$@" > $OUT/ab_${var}_${v}_$round.json 2> $OUT/ab.err; echo "$var=$v round $round"; digest $OUT/ab_${var}_${v}_$round.json
       done; done ;;
-  *) echo "usage: gpu_r4.sh tests|bench|ab ..." ;;
+  power) # power <tag> <bench args>: package power and sclk (rocm-smi) during a long run -> gpurun_out/profiles/r04_power_<tag>.log
+      tag=$2; shift 2; mkdir -p gpurun_out/profiles
+      bash tools/power_probe.sh "--no-side-configs $*" > gpurun_out/profiles/r04_power_$tag.log 2>&1; tail -4 gpurun_out/profiles/r04_power_$tag.log ;;
+  prof) # prof <tag> [bench args]: the rocprofv3 evidence (profiles/run_profile.sh) -> gpurun_out/profiles/<tag>_*
+      tag=$2; shift 2; mkdir -p gpurun_out/profiles
+      bash profiles/run_profile.sh "$tag" "$*" > $OUT/prof_$tag.log 2>&1; grep -E "^(ok|FAIL) |summarize rc" $OUT/prof_$tag.log | cut -c1-220
+      cp profiles/${tag}_* gpurun_out/profiles/; rm -rf gpurun_out/prof_$tag ;;
+  *) echo "usage: gpu_r4.sh tests|bench|ab|power|prof ..." ;;
 esac

@@ -1,6 +1,6 @@
 # tools/power_probe.sh "<bench args>" — socket power and clocks (rocm-smi) sampled while bench.py runs; is the kernel at the power limit?
 ARGS="$1"
-python bench.py --steps 1500 --warmup 2 --no-cpu $ARGS > /tmp/pp_bench.log 2>&1 &
+python bench.py --steps ${PP_STEPS:-1500} --warmup 2 --no-cpu $ARGS > /tmp/pp_bench.log 2>&1 &
 BP=$!
 for i in $(seq 1 40); do
   kill -0 $BP 2>/dev/null || break
