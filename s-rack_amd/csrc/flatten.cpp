@@ -1119,7 +1119,105 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             }
             if (back) A.exact_src[(size_t)m] = 1;
         }
-        if (loop_through_pitch) {
+        // Two more ways for a loop to iterate a 1e-7 (round 4; the fuzzer's seeds 725 and 1459; SRACK_LOOSE_LOOPS=1 restores the older rules):
+        //  * a cycle through an EVENT input — an oscillator's sync (oscillator.rs:125-131), an envelope's or the sample player's gate, a
+        //    sequencer's step or sync: a value that differs in its last bits crosses the threshold a sample earlier or later, the event
+        //    moves, and the loop feeds the moved event back into what produced it: the renders part for good;
+        //  * a filter inside a cycle that can AMPLIFY — a mixer whose gains on the cycle add up to more than 1, a multiplication by more
+        //    than 1 or by another signal, a sum of two signals of the cycle, a VCA that is not driven by an envelope, a band- or highpass
+        //    port (|3 (b3 - b4)| reaches 6), anything that is not plain arithmetic: the literal ladder keeps the filter's own rounding
+        //    the reference's, but every other approximation that enters the cycle (an f32 PolyBLEP on the cutoff's CV ...) is amplified.
+        // Both get the exact flavour of the whole patch, as a loop through a pitch does.
+        bool loop_needs_exact = false;
+        if (!(getenv("SRACK_LOOSE_LOOPS") && getenv("SRACK_LOOSE_LOOPS")[0] == '1')) {
+            auto reads = [&](int j, int k) {  // module j reads module k
+                for (const InputRef& in : g.modules[(size_t)j].in)
+                    if (in.src == k) return true;
+                return false;
+            };
+            auto reach = [&](int from, bool forward) {  // modules reachable from `from` along (forward) or against the wires, `from` itself only through a cycle
+                std::vector<char> seen((size_t)n_mod, 0);
+                std::vector<int> stack{from};
+                while (!stack.empty()) {
+                    const int k = stack.back();
+                    stack.pop_back();
+                    for (int j = 0; j < n_mod; j++) {
+                        if (!A.live[(size_t)j] || seen[(size_t)j]) continue;
+                        if (forward ? reads(j, k) : reads(k, j)) {
+                            seen[(size_t)j] = 1;
+                            stack.push_back(j);
+                        }
+                    }
+                }
+                return seen;
+            };
+            auto is_event_input = [&](int module, int port) {
+                switch (g.modules[(size_t)module].type) {
+                case SRACK_MOD_ADSR: return true;
+                case SRACK_MOD_OSCILLATOR: return port == SRACK_OSC_IN_SYNC;
+                case SRACK_MOD_GRID_SEQUENCER:
+                case SRACK_MOD_PATTERN_SEQUENCER: return true;
+                case SRACK_MOD_SAMPLE: return port == SRACK_SAMPLE_IN_GATE;
+                default: return false;
+                }
+            };
+            auto max_abs_field = [&](int module, int field) {
+                double v = std::fabs(g.modules[(size_t)module].fields[(size_t)field]);
+                for (const auto& o : overrides)
+                    if (o.module == module && o.field == field)
+                        for (double x : o.values) v = std::max(v, std::fabs(x));
+                return v;
+            };
+            for (int m = 0; m < n_mod && !loop_needs_exact; m++) {
+                if (!A.live[(size_t)m]) continue;
+                const std::vector<char> down = reach(m, true);
+                if (!down[(size_t)m]) continue;  // not on a cycle
+                const std::vector<char> up = reach(m, false);
+                auto on_cycle = [&](int k) { return down[(size_t)k] && up[(size_t)k]; };  // m's strongly connected component
+                const Module& mod = g.modules[(size_t)m];
+                for (int port = 0; port < mod.n_in && !loop_needs_exact; port++)
+                    if (mod.in[(size_t)port].src >= 0 && on_cycle(mod.in[(size_t)port].src) && is_event_input(m, port)) loop_needs_exact = true;
+                if (mod.type != SRACK_MOD_MOOG_FILTER || loop_needs_exact) continue;
+                for (int k = 0; k < n_mod && !loop_needs_exact; k++) {
+                    if (!A.live[(size_t)k] || !on_cycle(k)) continue;
+                    const Module& c = g.modules[(size_t)k];
+                    int n_cyc_in = 0;
+                    for (int port = 0; port < c.n_in; port++) {
+                        const InputRef& in = c.in[(size_t)port];
+                        if (in.src < 0 || !on_cycle(in.src)) continue;
+                        n_cyc_in++;
+                        if (g.modules[(size_t)in.src].type == SRACK_MOD_MOOG_FILTER && in.port != SRACK_VCF_OUT_LOWPASS) loop_needs_exact = true;
+                    }
+                    switch (c.type) {
+                    case SRACK_MOD_MOOG_FILTER: break;
+                    case SRACK_MOD_MONO_MIXER: {
+                        double sum = 0.0;
+                        for (int port = 0; port < c.n_in; port++)
+                            if (c.in[(size_t)port].src >= 0 && on_cycle(c.in[(size_t)port].src)) sum += max_abs_field(k, SRACK_MIX_GAIN0 + port);
+                        if (sum > 1.0) loop_needs_exact = true;
+                        break;
+                    }
+                    case SRACK_MOD_MATH: {
+                        const int opn = (int)c.fields[SRACK_MATH_OPERATION];
+                        if (opn == SRACK_MATH_MULTIPLY) {
+                            if (c.in[1].src >= 0 || max_abs_field(k, SRACK_MATH_CONSTANT) > 1.0) loop_needs_exact = true;
+                        } else if (n_cyc_in > 1) {
+                            loop_needs_exact = true;
+                        }
+                        break;
+                    }
+                    case SRACK_MOD_VCA: {
+                        const InputRef& cv = c.in[SRACK_VCA_IN_CV];
+                        const bool env = cv.src >= 0 && g.modules[(size_t)cv.src].type == SRACK_MOD_ADSR && max_abs_field(cv.src, SRACK_ADSR_S_VAL) <= 1.0 && !on_cycle(cv.src);
+                        if (!env) loop_needs_exact = true;
+                        break;
+                    }
+                    default: loop_needs_exact = true; break;
+                    }
+                }
+            }
+        }
+        if (loop_through_pitch || loop_needs_exact) {
             render_flags |= SRACK_RENDER_EXACT_OSC;
             std::fill(A.sine_loose.begin(), A.sine_loose.end(), 0);  // (the exact oscillator has one sine)
         }

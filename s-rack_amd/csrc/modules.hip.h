@@ -222,6 +222,124 @@ SRK_DEV double exp2_cr(double e)
     return __builtin_ldexp(r, (int)n);
 }
 
+// 2^e as the HOST's libm computes `pow(2.0, e)` — what the reference's `2.0_f64.powf(e)` is (oscillator.rs:45; Rust's f64::powf is the
+// platform libm's pow).  glibc's pow (2.28 and later: Szabolcs Nagy's algorithm, sysdeps/ieee754/dbl-64/e_pow.c) is within 0.52 ulp of the
+// true value: NOT always the correctly rounded double — one argument in 1300 comes out one ulp off (tools/pow_misround.py), and a patch
+// that iterates its phases (a loop through a pitch or sync input) grows that last bit into different samples.  Until round 3 the exact
+// mode evaluated the power correctly rounded (exp2_cr below, double-double): bit-identical to the reference except on those arguments,
+// and so not on the fuzzer's seeds 725 and 1473.  This is the algorithm itself, operation for operation as the x86-64 FMA build of glibc
+// 2.35 executes it (disassembled: which products are contracted into fused multiply-adds is the compiler's choice, and part of the
+// result): log(2) = lhi + llo falls out of its log step as constants (x = 2: table entry 75, r = 0), then
+//     ehi = e * lhi,  elo = fma(e, llo, fma(lhi, e, -ehi)),  kd = fma(ehi, N / ln 2, 0x1.8p52) - 0x1.8p52  (N = 128),
+//     r = fma(kd, -ln2lo / N, fma(kd, -ln2hi / N, ehi)) + elo,  2^(k / N) = (1 + tail) * scale from its 128-entry table,
+//     result = fma(tail + r + r^2 (C2 + r C3) + r^4 (C4 + r C5), scale, scale)   (the sums as the fmas written below).
+// tools/powcheck.hip compares it with the host's pow over 2^22 oscillator arguments on the GPU box (0 differ), tests/test_oracle.py runs
+// a Python transliteration (exact fused multiply-adds) against the host's pow.  |e ln 2| >= 512 (a pitch of 2^738 cycles per sample)
+// and NaNs go to ocml's pow: inf, 0 and NaN are the same there, and nothing in between is a pitch.
+__device__ const uint64_t kLibmExpTab[256] = {  // glibc's __exp_data.tab (N = 128): {bits(tail_k), bits(2^(k/N)) - (k << 52) / N}
+    0x0000000000000000ull, 0x3ff0000000000000ull, 0x3c9b3b4f1a88bf6eull, 0x3feff63da9fb3335ull,
+    0xbc7160139cd8dc5dull, 0x3fefec9a3e778061ull, 0xbc905e7a108766d1ull, 0x3fefe315e86e7f85ull,
+    0x3c8cd2523567f613ull, 0x3fefd9b0d3158574ull, 0xbc8bce8023f98efaull, 0x3fefd06b29ddf6deull,
+    0x3c60f74e61e6c861ull, 0x3fefc74518759bc8ull, 0x3c90a3e45b33d399ull, 0x3fefbe3ecac6f383ull,
+    0x3c979aa65d837b6dull, 0x3fefb5586cf9890full, 0x3c8eb51a92fdeffcull, 0x3fefac922b7247f7ull,
+    0x3c3ebe3d702f9cd1ull, 0x3fefa3ec32d3d1a2ull, 0xbc6a033489906e0bull, 0x3fef9b66affed31bull,
+    0xbc9556522a2fbd0eull, 0x3fef9301d0125b51ull, 0xbc5080ef8c4eea55ull, 0x3fef8abdc06c31ccull,
+    0xbc91c923b9d5f416ull, 0x3fef829aaea92de0ull, 0x3c80d3e3e95c55afull, 0x3fef7a98c8a58e51ull,
+    0xbc801b15eaa59348ull, 0x3fef72b83c7d517bull, 0xbc8f1ff055de323dull, 0x3fef6af9388c8deaull,
+    0x3c8b898c3f1353bfull, 0x3fef635beb6fcb75ull, 0xbc96d99c7611eb26ull, 0x3fef5be084045cd4ull,
+    0x3c9aecf73e3a2f60ull, 0x3fef54873168b9aaull, 0xbc8fe782cb86389dull, 0x3fef4d5022fcd91dull,
+    0x3c8a6f4144a6c38dull, 0x3fef463b88628cd6ull, 0x3c807a05b0e4047dull, 0x3fef3f49917ddc96ull,
+    0x3c968efde3a8a894ull, 0x3fef387a6e756238ull, 0x3c875e18f274487dull, 0x3fef31ce4fb2a63full,
+    0x3c80472b981fe7f2ull, 0x3fef2b4565e27cddull, 0xbc96b87b3f71085eull, 0x3fef24dfe1f56381ull,
+    0x3c82f7e16d09ab31ull, 0x3fef1e9df51fdee1ull, 0xbc3d219b1a6fbffaull, 0x3fef187fd0dad990ull,
+    0x3c8b3782720c0ab4ull, 0x3fef1285a6e4030bull, 0x3c6e149289cecb8full, 0x3fef0cafa93e2f56ull,
+    0x3c834d754db0abb6ull, 0x3fef06fe0a31b715ull, 0x3c864201e2ac744cull, 0x3fef0170fc4cd831ull,
+    0x3c8fdd395dd3f84aull, 0x3feefc08b26416ffull, 0xbc86a3803b8e5b04ull, 0x3feef6c55f929ff1ull,
+    0xbc924aedcc4b5068ull, 0x3feef1a7373aa9cbull, 0xbc9907f81b512d8eull, 0x3feeecae6d05d866ull,
+    0xbc71d1e83e9436d2ull, 0x3feee7db34e59ff7ull, 0xbc991919b3ce1b15ull, 0x3feee32dc313a8e5ull,
+    0x3c859f48a72a4c6dull, 0x3feedea64c123422ull, 0xbc9312607a28698aull, 0x3feeda4504ac801cull,
+    0xbc58a78f4817895bull, 0x3feed60a21f72e2aull, 0xbc7c2c9b67499a1bull, 0x3feed1f5d950a897ull,
+    0x3c4363ed60c2ac11ull, 0x3feece086061892dull, 0x3c9666093b0664efull, 0x3feeca41ed1d0057ull,
+    0x3c6ecce1daa10379ull, 0x3feec6a2b5c13cd0ull, 0x3c93ff8e3f0f1230ull, 0x3feec32af0d7d3deull,
+    0x3c7690cebb7aafb0ull, 0x3feebfdad5362a27ull, 0x3c931dbdeb54e077ull, 0x3feebcb299fddd0dull,
+    0xbc8f94340071a38eull, 0x3feeb9b2769d2ca7ull, 0xbc87deccdc93a349ull, 0x3feeb6daa2cf6642ull,
+    0xbc78dec6bd0f385full, 0x3feeb42b569d4f82ull, 0xbc861246ec7b5cf6ull, 0x3feeb1a4ca5d920full,
+    0x3c93350518fdd78eull, 0x3feeaf4736b527daull, 0x3c7b98b72f8a9b05ull, 0x3feead12d497c7fdull,
+    0x3c9063e1e21c5409ull, 0x3feeab07dd485429ull, 0x3c34c7855019c6eaull, 0x3feea9268a5946b7ull,
+    0x3c9432e62b64c035ull, 0x3feea76f15ad2148ull, 0xbc8ce44a6199769full, 0x3feea5e1b976dc09ull,
+    0xbc8c33c53bef4da8ull, 0x3feea47eb03a5585ull, 0xbc845378892be9aeull, 0x3feea34634ccc320ull,
+    0xbc93cedd78565858ull, 0x3feea23882552225ull, 0x3c5710aa807e1964ull, 0x3feea155d44ca973ull,
+    0xbc93b3efbf5e2228ull, 0x3feea09e667f3bcdull, 0xbc6a12ad8734b982ull, 0x3feea012750bdabfull,
+    0xbc6367efb86da9eeull, 0x3fee9fb23c651a2full, 0xbc80dc3d54e08851ull, 0x3fee9f7df9519484ull,
+    0xbc781f647e5a3ecfull, 0x3fee9f75e8ec5f74ull, 0xbc86ee4ac08b7db0ull, 0x3fee9f9a48a58174ull,
+    0xbc8619321e55e68aull, 0x3fee9feb564267c9ull, 0x3c909ccb5e09d4d3ull, 0x3feea0694fde5d3full,
+    0xbc7b32dcb94da51dull, 0x3feea11473eb0187ull, 0x3c94ecfd5467c06bull, 0x3feea1ed0130c132ull,
+    0x3c65ebe1abd66c55ull, 0x3feea2f336cf4e62ull, 0xbc88a1c52fb3cf42ull, 0x3feea427543e1a12ull,
+    0xbc9369b6f13b3734ull, 0x3feea589994cce13ull, 0xbc805e843a19ff1eull, 0x3feea71a4623c7adull,
+    0xbc94d450d872576eull, 0x3feea8d99b4492edull, 0x3c90ad675b0e8a00ull, 0x3feeaac7d98a6699ull,
+    0x3c8db72fc1f0eab4ull, 0x3feeace5422aa0dbull, 0xbc65b6609cc5e7ffull, 0x3feeaf3216b5448cull,
+    0x3c7bf68359f35f44ull, 0x3feeb1ae99157736ull, 0xbc93091fa71e3d83ull, 0x3feeb45b0b91ffc6ull,
+    0xbc5da9b88b6c1e29ull, 0x3feeb737b0cdc5e5ull, 0xbc6c23f97c90b959ull, 0x3feeba44cbc8520full,
+    0xbc92434322f4f9aaull, 0x3feebd829fde4e50ull, 0xbc85ca6cd7668e4bull, 0x3feec0f170ca07baull,
+    0x3c71affc2b91ce27ull, 0x3feec49182a3f090ull, 0x3c6dd235e10a73bbull, 0x3feec86319e32323ull,
+    0xbc87c50422622263ull, 0x3feecc667b5de565ull, 0x3c8b1c86e3e231d5ull, 0x3feed09bec4a2d33ull,
+    0xbc91bbd1d3bcbb15ull, 0x3feed503b23e255dull, 0x3c90cc319cee31d2ull, 0x3feed99e1330b358ull,
+    0x3c8469846e735ab3ull, 0x3feede6b5579fdbfull, 0xbc82dfcd978e9db4ull, 0x3feee36bbfd3f37aull,
+    0x3c8c1a7792cb3387ull, 0x3feee89f995ad3adull, 0xbc907b8f4ad1d9faull, 0x3feeee07298db666ull,
+    0xbc55c3d956dcaebaull, 0x3feef3a2b84f15fbull, 0xbc90a40e3da6f640ull, 0x3feef9728de5593aull,
+    0xbc68d6f438ad9334ull, 0x3feeff76f2fb5e47ull, 0xbc91eee26b588a35ull, 0x3fef05b030a1064aull,
+    0x3c74ffd70a5fddcdull, 0x3fef0c1e904bc1d2ull, 0xbc91bdfbfa9298acull, 0x3fef12c25bd71e09ull,
+    0x3c736eae30af0cb3ull, 0x3fef199bdd85529cull, 0x3c8ee3325c9ffd94ull, 0x3fef20ab5fffd07aull,
+    0x3c84e08fd10959acull, 0x3fef27f12e57d14bull, 0x3c63cdaf384e1a67ull, 0x3fef2f6d9406e7b5ull,
+    0x3c676b2c6c921968ull, 0x3fef3720dcef9069ull, 0xbc808a1883ccb5d2ull, 0x3fef3f0b555dc3faull,
+    0xbc8fad5d3ffffa6full, 0x3fef472d4a07897cull, 0xbc900dae3875a949ull, 0x3fef4f87080d89f2ull,
+    0x3c74a385a63d07a7ull, 0x3fef5818dcfba487ull, 0xbc82919e2040220full, 0x3fef60e316c98398ull,
+    0x3c8e5a50d5c192acull, 0x3fef69e603db3285ull, 0x3c843a59ac016b4bull, 0x3fef7321f301b460ull,
+    0xbc82d52107b43e1full, 0x3fef7c97337b9b5full, 0xbc892ab93b470dc9ull, 0x3fef864614f5a129ull,
+    0x3c74b604603a88d3ull, 0x3fef902ee78b3ff6ull, 0x3c83c5ec519d7271ull, 0x3fef9a51fbc74c83ull,
+    0xbc8ff7128fd391f0ull, 0x3fefa4afa2a490daull, 0xbc8dae98e223747dull, 0x3fefaf482d8e67f1ull,
+    0x3c8ec3bc41aa2008ull, 0x3fefba1bee615a27ull, 0x3c842b94c3a9eb32ull, 0x3fefc52b376bba97ull,
+    0x3c8a64a931d185eeull, 0x3fefd0765b6e4540ull, 0xbc8e37bae43be3edull, 0x3fefdbfdad9cbe14ull,
+    0x3c77893b4d91cd9dull, 0x3fefe7c1819e90d8ull, 0x3c5305c14160cc89ull, 0x3feff3c22b8f71f1ull,
+};
+
+SRK_DEV double exp2_libm(double e)
+{
+    constexpr double lhi = 0x1.62e42fefa39efp-1, llo = 0x1.abc9e3b398000p-56;  // log(2.0) as glibc's log_inline returns it
+    const double ehi = e * lhi;
+    const double elo = __builtin_fma(e, llo, __builtin_fma(lhi, e, -ehi));
+    const uint32_t abstop = ((uint32_t)__double2hiint(ehi) >> 20) & 0x7ffu;
+    const bool plain = abstop - 0x3c9u <= 0x3eu;  // 2^-54 <= |e ln 2| < 512
+    const double kds = __builtin_fma(ehi, 0x1.71547652b82fep+7, 0x1.8p52);
+    const uint64_t ki = (uint64_t)__double_as_longlong(kds);
+    const double kd = kds - 0x1.8p52;
+    double r = __builtin_fma(kd, -0x1.cf79abc9e3b3ap-47, __builtin_fma(kd, -0x1.62e42fefa0000p-8, ehi));
+    r = elo + r;
+    const uint32_t idx = 2u * ((uint32_t)ki & 127u);
+    const double tail = __longlong_as_double((long long)kLibmExpTab[idx]);
+    const uint64_t sbits = kLibmExpTab[idx + 1u] + (ki << 45);
+    const double r2 = r * r;
+    const double a = __builtin_fma(r, 0x1.555555555543cp-3, 0x1.ffffffffffdbdp-2);
+    const double b = r + tail;
+    const double c = __builtin_fma(r, 0x1.1111167a4d017p-7, 0x1.55555cf172b91p-5);
+    double tmp = __builtin_fma(a, r2, b);
+    tmp = __builtin_fma(c, r2 * r2, tmp);
+    const double scale = __longlong_as_double((long long)sbits);
+    double y = __builtin_fma(tmp, scale, scale);
+    if (__builtin_amdgcn_ballot_w64(!plain) != 0) {
+        if (!plain) {
+            const uint32_t topy = ((uint32_t)__double2hiint(e) >> 20) & 0x7ffu;
+            if (topy < 0x3beu)
+                y = 1.0 + e;          // |e| < 2^-65: pow's own early exit for x > 1
+            else if (topy < 0x43eu && abstop < 0x3c9u)
+                y = 1.0 + ehi;        // |e ln 2| < 2^-54: exp_inline's
+            else
+                y = pow(2.0, e);      // overflow, underflow, NaN, and the scaled arithmetic of 512 <= |e ln 2| < 1024
+        }
+    }
+    return y;
+}
+
 // poly_blep, f64, literally (oscillator.rs:50-67)
 SRK_DEV double poly_blep_exact(double t, double dt)
 {
@@ -371,7 +489,7 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
             } else {
                 const double e = (double)cv + c.val;
                 // exact mode: 440 * 2^e / sr as written; default mode: (440 / sr) * 2^e with the series above
-                s.seen_delta = (flags & OSC_EXACT) ? 440.0 * exp2_cr(e) / c.sr
+                s.seen_delta = (flags & OSC_EXACT) ? 440.0 * exp2_libm(e) / c.sr
                                : (440.0 / c.sr) * ((flags & OSC_CV_SMALL) ? exp2_fast<false>(e) : exp2_fast<true>(e));
             }
             s.seen_cv = cv;

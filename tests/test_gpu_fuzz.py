@@ -18,8 +18,11 @@ from tests.fuzz_patches import random_patch  # noqa: E402
 
 # seeds past 159: found by tools/fuzz_soak.py — patches whose oscillators take an audio-rate pitch CV inside a feedback loop, where one
 # last-bit difference in 2^cv (ocml's pow against the host libm's) used to grow into different samples (780, 867, 944: fixed by
-# exp2_cr), and patches that overflow into NaNs (707, 774, 1000, 1157)
-@pytest.mark.parametrize("seed,noise", [(s, False) for s in list(range(160)) + [707, 774, 780, 867, 944, 1000, 1157]] + [(s, True) for s in range(40)])
+# exp2_cr in round 2), patches that overflow into NaNs (707, 774, 1000, 1157), and the three the default modes' soak found chaotic in
+# round 3 (725: a loop through a sync input, 1459: a filter <-> mixer loop with a gain above 1, 1473: a loop through a pitch): 725 and
+# 1473 parted from the oracle in exact mode too, at one of the arguments where the libm's pow is not the correctly rounded 2^e — since
+# round 4 the exact mode evaluates 2^cv with the libm's own algorithm (modules.hip.h, exp2_libm) and they are bit-identical
+@pytest.mark.parametrize("seed,noise", [(s, False) for s in list(range(160)) + [707, 725, 774, 780, 867, 944, 1000, 1157, 1459, 1473]] + [(s, True) for s in range(40)])
 def test_random_patch_matches_oracle(seed, noise, oracle, monkeypatch):
     S = srack_pkg.load()
     if seed % 2:  # few voices normally run as quarter-filled waves (more waves, same cost); odd seeds force the full,
@@ -60,17 +63,14 @@ def test_random_patch_matches_oracle(seed, noise, oracle, monkeypatch):
 # the denominator).  Default arithmetic is 1e-7-accurate, not bit-identical: the f32 PolyBLEP, the fma-contracted ladder, the polynomial
 # 2^cv and sine.  A patch that ITERATES such a value — feedback through a pitch or a sync input, a sample-player read index that truncates
 # the other way, a ladder at resonance > 0.9 inside a loop — is chaotic: any 1e-7 grows without bound, and no implementation that is
-# not bit-identical to the host libm stays within 1e-5 on it (NOTES.md section 2 has the soaks).  Those patches are listed here, one line each, as
-# strict xfails: if one starts passing, or another starts failing, the suite says so.
+# not bit-identical to the host libm stays within 1e-5 on it (NOTES.md section 2 has the soaks).  The flattener recognises those structures and
+# renders them with the exact flavour; a patch that still leaves the band would be listed in KNOWN_CHAOTIC as a strict xfail.
 DEFAULT_FLAGS = (0, 2, 4)          # fused / general path (interpreter at this size) / everything per voice
 DEFAULT_SPECIAL = 34               # the general path through a kernel specialised at run time (a compilation: every third seed)
 KNOWN_CHAOTIC = {
-    # (seed, noise): reason — none of the pinned seeds (0 ... 159, the seven soak finds, 0 ... 39 of the noise family) is chaotic since the
-    # flattener gives producers that reach a pitch the exact PolyBLEP / the literal ladder (NOTES.md section 2 has the soaks); these three are what
-    # tools/fuzz_soak_default.py finds in seeds 700 ... 759 and 1400 ... 1499 (480 renders, 9 outside the band, all three modes alike):
-    (725, False): "feedback loop through a sync input: one sample's 1e-7 moves an edge, the phases part for good (also parts in exact mode under tools/fuzz_soak_cfg.py)",
-    (1459, False): "filter <-> mixer loop with a per-voice mixer gain above 1 whose cutoff a square wave slams between two values: chaotic in one voice of 67",
-    (1473, False): "feedback through a pitch input: parts from the oracle in exact mode as well (the last bit of 2^cv against glibc's, iterated)",
+    # (seed, noise): reason.  Empty since round 4: the three the soak had found (725, 1459, 1473) now take the exact flavour by the
+    # flattener's own rules — a cycle through an event input (sync, gate, step), a filter inside a cycle that can amplify, a loop through a
+    # pitch (flatten.cpp 2b) — and the exact flavour follows the reference there to the bit (2^cv by the host libm's own algorithm).
 }
 
 

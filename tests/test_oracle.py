@@ -645,3 +645,26 @@ def test_adsr_sustain_holds_on_a_nan_gate(oracle):
     np.testing.assert_array_equal(bits(a[0]), bits(b[0]))
     assert a[1][60] == 1.0 and np.isnan(a[1][200:]).all()          # the gate: high, then NaN
     assert a[0][100] == np.float32(0.6) and (a[0][200:] == np.float32(0.6)).all()   # sustain reached, and held through the NaNs
+
+
+# ---- 2^cv of the exact render mode: the host libm's pow, operation for operation --------------------------------------------------
+def test_exp2_libm_transliteration_is_the_hosts_pow():
+    """`exp2_libm` (modules.hip.h) ports glibc's pow for the base 2.0 — the x86-64 FMA build, which contracts some of its products — so
+    that the exact render mode's increments are the reference's to the last bit, misroundings included (pow is a 0.52-ulp function: one
+    argument in 1300 is not the correctly rounded 2^e, tools/pow_misround.py).  Here: the same operations in Python with exact fused
+    multiply-adds, against the pow of the libm this host runs (the one the oracle calls), over oscillator-like and wide arguments; the
+    device itself is compared with the host's pow by tools/powcheck.hip and, end to end, by the fuzzer's chaotic seeds (-m gpu)."""
+    import math
+    import platform
+    from tests import libm_pow2 as L
+    if platform.machine() != "x86_64" or platform.libc_ver()[0] != "glibc":
+        pytest.skip("the port follows glibc's x86-64 FMA build of pow")
+    if "fma" not in open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split():
+        pytest.skip("a host without FMA runs glibc's other build of pow")
+    tab = L.header_table()
+    assert len(tab) == 256 and tab[0] == 0 and tab[1] == 0x3FF0000000000000
+    rng = np.random.default_rng(7)
+    args = np.concatenate([rng.uniform(-6, 6, 6000).astype(np.float32).astype(np.float64) + rng.uniform(-6, 3, 6000).astype(np.float32).astype(np.float64),
+                           rng.uniform(-700, 700, 3000), rng.uniform(-1, 1, 1000) * 2.0 ** rng.integers(-80, 0, 1000), [0.0, -0.0, 1.0, -1.0, 0.5, 1e-300]])
+    differ = [float(e) for e in args if L.exp2_libm(float(e), tab) != math.pow(2.0, float(e))]
+    assert not differ, differ[:5]

@@ -17,6 +17,11 @@ __global__ void k(const double* e, double* out, double* out2, int n)
         out2[i] = 440.0 * srack::dev::exp2_cr(e[i]) / 48000.0;
     }
 }
+__global__ void klibm(const double* e, double* out, int n)   // the port of the host libm's own algorithm (exact render mode since round 4)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = srack::dev::exp2_libm(e[i]);
+}
 __global__ void kraw(const double* e, double* out, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,6 +40,13 @@ __global__ void kziv(unsigned long long first, unsigned long long* differ)
     const double n = __builtin_rint(e), f = e - n;
     const double ref = __builtin_ldexp(srack::dev::exp2_cr_taylor(f), (int)n), got = srack::dev::exp2_cr(e);
     if (__double_as_longlong(ref) != __double_as_longlong(got)) atomicAdd(differ, 1ull);
+}
+// (the host compiler folds pow(2.0, x) into exp2(x) when it sees the constant base — LLVM's libcall simplifier, fast-math or not —: the
+// comparisons below are against the libm's POW, which is what the oracle (gcc) and an unoptimised build of the reference call)
+static double host_pow2(double e)
+{
+    volatile double two = 2.0;
+    return std::pow(two, e);
 }
 int main()
 {
@@ -69,17 +81,40 @@ int main()
         hipLaunchKernelGGL(kraw, dim3(n / 256), dim3(256), 0, 0, de, dr, n);
         hipMemcpy(raw.data(), dr, n * 8, hipMemcpyDeviceToHost);
         for (int i = 0; i < n; i++) {
-            const double l = (double)exp2l((long double)e[i]), m = std::pow(2.0, e[i]);
+            const double l = (double)exp2l((long double)e[i]), m = host_pow2(e[i]);
             if (memcmp(&l, &raw[i], 8)) cr_vs_l++;
             if (memcmp(&l, &m, 8)) libm_vs_l++;
         }
     }
     for (int i = 0; i < n; i++) {
-        const double want = 440.0 * std::pow(2.0, e[i]) / 48000.0, want2 = 440.0 * std::exp2(e[i]) / 48000.0;
+        const double want = 440.0 * host_pow2(e[i]) / 48000.0, want2 = 440.0 * std::exp2(e[i]) / 48000.0;
         if (memcmp(&want, &got[i], 8)) bad++;
         if (memcmp(&want, &got2[i], 8)) bad2++;
         if (memcmp(&want2, &got2[i], 8)) bade++;
         if (memcmp(&want, &want2, 8)) badp++;
+    }
+    {   // exp2_libm against the host's pow, bit for bit: the oscillator arguments above, then wide and tiny ones (every branch of the port)
+        double* dr; hipMalloc(&dr, n * 8);
+        std::vector<double> lm(n);
+        int differ = 0;
+        for (int pass = 0; pass < 4; pass++) {
+            std::vector<double> arg(e);
+            if (pass == 1) for (int i = 0; i < n; i++) arg[i] = e[i] * 50.0;              // up to +- 600: every scale the table reaches, the scaled-arithmetic range beyond 512 / ln 2
+            if (pass == 2) for (int i = 0; i < n; i++) arg[i] = std::ldexp(e[i], -40 - (i & 63));  // tiny: the 1 + x exits
+            if (pass == 3) for (int i = 0; i < n; i++) arg[i] = e[i] * 200.0;             // overflow / underflow / subnormal results
+            hipMemcpy(de, arg.data(), n * 8, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(klibm, dim3(n / 256), dim3(256), 0, 0, de, dr, n);
+            hipMemcpy(lm.data(), dr, n * 8, hipMemcpyDeviceToHost);
+            int d = 0;
+            for (int i = 0; i < n; i++) {
+                const double m = host_pow2(arg[i]);
+                if (memcmp(&m, &lm[i], 8)) { if (d < 3) printf("   pass %d: e = %a  libm %a  device %a\n", pass, arg[i], m, lm[i]); d++; }
+            }
+            printf("exp2_libm != host pow(2, e), pass %d (%s): %d of %d\n", pass, pass == 0 ? "oscillator arguments" : pass == 1 ? "x 50" : pass == 2 ? "tiny" : "x 200", d, n);
+            differ += d;
+        }
+        hipMemcpy(de, e.data(), n * 8, hipMemcpyHostToDevice);
+        printf("exp2_libm against the host libm: %d differ in all\n", differ);
     }
     printf("bare 2^e against RN(exp2l): exp2_cr differs in %d, libm pow in %d\n", cr_vs_l, libm_vs_l);
     printf("of %d: ocml pow != libm pow %d;  exp2_cr != libm pow %d;  exp2_cr != libm exp2 %d;  libm pow != libm exp2 %d\n", n, bad, bad2, bade, badp);
