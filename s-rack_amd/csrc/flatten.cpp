@@ -1093,6 +1093,50 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                 if (pitches_reached(back, false, any2, true)[(size_t)k]) loop_through_pitch = true;
             }
         }
+        // ... and a producer whose approximated output reaches an EVENT input — an envelope's or the sample player's gate, an oscillator's
+        // sync, a sequencer's step or sync: `value > 0.0` decides when something happens, and a value 1e-7 off crosses zero a sample
+        // earlier or later once in a few million crossings: an edge, and everything behind it, moves by a sample (the soak's seed 2691: a
+        // bandpass into a gate, one voice of 131 a sample late).  Those producers get the exact PolyBLEP / the literal ladder as well.
+        // Exempt: an oscillator's SQUARE wired straight to the input — the usual gate and clock source — whose default evaluation
+        // re-derives any value close to zero with the reference's own operations (modules.hip.h, square_sign_safe).
+        if (!(getenv("SRACK_LOOSE_EVENTS") && getenv("SRACK_LOOSE_EVENTS")[0] == '1'))
+            for (int m = 0; m < n_mod; m++) {
+                if (!A.live[(size_t)m] || A.exact_src[(size_t)m]) continue;
+                const int t = g.modules[(size_t)m].type;
+                const uint32_t ports = t == SRACK_MOD_OSCILLATOR ? (A.port_live[(size_t)m] & 6u) : t == SRACK_MOD_MOOG_FILTER ? (A.port_live[(size_t)m] & 7u) : 0u;
+                if (!ports) continue;
+                std::vector<uint32_t> tainted((size_t)n_mod, 0u);
+                tainted[(size_t)m] = ports;
+                for (bool changed = true; changed;) {  // where the value is carried to
+                    changed = false;
+                    for (int k = 0; k < n_mod; k++) {
+                        if (!A.live[(size_t)k]) continue;
+                        const Module& sink = g.modules[(size_t)k];
+                        for (int port = 0; port < sink.n_in; port++) {
+                            const InputRef& in = sink.in[(size_t)port];
+                            if (in.src < 0 || !(tainted[(size_t)in.src] & (1u << in.port))) continue;
+                            const uint32_t add = carried_to(sink.type, port) & ~tainted[(size_t)k];
+                            if (add) {
+                                tainted[(size_t)k] |= add;
+                                changed = true;
+                            }
+                        }
+                    }
+                }
+                for (int k = 0; k < n_mod && !A.exact_src[(size_t)m]; k++) {
+                    if (!A.live[(size_t)k]) continue;
+                    const Module& sink = g.modules[(size_t)k];
+                    for (int port = 0; port < sink.n_in; port++) {
+                        const InputRef& in = sink.in[(size_t)port];
+                        if (in.src < 0 || !(tainted[(size_t)in.src] & (1u << in.port))) continue;
+                        const bool event = sink.type == SRACK_MOD_ADSR || (sink.type == SRACK_MOD_OSCILLATOR && port == SRACK_OSC_IN_SYNC) ||
+                                           sink.type == SRACK_MOD_GRID_SEQUENCER || sink.type == SRACK_MOD_PATTERN_SEQUENCER ||
+                                           (sink.type == SRACK_MOD_SAMPLE && port == SRACK_SAMPLE_IN_GATE);
+                        const bool direct_square = in.src == m && t == SRACK_MOD_OSCILLATOR && in.port == SRACK_OSC_OUT_SQUARE;
+                        if (event && !direct_square) A.exact_src[(size_t)m] = 1;
+                    }
+                }
+            }
         // A filter inside ANY feedback loop iterates its own rounding too: the fma-contracted ladder stays within 1e-5 of the reference while
         // its differences die out (a damped recurrence, section 2 of NOTES.md), not when a loop feeds them back in — through a mixer into
         // its own input, or through a gate that restarts a sample player (random patches of that kind left the band after a few thousand
