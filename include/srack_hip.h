@@ -311,7 +311,9 @@ int srack_render_planes(srack_patch* p, int* channel_plane, int cap);
  *   d_mix    : device, f32 [channels][n_samples] = sum over voices of the channel's frames
  *              (the N-voice generalisation of MonoMixerModule's gain-1 sum, mixer.rs:109-118);
  *              may be NULL.
- *   stream   : hipStream_t (NULL = default stream).  The call is asynchronous w.r.t. the host.
+ *   stream   : hipStream_t (NULL = default stream).  The call is asynchronous w.r.t. the host.  The library enqueues on the stream
+ *              during the call and never touches it afterwards (a later call, edit or state read-back that depends on this call's
+ *              work waits for an event of the library's own): the host may destroy the stream whenever it could for its own work.
  */
 int srack_render(srack_patch* p, uint32_t n_samples, float* d_frames, float* d_mix,
                  uint32_t flags, void* stream);

@@ -127,7 +127,8 @@ struct TickSession {
     uint32_t R = 0;          // depth of the rings
     uint64_t c = 0;          // calls (= chunks) rendered
     uint64_t n0 = 0;         // absolute index of the session's first sample
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;          // the stream the session's calls come on: COMPARED with the next call's, never used after the call it came with
+    hipEvent_t done = nullptr;         // recorded on that stream at the end of every call of the session: whoever ends the session waits for it
     float* d_ring = nullptr;           // [R][n_tracks][L] control tracks
     size_t ring_bytes = 0;
     std::vector<uint32_t*> d_copies;   // per unit: [R][words] copies of its table
@@ -170,6 +171,7 @@ void device_release(DeviceState* d)
     (void)hipFree(d->d_mixpart);
     (void)hipFree(d->d_mixgroup);
     (void)hipFree(d->d_tracks);
+    if (d->tick.done) (void)hipEventDestroy(d->tick.done);
     (void)hipFree(d->tick.d_ring);
     for (uint32_t* c : d->tick.d_copies) (void)hipFree(c);
     for (auto& p : d->timings) {
@@ -213,16 +215,22 @@ int peek_program(PatchHandle& h, uint32_t flags, FlatPair& scratch, const FlatPa
     return rc;
 }
 
-// The state as of the last rendered sample goes back into the units' tables (on the session's stream); what was computed ahead is dropped.
-static int tick_end(PatchHandle& h)
+// The state as of the last rendered sample goes back into the units' tables; what was computed ahead is dropped.  The copies are issued
+// on `on` — the stream of the call that ends the session, or the null stream followed by a host-side wait when no call is at hand (an
+// edit, a state read-back) — after that stream has waited for the session's last call (TickSession::done).  The stream the session's
+// calls came on is not touched: a host may have destroyed it since (it moved to another stream, or is tearing down).  The session
+// is only forgotten once every copy has been enqueued: a failure leaves it in place and is reported.
+static int tick_end(PatchHandle& h, hipStream_t on, bool host_wait)
 {
     DeviceState* d = h.dev;
     if (!d || !d->tick.on) return SRACK_OK;
     TickSession& k = d->tick;
-    k.on = false;
+    if (k.done) HIP_TRY(hipStreamWaitEvent(on, k.done, 0));
     for (size_t s2 = 0; s2 < k.d_copies.size(); s2++)
         if (k.words[s2] > 0)  // chunk c - 1 left its state in copy c % R
-            HIP_TRY(hipMemcpyAsync(d->ctl[s2].d_table, k.d_copies[s2] + (size_t)(k.c % k.R) * k.words[s2], sizeof(uint32_t) * k.words[s2], hipMemcpyDeviceToDevice, k.st));
+            HIP_TRY(hipMemcpyAsync(d->ctl[s2].d_table, k.d_copies[s2] + (size_t)(k.c % k.R) * k.words[s2], sizeof(uint32_t) * k.words[s2], hipMemcpyDeviceToDevice, on));
+    k.on = false;
+    if (host_wait) HIP_TRY(hipStreamSynchronize(on));  // (whatever stream the next call comes on finds the tables in place)
     return SRACK_OK;
 }
 
@@ -230,7 +238,7 @@ int ensure_program(PatchHandle& h, uint32_t flags)
 {
     if (program_current(h, flags)) return SRACK_OK;
     {  // the program is about to be replaced: what it holds is read back (keep_state) or dropped — as of the last rendered sample either way
-        const int rc_tick = tick_end(h);
+        const int rc_tick = tick_end(h, nullptr, true);
         if (rc_tick != SRACK_OK) return rc_tick;
     }
     flags &= ~kLaunchPolicyFlags;
@@ -745,15 +753,25 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     for (const FlatProgram& Cp : h.prog.ctl) tick = tick && Cp.hdr.n_rings == 0 && Cp.fv_rows == 0;
     TickSession& tk = d->tick;
     // (a call that fails part-way — a launch error — must not leave a session behind whose bookkeeping is a call ahead of the device)
+    // (... it ends the session instead: the state as of the last call that completed goes back into the tables — on the null stream, after
+    // the device has come to rest —, and if even that fails the program is dropped, so that the next render starts from what the host
+    // holds rather than from tables nobody can vouch for)
     struct TickGuard {
+        PatchHandle& h;
         TickSession& t;
         bool done = false;
-        ~TickGuard() { if (!done) t.on = false; }
-    } tick_guard{tk};
+        ~TickGuard()
+        {
+            if (done || !t.on) return;
+            (void)hipDeviceSynchronize();
+            if (tick_end(h, nullptr, true) != SRACK_OK) {
+                t.on = false;
+                h.prog_valid = false;
+            }
+        }
+    } tick_guard{h, tk};
     if (tk.on && !(tick && tk.L == T && tk.st == st && tk.n0 + tk.c * (uint64_t)T == h.samples_rendered)) {  // not the call the session guessed
-        const hipStream_t was_on = tk.st;
-        if ((rc = tick_end(h)) != SRACK_OK) return rc;
-        if (was_on != st) HIP_TRY(hipStreamSynchronize(was_on));
+        if ((rc = tick_end(h, st, false)) != SRACK_OK) return rc;  // on THIS call's stream, behind the session's last call (an event: no host-side wait)
     }
     std::vector<std::pair<uint32_t, uint32_t>> chunks;       // (t_off, len)
     if (tick) {
@@ -1123,7 +1141,11 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         HIP_TRY(hipGetLastError());
     }
     h.samples_rendered += T;
-    if (tick) tk.c++;
+    if (tick) {
+        if (!tk.done) HIP_TRY(hipEventCreateWithFlags(&tk.done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(tk.done, st));  // what ends the session waits for this call, on whatever stream it ends it
+        tk.c++;
+    }
     tick_guard.done = true;
     return SRACK_OK;
 }
@@ -1207,7 +1229,7 @@ int device_read_rows(PatchHandle& h, int ctl_stage, int first_row, int n_rows, u
     const size_t V = P.n_voices;
     const uint32_t* d_table = h.dev ? (ctl_stage >= 0 ? h.dev->ctl[(size_t)ctl_stage].d_table : h.dev->voice.d_table) : nullptr;
     if (d_table) {
-        const int rc_tick = tick_end(h);
+        const int rc_tick = tick_end(h, nullptr, true);
         if (rc_tick != SRACK_OK) return rc_tick;
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(host_dst, d_table + (size_t)first_row * V, sizeof(uint32_t) * V * (size_t)n_rows, hipMemcpyDeviceToHost));

@@ -66,6 +66,34 @@ def main():
     for k in range(len(SPEC)):
         out[f"both_fr{k}"], out[f"both_mx{k}"] = bufs[k][0].cpu().numpy(), bufs[k][1].cpu().numpy()
         out[f"info{k}"] = np.array(patches[k].info())
+    # a stream that goes away: patch "p1" ticks on a raw non-blocking HIP stream, the host DESTROYS that stream, then (a) reads state back and
+    # carries on on the null stream, (b) carries on on a second raw stream straight away.  The library may not touch a stream after the call
+    # that passed it (the session's copy-back waits on an event of its own): both continue bit for bit like the patch alone.
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    for tag, read_back in (("gone_read", True), ("gone_move", False)):
+        p, V = build(S, "p1")
+        n_planes, _ = p.planes()
+        fr = torch.empty((N, n_planes, L, V), dtype=torch.float32, device=dev)
+        mx = torch.empty((N, 2, L), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        a, b = C.c_void_p(), C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(a), 1) == 0 and hip.hipStreamCreateWithFlags(C.byref(b), 1) == 0  # hipStreamNonBlocking
+        for i in range(4):
+            p.render_raw(L, fr[i].data_ptr(), mx[i].data_ptr(), 0, a.value)
+        assert hip.hipStreamDestroy(a) == 0   # (work in flight completes; the handle is dead)
+        if read_back:
+            out[tag + "_pos"] = p.get_voice_field(1, S.OSC_POS)   # the gate LFO: a module of the control program
+            for i in range(4, N):
+                p.render_raw(L, fr[i].data_ptr(), mx[i].data_ptr(), 0, None)
+        else:
+            for i in range(4, N):
+                p.render_raw(L, fr[i].data_ptr(), mx[i].data_ptr(), 0, b.value)
+        torch.cuda.synchronize()
+        assert hip.hipStreamDestroy(b) == 0
+        out[tag + "_fr"], out[tag + "_mx"] = fr.cpu().numpy(), mx.cpu().numpy()
     np.savez(sys.argv[1], **out)
 
 

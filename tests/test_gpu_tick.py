@@ -91,3 +91,8 @@ def test_two_patches_on_two_streams(tmp_path):
         np.testing.assert_array_equal(bits(d[f"both_fr{k}"]), bits(d[f"alone_fr{k}"]), err_msg=f"frames of patch {k}")
         np.testing.assert_array_equal(bits(d[f"both_mx{k}"]), bits(d[f"alone_mx{k}"]), err_msg=f"mix of patch {k}")
     assert "kernel=render_voice_chain_track" in str(d["info0"]) and "kernel=render_specialized" in str(d["info1"])
+    # ... and a session whose stream the host destroyed: carried on after a state read-back / on another stream, still the same bits
+    for tag in ("gone_read", "gone_move"):
+        np.testing.assert_array_equal(bits(d[tag + "_fr"]), bits(d["alone_fr0"]), err_msg=tag)
+        np.testing.assert_array_equal(bits(d[tag + "_mx"]), bits(d["alone_mx0"]), err_msg=tag)
+    assert ((d["gone_read_pos"] >= 0) & (d["gone_read_pos"] < 1)).all()
