@@ -1051,7 +1051,31 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                 if (A.live[(size_t)m] && g.modules[(size_t)m].type == SRACK_MOD_NONLINEAR) {
                     std::vector<uint32_t> from((size_t)n_mod, 0u);
                     from[(size_t)m] = 1u;
-                    A.nonlin_loose[(size_t)m] = !reaches_pitch(from, true);
+                    bool loose = !reaches_pitch(from, true);
+                    // ... nor may anything iterate or amplify its 4e-6: not on a feedback cycle (its own output coming back to one of its
+                    // inputs, through whatever), and not into another NonLinear's base, whose exponent multiplies a relative error
+                    if (loose) {
+                        std::vector<uint32_t> t2((size_t)n_mod, 0u);
+                        t2[(size_t)m] = 1u;
+                        for (bool changed = true; changed && loose;) {
+                            changed = false;
+                            for (int k = 0; k < n_mod && loose; k++) {
+                                if (!A.live[(size_t)k]) continue;
+                                const Module& sink = g.modules[(size_t)k];
+                                for (int port = 0; port < sink.n_in; port++) {
+                                    const InputRef& in = sink.in[(size_t)port];
+                                    if (in.src < 0 || !(t2[(size_t)in.src] & (1u << in.port))) continue;
+                                    if (k == m || (sink.type == SRACK_MOD_NONLINEAR && port == 0)) loose = false;
+                                    const uint32_t all = sink.n_out >= 32 ? ~0u : (1u << sink.n_out) - 1u;  // every input to all outputs: enough to close a loop
+                                    if (all & ~t2[(size_t)k]) {
+                                        t2[(size_t)k] |= all;
+                                        changed = true;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    A.nonlin_loose[(size_t)m] = loose;
                 }
         // A saw whose value nobody integrates (a pitch input) or thresholds (a gate, a sync, a clock, a VCA's CV) may run its phase in 2^-64
         // fixed point (modules.hip.h, FOsc): the two accumulators differ by 1e-14 after a second, far below f32 resolution at the output —

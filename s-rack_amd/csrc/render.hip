@@ -552,11 +552,9 @@ static int launch_fm_block(int out_mode, const KernelArgs& ka, const ChainRoles&
     const dim3 grid(ka.n_waves), block(kBlkVoices * kBlkSlices);
 #define SRK_BLK(O)                                                                                                              \
     do {                                                                                                                        \
-        static bool raised = false; /* more than 64 KB of dynamic LDS has to be asked for, once per kernel */                  \
-        if (!raised) {                                                                                                          \
-            HIP_TRY(hipFuncSetAttribute((const void*)render_fm_pair_block<O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            raised = true;                                                                                                      \
-        }                                                                                                                       \
+        /* more than 64 KB of dynamic LDS has to be asked for — per device (the attribute belongs to the current device's copy of the \
+           function) and from any thread: asked for before every launch, which costs nothing next to one */                    \
+        HIP_TRY(hipFuncSetAttribute((const void*)render_fm_pair_block<O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((render_fm_pair_block<O>), grid, block, lds, st, ka, roles);                                         \
     } while (0)
     if (out_mode == 3)

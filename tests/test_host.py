@@ -606,3 +606,19 @@ def test_nonlinear_takes_the_f32_power_only_where_nothing_integrates_it(S):
         q.connect(shaper, 0, out, 1)
         q.configure_voices(8)
         assert [f & 0x200 for f in nonlin_flags(q)] == [0], sink_type
+    # ... nor on a feedback cycle (shaper -> mixer -> back into the shaper), nor in front of another shaper's base
+    q = S.Patch(48000, 1024, 2)
+    osc, mix, shaper, out = q.add_module(S.MOD_OSCILLATOR), q.add_module(S.MOD_MONO_MIXER), q.add_module(S.MOD_NONLINEAR), q.add_module(S.MOD_OUTPUT)
+    q.connect(osc, S.OSC_OUT_SINE, mix, 0)
+    q.connect(shaper, 0, mix, 1)
+    q.connect(mix, 0, shaper, 0)
+    q.connect(shaper, 0, out, 0)
+    q.configure_voices(8)
+    assert [f & 0x200 for f in nonlin_flags(q)] == [0]
+    q = S.Patch(48000, 1024, 2)
+    osc, first, second, out = q.add_module(S.MOD_OSCILLATOR), q.add_module(S.MOD_NONLINEAR), q.add_module(S.MOD_NONLINEAR), q.add_module(S.MOD_OUTPUT)
+    q.connect(osc, S.OSC_OUT_SINE, first, 0)
+    q.connect(first, 0, second, 0)
+    q.connect(second, 0, out, 0)
+    q.configure_voices(8)
+    assert sorted(f & 0x200 for f in nonlin_flags(q)) == [0, 0x200]   # the first feeds a base: f64; the second feeds the output only: f32
