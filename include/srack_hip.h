@@ -281,6 +281,10 @@ int srack_patch_get_module_position(const srack_patch* p, int module, float* x, 
 /* Contents of one output buffer before the first tick (what a loaded file carries): `n` = buffer_size samples, or 0
  * for a fresh, zeroed buffer.  Only the sink of a broken feedback edge ever observes it. */
 int srack_patch_set_output_buffer(srack_patch* p, int module, int port, const float* samples, uint32_t n);
+/* SynthModule::get_output (synth.rs:243) as far as a host can observe it before the first tick: the block the patch holds for this
+ * port — what srack_patch_set_output_buffer or a loaded file put there.  Copies up to `cap` samples, returns how many the port holds
+ * (0: a fresh, zeroed buffer).  Err(()) for a bad port is SRACK_ERR_PORT. */
+int srack_patch_get_output_buffer(const srack_patch* p, int module, int port, float* dst, uint32_t cap);
 /* Noise modules (SRACK_MOD_NOISE).  With sm(x) = splitmix64's output function applied to x + 0x9E3779B97F4A7C15,
  *   base(module)  = sm(seed ^ sm(module))                       module = its index in the patch
  *   key(voice)    = sm(base ^ (first_voice + voice))            voice  = its index in this handle

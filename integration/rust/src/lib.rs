@@ -41,6 +41,8 @@ mod ffi {
         pub fn srack_patch_set_field(p: *mut SrackPatch, module: c_int, field: c_int, value: f64) -> c_int;
         pub fn srack_patch_get_field(p: *const SrackPatch, module: c_int, field: c_int, value: *mut f64) -> c_int;
         pub fn srack_patch_set_step(p: *mut SrackPatch, module: c_int, channel: c_int, step: c_int, state: c_int, value: c_int) -> c_int;
+        pub fn srack_patch_set_output_buffer(p: *mut SrackPatch, module: c_int, port: c_int, samples: *const f32, n: u32) -> c_int;
+        pub fn srack_patch_get_output_buffer(p: *const SrackPatch, module: c_int, port: c_int, dst: *mut f32, cap: u32) -> c_int;
         pub fn srack_patch_set_noise_seed(p: *mut SrackPatch, seed: u64, first_voice: u64) -> c_int;
         pub fn srack_patch_keep_state(p: *mut SrackPatch, keep: c_int) -> c_int;
         pub fn srack_patch_set_wave(p: *mut SrackPatch, module: c_int, samples: *const f32, n_samples: u32, sample_rate: f32) -> c_int;

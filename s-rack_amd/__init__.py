@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "srack_abi_version", "srack_last_error", "srack_patch_create", "srack_patch_destroy", "srack_patch_add_module",
     "srack_patch_num_modules", "srack_patch_module_type", "srack_module_num_inputs", "srack_module_num_outputs",
     "srack_patch_set_field", "srack_patch_get_field", "srack_patch_keep_state", "srack_patch_set_step", "srack_patch_get_step", "srack_patch_set_wave", "srack_patch_get_wave", "srack_patch_load_srk", "srack_patch_save_srk", "srack_patch_module_id",
-    "srack_patch_set_module_position", "srack_patch_get_module_position", "srack_patch_set_output_buffer", "srack_patch_set_noise_seed", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
+    "srack_patch_set_module_position", "srack_patch_get_module_position", "srack_patch_set_output_buffer", "srack_patch_get_output_buffer", "srack_patch_set_noise_seed", "srack_patch_connect", "srack_patch_disconnect", "srack_patch_get_input",
     "srack_patch_plan", "srack_patch_plan_list", "srack_patch_removed_edges", "srack_patch_delayed_edges",
     "srack_voices_configure", "srack_voices_set_field_f32", "srack_voices_set_field_f64", "srack_render_planes", "srack_render", "srack_render_reserve",
     "srack_render_info", "srack_render_kernel_source", "srack_render_kernel_compile", "srack_render_kernel_ms", "srack_voices_get_field", "srack_kernel_cache_set_dir", "srack_kernel_cache_stats", "srack_device_count", "srack_device_set", "srack_device_get",
@@ -74,6 +74,7 @@ def _load():
     L.srack_patch_set_module_position.argtypes = [vp, i32, C.c_float, C.c_float]
     L.srack_patch_get_module_position.argtypes = [vp, i32, fp, fp]
     L.srack_patch_set_output_buffer.argtypes = [vp, i32, i32, fp, u32]
+    L.srack_patch_get_output_buffer.argtypes = [vp, i32, i32, fp, u32]
     L.srack_patch_set_noise_seed.argtypes = [vp, C.c_uint64, C.c_uint64]
     L.srack_patch_keep_state.argtypes = [vp, i32]
     L.srack_patch_connect.argtypes = [vp, i32, i32, i32, i32]
@@ -230,6 +231,14 @@ class Patch:
     def set_output_buffer(self, module, port, samples):
         a = np.ascontiguousarray(samples, dtype=np.float32)
         _check(lib.srack_patch_set_output_buffer(self.h, module, port, a.ctypes.data_as(C.POINTER(C.c_float)), a.size))
+
+    def get_output_buffer(self, module, port):
+        """The block the patch holds for this port before the first tick (a loaded file's, or set_output_buffer's); empty: fresh zeros."""
+        n = _check(lib.srack_patch_get_output_buffer(self.h, module, port, None, 0))
+        a = np.zeros(n, dtype=np.float32)
+        if n:
+            _check(lib.srack_patch_get_output_buffer(self.h, module, port, a.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return a
 
     def keep_state(self, keep=True):
         """Edits between renders no longer restart the voices: the modules' device state is carried into the re-flattened program."""

@@ -365,6 +365,28 @@ int srack_patch_set_output_buffer(srack_patch* p, int module, int port, const fl
     });
 }
 
+int srack_patch_get_output_buffer(const srack_patch* p, int module, int port, float* dst, uint32_t cap)
+{
+    return guarded([&]() -> int {
+        CHECK_HANDLE(p);
+        const Graph& g = p->h.graph;
+        if (module < 0 || module >= (int)g.modules.size()) {
+            set_error("get_output_buffer: no such module");
+            return SRACK_ERR_INVALID;
+        }
+        const Module& m = g.modules[(size_t)module];
+        if (port < 0 || port >= m.n_out) {
+            set_error("get_output_buffer: no such port");  // Err(()) of get_output
+            return SRACK_ERR_PORT;
+        }
+        if ((size_t)port >= m.out_init.size()) return 0;
+        const std::vector<float>& b = m.out_init[(size_t)port];
+        if (dst)
+            for (size_t i = 0; i < b.size() && i < (size_t)cap; i++) dst[i] = b[i];
+        return (int)b.size();
+    });
+}
+
 int srack_patch_keep_state(srack_patch* p, int keep)
 {
     return guarded([&]() -> int {

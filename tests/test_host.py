@@ -622,3 +622,63 @@ def test_nonlinear_takes_the_f32_power_only_where_nothing_integrates_it(S):
     q.connect(second, 0, out, 0)
     q.configure_voices(8)
     assert sorted(f & 0x200 for f in nonlin_flags(q)) == [0, 0x200]   # the first feeds a base: f64; the second feeds the output only: f32
+
+
+# ---- the Rust binding's extern block against the C header, mechanically (scope row (f)3: no rustc in the image) -----------------------
+def _c_prototypes():
+    """name -> (return type, [parameter types]) of every function include/srack_hip.h declares, comments stripped"""
+    import re
+    text = open(os.path.join(ROOT, "include", "srack_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    protos = {}
+    for ret, name, args in re.findall(r"\b(int|const char\s*\*|void)\s+(srack_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        params = []
+        for a in [x.strip() for x in args.replace("\n", " ").split(",")]:
+            if a in ("void", ""):
+                continue
+            m = re.match(r"(.*?)(\w+)$", a)          # the last word is the parameter's name
+            params.append(re.sub(r"\s+", " ", m.group(1)).strip().replace(" *", "*"))
+        protos[name] = (re.sub(r"\s+", " ", ret).replace(" *", "*"), params)
+    return protos
+
+
+_C_TO_RUST = {
+    "int": {"c_int"}, "uint32_t": {"u32"}, "uint64_t": {"u64"}, "size_t": {"usize"}, "double": {"f64"}, "float": {"f32"},
+    "const char*": {"*const c_char"}, "char*": {"*mut c_char"}, "void*": {"*mut c_void", "*mut u8"}, "const void*": {"*const c_void", "*const u8"},
+    "void**": {"*mut *mut c_void"}, "srack_patch*": {"*mut SrackPatch"}, "const srack_patch*": {"*const SrackPatch", "*mut SrackPatch"},
+    "srack_patch**": {"*mut *mut SrackPatch"}, "float*": {"*mut f32"}, "const float*": {"*const f32"}, "double*": {"*mut f64"},
+    "const double*": {"*const f64"}, "int*": {"*mut c_int"}, "const int*": {"*const c_int"}, "size_t*": {"*mut usize"},
+    "srack_kernel_cache_info*": {"*mut SrackKernelCacheInfo"},
+}
+
+
+def _rust_externs(text):
+    """[(name, [parameter types], return type)] of the `fn srack_*` declarations inside `extern "C" { ... }` blocks"""
+    import re
+    out = []
+    for block in re.findall(r'extern "C" \{(.*?)\n\s*\}', text, flags=re.S):
+        block = re.sub(r"//[^\n]*", "", block)
+        for name, args, ret in re.findall(r"fn\s+(srack_\w+)\s*\((.*?)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+            params = [re.sub(r"\s+", " ", a.split(":", 1)[1]).strip() for a in args.split(",") if ":" in a]
+            out.append((name, params, (ret or "()").strip()))
+    return out
+
+
+@pytest.mark.parametrize("source", ["integration/rust/src/lib.rs", "INTEGRATION.md"])
+def test_rust_extern_block_matches_the_header(source):
+    """The Rust side cannot be compiled here (no rustc): at least every `extern "C"` declaration — the binding crate's and the glue shown
+    in INTEGRATION.md — must name a function the header declares, with the same number of parameters and types that are the C ones'
+    Rust spellings (c_int for int, *mut SrackPatch for srack_patch*, usize for size_t ...).  A signature that drifts is a crash at the
+    first call; this is the check a `bindgen` run would be."""
+    protos = _c_prototypes()
+    assert len(protos) >= 56 and "srack_render" in protos
+    decls = _rust_externs(open(os.path.join(ROOT, source)).read())
+    assert len(decls) >= 15, source
+    for name, params, ret in decls:
+        assert name in protos, f"{source}: {name} is not in include/srack_hip.h"
+        c_ret, c_params = protos[name]
+        assert ret in _C_TO_RUST[c_ret], f"{source}: {name} returns {ret}, the header says {c_ret}"
+        assert len(params) == len(c_params), f"{source}: {name} takes {len(params)} parameters, the header {len(c_params)}"
+        for k, (r, c) in enumerate(zip(params, c_params)):
+            assert r in _C_TO_RUST[c], f"{source}: {name} parameter {k} is {r}, the header says {c}"

@@ -6,6 +6,7 @@ the structure the reference's struct definitions spell; files produced by a seco
 to the same graph as the one built through the API; and the load-time rules of deserialize() (reversed module order,
 V0 migrations, set_audio_config, dropped connections) hold.
 """
+import os
 import struct
 
 import msgpack
@@ -420,3 +421,102 @@ def test_damaged_files_are_rejected_not_crashed_on(S):
             except S.SrackError:
                 pass
     assert loaded > 100 and rejected > 1000
+
+
+# ---- rack files written by the APP (scope row (f)2: none exists yet — the reference holds no fixture and cannot be built here) --------
+# The day a maintainer drops a real file into tests/golden/ (INTEGRATION.md section 5 has the three commands), these pin the codec
+# against the app's own bytes instead of against this repo's reading of rmp-serde: every such file must load, survive a save / load
+# round trip, and render — from the state and buffers it carries — like the oracle rebuilt from what the loaded patch reports.
+_NF = {0: 0, 1: 4, 2: 13, 3: 10, 4: 1, 5: 4, 6: 2, 7: 7, 8: 4, 9: 1, 10: 6, 11: 0, 12: 6}   # fields per module type
+
+
+def _app_files():
+    import glob
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.srk")))
+
+
+def _mirror(S, O, q, B):
+    """an OraclePatch holding what the loaded patch `q` reports through the graph API: types, fields (state included), steps, waves,
+    the blocks its ports carry, wiring"""
+    o = O.OraclePatch(48000, B, 2)
+    for m in range(q.num_modules()):
+        t = q.module_type(m)
+        assert o.add_module(t) == m
+        for f in range(_NF[t]):
+            o.set_field(m, f, q.get_field(m, f))
+        if t in (S.MOD_GRID_SEQUENCER, S.MOD_PATTERN_SEQUENCER):
+            for ch in ([0] if t == S.MOD_GRID_SEQUENCER else range(8)):
+                for i in range(64):
+                    st, val = q.get_step(m, ch, i)
+                    if st:
+                        o.set_step(m, ch, i, st, val)
+        if t == S.MOD_SAMPLE:
+            w, rate = q.get_wave(m)
+            newflag = q.get_field(m, S.SAMPLE_WAVE_NEW)
+            if len(w) or rate:
+                o.set_wave(m, w, rate)
+            o.set_field(m, S.SAMPLE_WAVE_NEW, newflag)
+        for port in range(q.get_num_outputs(m)):
+            blk = q.get_output_buffer(m, port)
+            if len(blk):
+                o.set_output_buffer(m, port, blk)
+    for m in range(q.num_modules()):
+        for k in range(q.get_num_inputs(m)):
+            src = q.get_input(m, k)
+            if src is not None:
+                o.connect(src[0], src[1], m, k)
+    return o
+
+
+def test_output_buffers_read_back(S):
+    """srack_patch_get_output_buffer (SynthModule::get_output before the first tick): what set_output_buffer / a loaded file put there"""
+    B = 16
+    p = S.Patch(48000, B, 2)
+    ids = S.build_p2(p)
+    assert len(p.get_output_buffer(ids["osc_m"], 0)) == 0
+    blk = np.linspace(-1, 1, B).astype(np.float32)
+    p.set_output_buffer(ids["osc_m"], 0, blk)
+    np.testing.assert_array_equal(p.get_output_buffer(ids["osc_m"], 0), blk)
+    q = S.Patch.load_srk(p.save_srk(), 48000, B, 2)
+    m = [k for k in range(q.num_modules()) if q.module_id(k) == p.module_id(ids["osc_m"])][0]
+    np.testing.assert_array_equal(q.get_output_buffer(m, 0), blk)
+    with pytest.raises(S.SrackError):
+        p.get_output_buffer(ids["osc_m"], 7)
+
+
+def test_app_written_files_load_and_round_trip(S):
+    files = _app_files()
+    if not files:
+        pytest.skip("no app-written rack file in tests/golden/ yet (INTEGRATION.md section 5: how to make one)")
+    for path in files:
+        raw = open(path, "rb").read()
+        p = S.Patch.load_srk(raw, 48000, 1024, 2)
+        assert p.num_modules() > 0, path
+        again = S.Patch.load_srk(p.save_srk(), 48000, 1024, 2)
+        assert _describe(again) == _describe(p), path
+        # the app's encoder and this one must agree on the bytes of a file that was loaded and saved without a render
+        assert p.save_srk() == raw, f"{path}: save(load(file)) differs from the app's own bytes"
+
+
+@pytest.mark.gpu
+def test_app_written_files_render_like_the_oracle(S):
+    files = _app_files()
+    if not files:
+        pytest.skip("no app-written rack file in tests/golden/ yet (INTEGRATION.md section 5: how to make one)")
+    from oracle import oracle as O
+    for path in files:
+        q = S.Patch.load_srk(open(path, "rb").read(), 48000, 1024, 2)
+        o = _mirror(S, O, q, 1024)
+        assert q.plan() == o.plan(), path
+        V, T = 3, 4096
+        ref, _ = o.render_batch(V, T, [], threads=2)
+        q.configure_voices(V)
+        fr = q.render_channels(T, 1)                                   # exact mode: bit for bit (NaNs as NaNs)
+        same = (fr.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(fr) & np.isnan(ref))
+        assert same.all(), path
+        q2 = S.Patch.load_srk(open(path, "rb").read(), 48000, 1024, 2)
+        q2.configure_voices(V)
+        fr = q2.render_channels(T, 0)                                  # default mode: the 1e-5 contract
+        ok = np.isfinite(ref) & np.isfinite(fr)
+        err = np.abs(fr.astype(np.float64)[ok] - ref.astype(np.float64)[ok]) / np.maximum(np.abs(ref.astype(np.float64)[ok]), 1.0)
+        assert (err.size == 0 or err.max() <= 1e-5), path
