@@ -1477,13 +1477,14 @@ struct MixArgs {
     float* mix;             // [channels][mix_stride], T samples of it
     uint32_t T, n_waves, n_channels, n_planes;
     uint32_t mix_stride;    // samples between channels of `mix` (the whole render's length; T is one segment of it)
+    uint32_t t_begin, t_end;  // mix_reduce_groups: the samples of the segment this launch sums (a chunk)
     int32_t channel_plane[8];
 };
 
 __global__ __launch_bounds__(256) void mix_reduce_groups(MixArgs m)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= m.T) return;
+    const uint32_t i = m.t_begin + blockIdx.x * 256u + threadIdx.x;  // samples [t_begin, t_end) of the segment: one chunk's, or all
+    if (i >= m.t_end) return;
     const uint32_t per = (m.n_waves + kMixSplit - 1) / kMixSplit;
     const uint32_t w0 = blockIdx.y * per, w1 = min(m.n_waves, w0 + per);
     for (uint32_t plane = 0; plane < m.n_planes; plane++) {

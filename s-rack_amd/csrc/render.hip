@@ -58,6 +58,9 @@ struct Knobs {
     uint32_t fm_block_min = 4096;     // ... and the shortest call it takes: a host that ticks block by block (one call per buffer_size samples) would move
                                       // the ring between HBM and LDS every call — config 4 at buffer_size 1024, 47 calls of 1024: 18.2 ms against 7.5 in one
                                       // call and 10.5 through render_fm_pair_ring; calls of 4096: 9.9 — so short calls keep the ring kernel
+    int mix_aside = 0;                // 1: the mix partials of chunk k are summed on a side stream while chunk k + 1 renders.  Measured (round 4, one box,
+                                      // three alternating rounds): config 3 11.52 / 11.54 / 11.57 ms per step all at once at the end, 11.62 / 11.67 / 11.69 aside;
+                                      // cfg3_poly 16.40 against 16.43 — at the power cap a kernel that runs beside the voices is paid for in clock
     int tick = 1;                     // calls of one chunk keep the control program running ahead across calls (TickSession below); 0: every call starts it afresh
 };
 static const Knobs& knobs()
@@ -83,6 +86,7 @@ static const Knobs& knobs()
         v.fm_block_chunk = (uint32_t)num("SRACK_FM_BLOCK_CHUNK", 256, 65536, 65536);
         v.fm_block_min = (uint32_t)num("SRACK_FM_BLOCK_MIN", 1, 65536, 4096);
         v.tick = (int)num("SRACK_TICK", 0, 1, 1);
+        v.mix_aside = (int)num("SRACK_MIX_ASIDE", 0, 1, 0);
         return v;
     }();
     return k;
@@ -140,6 +144,11 @@ constexpr uint32_t kTickBatch = 256, kTickFirstBatch = 8;  // (a session that th
 
 struct DeviceState {
     TickSession tick;
+    // The per-wave mix partials of chunk k are summed (mix_reduce_groups) on a side stream while chunk k + 1 renders, instead of all
+    // at once after the last chunk: the 0.17 ms that pass over V/64 x T floats were the one stretch of a step without a voice kernel.
+    hipStream_t mix_stream = nullptr;
+    std::vector<hipEvent_t> ev_mix;   // [chunk] recorded on the render's stream after the chunk's voice launch
+    hipEvent_t ev_mix_done = nullptr; // recorded on the side stream after its last sum
     DevProg voice;
     std::vector<DevProg> ctl;  // one per control stage
     KernelArgs* d_stage_slots = nullptr;  // [launches][stages] argument blocks of the staged control pipeline
@@ -172,6 +181,9 @@ void device_release(DeviceState* d)
     (void)hipFree(d->d_mixgroup);
     (void)hipFree(d->d_tracks);
     if (d->tick.done) (void)hipEventDestroy(d->tick.done);
+    for (hipEvent_t e : d->ev_mix) (void)hipEventDestroy(e);
+    if (d->ev_mix_done) (void)hipEventDestroy(d->ev_mix_done);
+    if (d->mix_stream) (void)hipStreamDestroy(d->mix_stream);
     (void)hipFree(d->tick.d_ring);
     for (uint32_t* c : d->tick.d_copies) (void)hipFree(c);
     for (auto& p : d->timings) {
@@ -1054,6 +1066,28 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         roles.track = P.ops[0].aux;  // the ring's state row
         if (!special) d->kernel_name = fm_block ? "render_fm_pair_block" : P.fused_variant == 1 ? "render_fm_pair_ring" : "render_fm_pair";
     }
+    MixArgs m{};
+    if (d_mix) {
+        m.mixpart = d->d_mixpart;
+        m.mixgroup = d->d_mixgroup;
+        m.mix = d_mix;
+        m.T = T;
+        m.mix_stride = T_total;
+        m.n_waves = n_waves;
+        m.n_channels = C;
+        m.n_planes = (uint32_t)P.hdr.n_planes;
+        for (int c = 0; c < 8; c++) m.channel_plane[c] = P.hdr.channel_plane[c];
+    }
+    const bool mix_aside = d_mix && n_chunks > 1 && knobs().mix_aside;  // chunk k's partials are summed beside chunk k + 1's voices
+    if (mix_aside) {
+        if (!d->mix_stream) HIP_TRY(hipStreamCreateWithFlags(&d->mix_stream, hipStreamNonBlocking));
+        if (!d->ev_mix_done) HIP_TRY(hipEventCreateWithFlags(&d->ev_mix_done, hipEventDisableTiming));
+        while (d->ev_mix.size() < n_chunks) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            d->ev_mix.push_back(e);
+        }
+    }
     for (uint32_t k = 0; k < n_chunks; k++) {
         const uint32_t t_off = chunks[k].first, len = chunks[k].second;
         KernelArgs ka{};
@@ -1112,6 +1146,15 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
             launch_interp(P, ka, st);
         }
         HIP_TRY(hipGetLastError());
+        if (mix_aside && k + 1 < n_chunks) {
+            HIP_TRY(hipEventRecord(d->ev_mix[k], st));
+            HIP_TRY(hipStreamWaitEvent(d->mix_stream, d->ev_mix[k], 0));
+            MixArgs mk = m;
+            mk.t_begin = t_off;
+            mk.t_end = t_off + len;
+            hipLaunchKernelGGL(mix_reduce_groups, dim3((len + 255) / 256, kMixSplit), dim3(256), 0, d->mix_stream, mk);
+            HIP_TRY(hipGetLastError());
+        }
         if (timed) {
             HIP_TRY(hipEventRecord(e1, st));
             d->timings.emplace_back(e0, e1);
@@ -1124,17 +1167,14 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     }
 
     if (d_mix) {
-        MixArgs m{};
-        m.mixpart = d->d_mixpart;
-        m.mixgroup = d->d_mixgroup;
-        m.mix = d_mix;
-        m.T = T;
-        m.mix_stride = T_total;
-        m.n_waves = n_waves;
-        m.n_channels = C;
-        m.n_planes = (uint32_t)P.hdr.n_planes;
-        for (int c = 0; c < 8; c++) m.channel_plane[c] = P.hdr.channel_plane[c];
-        hipLaunchKernelGGL(mix_reduce_groups, dim3((T + 255) / 256, kMixSplit), dim3(256), 0, st, m);
+        // what is left to sum: everything, or — the earlier chunks being summed on the side stream — the last chunk only
+        m.t_begin = mix_aside ? chunks[n_chunks - 1].first : 0u;
+        m.t_end = T;
+        hipLaunchKernelGGL(mix_reduce_groups, dim3((m.t_end - m.t_begin + 255) / 256, kMixSplit), dim3(256), 0, st, m);
+        if (mix_aside) {
+            HIP_TRY(hipEventRecord(d->ev_mix_done, d->mix_stream));
+            HIP_TRY(hipStreamWaitEvent(st, d->ev_mix_done, 0));  // (also keeps the NEXT render's voice launches off the partials until they are summed)
+        }
         hipLaunchKernelGGL(mix_reduce_final, dim3((T + 255) / 256), dim3(256), 0, st, m);
         HIP_TRY(hipGetLastError());
     }
