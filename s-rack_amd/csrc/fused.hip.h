@@ -363,14 +363,6 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
     XSaw xo;
     const bool xs = kExact && kOscAPort == OSC_OUT_SAW && xsaw_usable(sa.pos, ka.delta) && vcf_nan_free(sv);
     if (xs) xsaw_init(xo, sa.pos, ka.delta);
-#ifdef SRK_MIX_MFMA
-    // (experiment, wave.hip.h) default mode, frames + mix, a full wave, finite filter state and coefficients: then every filter output
-    // of the launch is finite (clamped states, a saw / square / sine within +-2 as input), and a tile's samples are finite iff its
-    // envelope values are.  Everything else — ragged tiles, the last wave, exact mode — keeps the LDS tile.
-    MfmaMix mm;
-    const bool mfma_launch = !kExact && kOut == 3 && em.full_wave && vcf_nan_free(sv);
-    if (mfma_launch) mfma_mix_init(mm, lane);
-#endif
     for (uint32_t t0 = 0; t0 < a.T; t0 += kMixRows) {
         const int n = (int)min((uint32_t)kMixRows, a.T - t0);
         if (xs) {
@@ -423,39 +415,6 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
             const float o = (negative || cv_pos) ? y * env : 0.0f;
             emit_put<kOut>(em, mix_tile, o, i, V);
         };
-#ifdef SRK_MIX_MFMA
-        if (mfma_launch && n == kMixRows) {
-            // the tile's 32 envelope values are finite <=> every sample y * env of it is (the filter's outputs are, see mfma_launch)
-            const uint32_t eb = ((const uint32_t*)env_track)[t0 + (uint32_t)(lane & 31)];
-            if (__builtin_amdgcn_ballot_w64((eb & 0x7f800000u) == 0x7f800000u) == 0) {
-                auto sample_m = [&](int i) {
-                    const float env = env_s[t0 + (uint32_t)i];
-                    float lp, bp, hp;
-                    vcf_run<true>(sv, sv_fin, x, lp, bp, hp);
-                    const float y = kVcfPort == VCF_OUT_LP ? lp : (kVcfPort == VCF_OUT_BP ? bp : hp);
-                    if (kFixed) {
-                        fpos_lo = fa_osc.lo;
-                        fpos_hi = fa_osc.hi;
-                        x = fosc_saw(fa_osc);
-                    } else {
-                        pos_a = ca.pos;
-                        x = cosc_step<kOscAPort>(ca);
-                    }
-                    const bool cv_pos = (uint32_t)(__float_as_int(env) - 1) < 0x7f800000u;
-                    const float o = (negative || cv_pos) ? y * env : 0.0f;
-                    emit_put<kOut & 1>(em, mix_tile, o, i, V);  // frames as before (kOut & 1 == 0 cannot happen here: a mix-only launch has kOut == 2)
-                    mfma_mix_put(mm, o, i, em.mp + t0, lane);
-                };
-#pragma unroll 32
-                for (int i = 0; i < kMixRows; i++) sample_m(i);
-                if (kOut & 1) {
-                    em.frame_row += (size_t)kMixRows * V;
-                    emit_rebase(em);
-                }
-                continue;
-            }
-        }
-#endif
         if (n == kMixRows) {  // constant trip count: unrollable (readlane is convergent, so a runtime count is not)
 #pragma unroll 32
             for (int i = 0; i < kMixRows; i++) sample(i);

@@ -693,120 +693,56 @@ static uint32_t lanes_per_wave(uint32_t V)
     return lanes;
 }
 
-// One segment [t_seg, t_seg + T) of a render of T_total samples.  d_frames / d_mix point at the WHOLE render's buffers.
-static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint32_t T, float* d_frames, float* d_mix, uint32_t flags, hipStream_t st)
-{
+// One segment [t_seg, t_seg + T) of a render of T_total samples (d_frames / d_mix point at the WHOLE render's buffers), in the order it is
+// carried out: prepare (silence, scratch) -> plan (which kernel, how the control program overlaps, the chunk schedule, tick session or
+// not) -> control (what the control program must have finished before the first voice launch; a session's bookkeeping) -> roles (the
+// hand-written kernels' op roles) -> voices (one launch per chunk) -> mix (the partials' sums) -> finish.
+struct Segment {
+    PatchHandle& h;
+    const FlatProgram& P;
+    DeviceState* const d;
+    TickSession& tk;
+    const uint32_t V, C, T_total, t_seg, T, flags;
+    float *d_frames, *d_mix;
+    const hipStream_t st;
     int rc = SRACK_OK;
-    const FlatProgram& P = h.prog.voice;
-    const uint32_t V = P.n_voices, C = (uint32_t)P.hdr.n_channels;
-    if (d_frames) d_frames += (size_t)t_seg * V;
-    if (d_mix) d_mix += t_seg;
-    if (!h.dev) {
-        rc = upload_program(h);
-        if (rc != SRACK_OK) return rc;
-    }
-    DeviceState* d = h.dev;
     // Voices per wave.  A full wave (64) is right whenever there are enough voices to give every SIMD work.
     // With few voices, half- or quarter-filled waves double / quadruple the number of waves: a VALU instruction
     // costs the same for 16 lanes as for 64, so this only pays while SIMDs would otherwise sit idle (VALU-bound
     // kernels: up to one wave per SIMD) or while waves are latency-bound (FM pair, interpreter: up to four).
-    const bool fm_block = fm_block_shape(P, flags, T);  // 32 voices per workgroup, whatever the voice count
-    const uint32_t lanes = fm_block ? (uint32_t)kBlkVoices : lanes_per_wave(V);
-    const uint32_t n_waves = (V + lanes - 1) / lanes;
+    const bool fm_block;  // 32 voices per workgroup, whatever the voice count
+    const uint32_t lanes, n_waves;
+    // plan
+    bool has_ctl = false, co_ctl = false, special_ctl = false, tick = false;
+    uint32_t n_stages = 0, n_tracks = 0, kChunkMax = 0, kChunkFirst = 0, max_lag = 0, n_chunks = 0, n_ctl_launch = 0;
+    const JitKernel* special = nullptr;  // a kernel specialised for this program (jit.cpp), if the program takes one; special_ctl: with the control units as extra blocks of every launch
+    std::vector<std::pair<uint32_t, uint32_t>> chunks;  // (t_off, len)
+    // roles
+    ChainRoles roles{};
+    SeqRoles seq{};
+    uint32_t osc_port = 0, vcf_port = 0, seq_port = 0;
+    bool fused = false, track = false, seq_chain = false, fm_pair = false;
+    // mix
+    MixArgs m{};
+    bool mix_aside = false;
 
-    if (P.hdr.n_planes == 0) {  // nothing reaches the output: silence (output.rs:55)
-        if (d_mix)
-            for (uint32_t c = 0; c < C; c++)
-                hipLaunchKernelGGL(fill_zero, dim3((T + 255) / 256), dim3(256), 0, st, d_mix + (size_t)c * T_total, (size_t)T);
-        // Under srack_patch_keep_state the program holds every planned module (the reference's execute() ticks them all, heard or
-        // not): they must keep running — phases, envelopes, sequencer steps, rings — or a wire patched into the output later would
-        // find them frozen while the sample counter moved on.  The kernels run with nothing to write.
-        if (!h.keep_state || (P.ops.empty() && h.prog.n_tracks == 0)) {
-            h.samples_rendered += T;
-            return SRACK_OK;
-        }
-        d_frames = nullptr;
-        d_mix = nullptr;
+    Segment(PatchHandle& h_, uint32_t T_total_, uint32_t t_seg_, uint32_t T_, float* d_frames_, float* d_mix_, uint32_t flags_, hipStream_t st_)
+        : h(h_), P(h_.prog.voice), d(h_.dev), tk(h_.dev->tick), V(h_.prog.voice.n_voices), C((uint32_t)h_.prog.voice.hdr.n_channels), T_total(T_total_),
+          t_seg(t_seg_), T(T_), flags(flags_), d_frames(d_frames_ ? d_frames_ + (size_t)t_seg_ * h_.prog.voice.n_voices : nullptr),
+          d_mix(d_mix_ ? d_mix_ + t_seg_ : nullptr), st(st_), fm_block(fm_block_shape(h_.prog.voice, flags_, T_)),
+          lanes(fm_block ? (uint32_t)kBlkVoices : lanes_per_wave(h_.prog.voice.n_voices)), n_waves((h_.prog.voice.n_voices + lanes - 1) / lanes)
+    {
     }
-    if (d_mix && (rc = grow(d->d_mixpart, d->mixpart_bytes, sizeof(float) * (size_t)P.hdr.n_planes * n_waves * T)) != SRACK_OK) return rc;
-    if (d_mix && (rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * T)) != SRACK_OK) return rc;
 
-    const bool has_ctl = h.prog.n_tracks > 0;
-    // Two ways to overlap the control program with the voice kernels:
-    //  co-scheduled (fused track kernel + fused gate-envelope control program): voice launch k carries one extra
-    //    block that computes the track of chunk k+1; everything stays on the caller's stream.
-    //  two streams (any other combination): control chunks run on a private stream, voice chunk k waits on event k.
-    //    This overlaps only while the two streams map to different hardware queues (GPU_MAX_HW_QUEUES, default 4,
-    //    shared with the host's other streams): measured 15 ms -> 20 ms per step once RCCL's streams are alive.
-    const uint32_t n_stages = (uint32_t)h.prog.ctl.size();
-    const bool co_ctl = has_ctl && P.fused == FUSED_VOICE_CHAIN_TRACK && n_stages == 1 && h.prog.ctl[0].fused == FUSED_CTL_GATE_ENV && h.prog.n_tracks == 1;
-    auto ctl_work = [&](uint32_t t_off, uint32_t len) {
+    // ---- small helpers -------------------------------------------------------------------------------------------------------------------
+    CtlWork ctl_work(uint32_t t_off, uint32_t len)
+    {
         const FlatProgram& Cp = h.prog.ctl[0];
         return CtlWork{d->ctl[0].d_ops, d->ctl[0].d_table, d->d_tracks + (size_t)Cp.ops[2].aux * T + t_off, len,
                        Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_EXACT), nullptr, 0u};
-    };
-    const JitKernel* special = nullptr;  // a kernel specialised for this program (jit.cpp), if the program takes one
-    bool special_ctl = false;            // ... with the control program's units as extra blocks of every launch
+    }
+    int get_event(hipEvent_t& e)
     {
-        const int om = (d_frames ? 1 : 0) | (d_mix ? 2 : 0);
-        if ((rc = resolve_specialized(h, flags, om ? om : 4, &special, &special_ctl)) != SRACK_OK) return rc;
-    }
-    // chunk schedule: short first chunks (only control chunk 0 is exposed), doubling up to kChunkMax
-    // With a control pipeline of depth L the first voice chunk waits for L + 1 control launches: those stay short.
-    const uint32_t kChunkMax = knobs().chunk_max;
-    const uint32_t kChunkFirst = std::min(knobs().chunk_first, kChunkMax);
-    uint32_t max_lag = 0;
-    for (int lag : h.prog.ctl_lag) max_lag = std::max(max_lag, (uint32_t)lag);
-    // A call of one chunk whose control program runs as blocks of the voice launches is (the start of) a tick session (TickSession):
-    // everything the units hold must live in their tables (no rings in HBM, no reverb lines — those have no copies to move through).
-    bool tick = knobs().tick && has_ctl && (co_ctl || (special && special_ctl)) && t_seg == 0 && T_total == T && T <= kChunkMax;
-    for (const FlatProgram& Cp : h.prog.ctl) tick = tick && Cp.hdr.n_rings == 0 && Cp.fv_rows == 0;
-    TickSession& tk = d->tick;
-    // (a call that fails part-way — a launch error — must not leave a session behind whose bookkeeping is a call ahead of the device)
-    // (... it ends the session instead: the state as of the last call that completed goes back into the tables — on the null stream, after
-    // the device has come to rest —, and if even that fails the program is dropped, so that the next render starts from what the host
-    // holds rather than from tables nobody can vouch for)
-    struct TickGuard {
-        PatchHandle& h;
-        TickSession& t;
-        bool done = false;
-        ~TickGuard()
-        {
-            if (done || !t.on) return;
-            (void)hipDeviceSynchronize();
-            if (tick_end(h, nullptr, true) != SRACK_OK) {
-                t.on = false;
-                h.prog_valid = false;
-            }
-        }
-    } tick_guard{h, tk};
-    if (tk.on && !(tick && tk.L == T && tk.st == st && tk.n0 + tk.c * (uint64_t)T == h.samples_rendered)) {  // not the call the session guessed
-        if ((rc = tick_end(h, st, false)) != SRACK_OK) return rc;  // on THIS call's stream, behind the session's last call (an event: no host-side wait)
-    }
-    std::vector<std::pair<uint32_t, uint32_t>> chunks;       // (t_off, len)
-    if (tick) {
-        chunks.emplace_back(0u, T);
-    } else if (has_ctl) {
-        uint32_t k = 0;
-        for (uint32_t t_off = 0, len = kChunkFirst; t_off < T; t_off += len, k++) {
-            if (k > max_lag) len = std::min(len * 2, kChunkMax);
-            len = std::min(len, T - t_off);
-            chunks.emplace_back(t_off, len);
-        }
-    } else {  // no control program to overlap with, but short launches still win: the waves of a launch stay within a few
-              // samples of each other, so their frame rows land in the same DRAM pages (FM pair 13.2 -> 9.9 ms per step)
-        // The z^-1 FM pair (one wave per SIMD at config 4's 65 536 voices, no ring traffic) wants them shorter still: 2048 samples 7.26 ms per
-        // step, 4096 7.39, 1536 7.31, 1024 7.43, 8192 7.85 (tools/ab_env.sh, one box); its ring variant and the flagship are flat from 3072 to 6144.
-        // A specialised kernel without rings in HBM at one wave per SIMD or fewer is in the same position (config 4 through the general
-        // path: 7.36 - 7.46 ms per step at 4096, 7.26 - 7.28 at 2048, two rounds on one box).
-        const bool fm_z1 = P.fused == FUSED_FM_PAIR && P.fused_variant == 0 && !(flags & (SRACK_RENDER_NO_FUSION | SRACK_RENDER_EXACT_OSC));
-        const bool lone_waves = special && P.hdr.n_rings == 0 && n_waves <= 1024 && !(flags & SRACK_RENDER_EXACT_OSC);
-        // (the time-parallel FM pair keeps its ring in LDS for a launch and moves it to and from HBM at the ends: one launch per segment)
-        const uint32_t len = fm_block ? knobs().fm_block_chunk : (fm_z1 || lone_waves) ? std::min(kChunkMax, 2048u) : kChunkMax;
-        for (uint32_t t_off = 0; t_off < T; t_off += len) chunks.emplace_back(t_off, std::min(len, T - t_off));
-    }
-    const uint32_t n_chunks = (uint32_t)chunks.size();
-    auto get_event = [&](hipEvent_t& e) -> int {
         if (!d->pool.empty()) {
             e = d->pool.back();
             d->pool.pop_back();
@@ -814,12 +750,12 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         }
         HIP_TRY(hipEventCreate(&e));
         return SRACK_OK;
-    };
+    }
 
-    if (has_ctl && (rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
     // One argument block per (launch, control unit): launch j runs unit s on chunk j - lag[s]; chunk c is complete after launch
     // c + max_lag.  (A control program that was not cut into units is one unit with lag 0.)
-    auto stage_args = [&](uint32_t s, uint32_t k) {
+    KernelArgs stage_args(uint32_t s, uint32_t k)
+    {
         const uint32_t t_off = chunks[k].first, len = chunks[k].second;
         KernelArgs kc{};
         kc.ops = d->ctl[s].d_ops;
@@ -838,9 +774,9 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         kc.lanes = 64;
         kc.n0 = h.samples_rendered + t_off;
         return kc;
-    };
-    const uint32_t n_ctl_launch = n_chunks + max_lag;
-    auto upload_stage_slots = [&](hipStream_t on) -> int {
+    }
+    int upload_stage_slots(hipStream_t on)
+    {
         d->h_stage_slots.assign((size_t)n_ctl_launch * n_stages, KernelArgs{});
         for (uint32_t s2 = 0; s2 < n_stages; s2++)
             for (uint32_t k = 0; k < n_chunks; k++) {
@@ -858,15 +794,19 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         }
         HIP_TRY(hipMemcpyAsync(d->d_stage_slots, d->h_stage_slots.data(), bytes, hipMemcpyHostToDevice, on));
         return SRACK_OK;
-    };
+    }
     // ---- tick session: argument blocks of unit s2 on chunk x, and the launches that start a session ----
-    const uint32_t n_tracks = (uint32_t)h.prog.n_tracks;
-    auto tick_tracks = [&](uint64_t x) { return tk.d_ring + (size_t)(x % tk.R) * n_tracks * tk.L; };
-    auto tick_table = [&](uint32_t s2, uint64_t x) -> uint32_t* {  // the copy chunk x reads (x = 0: the table itself) / chunk x - 1 wrote
+    float* tick_tracks(uint64_t x)
+    {
+        return tk.d_ring + (size_t)(x % tk.R) * n_tracks * tk.L;
+    }
+    uint32_t* tick_table(uint32_t s2, uint64_t x)
+    {  // the copy chunk x reads (x = 0: the table itself) / chunk x - 1 wrote
         if (tk.words[s2] == 0) return nullptr;
         return x == 0 ? d->ctl[s2].d_table : tk.d_copies[s2] + (size_t)(x % tk.R) * tk.words[s2];
-    };
-    auto tick_unit_args = [&](uint32_t s2, uint64_t x) {
+    }
+    KernelArgs tick_unit_args(uint32_t s2, uint64_t x)
+    {
         KernelArgs kc{};
         kc.ops = d->ctl[s2].d_ops;
         kc.prog = h.prog.ctl[s2].hdr;
@@ -884,15 +824,17 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         kc.n0 = tk.n0 + x * tk.L;
         kc.block0 = s2;
         return kc;
-    };
-    auto tick_work = [&](uint64_t x) {  // the fused gate -> envelope control program on chunk x
+    }
+    CtlWork tick_work(uint64_t x)
+    {  // the fused gate -> envelope control program on chunk x
         const FlatProgram& Cp = h.prog.ctl[0];
         return CtlWork{d->ctl[0].d_ops, tick_table(0, x), tick_tracks(x) + (size_t)Cp.ops[2].aux * tk.L, tk.L,
                        Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_EXACT), tick_table(0, x + 1), (uint32_t)Cp.hdr.n_rows};
-    };
+    }
     // global launch g of the session runs unit s2 on chunk g - lag[s2]: launches 0 .. max_lag run alone when the session starts (they
     // complete chunk 0), launch max_lag + 1 + i rides on the voice launch of call i.  The device holds the first ones and a batch of the others.
-    auto tick_upload_slots = [&](uint64_t base) -> int {
+    int tick_upload_slots(uint64_t base)
+    {
         const uint32_t fill = max_lag + 1, batch = base == 0 ? kTickFirstBatch : kTickBatch;
         d->h_stage_slots.assign((size_t)(fill + batch) * n_stages, KernelArgs{});
         for (uint32_t s2 = 0; s2 < n_stages; s2++) {
@@ -913,279 +855,424 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
         tk.slots_base = base;
         tk.slots_n = batch;
         return SRACK_OK;
-    };
-    if (tick && !tk.on) {  // a session starts: its first chunk's control work is exposed, like any render's
-        const uint32_t R = max_lag + 2;
-        if ((rc = grow(tk.d_ring, tk.ring_bytes, sizeof(float) * (size_t)R * n_tracks * T)) != SRACK_OK) return rc;
-        if (tk.d_copies.empty()) {
-            tk.d_copies.assign(n_stages, nullptr);
-            tk.words.assign(n_stages, 0);
-            for (uint32_t s2 = 0; s2 < n_stages; s2++) {
-                tk.words[s2] = h.prog.ctl[s2].table.size();
-                if (tk.words[s2] > 0) HIP_TRY(hipMalloc(&tk.d_copies[s2], sizeof(uint32_t) * tk.words[s2] * R));
+    }
+    // ---- prepare: a program nothing of which reaches the output; the mix scratch -----------------------------------------------------------
+    int prepare(bool& done)
+    {
+        done = false;
+        if (P.hdr.n_planes == 0) {  // nothing reaches the output: silence (output.rs:55)
+            if (d_mix)
+                for (uint32_t c = 0; c < C; c++)
+                    hipLaunchKernelGGL(fill_zero, dim3((T + 255) / 256), dim3(256), 0, st, d_mix + (size_t)c * T_total, (size_t)T);
+            // Under srack_patch_keep_state the program holds every planned module (the reference's execute() ticks them all, heard or
+            // not): they must keep running — phases, envelopes, sequencer steps, rings — or a wire patched into the output later would
+            // find them frozen while the sample counter moved on.  The kernels run with nothing to write.
+            if (!h.keep_state || (P.ops.empty() && h.prog.n_tracks == 0)) {
+                h.samples_rendered += T;
+                done = true;
+                return SRACK_OK;
             }
+            d_frames = nullptr;
+            d_mix = nullptr;
         }
-        tk.on = true;
-        tk.L = T;
-        tk.R = R;
-        tk.c = 0;
-        tk.n0 = h.samples_rendered;
-        tk.st = st;
-        if (co_ctl) {
-            hipLaunchKernelGGL(render_ctl_gate_env, dim3(1), dim3(64), 0, st, tick_work(0));
-            HIP_TRY(hipGetLastError());
-        } else {
-            if ((rc = tick_upload_slots(0)) != SRACK_OK) return rc;
-            for (uint32_t g = 0; g <= max_lag; g++) {
+        if (d_mix && (rc = grow(d->d_mixpart, d->mixpart_bytes, sizeof(float) * (size_t)P.hdr.n_planes * n_waves * T)) != SRACK_OK) return rc;
+        if (d_mix && (rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * T)) != SRACK_OK) return rc;
+
+        return SRACK_OK;
+    }
+
+    // ---- plan: the kernel, the way the control program overlaps with the voices, tick session or not, the chunk schedule -------------------
+    int plan()
+    {
+        has_ctl = h.prog.n_tracks > 0;
+        // Two ways to overlap the control program with the voice kernels:
+        //  co-scheduled (fused track kernel + fused gate-envelope control program): voice launch k carries one extra
+        //    block that computes the track of chunk k+1; everything stays on the caller's stream.
+        //  two streams (any other combination): control chunks run on a private stream, voice chunk k waits on event k.
+        //    This overlaps only while the two streams map to different hardware queues (GPU_MAX_HW_QUEUES, default 4,
+        //    shared with the host's other streams): measured 15 ms -> 20 ms per step once RCCL's streams are alive.
+        n_stages = (uint32_t)h.prog.ctl.size();
+        co_ctl = has_ctl && P.fused == FUSED_VOICE_CHAIN_TRACK && n_stages == 1 && h.prog.ctl[0].fused == FUSED_CTL_GATE_ENV && h.prog.n_tracks == 1;
+        {
+            const int om = (d_frames ? 1 : 0) | (d_mix ? 2 : 0);
+            if ((rc = resolve_specialized(h, flags, om ? om : 4, &special, &special_ctl)) != SRACK_OK) return rc;
+        }
+        // chunk schedule: short first chunks (only control chunk 0 is exposed), doubling up to kChunkMax
+        // With a control pipeline of depth L the first voice chunk waits for L + 1 control launches: those stay short.
+        kChunkMax = knobs().chunk_max;
+        kChunkFirst = std::min(knobs().chunk_first, kChunkMax);
+        max_lag = 0;
+        for (int lag : h.prog.ctl_lag) max_lag = std::max(max_lag, (uint32_t)lag);
+        // A call of one chunk whose control program runs as blocks of the voice launches is (the start of) a tick session (TickSession):
+        // everything the units hold must live in their tables (no rings in HBM, no reverb lines — those have no copies to move through).
+        tick = knobs().tick && has_ctl && (co_ctl || (special && special_ctl)) && t_seg == 0 && T_total == T && T <= kChunkMax;
+        for (const FlatProgram& Cp : h.prog.ctl) tick = tick && Cp.hdr.n_rings == 0 && Cp.fv_rows == 0;
+        if (tk.on && !(tick && tk.L == T && tk.st == st && tk.n0 + tk.c * (uint64_t)T == h.samples_rendered)) {  // not the call the session guessed
+            if ((rc = tick_end(h, st, false)) != SRACK_OK) return rc;  // on THIS call's stream, behind the session's last call (an event: no host-side wait)
+        }
+        chunks.clear();
+        if (tick) {
+            chunks.emplace_back(0u, T);
+        } else if (has_ctl) {
+            uint32_t k = 0;
+            for (uint32_t t_off = 0, len = kChunkFirst; t_off < T; t_off += len, k++) {
+                if (k > max_lag) len = std::min(len * 2, kChunkMax);
+                len = std::min(len, T - t_off);
+                chunks.emplace_back(t_off, len);
+            }
+        } else {  // no control program to overlap with, but short launches still win: the waves of a launch stay within a few
+                  // samples of each other, so their frame rows land in the same DRAM pages (FM pair 13.2 -> 9.9 ms per step)
+            // The z^-1 FM pair (one wave per SIMD at config 4's 65 536 voices, no ring traffic) wants them shorter still: 2048 samples 7.26 ms per
+            // step, 4096 7.39, 1536 7.31, 1024 7.43, 8192 7.85 (tools/ab_env.sh, one box); its ring variant and the flagship are flat from 3072 to 6144.
+            // A specialised kernel without rings in HBM at one wave per SIMD or fewer is in the same position (config 4 through the general
+            // path: 7.36 - 7.46 ms per step at 4096, 7.26 - 7.28 at 2048, two rounds on one box).
+            const bool fm_z1 = P.fused == FUSED_FM_PAIR && P.fused_variant == 0 && !(flags & (SRACK_RENDER_NO_FUSION | SRACK_RENDER_EXACT_OSC));
+            const bool lone_waves = special && P.hdr.n_rings == 0 && n_waves <= 1024 && !(flags & SRACK_RENDER_EXACT_OSC);
+            // (the time-parallel FM pair keeps its ring in LDS for a launch and moves it to and from HBM at the ends: one launch per segment)
+            const uint32_t len = fm_block ? knobs().fm_block_chunk : (fm_z1 || lone_waves) ? std::min(kChunkMax, 2048u) : kChunkMax;
+            for (uint32_t t_off = 0; t_off < T; t_off += len) chunks.emplace_back(t_off, std::min(len, T - t_off));
+        }
+        n_chunks = (uint32_t)chunks.size();
+        n_ctl_launch = n_chunks + max_lag;
+        n_tracks = (uint32_t)h.prog.n_tracks;
+        if (has_ctl && (rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
+        // One argument block per (launch, control unit): launch j runs unit s on chunk j - lag[s]; chunk c is complete after launch
+        // c + max_lag.  (A control program that was not cut into units is one unit with lag 0.)
+        return SRACK_OK;
+    }
+
+    // ---- control: what must run before the first voice launch (a session's start and bookkeeping; chunk 0's control work; the two-stream
+    // fallback's whole control pipeline) ---------------------------------------------------------------------------------------------------
+    int control()
+    {
+        if (tick && !tk.on) {  // a session starts: its first chunk's control work is exposed, like any render's
+            const uint32_t R = max_lag + 2;
+            if ((rc = grow(tk.d_ring, tk.ring_bytes, sizeof(float) * (size_t)R * n_tracks * T)) != SRACK_OK) return rc;
+            if (tk.d_copies.empty()) {
+                tk.d_copies.assign(n_stages, nullptr);
+                tk.words.assign(n_stages, 0);
+                for (uint32_t s2 = 0; s2 < n_stages; s2++) {
+                    tk.words[s2] = h.prog.ctl[s2].table.size();
+                    if (tk.words[s2] > 0) HIP_TRY(hipMalloc(&tk.d_copies[s2], sizeof(uint32_t) * tk.words[s2] * R));
+                }
+            }
+            tk.on = true;
+            tk.L = T;
+            tk.R = R;
+            tk.c = 0;
+            tk.n0 = h.samples_rendered;
+            tk.st = st;
+            if (co_ctl) {
+                hipLaunchKernelGGL(render_ctl_gate_env, dim3(1), dim3(64), 0, st, tick_work(0));
+                HIP_TRY(hipGetLastError());
+            } else {
+                if ((rc = tick_upload_slots(0)) != SRACK_OK) return rc;
+                for (uint32_t g = 0; g <= max_lag; g++) {
+                    KernelArgs kp{};
+                    kp.block0 = n_stages;
+                    kp.ctl_slots = d->d_stage_slots + (size_t)g * n_stages;
+                    if ((rc = jit_launch(*special, kp, n_stages, st)) != SRACK_OK) return rc;
+                }
+            }
+        } else if (tick && !co_ctl && tk.c >= tk.slots_base + tk.slots_n) {
+            if ((rc = tick_upload_slots(tk.c)) != SRACK_OK) return rc;
+        }
+        if (tick) {
+            // (below: the voice launch of this call, with the units' next launch as its first blocks)
+        } else if (special && special_ctl) {
+            // Co-scheduled control units: everything on the caller's stream.  Launches 0 .. max_lag of the control pipeline run alone
+            // (they complete chunk 0: the only exposed control work, kept short by the 1024-sample first chunks); voice launch k then
+            // carries control launch k + max_lag + 1 as its first blocks, which completes chunk k + 1 while chunk k is consumed.
+            if ((rc = upload_stage_slots(st)) != SRACK_OK) return rc;
+            for (uint32_t j = 0; j <= max_lag && j < n_ctl_launch; j++) {
                 KernelArgs kp{};
                 kp.block0 = n_stages;
-                kp.ctl_slots = d->d_stage_slots + (size_t)g * n_stages;
+                kp.ctl_slots = d->d_stage_slots + (size_t)j * n_stages;
                 if ((rc = jit_launch(*special, kp, n_stages, st)) != SRACK_OK) return rc;
             }
-        }
-    } else if (tick && !co_ctl && tk.c >= tk.slots_base + tk.slots_n) {
-        if ((rc = tick_upload_slots(tk.c)) != SRACK_OK) return rc;
-    }
-    if (tick) {
-        // (below: the voice launch of this call, with the units' next launch as its first blocks)
-    } else if (special && special_ctl) {
-        // Co-scheduled control units: everything on the caller's stream.  Launches 0 .. max_lag of the control pipeline run alone
-        // (they complete chunk 0: the only exposed control work, kept short by the 1024-sample first chunks); voice launch k then
-        // carries control launch k + max_lag + 1 as its first blocks, which completes chunk k + 1 while chunk k is consumed.
-        if ((rc = upload_stage_slots(st)) != SRACK_OK) return rc;
-        for (uint32_t j = 0; j <= max_lag && j < n_ctl_launch; j++) {
-            KernelArgs kp{};
-            kp.block0 = n_stages;
-            kp.ctl_slots = d->d_stage_slots + (size_t)j * n_stages;
-            if ((rc = jit_launch(*special, kp, n_stages, st)) != SRACK_OK) return rc;
-        }
-    } else if (co_ctl) {  // chunk 0's track: the only control work that is not hidden (1024 samples, ~0.15 ms)
-        hipLaunchKernelGGL(render_ctl_gate_env, dim3(1), dim3(64), 0, st, ctl_work(chunks[0].first, chunks[0].second));
-        HIP_TRY(hipGetLastError());
-    } else if (has_ctl) {
-        if (!d->ctl_stream) {
-            // Highest priority: HIP keeps a separate pool of hardware queues per priority, so this stream does not end up sharing
-            // a queue with the caller's stream once other libraries (RCCL) have created streams of their own — the overlap of
-            // control chunks with voice chunks depends on the two running on different queues.
-            int prio_lo = 0, prio_hi = 0;
-            if (knobs().high_prio_ctl && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_hi != prio_lo)
-                HIP_TRY(hipStreamCreateWithPriority(&d->ctl_stream, hipStreamNonBlocking, prio_hi));
-            else
-                HIP_TRY(hipStreamCreateWithFlags(&d->ctl_stream, hipStreamNonBlocking));
-        }
-        if (!d->ev_begin) HIP_TRY(hipEventCreateWithFlags(&d->ev_begin, hipEventDisableTiming));
-        while (d->ev_chunk.size() < n_chunks) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            d->ev_chunk.push_back(e);
-        }
-        // the track buffer may still be read by the previous render on `st`: start after it
-        HIP_TRY(hipEventRecord(d->ev_begin, st));
-        HIP_TRY(hipStreamWaitEvent(d->ctl_stream, d->ev_begin, 0));
-        const bool staged = h.prog.ctl[0].fused == FUSED_NONE;  // the interpreter: all stages side by side in one launch
-        if (staged) {
-            const uint32_t n_launch = n_ctl_launch;
-            size_t lds = 0;
-            for (uint32_t s2 = 0; s2 < n_stages; s2++) {
-                const DevProgram& H = h.prog.ctl[s2].hdr;
-                lds = std::max(lds, ((size_t)H.n_rows + 2 + (size_t)H.n_tracks + (size_t)H.n_slots * H.tile) * 256);
-            }
-            if ((rc = upload_stage_slots(d->ctl_stream)) != SRACK_OK) return rc;
-            for (uint32_t j = 0; j < n_launch; j++) {
-                const KernelArgs* slots = d->d_stage_slots + (size_t)j * n_stages;
-                if (flags & SRACK_RENDER_EXACT_OSC)
-                    hipLaunchKernelGGL(render_interp_stages<true>, dim3(n_stages), dim3(64), lds, d->ctl_stream, slots);
+        } else if (co_ctl) {  // chunk 0's track: the only control work that is not hidden (1024 samples, ~0.15 ms)
+            hipLaunchKernelGGL(render_ctl_gate_env, dim3(1), dim3(64), 0, st, ctl_work(chunks[0].first, chunks[0].second));
+            HIP_TRY(hipGetLastError());
+        } else if (has_ctl) {
+            if (!d->ctl_stream) {
+                // Highest priority: HIP keeps a separate pool of hardware queues per priority, so this stream does not end up sharing
+                // a queue with the caller's stream once other libraries (RCCL) have created streams of their own — the overlap of
+                // control chunks with voice chunks depends on the two running on different queues.
+                int prio_lo = 0, prio_hi = 0;
+                if (knobs().high_prio_ctl && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_hi != prio_lo)
+                    HIP_TRY(hipStreamCreateWithPriority(&d->ctl_stream, hipStreamNonBlocking, prio_hi));
                 else
-                    hipLaunchKernelGGL(render_interp_stages<false>, dim3(n_stages), dim3(64), lds, d->ctl_stream, slots);
-                HIP_TRY(hipGetLastError());
-                if (j >= max_lag) HIP_TRY(hipEventRecord(d->ev_chunk[j - max_lag], d->ctl_stream));
+                    HIP_TRY(hipStreamCreateWithFlags(&d->ctl_stream, hipStreamNonBlocking));
             }
-        } else {
-            for (uint32_t k = 0; k < n_chunks; k++) {
-                launch_ctl(h.prog.ctl[0], stage_args(0, k), d->ctl_stream);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipEventRecord(d->ev_chunk[k], d->ctl_stream));
+            if (!d->ev_begin) HIP_TRY(hipEventCreateWithFlags(&d->ev_begin, hipEventDisableTiming));
+            while (d->ev_chunk.size() < n_chunks) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                d->ev_chunk.push_back(e);
             }
-        }
-    }
-
-    ChainRoles roles{};
-    uint32_t osc_port = 0, vcf_port = 0;
-    const bool fused = P.fused == FUSED_VOICE_CHAIN || P.fused == FUSED_VOICE_CHAIN_TRACK;
-    const bool track = P.fused == FUSED_VOICE_CHAIN_TRACK;
-    if (fused) {
-        for (int i = 0; i < (int)P.ops.size(); i++) {
-            const DevOp& op = P.ops[(size_t)i];
-            if (op.kind == OP_VCF) { roles.vcf = i; vcf_port = op.flags & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP); }
-            if (op.kind == OP_ADSR) roles.adsr = i;
-            if (op.kind == OP_VCA) roles.vca = i;
-            if (op.kind == OP_OUT) roles.out = i;
-            if (op.kind == OP_VCA && track) roles.track = P.hdr.track_id[op.in_slot[1] - kTrackSlot];
-        }
-        const Graph& g = h.graph;
-        roles.osc_a = P.op_of_module[(size_t)g.modules[(size_t)P.ops[(size_t)roles.vcf].module].in[0].src];
-        if (!track) roles.osc_l = P.op_of_module[(size_t)g.modules[(size_t)P.ops[(size_t)roles.adsr].module].in[0].src];
-        osc_port = P.ops[(size_t)roles.osc_a].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
-        d->kernel_name = track ? "render_voice_chain_track" : "render_voice_chain";
-    } else {
-        d->kernel_name = "render_interp";
-    }
-
-    const bool seq_chain = P.fused == FUSED_VOICE_CHAIN_SEQ;
-    SeqRoles seq{};
-    uint32_t seq_port = 0;
-    if (seq_chain) {
-        seq.math = seq.trk_cutoff = -1;
-        auto track_row = [&](int slot) { return P.hdr.track_id[slot - kTrackSlot]; };
-        for (int i = 0; i < (int)P.ops.size(); i++) {
-            const DevOp& op = P.ops[(size_t)i];
-            if (op.kind == OP_MATH) { seq.math = i; seq.trk_pitch = track_row(op.in_slot[0]); }
-            if (op.kind == OP_OSC) { seq.osc = i; seq_port = op.flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW); }
-            if (op.kind == OP_VCF) { seq.vcf = i; if (op.flags & VCF_HAS_CV) seq.trk_cutoff = track_row(op.in_slot[1]); }
-            if (op.kind == OP_VCA) { seq.vca = i; seq.trk_env = track_row(op.in_slot[1]); }
-            if (op.kind == OP_OUT) {
-                if (op.in_slot[0] >= kTrackSlot) {
-                    seq.extra_plane[seq.n_extra] = op.aux;
-                    seq.extra_trk[seq.n_extra++] = track_row(op.in_slot[0]);
-                } else {
-                    seq.out = i;
+            // the track buffer may still be read by the previous render on `st`: start after it
+            HIP_TRY(hipEventRecord(d->ev_begin, st));
+            HIP_TRY(hipStreamWaitEvent(d->ctl_stream, d->ev_begin, 0));
+            const bool staged = h.prog.ctl[0].fused == FUSED_NONE;  // the interpreter: all stages side by side in one launch
+            if (staged) {
+                const uint32_t n_launch = n_ctl_launch;
+                size_t lds = 0;
+                for (uint32_t s2 = 0; s2 < n_stages; s2++) {
+                    const DevProgram& H = h.prog.ctl[s2].hdr;
+                    lds = std::max(lds, ((size_t)H.n_rows + 2 + (size_t)H.n_tracks + (size_t)H.n_slots * H.tile) * 256);
+                }
+                if ((rc = upload_stage_slots(d->ctl_stream)) != SRACK_OK) return rc;
+                for (uint32_t j = 0; j < n_launch; j++) {
+                    const KernelArgs* slots = d->d_stage_slots + (size_t)j * n_stages;
+                    if (flags & SRACK_RENDER_EXACT_OSC)
+                        hipLaunchKernelGGL(render_interp_stages<true>, dim3(n_stages), dim3(64), lds, d->ctl_stream, slots);
+                    else
+                        hipLaunchKernelGGL(render_interp_stages<false>, dim3(n_stages), dim3(64), lds, d->ctl_stream, slots);
+                    HIP_TRY(hipGetLastError());
+                    if (j >= max_lag) HIP_TRY(hipEventRecord(d->ev_chunk[j - max_lag], d->ctl_stream));
+                }
+            } else {
+                for (uint32_t k = 0; k < n_chunks; k++) {
+                    launch_ctl(h.prog.ctl[0], stage_args(0, k), d->ctl_stream);
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipEventRecord(d->ev_chunk[k], d->ctl_stream));
                 }
             }
         }
-        if (seq.math < 0) seq.trk_pitch = track_row(P.ops[(size_t)seq.osc].in_slot[0]);
-        d->kernel_name = "render_voice_chain_seq";
+
+        return SRACK_OK;
     }
-    if (special) d->kernel_name = "render_specialized";
-    const bool fm_pair = P.fused == FUSED_FM_PAIR;
-    if (fm_pair) {  // op order fixed by the matcher: DELAY_RD, MATH_FB, OSC_M, DELAY_WR, MATH_IDX, OSC_C, OUT
-        roles.adsr = 1;
-        roles.osc_l = 2;
-        roles.vca = 4;
-        roles.osc_a = 5;
-        roles.out = 6;
-        roles.track = P.ops[0].aux;  // the ring's state row
-        if (!special) d->kernel_name = fm_block ? "render_fm_pair_block" : P.fused_variant == 1 ? "render_fm_pair_ring" : "render_fm_pair";
-    }
-    MixArgs m{};
-    if (d_mix) {
-        m.mixpart = d->d_mixpart;
-        m.mixgroup = d->d_mixgroup;
-        m.mix = d_mix;
-        m.T = T;
-        m.mix_stride = T_total;
-        m.n_waves = n_waves;
-        m.n_channels = C;
-        m.n_planes = (uint32_t)P.hdr.n_planes;
-        for (int c = 0; c < 8; c++) m.channel_plane[c] = P.hdr.channel_plane[c];
-    }
-    const bool mix_aside = d_mix && n_chunks > 1 && knobs().mix_aside;  // chunk k's partials are summed beside chunk k + 1's voices
-    if (mix_aside) {
-        if (!d->mix_stream) HIP_TRY(hipStreamCreateWithFlags(&d->mix_stream, hipStreamNonBlocking));
-        if (!d->ev_mix_done) HIP_TRY(hipEventCreateWithFlags(&d->ev_mix_done, hipEventDisableTiming));
-        while (d->ev_mix.size() < n_chunks) {
-            hipEvent_t e = nullptr;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            d->ev_mix.push_back(e);
-        }
-    }
-    for (uint32_t k = 0; k < n_chunks; k++) {
-        const uint32_t t_off = chunks[k].first, len = chunks[k].second;
-        KernelArgs ka{};
-        ka.ops = d->voice.d_ops;
-        ka.prog = P.hdr;
-        ka.table = d->voice.d_table;
-        ka.rings = d->voice.d_rings;
-        ka.seqtab = d->voice.d_seqtab;
-        ka.fv = d->voice.d_fv;
-        ka.frames = d_frames ? d_frames + (size_t)t_off * V : nullptr;
-        ka.mixpart = d_mix ? d->d_mixpart + t_off : nullptr;
-        ka.tracks = tick ? tick_tracks(tk.c) : has_ctl ? d->d_tracks + t_off : nullptr;
-        ka.plane_stride = (uint64_t)T_total * V;
-        ka.t_stride = T;
-        ka.V = V;
-        ka.T = len;
-        ka.n_waves = n_waves;
-        ka.lanes = lanes;
-        ka.n0 = h.samples_rendered + t_off;
-        CtlWork co{};
-        if (tick && co_ctl) {  // block 0: the track of the chunk the next call is expected to ask for
-            co = tick_work(tk.c + 1);
-            ka.block0 = 1;
-        } else if (tick) {
-            ka.block0 = n_stages;
-            ka.ctl_slots = d->d_stage_slots + (size_t)(max_lag + 1 + (tk.c - tk.slots_base)) * n_stages;
-        } else if (co_ctl && k + 1 < n_chunks) {  // this launch's block 0 prepares the next chunk's track
-            co = ctl_work(chunks[k + 1].first, chunks[k + 1].second);
-            ka.block0 = 1;
-        }
-        if (has_ctl && !co_ctl && !(special && special_ctl)) HIP_TRY(hipStreamWaitEvent(st, d->ev_chunk[k], 0));
-        if (!tick && special && special_ctl && k + max_lag + 1 < n_ctl_launch) {  // this launch's first blocks: the control units' next launch
-            ka.block0 = n_stages;
-            ka.ctl_slots = d->d_stage_slots + (size_t)(k + max_lag + 1) * n_stages;
-        }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timed = h.timing_armed;  // only a host that asked for srack_render_kernel_ms pays for the event pair
-        if (timed) {
-            if ((rc = get_event(e0)) != SRACK_OK || (rc = get_event(e1)) != SRACK_OK) return rc;
-            HIP_TRY(hipEventRecord(e0, st));
-        }
-        if (special) {
-            if ((rc = jit_launch(*special, ka, n_waves + ka.block0, st)) != SRACK_OK) return rc;
-        } else if (fused) {
-            const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
-            launch_fused(osc_port, vcf_port, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, track, ka, roles, co, dim3(n_waves + ka.block0), st);
-        } else if (seq_chain) {
-            const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
-            launch_seq(seq_port, out_mode, ka, seq, dim3(n_waves), st);
-        } else if (fm_pair && fm_block) {
-            if ((rc = launch_fm_block((ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0), ka, roles, st)) != SRACK_OK) return rc;
-        } else if (fm_pair) {
-            const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
-            launch_fm_pair(P.fused_variant == 1, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, ka, roles, dim3(n_waves), st);
-        } else {
-            launch_interp(P, ka, st);
-        }
-        HIP_TRY(hipGetLastError());
-        if (mix_aside && k + 1 < n_chunks) {
-            HIP_TRY(hipEventRecord(d->ev_mix[k], st));
-            HIP_TRY(hipStreamWaitEvent(d->mix_stream, d->ev_mix[k], 0));
-            MixArgs mk = m;
-            mk.t_begin = t_off;
-            mk.t_end = t_off + len;
-            hipLaunchKernelGGL(mix_reduce_groups, dim3((len + 255) / 256, kMixSplit), dim3(256), 0, d->mix_stream, mk);
-            HIP_TRY(hipGetLastError());
-        }
-        if (timed) {
-            HIP_TRY(hipEventRecord(e1, st));
-            d->timings.emplace_back(e0, e1);
-            if (d->timings.size() > 4096) {  // nobody is reading them: recycle the oldest
-                d->pool.push_back(d->timings.front().first);
-                d->pool.push_back(d->timings.front().second);
-                d->timings.erase(d->timings.begin());
+
+    // ---- roles: which op is what for the hand-written kernels, and the kernel's name for srack_render_info --------------------------------
+    void pick_roles()
+    {
+        fused = P.fused == FUSED_VOICE_CHAIN || P.fused == FUSED_VOICE_CHAIN_TRACK;
+        track = P.fused == FUSED_VOICE_CHAIN_TRACK;
+        if (fused) {
+            for (int i = 0; i < (int)P.ops.size(); i++) {
+                const DevOp& op = P.ops[(size_t)i];
+                if (op.kind == OP_VCF) { roles.vcf = i; vcf_port = op.flags & (VCF_OUT_LP | VCF_OUT_BP | VCF_OUT_HP); }
+                if (op.kind == OP_ADSR) roles.adsr = i;
+                if (op.kind == OP_VCA) roles.vca = i;
+                if (op.kind == OP_OUT) roles.out = i;
+                if (op.kind == OP_VCA && track) roles.track = P.hdr.track_id[op.in_slot[1] - kTrackSlot];
             }
+            const Graph& g = h.graph;
+            roles.osc_a = P.op_of_module[(size_t)g.modules[(size_t)P.ops[(size_t)roles.vcf].module].in[0].src];
+            if (!track) roles.osc_l = P.op_of_module[(size_t)g.modules[(size_t)P.ops[(size_t)roles.adsr].module].in[0].src];
+            osc_port = P.ops[(size_t)roles.osc_a].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
+            d->kernel_name = track ? "render_voice_chain_track" : "render_voice_chain";
+        } else {
+            d->kernel_name = "render_interp";
+        }
+
+        seq_chain = P.fused == FUSED_VOICE_CHAIN_SEQ;
+        if (seq_chain) {
+            seq.math = seq.trk_cutoff = -1;
+            auto track_row = [&](int slot) { return P.hdr.track_id[slot - kTrackSlot]; };
+            for (int i = 0; i < (int)P.ops.size(); i++) {
+                const DevOp& op = P.ops[(size_t)i];
+                if (op.kind == OP_MATH) { seq.math = i; seq.trk_pitch = track_row(op.in_slot[0]); }
+                if (op.kind == OP_OSC) { seq.osc = i; seq_port = op.flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW); }
+                if (op.kind == OP_VCF) { seq.vcf = i; if (op.flags & VCF_HAS_CV) seq.trk_cutoff = track_row(op.in_slot[1]); }
+                if (op.kind == OP_VCA) { seq.vca = i; seq.trk_env = track_row(op.in_slot[1]); }
+                if (op.kind == OP_OUT) {
+                    if (op.in_slot[0] >= kTrackSlot) {
+                        seq.extra_plane[seq.n_extra] = op.aux;
+                        seq.extra_trk[seq.n_extra++] = track_row(op.in_slot[0]);
+                    } else {
+                        seq.out = i;
+                    }
+                }
+            }
+            if (seq.math < 0) seq.trk_pitch = track_row(P.ops[(size_t)seq.osc].in_slot[0]);
+            d->kernel_name = "render_voice_chain_seq";
+        }
+        if (special) d->kernel_name = "render_specialized";
+        fm_pair = P.fused == FUSED_FM_PAIR;
+        if (fm_pair) {  // op order fixed by the matcher: DELAY_RD, MATH_FB, OSC_M, DELAY_WR, MATH_IDX, OSC_C, OUT
+            roles.adsr = 1;
+            roles.osc_l = 2;
+            roles.vca = 4;
+            roles.osc_a = 5;
+            roles.out = 6;
+            roles.track = P.ops[0].aux;  // the ring's state row
+            if (!special) d->kernel_name = fm_block ? "render_fm_pair_block" : P.fused_variant == 1 ? "render_fm_pair_ring" : "render_fm_pair";
         }
     }
 
-    if (d_mix) {
-        // what is left to sum: everything, or — the earlier chunks being summed on the side stream — the last chunk only
-        m.t_begin = mix_aside ? chunks[n_chunks - 1].first : 0u;
-        m.t_end = T;
-        hipLaunchKernelGGL(mix_reduce_groups, dim3((m.t_end - m.t_begin + 255) / 256, kMixSplit), dim3(256), 0, st, m);
-        if (mix_aside) {
-            HIP_TRY(hipEventRecord(d->ev_mix_done, d->mix_stream));
-            HIP_TRY(hipStreamWaitEvent(st, d->ev_mix_done, 0));  // (also keeps the NEXT render's voice launches off the partials until they are summed)
+    // ---- voices: one launch per chunk (with the control program's next work as its first blocks where that is how they overlap) ---------
+    int voices()
+    {
+        if (d_mix) {
+            m.mixpart = d->d_mixpart;
+            m.mixgroup = d->d_mixgroup;
+            m.mix = d_mix;
+            m.T = T;
+            m.mix_stride = T_total;
+            m.n_waves = n_waves;
+            m.n_channels = C;
+            m.n_planes = (uint32_t)P.hdr.n_planes;
+            for (int c = 0; c < 8; c++) m.channel_plane[c] = P.hdr.channel_plane[c];
         }
-        hipLaunchKernelGGL(mix_reduce_final, dim3((T + 255) / 256), dim3(256), 0, st, m);
-        HIP_TRY(hipGetLastError());
+        mix_aside = d_mix && n_chunks > 1 && knobs().mix_aside;  // chunk k's partials are summed beside chunk k + 1's voices
+        if (mix_aside) {
+            if (!d->mix_stream) HIP_TRY(hipStreamCreateWithFlags(&d->mix_stream, hipStreamNonBlocking));
+            if (!d->ev_mix_done) HIP_TRY(hipEventCreateWithFlags(&d->ev_mix_done, hipEventDisableTiming));
+            while (d->ev_mix.size() < n_chunks) {
+                hipEvent_t e = nullptr;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                d->ev_mix.push_back(e);
+            }
+        }
+        for (uint32_t k = 0; k < n_chunks; k++) {
+            const uint32_t t_off = chunks[k].first, len = chunks[k].second;
+            KernelArgs ka{};
+            ka.ops = d->voice.d_ops;
+            ka.prog = P.hdr;
+            ka.table = d->voice.d_table;
+            ka.rings = d->voice.d_rings;
+            ka.seqtab = d->voice.d_seqtab;
+            ka.fv = d->voice.d_fv;
+            ka.frames = d_frames ? d_frames + (size_t)t_off * V : nullptr;
+            ka.mixpart = d_mix ? d->d_mixpart + t_off : nullptr;
+            ka.tracks = tick ? tick_tracks(tk.c) : has_ctl ? d->d_tracks + t_off : nullptr;
+            ka.plane_stride = (uint64_t)T_total * V;
+            ka.t_stride = T;
+            ka.V = V;
+            ka.T = len;
+            ka.n_waves = n_waves;
+            ka.lanes = lanes;
+            ka.n0 = h.samples_rendered + t_off;
+            CtlWork co{};
+            if (tick && co_ctl) {  // block 0: the track of the chunk the next call is expected to ask for
+                co = tick_work(tk.c + 1);
+                ka.block0 = 1;
+            } else if (tick) {
+                ka.block0 = n_stages;
+                ka.ctl_slots = d->d_stage_slots + (size_t)(max_lag + 1 + (tk.c - tk.slots_base)) * n_stages;
+            } else if (co_ctl && k + 1 < n_chunks) {  // this launch's block 0 prepares the next chunk's track
+                co = ctl_work(chunks[k + 1].first, chunks[k + 1].second);
+                ka.block0 = 1;
+            }
+            if (has_ctl && !co_ctl && !(special && special_ctl)) HIP_TRY(hipStreamWaitEvent(st, d->ev_chunk[k], 0));
+            if (!tick && special && special_ctl && k + max_lag + 1 < n_ctl_launch) {  // this launch's first blocks: the control units' next launch
+                ka.block0 = n_stages;
+                ka.ctl_slots = d->d_stage_slots + (size_t)(k + max_lag + 1) * n_stages;
+            }
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            const bool timed = h.timing_armed;  // only a host that asked for srack_render_kernel_ms pays for the event pair
+            if (timed) {
+                if ((rc = get_event(e0)) != SRACK_OK || (rc = get_event(e1)) != SRACK_OK) return rc;
+                HIP_TRY(hipEventRecord(e0, st));
+            }
+            if (special) {
+                if ((rc = jit_launch(*special, ka, n_waves + ka.block0, st)) != SRACK_OK) return rc;
+            } else if (fused) {
+                const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
+                launch_fused(osc_port, vcf_port, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, track, ka, roles, co, dim3(n_waves + ka.block0), st);
+            } else if (seq_chain) {
+                const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
+                launch_seq(seq_port, out_mode, ka, seq, dim3(n_waves), st);
+            } else if (fm_pair && fm_block) {
+                if ((rc = launch_fm_block((ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0), ka, roles, st)) != SRACK_OK) return rc;
+            } else if (fm_pair) {
+                const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
+                launch_fm_pair(P.fused_variant == 1, (flags & SRACK_RENDER_EXACT_OSC) != 0, out_mode, ka, roles, dim3(n_waves), st);
+            } else {
+                launch_interp(P, ka, st);
+            }
+            HIP_TRY(hipGetLastError());
+            if (mix_aside && k + 1 < n_chunks) {
+                HIP_TRY(hipEventRecord(d->ev_mix[k], st));
+                HIP_TRY(hipStreamWaitEvent(d->mix_stream, d->ev_mix[k], 0));
+                MixArgs mk = m;
+                mk.t_begin = t_off;
+                mk.t_end = t_off + len;
+                hipLaunchKernelGGL(mix_reduce_groups, dim3((len + 255) / 256, kMixSplit), dim3(256), 0, d->mix_stream, mk);
+                HIP_TRY(hipGetLastError());
+            }
+            if (timed) {
+                HIP_TRY(hipEventRecord(e1, st));
+                d->timings.emplace_back(e0, e1);
+                if (d->timings.size() > 4096) {  // nobody is reading them: recycle the oldest
+                    d->pool.push_back(d->timings.front().first);
+                    d->pool.push_back(d->timings.front().second);
+                    d->timings.erase(d->timings.begin());
+                }
+            }
+        }
+
+        return SRACK_OK;
     }
-    h.samples_rendered += T;
-    if (tick) {
-        if (!tk.done) HIP_TRY(hipEventCreateWithFlags(&tk.done, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(tk.done, st));  // what ends the session waits for this call, on whatever stream it ends it
-        tk.c++;
+
+    // ---- mix: the per-wave partials' deterministic sums -----------------------------------------------------------------------------------
+    int mix()
+    {
+        if (d_mix) {
+            // what is left to sum: everything, or — the earlier chunks being summed on the side stream — the last chunk only
+            m.t_begin = mix_aside ? chunks[n_chunks - 1].first : 0u;
+            m.t_end = T;
+            hipLaunchKernelGGL(mix_reduce_groups, dim3((m.t_end - m.t_begin + 255) / 256, kMixSplit), dim3(256), 0, st, m);
+            if (mix_aside) {
+                HIP_TRY(hipEventRecord(d->ev_mix_done, d->mix_stream));
+                HIP_TRY(hipStreamWaitEvent(st, d->ev_mix_done, 0));  // (also keeps the NEXT render's voice launches off the partials until they are summed)
+            }
+            hipLaunchKernelGGL(mix_reduce_final, dim3((T + 255) / 256), dim3(256), 0, st, m);
+            HIP_TRY(hipGetLastError());
+        }
+        return SRACK_OK;
     }
-    tick_guard.done = true;
-    return SRACK_OK;
+
+    // ---- finish: the sample counter; a session's event and count -------------------------------------------------------------------------
+    int finish()
+    {
+        h.samples_rendered += T;
+        if (tick) {
+            if (!tk.done) HIP_TRY(hipEventCreateWithFlags(&tk.done, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(tk.done, st));  // what ends the session waits for this call, on whatever stream it ends it
+            tk.c++;
+        }
+        return SRACK_OK;
+    }
+
+    int run()
+    {
+        bool done = false;
+        if ((rc = prepare(done)) != SRACK_OK || done) return rc;
+        // (a call that fails part-way — a launch error — must not leave a session behind whose bookkeeping is a call ahead of the device)
+        // (... it ends the session instead: the state as of the last call that completed goes back into the tables — on the null stream, after
+        // the device has come to rest —, and if even that fails the program is dropped, so that the next render starts from what the host
+        // holds rather than from tables nobody can vouch for)
+        struct TickGuard {
+            PatchHandle& h;
+            TickSession& t;
+            bool done = false;
+            ~TickGuard()
+            {
+                if (done || !t.on) return;
+                (void)hipDeviceSynchronize();
+                if (tick_end(h, nullptr, true) != SRACK_OK) {
+                    t.on = false;
+                    h.prog_valid = false;
+                }
+            }
+        } tick_guard{h, tk};
+        if ((rc = plan()) != SRACK_OK || (rc = control()) != SRACK_OK) return rc;
+        pick_roles();
+        if ((rc = voices()) != SRACK_OK || (rc = mix()) != SRACK_OK || (rc = finish()) != SRACK_OK) return rc;
+        tick_guard.done = true;
+        return SRACK_OK;
+    }
+};
+
+static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint32_t T, float* d_frames, float* d_mix, uint32_t flags, hipStream_t st)
+{
+    if (!h.dev) {
+        const int rc = upload_program(h);
+        if (rc != SRACK_OK) return rc;
+    }
+    return Segment(h, T_total, t_seg, T, d_frames, d_mix, flags, st).run();
 }
 
 // A render is cut into segments of at most kSegment samples so that the scratch it needs (per-wave mix partials

@@ -178,42 +178,6 @@ SRK_DEV void emit_rows_end(Emit& e, int n, uint32_t V)  // end of a 32-sample ti
     }
 }
 
-// ---- experiment (round 3, -DSRK_MIX_MFMA=1): the mix-down's cross-lane sum on the matrix pipe --------------------------------------
-// v_mfma_f32_16x16x4_f32 is exact f32 (a k-ordered fmaf chain) and runs beside the VALU.  With the sample as the A operand
-// (A[i][k] = lane 16 k + i) and a one-hot column selector as B (B[k][j] = [j == t mod 16]), sample t adds its four-lane partial sums
-// sum_k o[16 k + i] into column t mod 16 of a 16 x 16 accumulator: sixteen samples fill the tile.  Four more MFMAs with A = ones and
-// the tile's four VGPRs as B (VGPR r of the C/D layout, read as a B operand, is rows 4 k + r) sum the rows: lanes 0 .. 15 of the
-// result hold the sixteen samples' sums over all 64 lanes.  1.25 MFMA per wave-sample, no ds_write, no flush, no barrier.
-// 0 x inf = NaN would leak one sample's overflow into its fifteen neighbours: the caller only takes this path for tiles whose
-// samples are provably finite (render_voice_chain_track: finite filter state, finite envelope tile).
-#ifdef SRK_MIX_MFMA
-typedef float mfma_f4 __attribute__((ext_vector_type(4)));
-struct MfmaMix {
-    mfma_f4 acc;
-    float sel[16];  // sel[c]: 1.0 in the lanes of column c (lane & 15 == c), else 0.0 — sixteen loop-invariant VGPRs
-};
-SRK_DEV void mfma_mix_init(MfmaMix& m, int lane)
-{
-#pragma unroll
-    for (int c = 0; c < 16; c++) m.sel[c] = (lane & 15) == c ? 1.0f : 0.0f;
-    m.acc = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
-}
-// sample `i` of the tile (compile-time in the unrolled loop); after samples 15 and 31 the sixteen sums leave through lanes 0 .. 15
-SRK_DEV void mfma_mix_put(MfmaMix& m, float o, int i, float* mp_t0, int lane)
-{
-    m.acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o, m.sel[i & 15], m.acc, 0, 0, 0);
-    if ((i & 15) == 15) {
-        mfma_f4 e = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
-        e = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, m.acc[0], e, 0, 0, 0);
-        e = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, m.acc[1], e, 0, 0, 0);
-        e = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, m.acc[2], e, 0, 0, 0);
-        e = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, m.acc[3], e, 0, 0, 0);
-        if (lane < 16) mp_t0[(i & 16) + lane] = e[0];
-        m.acc = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-}
-#endif
-
 // A plane that carries a control track unchanged (every voice plays the same sample): the frames are a broadcast store of a
 // wave-uniform value; the wave's mix partial is (number of real voices) x sample, written once per tile (emit_track_flush).
 SRK_DEV void emit_track_put(Emit& e, float v, uint32_t V, bool frames)
