@@ -303,6 +303,11 @@ __device__ const uint64_t kLibmExpTab[256] = {  // glibc's __exp_data.tab (N = 1
     0x3c77893b4d91cd9dull, 0x3fefe7c1819e90d8ull, 0x3c5305c14160cc89ull, 0x3feff3c22b8f71f1ull,
 };
 
+// (the library's pow and fmod behind the cold branches below: out of line — inlined, each of their copies per oscillator was a few hundred
+// instructions and several dozen registers the hot path never uses)
+__device__ __attribute__((noinline)) double pow2_cold(double e) { return pow(2.0, e); }
+__device__ __attribute__((noinline)) double fmod1_cold(double x) { return fmod(x, 1.0); }
+
 SRK_DEV double exp2_libm(double e)
 {
     constexpr double lhi = 0x1.62e42fefa39efp-1, llo = 0x1.abc9e3b398000p-56;  // log(2.0) as glibc's log_inline returns it
@@ -334,7 +339,7 @@ SRK_DEV double exp2_libm(double e)
             else if (topy < 0x43eu && abstop < 0x3c9u)
                 y = 1.0 + ehi;        // |e ln 2| < 2^-54: exp_inline's
             else
-                y = pow(2.0, e);      // overflow, underflow, NaN, and the scaled arithmetic of 512 <= |e ln 2| < 1024
+                y = pow2_cold(e);     // overflow, underflow, NaN, and the scaled arithmetic of 512 <= |e ln 2| < 1024
         }
     }
     return y;
@@ -441,7 +446,7 @@ SRK_DEV double fmod1(double x)
 {
     double r = x - __builtin_floor(x);
     if (__builtin_amdgcn_ballot_w64(x < 0.0) != 0) {
-        if (x < 0.0) r = fmod(x, 1.0);
+        if (x < 0.0) r = fmod1_cold(x);
     }
     return r;
 }

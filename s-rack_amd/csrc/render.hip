@@ -626,6 +626,8 @@ static bool specializable_shape(const FlatProgram& P, uint32_t flags)
     return P.fused == FUSED_NONE || P.fused == FUSED_VOICE_CHAIN || P.fused == FUSED_VOICE_CHAIN_SEQ;
 }
 
+static uint32_t lanes_per_wave(uint32_t V);
+
 static int resolve_specialized(PatchHandle& h, uint32_t flags, int out_mode, const JitKernel** out, bool* with_ctl)
 {
     *out = nullptr;
@@ -639,7 +641,9 @@ static int resolve_specialized(PatchHandle& h, uint32_t flags, int out_mode, con
     const bool ctl = h.prog.n_tracks > 0 && knobs().special_ctl && jit_ctl_supported(h.prog);
     if (!d->jit[out_mode]) {
         JitFetchInfo how;
-        const int rc = jit_get(h.prog, out_mode, ctl, &d->jit[out_mode], &how);
+        // (how many waves per SIMD this render has for the kernel: one wave per 64 voices on 1024 SIMDs)
+        const uint32_t n_waves = (P.n_voices + lanes_per_wave(P.n_voices) - 1) / lanes_per_wave(P.n_voices);
+        const int rc = jit_get(h.prog, out_mode, ctl, &d->jit[out_mode], &how, (int)std::min(4u, (n_waves + 1023u) / 1024u));
         if (rc != SRACK_OK) {
             if (forced) return rc;  // asked for explicitly: fail loudly
             d->jit_note = std::string(" jit=unavailable(") + last_error() + ")";
@@ -650,11 +654,13 @@ static int resolve_specialized(PatchHandle& h, uint32_t flags, int out_mode, con
             d->jit_failed = true;
             return SRACK_OK;
         }
-        char note[96];
+        char note[160];
+        char budget[40] = "";
+        if (how.waves > 0) std::snprintf(budget, sizeof budget, " regs=%d(budget for %d waves)", how.vgprs, how.waves);
         if (how.how == 2)
-            std::snprintf(note, sizeof note, " jit=compiled(%.0f ms)", how.compile_ms);
+            std::snprintf(note, sizeof note, " jit=compiled(%.0f ms)%s", how.compile_ms, budget);
         else
-            std::snprintf(note, sizeof note, " jit=%s", how.how == 1 ? "disk-cache" : "memory-cache");
+            std::snprintf(note, sizeof note, " jit=%s%s", how.how == 1 ? "disk-cache" : "memory-cache", budget);
         d->jit_note = note;
     }
     *out = d->jit[out_mode].get();
