@@ -1121,27 +1121,40 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
         // sync, a sequencer's step or sync: `value > 0.0` decides when something happens, and a value 1e-7 off crosses zero a sample
         // earlier or later once in a few million crossings: an edge, and everything behind it, moves by a sample (the soak's seed 2691: a
         // bandpass into a gate, one voice of 131 a sample late).  Those producers get the exact PolyBLEP / the literal ladder as well.
-        // Exempt: an oscillator's SQUARE wired straight to the input — the usual gate and clock source — whose default evaluation
-        // re-derives any value close to zero with the reference's own operations (modules.hip.h, square_sign_safe).
+        // Exempt: an oscillator's SQUARE that arrives unchanged — wired straight to the input, or handed on by a sequencer's gate outputs:
+        // the usual gate and clock sources — whose default evaluation re-derives any value close to zero with the reference's own
+        // operations (modules.hip.h, square_sign_safe).
         if (!(getenv("SRACK_LOOSE_EVENTS") && getenv("SRACK_LOOSE_EVENTS")[0] == '1'))
             for (int m = 0; m < n_mod; m++) {
                 if (!A.live[(size_t)m] || A.exact_src[(size_t)m]) continue;
                 const int t = g.modules[(size_t)m].type;
                 const uint32_t ports = t == SRACK_MOD_OSCILLATOR ? (A.port_live[(size_t)m] & 6u) : t == SRACK_MOD_MOOG_FILTER ? (A.port_live[(size_t)m] & 7u) : 0u;
                 if (!ports) continue;
-                std::vector<uint32_t> tainted((size_t)n_mod, 0u);
-                tainted[(size_t)m] = ports;
+                // Two kinds of taint: `pure` — the oscillator's square as it left the oscillator (or replaced by a constant level): straight
+                // wires, and a sequencer's gate outputs, which hand their step input on unchanged where the cell is on (sequencer.rs:190-246) —
+                // and `mixed`: the value after any arithmetic, a filter, another oscillator's CV ..., and a saw from the start.
+                std::vector<uint32_t> pure((size_t)n_mod, 0u), mixed((size_t)n_mod, 0u);
+                if (t == SRACK_MOD_OSCILLATOR) {
+                    pure[(size_t)m] = ports & (1u << SRACK_OSC_OUT_SQUARE);
+                    mixed[(size_t)m] = ports & ~(1u << SRACK_OSC_OUT_SQUARE);
+                } else {
+                    mixed[(size_t)m] = ports;
+                }
                 for (bool changed = true; changed;) {  // where the value is carried to
                     changed = false;
                     for (int k = 0; k < n_mod; k++) {
                         if (!A.live[(size_t)k]) continue;
                         const Module& sink = g.modules[(size_t)k];
+                        const bool seq = sink.type == SRACK_MOD_GRID_SEQUENCER || sink.type == SRACK_MOD_PATTERN_SEQUENCER;
                         for (int port = 0; port < sink.n_in; port++) {
                             const InputRef& in = sink.in[(size_t)port];
-                            if (in.src < 0 || !(tainted[(size_t)in.src] & (1u << in.port))) continue;
-                            const uint32_t add = carried_to(sink.type, port) & ~tainted[(size_t)k];
-                            if (add) {
-                                tainted[(size_t)k] |= add;
+                            if (in.src < 0) continue;
+                            const bool from_pure = (pure[(size_t)in.src] >> in.port) & 1u, from_mixed = (mixed[(size_t)in.src] >> in.port) & 1u;
+                            if (!from_pure && !from_mixed) continue;
+                            const uint32_t carried = carried_to(sink.type, port);
+                            std::vector<uint32_t>& into = (from_mixed || !seq) ? mixed : pure;
+                            if (carried & ~into[(size_t)k]) {
+                                into[(size_t)k] |= carried;
                                 changed = true;
                             }
                         }
@@ -1152,12 +1165,11 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                     const Module& sink = g.modules[(size_t)k];
                     for (int port = 0; port < sink.n_in; port++) {
                         const InputRef& in = sink.in[(size_t)port];
-                        if (in.src < 0 || !(tainted[(size_t)in.src] & (1u << in.port))) continue;
+                        if (in.src < 0 || !((mixed[(size_t)in.src] >> in.port) & 1u)) continue;
                         const bool event = sink.type == SRACK_MOD_ADSR || (sink.type == SRACK_MOD_OSCILLATOR && port == SRACK_OSC_IN_SYNC) ||
                                            sink.type == SRACK_MOD_GRID_SEQUENCER || sink.type == SRACK_MOD_PATTERN_SEQUENCER ||
                                            (sink.type == SRACK_MOD_SAMPLE && port == SRACK_SAMPLE_IN_GATE);
-                        const bool direct_square = in.src == m && t == SRACK_MOD_OSCILLATOR && in.port == SRACK_OSC_OUT_SQUARE;
-                        if (event && !direct_square) A.exact_src[(size_t)m] = 1;
+                        if (event) A.exact_src[(size_t)m] = 1;
                     }
                 }
             }
@@ -1191,10 +1203,10 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
         //  * a cycle through an EVENT input — an oscillator's sync (oscillator.rs:125-131), an envelope's or the sample player's gate, a
         //    sequencer's step or sync: a value that differs in its last bits crosses the threshold a sample earlier or later, the event
         //    moves, and the loop feeds the moved event back into what produced it: the renders part for good;
-        //  * a filter inside a cycle that can AMPLIFY — a mixer whose gains on the cycle add up to more than 1, a multiplication by more
+        //  * a cycle that can AMPLIFY — a mixer whose gains on the cycle add up to more than 1, a multiplication by more
         //    than 1 or by another signal, a sum of two signals of the cycle, a VCA that is not driven by an envelope, a band- or highpass
-        //    port (|3 (b3 - b4)| reaches 6), anything that is not plain arithmetic: the literal ladder keeps the filter's own rounding
-        //    the reference's, but every other approximation that enters the cycle (an f32 PolyBLEP on the cutoff's CV ...) is amplified.
+        //    port (|3 (b3 - b4)| reaches 6), anything that is not plain arithmetic: whatever approximation enters the cycle (an f32 PolyBLEP
+        //    on a cutoff's CV, a phase whose increment came from the polynomial 2^cv ...) is amplified sample after sample.
         // Both get the exact flavour of the whole patch, as a loop through a pitch does.
         bool loop_needs_exact = false;
         if (!(getenv("SRACK_LOOSE_LOOPS") && getenv("SRACK_LOOSE_LOOPS")[0] == '1')) {
@@ -1245,7 +1257,7 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                 const Module& mod = g.modules[(size_t)m];
                 for (int port = 0; port < mod.n_in && !loop_needs_exact; port++)
                     if (mod.in[(size_t)port].src >= 0 && on_cycle(mod.in[(size_t)port].src) && is_event_input(m, port)) loop_needs_exact = true;
-                if (mod.type != SRACK_MOD_MOOG_FILTER || loop_needs_exact) continue;
+                if (loop_needs_exact) continue;  // (every cycle is looked at, with or without a filter: the soak's seed 4386 is two mixers feeding each other with gains above 1)
                 for (int k = 0; k < n_mod && !loop_needs_exact; k++) {
                     if (!A.live[(size_t)k] || !on_cycle(k)) continue;
                     const Module& c = g.modules[(size_t)k];
@@ -1258,6 +1270,8 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                     }
                     switch (c.type) {
                     case SRACK_MOD_MOOG_FILTER: break;
+                    case SRACK_MOD_OSCILLATOR: break;  // on the cycle through its pitch CV (a sync input was an event, above): FM feedback — what its saw /
+                                                       // square carry around is the loop-through-a-pitch rule's, its sine is the reference's own to half an ulp
                     case SRACK_MOD_MONO_MIXER: {
                         double sum = 0.0;
                         for (int port = 0; port < c.n_in; port++)

@@ -210,13 +210,17 @@ def test_p2_feedback_vs_oracle(S, oracle, B, flags):
 
 @pytest.mark.parametrize("flags", [0, 1, 2])
 @pytest.mark.parametrize("B", [1, 64, 1024])
-def test_fm_pair_sample_loops(S, oracle, B, flags):
-    """The fused FM kernels choose their sample loop per wave from what the wave can prove about its 64 voices (default mode): both
+def test_fm_pair_sample_loops(S, oracle, B, flags, monkeypatch):
+    """(Under SRACK_LOOSE_LOOPS=1: since round 4 the flattener gives a patch whose feedback loop can AMPLIFY — here feedback gains
+    above 1 — the exact flavour, see test_fm_feedback_gain_above_one_takes_the_exact_flavour; this test keeps the default-mode kernels'
+    per-wave classes covered with the draw that reaches all of them.)
+    The fused FM kernels choose their sample loop per wave from what the wave can prove about its 64 voices (default mode): both
     CVs within 1/2 (no range reduction in 2^x, one-instruction phase wrap), the carrier's within two octaves ((2^(cv/4))^4), beyond
     (range reduction), or nothing at all — a voice whose feedback gain lets 2^x overflow, after which its phase is NaN as in the reference, and its 63
     well-behaved neighbours, which take the literal forms with it.  One wave of each, plus a modulator `val` that moves a wave from
     one class to the next; every voice against the oracle."""
     # (buffer_size 1024: the time-parallel pair takes calls of 4096 samples and more — shorter ones keep the ring kernel, see below)
+    monkeypatch.setenv("SRACK_LOOSE_LOOPS", "1")
     T, W, cut = (9000, 64, 4501) if B == 1024 else (2500, 64, 1001)
     rng = np.random.default_rng(11)
     beta = np.concatenate([rng.uniform(0.05, 0.45, W), rng.uniform(0.1, 0.4, W), rng.uniform(0.6, 1.8, W), rng.uniform(0.1, 0.4, W),
@@ -270,6 +274,37 @@ def test_fm_pair_sample_loops(S, oracle, B, flags):
         assert np.abs(ab[fin].astype(np.float64) - out[0][fin]).max() <= 4e-7 and (bits(ab) != bits(out[0])).mean() < 1e-3
     else:
         np.testing.assert_array_equal(bits(np.concatenate([a[0], b[0]])), bits(out[0]))
+
+
+@pytest.mark.parametrize("B", [1, 1024])
+def test_fm_feedback_gain_above_one_takes_the_exact_flavour(S, oracle, B):
+    """A cycle that can amplify iterates whatever approximation enters it: FM feedback with a gain above 1 (2^(1.8 sin) on its own pitch)
+    let the default mode drift to 1.8e-5 within 9000 samples.  The flattener now renders such a patch with the exact flavour (flatten.cpp
+    2b: a multiplication by more than 1 on a cycle): default flags, bit for bit the oracle; config 4's own draw (gains up to 0.4) keeps
+    the default-mode kernels."""
+    V, T = 128, 6000
+    rng = np.random.default_rng(5)
+    beta, index = rng.uniform(0.6, 1.8, V).astype(np.float32), rng.uniform(0.5, 1.5, V).astype(np.float32)
+    o = oracle.OraclePatch(48000, B, 2)
+    ids = S.build_p2(o)
+    over = [(ids["mul_fb"], S.MATH_CONSTANT, beta), (ids["mul_idx"], S.MATH_CONSTANT, index)]
+    ref, _ = o.render_batch(V, T, over, threads=8)
+    p = S.Patch(48000, B, 2)
+    S.build_p2(p)
+    p.configure_voices(V)
+    for m, f, v in over:
+        p.set_voice_field(m, f, v)
+    out = p.render_channels(T, 0)
+    assert assert_close(out[0], ref[0]) < 3e-7   # (the sine port: ocml's sin against the libm's — everything else is the reference's to the bit)
+    q = S.Patch(48000, B, 2)
+    S.build_p2(q)
+    q.configure_voices(V)
+    b2, i2 = S.p2_voice_params(V)
+    q.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, b2)
+    q.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, i2)
+    q.render_channels(4096, 0)
+    assert ("render_fm_pair_block" in q.info()) if B == 1024 else ("render_fm_pair" in q.info() or "render_specialized" in q.info())
+    assert "render_fm_pair_block" not in p.info() and ("render_fm_pair" in p.info())
 
 
 def _envelope_fm(g, S):
