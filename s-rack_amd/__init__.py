@@ -74,7 +74,8 @@ def _load():
     L.srack_patch_set_module_position.argtypes = [vp, i32, C.c_float, C.c_float]
     L.srack_patch_get_module_position.argtypes = [vp, i32, fp, fp]
     L.srack_patch_set_output_buffer.argtypes = [vp, i32, i32, fp, u32]
-    L.srack_patch_get_output_buffer.argtypes = [vp, i32, i32, fp, u32]
+    if hasattr(L, "srack_patch_get_output_buffer"):  # (tools/ab.sh alternates older builds of the library under this binding)
+        L.srack_patch_get_output_buffer.argtypes = [vp, i32, i32, fp, u32]
     L.srack_patch_set_noise_seed.argtypes = [vp, C.c_uint64, C.c_uint64]
     L.srack_patch_keep_state.argtypes = [vp, i32]
     L.srack_patch_connect.argtypes = [vp, i32, i32, i32, i32]
