@@ -719,11 +719,8 @@ SRK_DEV bool cosc_square_calm(const COsc& o)
     return !(h <= o.hA || h >= o.hB || (uint32_t)(h - o.hQ0) <= o.hQspan);
 }
 SRK_DEV float cosc_square_level(const COsc& o) { return __double2hiint(o.pos) < 0x3fe00000 ? -1.0f : 1.0f; }
-SRK_DEV void cosc_quiet_step(COsc& o)
-{
-    bool wrapped;
-    o.pos = cosc_advance(o, wrapped);
-}
+// (a quiet group ends below 1 - g: `pos %= 1.0` is the identity on every one of its sums, the wrap instruction is not needed)
+SRK_DEV void cosc_quiet_step(COsc& o) { o.pos = o.pos + o.delta; }
 
 // The exact render mode's constant-pitch square / saw behind the same guards (host-proved OSC_CONST_SMALL).  Outside its PolyBLEP
 // windows the reference's own value is -1 / +1 (the two blep terms are 0.0 and 0.0 - 0.0 = 0.0) resp. (pos as f32) * 2 - 1, and its
@@ -1358,6 +1355,26 @@ SRK_DEV bool adsr_seg_calm(const AdsrRegs& s, const AdsrSeg& g, float gate, uint
     const uint64_t m_leave = (m_high & g.on_high) | (~m_high & g.on_low) | (m_high & ~g.last & g.on_edge);
     return m_leave == 0 && !(s.phase + g.inc >= 1.0f);
 }
+// The VCA behind such an envelope asks `cv > 0.0` every sample (vca.rs:132).  Within a quiet group the answer is one per lane: the
+// segment's output c0 + c1 u is monotonic in u, u moves one way, and with c0, c1 >= 0 it is positive from the first sample on if c0 > 0
+// or c1 u > 0 — OPEN — and exactly +0.0 if both are zero (mode None; Sustain at level 0; a release from 0) — CLOSED.  `decided`: this
+// lane is one or the other (a negative level, or a product that could underflow, is neither: the group then takes the per-sample forms).
+SRK_DEV bool adsr_seg_open(const AdsrRegs& s, const AdsrSeg& g, bool& decided)
+{
+    const bool closed = g.c0 == 0.0f && g.c1 == 0.0f;
+    // u of the group's samples: phase + inc ... (Attack), 1 - phase - inc ... >= 1e-4 (otherwise; the group's own guard keeps phase <= 0.9999)
+    const float u_first = g.k0 + g.k1 * (s.phase + g.inc);
+    const bool open = g.c0 >= 0.0f && g.c1 >= 0.0f && (g.c0 > 0.0f || (g.c1 > 1.0e-30f && u_first > 1.0e-6f)) && g.c0 < 1.0e30f && g.c1 < 1.0e30f;
+    decided = open || closed;
+    return open;
+}
+// ... and the VCA's sample with that answer (a per-lane bool that is constant over the group lives in an SGPR pair: one v_cndmask, no compare)
+SRK_DEV float vca_step_decided(bool open_lane, float audio, float cv)
+{
+    const float y = audio * cv;
+    return open_lane ? y : 0.0f;
+}
+
 // one sample of such a group: adsr_seg_step's hot path without its questions (the caller sets g.last = m_high after the group)
 SRK_DEV float adsr_seg_quiet_step(AdsrRegs& s, AdsrSeg& g)
 {
