@@ -46,7 +46,7 @@ for seed in range(lo, hi):
             if pl < 0:
                 continue
             f64 = fr[pl].astype(np.float64)
-            fin = np.isfinite(f64).all(axis=1)
+            fin = np.isfinite(f64).all(axis=1) & (np.abs(f64).sum(axis=1) < 3.0e38)  # (an exploding patch: finite frames whose f32 sum is not — seed 370)
             own, scale = f64.sum(axis=1), np.abs(f64).sum(axis=1)
             ok = ok and bool((np.abs(mx[c][fin] - own[fin]) <= 1e-5 * np.maximum(scale[fin], 1.0)).all())
         if not (same and ok):
