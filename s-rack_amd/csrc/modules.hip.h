@@ -854,8 +854,9 @@ struct FOsc {
     uint32_t lo, hi;    // pos * 2^64
     uint32_t dlo, dhi;  // delta * 2^64
     float c32;          // f32(hi) = f32(pos) * 2^32
-    float ta;           // f32(pos) / dt
+    float ta;           // f32(pos) / dt — kept up to date in the lanes that need it: those whose last step wrapped
     float inv_s;        // 2^-32 / f32(delta)
+    bool first;         // pos < delta: this sample is inside the first PolyBLEP window (<=> the step that led here wrapped)
 };
 
 SRK_DEV void fosc_init(FOsc& o, uint32_t lo, uint32_t hi, uint32_t dlo, uint32_t dhi)
@@ -868,9 +869,15 @@ SRK_DEV void fosc_init(FOsc& o, uint32_t lo, uint32_t hi, uint32_t dlo, uint32_t
     o.inv_s = (1.0f / (float)delta) * 0x1p-32f;
     o.c32 = (float)hi;
     o.ta = o.c32 * o.inv_s;
+    o.first = hi < dhi || (hi == dhi && lo < dlo);
 }
 
-// saw port: as cosc_saw, with the carried terms derived from the upper phase word
+// saw port: as cosc_saw, with the carried terms derived from the upper phase word — and the two PolyBLEP corrections PREDICATED on the
+// lanes that need them.  At the package power cap an instruction's price is its energy, and a lane that is switched off costs next to
+// none (tools/energybench: v_fma_f32 0.70 nJ per wave-instruction with 64 lanes enabled, 0.32 with sixteen, 0.09 with one).  A voice is
+// inside a window for two samples of its period (2 of 109 at 440 Hz): the first window is the sample after a wrap — `first`, the
+// previous step's carry —, the second the sample whose own step wraps — this step's carry.  Neither needs a compare.  Outside them the
+// select-free form computed u = max(1 - ta, 0) = 0 and took s1 = fma(0, 0, base) = base: the same bits as not computing them.
 SRK_DEV float fosc_saw(FOsc& o)
 {
     uint32_t nlo, nhi;
@@ -879,16 +886,22 @@ SRK_DEV float fosc_saw(FOsc& o)
     const bool c2 = __builtin_add_overflow(nhi, (uint32_t)c0, &nhi);
     const bool wrapped = c1 | c2;                                  // pos + delta >= 1: `pos %= 1.0` is the dropped carry
     const float cn = (float)nhi;
-    const float tn = cn * o.inv_s;
-    const float base = __builtin_fmaf(o.c32, 0x1p-31f, -1.0f);    // (pos as f32) * 2.0 - 1.0: the power-of-two scale is exact
-    const float u = __builtin_amdgcn_fmed3f(1.0f - o.ta, 0.0f, 1.0f);  // = max(1 - ta, 0) since ta >= 0; written as a [0,1] clamp so it folds into the subtract's output modifier
-    const float s1 = __builtin_fmaf(u, u, base);
-    const float s2 = keep(__builtin_fmaf(-tn, tn, s1));
-    const float saw = wrapped ? s2 : s1;
+    float saw = __builtin_fmaf(o.c32, 0x1p-31f, -1.0f);           // (pos as f32) * 2.0 - 1.0: the power-of-two scale is exact
+    if (o.first) {                                                 // 2t - t^2 - 1 = -(1 - t)^2, t = pos / dt < 1 (or, rounded up to 1: u = 0)
+        asm volatile("");                                          // (not to be speculated into a select: the point is the exec mask)
+        const float u = __builtin_amdgcn_fmed3f(1.0f - o.ta, 0.0f, 1.0f);
+        saw = __builtin_fmaf(u, u, saw);
+    }
+    if (wrapped) {                                                 // t'^2 + 2t' + 1 = (t' + 1)^2 = (next phase / dt)^2
+        asm volatile("");
+        const float tn = cn * o.inv_s;
+        saw = __builtin_fmaf(-tn, tn, saw);
+        o.ta = tn;
+    }
     o.lo = nlo;
     o.hi = nhi;
     o.c32 = cn;
-    o.ta = tn;
+    o.first = wrapped;
     return saw;
 }
 

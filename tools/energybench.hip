@@ -56,6 +56,10 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float seed)
             asm volatile("s_nop 0");
         } else if (kVariant == 14) {  // v_fract_f64
             REP16(asm volatile("v_fract_f64 %0, %0\n v_fract_f64 %1, %1\n v_fract_f64 %2, %2\n v_fract_f64 %3, %3" : "+v"(p), "+v"(q), "+v"(r), "+v"(s));)
+        } else if (kVariant == 16 || kVariant == 17) {  // v_fma_f32 with ONE lane (16) / SIXTEEN lanes (17) enabled: what does a predicated-off lane cost?
+            asm volatile("s_mov_b64 exec, %0" ::"s"(kVariant == 16 ? 1ull : 0xffffull));
+            REP16(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f));)
+            asm volatile("s_mov_b64 exec, -1");
         } else if (kVariant == 15) {  // v_pk_fma_f32 (two values per lane and instruction)
             typedef float f2 __attribute__((ext_vector_type(2)));
             f2 pa = {a, b}, pb = {c, d}, pc = {e, f}, pd = {g, h};
@@ -95,7 +99,7 @@ int main(int argc, char** argv)
     float* out; hipMalloc(&out, 4096 * 64 * 4);
     switch (v) {
 #define C(n) case n: run<n>(out, sec); break;
-        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15)
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17)
     }
     return 0;
 }
