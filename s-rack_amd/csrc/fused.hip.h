@@ -1462,7 +1462,7 @@ __global__ __launch_bounds__(256) void mix_reduce_groups(MixArgs m)
 __global__ __launch_bounds__(256) void mix_reduce_final(MixArgs m)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= m.T) return;
+    if (i >= m.t_end) return;  // (m.T is the row pitch of the partials, not the segment's length)
     for (uint32_t c = 0; c < m.n_channels; c++) {
         const int plane = m.channel_plane[c];
         float s = 0.0f;

@@ -61,7 +61,7 @@ struct Knobs {
     int mix_aside = 0;                // 1: the mix partials of chunk k are summed on a side stream while chunk k + 1 renders.  Measured (round 4, one box,
                                       // three alternating rounds): config 3 11.52 / 11.54 / 11.57 ms per step all at once at the end, 11.62 / 11.67 / 11.69 aside;
                                       // cfg3_poly 16.40 against 16.43 — at the power cap a kernel that runs beside the voices is paid for in clock
-    int tick = 1;                     // calls of one chunk keep the control program running ahead across calls (TickSession below); 0: every call starts it afresh
+    int tick = 2;                     // calls keep the control program running ahead across calls (TickSession below); 1: calls of one chunk only (round 3); 0: every call starts it afresh
 };
 static const Knobs& knobs()
 {
@@ -85,7 +85,7 @@ static const Knobs& knobs()
         v.fm_block = (int)num("SRACK_FM_BLOCK", 0, 1, 1);
         v.fm_block_chunk = (uint32_t)num("SRACK_FM_BLOCK_CHUNK", 256, 65536, 65536);
         v.fm_block_min = (uint32_t)num("SRACK_FM_BLOCK_MIN", 1, 65536, 4096);
-        v.tick = (int)num("SRACK_TICK", 0, 1, 1);
+        v.tick = (int)num("SRACK_TICK", 0, 2, 2);
         v.mix_aside = (int)num("SRACK_MIX_ASIDE", 0, 1, 0);
         return v;
     }();
@@ -125,15 +125,22 @@ struct DevProg {  // device copy of one FlatProgram
 // copy (x + 1) % R), the tracks through a ring of R chunk buffers.  Ending a session (another length, an edit, a state read-back)
 // copies the state as of the last rendered chunk into the tables and forgets the rest.  Sample for sample the units do what they
 // would do in separate calls of the same length, so a session changes no bit of any render.
+// Since round 4 a call may be SEVERAL chunks (a host that renders a second of audio per call, back to back: bench.py's steps): the session's
+// unit is the chunk — call j is chunks [j n, (j + 1) n) of one schedule, full chunks of Lmax samples and a shorter last one — so the
+// launches of a call's last chunks already carry the control work of the next call's first ones: no exposed control launch at the start of
+// a call, no ramp of short first chunks (config 2, whose five control units were five exposed launches per call: 3.44 -> see NOTES R4.8).
 struct TickSession {
     bool on = false;
     uint32_t L = 0;          // samples per call
+    uint32_t Lmax = 0;       // samples per full chunk (a slot of the track ring)
+    uint32_t S = 0;          // floats between two tracks of the ring — and between two rows of the mix partials, which share KernelArgs::t_stride: max(L, R * Lmax)
+    uint32_t n = 0;          // chunks per call
     uint32_t R = 0;          // depth of the rings
-    uint64_t c = 0;          // calls (= chunks) rendered
+    uint64_t c = 0;          // chunks rendered (a multiple of n between calls)
     uint64_t n0 = 0;         // absolute index of the session's first sample
     hipStream_t st = nullptr;          // the stream the session's calls come on: COMPARED with the next call's, never used after the call it came with
     hipEvent_t done = nullptr;         // recorded on that stream at the end of every call of the session: whoever ends the session waits for it
-    float* d_ring = nullptr;           // [R][n_tracks][L] control tracks
+    float* d_ring = nullptr;           // [n_tracks][S] control tracks: chunk x in floats [(x % R) Lmax, ... + its length) of every track
     size_t ring_bytes = 0;
     std::vector<uint32_t*> d_copies;   // per unit: [R][words] copies of its table
     std::vector<size_t> words;
@@ -721,6 +728,7 @@ struct Segment {
     // plan
     bool has_ctl = false, co_ctl = false, special_ctl = false, tick = false;
     uint32_t n_stages = 0, n_tracks = 0, kChunkMax = 0, kChunkFirst = 0, max_lag = 0, n_chunks = 0, n_ctl_launch = 0;
+    uint32_t stride = 0;  // KernelArgs::t_stride of the voice launches: floats between two rows of the mix partials and between two control tracks
     const JitKernel* special = nullptr;  // a kernel specialised for this program (jit.cpp), if the program takes one; special_ctl: with the control units as extra blocks of every launch
     std::vector<std::pair<uint32_t, uint32_t>> chunks;  // (t_off, len)
     // roles
@@ -804,7 +812,16 @@ struct Segment {
     // ---- tick session: argument blocks of unit s2 on chunk x, and the launches that start a session ----
     float* tick_tracks(uint64_t x)
     {
-        return tk.d_ring + (size_t)(x % tk.R) * n_tracks * tk.L;
+        return tk.d_ring + (size_t)(x % tk.R) * tk.Lmax;
+    }
+    uint32_t tick_len(uint64_t x)  // chunk x of the session: its length ...
+    {
+        const uint32_t k = (uint32_t)(x % tk.n);
+        return std::min(tk.Lmax, tk.L - k * tk.Lmax);
+    }
+    uint64_t tick_n0(uint64_t x)  // ... and the absolute index of its first sample
+    {
+        return tk.n0 + (x / tk.n) * tk.L + (x % tk.n) * (uint64_t)tk.Lmax;
     }
     uint32_t* tick_table(uint32_t s2, uint64_t x)
     {  // the copy chunk x reads (x = 0: the table itself) / chunk x - 1 wrote
@@ -821,27 +838,27 @@ struct Segment {
         kc.seqtab = d->ctl[s2].d_seqtab;
         kc.frames = tick_tracks(x);
         kc.tracks = kc.frames;
-        kc.plane_stride = tk.L;
-        kc.t_stride = tk.L;
+        kc.plane_stride = tk.S;
+        kc.t_stride = tk.S;
         kc.V = 1;
-        kc.T = tk.L;
+        kc.T = tick_len(x);
         kc.n_waves = 1;
         kc.lanes = 64;
-        kc.n0 = tk.n0 + x * tk.L;
+        kc.n0 = tick_n0(x);
         kc.block0 = s2;
         return kc;
     }
     CtlWork tick_work(uint64_t x)
     {  // the fused gate -> envelope control program on chunk x
         const FlatProgram& Cp = h.prog.ctl[0];
-        return CtlWork{d->ctl[0].d_ops, tick_table(0, x), tick_tracks(x) + (size_t)Cp.ops[2].aux * tk.L, tk.L,
+        return CtlWork{d->ctl[0].d_ops, tick_table(0, x), tick_tracks(x) + (size_t)Cp.ops[2].aux * tk.S, tick_len(x),
                        Cp.ops[0].flags & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW | OSC_EXACT), tick_table(0, x + 1), (uint32_t)Cp.hdr.n_rows};
     }
     // global launch g of the session runs unit s2 on chunk g - lag[s2]: launches 0 .. max_lag run alone when the session starts (they
-    // complete chunk 0), launch max_lag + 1 + i rides on the voice launch of call i.  The device holds the first ones and a batch of the others.
+    // complete chunk 0), launch max_lag + 1 + i rides on the voice launch of chunk i.  The device holds the first ones and a batch of the others.
     int tick_upload_slots(uint64_t base)
     {
-        const uint32_t fill = max_lag + 1, batch = base == 0 ? kTickFirstBatch : kTickBatch;
+        const uint32_t fill = max_lag + 1, batch = std::max(base == 0 ? kTickFirstBatch : kTickBatch, tk.n);  // (at least a whole call's chunks)
         d->h_stage_slots.assign((size_t)(fill + batch) * n_stages, KernelArgs{});
         for (uint32_t s2 = 0; s2 < n_stages; s2++) {
             const uint32_t lag = (uint32_t)h.prog.ctl_lag[s2];
@@ -881,8 +898,6 @@ struct Segment {
             d_frames = nullptr;
             d_mix = nullptr;
         }
-        if (d_mix && (rc = grow(d->d_mixpart, d->mixpart_bytes, sizeof(float) * (size_t)P.hdr.n_planes * n_waves * T)) != SRACK_OK) return rc;
-        if (d_mix && (rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * T)) != SRACK_OK) return rc;
 
         return SRACK_OK;
     }
@@ -911,14 +926,16 @@ struct Segment {
         for (int lag : h.prog.ctl_lag) max_lag = std::max(max_lag, (uint32_t)lag);
         // A call of one chunk whose control program runs as blocks of the voice launches is (the start of) a tick session (TickSession):
         // everything the units hold must live in their tables (no rings in HBM, no reverb lines — those have no copies to move through).
-        tick = knobs().tick && has_ctl && (co_ctl || (special && special_ctl)) && t_seg == 0 && T_total == T && T <= kChunkMax;
+        tick = knobs().tick && has_ctl && (co_ctl || (special && special_ctl)) && t_seg == 0 && T_total == T && (T <= kChunkMax || knobs().tick >= 2);
         for (const FlatProgram& Cp : h.prog.ctl) tick = tick && Cp.hdr.n_rings == 0 && Cp.fv_rows == 0;
-        if (tk.on && !(tick && tk.L == T && tk.st == st && tk.n0 + tk.c * (uint64_t)T == h.samples_rendered)) {  // not the call the session guessed
+        const uint32_t tick_n = (T + kChunkMax - 1) / kChunkMax;  // chunks of a ticked call: full ones and a shorter last one
+        if (tk.on && !(tick && tk.L == T && tk.Lmax == std::min(T, kChunkMax) && tk.st == st && tk.c % tk.n == 0 &&
+                       tk.n0 + (tk.c / tk.n) * (uint64_t)T == h.samples_rendered)) {  // not the call the session guessed
             if ((rc = tick_end(h, st, false)) != SRACK_OK) return rc;  // on THIS call's stream, behind the session's last call (an event: no host-side wait)
         }
         chunks.clear();
         if (tick) {
-            chunks.emplace_back(0u, T);
+            for (uint32_t k = 0; k < tick_n; k++) chunks.emplace_back(k * kChunkMax, std::min(kChunkMax, T - k * kChunkMax));
         } else if (has_ctl) {
             uint32_t k = 0;
             for (uint32_t t_off = 0, len = kChunkFirst; t_off < T; t_off += len, k++) {
@@ -941,6 +958,10 @@ struct Segment {
         n_chunks = (uint32_t)chunks.size();
         n_ctl_launch = n_chunks + max_lag;
         n_tracks = (uint32_t)h.prog.n_tracks;
+        // (a ticked call reads its tracks from the session's ring, R slots of a full chunk per track: the one stride must cover both)
+        stride = tick ? std::max(T, (max_lag + 2) * std::min(T, kChunkMax)) : T;
+        if (d_mix && (rc = grow(d->d_mixpart, d->mixpart_bytes, sizeof(float) * (size_t)P.hdr.n_planes * n_waves * stride)) != SRACK_OK) return rc;
+        if (d_mix && (rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * stride)) != SRACK_OK) return rc;
         if (has_ctl && (rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
         // One argument block per (launch, control unit): launch j runs unit s on chunk j - lag[s]; chunk c is complete after launch
         // c + max_lag.  (A control program that was not cut into units is one unit with lag 0.)
@@ -953,7 +974,7 @@ struct Segment {
     {
         if (tick && !tk.on) {  // a session starts: its first chunk's control work is exposed, like any render's
             const uint32_t R = max_lag + 2;
-            if ((rc = grow(tk.d_ring, tk.ring_bytes, sizeof(float) * (size_t)R * n_tracks * T)) != SRACK_OK) return rc;
+            if ((rc = grow(tk.d_ring, tk.ring_bytes, sizeof(float) * (size_t)n_tracks * stride)) != SRACK_OK) return rc;
             if (tk.d_copies.empty()) {
                 tk.d_copies.assign(n_stages, nullptr);
                 tk.words.assign(n_stages, 0);
@@ -964,6 +985,9 @@ struct Segment {
             }
             tk.on = true;
             tk.L = T;
+            tk.Lmax = std::min(T, kChunkMax);
+            tk.S = stride;
+            tk.n = n_chunks;
             tk.R = R;
             tk.c = 0;
             tk.n0 = h.samples_rendered;
@@ -980,7 +1004,7 @@ struct Segment {
                     if ((rc = jit_launch(*special, kp, n_stages, st)) != SRACK_OK) return rc;
                 }
             }
-        } else if (tick && !co_ctl && tk.c >= tk.slots_base + tk.slots_n) {
+        } else if (tick && !co_ctl && tk.c + n_chunks > tk.slots_base + tk.slots_n) {  // this call's chunks need argument blocks the device does not hold yet
             if ((rc = tick_upload_slots(tk.c)) != SRACK_OK) return rc;
         }
         if (tick) {
@@ -1114,7 +1138,7 @@ struct Segment {
             m.mixpart = d->d_mixpart;
             m.mixgroup = d->d_mixgroup;
             m.mix = d_mix;
-            m.T = T;
+            m.T = stride;  // (the partials' row pitch; the samples summed are [t_begin, t_end))
             m.mix_stride = T_total;
             m.n_waves = n_waves;
             m.n_channels = C;
@@ -1142,21 +1166,21 @@ struct Segment {
             ka.fv = d->voice.d_fv;
             ka.frames = d_frames ? d_frames + (size_t)t_off * V : nullptr;
             ka.mixpart = d_mix ? d->d_mixpart + t_off : nullptr;
-            ka.tracks = tick ? tick_tracks(tk.c) : has_ctl ? d->d_tracks + t_off : nullptr;
+            ka.tracks = tick ? tick_tracks(tk.c + k) : has_ctl ? d->d_tracks + t_off : nullptr;
             ka.plane_stride = (uint64_t)T_total * V;
-            ka.t_stride = T;
+            ka.t_stride = stride;
             ka.V = V;
             ka.T = len;
             ka.n_waves = n_waves;
             ka.lanes = lanes;
             ka.n0 = h.samples_rendered + t_off;
             CtlWork co{};
-            if (tick && co_ctl) {  // block 0: the track of the chunk the next call is expected to ask for
-                co = tick_work(tk.c + 1);
+            if (tick && co_ctl) {  // block 0: the track of the next chunk — this call's, or the first of the call the session expects next
+                co = tick_work(tk.c + k + 1);
                 ka.block0 = 1;
             } else if (tick) {
                 ka.block0 = n_stages;
-                ka.ctl_slots = d->d_stage_slots + (size_t)(max_lag + 1 + (tk.c - tk.slots_base)) * n_stages;
+                ka.ctl_slots = d->d_stage_slots + (size_t)(max_lag + 1 + (tk.c + k - tk.slots_base)) * n_stages;
             } else if (co_ctl && k + 1 < n_chunks) {  // this launch's block 0 prepares the next chunk's track
                 co = ctl_work(chunks[k + 1].first, chunks[k + 1].second);
                 ka.block0 = 1;
@@ -1237,7 +1261,7 @@ struct Segment {
         if (tick) {
             if (!tk.done) HIP_TRY(hipEventCreateWithFlags(&tk.done, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(tk.done, st));  // what ends the session waits for this call, on whatever stream it ends it
-            tk.c++;
+            tk.c += n_chunks;
         }
         return SRACK_OK;
     }

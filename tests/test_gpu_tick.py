@@ -3,7 +3,7 @@
 a session changes no bit — of any render, of any state read back between ticks — whatever the host does between ticks (another
 length, one long call, frames only / mix only, a state read-back, a parameter edit under keep_state).
 
-Each scenario of tests/tick_driver.py runs in two processes, SRACK_TICK=1 (the default) and SRACK_TICK=0 (every call starts the
+Each scenario of tests/tick_driver.py runs in two processes, SRACK_TICK=2 (the default) and SRACK_TICK=0 (every call starts the
 control program afresh: the library as it was before sessions existed), and the two .npz files must agree bit for bit; the renders
 are also held to the CPU oracle at the 1e-5 bar, so that "both wrong alike" does not pass.
 """
@@ -37,10 +37,12 @@ def bits(a):
 # flags: 0 default, 1 exact oscillators; 32 = SRACK_RENDER_SPECIALIZE (the generated kernel with the control units as its first blocks:
 # by default it is reserved for 4096 voices and more)
 @pytest.mark.parametrize("scenario,flags", [("p1", 0), ("p1", 1), ("p1", 32), ("p1", 33), ("p1_wide", 0), ("identical", 32), ("identical", 33),
-                                            ("p3", 32), ("p3", 33), ("keep", 32), ("keep", 33)])
+                                            ("p3", 32), ("p3", 33), ("keep", 32), ("keep", 33),
+                                            ("p1_multi", 0), ("p1_multi", 1), ("p1_multi", 32), ("identical_multi", 32), ("identical_multi", 33),
+                                            ("p3_multi", 32), ("p3_multi", 33), ("keep_multi", 32)])
 def test_a_tick_session_changes_no_bit(oracle, tmp_path, scenario, flags):
     S = srack_pkg.load()
-    on, off = run(scenario, flags, 1, tmp_path), run(scenario, flags, 0, tmp_path)
+    on, off = run(scenario, flags, 2, tmp_path), run(scenario, flags, 0, tmp_path)   # SRACK_TICK=2: sessions of one or several chunks per call (the default)
     assert sorted(on.files) == sorted(off.files)
     for k in on.files:
         if k == "infos":

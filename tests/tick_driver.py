@@ -18,6 +18,7 @@ import srack_pkg  # noqa: E402
 
 def make(S, g, scenario, V):
     """The scenario's patch on `g` (a product Patch or an OraclePatch) -> (ids, per-voice overrides)."""
+    scenario = scenario.replace("_multi", "")   # the same patches driven in calls of several chunks (SCRIPTS below)
     if scenario in ("p1", "p1_wide"):
         ids = S.build_p1(g, adsr="finite", lfo_val=-2.0)   # gate at 110 Hz: an edge every 218 samples
         det, cut = S.p1_voice_params(V)
@@ -34,7 +35,7 @@ def make(S, g, scenario, V):
 
 
 def voices_of(scenario):
-    return {"p1": 192, "p1_wide": 4096 + 37, "identical": 96, "p3": 160, "keep": 130}[scenario]
+    return {"p1": 192, "p1_wide": 4096 + 37, "identical": 96, "p3": 160, "keep": 130}[scenario.replace("_multi", "")]
 
 
 # what a host does, in order: ("render", n_samples, what) with what in "fm" / "f" / "m"; ("read",) reads state back; ("edit",) a parameter
@@ -44,6 +45,13 @@ SCRIPTS = {
     "p1_wide": [("render", 1024, "fm")] * 4 + [("read",)] + [("render", 1024, "fm")] * 2,
     "identical": [("render", 256, "fm")] * 9 + [("read",)] + [("render", 256, "fm")] * 2 + [("render", 1000, "fm")] * 3 + [("render", 6000, "fm")] + [("render", 256, "m")] * 3,
     "p3": [("render", 256, "fm")] * 12 + [("read",)] + [("render", 1024, "fm")] * 3 + [("render", 4500, "fm")] + [("render", 1024, "f")] * 2 + [("read",)],
+    # calls of SEVERAL chunks, back to back (a host that renders long blocks; bench.py's steps): a session whose unit is the chunk — two
+    # full chunks and a short one per call —, interrupted by a read-back, another length, a one-chunk call, mix only / frames only
+    "p1_multi": [("render", 9000, "fm")] * 3 + [("read",)] + [("render", 9000, "fm")] * 2 + [("render", 5000, "fm")] * 2 + [("render", 512, "fm")] * 2
+                + [("render", 9000, "m")] * 2 + [("render", 9000, "f")] + [("read",)] + [("render", 8192, "fm")] * 2,
+    "identical_multi": [("render", 9000, "fm")] * 3 + [("read",)] + [("render", 9000, "fm")] + [("render", 4097, "fm")] * 2 + [("render", 9000, "m")] * 2,
+    "p3_multi": [("render", 10000, "fm")] * 3 + [("read",)] + [("render", 10000, "fm")] + [("render", 300, "fm")] * 2 + [("render", 10000, "f")] * 2 + [("read",)],
+    "keep_multi": [("render", 6000, "fm")] * 3 + [("edit",)] + [("render", 6000, "fm")] * 3 + [("read",)] + [("render", 6000, "fm")],
     "keep": [("render", 512, "fm")] * 5 + [("edit",)] + [("render", 512, "fm")] * 5 + [("read",)] + [("render", 512, "fm")] * 2,
 }
 
@@ -54,7 +62,7 @@ def main():
     V = voices_of(scenario)
     p = S.Patch(48000, 1024, 2)
     ids, over = make(S, p, scenario, V)
-    if scenario == "keep":
+    if scenario.startswith("keep"):
         p.keep_state(True)
     p.configure_voices(V)
     for m, f, v in over:
