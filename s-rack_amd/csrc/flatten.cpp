@@ -279,6 +279,8 @@ int Builder::build()
             if (render_flags & SRACK_RENDER_EXACT_OSC) op.flags |= OSC_EXACT;
             if (A.sine_loose[(size_t)m]) op.flags |= OSC_SINE_LOOSE;
             if (A.exact_src[(size_t)m] && !(op.flags & OSC_EXACT)) op.flags |= OSC_EXACT_BLEP;
+            if (const char* e = getenv("SRACK_OSC_EXACT_MASK"))  // (tools/: the exact PolyBLEP for the oscillators whose module index is set in the mask)
+                if (!(op.flags & OSC_EXACT) && ((strtoul(e, nullptr, 0) >> m) & 1u)) op.flags |= OSC_EXACT_BLEP;
             op.sample_rate = (double)g.cfg.sample_rate;  // `self.sample_rate as f64`, u16 in the reference
             {   // pos: f64 state, two rows (lo, hi)
                 const VoiceOverride* o = find_override(m, SRACK_OSC_POS);
@@ -310,6 +312,8 @@ int Builder::build()
             if (pl & 2u) op.flags |= VCF_OUT_BP;
             if (pl & 4u) op.flags |= VCF_OUT_HP;
             if (A.exact_src[(size_t)m] && !(render_flags & SRACK_RENDER_EXACT_OSC)) op.flags |= VCF_LITERAL;
+            if (const char* e = getenv("SRACK_VCF_LITERAL_MASK"))  // (tools/: the literal ladder for the filters whose module index is set in the mask)
+                if (!(render_flags & SRACK_RENDER_EXACT_OSC) && ((strtoul(e, nullptr, 0) >> m) & 1u)) op.flags |= VCF_LITERAL;
             op.state_row = state_row_f32(m, SRACK_VCF_ST_F);
             state_row_f32(m, SRACK_VCF_ST_P);
             state_row_f32(m, SRACK_VCF_ST_Q);
@@ -1034,6 +1038,58 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             pitches_reached(tainted, also_thresholds, any);
             return any;
         };
+        // A filter's cutoff CV is its pitch: `2^(cv * amount)` scales the coefficient of all four stages, and behind a band- or highpass port
+        // (input minus a stage: a difference of nearly equal values) the producers' 1e-7 comes out 250 times larger (the soak's seed 10901:
+        // a saw through a highpass into a second filter's audio AND cutoff, 2.6e-5 in 1 voice-sample of 17 000; with every producer on the
+        // way to that cutoff exact 3e-6, the modulated filter itself approximated).  SRACK_LOOSE_CUTOFF=1: the rule off (tools/).
+        const bool cutoff_rule = !(getenv("SRACK_LOOSE_CUTOFF") && getenv("SRACK_LOOSE_CUTOFF")[0] == '1');
+        // per filter: 1 if a value that starts on the given output ports arrives at its input `in_port` (carried port by port, as above)
+        auto filters_reached = [&](std::vector<uint32_t> tainted, int in_port) {
+            std::vector<char> hit((size_t)n_mod, 0);
+            for (bool changed = true; changed;) {
+                changed = false;
+                for (int k = 0; k < n_mod; k++) {
+                    if (!A.live[(size_t)k]) continue;
+                    const Module& sink = g.modules[(size_t)k];
+                    for (int port = 0; port < sink.n_in; port++) {
+                        const InputRef& in = sink.in[(size_t)port];
+                        if (in.src < 0 || !(tainted[(size_t)in.src] & (1u << in.port))) continue;
+                        if (sink.type == SRACK_MOD_MOOG_FILTER && port == in_port) hit[(size_t)k] = 1;
+                        const uint32_t add = carried_to(sink.type, port) & ~tainted[(size_t)k];
+                        if (add) {
+                            tainted[(size_t)k] |= add;
+                            changed = true;
+                        }
+                    }
+                }
+            }
+            return hit;
+        };
+        auto reaches_cutoff = [&](const std::vector<uint32_t>& tainted) {
+            if (!cutoff_rule) return false;
+            for (char h : filters_reached(tainted, SRACK_VCF_IN_CV))
+                if (h) return true;
+            return false;
+        };
+        // ... and white noise on a cutoff (the noise family's soak, seeds 2127, 2203, 2360: up to 3.2e-4 in 0.2 % of the samples) moves the
+        // coefficient across its whole range from one sample to the next: such a filter does not forget a difference the way a filter with a
+        // steady cutoff does.  Literal ladder for it, exact PolyBLEP / literal ladder for what reaches its audio input: bit-identical
+        // on all three (either half alone: 1.2e-4 / 3.2e-4).
+        std::vector<char> noisy_cutoff((size_t)n_mod, 0);
+        if (cutoff_rule && !(render_flags & SRACK_RENDER_EXACT_OSC))
+            for (int m = 0; m < n_mod; m++)
+                if (A.live[(size_t)m] && g.modules[(size_t)m].type == SRACK_MOD_NOISE) {
+                    std::vector<uint32_t> from((size_t)n_mod, 0u);
+                    from[(size_t)m] = 1u;
+                    const std::vector<char> hit = filters_reached(from, SRACK_VCF_IN_CV);
+                    for (int k = 0; k < n_mod; k++) noisy_cutoff[(size_t)k] |= hit[(size_t)k];
+                }
+        auto reaches_noisy_filter = [&](const std::vector<uint32_t>& tainted) {
+            const std::vector<char> hit = filters_reached(tainted, SRACK_VCF_IN_AUDIO);
+            for (int k = 0; k < n_mod; k++)
+                if (hit[(size_t)k] && noisy_cutoff[(size_t)k]) return true;
+            return false;
+        };
         // An oscillator's sine port that can reach neither a pitch nor a threshold may be evaluated in f32 in the default mode (modules.hip.h,
         // sine_loose: 2e-7, where the f64 form is the correctly rounded sine and therefore has the reference's own zero crossings).
         A.sine_loose.assign((size_t)n_mod, 0);
@@ -1104,7 +1160,7 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             from[(size_t)m] = ports;
             bool any = false;
             const std::vector<char> hit = pitches_reached(from, false, any);
-            A.exact_src[(size_t)m] = any;
+            A.exact_src[(size_t)m] = any || reaches_cutoff(from) || noisy_cutoff[(size_t)m] || reaches_noisy_filter(from);
             // ... unless the pitch it reaches closes a LOOP: a module whose own output comes back to its pitch input iterates a map, and in
             // such a loop the consumer's 1e-12 (the polynomial 2^cv against the reference's libm) can grow like anything else (random
             // patches with saw / filter feedback into a pitch part from the oracle within a few hundred samples).  Only the exact flavour of

@@ -486,7 +486,6 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
     ko.val = (double)parv(oo, OSC_P_VAL);
     ko.delta = 0.0;
     ko.inv_dt = 0.0f;
-    const double hz_scale = 440.0 / ko.sr;
     COsc co;
     co.pos = make_f64(row(oo.state_row + OSC_S_POS_LO), row(oo.state_row + OSC_S_POS_HI));
     co.delta = 0.0;
@@ -558,7 +557,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
                     seen_pitch = pb;
                     const float note = __uint_as_float(pb);
                     cv_lane = has_math ? math_step(mflags, note, 0.0f, mconst) : note;
-                    const double delta = hz_scale * exp2_fast((double)cv_lane + ko.val);
+                    const double delta = osc_delta_fast((double)cv_lane + ko.val, ko.sr);
                     carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
                     cosc_init(co, co.pos, delta);
                 }
@@ -663,7 +662,7 @@ SRK_DEV FmFacts fm_facts(float c_fb, const dev::OscConst& km, double pos_m, floa
     // not), and then scale = 440 / sr * 2^val and scale * 2^cv are finite too
     const bool sizes = (double)__builtin_fabsf(c_fb) + __builtin_fabs(km.val) < 1000.0 && (double)__builtin_fabsf(c_ix) + __builtin_fabs(kc.val) < 1000.0;
     const bool phases = pos_m >= 0.0 && pos_m < 1.0 && pos_c >= 0.0 && pos_c < 1.0;
-    const bool rates = km.sr >= 1.0 && kc.sr >= 1.0;  // 440 / sr finite
+    const bool rates = km.sr >= 1.0 && kc.sr >= 1.0 && sizes && dev::osc_below_rate(c_fb, km.val, km.sr) && dev::osc_below_rate(c_ix, kc.val, kc.sr);  // 440 / sr finite, increments below a cycle per sample (modules.hip.h)
     FmFacts f;
     f.tame = __builtin_amdgcn_ballot_w64(!(sizes && phases && rates)) == 0;  // NaNs vote no
     f.mod = fm_gain_class(c_fb);
@@ -820,7 +819,7 @@ SRK_DEV OscFacts fm_osc_facts(float gain, const dev::OscConst& k, double pos)
 {
     const float e = __builtin_fabsf(gain) + __builtin_fabsf((float)k.val);
     OscFacts f;
-    f.tame = __builtin_amdgcn_ballot_w64(!(e < 1000.0f && pos >= 0.0 && pos < 1.0 && k.sr >= 1.0)) == 0;
+    f.tame = __builtin_amdgcn_ballot_w64(!(e < 1000.0f && pos >= 0.0 && pos < 1.0 && k.sr >= 1.0 && dev::osc_below_rate(gain, k.val, k.sr))) == 0;
     f.small = __builtin_amdgcn_ballot_w64(!(e <= 0.4999f)) == 0;
     return f;
 }

@@ -345,6 +345,26 @@ SRK_DEV double exp2_libm(double e)
     return y;
 }
 
+// The default mode's phase increment, 440 / sr * 2^e with the polynomial above — up to ONE CYCLE PER SAMPLE.  From there on (a pitch CV of
+// +7 and more at 48 kHz: a gain close to 1 on a feedback cycle gets a patch there, the soak's seed 16340) the polynomial's 1e-12 is no
+// longer a relative error of something small but an absolute phase error per sample, which a saw or a square shows within a few hundred
+// samples; what the reference renders up there is aliasing noise, but it is ITS noise: such an increment is evaluated as the reference
+// spells it, with the host libm's own 2^e (out of line: the hot path pays a compare of the upper word and a branch).
+__device__ __attribute__((noinline)) double osc_delta_cold(double e, double sr) { return 440.0 * exp2_libm(e) / sr; }
+template <bool kReduce = true>
+SRK_DEV double osc_delta_fast(double e, double sr)
+{
+    double d = (440.0 / sr) * exp2_fast<kReduce>(e);
+    if (__builtin_expect((uint32_t)__double2hiint(d) >= 0x3ff00000u, 0)) d = osc_delta_cold(e, sr);  // d >= 1.0, a NaN, a negative rate
+    return d;
+}
+// ... which the PROVED loops (below: a bound on |cv| for the whole launch) rule out beforehand: 440 / sr * 2^(val + bound) < 1, the
+// exponent rounded up to an integer.  (Callers have checked bound + |val| < 1000.)
+SRK_DEV bool osc_below_rate(float bound, double val, double sr)
+{
+    return __builtin_ldexp(440.0 / sr, (int)__builtin_ceil((double)__builtin_fabsf(bound) + val)) < 1.0;
+}
+
 // poly_blep, f64, literally (oscillator.rs:50-67)
 SRK_DEV double poly_blep_exact(double t, double dt)
 {
@@ -495,7 +515,7 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
                 const double e = (double)cv + c.val;
                 // exact mode: 440 * 2^e / sr as written; default mode: (440 / sr) * 2^e with the series above
                 s.seen_delta = (flags & OSC_EXACT) ? 440.0 * exp2_libm(e) / c.sr
-                               : (440.0 / c.sr) * ((flags & OSC_CV_SMALL) ? exp2_fast<false>(e) : exp2_fast<true>(e));
+                               : (flags & OSC_CV_SMALL) ? (440.0 / c.sr) * exp2_fast<false>(e) : osc_delta_fast(e, c.sr);  // (OSC_CV_SMALL: proved below the rate)
             }
             s.seen_cv = cv;
         }
@@ -822,7 +842,7 @@ SRK_DEV float steposc_step(StepOsc& s, const OscConst& k, float cv)
 {
     COsc& o = s.o;
     if (__builtin_amdgcn_ballot_w64(cv != s.seen_cv) != 0) {
-        const double delta = (440.0 / k.sr) * exp2_fast((double)cv + k.val);
+        const double delta = osc_delta_fast((double)cv + k.val, k.sr);
         s.seen_cv = cv;
         s.carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
         cosc_init(o, o.pos, delta);
