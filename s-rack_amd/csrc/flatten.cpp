@@ -184,6 +184,32 @@ struct Builder {
         }
     }
 
+    // Does this wire SWEEP — an oscillator, a filter, noise, a sample player, a reverb somewhere upstream: a new value every sample — as
+    // opposed to HOLD (a sequencer's notes, an envelope's sustain, constants, arithmetic on those)?  A pitch CV that sweeps takes the
+    // polynomial 2^cv every sample (OSC_CV_AUDIO_RATE: its 1e-12 changes sign as the CV moves); one that holds recomputes the increment
+    // only when the value changed, with the reference's own 2^cv (modules.hip.h, osc_delta_cold: a held CV's polynomial error is a
+    // constant, i.e. a drift).  Feedback cycles run into the depth limit: sweeping.
+    bool sweeps(int module, int port, int depth) const
+    {
+        (void)port;
+        if (module < 0) return false;
+        if (depth > 12) return true;
+        const Module& m = g.modules[(size_t)module];
+        switch (m.type) {
+        case SRACK_MOD_ADSR:
+        case SRACK_MOD_GRID_SEQUENCER:
+        case SRACK_MOD_PATTERN_SEQUENCER: return false;
+        case SRACK_MOD_MATH:
+        case SRACK_MOD_MONO_MIXER:
+        case SRACK_MOD_VCA:
+        case SRACK_MOD_NONLINEAR:
+            for (const InputRef& in : m.in)
+                if (in.src >= 0 && sweeps(in.src, in.port, depth + 1)) return true;
+            return false;
+        default: return true;  // oscillator, filter, noise, sample player, reverb
+        }
+    }
+
     int build();
     void match_fused(bool has_rings);
 };
@@ -272,6 +298,7 @@ int Builder::build()
             if (connected(0)) op.flags |= OSC_HAS_CV;
             if (connected(1)) op.flags |= OSC_HAS_SYNC;
             if (connected(0) && stepwise(mod.in[0].src, mod.in[0].port, 0)) op.flags |= OSC_CV_STEPWISE;
+            if (connected(0) && sweeps(mod.in[0].src, mod.in[0].port, 0)) op.flags |= OSC_CV_AUDIO_RATE;
             if (field(m, SRACK_OSC_ANTIALIASING) != 0.0) op.flags |= OSC_AA;
             if (pl & 1u) op.flags |= OSC_OUT_SINE;
             if (pl & 2u) op.flags |= OSC_OUT_SQUARE;

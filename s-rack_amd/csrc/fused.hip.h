@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_seq(KernelArgs a, SeqRo
                     seen_pitch = pb;
                     const float note = __uint_as_float(pb);
                     cv_lane = has_math ? math_step(mflags, note, 0.0f, mconst) : note;
-                    const double delta = osc_delta_fast((double)cv_lane + ko.val, ko.sr);
+                    const double delta = osc_delta_cold((double)cv_lane + ko.val, ko.sr);  // once per note: the reference's own increment (modules.hip.h)
                     carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
                     cosc_init(co, co.pos, delta);
                 }

@@ -350,6 +350,11 @@ SRK_DEV double exp2_libm(double e)
 // longer a relative error of something small but an absolute phase error per sample, which a saw or a square shows within a few hundred
 // samples; what the reference renders up there is aliasing noise, but it is ITS noise: such an increment is evaluated as the reference
 // spells it, with the host libm's own 2^e (out of line: the hot path pays a compare of the upper word and a branch).
+// The same function serves every CV that holds its values (osc_step's recompute-on-change path, steposc_step): there the polynomial's
+// 1e-12 is a CONSTANT error for as long as a note lasts, the phase drifts one way (8e-10 cycles after a second), the f32 roundings of the
+// saw it produces flip one way too, and an oscillator that takes that saw as its pitch integrates the flips: 3.5e-5 on its square's
+// edges after one second (the one-second soak's seed 30111).  A call per note is free; an audio-rate CV sweeps the polynomial's
+// error through both signs and keeps the polynomial.
 __device__ __attribute__((noinline)) double osc_delta_cold(double e, double sr) { return 440.0 * exp2_libm(e) / sr; }
 template <bool kReduce = true>
 SRK_DEV double osc_delta_fast(double e, double sr)
@@ -514,8 +519,13 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
             } else {
                 const double e = (double)cv + c.val;
                 // exact mode: 440 * 2^e / sr as written; default mode: (440 / sr) * 2^e with the series above
-                s.seen_delta = (flags & OSC_EXACT) ? 440.0 * exp2_libm(e) / c.sr
-                               : (flags & OSC_CV_SMALL) ? (440.0 / c.sr) * exp2_fast<false>(e) : osc_delta_fast(e, c.sr);  // (OSC_CV_SMALL: proved below the rate)
+                // ... and a CV that HOLDS its values (a sequencer's notes, an envelope's sustain: no OSC_CV_AUDIO_RATE, the increment is only
+                // recomputed when the CV changed) gets the reference's own increment too: the polynomial's error is a constant for a
+                // constant CV, i.e. a phase that drifts one way for as long as the note lasts (osc_delta_cold)
+                s.seen_delta = (flags & OSC_EXACT)           ? 440.0 * exp2_libm(e) / c.sr
+                               : (flags & OSC_CV_SMALL)      ? (440.0 / c.sr) * exp2_fast<false>(e)  // (proved below the rate)
+                               : (flags & OSC_CV_AUDIO_RATE) ? osc_delta_fast(e, c.sr)
+                                                             : osc_delta_cold(e, c.sr);
             }
             s.seen_cv = cv;
         }
@@ -842,7 +852,7 @@ SRK_DEV float steposc_step(StepOsc& s, const OscConst& k, float cv)
 {
     COsc& o = s.o;
     if (__builtin_amdgcn_ballot_w64(cv != s.seen_cv) != 0) {
-        const double delta = osc_delta_fast((double)cv + k.val, k.sr);
+        const double delta = osc_delta_cold((double)cv + k.val, k.sr);  // a held CV: the reference's own increment (osc_delta_cold)
         s.seen_cv = cv;
         s.carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
         cosc_init(o, o.pos, delta);

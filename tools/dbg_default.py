@@ -9,6 +9,8 @@ NOISE = len(sys.argv) > 1 and sys.argv[1] == "noise"
 for seed in [int(a) for a in sys.argv[1 + NOISE:]]:
     B, build, overrides = random_patch(seed, NOISE)
     V, T = (67, 1300) if B < 1024 else (131, 2300)
+    if os.environ.get("SOAK_VT"):
+        V, T = (int(x) for x in os.environ["SOAK_VT"].split(","))
     o = O.OraclePatch(48000, B, 2)
     ids = build(o)
     ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]
@@ -27,6 +29,6 @@ for seed in [int(a) for a in sys.argv[1 + NOISE:]]:
         if os.environ.get("DBG_VOICES") and len(bad):
             for v in sorted(set(bad[:, 2]))[:8]:
                 b = bad[bad[:, 2] == v]
-                print(f"      voice {v}: {len(b)} bad, first t {b[:,1].min()} last t {b[:,1].max()}; ref/gpu at first: {ref[b[0][0], b[0][1], v]:.6f} {fr[b[0][0], b[0][1], v]:.6f}")
+                print(f"      voice {v}: {len(b)} bad, channels {sorted(set(b[:,0]))}, first t {b[:,1].min()} last t {b[:,1].max()}; ref/gpu around the first: {ref[b[0][0], max(b[0][1]-2,0):b[0][1]+3, v]} {fr[b[0][0], max(b[0][1]-2,0):b[0][1]+3, v]}")
     print("   ", p.info()[:200])
     print("    types", [p.module_type(m) for m in range(p.num_modules())], "B", B)

@@ -15,14 +15,16 @@ for probe in args[2:]:
     m, port = map(int, probe.split("."))
     B, build, overrides = random_patch(seed, NOISE)
     V, T = (67, 1300) if B < 1024 else (131, 2300)
+    if os.environ.get("SOAK_VT"):
+        V, T = (int(x) for x in os.environ["SOAK_VT"].split(","))
     o = O.OraclePatch(48000, B, 2)
     ids = build(o)
-    o.connect(ids[m], port, ids[out], 1)
+    o.connect(m, port, out, 1)  # (handles are module indices)
     ov = [(ids[mm], f, fn(V)) for mm, f, fn in overrides]
     ref, _ = o.render_batch(V, T, ov, threads=8)
     p = S.Patch(48000, B, 2)
     ids2 = build(p)
-    p.connect(ids2[m], port, ids2[out], 1)
+    p.connect(m, port, out, 1)
     p.configure_voices(V)
     for mm, f, vals in ov: p.set_voice_field(mm, f, vals)
     fr = p.render_channels(T, flags)

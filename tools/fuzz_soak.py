@@ -15,6 +15,8 @@ for seed in range(lo, hi):
     os.environ["SRACK_WANT_WAVES"] = "1" if seed % 2 else "0"
     B, build, overrides = random_patch(seed, noise)
     V, T = (67, 1300) if B < 1024 else (131, 2300)
+    if os.environ.get("SOAK_VT"):  # e.g. SOAK_VT=16,48000: a full second of fewer voices
+        V, T = (int(x) for x in os.environ["SOAK_VT"].split(","))
     o = O.OraclePatch(48000, B, 2)
     ids = build(o)
     ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]

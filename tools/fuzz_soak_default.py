@@ -14,6 +14,8 @@ worst, n, n_bad, t0 = [], 0, 0, time.time()
 for seed in range(lo, hi):
     B, build, overrides = random_patch(seed, noise)
     V, T = (67, 1300) if B < 1024 else (131, 2300)
+    if os.environ.get("SOAK_VT"):  # e.g. SOAK_VT=16,48000: a full second of fewer voices
+        V, T = (int(x) for x in os.environ["SOAK_VT"].split(","))
     o = O.OraclePatch(48000, B, 2)
     ids = build(o)
     ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]
