@@ -1092,11 +1092,16 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             }
             return hit;
         };
+        // (... and the filter whose cutoff such a producer moves runs the literal ladder: a cutoff that jumps with a square's edges throws the
+        // ladder into transients where the contracted form's 1e-7 comes out at 2e-5 for a sample or two — seed 28336, bit-identical with it)
+        std::vector<char> moved_cutoff((size_t)n_mod, 0);
         auto reaches_cutoff = [&](const std::vector<uint32_t>& tainted) {
             if (!cutoff_rule) return false;
-            for (char h : filters_reached(tainted, SRACK_VCF_IN_CV))
-                if (h) return true;
-            return false;
+            bool any = false;
+            const std::vector<char> hit = filters_reached(tainted, SRACK_VCF_IN_CV);
+            for (int k = 0; k < n_mod; k++)
+                if (hit[(size_t)k]) moved_cutoff[(size_t)k] = 1, any = true;
+            return any;
         };
         // ... and white noise on a cutoff (the noise family's soak, seeds 2127, 2203, 2360: up to 3.2e-4 in 0.2 % of the samples) moves the
         // coefficient across its whole range from one sample to the next: such a filter does not forget a difference the way a filter with a
@@ -1187,7 +1192,8 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             from[(size_t)m] = ports;
             bool any = false;
             const std::vector<char> hit = pitches_reached(from, false, any);
-            A.exact_src[(size_t)m] = any || reaches_cutoff(from) || noisy_cutoff[(size_t)m] || reaches_noisy_filter(from);
+            const bool to_cutoff = reaches_cutoff(from);  // (marks the filters it reaches)
+            A.exact_src[(size_t)m] = any || to_cutoff || noisy_cutoff[(size_t)m] || reaches_noisy_filter(from);
             // ... unless the pitch it reaches closes a LOOP: a module whose own output comes back to its pitch input iterates a map, and in
             // such a loop the consumer's 1e-12 (the polynomial 2^cv against the reference's libm) can grow like anything else (random
             // patches with saw / filter feedback into a pitch part from the oracle within a few hundred samples).  Only the exact flavour of
@@ -1200,6 +1206,8 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                 if (pitches_reached(back, false, any2, true)[(size_t)k]) loop_through_pitch = true;
             }
         }
+        for (int m = 0; m < n_mod; m++)
+            if (moved_cutoff[(size_t)m] && A.live[(size_t)m]) A.exact_src[(size_t)m] = 1;
         // ... and a producer whose approximated output reaches an EVENT input — an envelope's or the sample player's gate, an oscillator's
         // sync, a sequencer's step or sync: `value > 0.0` decides when something happens, and a value 1e-7 off crosses zero a sample
         // earlier or later once in a few million crossings: an edge, and everything behind it, moves by a sample (the soak's seed 2691: a

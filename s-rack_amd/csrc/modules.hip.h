@@ -117,6 +117,34 @@ SRK_DEV double exp2_fast(double x)
     return kReduce ? __builtin_ldexp(p, (int)n) : p;
 }
 
+// The same with the interpolant of degree 10 (tools/exp2_coeffs.py: 3.1e-16 with the coefficients rounded to f64; 10 fma + 3 mul, depth 5)
+// — for every oscillator OUTSIDE the proved FM loops (osc_delta_fast).  1.1e-12 is three orders below what ONE oscillator's phase needs,
+// but it is a smooth function of the CV, not noise: a CV that is flagged as sweeping and in fact sits still (a filter that renders
+// silence, a square between its edges) makes the phase drift one way, 1e-9 cycles in a second; the f32 roundings of the saw it produces
+// then flip one way, and an oscillator that takes that saw as its pitch integrates the flips — 4e-5 on ITS saw after a second (the
+// one-second soak's seeds 30111, 31051).  At 3e-16 the chain ends at 1e-8.  The proved loops keep degree 8: their CVs are sines through
+// gains, which do sweep.
+template <bool kReduce = true>
+SRK_DEV double exp2_fast10(double x)
+{
+    const double n = kReduce ? __builtin_rint(x) : 0.0;
+    const double f = kReduce ? x - n : x;
+    const double f2 = f * f;
+    const double a01 = __builtin_fma(0x1.62e42fefa3a19p-1, f, 1.0);
+    const double a23 = __builtin_fma(0x1.c6b08d703ce49p-5, f, 0x1.ebfbdff82c598p-3);
+    const double a45 = __builtin_fma(0x1.5d87fe9d7a584p-10, f, 0x1.3b2ab6fba1ddap-7);
+    const double a67 = __builtin_fma(0x1.ffcb54062e698p-17, f, 0x1.430913096fd9fp-13);
+    const double a89 = __builtin_fma(0x1.b675bca4eeebbp-24, f, 0x1.62bfd47773353p-20);
+    const double f4 = f2 * f2;
+    const double b0 = __builtin_fma(a23, f2, a01);
+    const double b1 = __builtin_fma(a67, f2, a45);
+    const double b2 = __builtin_fma(0x1.e6063f7217bc6p-28, f2, a89);
+    const double f8 = f4 * f4;
+    const double lo = __builtin_fma(b1, f4, b0);
+    const double p = __builtin_fma(b2, f8, lo);
+    return kReduce ? __builtin_ldexp(p, (int)n) : p;
+}
+
 // 2^e, correctly rounded (exact render mode).  The reference evaluates `2.0_f64.powf(e)` with the host's libm, whose pow is
 // within 0.52 ulp of the true value, i.e. the correctly rounded double except for a fraction of a percent of the arguments.
 // ocml's pow / exp2 are ~1 ulp functions: 19 % of their results differ from the host's in the last bit (tools/powcheck.hip),
@@ -359,7 +387,7 @@ __device__ __attribute__((noinline)) double osc_delta_cold(double e, double sr) 
 template <bool kReduce = true>
 SRK_DEV double osc_delta_fast(double e, double sr)
 {
-    double d = (440.0 / sr) * exp2_fast<kReduce>(e);
+    double d = (440.0 / sr) * exp2_fast10<kReduce>(e);
     if (__builtin_expect((uint32_t)__double2hiint(d) >= 0x3ff00000u, 0)) d = osc_delta_cold(e, sr);  // d >= 1.0, a NaN, a negative rate
     return d;
 }
