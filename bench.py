@@ -457,12 +457,13 @@ def profiled_traffic(kernel_name, workload, flags, V, T):
 def arithmetic_note(flags):
     """What the render mode computes in, where it is not the reference's own operation sequence."""
     if flags & 1:
-        return ("exact mode: the reference's operations one by one — f64 phase / 2^cv (correctly rounded) / PolyBLEP with its f64 division, the ladder "
+        return ("exact mode: the reference's operations one by one — f64 phase / 2^cv (the host libm's pow, operation for operation) / PolyBLEP with its f64 division, the ladder "
                 "uncontracted with min/max clamps; frames bit-identical to the CPU tick (oscillator.rs:108-158, filter.rs:58-92)")
     return ("default mode, within the 1e-5 contract but NOT the reference's arithmetic everywhere: PolyBLEP evaluated in f32 (reference: f64, "
             "oscillator.rs:50-67); the ladder with one product of each a*b - c*d folded into an fma and v_med3 clamps (reference: uncontracted, "
             "min/max, filter.rs:69-89); the audio saw's phase accumulator in 2^-64 fixed point where the flattener proves nothing integrates it "
-            "(reference: f64 with fmod; gate-producing oscillators keep the f64 phase); 2^cv and sine by polynomials (1e-12) where a pitch CV is connected. "
+            "(reference: f64 with fmod; gate-producing oscillators keep the f64 phase); where a pitch CV is connected: 2^cv by a polynomial (3e-16; 1e-12 inside proved FM loops; "
+            "the libm's own pow per held value for a CV that holds: sequencer notes, envelopes), sine by a polynomial (f64, one rounding). "
             "ADSR, VCA, mixer, math, sequencers: the reference's f32 operations in its order, bit-identical in every mode. "
             "`cfg3_exact_*` on this line is the same workload in the reference's own arithmetic")
 
