@@ -682,3 +682,52 @@ def test_rust_extern_block_matches_the_header(source):
         assert len(params) == len(c_params), f"{source}: {name} takes {len(params)} parameters, the header {len(c_params)}"
         for k, (r, c) in enumerate(zip(params, c_params)):
             assert r in _C_TO_RUST[c], f"{source}: {name} parameter {k} is {r}, the header says {c}"
+
+
+# ---- round 4's last flattener rules, read off the generated source (no GPU) -----------------------------------------------------------
+def test_pitch_cv_that_holds_and_pitch_cv_that_sweeps(S):
+    """OSC_CV_AUDIO_RATE (program.hpp) is the flattener's: a pitch CV with an oscillator, a filter, noise or a sample player upstream sweeps
+    (the polynomial 2^cv every sample); one with nothing upstream but envelopes, sequencers and arithmetic on them holds, and its oscillator
+    recomputes the increment per held value with the reference's own 2^cv (modules.hip.h, osc_delta_cold; flatten.cpp, `sweeps`)."""
+    import re
+
+    def osc_flags(p):
+        src = p.kernel_source(S.RENDER_NO_UNIFORM_HOIST | S.RENDER_NO_FUSION)
+        return [int(x, 16) for x in re.findall(r"osc_step\(\(?(0x[0-9a-f]+)u", src)]
+
+    AUDIO, HAS_CV = 0x100, 0x1
+    for upstream, expect in ((S.MOD_ADSR, 0), (S.MOD_OSCILLATOR, AUDIO), (S.MOD_MOOG_FILTER, AUDIO)):
+        p = S.Patch(48000, 64, 2)
+        src_m, gain, osc, out = p.add_module(upstream), p.add_module(S.MOD_MATH), p.add_module(S.MOD_OSCILLATOR), p.add_module(S.MOD_OUTPUT)
+        p.set_field(gain, S.MATH_OPERATION, S.MATH_MULTIPLY)
+        p.set_field(gain, S.MATH_CONSTANT, 0.5)
+        p.connect(src_m, 0, gain, 0)
+        p.connect(gain, 0, osc, 0)
+        p.connect(osc, S.OSC_OUT_SINE, out, 0)
+        p.configure_voices(8)
+        with_cv = [f for f in osc_flags(p) if f & HAS_CV]
+        assert with_cv and all((f & AUDIO) == expect for f in with_cv), (upstream, [hex(f) for f in with_cv])
+
+
+def test_cutoff_rules_of_the_flattener(S):
+    """flatten.cpp 2b: an approximated producer (a square) that reaches a filter's cutoff CV gets the exact PolyBLEP and that filter the literal
+    ladder (the saw on its audio input keeps the fast form); white noise on a cutoff: literal ladder AND the exact PolyBLEP for the oscillator
+    on the audio input; an envelope on the cutoff — P3's sweep — changes nothing."""
+    import re
+    EXACT_BLEP = 1 << 13
+    for cv_source in (S.MOD_OSCILLATOR, S.MOD_NOISE, S.MOD_ADSR):
+        p = S.Patch(48000, 64, 2)
+        audio, cv, vcf, out = p.add_module(S.MOD_OSCILLATOR), p.add_module(cv_source), p.add_module(S.MOD_MOOG_FILTER), p.add_module(S.MOD_OUTPUT)
+        p.connect(audio, S.OSC_OUT_SAW, vcf, 0)
+        p.connect(cv, S.OSC_OUT_SQUARE if cv_source == S.MOD_OSCILLATOR else 0, vcf, 1)
+        p.connect(vcf, 0, out, 0)
+        p.configure_voices(8)
+        src = p.kernel_source(S.RENDER_NO_UNIFORM_HOIST | S.RENDER_NO_FUSION)
+        literal_forms = [int(x, 16) for x in re.findall(r"osc_step\(\(?(0x[0-9a-f]+)u", src)]   # (the fast constant-pitch forms have other names)
+        assert ("vcf_run<true>" in src) == (cv_source == S.MOD_ADSR), cv_source
+        if cv_source == S.MOD_ADSR:
+            assert "fosc_saw" in src and not literal_forms
+        elif cv_source == S.MOD_NOISE:
+            assert "fosc_saw" not in src and len(literal_forms) == 1 and literal_forms[0] & EXACT_BLEP   # the audio saw
+        else:
+            assert "fosc_saw" in src and len(literal_forms) == 1 and literal_forms[0] & EXACT_BLEP       # the square on the cutoff; the audio saw stays fast
