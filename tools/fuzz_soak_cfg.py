@@ -1,5 +1,5 @@
 """Soak of the differential fuzzer over the CONFIGURATION space the pinned tests fix: sample rate, buffer size, channel count, voice
-count and render length are drawn per seed (exact modes, bit for bit against the oracle).  usage: <first> <last> [noise]"""
+count and render length are drawn per seed (exact modes, bit for bit against the oracle; SOAK_DEFAULT=1: the default modes at the 1e-5 bar).  usage: <first> <last> [noise]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -24,7 +24,8 @@ for seed in range(lo, hi):
     ids = build(o)
     ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]
     ref, _ = o.render_batch(V, T, ov, threads=8)
-    for flags in (1, 3, 7, 11):
+    DEFAULT = bool(os.environ.get("SOAK_DEFAULT"))  # the default modes over the same configurations, at the 1e-5 bar
+    for flags in ((0, 2, 4) if DEFAULT else (1, 3, 7, 11)):
         p = S.Patch(sr, B, C)
         build(p)
         p.configure_voices(V)
@@ -33,8 +34,13 @@ for seed in range(lo, hi):
         fr = p.render_channels(T, flags)
         n += 1
         same = (fr.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(fr) & np.isnan(ref))
+        if DEFAULT and fr.shape == ref.shape:
+            r64, f64 = ref.astype(np.float64), fr.astype(np.float64)
+            fin = np.isfinite(r64) & np.isfinite(f64)
+            with np.errstate(invalid="ignore"):
+                same = np.where(fin, np.abs(f64 - r64) <= 1e-5 * np.maximum(np.abs(r64), 1.0), (np.isnan(fr) & np.isnan(ref)) | (fr == ref))
         if fr.shape != ref.shape or not same.all():
             bad.append((seed, flags, (sr, B, C, V, T), float(1 - same.mean())))
-print(f"configs, seeds {lo}..{hi - 1} noise={noise}: {n} renders, {len(bad)} not bit-identical, {time.time() - t0:.0f} s")
+print(f"configs, seeds {lo}..{hi - 1} noise={noise}: {n} renders, {len(bad)} {'outside the 1e-5 band' if os.environ.get('SOAK_DEFAULT') else 'not bit-identical'}, {time.time() - t0:.0f} s")
 for b in bad[:40]:
     print("  seed %d flags %d (sr, B, C, V, T) = %s: %.5f of the samples differ" % b)
