@@ -50,13 +50,15 @@ enum : uint32_t {
     OSC_EXACT = 1u << 6,      // f64 PolyBLEP / sin / pow exactly as the reference spells them
     OSC_CONST_FAST = 1u << 7, // host-proved: no CV, no sync, one live port, PolyBLEP on, every voice's delta < 0.25
                               // => the carried-phase oscillator (modules.hip.h, COsc) may be used
-    OSC_CV_AUDIO_RATE = 1u << 8,  // the CV changes every sample (FM): do not bother caching 2^cv per CV value
+    OSC_CV_AUDIO_RATE = 1u << 8,  // the CV SWEEPS (flatten.cpp `sweeps`: an oscillator, a filter, noise, a sample player upstream): 2^cv by polynomial every sample.
+                                  // Without it the CV HOLDS (envelopes, sequencers, arithmetic on them): the increment is recomputed when the value changes, with the
+                                  // reference's own 2^cv (modules.hip.h, osc_delta_cold) — a polynomial's error would be a constant per held value, i.e. a phase drift
     OSC_FIXED_PHASE = 1u << 10,   // pos rows and delta (rows or DevOp::delta's bit pattern) hold phase * 2^64 as u64, not f64 (fused voice kernels, default mode, saw)
     OSC_CV_STEPWISE = 1u << 9,    // host-proved: the CV is a sequencer's note CV (plus constants): constant between steps
     OSC_SINE_LOOSE = 1u << 12,    // host-proved: the sine port's value cannot reach a pitch input (an oscillator's or the sample player's CV), so
                                   // nothing integrates its rounding: default mode may evaluate it in f32 after the exact f64 fold
     OSC_EXACT_BLEP = 1u << 13,    // host-proved need, default mode only: this oscillator's saw / square can reach a pitch input, where an error is
-                                  // INTEGRATED — its PolyBLEP is evaluated as in exact mode (f64, true division); everything else about it
+                                  // INTEGRATED (or an event input, a filter's cutoff CV, the audio input of a filter with noise on its cutoff: flatten.cpp 2b) — its PolyBLEP is evaluated as in exact mode (f64, true division); everything else about it
                                   // (2^cv, sine, the rest of the patch) stays in the default arithmetic
     OSC_CONST_SMALL = 1u << 11,   // host-proved, whatever the render mode: no CV, no sync, one live port, PolyBLEP on, every voice's delta < 0.25
                                   // (OSC_CONST_FAST = this and not OSC_EXACT)
@@ -74,7 +76,8 @@ enum : uint32_t {
     VCF_OUT_LP = 1u << 3,
     VCF_OUT_BP = 1u << 4,
     VCF_OUT_HP = 1u << 5,
-    VCF_LITERAL = 1u << 6,    // default mode only: an output can reach a pitch input — the ladder runs the reference's operations one by one (no fma contraction)
+    VCF_LITERAL = 1u << 6,    // default mode only: an output can reach a pitch / event input or another filter's cutoff, the filter sits on a cycle, or its own cutoff is moved by an
+                              // approximated producer or by noise (flatten.cpp 2b) — the ladder runs the reference's operations one by one (no fma contraction)
     // OP_ADSR
     ADSR_HAS_GATE = 1u << 0,
     // OP_VCA
