@@ -731,3 +731,26 @@ def test_cutoff_rules_of_the_flattener(S):
             assert "fosc_saw" not in src and len(literal_forms) == 1 and literal_forms[0] & EXACT_BLEP   # the audio saw
         else:
             assert "fosc_saw" in src and len(literal_forms) == 1 and literal_forms[0] & EXACT_BLEP       # the square on the cutoff; the audio saw stays fast
+
+
+def test_exp2_fast10_coefficients_in_the_header():
+    """modules.hip.h's polynomial 2^f for sweeping pitch CVs (exp2_fast10), read out of the header and evaluated in f64 by its own scheme against
+    mpmath: 5e-16 over |f| <= 1/2 (tools/exp2_coeffs.py made the coefficients; the degree-8 form it replaced outside the proved FM loops
+    was 1.1e-12, a phase drift wherever such a CV sat still — tests/test_gpu_fuzz.py, the one-second cases)."""
+    import re
+    mp = pytest.importorskip("mpmath")
+    text = open(os.path.join(ROOT, "s-rack_amd", "csrc", "modules.hip.h")).read()
+    body = text[text.index("SRK_DEV double exp2_fast10(double x)"):]
+    body = body[:body.index("return kReduce")]
+    hx = [float.fromhex(h) for h in re.findall(r"0x1\.[0-9a-f]+p[+-]\d+", body)]
+    assert len(hx) == 10   # c1, c3, c2, c5, c4, c7, c6, c9, c8, c10 in the order the fmas name them; c0 = 1.0
+    c1, c3, c2, c5, c4, c7, c6, c9, c8, c10 = hx
+    f = np.linspace(-0.5, 0.5, 4001)
+    f2 = f * f
+    a01, a23, a45, a67, a89 = c1 * f + 1.0, c3 * f + c2, c5 * f + c4, c7 * f + c6, c9 * f + c8
+    f4 = f2 * f2
+    b0, b1, b2 = a23 * f2 + a01, a67 * f2 + a45, c10 * f2 + a89
+    p = b2 * (f4 * f4) + (b1 * f4 + b0)
+    mp.mp.dps = 40
+    worst = max(abs(mp.mpf(float(pi)) / mp.power(2, mp.mpf(float(fi))) - 1) for pi, fi in zip(p, f))
+    assert worst < 6e-16, float(worst)
