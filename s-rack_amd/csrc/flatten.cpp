@@ -1360,7 +1360,13 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                         if (g.modules[(size_t)in.src].type == SRACK_MOD_MOOG_FILTER && in.port != SRACK_VCF_OUT_LOWPASS) loop_needs_exact = true;
                     }
                     switch (c.type) {
-                    case SRACK_MOD_MOOG_FILTER: break;
+                    case SRACK_MOD_MOOG_FILTER:
+                        // a ladder on a cycle: its own feedback q·b4 and the cycle's add up — a lowpass through a subtraction back into its input
+                        // (gain -1) raises the effective resonance by one unit of q, past self-oscillation from res ~0.8 — and what the
+                        // clamps then bound is chaotic: ANY approximation that enters the cycle (an f32 PolyBLEP saw on the filter's input:
+                        // the soak's seed 40214, 6e-3 at 200 voices x 6000 samples) grows.  The literal ladder alone is not enough.
+                        loop_needs_exact = true;
+                        break;
                     case SRACK_MOD_OSCILLATOR: break;  // on the cycle through its pitch CV (a sync input was an event, above): FM feedback — what its saw /
                                                        // square carry around is the loop-through-a-pitch rule's, its sine is the reference's own to half an ulp
                     case SRACK_MOD_MONO_MIXER: {
