@@ -1395,6 +1395,24 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
                     }
                 }
             }
+            // ... and a cycle that does not amplify still REMEMBERS: Add <-> Subtract around a delayed edge has gain exactly 1 — an integrator —
+            // and sums up the 1e-7 of whatever feeds it, one way, for as long as the render lasts (the soak's seed 40913 at 200 voices x 6000
+            // samples: a contracted highpass into such a pair, 8.5e-5).  An approximated producer that reaches a module on ANY cycle gets the
+            // exact PolyBLEP / the literal ladder, like one that reaches a pitch (sines are not approximated producers: config 4 keeps its forms).
+            if (!loop_needs_exact) {
+                std::vector<char> cyc((size_t)n_mod, 0);
+                for (int k = 0; k < n_mod; k++)
+                    if (A.live[(size_t)k]) cyc[(size_t)k] = reach(k, true)[(size_t)k];
+                for (int m = 0; m < n_mod; m++) {
+                    if (!A.live[(size_t)m] || A.exact_src[(size_t)m]) continue;
+                    const int t = g.modules[(size_t)m].type;
+                    const uint32_t ports = t == SRACK_MOD_OSCILLATOR ? (A.port_live[(size_t)m] & 6u) : t == SRACK_MOD_MOOG_FILTER ? (A.port_live[(size_t)m] & 7u) : 0u;
+                    if (!ports) continue;
+                    const std::vector<char> down = reach(m, true);
+                    for (int k = 0; k < n_mod; k++)
+                        if (down[(size_t)k] && cyc[(size_t)k]) A.exact_src[(size_t)m] = 1;
+                }
+            }
         }
         if (loop_through_pitch || loop_needs_exact) {
             render_flags |= SRACK_RENDER_EXACT_OSC;
