@@ -754,3 +754,38 @@ def test_exp2_fast10_coefficients_in_the_header():
     mp.mp.dps = 40
     worst = max(abs(mp.mpf(float(pi)) / mp.power(2, mp.mpf(float(fi))) - 1) for pi, fi in zip(p, f))
     assert worst < 6e-16, float(worst)
+
+
+def test_cycle_rules_of_the_flattener(S):
+    """flatten.cpp 2b, the cycles: a filter ON a cycle turns the whole patch exact (effective flags); an approximated producer that merely FEEDS
+    a cycle — here an Add <-> Subtract pair, an integrator — keeps the patch in the default flavour and gets the exact PolyBLEP itself; the
+    same saw into no cycle keeps the fast form."""
+    import re
+
+    def source(wire_cycle, filter_on_cycle):
+        p = S.Patch(48000, 16, 2)
+        osc, add, sub, out = p.add_module(S.MOD_OSCILLATOR), p.add_module(S.MOD_MATH), p.add_module(S.MOD_MATH), p.add_module(S.MOD_OUTPUT)
+        p.set_field(add, S.MATH_OPERATION, S.MATH_ADD)
+        p.set_field(sub, S.MATH_OPERATION, S.MATH_SUBTRACT)
+        p.connect(osc, S.OSC_OUT_SAW, add, 1)
+        p.connect(add, 0, sub, 0)
+        p.connect(add, 0, out, 0)
+        if wire_cycle:
+            if filter_on_cycle:
+                vcf = p.add_module(S.MOD_MOOG_FILTER)
+                p.connect(sub, 0, vcf, 0)
+                p.connect(vcf, 0, add, 0)
+            else:
+                p.connect(sub, 0, add, 0)
+        p.configure_voices(8)
+        return p.kernel_source(S.RENDER_NO_UNIFORM_HOIST | S.RENDER_NO_FUSION)
+
+    EXACT, EXACT_BLEP = 1 << 6, 1 << 13   # program.hpp: OSC_EXACT, OSC_EXACT_BLEP
+    flags_of = lambda src: [int(x, 16) for x in re.findall(r"osc_step\(\(?(0x[0-9a-f]+)u", src)]
+    plain = source(False, False)
+    assert "fosc_saw" in plain and not flags_of(plain)
+    fed = source(True, False)
+    assert "fosc_saw" not in fed and [f & (EXACT | EXACT_BLEP) for f in flags_of(fed)] == [EXACT_BLEP]
+    ladder = source(True, True)
+    assert "vcf_run<true>" not in ladder and "fosc_saw" not in ladder
+    assert "xsaw_" in ladder or any(f & EXACT for f in flags_of(ladder))   # the exact flavour's saw (tile-wise, or the literal form)
