@@ -307,7 +307,7 @@ int Builder::build()
             if (A.sine_loose[(size_t)m]) op.flags |= OSC_SINE_LOOSE;
             if (A.exact_src[(size_t)m] && !(op.flags & OSC_EXACT)) op.flags |= OSC_EXACT_BLEP;
             if (const char* e = getenv("SRACK_OSC_EXACT_MASK"))  // (tools/: the exact PolyBLEP for the oscillators whose module index is set in the mask)
-                if (!(op.flags & OSC_EXACT) && ((strtoul(e, nullptr, 0) >> m) & 1u)) op.flags |= OSC_EXACT_BLEP;
+                if (!(op.flags & OSC_EXACT) && m < 64 && ((strtoull(e, nullptr, 0) >> m) & 1u)) op.flags |= OSC_EXACT_BLEP;
             op.sample_rate = (double)g.cfg.sample_rate;  // `self.sample_rate as f64`, u16 in the reference
             {   // pos: f64 state, two rows (lo, hi)
                 const VoiceOverride* o = find_override(m, SRACK_OSC_POS);
@@ -340,7 +340,7 @@ int Builder::build()
             if (pl & 4u) op.flags |= VCF_OUT_HP;
             if (A.exact_src[(size_t)m] && !(render_flags & SRACK_RENDER_EXACT_OSC)) op.flags |= VCF_LITERAL;
             if (const char* e = getenv("SRACK_VCF_LITERAL_MASK"))  // (tools/: the literal ladder for the filters whose module index is set in the mask)
-                if (!(render_flags & SRACK_RENDER_EXACT_OSC) && ((strtoul(e, nullptr, 0) >> m) & 1u)) op.flags |= VCF_LITERAL;
+                if (!(render_flags & SRACK_RENDER_EXACT_OSC) && m < 64 && ((strtoull(e, nullptr, 0) >> m) & 1u)) op.flags |= VCF_LITERAL;
             op.state_row = state_row_f32(m, SRACK_VCF_ST_F);
             state_row_f32(m, SRACK_VCF_ST_P);
             state_row_f32(m, SRACK_VCF_ST_Q);
@@ -1065,7 +1065,7 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             pitches_reached(tainted, also_thresholds, any);
             return any;
         };
-        // A filter's cutoff CV is its pitch: `2^(cv * amount)` scales the coefficient of all four stages, and behind a band- or highpass port
+        // A filter's cutoff CV is its pitch: `freq + cv * amount` (clamped, filter.rs) sets the coefficient of all four stages, and behind a band- or highpass port
         // (input minus a stage: a difference of nearly equal values) the producers' 1e-7 comes out 250 times larger (the soak's seed 10901:
         // a saw through a highpass into a second filter's audio AND cutoff, 2.6e-5 in 1 voice-sample of 17 000; with every producer on the
         // way to that cutoff exact 3e-6, the modulated filter itself approximated).  SRACK_LOOSE_CUTOFF=1: the rule off (tools/).
