@@ -374,8 +374,8 @@ SRK_DEV double exp2_libm(double e)
 }
 
 // The default mode's phase increment, 440 / sr * 2^e with the polynomial above — up to ONE CYCLE PER SAMPLE.  From there on (a pitch CV of
-// +7 and more at 48 kHz: a gain close to 1 on a feedback cycle gets a patch there, the soak's seed 16340) the polynomial's 1e-12 is no
-// longer a relative error of something small but an absolute phase error per sample, which a saw or a square shows within a few hundred
+// +7 and more at 48 kHz: a gain close to 1 on a feedback cycle gets a patch there, the soak's seed 16340) the polynomial's error (1e-12
+// when the seed was found, 3e-16 since) is no longer a relative error of something small but an absolute phase error per sample — at 2^60 cycles per sample either is —, which a saw or a square shows within a few hundred
 // samples; what the reference renders up there is aliasing noise, but it is ITS noise: such an increment is evaluated as the reference
 // spells it, with the host libm's own 2^e (out of line: the hot path pays a compare of the upper word and a branch).
 // The same function serves every CV that holds its values (osc_step's recompute-on-change path, steposc_step): there the polynomial's
