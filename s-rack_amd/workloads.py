@@ -244,3 +244,38 @@ def p2_voice_params(n_voices, seed=SEED, first_voice=0):
     u0 = voice_uniform(n_voices, 0, seed, first_voice)
     u1 = voice_uniform(n_voices, 1, seed, first_voice)
     return (np.float32(0.1) + u0 * np.float32(0.3)).astype(np.float32), (np.float32(0.5) + u1).astype(np.float32)
+
+
+BENCH_WORKLOADS = ("cfg3", "cfg3_poly", "cfg2", "cfg4", "cfg4_b1024", "p3", "p4")
+
+
+def bench_workload(name, n_voices, first_voice=0, seed=SEED):
+    """The workloads `bench.py` times, by name, as data: -> (buffer_size, build(g) -> ids, overrides(ids) -> [(module, field, f32[n_voices])]).
+    `build` takes any object with the graph API (the product's Patch, the test oracle's OraclePatch); the per-voice draws are keyed by the
+    GLOBAL voice index first_voice + v, so a shard is the same voices whatever the rank count."""
+    f = np.float32
+    if name in ("cfg3", "cfg2", "cfg3_poly"):
+        def overrides(ids):
+            if name == "cfg2":
+                return []
+            if name == "cfg3_poly":
+                return p1_poly_overrides(ids, p1_poly_voice_params(n_voices, seed, first_voice))
+            det, cut = p1_voice_params(n_voices, seed, first_voice)
+            return [(ids["osc_a"], OSC_VAL, det), (ids["vcf"], VCF_FREQ, cut)]
+        return 1024, build_p1, overrides
+    if name in ("cfg4", "cfg4_b1024"):
+        def overrides(ids):
+            beta, index = p2_voice_params(n_voices, seed, first_voice)
+            return [(ids["mul_fb"], MATH_CONSTANT, beta), (ids["mul_idx"], MATH_CONSTANT, index)]
+        return (1 if name == "cfg4" else 1024), build_p2, overrides
+    if name == "p3":
+        def overrides(ids):
+            u0, u1 = voice_uniform(n_voices, 0, seed, first_voice), voice_uniform(n_voices, 1, seed, first_voice)
+            return [(ids["transpose"], MATH_CONSTANT, (u0 * f(2.5) - f(2.0)).astype(f)), (ids["vcf"], VCF_FREQ, (f(0.05) + u1 * f(0.35)).astype(f))]
+        return 1024, build_p3, overrides
+    if name == "p4":
+        def overrides(ids):
+            depth, expo = p4_voice_params(n_voices, seed, first_voice)
+            return [(ids["depth"], MATH_CONSTANT, depth), (ids["shaper"], NONLIN_CONSTANT, expo)]
+        return 1024, build_p4, overrides
+    raise ValueError(f"unknown workload {name!r}")

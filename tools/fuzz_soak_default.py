@@ -47,3 +47,8 @@ seeds = sorted(set(w[0] for w in worst))
 print(f"  {len(seeds)} patches: {seeds[:60]}")
 for w in worst[:12]:
     print("  seed %d flags %d: max rel err %.2e, %.5f of the samples outside, non-finite masks equal %s %s" % w)
+if os.environ.get("SOAK_JSON"):  # (tools/soak_par.py merges its workers' results)
+    import json
+    with open(os.environ["SOAK_JSON"], "w") as f:
+        json.dump(dict(first=lo, last=hi, noise=noise, renders=n, bad=n_bad, seconds=time.time() - t0, vt=os.environ.get("SOAK_VT", ""),
+                       special=bool(os.environ.get("FUZZ_SPECIAL")), worst=[list(w[:5]) for w in worst]), f)
