@@ -221,52 +221,29 @@ class HipBackend:
         S, args = self.S, self.args
         V = args.voices
         w = args.workload
-        B = 1 if w == "cfg4" else 1024
-        p = S.Patch(48000, B, 2)
         first = self.rank * V  # global voice index => same draw as the 1-GPU run of the same voices
-        if w == "cfg3_poly":
-            ids = S.build_p1(p)
-            p.configure_voices(V)
-            for m, f, v in S.p1_poly_overrides(ids, S.p1_poly_voice_params(V, first_voice=first)):
-                p.set_voice_field(m, f, v)
-            what = (f"config 3's patch and size with nothing voice-invariant: P1, {V} voices/GPU with per-voice detune / cutoff / gate-LFO rate "
-                    "(1.7 ... 13.8 Hz) / envelope times — saw VCO, gate LFO, ladder VCF, ADSR and VCA all evaluated per voice")
-        elif w in ("cfg3", "cfg2"):
-            ids = S.build_p1(p)
-            p.configure_voices(V)
-            if w == "cfg3":
-                det, cut = S.p1_voice_params(V, first_voice=first)
-                p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
-                p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
-                what = ("BASELINE config 3 per GPU (config 5 at 8 GPUs): patch P1 saw VCO->ladder VCF->ADSR->VCA, "
-                        f"{V} voices/GPU with per-voice randomised detune/cutoff")
-            else:
-                what = (f"BASELINE config 2: patch P1, {V} IDENTICAL voices (every module is voice-invariant: one wave evaluates the patch "
-                        "once — a latency chain — and the frames are a broadcast)")
-        elif w in ("cfg4", "cfg4_b1024"):
-            ids = S.build_p2(p)
-            p.configure_voices(V)
-            beta, index = S.p2_voice_params(V, first_voice=first)
-            p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, beta)
-            p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
-            what = (f"BASELINE config 4: patch P2 2-op FM with a feedback edge, {V} voices with per-voice feedback / index, "
-                    f"buffer_size {B} (" + ("z^-1 feedback in a register" if B == 1 else "the app's block size: the feedback delay is a ring in HBM") + ")")
-        elif w == "p4":
-            ids = S.build_p4(p)
-            p.configure_voices(V)
-            depth, expo = S.p4_voice_params(V, first_voice=first)
-            p.set_voice_field(ids["depth"], S.MATH_CONSTANT, depth)
-            p.set_voice_field(ids["shaper"], S.NONLIN_CONSTANT, expo)
-            what = ("patch P4 (diagnostic): clock -> sample player with per-voice vibrato depth -> sign-preserving waveshaper with a per-voice "
-                    f"exponent, raw sample on channel 2, {V} voices/GPU")
-        else:
-            ids = S.build_p3(p)
-            p.configure_voices(V)
-            u0, u1 = S.voice_uniform(V, 0, first_voice=first), S.voice_uniform(V, 1, first_voice=first)
-            p.set_voice_field(ids["transpose"], S.MATH_CONSTANT, (u0 * np.float32(2.5) - np.float32(2.0)).astype(np.float32))
-            p.set_voice_field(ids["vcf"], S.VCF_FREQ, (np.float32(0.05) + u1 * np.float32(0.35)).astype(np.float32))
-            what = ("patch P3 (diagnostic): clock -> grid + pattern sequencers -> per-voice transposed saw VCO -> VCF swept by an "
-                    f"envelope -> VCA, raw gate on channel 2, {V} voices/GPU with per-voice transpose/cutoff")
+        B, build, overrides = S.bench_workload(w, V, first_voice=first)   # (s-rack_amd/workloads.py: the workloads as data — the parity tests build the same)
+        p = S.Patch(48000, B, 2)
+        ids = build(p)
+        p.configure_voices(V)
+        for m, f, v in overrides(ids):
+            p.set_voice_field(m, f, v)
+        what = {
+            "cfg3_poly": (f"config 3's patch and size with nothing voice-invariant: P1, {V} voices/GPU with per-voice detune / cutoff / gate-LFO rate "
+                          "(1.7 ... 13.8 Hz) / envelope times — saw VCO, gate LFO, ladder VCF, ADSR and VCA all evaluated per voice"),
+            "cfg3": ("BASELINE config 3 per GPU (config 5 at 8 GPUs): patch P1 saw VCO->ladder VCF->ADSR->VCA, "
+                     f"{V} voices/GPU with per-voice randomised detune/cutoff"),
+            "cfg2": (f"BASELINE config 2: patch P1, {V} IDENTICAL voices (every module is voice-invariant: one wave evaluates the patch "
+                     "once — a latency chain — and the frames are a broadcast)"),
+            "cfg4": (f"BASELINE config 4: patch P2 2-op FM with a feedback edge, {V} voices with per-voice feedback / index, "
+                     f"buffer_size {B} (z^-1 feedback in a register)"),
+            "cfg4_b1024": (f"BASELINE config 4: patch P2 2-op FM with a feedback edge, {V} voices with per-voice feedback / index, "
+                           f"buffer_size {B} (the app's block size: the feedback delay is a ring in HBM)"),
+            "p4": ("patch P4 (scope row (f)4): clock -> sample player with per-voice vibrato depth -> sign-preserving waveshaper with a per-voice "
+                   f"exponent, raw sample on channel 2, {V} voices/GPU"),
+            "p3": ("patch P3 (scope row (f)1): clock -> grid + pattern sequencers -> per-voice transposed saw VCO -> VCF swept by an "
+                   f"envelope -> VCA, raw gate on channel 2, {V} voices/GPU with per-voice transpose/cutoff"),
+        }[w]
         return p, what, B
 
     def dump(self, directory):
@@ -381,8 +358,10 @@ def cpu_baseline(S, workload, n_samples=48000):
 
 
 # (name on the line, workload, render flags): the headline in the exact render mode (the reference's arithmetic bit for bit), the fully
-# per-voice variant of the headline, and BASELINE.json configs[1] and configs[3] — the other single-GPU configurations
-SIDE_CONFIGS = (("cfg3_exact", "cfg3", 1), ("cfg3_poly", "cfg3_poly", 0), ("cfg2", "cfg2", 0), ("cfg4", "cfg4", 0))
+# per-voice variant of the headline, BASELINE.json configs[1] and configs[3] — the other single-GPU configurations —
+SIDE_CONFIGS = (("cfg3_exact", "cfg3", 1), ("cfg3_poly", "cfg3_poly", 0), ("cfg2", "cfg2", 0), ("cfg4", "cfg4", 0),
+                # ... config 4 at the app's block size, and the workloads of scope rows (f)1 and (f)4 (two output planes each)
+                ("cfg4_b1024", "cfg4_b1024", 0), ("p3", "p3", 0), ("p4", "p4", 0))
 SIDE_STEPS, SIDE_WARMUP = 5, 1
 
 

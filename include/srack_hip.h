@@ -187,7 +187,13 @@ enum {
      * interpreter, which executes the same device functions
      * tile by tile with the wires in LDS.  Both are parity-tested against the oracle. */
     SRACK_RENDER_NO_SPECIALIZE = 1u << 4, /* always the tile interpreter */
-    SRACK_RENDER_SPECIALIZE    = 1u << 5  /* specialise whatever the voice count (fails loudly if it cannot) */
+    SRACK_RENDER_SPECIALIZE    = 1u << 5, /* specialise whatever the voice count (fails loudly if it cannot) */
+    /* Default mode decides per patch which of its cheaper forms each module takes, from a first-order error bound against the 1e-5
+     * contract (csrc/approx.cpp), and renders a patch whose graph has an unbounded error gain — a loop that amplifies, a ladder near
+     * self-oscillation, a loop through a gate or a pitch — in the exact flavour altogether.  This flag keeps the DEFAULT flavour for
+     * such a patch too (modules still take their exact forms one by one where the bound asks for it): faster, and outside the parity
+     * contract — srack_render_info says "approx[kept default: ...]". */
+    SRACK_RENDER_KEEP_DEFAULT  = 1u << 6
 };
 
 typedef struct srack_patch srack_patch; /* opaque: the workspace's module list + plan + device voice state */

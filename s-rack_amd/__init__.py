@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrack_hip.so")
 
 OK, ERR_INVALID, ERR_PORT, ERR_NO_OUTPUT, ERR_SELF_LOOP, ERR_STATE, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7, -8
-RENDER_DEFAULT, RENDER_EXACT_OSC, RENDER_NO_FUSION, RENDER_NO_UNIFORM_HOIST, RENDER_NO_CTL_STAGES, RENDER_NO_SPECIALIZE, RENDER_SPECIALIZE = 0, 1, 2, 4, 8, 16, 32
+RENDER_DEFAULT, RENDER_EXACT_OSC, RENDER_NO_FUSION, RENDER_NO_UNIFORM_HOIST, RENDER_NO_CTL_STAGES, RENDER_NO_SPECIALIZE, RENDER_SPECIALIZE, RENDER_KEEP_DEFAULT = 0, 1, 2, 4, 8, 16, 32, 64
 
 # every symbol include/srack_hip.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = [

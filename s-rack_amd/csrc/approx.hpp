@@ -1,0 +1,47 @@
+// approx.hpp — which approximations of the default render mode a patch may take (flatten.cpp step 2b).
+//
+// The default mode's kernels have cheaper forms of four of the reference's computations — PolyBLEP in f32 (reference: f64,
+// oscillator.rs:50-67), the ladder with one product of each a*b - c*d folded into an fma (filter.rs:69-82), the sine in f32, NonLinear's
+// power through the f32 transcendental unit (math.rs:203-205) — and a constant-pitch saw's phase in 2^-64 fixed point.  Each is an error
+// EPSILON injected on a wire; whether a patch may take it is decided here from a first-order bound: epsilon times the GAIN from that wire
+// to every output channel, summed over the forms taken, must stay below kBudget (half the 1e-5 contract).  The gains come from one
+// backward pass over the graph with a table per module type (approx.cpp): arithmetic passes errors on with its coefficients, a filter
+// with the L1 norm of its impulse response (computed from its own coefficients: a ladder near self-oscillation has none), a pitch input
+// INTEGRATES (gain ~ the render's length), an event input THRESHOLDS (gain ~ 1 / the probability that matters), a cycle multiplies by
+// 1 / (1 - loop gain) or diverges.  A patch where a gain is unbounded in front of something the default mode cannot evaluate exactly
+// module by module is rendered in the exact flavour altogether.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "flatten.hpp"
+
+namespace srack {
+
+constexpr double kApproxBudget = 5e-6;     // sup of the first-order error bound allowed at any output channel, in the contract's units (|gpu - ref| / max(|ref|, 1))
+constexpr double kApproxHorizon = 2.88e7;  // samples the bound is derived for: ten minutes at 48 kHz (what integrates grows with the render's length)
+
+struct ApproxPlan {
+    // decisions, per module
+    std::vector<char> exact_blep;    // oscillator: f64 PolyBLEP (OSC_EXACT_BLEP)
+    std::vector<char> literal;       // filter: the literal ladder (VCF_LITERAL)
+    std::vector<char> sine_loose;    // oscillator: f32 sine (OSC_SINE_LOOSE)
+    std::vector<char> nonlin_loose;  // NonLinear: f32 power (NONLIN_LOOSE)
+    std::vector<char> saw_fixed;     // oscillator: phase in 2^-64 fixed point where the pitch is constant (OSC_FIXED_PHASE)
+    bool exact_patch = false;        // the whole patch in the exact flavour (SRACK_RENDER_EXACT_OSC)
+    std::string why;                 // what decided exact_patch ("" otherwise), for srack_render_info
+    // the analysis itself (tests, diagnostics)
+    std::vector<std::vector<double>> mag;    // [module][output port]: sup |value| on the wire (inf: unbounded)
+    std::vector<std::vector<double>> gain;   // [module][output port]: max over output channels of d(channel) / d(this wire) (inf: unbounded)
+    double bound = 0.0;                      // the first-order bound at the worst channel with the decisions above
+};
+
+// live / port_live: flatten.cpp steps 1 and 2 (which modules the output can hear, which of their ports anything reads).
+ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, const std::vector<uint32_t>& port_live,
+                               const std::vector<VoiceOverride>& overrides, bool exact_requested);
+
+// Does the wire SWEEP — an oscillator, a filter, noise, a sample player, a reverb somewhere upstream: a new value every sample — as opposed
+// to HOLD (a sequencer's notes, an envelope, constants, arithmetic on those)?  (OSC_CV_AUDIO_RATE, program.hpp)
+bool wire_sweeps(const Graph& g, int module);
+
+}  // namespace srack

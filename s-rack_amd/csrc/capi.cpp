@@ -562,6 +562,23 @@ int srack_render_reserve(srack_patch* p, uint32_t n_samples, int want_mix, uint3
     });
 }
 
+// Every SRACK_* variable of the environment that the library's tuning knobs read (tools/: chunk lengths, generator experiments ...): a host
+// process that carries one renders with other kernels than the ones measured and tested — srack_render_info says so (" knobs=[...]"),
+// and the parity suites refuse to run with any set (tests/conftest.py).  Not listed: where the kernel cache lives and how much it keeps.
+extern char** environ;
+static std::string tuning_knobs_note()
+{
+    std::string s;
+    for (char** e = environ; e && *e; e++) {
+        if (std::strncmp(*e, "SRACK_", 6) != 0) continue;
+        if (std::strncmp(*e, "SRACK_KERNEL_CACHE_", 19) == 0 || std::strncmp(*e, "SRACK_BENCH_", 12) == 0 || std::strncmp(*e, "SRACK_TEST_", 11) == 0) continue;
+        s += s.empty() ? " knobs=[" : " ";
+        s += *e;
+    }
+    if (!s.empty()) s += "]";
+    return s;
+}
+
 int srack_render_info(srack_patch* p, char* buf, size_t cap)
 {
     return guarded([&]() -> int {
@@ -569,6 +586,7 @@ int srack_render_info(srack_patch* p, char* buf, size_t cap)
         int rc = ensure_program(p->h, p->h.prog_valid ? p->h.prog_flags : 0u);
         if (rc != SRACK_OK) return rc;
         std::string s = p->h.prog.description;
+        s += tuning_knobs_note();
         const char* k = device_kernel_name(p->h);
         // (the kernel's name stays LAST: hosts and tests read it with split("kernel="))
         s += device_jit_note(p->h);

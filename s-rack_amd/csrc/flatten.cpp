@@ -6,10 +6,10 @@
 //   2. dead-port elimination: an oscillator / filter port nobody reads is not computed
 //      (the reference always computes all three, oscillator.rs:133-149; results on the read
 //      ports are unaffected).
-//  2b. default mode: an oscillator whose saw / square, a filter whose output can reach a pitch CV gets the
-//      exact PolyBLEP / the literal ladder — that module only (the phase accumulator behind the pitch would
-//      integrate its biased 1e-7); a filter inside a feedback loop gets the literal ladder too; a pitch
-//      input that sits on a loop, or a resonance of 0.9 or more, puts the whole patch into the exact flavour.
+//  2b. default mode: which of the cheaper forms (f32 PolyBLEP, contracted ladder, f32 sine / power, fixed-point phase)
+//      each module may take — approx.cpp: the forms' errors times the gain from their wires to the outputs, against
+//      half the contract; an unbounded gain (a loop that amplifies, a ladder near self-oscillation, a loop through an
+//      event or a pitch) behind something without an exact form of its own puts the whole patch into the exact flavour.
 //   3. uniform hoisting: a module whose fields carry no per-voice override and whose inputs all
 //      come from such modules produces the same samples for every voice.  That sub-graph becomes
 //      the CONTROL program, evaluated once (one voice) into control tracks; the VOICE program reads
@@ -30,8 +30,11 @@
 //      chain, the FM pair with a register or an HBM ring, the gate -> envelope control program).
 #include "flatten.hpp"
 
+#include "approx.hpp"
+
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -184,32 +187,6 @@ struct Builder {
         }
     }
 
-    // Does this wire SWEEP — an oscillator, a filter, noise, a sample player, a reverb somewhere upstream: a new value every sample — as
-    // opposed to HOLD (a sequencer's notes, an envelope's sustain, constants, arithmetic on those)?  A pitch CV that sweeps takes the
-    // polynomial 2^cv every sample (OSC_CV_AUDIO_RATE: its 1e-12 changes sign as the CV moves); one that holds recomputes the increment
-    // only when the value changed, with the reference's own 2^cv (modules.hip.h, osc_delta_cold: a held CV's polynomial error is a
-    // constant, i.e. a drift).  Feedback cycles run into the depth limit: sweeping.
-    bool sweeps(int module, int port, int depth) const
-    {
-        (void)port;
-        if (module < 0) return false;
-        if (depth > 12) return true;
-        const Module& m = g.modules[(size_t)module];
-        switch (m.type) {
-        case SRACK_MOD_ADSR:
-        case SRACK_MOD_GRID_SEQUENCER:
-        case SRACK_MOD_PATTERN_SEQUENCER: return false;
-        case SRACK_MOD_MATH:
-        case SRACK_MOD_MONO_MIXER:
-        case SRACK_MOD_VCA:
-        case SRACK_MOD_NONLINEAR:
-            for (const InputRef& in : m.in)
-                if (in.src >= 0 && sweeps(in.src, in.port, depth + 1)) return true;
-            return false;
-        default: return true;  // oscillator, filter, noise, sample player, reverb
-        }
-    }
-
     int build();
     void match_fused(bool has_rings);
 };
@@ -298,7 +275,7 @@ int Builder::build()
             if (connected(0)) op.flags |= OSC_HAS_CV;
             if (connected(1)) op.flags |= OSC_HAS_SYNC;
             if (connected(0) && stepwise(mod.in[0].src, mod.in[0].port, 0)) op.flags |= OSC_CV_STEPWISE;
-            if (connected(0) && sweeps(mod.in[0].src, mod.in[0].port, 0)) op.flags |= OSC_CV_AUDIO_RATE;
+            if (connected(0) && wire_sweeps(g, mod.in[0].src)) op.flags |= OSC_CV_AUDIO_RATE;
             if (field(m, SRACK_OSC_ANTIALIASING) != 0.0) op.flags |= OSC_AA;
             if (pl & 1u) op.flags |= OSC_OUT_SINE;
             if (pl & 2u) op.flags |= OSC_OUT_SQUARE;
@@ -306,8 +283,6 @@ int Builder::build()
             if (render_flags & SRACK_RENDER_EXACT_OSC) op.flags |= OSC_EXACT;
             if (A.sine_loose[(size_t)m]) op.flags |= OSC_SINE_LOOSE;
             if (A.exact_src[(size_t)m] && !(op.flags & OSC_EXACT)) op.flags |= OSC_EXACT_BLEP;
-            if (const char* e = getenv("SRACK_OSC_EXACT_MASK"))  // (tools/: the exact PolyBLEP for the oscillators whose module index is set in the mask)
-                if (!(op.flags & OSC_EXACT) && m < 64 && ((strtoull(e, nullptr, 0) >> m) & 1u)) op.flags |= OSC_EXACT_BLEP;
             op.sample_rate = (double)g.cfg.sample_rate;  // `self.sample_rate as f64`, u16 in the reference
             {   // pos: f64 state, two rows (lo, hi)
                 const VoiceOverride* o = find_override(m, SRACK_OSC_POS);
@@ -339,8 +314,6 @@ int Builder::build()
             if (pl & 2u) op.flags |= VCF_OUT_BP;
             if (pl & 4u) op.flags |= VCF_OUT_HP;
             if (A.exact_src[(size_t)m] && !(render_flags & SRACK_RENDER_EXACT_OSC)) op.flags |= VCF_LITERAL;
-            if (const char* e = getenv("SRACK_VCF_LITERAL_MASK"))  // (tools/: the literal ladder for the filters whose module index is set in the mask)
-                if (!(render_flags & SRACK_RENDER_EXACT_OSC) && m < 64 && ((strtoull(e, nullptr, 0) >> m) & 1u)) op.flags |= VCF_LITERAL;
             op.state_row = state_row_f32(m, SRACK_VCF_ST_F);
             state_row_f32(m, SRACK_VCF_ST_P);
             state_row_f32(m, SRACK_VCF_ST_Q);
@@ -854,10 +827,12 @@ void Builder::match_fused(bool has_rings)
         if (ok) out.fused = FUSED_VOICE_CHAIN;
     } else {
         ok = A.in_ctl[(size_t)src_of(vca->module, 1).src] && vca->in_slot[1] >= kTrackSlot;
-        if (ok) {
-            out.fused = FUSED_VOICE_CHAIN_TRACK;
-            // (default mode, saw port: the oscillator's phase is in 64-bit fixed point — OSC_FIXED_PHASE, set above for every kernel)
-        }
+        // render_voice_chain_track decides at COMPILE time that a default-mode saw keeps its phase in 64-bit fixed point: the shape is only
+        // this kernel's when the rows were converted above (OSC_FIXED_PHASE) — a saw that something integrates or thresholds, whose phase
+        // stays an f64, renders through the general path
+        const DevOp& osc = out.ops[(size_t)out.op_of_module[(size_t)src_of(vcf->module, 0).src]];
+        if (!(osc.flags & OSC_EXACT) && (osc.flags & OSC_OUT_SAW) && !(osc.flags & OSC_FIXED_PHASE)) ok = false;
+        if (ok) out.fused = FUSED_VOICE_CHAIN_TRACK;
     }
 }
 
@@ -992,452 +967,27 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
         render_flags &= ~kFlattenEvalAll;
     }
 
-    // ---- 2b. approximated ports that drive a pitch ----------------------------------------------------
-    // Default mode evaluates PolyBLEP in f32 and the ladder filter with fma contraction (~1e-7, slightly biased).  Harmless on
-    // the way to the output;
-    // but an oscillator's CV — and the sample player's — is INTEGRATED into a phase, so a biased 1e-7 on a saw or
-    // square that modulates a pitch grows with time (measured: 2e-4 on the carrier's saw after one second of
-    // feed-forward FM from a 1760 Hz saw).  Such patches are rendered with the exact oscillator throughout.  (The sine
-    // port is exempt: its default evaluation already carries the reference's own half-ulp error.)
+    // ---- 2b. which of the default mode's approximations this patch may take --------------------------------------------------------
+    // (approx.cpp: a first-order error bound per wire — epsilon of each cheaper form times the gain from its wire to every output channel,
+    // against half the contract; a patch with an unbounded gain behind something that has no exact form of its own goes exact altogether)
     {
-        // Which outputs carry an input's VALUE on (as opposed to its sign: gates, sync and step inputs are thresholds)?
-        auto carried_to = [&](int type, int in_port) -> uint32_t {  // mask of output ports
-            switch (type) {
-            case SRACK_MOD_OSCILLATOR: return in_port == SRACK_OSC_IN_CV ? 7u : 0u;
-            case SRACK_MOD_MOOG_FILTER: return 7u;
-            case SRACK_MOD_VCA:
-            case SRACK_MOD_MONO_MIXER:
-            case SRACK_MOD_MATH:
-            case SRACK_MOD_NONLINEAR: return 1u;
-            case SRACK_MOD_SAMPLE: return in_port == SRACK_SAMPLE_IN_CV ? 1u : 0u;
-            case SRACK_MOD_GRID_SEQUENCER: return in_port == SRACK_SEQ_IN_STEP ? 1u << SRACK_GRIDSEQ_OUT_GATE : 0u;  // gate = the clock itself
-            case SRACK_MOD_PATTERN_SEQUENCER: return in_port == SRACK_SEQ_IN_STEP ? 0xffu : 0u;
-            default: return 0u;  // ADSR: the gate is a threshold; OutputModule: a sink
-            }
-        };
-        auto is_pitch_input = [&](int module, int port) {
-            const int t = g.modules[(size_t)module].type;
-            return (t == SRACK_MOD_OSCILLATOR && port == SRACK_OSC_IN_CV) || (t == SRACK_MOD_SAMPLE && port == SRACK_SAMPLE_IN_CV);
-        };
-        // Inputs that only look at the SIGN of what they read: an ADSR's gate, an oscillator's sync, a sequencer's step and sync, the sample
-        // player's gate, and the VCA's CV (`cv > 0.0` opens it).  An error of 1e-7 does not pass through them — unless it flips the sign at a
-        // zero crossing, which moves an edge by a sample.
-        auto is_threshold_input = [&](int module, int port) {
-            switch (g.modules[(size_t)module].type) {
-            case SRACK_MOD_ADSR: return true;
-            case SRACK_MOD_OSCILLATOR: return port == SRACK_OSC_IN_SYNC;
-            case SRACK_MOD_GRID_SEQUENCER:
-            case SRACK_MOD_PATTERN_SEQUENCER: return true;
-            case SRACK_MOD_SAMPLE: return port == SRACK_SAMPLE_IN_GATE;
-            case SRACK_MOD_VCA: return port == SRACK_VCA_IN_CV;
-            default: return false;
-            }
-        };
-        // Which pitch inputs does a value that starts on the given output ports reach (port by port through the graph)?  -> per module: 1 if
-        // its pitch input is reached.  also_thresholds: inputs that take the value's sign count as well (any hit sets hit_any).
-        // influence_all: follow EVERY input to all of the module's outputs (a gate, a sync or a step input does not carry the value on, but
-        // it decides when things happen: enough to close a loop).
-        auto pitches_reached = [&](std::vector<uint32_t> tainted, bool also_thresholds, bool& hit_any, bool influence_all = false) {
-            std::vector<char> hit((size_t)n_mod, 0);
-            hit_any = false;
-            for (bool changed = true; changed;) {
-                changed = false;
-                for (int k = 0; k < n_mod; k++) {
-                    if (!A.live[(size_t)k]) continue;
-                    const Module& sink = g.modules[(size_t)k];
-                    for (int port = 0; port < sink.n_in; port++) {
-                        const InputRef& in = sink.in[(size_t)port];
-                        if (in.src < 0 || !(tainted[(size_t)in.src] & (1u << in.port))) continue;
-                        if (is_pitch_input(k, port)) hit[(size_t)k] = 1, hit_any = true;
-                        if (also_thresholds && is_threshold_input(k, port)) hit_any = true;
-                        const uint32_t add = (influence_all ? (sink.n_out >= 32 ? ~0u : (1u << sink.n_out) - 1u) : carried_to(sink.type, port)) & ~tainted[(size_t)k];
-                        if (add) {
-                            tainted[(size_t)k] |= add;
-                            changed = true;
-                        }
-                    }
-                }
-            }
-            return hit;
-        };
-        auto reaches_pitch = [&](const std::vector<uint32_t>& tainted, bool also_thresholds = false) {
-            bool any = false;
-            pitches_reached(tainted, also_thresholds, any);
-            return any;
-        };
-        // A filter's cutoff CV is its pitch: `freq + cv * amount` (clamped, filter.rs) sets the coefficient of all four stages, and behind a band- or highpass port
-        // (input minus a stage: a difference of nearly equal values) the producers' 1e-7 comes out 250 times larger (the soak's seed 10901:
-        // a saw through a highpass into a second filter's audio AND cutoff, 2.6e-5 in 1 voice-sample of 17 000; with every producer on the
-        // way to that cutoff exact 3e-6, the modulated filter itself approximated).  SRACK_LOOSE_CUTOFF=1: the rule off (tools/).
-        const bool cutoff_rule = !(getenv("SRACK_LOOSE_CUTOFF") && getenv("SRACK_LOOSE_CUTOFF")[0] == '1');
-        // per filter: 1 if a value that starts on the given output ports arrives at its input `in_port` (carried port by port, as above)
-        auto filters_reached = [&](std::vector<uint32_t> tainted, int in_port) {
-            std::vector<char> hit((size_t)n_mod, 0);
-            for (bool changed = true; changed;) {
-                changed = false;
-                for (int k = 0; k < n_mod; k++) {
-                    if (!A.live[(size_t)k]) continue;
-                    const Module& sink = g.modules[(size_t)k];
-                    for (int port = 0; port < sink.n_in; port++) {
-                        const InputRef& in = sink.in[(size_t)port];
-                        if (in.src < 0 || !(tainted[(size_t)in.src] & (1u << in.port))) continue;
-                        if (sink.type == SRACK_MOD_MOOG_FILTER && port == in_port) hit[(size_t)k] = 1;
-                        const uint32_t add = carried_to(sink.type, port) & ~tainted[(size_t)k];
-                        if (add) {
-                            tainted[(size_t)k] |= add;
-                            changed = true;
-                        }
-                    }
-                }
-            }
-            return hit;
-        };
-        // (... and the filter whose cutoff such a producer moves runs the literal ladder: a cutoff that jumps with a square's edges throws the
-        // ladder into transients where the contracted form's 1e-7 comes out at 2e-5 for a sample or two — seed 28336, bit-identical with it)
-        std::vector<char> moved_cutoff((size_t)n_mod, 0);
-        auto reaches_cutoff = [&](const std::vector<uint32_t>& tainted) {
-            if (!cutoff_rule) return false;
-            bool any = false;
-            const std::vector<char> hit = filters_reached(tainted, SRACK_VCF_IN_CV);
-            for (int k = 0; k < n_mod; k++)
-                if (hit[(size_t)k]) moved_cutoff[(size_t)k] = 1, any = true;
-            return any;
-        };
-        // ... and white noise on a cutoff (the noise family's soak, seeds 2127, 2203, 2360: up to 3.2e-4 in 0.2 % of the samples) moves the
-        // coefficient across its whole range from one sample to the next: such a filter does not forget a difference the way a filter with a
-        // steady cutoff does.  Literal ladder for it, exact PolyBLEP / literal ladder for what reaches its audio input: bit-identical
-        // on all three (either half alone: 1.2e-4 / 3.2e-4).
-        std::vector<char> noisy_cutoff((size_t)n_mod, 0);
-        if (cutoff_rule && !(render_flags & SRACK_RENDER_EXACT_OSC))
-            for (int m = 0; m < n_mod; m++)
-                if (A.live[(size_t)m] && g.modules[(size_t)m].type == SRACK_MOD_NOISE) {
-                    std::vector<uint32_t> from((size_t)n_mod, 0u);
-                    from[(size_t)m] = 1u;
-                    const std::vector<char> hit = filters_reached(from, SRACK_VCF_IN_CV);
-                    for (int k = 0; k < n_mod; k++) noisy_cutoff[(size_t)k] |= hit[(size_t)k];
-                }
-        auto reaches_noisy_filter = [&](const std::vector<uint32_t>& tainted) {
-            const std::vector<char> hit = filters_reached(tainted, SRACK_VCF_IN_AUDIO);
-            for (int k = 0; k < n_mod; k++)
-                if (hit[(size_t)k] && noisy_cutoff[(size_t)k]) return true;
-            return false;
-        };
-        // An oscillator's sine port that can reach neither a pitch nor a threshold may be evaluated in f32 in the default mode (modules.hip.h,
-        // sine_loose: 2e-7, where the f64 form is the correctly rounded sine and therefore has the reference's own zero crossings).
-        A.sine_loose.assign((size_t)n_mod, 0);
-        if (!(render_flags & SRACK_RENDER_EXACT_OSC))
-            for (int m = 0; m < n_mod; m++)
-                if (A.live[(size_t)m] && g.modules[(size_t)m].type == SRACK_MOD_OSCILLATOR && (A.port_live[(size_t)m] & 1u)) {
-                    std::vector<uint32_t> from((size_t)n_mod, 0u);
-                    from[(size_t)m] = 1u;
-                    A.sine_loose[(size_t)m] = !reaches_pitch(from, true);
-                }
-        // The same for a NonLinear module's power: through the f32 transcendental unit where nothing integrates the result (modules.hip.h, powf_pos)
-        A.nonlin_loose.assign((size_t)n_mod, 0);
-        if (!(render_flags & SRACK_RENDER_EXACT_OSC) && !getenv("SRACK_NONLIN_F64"))
-            for (int m = 0; m < n_mod; m++)
-                if (A.live[(size_t)m] && g.modules[(size_t)m].type == SRACK_MOD_NONLINEAR) {
-                    std::vector<uint32_t> from((size_t)n_mod, 0u);
-                    from[(size_t)m] = 1u;
-                    bool loose = !reaches_pitch(from, true);
-                    // ... nor may anything iterate or amplify its 4e-6: not on a feedback cycle (its own output coming back to one of its
-                    // inputs, through whatever), and not into another NonLinear's base, whose exponent multiplies a relative error
-                    if (loose) {
-                        std::vector<uint32_t> t2((size_t)n_mod, 0u);
-                        t2[(size_t)m] = 1u;
-                        for (bool changed = true; changed && loose;) {
-                            changed = false;
-                            for (int k = 0; k < n_mod && loose; k++) {
-                                if (!A.live[(size_t)k]) continue;
-                                const Module& sink = g.modules[(size_t)k];
-                                for (int port = 0; port < sink.n_in; port++) {
-                                    const InputRef& in = sink.in[(size_t)port];
-                                    if (in.src < 0 || !(t2[(size_t)in.src] & (1u << in.port))) continue;
-                                    if (k == m || (sink.type == SRACK_MOD_NONLINEAR && port == 0)) loose = false;
-                                    const uint32_t all = sink.n_out >= 32 ? ~0u : (1u << sink.n_out) - 1u;  // every input to all outputs: enough to close a loop
-                                    if (all & ~t2[(size_t)k]) {
-                                        t2[(size_t)k] |= all;
-                                        changed = true;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    A.nonlin_loose[(size_t)m] = loose;
-                }
-        // A saw whose value nobody integrates (a pitch input) or thresholds (a gate, a sync, a clock, a VCA's CV) may run its phase in 2^-64
-        // fixed point (modules.hip.h, FOsc): the two accumulators differ by 1e-14 after a second, far below f32 resolution at the output —
-        // but enough to move a zero crossing by a sample once in 1e10 crossings, which a threshold would turn into an event.
-        A.saw_fixed.assign((size_t)n_mod, 0);
-        if (!(render_flags & SRACK_RENDER_EXACT_OSC) && !(getenv("SRACK_NO_FIXED_SAW") && getenv("SRACK_NO_FIXED_SAW")[0] == '1'))
-            for (int m = 0; m < n_mod; m++)
-                if (A.live[(size_t)m] && g.modules[(size_t)m].type == SRACK_MOD_OSCILLATOR && (A.port_live[(size_t)m] & 7u) == 4u) {
-                    std::vector<uint32_t> from((size_t)n_mod, 0u);
-                    from[(size_t)m] = 4u;
-                    A.saw_fixed[(size_t)m] = !reaches_pitch(from, true);
-                }
-      A.exact_src.assign((size_t)n_mod, 0);
-      if (!(render_flags & SRACK_RENDER_EXACT_OSC)) {
-        // Module by module: an oscillator whose saw / square, a filter whose output can reach a pitch input gets the exact PolyBLEP / the
-        // literal ladder — that module only.  (Until round 2 one such module switched the whole patch to the exact flavour, whose 2^cv in
-        // double-double and library sine made e.g. a saw-LFO vibrato patch an order of magnitude slower than it has to be: what is
-        // integrated is the producer's biased 1e-7, not the consumer's 1e-12.)
-        bool loop_through_pitch = false;
-        for (int m = 0; m < n_mod; m++) {
-            if (!A.live[(size_t)m]) continue;
-            const int t = g.modules[(size_t)m].type;
-            const uint32_t ports = t == SRACK_MOD_OSCILLATOR ? (A.port_live[(size_t)m] & 6u) : t == SRACK_MOD_MOOG_FILTER ? (A.port_live[(size_t)m] & 7u) : 0u;
-            if (!ports) continue;
-            std::vector<uint32_t> from((size_t)n_mod, 0u);
-            from[(size_t)m] = ports;
-            bool any = false;
-            const std::vector<char> hit = pitches_reached(from, false, any);
-            const bool to_cutoff = reaches_cutoff(from);  // (marks the filters it reaches)
-            A.exact_src[(size_t)m] = any || to_cutoff || noisy_cutoff[(size_t)m] || reaches_noisy_filter(from);
-            // ... unless the pitch it reaches closes a LOOP: a module whose own output comes back to its pitch input iterates a map, and in
-            // such a loop the consumer's 1e-12 (the polynomial 2^cv against the reference's libm) can grow like anything else (random
-            // patches with saw / filter feedback into a pitch part from the oracle within a few hundred samples).  Only the exact flavour of
-            // the WHOLE patch — phases bit-identical to the reference's — follows the reference there, as before round 2.
-            for (int k = 0; k < n_mod && any; k++) {
-                if (!hit[(size_t)k]) continue;
-                std::vector<uint32_t> back((size_t)n_mod, 0u);
-                back[(size_t)k] = g.modules[(size_t)k].type == SRACK_MOD_OSCILLATOR ? 7u : 1u;
-                bool any2 = false;
-                if (pitches_reached(back, false, any2, true)[(size_t)k]) loop_through_pitch = true;
-            }
-        }
-        for (int m = 0; m < n_mod; m++)
-            if (moved_cutoff[(size_t)m] && A.live[(size_t)m]) A.exact_src[(size_t)m] = 1;
-        // ... and a producer whose approximated output reaches an EVENT input — an envelope's or the sample player's gate, an oscillator's
-        // sync, a sequencer's step or sync: `value > 0.0` decides when something happens, and a value 1e-7 off crosses zero a sample
-        // earlier or later once in a few million crossings: an edge, and everything behind it, moves by a sample (the soak's seed 2691: a
-        // bandpass into a gate, one voice of 131 a sample late).  Those producers get the exact PolyBLEP / the literal ladder as well.
-        // Exempt: an oscillator's SQUARE that arrives unchanged — wired straight to the input, or handed on by a sequencer's gate outputs:
-        // the usual gate and clock sources — whose default evaluation re-derives any value close to zero with the reference's own
-        // operations (modules.hip.h, square_sign_safe).
-        if (!(getenv("SRACK_LOOSE_EVENTS") && getenv("SRACK_LOOSE_EVENTS")[0] == '1'))
-            for (int m = 0; m < n_mod; m++) {
-                if (!A.live[(size_t)m] || A.exact_src[(size_t)m]) continue;
-                const int t = g.modules[(size_t)m].type;
-                const uint32_t ports = t == SRACK_MOD_OSCILLATOR ? (A.port_live[(size_t)m] & 6u) : t == SRACK_MOD_MOOG_FILTER ? (A.port_live[(size_t)m] & 7u) : 0u;
-                if (!ports) continue;
-                // Two kinds of taint: `pure` — the oscillator's square as it left the oscillator (or replaced by a constant level): straight
-                // wires, and a sequencer's gate outputs, which hand their step input on unchanged where the cell is on (sequencer.rs:190-246) —
-                // and `mixed`: the value after any arithmetic, a filter, another oscillator's CV ..., and a saw from the start.
-                std::vector<uint32_t> pure((size_t)n_mod, 0u), mixed((size_t)n_mod, 0u);
-                if (t == SRACK_MOD_OSCILLATOR) {
-                    pure[(size_t)m] = ports & (1u << SRACK_OSC_OUT_SQUARE);
-                    mixed[(size_t)m] = ports & ~(1u << SRACK_OSC_OUT_SQUARE);
-                } else {
-                    mixed[(size_t)m] = ports;
-                }
-                for (bool changed = true; changed;) {  // where the value is carried to
-                    changed = false;
-                    for (int k = 0; k < n_mod; k++) {
-                        if (!A.live[(size_t)k]) continue;
-                        const Module& sink = g.modules[(size_t)k];
-                        const bool seq = sink.type == SRACK_MOD_GRID_SEQUENCER || sink.type == SRACK_MOD_PATTERN_SEQUENCER;
-                        for (int port = 0; port < sink.n_in; port++) {
-                            const InputRef& in = sink.in[(size_t)port];
-                            if (in.src < 0) continue;
-                            const bool from_pure = (pure[(size_t)in.src] >> in.port) & 1u, from_mixed = (mixed[(size_t)in.src] >> in.port) & 1u;
-                            if (!from_pure && !from_mixed) continue;
-                            const uint32_t carried = carried_to(sink.type, port);
-                            std::vector<uint32_t>& into = (from_mixed || !seq) ? mixed : pure;
-                            if (carried & ~into[(size_t)k]) {
-                                into[(size_t)k] |= carried;
-                                changed = true;
-                            }
-                        }
-                    }
-                }
-                for (int k = 0; k < n_mod && !A.exact_src[(size_t)m]; k++) {
-                    if (!A.live[(size_t)k]) continue;
-                    const Module& sink = g.modules[(size_t)k];
-                    for (int port = 0; port < sink.n_in; port++) {
-                        const InputRef& in = sink.in[(size_t)port];
-                        if (in.src < 0 || !((mixed[(size_t)in.src] >> in.port) & 1u)) continue;
-                        const bool event = sink.type == SRACK_MOD_ADSR || (sink.type == SRACK_MOD_OSCILLATOR && port == SRACK_OSC_IN_SYNC) ||
-                                           sink.type == SRACK_MOD_GRID_SEQUENCER || sink.type == SRACK_MOD_PATTERN_SEQUENCER ||
-                                           (sink.type == SRACK_MOD_SAMPLE && port == SRACK_SAMPLE_IN_GATE);
-                        if (event) A.exact_src[(size_t)m] = 1;
-                    }
-                }
-            }
-        // A filter inside ANY feedback loop iterates its own rounding too: the fma-contracted ladder stays within 1e-5 of the reference while
-        // its differences die out (a damped recurrence, section 2 of NOTES.md), not when a loop feeds them back in — through a mixer into
-        // its own input, or through a gate that restarts a sample player (random patches of that kind left the band after a few thousand
-        // samples).  Such a filter runs the literal ladder.
-        for (int m = 0; m < n_mod; m++) {
-            if (!A.live[(size_t)m] || g.modules[(size_t)m].type != SRACK_MOD_MOOG_FILTER || A.exact_src[(size_t)m]) continue;
-            std::vector<char> seen((size_t)n_mod, 0);
-            std::vector<int> stack{m};
-            bool back = false;
-            while (!stack.empty() && !back) {
-                const int k = stack.back();
-                stack.pop_back();
-                for (int j = 0; j < n_mod && !back; j++) {  // every module j that reads k
-                    if (!A.live[(size_t)j]) continue;
-                    bool reads = false;
-                    for (const InputRef& in : g.modules[(size_t)j].in) reads = reads || in.src == k;
-                    if (!reads) continue;
-                    if (j == m) back = true;
-                    if (!seen[(size_t)j]) {
-                        seen[(size_t)j] = 1;
-                        stack.push_back(j);
-                    }
-                }
-            }
-            if (back) A.exact_src[(size_t)m] = 1;
-        }
-        // Two more ways for a loop to iterate a 1e-7 (round 4; the fuzzer's seeds 725 and 1459; SRACK_LOOSE_LOOPS=1 restores the older rules):
-        //  * a cycle through an EVENT input — an oscillator's sync (oscillator.rs:125-131), an envelope's or the sample player's gate, a
-        //    sequencer's step or sync: a value that differs in its last bits crosses the threshold a sample earlier or later, the event
-        //    moves, and the loop feeds the moved event back into what produced it: the renders part for good;
-        //  * a cycle that can AMPLIFY — a mixer whose gains on the cycle add up to more than 1, a multiplication by more
-        //    than 1 or by another signal, a sum of two signals of the cycle, a VCA that is not driven by an envelope, a band- or highpass
-        //    port (|3 (b3 - b4)| reaches 6), anything that is not plain arithmetic: whatever approximation enters the cycle (an f32 PolyBLEP
-        //    on a cutoff's CV, a phase whose increment came from the polynomial 2^cv ...) is amplified sample after sample.
-        // Both get the exact flavour of the whole patch, as a loop through a pitch does.
-        bool loop_needs_exact = false;
-        if (!(getenv("SRACK_LOOSE_LOOPS") && getenv("SRACK_LOOSE_LOOPS")[0] == '1')) {
-            auto reads = [&](int j, int k) {  // module j reads module k
-                for (const InputRef& in : g.modules[(size_t)j].in)
-                    if (in.src == k) return true;
-                return false;
-            };
-            auto reach = [&](int from, bool forward) {  // modules reachable from `from` along (forward) or against the wires, `from` itself only through a cycle
-                std::vector<char> seen((size_t)n_mod, 0);
-                std::vector<int> stack{from};
-                while (!stack.empty()) {
-                    const int k = stack.back();
-                    stack.pop_back();
-                    for (int j = 0; j < n_mod; j++) {
-                        if (!A.live[(size_t)j] || seen[(size_t)j]) continue;
-                        if (forward ? reads(j, k) : reads(k, j)) {
-                            seen[(size_t)j] = 1;
-                            stack.push_back(j);
-                        }
-                    }
-                }
-                return seen;
-            };
-            auto is_event_input = [&](int module, int port) {
-                switch (g.modules[(size_t)module].type) {
-                case SRACK_MOD_ADSR: return true;
-                case SRACK_MOD_OSCILLATOR: return port == SRACK_OSC_IN_SYNC;
-                case SRACK_MOD_GRID_SEQUENCER:
-                case SRACK_MOD_PATTERN_SEQUENCER: return true;
-                case SRACK_MOD_SAMPLE: return port == SRACK_SAMPLE_IN_GATE;
-                default: return false;
-                }
-            };
-            auto max_abs_field = [&](int module, int field) {
-                double v = std::fabs(g.modules[(size_t)module].fields[(size_t)field]);
-                for (const auto& o : overrides)
-                    if (o.module == module && o.field == field)
-                        for (double x : o.values) v = std::max(v, std::fabs(x));
-                return v;
-            };
-            for (int m = 0; m < n_mod && !loop_needs_exact; m++) {
-                if (!A.live[(size_t)m]) continue;
-                const std::vector<char> down = reach(m, true);
-                if (!down[(size_t)m]) continue;  // not on a cycle
-                const std::vector<char> up = reach(m, false);
-                auto on_cycle = [&](int k) { return down[(size_t)k] && up[(size_t)k]; };  // m's strongly connected component
-                const Module& mod = g.modules[(size_t)m];
-                for (int port = 0; port < mod.n_in && !loop_needs_exact; port++)
-                    if (mod.in[(size_t)port].src >= 0 && on_cycle(mod.in[(size_t)port].src) && is_event_input(m, port)) loop_needs_exact = true;
-                if (loop_needs_exact) continue;  // (every cycle is looked at, with or without a filter: the soak's seed 4386 is two mixers feeding each other with gains above 1)
-                for (int k = 0; k < n_mod && !loop_needs_exact; k++) {
-                    if (!A.live[(size_t)k] || !on_cycle(k)) continue;
-                    const Module& c = g.modules[(size_t)k];
-                    int n_cyc_in = 0;
-                    for (int port = 0; port < c.n_in; port++) {
-                        const InputRef& in = c.in[(size_t)port];
-                        if (in.src < 0 || !on_cycle(in.src)) continue;
-                        n_cyc_in++;
-                        if (g.modules[(size_t)in.src].type == SRACK_MOD_MOOG_FILTER && in.port != SRACK_VCF_OUT_LOWPASS) loop_needs_exact = true;
-                    }
-                    switch (c.type) {
-                    case SRACK_MOD_MOOG_FILTER:
-                        // a ladder on a cycle: its own feedback q·b4 and the cycle's add up — a lowpass through a subtraction back into its input
-                        // (gain -1) raises the effective resonance by one unit of q, past self-oscillation from res ~0.8 — and what the
-                        // clamps then bound is chaotic: ANY approximation that enters the cycle (an f32 PolyBLEP saw on the filter's input:
-                        // the soak's seed 40214, 6e-3 at 200 voices x 6000 samples) grows.  The literal ladder alone is not enough.
-                        loop_needs_exact = true;
-                        break;
-                    case SRACK_MOD_OSCILLATOR: break;  // on the cycle through its pitch CV (a sync input was an event, above): FM feedback — what its saw /
-                                                       // square carry around is the loop-through-a-pitch rule's, its sine is the reference's own to half an ulp
-                    case SRACK_MOD_MONO_MIXER: {
-                        double sum = 0.0;
-                        for (int port = 0; port < c.n_in; port++)
-                            if (c.in[(size_t)port].src >= 0 && on_cycle(c.in[(size_t)port].src)) sum += max_abs_field(k, SRACK_MIX_GAIN0 + port);
-                        if (sum > 1.0) loop_needs_exact = true;
-                        break;
-                    }
-                    case SRACK_MOD_MATH: {
-                        const int opn = (int)c.fields[SRACK_MATH_OPERATION];
-                        if (opn == SRACK_MATH_MULTIPLY) {
-                            if (c.in[1].src >= 0 || max_abs_field(k, SRACK_MATH_CONSTANT) > 1.0) loop_needs_exact = true;
-                        } else if (n_cyc_in > 1) {
-                            loop_needs_exact = true;
-                        }
-                        break;
-                    }
-                    case SRACK_MOD_VCA: {
-                        const InputRef& cv = c.in[SRACK_VCA_IN_CV];
-                        const bool env = cv.src >= 0 && g.modules[(size_t)cv.src].type == SRACK_MOD_ADSR && max_abs_field(cv.src, SRACK_ADSR_S_VAL) <= 1.0 && !on_cycle(cv.src);
-                        if (!env) loop_needs_exact = true;
-                        break;
-                    }
-                    default: loop_needs_exact = true; break;
-                    }
-                }
-            }
-            // ... and a cycle that does not amplify still REMEMBERS: Add <-> Subtract around a delayed edge has gain exactly 1 — an integrator —
-            // and sums up the 1e-7 of whatever feeds it, one way, for as long as the render lasts (the soak's seed 40913 at 200 voices x 6000
-            // samples: a contracted highpass into such a pair, 8.5e-5).  An approximated producer that reaches a module on ANY cycle gets the
-            // exact PolyBLEP / the literal ladder, like one that reaches a pitch (sines are not approximated producers: config 4 keeps its forms).
-            if (!loop_needs_exact) {
-                std::vector<char> cyc((size_t)n_mod, 0);
-                for (int k = 0; k < n_mod; k++)
-                    if (A.live[(size_t)k]) cyc[(size_t)k] = reach(k, true)[(size_t)k];
-                for (int m = 0; m < n_mod; m++) {
-                    if (!A.live[(size_t)m] || A.exact_src[(size_t)m]) continue;
-                    const int t = g.modules[(size_t)m].type;
-                    const uint32_t ports = t == SRACK_MOD_OSCILLATOR ? (A.port_live[(size_t)m] & 6u) : t == SRACK_MOD_MOOG_FILTER ? (A.port_live[(size_t)m] & 7u) : 0u;
-                    if (!ports) continue;
-                    const std::vector<char> down = reach(m, true);
-                    for (int k = 0; k < n_mod; k++)
-                        if (down[(size_t)k] && cyc[(size_t)k]) A.exact_src[(size_t)m] = 1;
-                }
-            }
-        }
-        if (loop_through_pitch || loop_needs_exact) {
+        const ApproxPlan plan = plan_approximations(g, A.live, A.port_live, overrides, (render_flags & SRACK_RENDER_EXACT_OSC) != 0);
+        A.sine_loose = plan.sine_loose;
+        A.nonlin_loose = plan.nonlin_loose;
+        A.saw_fixed = plan.saw_fixed;
+        A.exact_src.assign((size_t)n_mod, 0);
+        for (int m = 0; m < n_mod; m++) A.exact_src[(size_t)m] = plan.exact_blep[(size_t)m] || plan.literal[(size_t)m];
+        if (plan.exact_patch && !(render_flags & SRACK_RENDER_EXACT_OSC) && (render_flags & SRACK_RENDER_KEEP_DEFAULT)) {
+            out.approx_note = "kept default: " + plan.why;
+        } else if (plan.exact_patch && !(render_flags & SRACK_RENDER_EXACT_OSC)) {
             render_flags |= SRACK_RENDER_EXACT_OSC;
             std::fill(A.sine_loose.begin(), A.sine_loose.end(), 0);  // (the exact oscillator has one sine)
+            out.approx_note = "exact: " + plan.why;
+        } else if (!(render_flags & SRACK_RENDER_EXACT_OSC)) {
+            char buf[64];
+            snprintf(buf, sizeof buf, "bound %.1e", plan.bound);
+            out.approx_note = buf;
         }
-        if (getenv("SRACK_TAINT_GLOBAL")) {  // (tools/: the pre-round-2 rule — one such module switches the whole patch to the exact flavour)
-            for (int m = 0; m < n_mod; m++)
-                if (A.exact_src[(size_t)m]) render_flags |= SRACK_RENDER_EXACT_OSC;
-        }
-        // The other amplifier of a 1e-7: a ladder filter close to self-oscillation.  Its feedback gain q grows with the resonance, and
-        // from ~0.93 up (tools/shape_soak.py: 7 of 150 random P1 parameter sets, all with res >= 0.928, a few voices each, up to 3e-3)
-        // the fma-contracted ladder of the default mode leaves the 1e-5 band although every stage is closer to the real-number
-        // result than the reference's.  Such a patch gets the literal ladder, i.e. the exact flavour of the kernels.
-        for (int m = 0; m < n_mod && !(render_flags & SRACK_RENDER_EXACT_OSC); m++) {
-            if (!A.live[(size_t)m] || g.modules[(size_t)m].type != SRACK_MOD_MOOG_FILTER) continue;
-            double res = g.modules[(size_t)m].fields[SRACK_VCF_RES];
-            for (const auto& o : overrides)
-                if (o.module == m && o.field == SRACK_VCF_RES)
-                    for (double v : o.values) res = std::max(res, v);
-            if (res >= 0.9) {
-                render_flags |= SRACK_RENDER_EXACT_OSC;
-                std::fill(A.sine_loose.begin(), A.sine_loose.end(), 0);
-            }
-        }
-      }
     }
     out.effective_flags = render_flags;
 
@@ -1620,6 +1170,7 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
     for (const FlatProgram& c : out.ctl) d << " + " << c.description;
     if (out.n_tracks > 0) d << " tracks=" << out.n_tracks;
     d << " B=" << g.cfg.buffer_size;
+    if (!out.approx_note.empty()) d << " approx[" << out.approx_note << "]";
     out.description = d.str();
     return SRACK_OK;
 }

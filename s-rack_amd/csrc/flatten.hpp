@@ -68,6 +68,7 @@ struct FlatPair {
     std::vector<int> ctl_lag;   // per unit: dependency depth = how many chunks it trails
     int n_tracks = 0;           // rows of the track buffer
     uint32_t effective_flags = 0;  // the render flags the programs were built for (the request, plus what flatten had to add)
+    std::string approx_note;       // default mode: the first-order error bound of the forms taken (approx.cpp), or why the patch went exact
     std::vector<char> in_ctl;   // per module: evaluated by the control program
     std::vector<int> ctl_stage; // per module: its unit, -1 if not in the control program
     std::string description;

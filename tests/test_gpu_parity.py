@@ -211,7 +211,7 @@ def test_p2_feedback_vs_oracle(S, oracle, B, flags):
 @pytest.mark.parametrize("flags", [0, 1, 2])
 @pytest.mark.parametrize("B", [1, 64, 1024])
 def test_fm_pair_sample_loops(S, oracle, B, flags, monkeypatch):
-    """(Under SRACK_LOOSE_LOOPS=1: since round 4 the flattener gives a patch whose feedback loop can AMPLIFY — here feedback gains
+    """(With SRACK_RENDER_KEEP_DEFAULT: since round 4 the flattener gives a patch whose feedback loop can AMPLIFY — here feedback gains
     above 1 — the exact flavour, see test_fm_feedback_gain_above_one_takes_the_exact_flavour; this test keeps the default-mode kernels'
     per-wave classes covered with the draw that reaches all of them.)
     The fused FM kernels choose their sample loop per wave from what the wave can prove about its 64 voices (default mode): both
@@ -220,7 +220,7 @@ def test_fm_pair_sample_loops(S, oracle, B, flags, monkeypatch):
     well-behaved neighbours, which take the literal forms with it.  One wave of each, plus a modulator `val` that moves a wave from
     one class to the next; every voice against the oracle."""
     # (buffer_size 1024: the time-parallel pair takes calls of 4096 samples and more — shorter ones keep the ring kernel, see below)
-    monkeypatch.setenv("SRACK_LOOSE_LOOPS", "1")
+    flags |= S.RENDER_KEEP_DEFAULT
     T, W, cut = (9000, 64, 4501) if B == 1024 else (2500, 64, 1001)
     rng = np.random.default_rng(11)
     beta = np.concatenate([rng.uniform(0.05, 0.45, W), rng.uniform(0.1, 0.4, W), rng.uniform(0.6, 1.8, W), rng.uniform(0.1, 0.4, W),

@@ -393,7 +393,8 @@ def test_specialised_kernel_source_of_p1_and_p3(S):
     # parameter VALUES are not part of the kernel: an edit does not ask for another compilation
     p.set_field(ids["vcf"], S.VCF_RES, 0.7)
     p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut[::-1].copy())
-    assert p.kernel_source(S.RENDER_NO_FUSION) == src
+    body = lambda text: text.split("\n", 1)[1]   # (the first line names the program, with the error bound of its parameter values: a comment for the reader)
+    assert body(p.kernel_source(S.RENDER_NO_FUSION)) == body(src)
     q = S.Patch(48000, 1024, 2)
     qi = S.build_p3(q)
     q.configure_voices(70)
@@ -757,12 +758,14 @@ def test_exp2_fast10_coefficients_in_the_header():
 
 
 def test_cycle_rules_of_the_flattener(S):
-    """flatten.cpp 2b, the cycles: a filter ON a cycle turns the whole patch exact (effective flags); an approximated producer that merely FEEDS
-    a cycle — here an Add <-> Subtract pair, an integrator — keeps the patch in the default flavour and gets the exact PolyBLEP itself; the
-    same saw into no cycle keeps the fast form."""
+    """approx.cpp, the cycles: an approximated producer that FEEDS a cycle whose loop gain is one or more — an Add <-> Subtract pair, an
+    integrator; the same pair with a ladder in it — gets the exact PolyBLEP itself (its epsilon times an unbounded gain), the ladder on the cycle
+    the literal form, and as a constant-pitch saw has an exact form of its own the patch stays in the default flavour; the same cycle behind an
+    oscillator whose PITCH moves (2^cv by polynomial: no exact form of its own) turns the whole patch exact; the same saw into no cycle keeps
+    the fast form."""
     import re
 
-    def source(wire_cycle, filter_on_cycle):
+    def source(wire_cycle, filter_on_cycle, vibrato=False):
         p = S.Patch(48000, 16, 2)
         osc, add, sub, out = p.add_module(S.MOD_OSCILLATOR), p.add_module(S.MOD_MATH), p.add_module(S.MOD_MATH), p.add_module(S.MOD_OUTPUT)
         p.set_field(add, S.MATH_OPERATION, S.MATH_ADD)
@@ -770,6 +773,9 @@ def test_cycle_rules_of_the_flattener(S):
         p.connect(osc, S.OSC_OUT_SAW, add, 1)
         p.connect(add, 0, sub, 0)
         p.connect(add, 0, out, 0)
+        if vibrato:
+            lfo = p.add_module(S.MOD_OSCILLATOR)
+            p.connect(lfo, S.OSC_OUT_SINE, osc, 0)
         if wire_cycle:
             if filter_on_cycle:
                 vcf = p.add_module(S.MOD_MOOG_FILTER)
@@ -783,9 +789,11 @@ def test_cycle_rules_of_the_flattener(S):
     EXACT, EXACT_BLEP = 1 << 6, 1 << 13   # program.hpp: OSC_EXACT, OSC_EXACT_BLEP
     flags_of = lambda src: [int(x, 16) for x in re.findall(r"osc_step\(\(?(0x[0-9a-f]+)u", src)]
     plain = source(False, False)
-    assert "fosc_saw" in plain and not flags_of(plain)
+    assert "fosc_saw" in plain and not flags_of(plain) and "approx[bound" in plain
     fed = source(True, False)
     assert "fosc_saw" not in fed and [f & (EXACT | EXACT_BLEP) for f in flags_of(fed)] == [EXACT_BLEP]
     ladder = source(True, True)
-    assert "vcf_run<true>" not in ladder and "fosc_saw" not in ladder
-    assert "xsaw_" in ladder or any(f & EXACT for f in flags_of(ladder))   # the exact flavour's saw (tile-wise, or the literal form)
+    assert "vcf_run<true>" not in ladder and "fosc_saw" not in ladder and [f & (EXACT | EXACT_BLEP) for f in flags_of(ladder)] == [EXACT_BLEP]
+    moving = source(True, False, vibrato=True)
+    assert "approx[exact: unbounded gain" in moving and "fosc_saw" not in moving
+    assert all(f & EXACT for f in flags_of(moving)) and flags_of(moving)   # every oscillator in the exact flavour
