@@ -12,10 +12,10 @@
 // Where the numbers come from.  Epsilons: f32 PolyBLEP / sine — two roundings at values in [1, 2): 2.4e-7.  The contracted ladder —
 // tools/ladder_calib.c emulates both forms on the CPU (filter.rs:58-92 against modules.hip.h vcf_step<true>): over resonance 0 ... 0.89,
 // cutoff 0.02 ... 0.9, saw inputs and still / ramped / sine-swept cutoffs the difference stays below 1.3e-6 (lowpass), 3.9e-6 (bandpass),
-// 3.1e-6 (highpass) whatever the L1 norm (the roundings are not aligned with the impulse response); a cutoff that JUMPS at audio rate (a
+// 3.3e-6 (highpass) whatever the L1 norm (the roundings are not aligned with the impulse response); a cutoff that JUMPS at audio rate (a
 // square, noise on the CV) breaks that: 5e-5 and worse — such a filter has no contracted form.  Gains: the L1 norms are computed here, per
 // filter, from its coefficients (resonance 0.5: 1.1 ... 3.2; 0.89: up to 47 at cutoff 0.2; from ~0.9 the linear ladder does not decay at
-// mid cutoffs: unbounded); the sensitivity to the cutoff is measured at 1.4 / cutoff times the port's L1 norm (same tool).
+// mid cutoffs: unbounded); the sensitivity to the cutoff is measured at up to 2.7 / cutoff times the port's L1 norm (same tool: 3.0 here).
 // What is NOT bounded here: the default forms' own last-bit differences from the reference's libm (polynomial 2^cv at 3e-16, 1e-12 inside
 // the proved FM loops; the f64 sine at one rounding) — zero-mean, measured over minutes instead (profiles/r05_horizon.json); they only
 // decide anything where a gain is unbounded.
@@ -38,7 +38,7 @@ constexpr double kEpsBlep = 2.4e-7;         // f32 PolyBLEP against the f64 one
 constexpr double kEpsSine = 2.4e-7;         // f32 sine after the exact f64 fold
 constexpr double kEpsFixed = 3.2e-12;       // 2^-64 fixed-point phase: kApproxHorizon steps x 2^-64 = 1.6e-12 of phase, saw slope 2
 constexpr double kEpsNonlin = 4e-6;         // v_log_f32 / v_exp_f32 power, relative to max(|out|, 1)
-constexpr double kEpsLadder[3] = {1.5e-6, 4.0e-6, 3.2e-6};  // contracted ladder, lowpass / bandpass / highpass (tools/ladder_calib.c)
+constexpr double kEpsLadder[3] = {1.5e-6, 4.2e-6, 3.6e-6};  // contracted ladder, lowpass / bandpass / highpass (tools/ladder_calib.c)
 constexpr double kLadderRareJumps = 2.0;    // ... with a cutoff that jumps now and then (an envelope's attack, a sequencer's step): same tool, 7e-6 on the bandpass
 constexpr double kLadderL1Max = 64.0;       // beyond this lowpass L1 norm the ladder is treated as self-oscillating (the calibration stops at 47)
 constexpr double kNonlinSteep = 1e4;        // d|a|^b / da near a = 0 for b < 1: (2.4e-7)^0.5 / 2.4e-7 = 2e3
@@ -401,7 +401,7 @@ struct Analysis {
             if (!L.stable) L.l1[0] = L.l1[1] = L.l1[2] = kInf;
             const double audio = std::max(1.0, in_mag(m, SRACK_VCF_IN_AUDIO));
             for (int p = 0; p < 3; p++)
-                L.cutoff[p] = !has_cv ? 0.0 : !L.stable ? kInf : 1.5 / std::max(lo, 0.01) * L.l1[p] * amount.abs_max() * audio;  // tools/ladder_calib.c: 1.4 / cutoff x L1
+                L.cutoff[p] = !has_cv ? 0.0 : !L.stable ? kInf : 3.0 / std::max(lo, 0.01) * L.l1[p] * amount.abs_max() * audio;  // tools/ladder_calib.c l1: at most 2.7 / cutoff x L1
         }
     }
 
@@ -584,8 +584,8 @@ struct Analysis {
             if (is_event_input(r.k, r.i)) {
                 if (same_cycle(m, r.k)) return kInf;
                 if (seq && r.i == SRACK_SEQ_IN_STEP && depth < 4) {
-                    const int first = type(r.k) == SRACK_MOD_GRID_SEQUENCER ? SRACK_GRIDSEQ_OUT_GATE : SRACK_PATSEQ_OUT_GATE0;
-                    const int last = type(r.k) == SRACK_MOD_GRID_SEQUENCER ? SRACK_GRIDSEQ_OUT_GATE : SRACK_PATSEQ_OUT_GATE0 + 7;
+                    const int first = type(r.k) == SRACK_MOD_GRID_SEQUENCER ? (int)SRACK_GRIDSEQ_OUT_GATE : (int)SRACK_PATSEQ_OUT_GATE0;
+                    const int last = type(r.k) == SRACK_MOD_GRID_SEQUENCER ? (int)SRACK_GRIDSEQ_OUT_GATE : (int)SRACK_PATSEQ_OUT_GATE0 + 7;
                     for (int o = first; o <= last; o++)
                         if (port_is_live(r.k, o)) s += pure_square_gain(G, r.k, o, c, depth + 1);
                 }
@@ -602,6 +602,31 @@ struct Analysis {
 };
 
 }  // namespace
+
+int audible(const Graph& g, std::vector<char>& live, std::vector<uint32_t>& port_live, int* self_loop)
+{
+    const int n_mod = (int)g.modules.size();
+    live.assign((size_t)n_mod, 0);
+    port_live.assign((size_t)n_mod, 0);
+    if (g.plan.output < 0) return 0;
+    std::vector<int> stack{g.plan.output};
+    while (!stack.empty()) {
+        const int m = stack.back();
+        stack.pop_back();
+        if (live[(size_t)m]) continue;
+        live[(size_t)m] = 1;
+        for (const InputRef& in : g.modules[(size_t)m].in)
+            if (in.src >= 0) {
+                if (in.src == m) {
+                    if (self_loop) *self_loop = m;
+                    return -1;
+                }
+                port_live[(size_t)in.src] |= 1u << in.port;
+                stack.push_back(in.src);
+            }
+    }
+    return 0;
+}
 
 bool wire_sweeps(const Graph& g, int module)
 {

@@ -36,6 +36,10 @@ struct ApproxPlan {
     double bound = 0.0;                      // the first-order bound at the worst channel with the decisions above
 };
 
+// flatten.cpp steps 1 and 2: the modules the plan's OutputModule can hear and which of their output ports anything reads.  Returns -1 and
+// the module's index in `self_loop` for a module wired to itself (the reference deadlocks on it, synth.rs:99,251), else 0.
+int audible(const Graph& g, std::vector<char>& live, std::vector<uint32_t>& port_live, int* self_loop);
+
 // live / port_live: flatten.cpp steps 1 and 2 (which modules the output can hear, which of their ports anything reads).
 ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, const std::vector<uint32_t>& port_live,
                                const std::vector<VoiceOverride>& overrides, bool exact_requested);

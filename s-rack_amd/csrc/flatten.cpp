@@ -933,21 +933,10 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
 
     // ---- 1. reachability from the output, 2. live ports -------------------------------------------
     {
-        std::vector<int> stack{output};
-        while (!stack.empty()) {
-            int m = stack.back();
-            stack.pop_back();
-            if (A.live[(size_t)m]) continue;
-            A.live[(size_t)m] = 1;
-            for (const InputRef& in : g.modules[(size_t)m].in)
-                if (in.src >= 0) {
-                    if (in.src == m) {
-                        set_error("module " + std::to_string(m) + " is wired to itself: the reference deadlocks on this (synth.rs:99,251)");
-                        return SRACK_ERR_SELF_LOOP;
-                    }
-                    A.port_live[(size_t)in.src] |= 1u << in.port;
-                    stack.push_back(in.src);
-                }
+        int self_loop = -1;
+        if (audible(g, A.live, A.port_live, &self_loop) != 0) {
+            set_error("module " + std::to_string(self_loop) + " is wired to itself: the reference deadlocks on this (synth.rs:99,251)");
+            return SRACK_ERR_SELF_LOOP;
         }
     }
 

@@ -1,0 +1,393 @@
+"""csrc/approx.cpp on its own (CPU only): the default mode's approximations as an error budget — one case per structure the bound has to
+get right (what were soak-derived rules in flatten.cpp 2b until round 5, each named after the fuzz seed that had found it), the numbers it
+rests on against tools/ladder_calib.c's emulation of the two ladders, and the benchmarked workloads (none may lose a fast form).
+The analysis is compiled by g++ without HIP (tests/cpp/approx_probe.cpp + csrc/graph.cpp + csrc/approx.cpp) and fed patches on stdin."""
+import json
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import srack_pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W = srack_pkg.load_workloads()
+CSRC = os.path.join(ROOT, "s-rack_amd", "csrc")
+BUDGET, HORIZON, EVENT = 5e-6, 2.88e7, 1e9   # approx.hpp / approx.cpp
+
+
+def _build(binary, sources, extra=()):
+    if not os.path.exists(binary) or os.path.getmtime(binary) < max(os.path.getmtime(s) for s in sources):
+        tmp = f"{binary}.{os.getpid()}.tmp"   # (pytest-xdist workers build side by side: each into its own file, then an atomic rename)
+        subprocess.run(["g++" if sources[0].endswith("pp") else "gcc", "-O1", "-o", tmp] + list(extra) + [s for s in sources if not s.endswith(".hpp") and not s.endswith(".h")] + ["-lm"], check=True)
+        os.replace(tmp, binary)
+    return binary
+
+
+@pytest.fixture(scope="module")
+def probe():
+    srcs = [os.path.join(ROOT, "tests", "cpp", "approx_probe.cpp"), os.path.join(CSRC, "graph.cpp"), os.path.join(CSRC, "approx.cpp"),
+            os.path.join(CSRC, "approx.hpp"), os.path.join(CSRC, "graph.hpp"), os.path.join(CSRC, "flatten.hpp"), os.path.join(ROOT, "include", "srack_hip.h")]
+    return _build(os.path.join(ROOT, "tests", "cpp", "approx_probe"), srcs, ["-std=c++17", "-Wall"])
+
+
+class Rec:
+    """The graph API of Patch / OraclePatch, recorded as the probe's input lines."""
+
+    def __init__(self, sample_rate=48000, buffer_size=1024, channels=2):
+        self.lines, self.n = [f"cfg {sample_rate} {buffer_size} {channels}"], 0
+
+    def add_module(self, t):
+        self.lines.append(f"mod {t}")
+        self.n += 1
+        return self.n - 1
+
+    def set_field(self, m, f, v):
+        self.lines.append(f"field {m} {f} {float(v)!r}")
+
+    def set_step(self, m, ch, i, st, val=0):
+        self.lines.append(f"step {m} {ch} {i} {st} {val}")
+
+    def set_wave(self, m, wave, rate):
+        self.lines.append(f"wave {m} {len(wave)} " + " ".join(repr(float(x)) for x in wave))
+
+    def connect(self, a, ap, b, bp):
+        self.lines.append(f"conn {a} {ap} {b} {bp}")
+
+    def override(self, m, f, values):
+        self.lines.append(f"ov {m} {f} {len(values)} " + " ".join(repr(float(x)) for x in values))
+
+    def run(self, probe, exact=False):
+        r = subprocess.run([probe], input="\n".join(self.lines + (["exact"] if exact else [])) + "\n", capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        return json.loads(r.stdout)
+
+
+OSC, VCF, ADSR, VCA, MIX, MATH, GRID, PAT, NONLIN, SMP, NOISE = (W.MOD_OSCILLATOR, W.MOD_MOOG_FILTER, W.MOD_ADSR, W.MOD_VCA, W.MOD_MONO_MIXER, W.MOD_MATH,
+                                                               W.MOD_GRID_SEQUENCER, W.MOD_PATTERN_SEQUENCER, W.MOD_NONLINEAR, W.MOD_SAMPLE, W.MOD_NOISE)
+SINE, SQUARE, SAW = 0, 1, 2
+
+
+def chain(*specs):
+    """modules by type, then wires (a, port, b, port); the last module added is the OutputModule.  -> Rec, ids"""
+    g = Rec()
+    return g, [g.add_module(t) for t in specs] + [g.add_module(W.MOD_OUTPUT)]
+
+
+# ---- the straight way to the output: every cheap form taken, the bound is the sum of their contributions -------------------------------
+def test_straight_chain_takes_every_form_and_says_its_bound(probe):
+    g, (osc, vcf, out) = chain(OSC, VCF)
+    g.connect(osc, SAW, vcf, 0)
+    g.connect(vcf, 0, out, 0)
+    r = g.run(probe)
+    assert r["exact_blep"][osc] == 0 and r["literal"][vcf] == 0 and r["saw_fixed"][osc] == 1 and not r["exact_patch"]
+    l1 = r["gain"][osc][SAW]                       # the lowpass's L1 norm at the default cutoff 0.2 / resonance 0.5 (tools/ladder_calib.c l1: 1.54)
+    assert 1.5 < l1 < 1.6
+    assert r["bound"] == pytest.approx(1.5e-6 + 2.4e-7 * l1 + 3.2e-12 * l1, rel=1e-6) and r["bound"] < BUDGET
+    assert g.run(probe, exact=True)["saw_fixed"][osc] == 0   # exact mode: no form on offer at all
+
+
+def test_ladder_l1_norms_against_known_values(probe):
+    """resonance 0: the lowpass's impulse response is positive and sums to its DC gain 1; the highpass = input - lowpass: 2 at low cutoffs."""
+    g, (osc, vcf, out) = chain(OSC, VCF)
+    g.set_field(vcf, W.VCF_RES, 0.0)
+    g.set_field(vcf, W.VCF_FREQ, 0.05)
+    g.connect(osc, SAW, vcf, 0)
+    g.connect(vcf, 2, out, 0)
+    g.connect(vcf, 0, out, 1)
+    r = g.run(probe)
+    assert r["gain"][vcf] == [1.0, 0.0, 1.0]
+    assert r["gain"][osc][SAW] == pytest.approx(2.0, abs=0.01)   # max over the two channels: the highpass's
+
+
+# ---- what integrates: a pitch input -------------------------------------------------------------------------------------------------------
+def test_a_producer_into_a_pitch_is_exact_by_the_horizon(probe):
+    g, (lfo, osc, out) = chain(OSC, OSC)
+    g.set_field(lfo, W.OSC_VAL, -6.0)
+    g.connect(lfo, SAW, osc, 0)
+    g.connect(osc, SINE, out, 0)
+    r = g.run(probe)
+    # d sine / d cv = horizon x ln2 x delta x 2 pi with delta = 440 x 2^(0 + |saw| <= 2) / 48000
+    delta = 440.0 * 4.0 / 48000.0
+    assert r["gain"][lfo][SAW] == pytest.approx(HORIZON * math.log(2) * delta * 2 * math.pi, rel=1e-6)
+    assert r["exact_blep"][lfo] == 1 and r["saw_fixed"][lfo] == 0 and not r["exact_patch"]
+    assert r["sine_loose"][osc] == 1     # the carrier's own sine goes straight out
+
+
+def test_a_sine_into_a_pitch_keeps_its_f64_form_and_the_patch_its_flavour(probe):
+    g, (mod, car, out) = chain(OSC, OSC)
+    g.connect(mod, SINE, car, 0)
+    g.connect(car, SINE, out, 0)
+    r = g.run(probe)
+    assert r["sine_loose"] [mod] == 0 and r["sine_loose"][car] == 1 and not r["exact_patch"]
+
+
+# ---- what thresholds: event inputs -----------------------------------------------------------------------------------------------------------
+def test_event_inputs_and_the_square_that_arrives_unchanged(probe):
+    # a square wired straight to a gate (P1's gate LFO): nothing to pay — square_sign_safe makes its edges the reference's
+    g, (lfo, env, out) = chain(OSC, ADSR)
+    g.connect(lfo, SQUARE, env, 0)
+    g.connect(env, 0, out, 0)
+    r = g.run(probe)
+    assert r["exact_blep"][lfo] == 0 and r["gain"][lfo][SQUARE] == pytest.approx(EVENT)     # (the wire's gain is an event's all the same)
+    # ... handed on by a sequencer's gate output: the same
+    g, (lfo, seq, env, out) = chain(OSC, GRID, ADSR)
+    g.set_step(seq, 0, 0, W.STEP_ON, 3)
+    g.connect(lfo, SQUARE, seq, 0)
+    g.connect(seq, W.GRIDSEQ_OUT_GATE, env, 0)
+    g.connect(env, 0, out, 0)
+    assert g.run(probe)["exact_blep"][lfo] == 0
+    # ... after arithmetic it is a value like any other (round 4's seed 2691: a bandpass into a gate): exact PolyBLEP
+    g, (lfo, gain, env, out) = chain(OSC, MATH, ADSR)
+    g.set_field(gain, W.MATH_OPERATION, W.MATH_MULTIPLY)
+    g.set_field(gain, W.MATH_CONSTANT, 0.5)
+    g.connect(lfo, SQUARE, gain, 0)
+    g.connect(gain, 0, env, 0)
+    g.connect(env, 0, out, 0)
+    assert g.run(probe)["exact_blep"][lfo] == 1
+    # a saw into a gate; a filter into a sync: both pay
+    g, (osc, vcf, slave, out) = chain(OSC, VCF, OSC)
+    g.connect(osc, SAW, vcf, 0)
+    g.connect(vcf, 1, slave, 1)
+    g.connect(slave, SAW, out, 0)
+    r = g.run(probe)
+    assert r["exact_blep"][osc] == 1 and r["literal"][vcf] == 1 and r["exact_blep"][slave] == 0 and r["saw_fixed"][osc] == 0
+
+
+def test_a_fixed_point_phase_is_denied_in_front_of_an_event_but_not_of_a_vca(probe):
+    g, (osc, env, lfo, vca, out) = chain(OSC, ADSR, OSC, VCA)
+    g.connect(lfo, SQUARE, env, 0)
+    g.connect(env, 0, vca, 0)
+    g.connect(osc, SAW, vca, 1)        # the saw opens the VCA: `cv > 0.0` there is continuous in the output (audio * cv), not an event
+    g.connect(vca, 0, out, 0)
+    assert g.run(probe)["saw_fixed"][osc] == 1
+    g, (osc, env, out) = chain(OSC, ADSR)
+    g.connect(osc, SAW, env, 0)
+    g.connect(env, 0, out, 0)
+    r = g.run(probe)
+    assert r["saw_fixed"][osc] == 0 and r["exact_blep"][osc] == 1
+
+
+# ---- a filter's cutoff ---------------------------------------------------------------------------------------------------------------------------
+def test_producers_into_a_cutoff_pay_by_the_filters_sensitivity(probe):
+    """Round 4's seed 10901: a saw through a highpass into a second filter's audio AND cutoff (amount 0.92, resonance 0.76), 2.6e-5 in the
+    default forms.  The bound: epsilon x the highpass's L1 norm x 3 / cutoff x the second filter's norm x amount — far over; the same saw
+    into a cutoff with a small amount at a high cutoff stays fast: a bound, not a reachability rule."""
+    def patch(amount, freq, res):
+        g, (osc, a, b, out) = chain(OSC, VCF, VCF)
+        g.set_field(b, W.VCF_EXP_AMT, amount)
+        g.set_field(b, W.VCF_FREQ, freq)
+        g.set_field(b, W.VCF_RES, res)
+        g.connect(osc, SAW, a, 0)
+        g.connect(a, 2, b, 0)
+        g.connect(a, 2, b, 1)
+        g.connect(b, 1, out, 0)
+        return g, osc, a, b
+    g, osc, a, b = patch(0.92, 0.2, 0.76)
+    r = g.run(probe)
+    assert r["exact_blep"][osc] == 1 and r["literal"][a] == 1
+    g, (lfo, osc, vcf, out) = chain(OSC, OSC, VCF)
+    g.set_field(vcf, W.VCF_EXP_AMT, 0.01)
+    g.set_field(vcf, W.VCF_FREQ, 0.6)
+    g.connect(osc, SAW, vcf, 0)
+    g.connect(lfo, SINE, vcf, 1)
+    g.connect(vcf, 0, out, 0)
+    r = g.run(probe)
+    assert r["sine_loose"][lfo] == 1 and r["literal"][vcf] == 0 and r["bound"] < BUDGET
+
+
+def test_a_cutoff_that_jumps(probe):
+    """tools/ladder_calib.c: a square on the cutoff CV takes the contracted ladder out of its band (5e-5) and makes the literal one respond up
+    to 3.5 x its static gain up to resonance 0.8, without bound above; white noise on the CV: without bound from resonance 0.2 (round 4's
+    seeds 28336; 2127 / 2203 / 2360)."""
+    def patch(cv_type, res):
+        g, (audio, cv, vcf, out) = chain(OSC, cv_type, VCF)
+        g.set_field(vcf, W.VCF_RES, res)
+        g.connect(audio, SAW, vcf, 0)
+        g.connect(cv, SQUARE if cv_type == OSC else 0, vcf, 1)
+        g.connect(vcf, 0, out, 0)
+        return g, audio, cv, vcf
+    g, audio, cv, vcf = patch(OSC, 0.5)
+    r = g.run(probe)
+    assert r["literal"][vcf] == 1 and r["exact_blep"][cv] == 1 and r["exact_blep"][audio] == 0     # the audio saw keeps the fast form ...
+    g, audio, cv, vcf = patch(OSC, 0.85)
+    r = g.run(probe)
+    assert r["literal"][vcf] == 1 and r["exact_blep"][audio] == 1 and r["gain"][audio][SAW] == float("inf")   # ... until the margin is gone
+    g, audio, cv, vcf = patch(NOISE, 0.5)
+    r = g.run(probe)
+    assert r["literal"][vcf] == 1 and r["exact_blep"][audio] == 1 and r["saw_fixed"][audio] == 0
+    g, audio, cv, vcf = patch(ADSR, 0.5)                     # an envelope (P3's sweep): jumps now and then — twice the still ladder's epsilon
+    g.connect(audio, SQUARE, cv, 0)
+    r = g.run(probe)
+    assert r["literal"][vcf] == 0 and r["exact_blep"][audio] == 0 and 3.0e-6 < r["bound"] < BUDGET
+
+
+def test_a_ladder_near_self_oscillation(probe):
+    """The L1 norm is computed from the filter's own coefficients over the cutoffs it can reach: resonance 0.85 at cutoff 0.2 is 11 (fine), 0.95
+    does not decay — an unbounded gain: the saw in front takes its exact form, and an oscillator whose pitch moves (no exact form of its
+    own in the default mode) turns the patch exact (round 2's finding: resonance >= 0.928 left the band in a few voices, up to 3e-3)."""
+    def patch(res, vibrato=False, per_voice=None):
+        g, (osc, vcf, lfo, out) = chain(OSC, VCF, OSC)
+        g.set_field(vcf, W.VCF_RES, res)
+        if per_voice is not None:
+            g.override(vcf, W.VCF_RES, per_voice)
+        g.connect(osc, SAW, vcf, 0)
+        g.connect(vcf, 0, out, 0)
+        if vibrato:
+            g.connect(lfo, SINE, osc, 0)
+        return g, osc, vcf
+    g, osc, vcf = patch(0.85)
+    r = g.run(probe)
+    assert r["literal"][vcf] == 0 and 10.0 < r["gain"][osc][SAW] < 12.0 and r["exact_blep"][osc] == 0
+    g, osc, vcf = patch(0.95)
+    r = g.run(probe)
+    assert r["literal"][vcf] == 1 and r["exact_blep"][osc] == 1 and r["gain"][osc][SAW] == float("inf") and not r["exact_patch"]
+    g, osc, vcf = patch(0.95, vibrato=True)
+    r = g.run(probe)
+    assert r["exact_patch"] and "unbounded gain" in r["why"]
+    g, osc, vcf = patch(0.5, per_voice=[0.1, 0.96, 0.3])     # one voice is enough
+    assert g.run(probe)["literal"][vcf] == 1
+
+
+# ---- cycles -------------------------------------------------------------------------------------------------------------------------------------
+def test_cycles_converge_to_their_geometric_series_or_diverge(probe):
+    def patch(feedback):
+        g, (osc, mix, out) = chain(OSC, MIX)
+        g.set_field(mix, W.MIX_GAIN0, 1.0)
+        g.set_field(mix, W.MIX_GAIN1, feedback)
+        g.connect(osc, SAW, mix, 0)
+        g.connect(mix, 0, mix + 0, 1) if False else None
+        return g, osc, mix
+    # (a module may not be wired to itself: the loop goes through a second mixer with unit gain)
+    def loop(feedback):
+        g, (osc, a, b, out) = chain(OSC, MIX, MIX)
+        g.set_field(a, W.MIX_GAIN1, feedback)
+        g.connect(osc, SAW, a, 0)
+        g.connect(a, 0, b, 0)
+        g.connect(b, 0, a, 1)
+        g.connect(a, 0, out, 0)
+        return g, osc, a
+    g, osc, a = loop(0.5)
+    r = g.run(probe)
+    assert r["gain"][osc][SAW] == pytest.approx(2.0, rel=1e-4) and r["exact_blep"][osc] == 0 and r["bound"] == pytest.approx(2 * (2.4e-7 + 3.2e-12), rel=1e-3)
+    g, osc, a = loop(0.96)      # 25: the f32 PolyBLEP's 2.4e-7 becomes 6e-6
+    r = g.run(probe)
+    assert r["gain"][osc][SAW] == pytest.approx(25.0, rel=2e-2) and r["exact_blep"][osc] == 1
+    g, osc, a = loop(1.0)       # round 4's seed 40913: gain exactly one — an integrator
+    r = g.run(probe)
+    assert r["gain"][osc][SAW] == float("inf") and r["exact_blep"][osc] == 1 and not r["exact_patch"]
+    g, osc, a = loop(1.2)       # seed 4386: two mixers feeding each other with gains above one
+    assert g.run(probe)["gain"][osc][SAW] == float("inf")
+
+
+def test_a_cycle_through_an_event_input_is_unbounded(probe):
+    """Round 4's seed 725: the moved event comes back to what produced it."""
+    g, (osc, env, vca, out) = chain(OSC, ADSR, VCA)
+    g.connect(osc, SINE, vca, 0)
+    g.connect(env, 0, vca, 1)
+    g.connect(vca, 0, env, 0)          # the envelope's own output (times a sine) is its gate
+    g.connect(vca, 0, out, 0)
+    r = g.run(probe)
+    assert r["gain"][osc][SINE] == float("inf") and r["exact_patch"]
+
+
+def test_feedback_fm_is_neutral_while_its_index_is_small(probe):
+    """Config 4's loop: OSC_M.sine -> x beta -> OSC_M.cv.  A pitch input integrates, so first order every loop through one diverges; the
+    loop's real multiplier per sample is 1 + a cos(...), a = delta ln2 2 pi beta (0.02 for config 4), whose logarithm averages to -a^2 / 4:
+    neutral (profiles/r05_horizon.json: flat over a minute).  The analysis cuts the loop at that pitch input when only sines travel round it and
+    a <= 0.25; feedback gains above one (1.8: a = 0.27 at 440 Hz x 2^1.8) or a saw in the loop leave it in, and the patch goes exact
+    (tests/test_gpu_parity.py: test_fm_feedback_gain_above_one_takes_the_exact_flavour)."""
+    def p2(beta, port=SINE, per_voice=None):
+        g = Rec(48000, 1, 2)
+        ids = W.build_p2(g, beta=beta)
+        if port != SINE:
+            g.lines = [l.replace(f"conn {ids['osc_m']} 0 {ids['mul_fb']} 0", f"conn {ids['osc_m']} {port} {ids['mul_fb']} 0") for l in g.lines]
+        if per_voice is not None:
+            g.override(ids["mul_fb"], W.MATH_CONSTANT, per_voice)
+        return g, ids
+    g, ids = p2(0.3, per_voice=W.p2_voice_params(4096)[0])
+    r = g.run(probe)
+    assert not r["exact_patch"] and r["sine_loose"][ids["osc_m"]] == 0 and r["sine_loose"][ids["osc_c"]] == 1
+    assert 1e10 < r["gain"][ids["osc_m"]][SINE] < 1e16            # finite: two pitch inputs in a row
+    g, ids = p2(1.8)
+    assert g.run(probe)["exact_patch"]
+    g, ids = p2(0.3, port=SAW)
+    assert g.run(probe)["exact_patch"]
+
+
+# ---- a waveshaper's slope ------------------------------------------------------------------------------------------------------------------------
+def test_a_shaper_with_an_exponent_below_one_is_steep_at_zero(probe):
+    """sign(a) |a|^b (math.rs:203-205) has slope b |a|^(b-1): unbounded at 0 for b < 1 — (2.4e-7)^0.5 = 5e-4.  Not among round 4's rules (the
+    fuzzer's patches have no NonLinearModule): derived."""
+    def patch(exponent):
+        g, (osc, shaper, out) = chain(OSC, NONLIN)
+        g.set_field(shaper, W.NONLIN_CONSTANT, exponent)
+        g.connect(osc, SAW, shaper, 0)
+        g.connect(shaper, 0, out, 0)
+        return g, osc, shaper
+    g, osc, shaper = patch(0.5)
+    r = g.run(probe)
+    assert r["exact_blep"][osc] == 1 and r["saw_fixed"][osc] == 0
+    assert r["nonlin_loose"][shaper] == 0      # (its own f32 power: 4e-6 relative to an output of up to 2^0.5 — over the budget by itself; P4's |sample| <= 1 fits)
+    g, osc, shaper = patch(2.0)
+    r = g.run(probe)
+    assert r["gain"][osc][SAW] == pytest.approx(2.0 * 2.0) and r["exact_blep"][osc] == 0 and r["saw_fixed"][osc] == 1   # b |a|^(b-1) at |a| = 2
+
+
+# ---- the budget is shared ----------------------------------------------------------------------------------------------------------------------
+def test_forms_are_denied_largest_first_until_the_channel_fits(probe):
+    g, (osc, vcf, out) = chain(OSC, VCF)
+    g.set_field(vcf, W.VCF_RES, 0.85)
+    g.connect(osc, SAW, vcf, 0)
+    g.connect(vcf, 1, out, 0)          # the bandpass at resonance 0.85: L1 = 23: the PolyBLEP's 5.6e-6 + the ladder's own 4.2e-6
+    r = g.run(probe)
+    assert r["exact_blep"][osc] == 1 and r["literal"][vcf] == 0 and r["bound"] == pytest.approx(4.2e-6, rel=1e-3)
+
+
+# ---- hold / sweep ----------------------------------------------------------------------------------------------------------------------------------
+def test_wire_sweeps(probe):
+    g, (env, gain, osc, mix_a, mix_b, out) = chain(ADSR, MATH, OSC, MIX, MIX)
+    g.connect(env, 0, gain, 0)
+    g.connect(mix_a, 0, mix_b, 0)
+    g.connect(mix_b, 0, mix_a, 0)
+    g.connect(osc, SINE, out, 0)
+    s = g.run(probe)["sweeps"]
+    assert s[env] == 0 and s[gain] == 0 and s[osc] == 1 and s[mix_a] == 1   # an envelope holds, arithmetic on it too; a feedback cycle of arithmetic sweeps
+
+
+# ---- the benchmarked workloads keep every fast form ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", W.BENCH_WORKLOADS)
+def test_benchmarked_workloads_keep_their_forms(probe, name):
+    V = 4096
+    B, build, overrides = W.bench_workload(name, V)
+    g = Rec(48000, B, 2)
+    ids = build(g)
+    for m, f, v in overrides(ids):
+        g.override(m, f, v)
+    r = g.run(probe)
+    assert not r["exact_patch"] and r["bound"] < BUDGET and sum(r["exact_blep"]) == 0 and sum(r["literal"]) == 0, r
+    if name.startswith("cfg3") or name == "cfg2":
+        assert r["saw_fixed"][ids["osc_a"]] == 1
+    if name == "p4":
+        assert r["nonlin_loose"][ids["shaper"]] == 1 and r["sine_loose"][ids["lfo"]] == 0
+    if name.startswith("cfg4"):
+        assert r["sine_loose"][ids["osc_c"]] == 1 and r["sine_loose"][ids["osc_m"]] == 0
+
+
+# ---- the numbers behind the ladder's epsilon, re-measured at a small size ---------------------------------------------------------------
+@pytest.fixture(scope="module")
+def calib():
+    return _build(os.path.join(ROOT, "tests", "cpp", "ladder_calib"), [os.path.join(ROOT, "tools", "ladder_calib.c")], ["-O2", "-ffp-contract=off"])
+
+
+def test_contracted_ladder_epsilon_covers_the_emulation(calib):
+    """approx.cpp's kEpsLadder = (1.5e-6, 4.2e-6, 3.6e-6) for a cutoff that stands still or moves smoothly, twice that for rare jumps; a square or
+    noise on the cutoff is outside any such figure (why such a filter has no contracted form)."""
+    out = subprocess.run([calib, "own", "30000", "60"], capture_output=True, text=True, timeout=300).stdout
+    rows = {l.split()[1]: [float(l.split()[k]) for k in (3, 5, 7)] for l in out.splitlines() if l.startswith("own")}
+    for kind in ("none", "ramp", "sineLFO", "sine700", "saw"):
+        assert all(e <= lim for e, lim in zip(rows[kind], (1.5e-6, 4.2e-6, 3.6e-6))), (kind, rows[kind])
+    assert all(e <= 2 * lim for e, lim in zip(rows["squareLFO"], (1.5e-6, 4.2e-6, 3.6e-6)))
+    assert max(rows["noise"]) > 1e-4
