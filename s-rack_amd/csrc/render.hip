@@ -932,6 +932,11 @@ struct Segment {
         if (tk.on && !(tick && tk.L == T && tk.Lmax == std::min(T, kChunkMax) && tk.st == st && tk.c % tk.n == 0 &&
                        tk.n0 + (tk.c / tk.n) * (uint64_t)T == h.samples_rendered)) {  // not the call the session guessed
             if ((rc = tick_end(h, st, false)) != SRACK_OK) return rc;  // on THIS call's stream, behind the session's last call (an event: no host-side wait)
+        } else if (tk.on && tk.done) {
+            // the session continues — on a stream with the same HANDLE as its last call's.  A host may have destroyed that stream and been
+            // handed the same value for a new one: order this call behind the session's last one explicitly (an event wait on a stream that
+            // already is behind it costs nothing)
+            HIP_TRY(hipStreamWaitEvent(st, tk.done, 0));
         }
         chunks.clear();
         if (tick) {
@@ -1270,10 +1275,10 @@ struct Segment {
     {
         bool done = false;
         if ((rc = prepare(done)) != SRACK_OK || done) return rc;
-        // (a call that fails part-way — a launch error — must not leave a session behind whose bookkeeping is a call ahead of the device)
-        // (... it ends the session instead: the state as of the last call that completed goes back into the tables — on the null stream, after
-        // the device has come to rest —, and if even that fails the program is dropped, so that the next render starts from what the host
-        // holds rather than from tables nobody can vouch for)
+        // (a call that fails part-way — a launch error — must not leave a session behind whose bookkeeping is a call ahead of the device.  It
+        // ends the session and drops the program: the ring of table copies cannot be trusted as a rollback — a session's first call has not
+        // written copy 0 yet, and a call of several chunks overwrites the copy its own start would restore — so the next render starts from
+        // what the host holds rather than from tables nobody can vouch for)
         struct TickGuard {
             PatchHandle& h;
             TickSession& t;
@@ -1282,10 +1287,8 @@ struct Segment {
             {
                 if (done || !t.on) return;
                 (void)hipDeviceSynchronize();
-                if (tick_end(h, nullptr, true) != SRACK_OK) {
-                    t.on = false;
-                    h.prog_valid = false;
-                }
+                t.on = false;
+                h.prog_valid = false;
             }
         } tick_guard{h, tk};
         if ((rc = plan()) != SRACK_OK || (rc = control()) != SRACK_OK) return rc;

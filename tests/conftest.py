@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The suites measure the library as a host gets it: a stray SRACK_* tuning variable in the environment (tools/ set them for experiments;
+    the library reads them: other chunk lengths, generator variants ...) would test something else.  srack_render_info lists such variables
+    ("knobs=[...]"); here the run refuses to start.  (Where the kernel cache lives and a test's own hooks are not tuning knobs.)"""
+    stray = sorted(k for k in os.environ if k.startswith("SRACK_") and not k.startswith(("SRACK_KERNEL_CACHE_", "SRACK_BENCH_", "SRACK_TEST_")))
+    if stray:
+        raise pytest.UsageError("SRACK_* tuning variables are set: " + ", ".join(stray) + " — unset them for the test suites")
+
+
 @pytest.fixture(scope="session")
 def W():
     import srack_pkg

@@ -1,0 +1,58 @@
+"""The default mode's contract over TIME (-m gpu): every benchmarked workload rendered for 30 seconds in calls of one second — state carried from
+call to call, as an offline renderer's host drives it — against the oracle, second by second.  The one-second parity tests cannot tell a
+plateau from the first second of a ramp (round 4 found two linear drifts only when its soaks went to whole seconds); this one can:
+the error of the last ten seconds may not exceed that of the first ten by more than rounding noise.  tools/horizon.py records the same
+curves over a minute (profiles/r05_horizon.json)."""
+import numpy as np
+import pytest
+
+import srack_pkg
+
+pytestmark = pytest.mark.gpu
+SR, SECONDS, V = 48000, 30, 64
+
+
+@pytest.fixture(scope="module")
+def S():
+    S = srack_pkg.load()
+    assert S.device_count() > 0, "no GPU visible: the render path has no CPU fallback"
+    return S
+
+
+_ref_cache = {}
+
+
+def reference(S, oracle, name):
+    if name not in _ref_cache:
+        B, build, overrides = S.bench_workload(name, V)
+        o = oracle.OraclePatch(SR, B, 2)
+        ids = build(o)
+        _ref_cache[name] = o.render_batch(V, SECONDS * SR, overrides(ids), threads=16)[0]   # [2][T][V]
+    return _ref_cache[name]
+
+
+# flags: 0 = what a small render gets (the hand-written kernels / the interpreter), 32 = the kernel specialised at run time that the benchmarked
+# voice counts get, 34 = the same without the fused shapes
+@pytest.mark.parametrize("flags", [0, 32, 34])
+@pytest.mark.parametrize("name", ["cfg3", "cfg3_poly", "cfg4", "cfg4_b1024", "p3", "p4"])
+def test_thirty_seconds_in_one_second_calls(S, oracle, name, flags):
+    ref = reference(S, oracle, name)
+    B, build, overrides = S.bench_workload(name, V)
+    p = S.Patch(SR, B, 2)
+    ids = build(p)
+    p.configure_voices(V)
+    for m, f, v in overrides(ids):
+        p.set_voice_field(m, f, v)
+    per_second = []
+    for s in range(SECONDS):
+        fr = p.render_channels(SR, flags).astype(np.float64)
+        r = ref[:, s * SR:(s + 1) * SR].astype(np.float64)
+        assert np.isfinite(fr).all() and np.isfinite(r).all()
+        per_second.append(float((np.abs(fr - r) / np.maximum(np.abs(r), 1.0)).max()))
+    assert "approx[bound" in p.info(), p.info()               # the default flavour, with its derived bound
+    worst, head, tail = max(per_second), max(per_second[:10]), max(per_second[-10:])
+    assert np.abs(ref).max() > 0.1
+    assert worst <= 1e-5, f"{name} flags {flags}: {worst:.2e} (per second: {['%.1e' % e for e in per_second]})"
+    # flat: what the last ten seconds add over the first ten is rounding noise, not a ramp (a ramp that reaches 1e-5 within ten minutes
+    # would add 3e-7 in twenty seconds)
+    assert tail <= head + 3e-7, f"{name} flags {flags}: first ten seconds {head:.2e}, last ten {tail:.2e}"

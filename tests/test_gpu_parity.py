@@ -2116,3 +2116,27 @@ def test_a_saw_that_reaches_a_pitch(S, oracle, loop, flags):
     else:
         assert assert_close(fr, ref) < 5e-6
     assert np.abs(ref[0]).max() > 0.05
+
+
+@pytest.mark.parametrize("B", [1, 1024])
+def test_exact_mode_frames_do_not_depend_on_the_sharding(S, B):
+    """What lets an N-GPU render be diffed against one GPU: in the exact mode a voice's frames are bit-identical whatever shard it is rendered
+    in — here config 4's patch (whose DEFAULT kernels vote per wave on what their 64 voices allow, so that a voice's last bits can depend
+    on its neighbours: DESIGN section 5), global voices [16384, 24576) as a shard of 8 192 and inside a shard of 65 536."""
+    T = 6000
+    name = "cfg4" if B == 1 else "cfg4_b1024"
+
+    def shard(first, n):
+        Bs, build, overrides = S.bench_workload(name, n, first_voice=first)
+        p = S.Patch(48000, Bs, 2)
+        ids = build(p)
+        p.configure_voices(n)
+        for m, f, v in overrides(ids):
+            p.set_voice_field(m, f, v)
+        fr, mix = p.render(T, flags=S.RENDER_EXACT_OSC)
+        return fr[0]
+
+    big = shard(0, 65536)
+    small = shard(16384, 8192)
+    np.testing.assert_array_equal(bits(small), bits(big[:, 16384:24576]))
+    assert np.abs(small).max() > 0.5
