@@ -359,9 +359,14 @@ def cpu_baseline(S, workload, n_samples=48000):
 
 # (name on the line, workload, render flags): the headline in the exact render mode (the reference's arithmetic bit for bit), the fully
 # per-voice variant of the headline, BASELINE.json configs[1] and configs[3] — the other single-GPU configurations —
-SIDE_CONFIGS = (("cfg3_exact", "cfg3", 1), ("cfg3_poly", "cfg3_poly", 0), ("cfg2", "cfg2", 0), ("cfg4", "cfg4", 0),
-                # ... config 4 at the app's block size, and the workloads of scope rows (f)1 and (f)4 (two output planes each)
-                ("cfg4_b1024", "cfg4_b1024", 0), ("p3", "p3", 0), ("p4", "p4", 0))
+KEEP_DEFAULT = 64  # SRACK_RENDER_KEEP_DEFAULT
+SIDE_CONFIGS = (("cfg3_exact", "cfg3", 1), ("cfg3_poly", "cfg3_poly", 0), ("cfg2", "cfg2", 0),
+                # config 4 as the library renders it by default — the exact flavour: its feedback loop runs through a pitch, where only the
+                # reference's own bits follow the reference for longer than seconds (csrc/approx.cpp; profiles/r05_horizon.json) — and
+                # with the fast kernels a host may ask for (KEEP_DEFAULT: within the contract for ~30 s); the same at the app's block size
+                ("cfg4", "cfg4", 0), ("cfg4_fast", "cfg4", KEEP_DEFAULT), ("cfg4_b1024", "cfg4_b1024", 0), ("cfg4_b1024_fast", "cfg4_b1024", KEEP_DEFAULT),
+                # the workloads of scope rows (f)1 and (f)4 (two output planes each)
+                ("p3", "p3", 0), ("p4", "p4", 0))
 SIDE_STEPS, SIDE_WARMUP = 5, 1
 
 
@@ -387,12 +392,13 @@ def side_config(args, workload, flags=0):
         kname = info.split("kernel=")[-1] if "kernel=" in info else ""
         launches = max(1, n_launch // SIDE_STEPS)
         bytes_per_step = BYTES_PER_VOICE_SAMPLE * be.n_planes * V * T
-        out = {"workload": be.what, "render_flags": flags, "arithmetic": arithmetic_note(flags), "voices": V, "samples_per_step": T, "buffer_size": be.buffer_size,
+        out = {"workload": be.what, "render_flags": flags, "arithmetic": arithmetic_note(flags, info), "voices": V, "samples_per_step": T, "buffer_size": be.buffer_size,
                "steps": SIDE_STEPS, "warmup": SIDE_WARMUP,
                "ms_per_step": step_s * 1e3, "voice_samples_per_s": V * T / step_s,
                "frac_hbm": bytes_per_step / step_s / 1e9 / HBM_PEAK_GBS, "kernel": kname, "kernel_ms": kernel_ms, "launches_per_step": launches,
                "frac_hbm_kernel": (bytes_per_step / launches / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms > 0 else 0.0, "program": info}
-        ops = FM_PAIR_F64_OPS.get(kname) if workload == "cfg4" or kname != "render_specialized" else None
+        # (the ISA counts are those of the fast kernels' loops: KEEP_DEFAULT; the exact flavour runs the libm's pow and ocml's sin)
+        ops = FM_PAIR_F64_OPS.get(kname) if (flags & KEEP_DEFAULT) and (workload == "cfg4" or kname != "render_specialized") else None
         if ops:
             out.update({"f64_ops_per_voice_sample": ops, "frac_valu_f64": ops * V * T / step_s / F64_LANE_OPS_PEAK,
                         "frac_of_measured_f64_rate": ops * V * T / step_s / F64_LANE_OPS_MEASURED})
@@ -433,10 +439,11 @@ def profiled_traffic(kernel_name, workload, flags, V, T):
     return best
 
 
-def arithmetic_note(flags):
-    """What the render mode computes in, where it is not the reference's own operation sequence."""
-    if flags & 1:
-        return ("exact mode: the reference's operations one by one — f64 phase / 2^cv (the host libm's pow, operation for operation) / PolyBLEP with its f64 division, the ladder "
+def arithmetic_note(flags, info=""):
+    """What the render mode computes in, where it is not the reference's own operation sequence.  `info`: srack_render_info —
+    "approx[exact: ...]" where the flattener's error bound gave the patch the exact flavour although default mode was asked for."""
+    if flags & 1 or "approx[exact" in info:
+        return (("exact flavour by the flattener's error bound (csrc/approx.cpp: " + info.split("approx[exact: ")[1].split("]")[0] + "): " if "approx[exact" in info else "") + "exact mode: the reference's operations one by one — f64 phase / 2^cv (the host libm's pow, operation for operation) / PolyBLEP with its f64 division, the ladder "
                 "uncontracted with min/max clamps; frames bit-identical to the CPU tick (oscillator.rs:108-158, filter.rs:58-92)")
     return ("default mode, within the 1e-5 contract but NOT the reference's arithmetic everywhere: PolyBLEP evaluated in f32 (reference: f64, "
             "oscillator.rs:50-67); the ladder with one product of each a*b - c*d folded into an fma and v_med3 clamps (reference: uncontracted, "
@@ -514,7 +521,7 @@ def run_rank(args, backend_cls=HipBackend):
                             + (" + RCCL reduce of the [2][T] mix (srack_dist_reduce_mix)" if getattr(be, "comm", None) is not None else ""),
                 "name": args.workload, "voices_per_gpu": V, "samples_per_step": T, "buffer_size": getattr(be, "buffer_size", 1024),
                 "render_flags": args.flags, "backend": be.name, "samples_per_call": args.block or T,
-                "arithmetic": arithmetic_note(args.flags),
+                "arithmetic": arithmetic_note(args.flags, info),
                 "frames_written": not args.no_frames, "mix_down": not args.no_mix, "program": info,
             },
             "roofline": {
@@ -528,7 +535,7 @@ def run_rank(args, backend_cls=HipBackend):
                 "traffic": None,
             },
         }
-        if args.workload in ("cfg4", "cfg4_b1024") and FM_PAIR_F64_OPS.get(kname) and not (kname == "render_specialized" and args.workload != "cfg4"):
+        if args.workload in ("cfg4", "cfg4_b1024") and (args.flags & KEEP_DEFAULT) and FM_PAIR_F64_OPS.get(kname) and not (kname == "render_specialized" and args.workload != "cfg4"):
             ops = FM_PAIR_F64_OPS[kname]
             lane_ops = ops * V * T / step_s
             out["roofline"].update({

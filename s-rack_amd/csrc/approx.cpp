@@ -42,7 +42,6 @@ constexpr double kEpsLadder[3] = {1.5e-6, 4.2e-6, 3.6e-6};  // contracted ladder
 constexpr double kLadderRareJumps = 2.0;    // ... with a cutoff that jumps now and then (an envelope's attack, a sequencer's step): same tool, 7e-6 on the bandpass
 constexpr double kLadderL1Max = 64.0;       // beyond this lowpass L1 norm the ladder is treated as self-oscillating (the calibration stops at 47)
 constexpr double kNonlinSteep = 1e4;        // d|a|^b / da near a = 0 for b < 1: (2.4e-7)^0.5 / 2.4e-7 = 2e3
-constexpr double kFmLoopMax = 0.25;         // a feedback-FM loop is neutral while delta * ln2 * 2 pi * |cv| stays below this (see fm_neutral)
 constexpr int kSweeps = 400;
 
 enum : uint32_t { kJumpAudio = 1u, kJumpRare = 2u, kJumpNoise = 4u };  // how a wire moves, for a cutoff CV: edges at audio rate (a square, a saw), now and then (an
@@ -104,7 +103,6 @@ struct Analysis {
     std::vector<int> scc;                 // strongly connected component per live module (-1: not live)
     std::vector<char> on_cycle;
     std::vector<Ladder> ladder;           // per module (filters only)
-    std::vector<char> cut;                // per oscillator: its pitch input closes a neutral feedback-FM loop (not followed recursively)
     struct Reader { int k, i; };
     std::vector<std::vector<std::vector<Reader>>> readers;  // [module][port] -> inputs that read the wire
 
@@ -478,8 +476,8 @@ struct Analysis {
 
     using Gains = std::vector<std::vector<double>>;
 
-    // the fixpoint for output channel c.  pitch_const: for the oscillators in `cut`, the gain of their pitch input as a constant (null: 0)
-    Gains gains_for(int c, const std::vector<double>* pitch_const) const
+    // the fixpoint for output channel c
+    Gains gains_for(int c) const
     {
         Gains G((size_t)n_mod);
         for (int m = 0; m < n_mod; m++) G[(size_t)m].assign(mag[(size_t)m].size(), 0.0);
@@ -494,10 +492,6 @@ struct Analysis {
                     continue;
                 }
                 if (type(r.k) == SRACK_MOD_OUTPUT) continue;  // a second OutputModule is never heard
-                if (type(r.k) == SRACK_MOD_OSCILLATOR && r.i == SRACK_OSC_IN_CV && cut[(size_t)r.k]) {
-                    if (pitch_const) s += (*pitch_const)[(size_t)r.k];
-                    continue;
-                }
                 for (int o = 0; o < (int)G[(size_t)r.k].size(); o++) {
                     if (!port_is_live(r.k, o)) continue;
                     const double go = G[(size_t)r.k][(size_t)o];
@@ -525,47 +519,14 @@ struct Analysis {
         return G;
     }
 
-    // A feedback-FM loop: an oscillator whose own sine (through gains) comes back to its pitch.  First order and in the sup norm a pitch input
-    // integrates for ever, so any loop through one diverges; what the loop really does to a phase perturbation psi is
-    // psi' = psi (1 + a cos(...)), a = delta ln2 2 pi |d cv / d sine|: the factor's logarithm averages to -a^2 / 4 — neutral, slightly
-    // contracting (config 4: a = 0.02; profiles/r05_horizon.json: flat over a minute).  That argument needs the loop to carry SINES only —
-    // nothing upstream of the pitch that the default mode approximates or that jumps — and a small a; then the pitch edge is not followed
-    // recursively (its first-order effect downstream still counts).  Anything else on a cycle through a pitch stays in the fixpoint and diverges.
-    bool fm_neutral(int k) const
-    {
-        const InputRef& cv = g.modules[(size_t)k].in[SRACK_OSC_IN_CV];
-        if (cv.src < 0 || !same_cycle(cv.src, k)) return false;
-        const double delta = osc_delta_max(k), index = in_mag(k, SRACK_OSC_IN_CV);
-        if (!(delta * 0.6931471805599453 * 6.283185307179586 * index <= kFmLoopMax)) return false;
-        std::vector<char> seen((size_t)n_mod * 16, 0);
-        std::vector<std::pair<int, int>> stack{{cv.src, cv.port}};
-        while (!stack.empty()) {  // every wire upstream of the pitch, through the inputs that carry values
-            const auto [m, p] = stack.back();
-            stack.pop_back();
-            if (p >= 16 || seen[(size_t)m * 16 + (size_t)p]) continue;
-            seen[(size_t)m * 16 + (size_t)p] = 1;
-            const Module& mod = g.modules[(size_t)m];
-            switch (mod.type) {
-            case SRACK_MOD_OSCILLATOR:
-                if (p != SRACK_OSC_OUT_SINE || mod.in[SRACK_OSC_IN_SYNC].src >= 0) return false;
-                if (mod.in[SRACK_OSC_IN_CV].src >= 0) stack.push_back({mod.in[SRACK_OSC_IN_CV].src, mod.in[SRACK_OSC_IN_CV].port});
-                break;
-            case SRACK_MOD_VCA:
-            case SRACK_MOD_MONO_MIXER:
-            case SRACK_MOD_MATH:
-                for (const InputRef& in : mod.in)
-                    if (in.src >= 0) stack.push_back({in.src, in.port});
-                break;
-            case SRACK_MOD_ADSR:
-            case SRACK_MOD_GRID_SEQUENCER:
-            case SRACK_MOD_PATTERN_SEQUENCER:
-                if (on_cycle[(size_t)m] && scc[(size_t)m] == scc[(size_t)k]) return false;
-                break;  // held values from outside the loop
-            default: return false;  // a filter, noise, a sample player, a shaper, a reverb
-            }
-        }
-        return true;
-    }
+    // (A feedback-FM loop — an oscillator whose own sine, through gains, comes back to its pitch: config 4 — is NOT cut out of the fixpoint.
+    // In real arithmetic it is neutral: a phase perturbation psi obeys psi' = psi (1 + a cos(...)), a = delta ln2 2 pi |d cv / d sine| = 0.02
+    // for config 4, whose logarithm averages to -a^2 / 4.  But the sine that travels round the loop is rounded to f32, and a phase
+    // difference of 1e-12 flips one of those roundings now and then; each flip is a kick of 6e-8 on the pitch — far larger than what caused
+    // it — and the kicks feed the difference that causes them.  Measured (tools/fm_sensitivity.c, the reference's own arithmetic twice,
+    // one copy's phase off by 1e-12): nothing for 20 s, 2.6e-9 cycles at 25 s, 1e-7 at 35 s; and on the GPU (profiles/r05_horizon.json,
+    // round 4's default kernels): config 4 at 4.6e-7 after one second, 1.5e-5 — outside the contract — after a minute, linear in between.
+    // Only identical bits follow the reference round such a loop: first order says "diverges", and first order is right.)
 
     // The square of an oscillator that arrives UNCHANGED at an event input — wired straight to it, or handed on by a sequencer's gate outputs
     // (sequencer.rs:190-246: the gate output IS the step input where the cell is on) — costs nothing there: the default evaluation re-derives
@@ -691,26 +652,10 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
     A.magnitudes();
     A.ladders();
     A.edges();
-    A.cut.assign((size_t)n_mod, 0);
-    for (int m = 0; m < n_mod; m++)
-        if (live[(size_t)m] && A.type(m) == SRACK_MOD_OSCILLATOR && A.on_cycle[(size_t)m]) A.cut[(size_t)m] = A.fm_neutral(m);
-
     const int n_ch = std::min((int)g.modules[(size_t)g.plan.output].n_in, 8);
     std::vector<Analysis::Gains> G((size_t)n_ch);
-    for (int c = 0; c < n_ch; c++) {
-        if (g.modules[(size_t)g.plan.output].in[(size_t)c].src < 0) continue;
-        const Analysis::Gains first = A.gains_for(c, nullptr);
-        std::vector<double> pitch((size_t)n_mod, 0.0);
-        bool any = false;
-        for (int k = 0; k < n_mod; k++) {
-            if (!A.cut[(size_t)k]) continue;
-            any = true;
-            for (int o = 0; o < 3; o++)
-                if (A.port_is_live(k, o) && first[(size_t)k][(size_t)o] != 0.0) pitch[(size_t)k] += A.edge(k, SRACK_OSC_IN_CV, o) * first[(size_t)k][(size_t)o];
-            if (!(pitch[(size_t)k] < kBig)) pitch[(size_t)k] = kInf;
-        }
-        G[(size_t)c] = any ? A.gains_for(c, &pitch) : first;
-    }
+    for (int c = 0; c < n_ch; c++)
+        if (g.modules[(size_t)g.plan.output].in[(size_t)c].src >= 0) G[(size_t)c] = A.gains_for(c);
     P.mag = A.mag;
     P.gain.assign((size_t)n_mod, {});
     for (int m = 0; m < n_mod; m++) {

@@ -293,28 +293,34 @@ def test_a_cycle_through_an_event_input_is_unbounded(probe):
     assert r["gain"][osc][SINE] == float("inf") and r["exact_patch"]
 
 
-def test_feedback_fm_is_neutral_while_its_index_is_small(probe):
-    """Config 4's loop: OSC_M.sine -> x beta -> OSC_M.cv.  A pitch input integrates, so first order every loop through one diverges; the
-    loop's real multiplier per sample is 1 + a cos(...), a = delta ln2 2 pi beta (0.02 for config 4), whose logarithm averages to -a^2 / 4:
-    neutral (profiles/r05_horizon.json: flat over a minute).  The analysis cuts the loop at that pitch input when only sines travel round it and
-    a <= 0.25; feedback gains above one (1.8: a = 0.27 at 440 Hz x 2^1.8) or a saw in the loop leave it in, and the patch goes exact
-    (tests/test_gpu_parity.py: test_fm_feedback_gain_above_one_takes_the_exact_flavour)."""
-    def p2(beta, port=SINE, per_voice=None):
+def test_a_loop_through_a_pitch_is_unbounded(probe):
+    """Config 4's loop: OSC_M.sine -> x beta -> OSC_M.cv.  A pitch input integrates, so first order every loop through one diverges.  In real
+    arithmetic this one is neutral (the loop's multiplier per sample, 1 + a cos(...) with a = 0.02, has a logarithm that averages to -a^2 / 4) —
+    but the sine on its way round is rounded to f32, a phase difference of 1e-12 flips one of those roundings now and then, and each flip
+    kicks the pitch by 6e-8: tools/fm_sensitivity.c (the reference's arithmetic twice, one phase off by 1e-12: 1e-7 cycles apart after 35 s)
+    and profiles/r05_horizon.json (round 4's default kernels: 4.6e-7 after a second, 1.5e-5 after a minute).  First order is right: the
+    patch is rendered in the exact flavour, which follows the reference bit for bit (same file: 0 for the whole minute); SRACK_RENDER_KEEP_DEFAULT
+    keeps the fast kernels for a host that renders seconds, not minutes."""
+    def p2(beta, port=SINE):
         g = Rec(48000, 1, 2)
         ids = W.build_p2(g, beta=beta)
         if port != SINE:
             g.lines = [l.replace(f"conn {ids['osc_m']} 0 {ids['mul_fb']} 0", f"conn {ids['osc_m']} {port} {ids['mul_fb']} 0") for l in g.lines]
-        if per_voice is not None:
-            g.override(ids["mul_fb"], W.MATH_CONSTANT, per_voice)
         return g, ids
-    g, ids = p2(0.3, per_voice=W.p2_voice_params(4096)[0])
+    for beta, port in ((0.3, SINE), (1.8, SINE), (0.3, SAW)):
+        g, ids = p2(beta, port)
+        r = g.run(probe)
+        assert r["exact_patch"] and "unbounded gain" in r["why"] and r["gain"][ids["osc_m"]][port] == float("inf")
+        assert r["sine_loose"][ids["osc_c"]] == 1     # (what KEEP_DEFAULT renders with: the carrier's sine goes straight out)
+    # feed-forward FM — a sine into another oscillator's pitch, no way back — is bounded: the default forms stay
+    g, (mod, gain, car, out) = chain(OSC, MATH, OSC)
+    g.set_field(gain, W.MATH_OPERATION, W.MATH_MULTIPLY)
+    g.set_field(gain, W.MATH_CONSTANT, 1.5)
+    g.connect(mod, SINE, gain, 0)
+    g.connect(gain, 0, car, 0)
+    g.connect(car, SINE, out, 0)
     r = g.run(probe)
-    assert not r["exact_patch"] and r["sine_loose"][ids["osc_m"]] == 0 and r["sine_loose"][ids["osc_c"]] == 1
-    assert 1e10 < r["gain"][ids["osc_m"]][SINE] < 1e16            # finite: two pitch inputs in a row
-    g, ids = p2(1.8)
-    assert g.run(probe)["exact_patch"]
-    g, ids = p2(0.3, port=SAW)
-    assert g.run(probe)["exact_patch"]
+    assert not r["exact_patch"] and r["gain"][mod][SINE] < 1e8
 
 
 # ---- a waveshaper's slope ------------------------------------------------------------------------------------------------------------------------
@@ -357,7 +363,7 @@ def test_wire_sweeps(probe):
     assert s[env] == 0 and s[gain] == 0 and s[osc] == 1 and s[mix_a] == 1   # an envelope holds, arithmetic on it too; a feedback cycle of arithmetic sweeps
 
 
-# ---- the benchmarked workloads keep every fast form ------------------------------------------------------------------------------------------
+# ---- the benchmarked workloads keep every fast form (config 4 apart: its loop) ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", W.BENCH_WORKLOADS)
 def test_benchmarked_workloads_keep_their_forms(probe, name):
     V = 4096
@@ -367,13 +373,14 @@ def test_benchmarked_workloads_keep_their_forms(probe, name):
     for m, f, v in overrides(ids):
         g.override(m, f, v)
     r = g.run(probe)
+    if name.startswith("cfg4"):   # the FM pair's feedback loop runs through a pitch: exact flavour (test_a_loop_through_a_pitch_is_unbounded)
+        assert r["exact_patch"] and r["sine_loose"][ids["osc_c"]] == 1 and r["sine_loose"][ids["osc_m"]] == 0
+        return
     assert not r["exact_patch"] and r["bound"] < BUDGET and sum(r["exact_blep"]) == 0 and sum(r["literal"]) == 0, r
     if name.startswith("cfg3") or name == "cfg2":
         assert r["saw_fixed"][ids["osc_a"]] == 1
     if name == "p4":
         assert r["nonlin_loose"][ids["shaper"]] == 1 and r["sine_loose"][ids["lfo"]] == 0
-    if name.startswith("cfg4"):
-        assert r["sine_loose"][ids["osc_c"]] == 1 and r["sine_loose"][ids["osc_m"]] == 0
 
 
 # ---- the numbers behind the ladder's epsilon, re-measured at a small size ---------------------------------------------------------------

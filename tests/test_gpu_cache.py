@@ -115,13 +115,14 @@ def poly(ids):
 def fm(ids):
     beta, index = S.p2_voice_params(V)
     return [(ids["mul_fb"], S.MATH_CONSTANT, beta), (ids["mul_idx"], S.MATH_CONSTANT, index)]
-for name, B, build_patch, per_voice in (("cfg2", 1024, S.build_p1, lambda ids: []), ("cfg3_poly", 1024, S.build_p1, poly), ("cfg4", 1, S.build_p2, fm)):
+for name, B, build_patch, per_voice, flags in (("cfg2", 1024, S.build_p1, lambda ids: [], 0), ("cfg3_poly", 1024, S.build_p1, poly, 0),
+                                              ("cfg4_fast", 1, S.build_p2, fm, S.RENDER_KEEP_DEFAULT)):
     p = S.Patch(48000, B, 2)
     ids = build_patch(p)
     p.configure_voices(V)
     for m, f, v in per_voice(ids):
         p.set_voice_field(m, f, v)
-    fr, mix = p.render(1024)
+    fr, mix = p.render(1024, flags=flags)
     out[name] = p.info()
 st = S.kernel_cache_stats()
 st["info"] = out
@@ -131,7 +132,7 @@ print(json.dumps(st))
 
 @pytest.mark.parametrize("torch_first", [False, True])
 def test_kernels_of_the_baseline_configurations_come_prebuilt(torch_first):
-    """`__graft_entry__.build()` pre-compiles the kernels the BASELINE configurations' default renders use (configs 2 and 4, cfg3_poly) into
+    """`__graft_entry__.build()` pre-compiles the kernels the BASELINE configurations' renders use (config 2, cfg3_poly, config 4's fast kernels) into
     the in-tree disk cache that ships with the library — once per HIP runtime a process may run on: the image's, and the one torch's
     wheel brings when torch is imported first (bench.py's order; round 3's driver line said `jit=compiled` because only the former had
     been built).  A FRESH process of either kind renders them without compiling anything."""

@@ -49,9 +49,16 @@ def test_thirty_seconds_in_one_second_calls(S, oracle, name, flags):
         r = ref[:, s * SR:(s + 1) * SR].astype(np.float64)
         assert np.isfinite(fr).all() and np.isfinite(r).all()
         per_second.append(float((np.abs(fr - r) / np.maximum(np.abs(r), 1.0)).max()))
-    assert "approx[bound" in p.info(), p.info()               # the default flavour, with its derived bound
     worst, head, tail = max(per_second), max(per_second[:10]), max(per_second[-10:])
     assert np.abs(ref).max() > 0.1
+    if name.startswith("cfg4"):
+        # The FM pair's feedback loop runs through a pitch: round 4's default kernels drifted linearly, 4.6e-7 after a second, 1.5e-5 after a
+        # minute (profiles/r05_horizon.json; tools/fm_sensitivity.c: the f32 rounding of the fed-back sine turns any difference into kicks);
+        # the flattener renders such a loop in the exact flavour, which follows the reference's bits for as long as it lasts.
+        assert "approx[exact: unbounded gain" in p.info(), p.info()
+        assert worst <= 3e-7, f"{name} flags {flags}: {worst:.2e}"
+        return
+    assert "approx[bound" in p.info(), p.info()               # the default flavour, with its derived bound
     assert worst <= 1e-5, f"{name} flags {flags}: {worst:.2e} (per second: {['%.1e' % e for e in per_second]})"
     # flat: what the last ten seconds add over the first ten is rounding noise, not a ramp (a ramp that reaches 1e-5 within ten minutes
     # would add 3e-7 in twenty seconds)

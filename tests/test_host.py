@@ -429,7 +429,11 @@ def test_specialised_kernel_versions_oscillators_with_a_bounded_cv(S):
     beta, index = S.p2_voice_params(128)
     p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, beta)
     p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
-    src = p.kernel_source(S.RENDER_NO_FUSION)
+    # (the patch's own feedback loop runs through a pitch: since round 5 its default is the exact flavour — approx.cpp — and the fast kernels,
+    # whose per-wave proofs these are, are what SRACK_RENDER_KEEP_DEFAULT renders)
+    assert "approx[exact: unbounded gain" in p.kernel_source(S.RENDER_NO_FUSION).split("\n", 1)[0]
+    src = p.kernel_source(S.RENDER_NO_FUSION | S.RENDER_KEEP_DEFAULT)
+    assert "approx[kept default: unbounded gain" in src.split("\n", 1)[0]
     # both operators: |cv| <= 1 x |gain|; the modulator's bound rests on the z^-1 ring's stored value being a sine's too
     assert "const float fm_b0 = (1.0f * __builtin_fabsf(m1_c));" in src and "const float fm_b1 = (1.0f * __builtin_fabsf(m4_c));" in src
     assert "fm_lane = fm_lane && __builtin_fabsf(ring6) <= 1.0f;" in src and "m2.pos >= 0.0 && m2.pos < 1.0" in src and "m5.pos >= 0.0 && m5.pos < 1.0" in src
@@ -447,7 +451,7 @@ def test_specialised_kernel_versions_oscillators_with_a_bounded_cv(S):
     q.configure_voices(128)
     q.set_voice_field(qi["mul_fb"], S.MATH_CONSTANT, beta)
     q.set_voice_field(qi["mul_idx"], S.MATH_CONSTANT, index)
-    ring = q.kernel_source(S.RENDER_NO_FUSION)
+    ring = q.kernel_source(S.RENDER_NO_FUSION | S.RENDER_KEEP_DEFAULT)
     assert "fm_run" not in ring and "osc_step(0x10du, m2" in ring and "osc_step(0x110du, m5" in ring
     # an envelope on the index: the bound is the envelope's hull times the gains, its time constants join the vote
     e = S.Patch(48000, 1024, 2)

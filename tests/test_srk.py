@@ -333,12 +333,13 @@ def test_loaded_feedback_ring_with_values_no_sine_has(S, B):
     o.set_output_buffer(ids["osc_m"], 0, saved)
     T, V = (4 if B == 1024 else 3) * B + 100, 70   # (the time-parallel pair takes calls of 4096 samples and more)
     ref, _ = o.render_batch(V, T, [], threads=2)
-    for flags in (4, 5):        # (4: everything per voice — identical voices would otherwise be rendered once, by the control program)
+    for flags in (4 | 64, 5):   # (4: everything per voice — identical voices would otherwise be rendered once, by the control program; 64: the fast
+                                # kernels — a loop through a pitch takes the exact flavour by default since round 5)
         p.configure_voices(V)
         fr = p.render_channels(T, flags)
         # (buffer_size 1024, default mode: the time-parallel pair, which sends a workgroup whose ring holds such values through the
         # recurrence itself for that launch; exact mode and buffer_size 64: the ring kernel and its per-tile check)
-        assert ("kernel=render_fm_pair_block" if (B, flags) == (1024, 4) else "kernel=render_fm_pair_ring") in p.info(), p.info()
+        assert ("kernel=render_fm_pair_block" if (B, flags) == (1024, 4 | 64) else "kernel=render_fm_pair_ring") in p.info(), p.info()
         err = np.abs(fr.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1.0)
         assert err.max() <= 1e-5, (flags, err.max())
 

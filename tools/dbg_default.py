@@ -16,7 +16,7 @@ for seed in [int(a) for a in sys.argv[1 + NOISE:]]:
     ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]
     ref, _ = o.render_batch(V, T, ov, threads=8)
     r64 = ref.astype(np.float64)
-    for flags in (0, 1, 18):
+    for flags in ([int(x) for x in os.environ["DBG_FLAGS"].split(",")] if os.environ.get("DBG_FLAGS") else (0, 1, 18)):
         p = S.Patch(48000, B, 2)
         build(p)
         p.configure_voices(V)

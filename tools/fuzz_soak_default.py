@@ -41,7 +41,7 @@ for seed in range(lo, hi):
         e = float(err.max()) if err.size else 0.0
         if e > 1e-5 or not mask_same:
             n_bad += 1
-            worst.append((seed, flags, e, float((err > 1e-5).mean()) if err.size else 0.0, mask_same, "exact" if (p.info().find("kernel=") >= 0 and False) else ""))
+            worst.append((seed, flags, e, float((err > 1e-5).mean()) if err.size else 0.0, bool(mask_same), "exact" if (p.info().find("kernel=") >= 0 and False) else ""))
 print(f"default modes, seeds {lo}..{hi - 1} noise={noise}: {n} renders, {n_bad} leave the 1e-5 band somewhere, {time.time() - t0:.0f} s")
 seeds = sorted(set(w[0] for w in worst))
 print(f"  {len(seeds)} patches: {seeds[:60]}")
