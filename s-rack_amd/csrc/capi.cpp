@@ -779,6 +779,9 @@ int srack_device_alloc(void** d_ptr, size_t bytes)
     return guarded([&]() -> int {
         if (!d_ptr) return SRACK_ERR_INVALID;
         HIP_TRY_C(hipMalloc(d_ptr, bytes));
+#if defined(SRK_POISON) && SRK_POISON
+        HIP_TRY_C(hipMemset(*d_ptr, 0xff, bytes));
+#endif
         return SRACK_OK;
     });
 }

@@ -450,6 +450,9 @@ static int upload_program(PatchHandle& h)
     return rc;
 }
 
+#ifndef SRK_POISON
+#define SRK_POISON 0
+#endif
 static int grow(float*& p, size_t& have, size_t need)
 {
     if (need <= have) return SRACK_OK;
@@ -457,6 +460,9 @@ static int grow(float*& p, size_t& have, size_t need)
     p = nullptr;
     have = 0;
     HIP_TRY(hipMalloc(&p, need));
+#if SRK_POISON  // (debug build, tools/: scratch buffers start as NaNs — whatever reads a word nobody wrote shows in the output)
+    HIP_TRY(hipMemset(p, 0xff, need));
+#endif
     have = need;
     return SRACK_OK;
 }
@@ -985,7 +991,12 @@ struct Segment {
                 tk.words.assign(n_stages, 0);
                 for (uint32_t s2 = 0; s2 < n_stages; s2++) {
                     tk.words[s2] = h.prog.ctl[s2].table.size();
-                    if (tk.words[s2] > 0) HIP_TRY(hipMalloc(&tk.d_copies[s2], sizeof(uint32_t) * tk.words[s2] * R));
+                    if (tk.words[s2] > 0) {
+                        HIP_TRY(hipMalloc(&tk.d_copies[s2], sizeof(uint32_t) * tk.words[s2] * R));
+#if SRK_POISON
+                        HIP_TRY(hipMemset(tk.d_copies[s2], 0xff, sizeof(uint32_t) * tk.words[s2] * R));
+#endif
+                    }
                 }
             }
             tk.on = true;

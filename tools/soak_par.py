@@ -47,3 +47,20 @@ print(f"soak {tag}: seeds {lo}..{hi - 1} ({merged['seeds_done']} done) VT={merge
       f"{merged['renders']} renders, {merged['bad']} outside the band, failed workers {merged['failed_workers']}, {merged['wall_s']:.0f} s", flush=True)
 for w in sorted(merged["worst"], key=lambda x: -x[2])[:20]:
     print("   seed %d flags %d: max rel err %.2e, %.5f of the samples outside, masks equal %s" % tuple(w[:5]), flush=True)
+# Whatever was flagged is rendered again ALONE, one process, the device otherwise idle: a structural violation of the contract reproduces;
+# what only shows while two dozen processes share the device (pass A of round 5 had such) does not.
+flagged = sorted(set(int(w[0]) for w in merged["worst"]))
+if flagged and script.endswith("fuzz_soak_default.py"):
+    import re
+    env = dict(os.environ, DBG_FLAGS="34,38" if os.environ.get("FUZZ_SPECIAL") else "0,2,4")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg_default.py")] + (["noise"] if extra else []) + [str(x) for x in flagged[:40]],
+                       env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    again = {}
+    for m in re.finditer(r"seed (\d+) flags (\d+): max ([0-9.e+-]+|nan)", r.stdout):
+        e = float(m.group(3))
+        again[int(m.group(1))] = max(again.get(int(m.group(1)), 0.0), e if e == e else 9.9)
+    repro = sorted(s for s, e in again.items() if e > 1e-5)
+    merged["flagged"], merged["rerun_alone"], merged["reproduced_alone"] = flagged, again, repro
+    json.dump(merged, open(os.path.join(out_dir, f"soak_{tag}.json"), "w"), indent=1)
+    print(f"   flagged {len(flagged)} patches; rendered alone afterwards ({len(again)} of them): {len(repro)} reproduce {repro[:20]}", flush=True)
+    open(os.path.join(out_dir, f"soak_{tag}_rerun.log"), "w").write(r.stdout + r.stderr[-3000:])
