@@ -365,8 +365,9 @@ class Patch:
         _check(lib.srack_render(self.h, n_samples, d_frames, d_mix, flags, stream))
 
     def info(self):
-        buf = C.create_string_buffer(512)
-        _check(lib.srack_render_info(self.h, buf, 512))
+        n = _check(lib.srack_render_info(self.h, None, 0))   # (the length: a description names every control unit and may pass any fixed size)
+        buf = C.create_string_buffer(n + 1)
+        _check(lib.srack_render_info(self.h, buf, n + 1))
         return buf.value.decode()
 
     def kernel_source(self, flags=0):

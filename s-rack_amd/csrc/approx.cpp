@@ -307,10 +307,14 @@ struct Analysis {
             o = {1.0};
             mv = {(uint32_t)(kJumpAudio | kJumpNoise)};
             break;
-        case SRACK_MOD_FREEVERB:
-            o = {kInf, kInf};  // (24 recirculating delay lines: not bounded here)
+        case SRACK_MOD_FREEVERB: {  // 8 recirculating combs and 4 allpasses per channel: the bound of edge_of() times the louder input
+            const double in = std::max(connected(m, 0) ? in_mag(m, 0) : 0.0, connected(m, 1) ? in_mag(m, 1) : 0.0);
+            const double fb = std::min(std::fabs(mod.fields[SRACK_FREEVERB_ROOM_SIZE]) * 0.28 + 0.7, 0.999);
+            const double gain = mod.fields[SRACK_FREEVERB_FREEZE] != 0.0 ? kInf : std::fabs(mod.fields[SRACK_FREEVERB_DRY]) + 3.0 * std::fabs(mod.fields[SRACK_FREEVERB_WET]) * 8.0 / (1.0 - fb) * 40.0;
+            o = {in == 0.0 ? 0.0 : in * gain, in == 0.0 ? 0.0 : in * gain};
             mv = {any_motion(), any_motion()};
             break;
+        }
         case SRACK_MOD_GRID_SEQUENCER: {
             double note = std::fabs(mod.fields[SRACK_GRIDSEQ_LAST]);
             const double spo = std::max(1.0, field(m, SRACK_GRIDSEQ_STEPS_PER_OCTAVE).lo);
@@ -665,6 +669,18 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
                 for (size_t p = 0; p < P.gain[(size_t)m].size(); p++) P.gain[(size_t)m][p] = std::max(P.gain[(size_t)m][p], G[(size_t)c][(size_t)m][p]);
     }
 
+    // ---- values without a bound: where they overflow, only the reference's own operations reproduce its infinities and NaNs (the default
+    // forms clamp with v_med3, which sends a NaN to -1 where min / max send it to +1; round 4's seed 4386: two mixers feeding each other
+    // with gains above one) ------------------------------------------------------------------------------------------------------------
+    for (int m = 0; m < n_mod && !P.exact_patch; m++) {
+        if (!live[(size_t)m] || m == g.plan.output) continue;
+        for (size_t p = 0; p < A.mag[(size_t)m].size(); p++)
+            if (A.port_is_live(m, (int)p) && A.mag[(size_t)m][p] == kInf) {
+                P.exact_patch = true;
+                P.why = "unbounded values at module " + std::to_string(m) + " port " + std::to_string(p);
+                break;
+            }
+    }
     // ---- an unbounded gain behind a module that has no exact form of its own in the default mode ---------------------------------------
     for (int m = 0; m < n_mod && !P.exact_patch; m++) {
         if (!live[(size_t)m]) continue;

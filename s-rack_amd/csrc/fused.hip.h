@@ -281,9 +281,6 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
 // ---- fused voice chain, envelope from a control track (P1 after uniform hoisting) ---------------------
 // OSC_A.<port> -> VCF.<port> -> VCA <- track[t]; the track sample is wave-uniform (scalar load, SGPR operand).
 // The loop body is one basic block: the filter chain of sample t interleaves with the oscillator of t+1.
-#ifndef SRK_FLAGSHIP_SPEC
-#define SRK_FLAGSHIP_SPEC 0   // (experiment, notes/r05.md: the flagship's speculative clamp-free tile)
-#endif
 template <uint32_t kOscAPort, uint32_t kVcfPort, bool kExact, int kOut>
 __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, ChainRoles r, CtlWork co)
 {
@@ -394,40 +391,6 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
             emit_flush<kOut>(em, mix_tile, t0, n, V);
             continue;
         }
-#if SRK_FLAGSHIP_SPEC
-        // Speculative tile (default mode, fixed-point saw, lowpass port): the 32 samples with the ladder's states b1 ... b4 unclamped and a
-        // running maximum of their magnitudes instead — two v_max3 where four v_med3 were.  If no lane's maximum passed 1, every clamp was
-        // the identity: the same bits, and the tile is done; otherwise the state is put back and the tile runs again in the clamped form.
-        if (kFixed && kVcfPort == VCF_OUT_LP && n == kMixRows) {
-            const VcfRegs sv_0 = sv;
-            const FOsc osc_0 = fa_osc;
-            const float x_0 = x;
-            const uint32_t lo_0 = fpos_lo, hi_0 = fpos_hi, soff_0 = em.soff;
-            float peak = 0.0f;
-#pragma unroll 32
-            for (int i = 0; i < kMixRows; i++) {
-                const float env = env_s[t0 + (uint32_t)i];
-                float y;
-                vcf_step_unclamped(sv, x, peak, y);
-                fpos_lo = fa_osc.lo;
-                fpos_hi = fa_osc.hi;
-                x = fosc_saw(fa_osc);
-                const bool cv_pos = (uint32_t)(__float_as_int(env) - 1) < 0x7f800000u;
-                const float o = (negative || cv_pos) ? y * env : 0.0f;
-                emit_put<kOut>(em, mix_tile, o, i, V);
-            }
-            if (__builtin_amdgcn_ballot_w64(!(peak <= 1.0f)) == 0) {
-                emit_flush<kOut>(em, mix_tile, t0, n, V);
-                continue;
-            }
-            sv = sv_0;
-            fa_osc = osc_0;
-            x = x_0;
-            fpos_lo = lo_0;
-            fpos_hi = hi_0;
-            em.soff = soff_0;
-        }
-#endif
         auto sample = [&](int i) {
             const float env = env_s[t0 + (uint32_t)i];
             if (kExact) {

@@ -1189,26 +1189,6 @@ SRK_DEV void vcf_step(VcfRegs& s, float input, float& lowpass, float& bandpass, 
     bandpass = 3.0f * (s.b3 - s.b4);
 }
 
-// The contracted ladder WITHOUT the clamps of b1 ... b4 (b0's stays: `input - q b4` does leave [-1, 1]), and the running maximum of what they
-// would have clamped.  While that maximum stays <= 1 every clamp was the identity and the step is bit for bit vcf_step<true>; a caller runs a
-// tile of samples this way and repeats it with the clamps if any lane's maximum says otherwise (fused.hip.h, the flagship's speculative tile).
-SRK_DEV void vcf_step_unclamped(VcfRegs& s, float input, float& peak, float& lowpass)
-{
-    input = __builtin_fmaf(-s.q, s.b4, input);
-    float t1 = s.b1;
-    s.b1 = __builtin_fmaf(input + s.b0, s.p, -(s.b1 * s.f));
-    float t2 = s.b2;
-    s.b2 = __builtin_fmaf(s.b1 + t1, s.p, -(s.b2 * s.f));
-    t1 = s.b3;
-    s.b3 = __builtin_fmaf(s.b2 + t2, s.p, -(s.b3 * s.f));
-    s.b4 = __builtin_fmaf(s.b3 + t1, s.p, -(s.b4 * s.f));
-    s.b4 = __builtin_fmaf(-(s.b4 * s.b4 * s.b4), 0.166667f, s.b4);
-    s.b0 = clamp1<true>(input);
-    peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fabsf(s.b1)), __builtin_fabsf(s.b2));  // v_max3_f32 with |.| source modifiers
-    peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fabsf(s.b3)), __builtin_fabsf(s.b4));
-    lowpass = s.b4;
-}
-
 // No lane of the wave holds a NaN (or an infinity) in the filter's state or coefficients: with a finite input every later
 // value is finite too (the states are clamped, the arithmetic is sums and products of bounded numbers).
 SRK_DEV bool vcf_nan_free(const VcfRegs& s)

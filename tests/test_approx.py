@@ -275,11 +275,23 @@ def test_cycles_converge_to_their_geometric_series_or_diverge(probe):
     g, osc, a = loop(0.96)      # 25: the f32 PolyBLEP's 2.4e-7 becomes 6e-6
     r = g.run(probe)
     assert r["gain"][osc][SAW] == pytest.approx(25.0, rel=2e-2) and r["exact_blep"][osc] == 1
-    g, osc, a = loop(1.0)       # round 4's seed 40913: gain exactly one — an integrator
+    g, osc, a = loop(1.0)       # round 4's seed 40913: gain exactly one — an integrator: the gain AND the values have no bound
     r = g.run(probe)
-    assert r["gain"][osc][SAW] == float("inf") and r["exact_blep"][osc] == 1 and not r["exact_patch"]
-    g, osc, a = loop(1.2)       # seed 4386: two mixers feeding each other with gains above one
-    assert g.run(probe)["gain"][osc][SAW] == float("inf")
+    assert r["gain"][osc][SAW] == float("inf") and r["exact_blep"][osc] == 1 and r["exact_patch"] and "unbounded values" in r["why"]
+    g, osc, a = loop(1.2)       # seed 4386: two mixers feeding each other with gains above one (its infinities and NaNs are the reference's only in the exact flavour)
+    r = g.run(probe)
+    assert r["gain"][osc][SAW] == float("inf") and r["exact_patch"]
+    # a loop of gain one whose values ARE bounded — a ladder's lowpass in it, clamped to [-1, 1]: unbounded gain, and the saw in front takes its
+    # exact form; nothing in the patch lacks one, so the flavour stays
+    g, (osc, add, sub, vcf, out) = chain(OSC, MATH, MATH, VCF)
+    g.set_field(sub, W.MATH_OPERATION, W.MATH_SUBTRACT)
+    g.connect(osc, SAW, add, 1)
+    g.connect(add, 0, sub, 0)
+    g.connect(sub, 0, vcf, 0)
+    g.connect(vcf, 0, add, 0)
+    g.connect(add, 0, out, 0)
+    r = g.run(probe)
+    assert r["gain"][osc][SAW] == float("inf") and r["exact_blep"][osc] == 1 and r["literal"][vcf] == 1 and not r["exact_patch"]
 
 
 def test_a_cycle_through_an_event_input_is_unbounded(probe):

@@ -1299,7 +1299,9 @@ def test_nonlinear_edge_cases_on_gpu(S, oracle, flags):
         return
     if flags & 32:
         assert "kernel=render_specialized" in p.info() and "powf_pos_loose" not in p.info()
-        assert re.search(r"nonlin_step\(0x[0-9a-f]*2[0-9a-f]{2}u", p.kernel_source(flags))      # NONLIN_LOOSE is what ran
+        # (which form of the power runs is approx.cpp's call — tests/test_approx.py; with bases up to 3 and exponents from -40 to 40 the values
+        # have no bound, and the patch is rendered in the exact flavour: "approx[exact: unbounded values ...")
+        assert "approx[exact: unbounded values" in p.info(), p.info()
     # The default mode's saw is the oracle's within 1e-7, and a power is as sensitive to its base as it likes: x^0.5 at a zero crossing
     # turns 1e-7 into 3e-4, x^40 multiplies a relative 1e-7 by 40.  The bar is the contract's where the power is well conditioned (the
     # base — the same for every voice: tapped from the oracle — at least 0.02 from zero); everywhere: finite where the oracle is but at

@@ -762,11 +762,11 @@ def test_exp2_fast10_coefficients_in_the_header():
 
 
 def test_cycle_rules_of_the_flattener(S):
-    """approx.cpp, the cycles: an approximated producer that FEEDS a cycle whose loop gain is one or more — an Add <-> Subtract pair, an
-    integrator; the same pair with a ladder in it — gets the exact PolyBLEP itself (its epsilon times an unbounded gain), the ladder on the cycle
-    the literal form, and as a constant-pitch saw has an exact form of its own the patch stays in the default flavour; the same cycle behind an
-    oscillator whose PITCH moves (2^cv by polynomial: no exact form of its own) turns the whole patch exact; the same saw into no cycle keeps
-    the fast form."""
+    """approx.cpp, the cycles: an Add <-> Subtract pair is an integrator — neither its gain nor its VALUES have a bound: the exact flavour; the
+    same pair with a ladder in it (whose lowpass is clamped: bounded values, unbounded gain): the saw that feeds it gets the exact PolyBLEP (its
+    epsilon times that gain), the ladder the literal form, and as a constant-pitch saw has an exact form of its own the patch stays in the
+    default flavour — unless an oscillator whose PITCH moves feeds the loop (2^cv by polynomial: no exact form of its own): the whole patch
+    exact; the same saw into no cycle keeps the fast form."""
     import re
 
     def source(wire_cycle, filter_on_cycle, vibrato=False):
@@ -795,9 +795,9 @@ def test_cycle_rules_of_the_flattener(S):
     plain = source(False, False)
     assert "fosc_saw" in plain and not flags_of(plain) and "approx[bound" in plain
     fed = source(True, False)
-    assert "fosc_saw" not in fed and [f & (EXACT | EXACT_BLEP) for f in flags_of(fed)] == [EXACT_BLEP]
+    assert "approx[exact: unbounded values" in fed and "fosc_saw" not in fed
     ladder = source(True, True)
     assert "vcf_run<true>" not in ladder and "fosc_saw" not in ladder and [f & (EXACT | EXACT_BLEP) for f in flags_of(ladder)] == [EXACT_BLEP]
-    moving = source(True, False, vibrato=True)
+    moving = source(True, True, vibrato=True)
     assert "approx[exact: unbounded gain" in moving and "fosc_saw" not in moving
     assert all(f & EXACT for f in flags_of(moving)) and flags_of(moving)   # every oscillator in the exact flavour

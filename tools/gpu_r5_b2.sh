@@ -5,6 +5,7 @@
 set -u
 OUT=gpurun_out/r5; mkdir -p $OUT
 W=${SOAK_WORKERS:-16}
+( timeout 1500 python -m pytest tests -m gpu -q -n 8 --timeout 1200 ) > $OUT/b2_tests.log 2>&1; echo "== tests rc=$?"; tail -12 $OUT/b2_tests.log | cut -c1-300
 ( SOAK_VT=16,48000 SOAK_TIMEOUT=1700 timeout 1800 python tools/soak_par.py new_1s 50000 60000 $W ) > $OUT/b2_soak_1s.log 2>&1; echo "== soak 1s rc=$?"; tail -12 $OUT/b2_soak_1s.log | cut -c1-230
 ( SOAK_VT=200,6000 SOAK_TIMEOUT=900 timeout 1000 python tools/soak_par.py new_v200 60000 70000 $W ) > $OUT/b2_soak_v200.log 2>&1; echo "== soak 200x6000 rc=$?"; tail -12 $OUT/b2_soak_v200.log | cut -c1-230
 ( SOAK_VT=16,480000 SOAK_TIMEOUT=1500 timeout 1600 python tools/soak_par.py new_10s 70000 71000 $W ) > $OUT/b2_soak_10s.log 2>&1; echo "== soak 10s rc=$?"; tail -12 $OUT/b2_soak_10s.log | cut -c1-230
