@@ -361,8 +361,8 @@ def cpu_baseline(S, workload, n_samples=48000):
 # per-voice variant of the headline, BASELINE.json configs[1] and configs[3] — the other single-GPU configurations —
 KEEP_DEFAULT = 64  # SRACK_RENDER_KEEP_DEFAULT
 SIDE_CONFIGS = (("cfg3_exact", "cfg3", 1), ("cfg3_poly", "cfg3_poly", 0), ("cfg2", "cfg2", 0),
-                # config 4 as the library renders it by default — the exact flavour: its feedback loop runs through a pitch, where only the
-                # reference's own bits follow the reference for longer than seconds (csrc/approx.cpp; profiles/r05_horizon.json) — and
+                # config 4 as the library renders it by default — its modulator exact as a whole: the feedback loop runs through a pitch, where only
+                # the reference's own bits follow the reference for longer than seconds (csrc/approx.cpp; profiles/r05_horizon.json) — and
                 # with the fast kernels a host may ask for (KEEP_DEFAULT: within the contract for ~30 s); the same at the app's block size
                 ("cfg4", "cfg4", 0), ("cfg4_fast", "cfg4", KEEP_DEFAULT), ("cfg4_b1024", "cfg4_b1024", 0), ("cfg4_b1024_fast", "cfg4_b1024", KEEP_DEFAULT),
                 # the workloads of scope rows (f)1 and (f)4 (two output planes each)
@@ -442,6 +442,10 @@ def profiled_traffic(kernel_name, workload, flags, V, T):
 def arithmetic_note(flags, info=""):
     """What the render mode computes in, where it is not the reference's own operation sequence.  `info`: srack_render_info —
     "approx[exact: ...]" where the flattener's error bound gave the patch the exact flavour although default mode was asked for."""
+    if "; exact osc " in info and not flags & 1:
+        return ("default mode with oscillator(s) " + info.split("; exact osc ")[1].split("]")[0] + " evaluated exactly as a whole — 2^cv by the host libm's pow operation for operation, the "
+                "reference's sine, f64 PolyBLEP: bit-identical to the CPU tick — because the flattener's error bound finds an unbounded gain behind them (csrc/approx.cpp: "
+                "config 4's feedback loop runs through a pitch); everything else: " + arithmetic_note(flags))
     if flags & 1 or "approx[exact" in info:
         return (("exact flavour by the flattener's error bound (csrc/approx.cpp: " + info.split("approx[exact: ")[1].split("]")[0] + "): " if "approx[exact" in info else "") + "exact mode: the reference's operations one by one — f64 phase / 2^cv (the host libm's pow, operation for operation) / PolyBLEP with its f64 division, the ladder "
                 "uncontracted with min/max clamps; frames bit-identical to the CPU tick (oscillator.rs:108-158, filter.rs:58-92)")

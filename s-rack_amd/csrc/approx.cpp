@@ -643,6 +643,7 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
 {
     const int n_mod = (int)g.modules.size();
     ApproxPlan P;
+    P.osc_exact.assign((size_t)n_mod, 0);
     P.exact_blep.assign((size_t)n_mod, 0);
     P.literal.assign((size_t)n_mod, 0);
     P.sine_loose.assign((size_t)n_mod, 0);
@@ -681,18 +682,25 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
                 break;
             }
     }
-    // ---- an unbounded gain behind a module that has no exact form of its own in the default mode ---------------------------------------
-    for (int m = 0; m < n_mod && !P.exact_patch; m++) {
+    // ---- an unbounded gain behind a module whose default evaluation is not the reference's to the bit -------------------------------------
+    // An oscillator whose pitch moves (2^cv by polynomial) or whose sine is heard there (the polynomial sine: the reference's own but for 3
+    // roundings in a million) is evaluated exactly as a whole — that oscillator: the libm's pow, the reference's sine, f64 PolyBLEP
+    // (config 4: the modulator inside its feedback loop; the carrier behind it keeps the default forms).  The sample player's pitch has no
+    // such form: the whole patch goes exact.
+    for (int m = 0; m < n_mod; m++) {
         if (!live[(size_t)m]) continue;
         const Module& mod = g.modules[(size_t)m];
-        bool residual = false;
-        if (mod.type == SRACK_MOD_OSCILLATOR) residual = mod.in[SRACK_OSC_IN_CV].src >= 0 || A.port_is_live(m, SRACK_OSC_OUT_SINE);  // 2^cv / the sine by polynomial
-        if (mod.type == SRACK_MOD_SAMPLE) residual = mod.in[SRACK_SAMPLE_IN_CV].src >= 0;
-        if (!residual) continue;
+        const bool osc = mod.type == SRACK_MOD_OSCILLATOR && (mod.in[SRACK_OSC_IN_CV].src >= 0 || A.port_is_live(m, SRACK_OSC_OUT_SINE));
+        const bool player = mod.type == SRACK_MOD_SAMPLE && mod.in[SRACK_SAMPLE_IN_CV].src >= 0;
+        if (!osc && !player) continue;
         for (size_t p = 0; p < P.gain[(size_t)m].size(); p++)
             if (A.port_is_live(m, (int)p) && P.gain[(size_t)m][p] == kInf) {
-                P.exact_patch = true;
-                P.why = "unbounded gain behind module " + std::to_string(m) + " port " + std::to_string(p);
+                if (osc) {
+                    P.osc_exact[(size_t)m] = 1;
+                } else if (!P.exact_patch) {
+                    P.exact_patch = true;
+                    P.why = "unbounded gain behind module " + std::to_string(m) + " port " + std::to_string(p);
+                }
             }
     }
     // (the decisions below are still made: SRACK_RENDER_KEEP_DEFAULT renders such a patch in the default flavour, module by module)
@@ -769,9 +777,11 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
         case kNonlin: P.nonlin_loose[(size_t)f.module] = f.taken; break;
         }
     }
-    // a fixed-point phase only makes sense with the f32 PolyBLEP (the kernels' fixed-point saw is that form)
-    for (int m = 0; m < n_mod; m++)
+    // a fixed-point phase only makes sense with the f32 PolyBLEP (the kernels' fixed-point saw is that form); an exact oscillator has no other form
+    for (int m = 0; m < n_mod; m++) {
         if (P.exact_blep[(size_t)m]) P.saw_fixed[(size_t)m] = 0;
+        if (P.osc_exact[(size_t)m]) P.saw_fixed[(size_t)m] = P.sine_loose[(size_t)m] = 0;  // (exact_blep stays: what SRACK_RENDER_KEEP_DEFAULT falls back on)
+    }
     for (int c = 0; c < n_ch; c++) {
         double s = 0.0;
         for (const Form& f : forms)

@@ -8,8 +8,9 @@
 // backward pass over the graph with a table per module type (approx.cpp): arithmetic passes errors on with its coefficients, a filter
 // with the L1 norm of its impulse response (computed from its own coefficients: a ladder near self-oscillation has none), a pitch input
 // INTEGRATES (gain ~ the render's length), an event input THRESHOLDS (gain ~ 1 / the probability that matters), a cycle multiplies by
-// 1 / (1 - loop gain) or diverges.  A patch where a gain is unbounded in front of something the default mode cannot evaluate exactly
-// module by module is rendered in the exact flavour altogether.
+// 1 / (1 - loop gain) or diverges.  Where a gain is unbounded every form in front of it is denied — an oscillator whose pitch moves, or whose
+// sine is heard there, is then evaluated exactly as a whole (2^cv by the libm's pow, the reference's sine) —, and a patch whose VALUES have no
+// bound, or with an unbounded gain behind a module without an exact form of its own, is rendered in the exact flavour altogether.
 #pragma once
 #include <string>
 #include <vector>
@@ -23,6 +24,7 @@ constexpr double kApproxHorizon = 2.88e7;  // samples the bound is derived for: 
 
 struct ApproxPlan {
     // decisions, per module
+    std::vector<char> osc_exact;     // oscillator: all of it as the reference spells it — 2^cv by the libm's pow, its sine, f64 PolyBLEP (OSC_EXACT on that op)
     std::vector<char> exact_blep;    // oscillator: f64 PolyBLEP (OSC_EXACT_BLEP)
     std::vector<char> literal;       // filter: the literal ladder (VCF_LITERAL)
     std::vector<char> sine_loose;    // oscillator: f32 sine (OSC_SINE_LOOSE)

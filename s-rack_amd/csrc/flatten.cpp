@@ -82,6 +82,7 @@ struct Analysis {  // whole-graph facts shared by both programs
     std::vector<char> sine_loose;                    // per oscillator: its sine port cannot reach a pitch input (OSC_SINE_LOOSE)
     std::vector<char> saw_fixed;                     // per oscillator, default mode: its saw can reach neither a pitch input nor a threshold (OSC_FIXED_PHASE where the pitch is constant)
     std::vector<char> nonlin_loose;                  // per NonLinear module: its output cannot reach a pitch input or a threshold (NONLIN_LOOSE)
+    std::vector<char> osc_exact;                     // per oscillator, default mode: evaluated as the reference spells it, all of it (OSC_EXACT on that op only: approx.cpp)
     std::vector<char> exact_src;                     // per oscillator / filter, default mode: an approximated output of it can reach a pitch input
                                                      // (OSC_EXACT_BLEP / VCF_LITERAL)
     std::vector<std::pair<int, int>> tracks;         // (module, port) exported by a control stage
@@ -280,8 +281,8 @@ int Builder::build()
             if (pl & 1u) op.flags |= OSC_OUT_SINE;
             if (pl & 2u) op.flags |= OSC_OUT_SQUARE;
             if (pl & 4u) op.flags |= OSC_OUT_SAW;
-            if (render_flags & SRACK_RENDER_EXACT_OSC) op.flags |= OSC_EXACT;
-            if (A.sine_loose[(size_t)m]) op.flags |= OSC_SINE_LOOSE;
+            if ((render_flags & SRACK_RENDER_EXACT_OSC) || (!A.osc_exact.empty() && A.osc_exact[(size_t)m])) op.flags |= OSC_EXACT;
+            if (A.sine_loose[(size_t)m] && !(op.flags & OSC_EXACT)) op.flags |= OSC_SINE_LOOSE;
             if (A.exact_src[(size_t)m] && !(op.flags & OSC_EXACT)) op.flags |= OSC_EXACT_BLEP;
             op.sample_rate = (double)g.cfg.sample_rate;  // `self.sample_rate as f64`, u16 in the reference
             {   // pos: f64 state, two rows (lo, hi)
@@ -709,6 +710,7 @@ int Builder::build()
     if (!(render_flags & SRACK_RENDER_NO_FUSION)) match_fused(!rings.empty());
     if (is_ctl && !(render_flags & SRACK_RENDER_NO_FUSION) && rings.empty() && H.n_ops == 3 && out.ops[0].kind == OP_OSC &&
         out.ops[1].kind == OP_ADSR && out.ops[2].kind == OP_OUT && (out.ops[0].flags & OSC_CONST_SMALL) && (out.ops[1].flags & ADSR_HAS_GATE) &&
+        (!(out.ops[0].flags & OSC_EXACT) || (render_flags & SRACK_RENDER_EXACT_OSC)) &&
         g.modules[(size_t)out.ops[1].module].in[0].src == out.ops[0].module && out.ops[2].module == out.ops[1].module)
         out.fused = FUSED_CTL_GATE_ENV;  // uniform parameters only (V == 1, no overrides): par_val / delta are used directly
 
@@ -727,6 +729,11 @@ int Builder::build()
 // Oscillators must be OSC_CONST_FAST (or the exact flavour of the same shape), filters have no CV.
 void Builder::match_fused(bool has_rings)
 {
+    // (the fused kernels take the exact flavour as ONE template parameter: a program in which single oscillators are exact — approx.cpp's
+    // answer to an unbounded gain — is the general path's)
+    if (!(render_flags & SRACK_RENDER_EXACT_OSC))
+        for (const DevOp& op : out.ops)
+            if (op.kind == OP_OSC && (op.flags & OSC_EXACT)) return;
     if (has_rings) {
         // 2-operator FM with a one-sample feedback edge (patch P2 at buffer_size 1):
         //   DELAY_RD -> MATH_FB -> OSC_M -> DELAY_WR ; OSC_M -> MATH_IDX -> OSC_C -> OUT ; only sine ports, no sync
@@ -964,18 +971,26 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
         A.sine_loose = plan.sine_loose;
         A.nonlin_loose = plan.nonlin_loose;
         A.saw_fixed = plan.saw_fixed;
+        A.osc_exact = plan.osc_exact;
         A.exact_src.assign((size_t)n_mod, 0);
         for (int m = 0; m < n_mod; m++) A.exact_src[(size_t)m] = plan.exact_blep[(size_t)m] || plan.literal[(size_t)m];
-        if (plan.exact_patch && !(render_flags & SRACK_RENDER_EXACT_OSC) && (render_flags & SRACK_RENDER_KEEP_DEFAULT)) {
-            out.approx_note = "kept default: " + plan.why;
-        } else if (plan.exact_patch && !(render_flags & SRACK_RENDER_EXACT_OSC)) {
+        std::string oscs;  // the oscillators that are exact as a whole
+        for (int m = 0; m < n_mod; m++)
+            if (plan.osc_exact[(size_t)m]) oscs += (oscs.empty() ? "" : ",") + std::to_string(m);
+        if (render_flags & SRACK_RENDER_EXACT_OSC) {
+            // (asked for: nothing to decide)
+        } else if ((render_flags & SRACK_RENDER_KEEP_DEFAULT) && (plan.exact_patch || !oscs.empty())) {
+            std::fill(A.osc_exact.begin(), A.osc_exact.end(), 0);
+            out.approx_note = "kept default: " + (plan.exact_patch ? plan.why : "unbounded gain behind oscillator " + oscs);
+        } else if (plan.exact_patch) {
             render_flags |= SRACK_RENDER_EXACT_OSC;
             std::fill(A.sine_loose.begin(), A.sine_loose.end(), 0);  // (the exact oscillator has one sine)
             out.approx_note = "exact: " + plan.why;
-        } else if (!(render_flags & SRACK_RENDER_EXACT_OSC)) {
+        } else {
             char buf[64];
             snprintf(buf, sizeof buf, "bound %.1e", plan.bound);
             out.approx_note = buf;
+            if (!oscs.empty()) out.approx_note += "; exact osc " + oscs;
         }
     }
     out.effective_flags = render_flags;

@@ -217,7 +217,7 @@ __device__ __noinline__ void tile_osc_general(const Ctx c_v, COp& op_v)
     OscSetup u = osc_setup(c, op);
     const Port in[2] = {in_port(c, op.in_slot[0]), in_port(c, op.in_slot[1])};
     const Port out[3] = {out_port(c, op.out_slot[0]), out_port(c, op.out_slot[1]), out_port(c, op.out_slot[2])};
-    const uint32_t f = kExact ? (fl | OSC_EXACT) : (fl & ~OSC_EXACT);
+    const uint32_t f = kExact ? (fl | OSC_EXACT) : fl;  // (default flavour: single oscillators may still be exact — the flattener's OSC_EXACT on that op)
     tile_run<2, 3>(c, in, out, [&](const float* x, float* y) {
         y[0] = y[1] = y[2] = 0.0f;
         osc_step(f, u.s, u.k, x[0], x[1], y[0], y[1], y[2]);
@@ -232,7 +232,7 @@ SRK_DEV void tile_osc(const Ctx& c, COp& op)
     const uint32_t ports = fl & (OSC_OUT_SINE | OSC_OUT_SQUARE | OSC_OUT_SAW);
     if (fl & OSC_CONST_FAST)
         tile_osc_const<kExact>(c, op);
-    else if (!kExact && (fl & (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_HAS_SYNC | OSC_AA | OSC_EXACT_BLEP)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1)))
+    else if (!kExact && (fl & (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_HAS_SYNC | OSC_AA | OSC_EXACT_BLEP | OSC_EXACT)) == (OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA) && ports && !(ports & (ports - 1)))
         tile_osc_stepwise<kExact>(c, op);
     else
         tile_osc_general<kExact>(c, op);

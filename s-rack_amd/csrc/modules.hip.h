@@ -472,6 +472,35 @@ SRK_DEV float sine_fast(double pos)
     const double p = __builtin_fma(b1, z4, b0);
     return __uint_as_float(__float_as_uint((float)(p * x)) ^ sign);  // (xor, not copysign: a phase outside [0, 1) — only a host can store one — folds to a negative x)
 }
+// The reference's own sine, `(pos * PI * 2.0).sin() as f32` (oscillator.rs:133), bit for bit — through the polynomial wherever that is decidable.
+// The polynomial's value y is within 8e-14 y of sin(2 pi pos) (tests/test_oracle.py evaluates it against mpmath); the reference's f64 sine is
+// within 1.6e-15 + 1.2e-16 y of it (one rounding of pos * PI, the libm's sub-ulp error).  Both round to the SAME f32 unless y lies within the
+// sum of those of a rounding boundary: that is tested here (y minus its f32 rounding, against half an ulp of that f32), and only the lanes
+// that fail — 3 in a million, and the neighbourhoods of the sine's zeros, where the reference's value is its argument's rounding error —
+// evaluate the reference's expression itself (ocml's sin, as the exact flavour did for every sample until round 5: 27.5 -> ms per step on
+// config 4).  A phase outside [0, 1) — only a host can store one — takes that way too.
+SRK_DEV float sine_exact(double pos)
+{
+    uint32_t sign;
+    const double x = sine_fold(pos, sign);
+    const double z = x * x;
+    const double a01 = __builtin_fma(-41.34170223990684, z, 6.283185307179272);
+    const double a23 = __builtin_fma(-76.70584757807868, z, 81.60524914955879);
+    const double a45 = __builtin_fma(-15.081496425342264, z, 42.05813586028645);
+    const double z2 = z * z;
+    const double b0 = __builtin_fma(a23, z2, a01);
+    const double b1 = __builtin_fma(3.6659216216293173, z2, a45);
+    const double z4 = z2 * z2;
+    const double y = __builtin_fma(b1, z4, b0) * x;        // >= 0 for a pos in [0, 1)
+    float r = (float)y;
+    const uint32_t e = __float_as_uint(r) & 0x7f800000u;   // r = 1.m x 2^(E - 127): half an ulp is 2^(E - 151)
+    const double room = (double)__uint_as_float(e - (24u << 23)) - __builtin_fabs(y - (double)r);   // distance of y to the nearer rounding boundary
+    // (an r that is a power of two has the narrower spacing below it: not decided here either)
+    const bool sure = e >= (64u << 23) && (__float_as_uint(r) & 0x007fffffu) != 0u && pos >= 0.0 && pos < 1.0 && room > __builtin_fma(1.0e-13, y, 2.0e-15);
+    if (!sure) return (float)sin(pos * 3.14159265358979323846 * 2.0);
+    return __uint_as_float(__float_as_uint(r) ^ sign);
+}
+
 // The same sine for a port whose value cannot reach a pitch input (host-proved, OSC_SINE_LOOSE): nothing integrates its error,
 // so f32 arithmetic after the exact f64 fold is inside the 1e-5 contract (max error 2e-7: a degree-9 polynomial in f32).
 SRK_DEV float sine_loose(double pos)
@@ -563,7 +592,7 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
     }
     if (flags & OSC_EXACT) {
         const bool aa = flags & OSC_AA;
-        if (flags & OSC_OUT_SINE) sine = (float)sin(pos * 3.14159265358979323846 * 2.0);
+        if (flags & OSC_OUT_SINE) sine = sine_exact(pos);
         if (flags & OSC_OUT_SQUARE)
             square = (pos < 0.5 ? -1.0f : 1.0f) - (aa ? (float)(poly_blep_exact(pos, delta) - poly_blep_exact(fmod1(pos + 0.5), delta)) : 0.0f);
         if (flags & OSC_OUT_SAW) saw = ((float)pos * 2.0f - 1.0f) - (aa ? (float)poly_blep_exact(pos, delta) : 0.0f);

@@ -52,6 +52,7 @@ int main()
         o << "], ";
     };
     o << "{";
+    flags("osc_exact", P.osc_exact);
     flags("exact_blep", P.exact_blep);
     flags("literal", P.literal);
     flags("sine_loose", P.sine_loose);

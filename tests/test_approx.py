@@ -226,8 +226,8 @@ def test_a_cutoff_that_jumps(probe):
 
 def test_a_ladder_near_self_oscillation(probe):
     """The L1 norm is computed from the filter's own coefficients over the cutoffs it can reach: resonance 0.85 at cutoff 0.2 is 11 (fine), 0.95
-    does not decay — an unbounded gain: the saw in front takes its exact form, and an oscillator whose pitch moves (no exact form of its
-    own in the default mode) turns the patch exact (round 2's finding: resonance >= 0.928 left the band in a few voices, up to 3e-3)."""
+    does not decay — an unbounded gain: the saw in front takes its exact form, and an oscillator whose pitch moves is evaluated exactly as a
+    whole (round 2's finding: resonance >= 0.928 left the band in a few voices, up to 3e-3)."""
     def patch(res, vibrato=False, per_voice=None):
         g, (osc, vcf, lfo, out) = chain(OSC, VCF, OSC)
         g.set_field(vcf, W.VCF_RES, res)
@@ -246,7 +246,7 @@ def test_a_ladder_near_self_oscillation(probe):
     assert r["literal"][vcf] == 1 and r["exact_blep"][osc] == 1 and r["gain"][osc][SAW] == float("inf") and not r["exact_patch"]
     g, osc, vcf = patch(0.95, vibrato=True)
     r = g.run(probe)
-    assert r["exact_patch"] and "unbounded gain" in r["why"]
+    assert not r["exact_patch"] and r["osc_exact"][osc] == 1 and r["osc_exact"][osc + 2] == 1   # the oscillator AND the LFO whose sine moves its pitch: exact as a whole
     g, osc, vcf = patch(0.5, per_voice=[0.1, 0.96, 0.3])     # one voice is enough
     assert g.run(probe)["literal"][vcf] == 1
 
@@ -302,7 +302,7 @@ def test_a_cycle_through_an_event_input_is_unbounded(probe):
     g.connect(vca, 0, env, 0)          # the envelope's own output (times a sine) is its gate
     g.connect(vca, 0, out, 0)
     r = g.run(probe)
-    assert r["gain"][osc][SINE] == float("inf") and r["exact_patch"]
+    assert r["gain"][osc][SINE] == float("inf") and r["osc_exact"][osc] == 1 and not r["exact_patch"]
 
 
 def test_a_loop_through_a_pitch_is_unbounded(probe):
@@ -311,8 +311,8 @@ def test_a_loop_through_a_pitch_is_unbounded(probe):
     but the sine on its way round is rounded to f32, a phase difference of 1e-12 flips one of those roundings now and then, and each flip
     kicks the pitch by 6e-8: tools/fm_sensitivity.c (the reference's arithmetic twice, one phase off by 1e-12: 1e-7 cycles apart after 35 s)
     and profiles/r05_horizon.json (round 4's default kernels: 4.6e-7 after a second, 1.5e-5 after a minute).  First order is right: the
-    patch is rendered in the exact flavour, which follows the reference bit for bit (same file: 0 for the whole minute); SRACK_RENDER_KEEP_DEFAULT
-    keeps the fast kernels for a host that renders seconds, not minutes."""
+    oscillator in the loop is evaluated exactly, and the render follows the reference bit for bit (same file: 0 for the whole minute);
+    SRACK_RENDER_KEEP_DEFAULT keeps the fast kernels for a host that renders seconds, not minutes."""
     def p2(beta, port=SINE):
         g = Rec(48000, 1, 2)
         ids = W.build_p2(g, beta=beta)
@@ -322,8 +322,10 @@ def test_a_loop_through_a_pitch_is_unbounded(probe):
     for beta, port in ((0.3, SINE), (1.8, SINE), (0.3, SAW)):
         g, ids = p2(beta, port)
         r = g.run(probe)
-        assert r["exact_patch"] and "unbounded gain" in r["why"] and r["gain"][ids["osc_m"]][port] == float("inf")
-        assert r["sine_loose"][ids["osc_c"]] == 1     # (what KEEP_DEFAULT renders with: the carrier's sine goes straight out)
+        # the oscillator inside the loop is exact as a whole (the libm's pow, the reference's sine) — that one; the carrier behind it, which
+        # nothing feeds back, keeps the default forms, and the patch its flavour
+        assert r["gain"][ids["osc_m"]][port] == float("inf") and r["osc_exact"][ids["osc_m"]] == 1 and r["osc_exact"][ids["osc_c"]] == 0
+        assert not r["exact_patch"] and r["sine_loose"][ids["osc_c"]] == 1 and r["sine_loose"][ids["osc_m"]] == 0
     # feed-forward FM — a sine into another oscillator's pitch, no way back — is bounded: the default forms stay
     g, (mod, gain, car, out) = chain(OSC, MATH, OSC)
     g.set_field(gain, W.MATH_OPERATION, W.MATH_MULTIPLY)
@@ -332,7 +334,7 @@ def test_a_loop_through_a_pitch_is_unbounded(probe):
     g.connect(gain, 0, car, 0)
     g.connect(car, SINE, out, 0)
     r = g.run(probe)
-    assert not r["exact_patch"] and r["gain"][mod][SINE] < 1e8
+    assert not r["exact_patch"] and r["gain"][mod][SINE] < 1e8 and sum(r["osc_exact"]) == 0
 
 
 # ---- a waveshaper's slope ------------------------------------------------------------------------------------------------------------------------
@@ -385,8 +387,8 @@ def test_benchmarked_workloads_keep_their_forms(probe, name):
     for m, f, v in overrides(ids):
         g.override(m, f, v)
     r = g.run(probe)
-    if name.startswith("cfg4"):   # the FM pair's feedback loop runs through a pitch: exact flavour (test_a_loop_through_a_pitch_is_unbounded)
-        assert r["exact_patch"] and r["sine_loose"][ids["osc_c"]] == 1 and r["sine_loose"][ids["osc_m"]] == 0
+    if name.startswith("cfg4"):   # the FM pair's feedback loop runs through a pitch: the modulator is exact (test_a_loop_through_a_pitch_is_unbounded)
+        assert not r["exact_patch"] and r["osc_exact"][ids["osc_m"]] == 1 and r["osc_exact"][ids["osc_c"]] == 0 and r["sine_loose"][ids["osc_c"]] == 1
         return
     assert not r["exact_patch"] and r["bound"] < BUDGET and sum(r["exact_blep"]) == 0 and sum(r["literal"]) == 0, r
     if name.startswith("cfg3") or name == "cfg2":

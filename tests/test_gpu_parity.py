@@ -189,7 +189,7 @@ def test_control_units_across_lanes(S, oracle, lfo_val, env, gate_port):
 
 
 # ---- FM patch with a feedback edge (config 4) ---------------------------------------------------------
-@pytest.mark.parametrize("flags", [0, 1, 64])   # (0: since round 5 the exact flavour — a loop through a pitch, approx.cpp; 64 = KEEP_DEFAULT: the fast kernels)
+@pytest.mark.parametrize("flags", [0, 1, 64])   # (0: since round 5 the modulator is exact as a whole — a loop through a pitch, approx.cpp; 64 = KEEP_DEFAULT: the fast kernels)
 @pytest.mark.parametrize("B", [1, 7, 16, 64, 1024])
 def test_p2_feedback_vs_oracle(S, oracle, B, flags):
     T, V = 3000, 70
@@ -206,7 +206,7 @@ def test_p2_feedback_vs_oracle(S, oracle, B, flags):
     out = p.render_channels(T, flags)
     assert_close(out[0], ref[0])
     assert np.abs(out[0]).max() > 0.9
-    assert ("approx[exact: unbounded gain" in p.info()) == (flags == 0) and ("approx[kept default" in p.info()) == (flags == 64), p.info()
+    assert ("; exact osc 0]" in p.info()) == (flags == 0) and ("approx[kept default" in p.info()) == (flags == 64), p.info()
 
 
 @pytest.mark.parametrize("flags", [0, 1, 2])
@@ -280,9 +280,9 @@ def test_fm_pair_sample_loops(S, oracle, B, flags, monkeypatch):
 @pytest.mark.parametrize("B", [1, 1024])
 def test_fm_feedback_gain_above_one_takes_the_exact_flavour(S, oracle, B):
     """A cycle that can amplify iterates whatever approximation enters it: FM feedback with a gain above 1 (2^(1.8 sin) on its own pitch)
-    let the default mode drift to 1.8e-5 within 9000 samples.  The flattener now renders such a patch with the exact flavour (flatten.cpp
-    2b: a multiplication by more than 1 on a cycle): default flags, bit for bit the oracle; config 4's own draw (gains up to 0.4) keeps
-    the default-mode kernels."""
+    let the default mode drift to 1.8e-5 within 9000 samples.  Since round 5 ANY loop through a pitch has its oscillator evaluated exactly as
+    a whole (approx.cpp: the loop's gain has no bound): the modulator follows the reference bit for bit, the carrier behind it keeps the
+    default forms; config 4's own draw (gains up to 0.4) renders the same way, its fast kernels under SRACK_RENDER_KEEP_DEFAULT."""
     V, T = 128, 6000
     rng = np.random.default_rng(5)
     beta, index = rng.uniform(0.6, 1.8, V).astype(np.float32), rng.uniform(0.5, 1.5, V).astype(np.float32)
@@ -296,7 +296,7 @@ def test_fm_feedback_gain_above_one_takes_the_exact_flavour(S, oracle, B):
     for m, f, v in over:
         p.set_voice_field(m, f, v)
     out = p.render_channels(T, 0)
-    assert assert_close(out[0], ref[0]) < 3e-7   # (the sine port: ocml's sin against the libm's — everything else is the reference's to the bit)
+    assert assert_close(out[0], ref[0]) < 5e-7   # (the carrier's sine in f32 after the exact fold, on a phase that is the reference's to 1e-12)
     q = S.Patch(48000, B, 2)
     S.build_p2(q)
     q.configure_voices(V)
@@ -305,7 +305,7 @@ def test_fm_feedback_gain_above_one_takes_the_exact_flavour(S, oracle, B):
     q.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, i2)
     q.render_channels(4096, S.RENDER_KEEP_DEFAULT)   # (round 5: config 4's own draw goes exact by default as well — any loop through a pitch; its fast kernels on request)
     assert ("render_fm_pair_block" in q.info()) if B == 1024 else ("render_fm_pair" in q.info() or "render_specialized" in q.info())
-    assert "render_fm_pair_block" not in p.info() and ("render_fm_pair" in p.info()) and "approx[exact" in p.info()
+    assert "render_fm_pair" not in p.info() and "; exact osc 0]" in p.info(), p.info()   # the general path, the modulator exact as a whole
 
 
 def _envelope_fm(g, S):
@@ -380,7 +380,7 @@ def test_cfg4_full_second_per_voice_params(S, oracle):
             p.configure_voices(V)
             p.set_voice_field(ids["mul_fb"], S.MATH_CONSTANT, beta)
             p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
-            assert assert_close(p.render_channels(T, flags), ref) < (2e-6 if flags == S.RENDER_KEEP_DEFAULT else 3e-7)
+            assert assert_close(p.render_channels(T, flags), ref) < (2e-6 if flags == S.RENDER_KEEP_DEFAULT else 5e-7)
 
 
 def _everything(g):
@@ -773,11 +773,11 @@ def test_cfg3_poly_modes(S, oracle, flags, V, T):
 
 # (since round 3 the kernels bench.py times for this patch: buffer_size 1 — the kernel specialised at run time, whose generator derives
 # the bounded pitch CVs render_fm_pair proves by hand; buffer_size 1024 — the time-parallel pair with its ring in LDS)
-@pytest.mark.parametrize("B,flags,kernel", [(1, 64, "render_specialized"), (1024, 64, "render_fm_pair_block"), (1, 0, "render_fm_pair"), (1024, 0, "render_fm_pair")])
+@pytest.mark.parametrize("B,flags,kernel", [(1, 64, "render_specialized"), (1024, 64, "render_fm_pair_block"), (1, 0, "render_specialized"), (1024, 0, "render_specialized")])
 def test_cfg4_exactly_as_benchmarked(S, oracle, B, flags, kernel):
     """BASELINE config 4 at full size, the workload `bench.py --workload cfg4` (and cfg4_b1024) times: 65 536 voices x 48 000
     samples of the 2-operator FM patch with its feedback edge, per-voice feedback / index (12.6 GB of frames, kept on the device) —
-    flags 0: the exact flavour the flattener gives a loop through a pitch (`cfg4_*` on the bench line); KEEP_DEFAULT: the fast kernels
+    flags 0: the modulator exact as a whole, as the flattener renders a loop through a pitch (`cfg4_*` on the bench line); KEEP_DEFAULT: the fast kernels
     (`cfg4_fast_*`), within the contract for a render of seconds (tests/test_gpu_horizon.py has the minute).  37 sampled voices against the oracle for the whole second — the feedback makes every error an integrated
     one — and the mix against an f64 sum of all the frames."""
     import ctypes as C
@@ -793,7 +793,7 @@ def test_cfg4_exactly_as_benchmarked(S, oracle, B, flags, kernel):
     try:
         p.render_raw(T, d_fr, d_mx, flags, None)
         assert S.lib.srack_device_sync(None) == 0
-        assert "kernel=" + kernel in p.info() and ("approx[kept default" if flags else "approx[exact") in p.info(), p.info()
+        assert "kernel=" + kernel in p.info() and ("approx[kept default" if flags else "; exact osc 0]") in p.info(), p.info()
         pick = np.unique(np.concatenate([np.arange(0, V, 2113), [0, 63, 64, V - 65, V - 64, V - 1]]))
         got = np.empty((T, len(pick)), dtype=np.float32)
         own, scale = np.empty(T), np.empty(T)
@@ -814,7 +814,7 @@ def test_cfg4_exactly_as_benchmarked(S, oracle, B, flags, kernel):
     o = oracle.OraclePatch(48000, B, 2)
     S.build_p2(o)
     ref, _ = o.render_batch(len(pick), T, [(ids["mul_fb"], S.MATH_CONSTANT, beta[pick]), (ids["mul_idx"], S.MATH_CONSTANT, index[pick])], threads=8)
-    assert assert_close(got, ref[0]) < (3e-6 if flags else 3e-7)   # (fast kernels: the carrier's sine is evaluated in f32 after the exact fold: 2e-7, not integrated by anything; exact flavour: ocml's sin against the libm's)
+    assert assert_close(got, ref[0]) < (3e-6 if flags else 5e-7)   # (the carrier's sine is evaluated in f32 after the exact fold: 2e-7, not integrated by anything; with the modulator exact that is all there is)
     assert np.abs(got).max() > 0.9
     assert (np.abs(mix[0].astype(np.float64) - own) <= 1e-5 * np.maximum(scale, 1.0)).all() and np.array_equal(mix[0], mix[1])
 

@@ -431,7 +431,7 @@ def test_specialised_kernel_versions_oscillators_with_a_bounded_cv(S):
     p.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, index)
     # (the patch's own feedback loop runs through a pitch: since round 5 its default is the exact flavour — approx.cpp — and the fast kernels,
     # whose per-wave proofs these are, are what SRACK_RENDER_KEEP_DEFAULT renders)
-    assert "approx[exact: unbounded gain" in p.kernel_source(S.RENDER_NO_FUSION).split("\n", 1)[0]
+    assert "; exact osc 0]" in p.kernel_source(S.RENDER_NO_FUSION).split("\n", 1)[0]   # (the modulator: exact as a whole; the carrier keeps the default forms)
     src = p.kernel_source(S.RENDER_NO_FUSION | S.RENDER_KEEP_DEFAULT)
     assert "approx[kept default: unbounded gain" in src.split("\n", 1)[0]
     # both operators: |cv| <= 1 x |gain|; the modulator's bound rests on the z^-1 ring's stored value being a sine's too
@@ -765,8 +765,8 @@ def test_cycle_rules_of_the_flattener(S):
     """approx.cpp, the cycles: an Add <-> Subtract pair is an integrator — neither its gain nor its VALUES have a bound: the exact flavour; the
     same pair with a ladder in it (whose lowpass is clamped: bounded values, unbounded gain): the saw that feeds it gets the exact PolyBLEP (its
     epsilon times that gain), the ladder the literal form, and as a constant-pitch saw has an exact form of its own the patch stays in the
-    default flavour — unless an oscillator whose PITCH moves feeds the loop (2^cv by polynomial: no exact form of its own): the whole patch
-    exact; the same saw into no cycle keeps the fast form."""
+    default flavour — and an oscillator whose PITCH moves in front of the loop (2^cv by polynomial) is evaluated exactly as a whole, with the
+    LFO that moves it; the same saw into no cycle keeps the fast form."""
     import re
 
     def source(wire_cycle, filter_on_cycle, vibrato=False):
@@ -799,5 +799,5 @@ def test_cycle_rules_of_the_flattener(S):
     ladder = source(True, True)
     assert "vcf_run<true>" not in ladder and "fosc_saw" not in ladder and [f & (EXACT | EXACT_BLEP) for f in flags_of(ladder)] == [EXACT_BLEP]
     moving = source(True, True, vibrato=True)
-    assert "approx[exact: unbounded gain" in moving and "fosc_saw" not in moving
-    assert all(f & EXACT for f in flags_of(moving)) and flags_of(moving)   # every oscillator in the exact flavour
+    assert "; exact osc 0,4]" in moving.split("\n", 1)[0] and "fosc_saw" not in moving
+    assert all(f & EXACT for f in flags_of(moving)) and len(flags_of(moving)) == 2   # the oscillator and the LFO that moves its pitch: exact as a whole
