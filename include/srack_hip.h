@@ -189,10 +189,12 @@ enum {
     SRACK_RENDER_NO_SPECIALIZE = 1u << 4, /* always the tile interpreter */
     SRACK_RENDER_SPECIALIZE    = 1u << 5, /* specialise whatever the voice count (fails loudly if it cannot) */
     /* Default mode decides per patch which of its cheaper forms each module takes, from a first-order error bound against the 1e-5
-     * contract (csrc/approx.cpp), and renders a patch whose graph has an unbounded error gain — a loop that amplifies, a ladder near
-     * self-oscillation, a loop through a gate or a pitch — in the exact flavour altogether.  This flag keeps the DEFAULT flavour for
-     * such a patch too (modules still take their exact forms one by one where the bound asks for it): faster, and outside the parity
-     * contract — srack_render_info says "approx[kept default: ...]". */
+     * contract over a ten-minute render (csrc/approx.cpp; srack_render_info: "approx[bound 2.3e-06]").  Where the graph has an unbounded
+     * error gain — a loop that amplifies, a ladder near self-oscillation, a loop through a gate or a pitch (BASELINE config 4's FM
+     * feedback) — the oscillators behind it are evaluated exactly as the reference spells them ("; exact osc 0,3"), and a patch whose
+     * VALUES have no bound is rendered in the exact flavour altogether ("approx[exact: ...]").  This flag keeps the default forms in
+     * both cases (the f32 PolyBLEP / contracted ladder are still denied module by module where the bound asks for it): faster — config 4:
+     * 7 ms per second of audio against ~11 — and inside the contract for renders of seconds, not minutes ("approx[kept default: ...]"). */
     SRACK_RENDER_KEEP_DEFAULT  = 1u << 6
 };
 
@@ -340,7 +342,10 @@ int srack_render_kernel_source(srack_patch* p, uint32_t flags, char* buf, size_t
 int srack_render_kernel_compile(srack_patch* p, uint32_t flags);
 
 /* Scratch the render needs for the mix-down partials etc. is owned by the handle; this reports it. */
-int srack_render_info(srack_patch* p, char* buf, size_t cap); /* human-readable: kernel picked, ops, rows */
+/* Human-readable: the programs (ops, rows, units), "approx[...]" — the default mode's error bound or why the flavour is exact —, any
+ * SRACK_* tuning variable the process carries ("knobs=[...]": such a process does not render what was tested), where the kernel came from,
+ * and last "kernel=<name>".  Returns the length; copies at most cap - 1 characters (buf may be NULL to ask for the length). */
+int srack_render_info(srack_patch* p, char* buf, size_t cap);
 
 /* Average duration in ms of the dominant render kernel over the renders since the last call with
  * reset != 0, measured with HIP events on the render's own stream.  Returns the number of launches

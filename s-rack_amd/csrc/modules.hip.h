@@ -336,13 +336,14 @@ __device__ const uint64_t kLibmExpTab[256] = {  // glibc's __exp_data.tab (N = 1
 __device__ __attribute__((noinline)) double pow2_cold(double e) { return pow(2.0, e); }
 __device__ __attribute__((noinline)) double fmod1_cold(double x) { return fmod(x, 1.0); }
 
-SRK_DEV double exp2_libm(double e)
+// (the arithmetic of the plain range, branch-free; `cold` is set where the argument is outside it and the value returned is not pow's)
+SRK_DEV double exp2_libm_plain(double e, bool& cold)
 {
     constexpr double lhi = 0x1.62e42fefa39efp-1, llo = 0x1.abc9e3b398000p-56;  // log(2.0) as glibc's log_inline returns it
     const double ehi = e * lhi;
     const double elo = __builtin_fma(e, llo, __builtin_fma(lhi, e, -ehi));
     const uint32_t abstop = ((uint32_t)__double2hiint(ehi) >> 20) & 0x7ffu;
-    const bool plain = abstop - 0x3c9u <= 0x3eu;  // 2^-54 <= |e ln 2| < 512
+    cold = cold || !(abstop - 0x3c9u <= 0x3eu);  // plain: 2^-54 <= |e ln 2| < 512
     const double kds = __builtin_fma(ehi, 0x1.71547652b82fep+7, 0x1.8p52);
     const uint64_t ki = (uint64_t)__double_as_longlong(kds);
     const double kd = kds - 0x1.8p52;
@@ -358,17 +359,25 @@ SRK_DEV double exp2_libm(double e)
     double tmp = __builtin_fma(a, r2, b);
     tmp = __builtin_fma(c, r2 * r2, tmp);
     const double scale = __longlong_as_double((long long)sbits);
-    double y = __builtin_fma(tmp, scale, scale);
-    if (__builtin_amdgcn_ballot_w64(!plain) != 0) {
-        if (!plain) {
-            const uint32_t topy = ((uint32_t)__double2hiint(e) >> 20) & 0x7ffu;
-            if (topy < 0x3beu)
-                y = 1.0 + e;          // |e| < 2^-65: pow's own early exit for x > 1
-            else if (topy < 0x43eu && abstop < 0x3c9u)
-                y = 1.0 + ehi;        // |e ln 2| < 2^-54: exp_inline's
-            else
-                y = pow2_cold(e);     // overflow, underflow, NaN, and the scaled arithmetic of 512 <= |e ln 2| < 1024
-        }
+    return __builtin_fma(tmp, scale, scale);
+}
+// (what pow does outside the plain range)
+SRK_DEV double exp2_libm_special(double e)
+{
+    constexpr double lhi = 0x1.62e42fefa39efp-1;
+    const double ehi = e * lhi;
+    const uint32_t abstop = ((uint32_t)__double2hiint(ehi) >> 20) & 0x7ffu;
+    const uint32_t topy = ((uint32_t)__double2hiint(e) >> 20) & 0x7ffu;
+    if (topy < 0x3beu) return 1.0 + e;                        // |e| < 2^-65: pow's own early exit for x > 1
+    if (topy < 0x43eu && abstop < 0x3c9u) return 1.0 + ehi;   // |e ln 2| < 2^-54: exp_inline's
+    return pow2_cold(e);                                       // overflow, underflow, NaN, and the scaled arithmetic of 512 <= |e ln 2| < 1024
+}
+SRK_DEV double exp2_libm(double e)
+{
+    bool cold = false;
+    double y = exp2_libm_plain(e, cold);
+    if (__builtin_amdgcn_ballot_w64(cold) != 0) {
+        if (cold) y = exp2_libm_special(e);
     }
     return y;
 }
@@ -479,7 +488,7 @@ SRK_DEV float sine_fast(double pos)
 // that fail — 3 in a million, and the neighbourhoods of the sine's zeros, where the reference's value is its argument's rounding error —
 // evaluate the reference's expression itself (ocml's sin, as the exact flavour did for every sample until round 5: 27.5 -> ms per step on
 // config 4).  A phase outside [0, 1) — only a host can store one — takes that way too.
-SRK_DEV float sine_exact(double pos)
+SRK_DEV float sine_exact_plain(double pos, bool& cold)  // (branch-free; `cold` is set where the rounding is not decided here)
 {
     uint32_t sign;
     const double x = sine_fold(pos, sign);
@@ -492,13 +501,22 @@ SRK_DEV float sine_exact(double pos)
     const double b1 = __builtin_fma(3.6659216216293173, z2, a45);
     const double z4 = z2 * z2;
     const double y = __builtin_fma(b1, z4, b0) * x;        // >= 0 for a pos in [0, 1)
-    float r = (float)y;
+    const float r = (float)y;
     const uint32_t e = __float_as_uint(r) & 0x7f800000u;   // r = 1.m x 2^(E - 127): half an ulp is 2^(E - 151)
     const double room = (double)__uint_as_float(e - (24u << 23)) - __builtin_fabs(y - (double)r);   // distance of y to the nearer rounding boundary
     // (an r that is a power of two has the narrower spacing below it: not decided here either)
     const bool sure = e >= (64u << 23) && (__float_as_uint(r) & 0x007fffffu) != 0u && pos >= 0.0 && pos < 1.0 && room > __builtin_fma(1.0e-13, y, 2.0e-15);
-    if (!sure) return (float)sin(pos * 3.14159265358979323846 * 2.0);
+    cold = cold || !sure;
     return __uint_as_float(__float_as_uint(r) ^ sign);
+}
+SRK_DEV float sine_exact(double pos)
+{
+    bool cold = false;
+    float r = sine_exact_plain(pos, cold);
+    if (__builtin_amdgcn_ballot_w64(cold) != 0) {
+        if (cold) r = (float)sin(pos * 3.14159265358979323846 * 2.0);
+    }
+    return r;
 }
 
 // The same sine for a port whose value cannot reach a pitch input (host-proved, OSC_SINE_LOOSE): nothing integrates its error,
@@ -550,6 +568,36 @@ SRK_DEV float square_sign_safe(float sq, double pos, double delta)
     return sq;
 }
 
+// RN(a / b), the reference's `440.0 * 2^e / sample_rate`, without the division's dozen dependent instructions inside an oscillator's
+// recurrence: y = RN(1 / b) is loop-invariant, q = RN(a y) is within an ulp of the quotient, r = a - b q is exact in an fma, and
+// RN(q + r y) is the correctly rounded quotient (Markstein's theorem; b's significand — a sample rate — is nowhere near all ones).
+// Checked against the division over 1e9 increments and thirteen sample rates on the CPU (notes/r05.md).  Quotients outside the normal
+// range — an overflowed or vanishing 2^e — take the division itself.
+SRK_DEV double div_rn_plain(double a, double b, bool& cold)  // (branch-free; `cold` is set where the quotient is outside the normal range)
+{
+    const double y = 1.0 / b;
+    const double q = a * y;
+    const double r = __builtin_fma(-q, b, a);
+    cold = cold || !(__builtin_fabs(q) > 0x1p-900 && __builtin_fabs(q) < 0x1p900);
+    return __builtin_fma(r, y, q);
+}
+SRK_DEV double div_rn(double a, double b)
+{
+    bool cold = false;
+    double out = div_rn_plain(a, b, cold);
+    if (__builtin_amdgcn_ballot_w64(cold) != 0) {
+        if (cold) out = a / b;
+    }
+    return out;
+}
+// An exact oscillator's sample where one of the branch-free forms could not decide (a 2^e outside pow's plain range, an increment outside
+// the normal range, a sine within 1e-13 of an f32 rounding boundary): the reference's expressions themselves, out of line.
+__device__ __attribute__((noinline)) void osc_exact_cold(double e, double sr, double pos, bool has_cv, double& delta, float& sine)
+{
+    if (has_cv) delta = 440.0 * exp2_libm(e) / sr;
+    sine = (float)sin(pos * 3.14159265358979323846 * 2.0);
+}
+
 SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, float sync, float& sine, float& square, float& saw)
 {
     if (flags & OSC_HAS_SYNC) {
@@ -560,7 +608,23 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
     }
     const double pos = s.pos;
     double delta;
-    if (flags & OSC_HAS_CV) {
+    // An exact oscillator whose pitch sweeps (config 4's modulator, inside its feedback recurrence): increment and sine through their
+    // branch-free forms, ONE test for "some lane could not decide" per sample — four separate wave-uniform branches were four scheduling
+    // barriers in a loop that runs at one wave per SIMD.
+    bool cold = false;
+    const bool merged = (flags & (OSC_EXACT | OSC_HAS_CV | OSC_CV_AUDIO_RATE)) == (OSC_EXACT | OSC_HAS_CV | OSC_CV_AUDIO_RATE);
+    if (merged) {
+        const double e = (double)cv + c.val;
+        delta = div_rn_plain(440.0 * exp2_libm_plain(e, cold), c.sr, cold);
+        float sn = 0.0f;
+        if (flags & OSC_OUT_SINE) sn = sine_exact_plain(pos, cold);
+        if (__builtin_amdgcn_ballot_w64(cold) != 0) {
+            if (cold) osc_exact_cold(e, c.sr, pos, true, delta, sn);
+        }
+        if (flags & OSC_OUT_SINE) sine = sn;
+        s.seen_delta = delta;
+        s.seen_cv = cv;
+    } else if (flags & OSC_HAS_CV) {
         // 440 * 2^(f64(cv) + f64(val)) / f64(sample_rate), per sample (oscillator.rs:45,132)
         if ((flags & OSC_CV_AUDIO_RATE) || __builtin_amdgcn_ballot_w64(cv != s.seen_cv) != 0) {
             if (!(flags & OSC_EXACT) && (flags & OSC_VAL_FOLDED)) {  // (a kernel that proved a bound on |cv|: see the flags)
@@ -579,7 +643,7 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
                 // ... and a CV that HOLDS its values (a sequencer's notes, an envelope's sustain: no OSC_CV_AUDIO_RATE, the increment is only
                 // recomputed when the CV changed) gets the reference's own increment too: the polynomial's error is a constant for a
                 // constant CV, i.e. a phase that drifts one way for as long as the note lasts (osc_delta_cold)
-                s.seen_delta = (flags & OSC_EXACT)           ? 440.0 * exp2_libm(e) / c.sr
+                s.seen_delta = (flags & OSC_EXACT)           ? div_rn(440.0 * exp2_libm(e), c.sr)
                                : (flags & OSC_CV_SMALL)      ? (440.0 / c.sr) * exp2_fast<false>(e)  // (proved below the rate)
                                : (flags & OSC_CV_AUDIO_RATE) ? osc_delta_fast(e, c.sr)
                                                              : osc_delta_cold(e, c.sr);
@@ -592,7 +656,7 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
     }
     if (flags & OSC_EXACT) {
         const bool aa = flags & OSC_AA;
-        if (flags & OSC_OUT_SINE) sine = sine_exact(pos);
+        if ((flags & OSC_OUT_SINE) && !merged) sine = sine_exact(pos);
         if (flags & OSC_OUT_SQUARE)
             square = (pos < 0.5 ? -1.0f : 1.0f) - (aa ? (float)(poly_blep_exact(pos, delta) - poly_blep_exact(fmod1(pos + 0.5), delta)) : 0.0f);
         if (flags & OSC_OUT_SAW) saw = ((float)pos * 2.0f - 1.0f) - (aa ? (float)poly_blep_exact(pos, delta) : 0.0f);

@@ -441,6 +441,11 @@ static int upload_program(PatchHandle& h)
     int rc = upload_one(h.prog.voice, h.dev->voice);
     h.dev->ctl.resize(h.prog.ctl.size());
     for (size_t s = 0; s < h.prog.ctl.size() && rc == SRACK_OK; s++) rc = upload_one(h.prog.ctl[s], h.dev->ctl[s]);
+    // The fills above (hipMemset of rings and reverb lines) are asynchronous on the null stream, and what reads them first may run on the
+    // caller's stream or on the control pipeline's non-blocking one: set-up ends with the device at rest.  (Round 5's soaks, sixteen processes
+    // on one device: one render in ~2 500 came out with a stretch of samples wrong in every voice and right on the spot when repeated —
+    // e.g. the first 3.5 laps of a feedback ring, as if the ring had not been zero yet; never seen from a process that had the device to itself.)
+    if (rc == SRACK_OK) HIP_TRY(hipDeviceSynchronize());
     if (rc == SRACK_OK && h.dev_old) {
         rc = transplant(h);
         device_release(h.dev_old);

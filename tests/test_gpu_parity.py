@@ -2100,8 +2100,9 @@ def _vibrato(g, S, loop):
 def test_a_saw_that_reaches_a_pitch(S, oracle, loop, flags):
     """A saw that modulates a pitch is INTEGRATED by the phase accumulator behind it: the default mode's f32 PolyBLEP (a biased 1e-7) left
     2e-4 on the carrier after one second.  Feed-forward, the producing oscillator alone gets the exact PolyBLEP (OSC_EXACT_BLEP) and the
-    rest of the patch keeps the default arithmetic; a loop through the pitch input puts the whole patch into the exact flavour.  Either
-    way the full second stays inside the contract."""
+    rest of the patch keeps the default arithmetic; with a loop through the pitch input the oscillator in the loop is evaluated exactly as a
+    whole (approx.cpp: the loop's gain has no bound) — its saw the reference's to the bit — and the ladder behind it, which feeds nothing
+    back, keeps its contracted form.  Either way the full second stays inside the contract."""
     V, T, B = 24, 48000, 64
     det, cut = S.p1_voice_params(V)
     o = oracle.OraclePatch(48000, B, 2)
@@ -2113,13 +2114,20 @@ def test_a_saw_that_reaches_a_pitch(S, oracle, loop, flags):
     p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
     p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
     src = p.kernel_source(flags)
-    assert ("vcf_run<false>" in src) == loop and ("vcf_run<true>" in src) == (not loop)   # the ladder tells which flavour the patch got
+    assert "vcf_run<true>" in src and ("; exact osc 0]" in src.split("\n", 1)[0]) == loop   # the default flavour; in the loop: oscillator 0 exact as a whole
     fr = p.render_channels(T, flags)
-    if loop:  # the exact flavour: saw and filter bit-identical
-        np.testing.assert_array_equal(bits(fr), bits(ref))
-    else:
-        assert assert_close(fr, ref) < 5e-6
+    assert assert_close(fr, ref) < 5e-6
     assert np.abs(ref[0]).max() > 0.05
+    if loop:   # ... and the oscillator alone (its saw straight to the output) is the reference's to the bit
+        o2, p2 = oracle.OraclePatch(48000, B, 2), S.Patch(48000, B, 2)
+        for g in (o2, p2):
+            i2 = _vibrato(g, S, True)
+            g.connect(i2["osc_a"], S.OSC_OUT_SAW, i2["out"], 0)
+            g.connect(i2["osc_a"], S.OSC_OUT_SAW, i2["out"], 1)
+        ref2, _ = o2.render_batch(V, T, [(ids["osc_a"], S.OSC_VAL, det)], threads=8)
+        p2.configure_voices(V)
+        p2.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+        np.testing.assert_array_equal(bits(p2.render_channels(T, flags)), bits(ref2))
 
 
 @pytest.mark.parametrize("B", [1, 1024])
