@@ -417,7 +417,7 @@ def profiled_traffic(kernel_name, workload, flags, V, T):
     if (V, T) != (default_voices(workload), 48000):
         return None
     tag = {("cfg3", 0): "", ("cfg3", 1): "_exact", ("cfg3", 2): "_special", ("cfg3", 3): "_special_exact", ("p3", 0): "_p3", ("p3", 1): "_p3_exact",
-           ("cfg4", 0): "_cfg4", ("cfg4", 2): "_cfg4_special", ("cfg4_b1024", 0): "_cfg4_b1024", ("cfg4_b1024", 2): "_cfg4_b1024_special", ("cfg2", 0): "_cfg2", ("p4", 0): "_p4", ("cfg3_poly", 0): "_poly"}.get((workload, flags))
+           ("cfg4", 0): "_cfg4", ("cfg4", 64): "_cfg4_fast", ("cfg4_b1024", 64): "_cfg4_b1024_fast", ("cfg4", 2): "_cfg4_special", ("cfg4_b1024", 0): "_cfg4_b1024", ("cfg4_b1024", 2): "_cfg4_b1024_special", ("cfg2", 0): "_cfg2", ("p4", 0): "_p4", ("cfg3_poly", 0): "_poly"}.get((workload, flags))
     if tag is None:
         return None
     best = None
