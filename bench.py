@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — voice-samples/sec of the batch render on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg3_poly|cfg2|cfg4|cfg4_b1024|p3|p4] [--flags F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg3_poly|cfg2|cfg4|cfg4_b1024|p3|p4] [--flags F]   (F: 1 exact, 64 keep the fast forms ...)
 
 Workloads (BASELINE.json `configs`; SURVEY 8(d) spells them out):
     cfg3 (default; = config 5 at 8 GPUs)  patch P1 saw VCO -> ladder VCF -> VCA, ADSR gated by an LFO square; 262 144 voices per GPU,
@@ -22,11 +22,14 @@ when WORLD_SIZE is not set — bench.py starts the N ranks itself (one per devic
 The control plane (barrier, max over ranks, handing the RCCL unique id around) is torch.distributed/gloo on CPU tensors;
 the data path never touches it.
 
-The default run (cfg3, 1 GPU, default sizes) ALSO times, after the headline steps, the headline workload in the exact render mode
-(`cfg3_exact`: the reference's own arithmetic, bit for bit), the fully per-voice variant (`cfg3_poly`) and the other two single-GPU
-BASELINE configurations — config 2 (4 096 identical voices) and config 4 (P2 FM pair, buffer_size 1, 65 536 voices) —, SIDE_STEPS steps
-each after one warm-up, same bracketing (device sync both sides), and carries them on the same line: flat scalars `cfg3_exact_*` /
-`cfg3_poly_*` / `cfg2_*` / `cfg4_*` inside `roofline`, full detail under `configs`.  metric / value / config / roofline.frac stay the headline's.  `--no-side-configs` skips them.
+The default run (cfg3, 1 GPU, default sizes) ALSO times, after the headline steps, SIDE_STEPS steps each after one warm-up, same bracketing
+(device sync both sides): the headline workload in the exact render mode (`cfg3_exact`: the reference's own arithmetic, bit for bit), the fully
+per-voice variant (`cfg3_poly`), config 2 (4 096 identical voices), config 4 (P2 FM pair, 65 536 voices) as the library renders it by default — the
+modulator inside its feedback loop exact as a whole (csrc/approx.cpp: a loop through a pitch has no error bound; profiles/r05_horizon.json) — and
+with the fast kernels a host may ask for (`cfg4_fast`: SRACK_RENDER_KEEP_DEFAULT, inside the contract for ~30 s of audio), both again at the app's
+buffer_size 1024 (`cfg4_b1024`, `cfg4_b1024_fast`), and the workloads of scope rows (f)1 and (f)4 (`p3`, `p4`: two output planes each).  They ride on
+the same line: flat scalars `<name>_ms_per_step` / `_frac_hbm` / `_kernel_ms` ... inside `roofline`, full detail under `configs`.  metric / value /
+config / roofline.frac stay the headline's.  `--no-side-configs` skips them.
 
 Prints ONE JSON line (rank 0): metric/value/unit per the driver's contract, plus
   roofline     — achieved = algorithmic bytes of a step / step time (4 B x planes x V x T / t_render, per GPU),

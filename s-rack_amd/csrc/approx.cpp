@@ -256,8 +256,11 @@ struct Analysis {
         switch (mod.type) {
         case SRACK_MOD_OSCILLATOR: {
             o = {1.0, 2.0, 2.0};
-            const uint32_t edges = osc_delta_max(m) < 1e-3 ? kJumpRare : kJumpAudio;  // below 48 Hz: an LFO's edges
-            mv = {0u, edges, edges};
+            // below 48 Hz: an LFO's edges — unless something hard-syncs it: the resets come at the sync source's rate, and each is a raw jump of
+            // the saw (round 5's soak at 200 voices x 6 000 samples, seed 66697: a 22 Hz saw, synced by a filter's highpass, on a second filter's
+            // cutoff: 4.5e-5 in the contracted form of that filter, in 8 voices of 200)
+            const uint32_t edges = osc_delta_max(m) < 1e-3 && !connected(m, SRACK_OSC_IN_SYNC) ? kJumpRare : kJumpAudio;
+            mv = {connected(m, SRACK_OSC_IN_SYNC) ? (uint32_t)kJumpAudio : 0u, edges, edges};
             break;
         }
         case SRACK_MOD_MOOG_FILTER: {

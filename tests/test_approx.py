@@ -412,3 +412,22 @@ def test_contracted_ladder_epsilon_covers_the_emulation(calib):
         assert all(e <= lim for e, lim in zip(rows[kind], (1.5e-6, 4.2e-6, 3.6e-6))), (kind, rows[kind])
     assert all(e <= 2 * lim for e, lim in zip(rows["squareLFO"], (1.5e-6, 4.2e-6, 3.6e-6)))
     assert max(rows["noise"]) > 1e-4
+
+
+def test_a_synced_lfo_on_a_cutoff_jumps_at_the_sync_sources_rate(probe):
+    """Round 5's soak, seed 66697 (200 voices x 6 000 samples): a 22 Hz saw — by its pitch an LFO, whose wraps are rare jumps — hard-synced by a
+    filter's highpass and wired to a second filter's cutoff: every sync is a raw jump of the saw, at audio rate, and the second filter's
+    contracted form came out at 4.5e-5 in 8 voices of 200.  An oscillator with its sync input connected moves like its sync source."""
+    def patch(synced):
+        g, (lfo, clock, osc, vcf, out) = chain(OSC, OSC, OSC, VCF)
+        g.set_field(lfo, W.OSC_VAL, -4.3)
+        g.connect(osc, SAW, vcf, 0)
+        g.connect(lfo, SAW, vcf, 1)
+        if synced:
+            g.connect(clock, SAW, lfo, 1)
+        g.connect(vcf, 0, out, 0)
+        return g, lfo, vcf
+    g, lfo, vcf = patch(False)
+    assert g.run(probe)["literal"][vcf] == 0
+    g, lfo, vcf = patch(True)
+    assert g.run(probe)["literal"][vcf] == 1
