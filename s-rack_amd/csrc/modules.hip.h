@@ -990,32 +990,6 @@ SRK_DEV float steposc_step(StepOsc& s, const OscConst& k, float cv)
     return kPort == OSC_OUT_SAW ? o3[2] : (kPort == OSC_OUT_SQUARE ? o3[1] : o3[0]);
 }
 
-// The same for a CV that is a function of control tracks and per-voice constants (kernels specialised at run time): whether it changed is
-// the caller's wave-uniform flag — the tracks' own values compared on the scalar unit — instead of a vector compare and a ballot per sample.
-// Where the flag is set although a lane's CV came out the same (an addition that rounded away the track's step), the recomputation gives
-// that lane the increment it had: the same bits either way.
-template <uint32_t kPort>
-SRK_DEV float steposc_step_u(StepOsc& s, const OscConst& k, float cv, bool changed)
-{
-    COsc& o = s.o;
-    if (changed) {
-        const double delta = osc_delta_cold((double)cv + k.val, k.sr);
-        s.seen_cv = cv;
-        s.carried = __builtin_amdgcn_ballot_w64(!(delta < 0.25)) == 0;
-        cosc_init(o, o.pos, delta);
-    }
-    if (s.carried) return cosc_step<kPort>(o);
-    OscRegs g;
-    g.pos = o.pos;
-    g.sync_last = false;
-    g.seen_cv = s.seen_cv;
-    g.seen_delta = o.delta;
-    float o3[3] = {0.0f, 0.0f, 0.0f};
-    osc_step(OSC_HAS_CV | OSC_CV_STEPWISE | OSC_AA | kPort, g, k, cv, 0.0f, o3[0], o3[1], o3[2]);
-    cosc_init(o, g.pos, o.delta);
-    return kPort == OSC_OUT_SAW ? o3[2] : (kPort == OSC_OUT_SQUARE ? o3[1] : o3[0]);
-}
-
 // ---------------------------------------------------------------------------------------------
 // The same constant-pitch saw with the phase in 64-bit FIXED POINT (pos = phase * 2^64) — default mode of the fused
 // voice kernels only (OSC_FIXED_PHASE, set by the host).  The reference accumulates the phase in f64 and wraps with

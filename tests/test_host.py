@@ -400,12 +400,10 @@ def test_specialised_kernel_source_of_p1_and_p3(S):
     q.configure_voices(70)
     q.set_voice_field(qi["transpose"], S.MATH_CONSTANT, np.linspace(-1, 0, 70).astype(np.float32))
     src3 = q.kernel_source(0)
-    assert src3.count("static __device__ __forceinline__ void srk_ctl") == 5 and "steposc_step_u<0x20u>(m1, m1_k, m0_y, tk0_chg)" in src3 and "emit_track_put" in src3
+    assert src3.count("static __device__ __forceinline__ void srk_ctl") == 5 and "steposc_step<0x20u>" in src3 and "emit_track_put" in src3
     assert "seq_advance" in src3 and "readlane_f32(trk" in src3
     # track values reach the sample function as arguments, fetched a group of samples ahead; a swept cutoff compares the frequency only
     assert "auto sample = [&](int i, float tk0, float tk1, float tk2, float tk3)" in src3 and "tg0[u] = trk0[t0 + (uint32_t)(i0 + u)]" in src3
-    # ... and whether the note or the cutoff moved at this sample is a scalar compare of the tracks' own values (wave-uniform), not a vector one
-    assert "const bool tk1_chg = srk_first || __float_as_uint(tk1) != tk1_prev;" in src3 and "if (tk1_chg)\n" in src3
     assert "vcf_res_settle(" in src3 and "vcf_coeffs_freq<true>" in src3 and "vcf_frequency_med3(" in src3 and "vca_step_uniform(" in src3
     exact3 = q.kernel_source(S.RENDER_EXACT_OSC)
     # exact mode: the sequenced saw tile-wise wherever its note track is flat over the tile, the literal ladder told so by a scalar;
