@@ -29,7 +29,30 @@ for seed in range(lo, hi):
         for m, f, vals in ov:
             p.set_voice_field(m, f, vals)
         try:
-            fr = p.render_channels(T, flags)
+            if os.environ.get("SOAK_RETRY") == "2":
+                # one render into device buffers, read back TWICE: a read-back that differs from the other is the copy's doing, two equal ones
+                # that differ from the oracle are what the device holds
+                import ctypes as C
+                n_planes, cp = p.planes()
+                d = C.c_void_p()
+                assert S.lib.srack_device_alloc(C.byref(d), max(1, n_planes * T * V * 4)) == 0
+                p.render_raw(T, d, None, flags, None)
+                reads = []
+                for _ in range(2):
+                    a = np.zeros((n_planes, T, V), np.float32)
+                    assert S.lib.srack_device_to_host(a.ctypes.data_as(C.c_void_p), d, a.nbytes, None) == 0
+                    reads.append(a)
+                S.lib.srack_device_free(d)
+                if not np.array_equal(reads[0], reads[1], equal_nan=True):
+                    w = np.argwhere(reads[0] != reads[1])
+                    print(f"READBACK seed {seed} flags {flags}: two read-backs of one render differ in {len(w)} words, planes {sorted(set(w[:, 0]))}, t {w[:, 1].min()}..{w[:, 1].max()}; "
+                          f"zeros in the first {bool((reads[0][reads[0] != reads[1]] == 0).all())}, in the second {bool((reads[1][reads[0] != reads[1]] == 0).all())}", flush=True)
+                fr = np.zeros((2, T, V), np.float32)
+                for c, pl in enumerate(cp):
+                    if pl >= 0:
+                        fr[c] = reads[0][pl]
+            else:
+                fr = p.render_channels(T, flags)
         except S.SrackError as e:  # a reverb: the generator does not cover it
             if flags & 32 and e.code == S.ERR_UNSUPPORTED:
                 continue
@@ -55,7 +78,8 @@ for seed in range(lo, hi):
                 build(o2)
                 ref2, _ = o2.render_batch(V, T, ov, threads=8)
                 e2 = np.abs(fr2.astype(np.float64) - r64) / np.maximum(np.abs(r64), 1.0)
-                print(f"RETRY seed {seed} flags {flags}: first render {e:.2e} ({len(bad)} bad samples, channels {sorted(set(bad[:, 0]))}, t {bad[:, 1].min()}..{bad[:, 1].max()}, "
+                zeros = bool((fr[tuple(bad.T)] == 0).all())
+                print(f"RETRY seed {seed} flags {flags}: first render {e:.2e} ({len(bad)} bad samples, all zeros in the GPU's frames: {zeros}, channels {sorted(set(bad[:, 0]))}, t {bad[:, 1].min()}..{bad[:, 1].max()}, "
                       f"{len(set(bad[:, 2]))} voices); second GPU render vs first oracle {np.nanmax(e2):.2e}; GPU renders equal {np.array_equal(fr, fr2, equal_nan=True)}; "
                       f"oracle renders equal {np.array_equal(ref, ref2, equal_nan=True)}; info {p.info()[-120:]}", flush=True)
             worst.append((seed, flags, e, float((err > 1e-5).mean()) if err.size else 0.0, bool(mask_same), "exact" if (p.info().find("kernel=") >= 0 and False) else ""))
