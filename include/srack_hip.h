@@ -384,6 +384,7 @@ int srack_device_set(int device);
 int srack_device_get(int* device, char* pci_bus_id, size_t cap);
 int srack_device_alloc(void** d_ptr, size_t bytes);
 int srack_device_free(void* d_ptr);
+/* Waits for `stream`, then copies through a pinned buffer of the library's own (the caller's memory may be pageable); returns when h_dst holds the bytes. */
 int srack_device_to_host(void* h_dst, const void* d_src, size_t bytes, void* stream);
 int srack_device_sync(void* stream);
 

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -794,11 +795,29 @@ int srack_device_free(void* d_ptr)
     });
 }
 
+// Device -> host through a PINNED bounce buffer of the library's own, a chunk at a time (DMA into pinned memory, then a CPU copy).  A plain
+// hipMemcpyAsync into the caller's pageable memory is what this was until round 5 — and what that round's soaks caught losing data: with
+// sixteen processes on one device, one read-back in a few thousand came back with a stretch of ZEROS (tens of pages, the same offsets
+// in call after call of one process) where a second read-back of the very same device bytes had the data (tools/fuzz_soak_default.py,
+// SOAK_RETRY=2; notes/r05.md R5.2).  The caller's pages are never handed to the copy engine now.
+namespace {
+std::mutex g_bounce_mutex;
+void* g_bounce = nullptr;
+constexpr size_t kBounceBytes = size_t(8) << 20;
+}  // namespace
 int srack_device_to_host(void* h_dst, const void* d_src, size_t bytes, void* stream)
 {
     return guarded([&]() -> int {
-        HIP_TRY_C(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-        HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));
+        if (bytes == 0) return SRACK_OK;
+        if (!h_dst || !d_src) return SRACK_ERR_INVALID;
+        std::lock_guard<std::mutex> lock(g_bounce_mutex);
+        if (!g_bounce) HIP_TRY_C(hipHostMalloc(&g_bounce, kBounceBytes, hipHostMallocDefault));  // (kept for the life of the process)
+        HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));  // what the caller enqueued before the copy
+        for (size_t off = 0; off < bytes; off += kBounceBytes) {
+            const size_t n = std::min(kBounceBytes, bytes - off);
+            HIP_TRY_C(hipMemcpy(g_bounce, (const char*)d_src + off, n, hipMemcpyDeviceToHost));
+            std::memcpy((char*)h_dst + off, g_bounce, n);
+        }
         return SRACK_OK;
     });
 }
