@@ -331,6 +331,21 @@ __device__ const uint64_t kLibmExpTab[256] = {  // glibc's __exp_data.tab (N = 1
     0x3c77893b4d91cd9dull, 0x3fefe7c1819e90d8ull, 0x3c5305c14160cc89ull, 0x3feff3c22b8f71f1ull,
 };
 
+// A kernel specialised at run time for a program with an exact oscillator whose pitch moves keeps the table in LDS (jit.cpp defines
+// SRK_LIBM_TAB_LDS and fills it at kernel entry): the lookup sits inside the oscillator's recurrence, at one wave per SIMD where nothing hides
+// a trip to the vector cache.
+#if defined(SRK_LIBM_TAB_LDS)
+static __shared__ uint64_t srk_libm_tab_lds[256];
+#define SRK_LIBM_TAB(i) srk_libm_tab_lds[(i)]
+SRK_DEV void libm_tab_fill(int lane)
+{
+    for (int k = lane; k < 256; k += 64) srk_libm_tab_lds[k] = kLibmExpTab[k];
+    __syncthreads();
+}
+#else
+#define SRK_LIBM_TAB(i) kLibmExpTab[(i)]
+#endif
+
 // (the library's pow and fmod behind the cold branches below: out of line — inlined, each of their copies per oscillator was a few hundred
 // instructions and several dozen registers the hot path never uses)
 __device__ __attribute__((noinline)) double pow2_cold(double e) { return pow(2.0, e); }
@@ -350,8 +365,8 @@ SRK_DEV double exp2_libm_plain(double e, bool& cold)
     double r = __builtin_fma(kd, -0x1.cf79abc9e3b3ap-47, __builtin_fma(kd, -0x1.62e42fefa0000p-8, ehi));
     r = elo + r;
     const uint32_t idx = 2u * ((uint32_t)ki & 127u);
-    const double tail = __longlong_as_double((long long)kLibmExpTab[idx]);
-    const uint64_t sbits = kLibmExpTab[idx + 1u] + (ki << 45);
+    const double tail = __longlong_as_double((long long)SRK_LIBM_TAB(idx));
+    const uint64_t sbits = SRK_LIBM_TAB(idx + 1u) + (ki << 45);
     const double r2 = r * r;
     const double a = __builtin_fma(r, 0x1.555555555543cp-3, 0x1.ffffffffffdbdp-2);
     const double b = r + tail;
@@ -485,7 +500,7 @@ SRK_DEV float sine_fast(double pos)
 // The polynomial's value y is within 8e-14 y of sin(2 pi pos) (tests/test_oracle.py evaluates it against mpmath); the reference's f64 sine is
 // within 1.6e-15 + 1.2e-16 y of it (one rounding of pos * PI, the libm's sub-ulp error).  Both round to the SAME f32 unless y lies within the
 // sum of those of a rounding boundary: that is tested here (y minus its f32 rounding, against half an ulp of that f32), and only the lanes
-// that fail — 3 in a million, and the neighbourhoods of the sine's zeros, where the reference's value is its argument's rounding error —
+// that fail — 3 in a million, the neighbourhoods of the sine's zeros, where the reference's value is its argument's rounding error —
 // evaluate the reference's expression itself (ocml's sin, as the exact flavour did for every sample until round 5: 27.5 -> ms per step on
 // config 4).  A phase outside [0, 1) — only a host can store one — takes that way too.
 SRK_DEV float sine_exact_plain(double pos, bool& cold)  // (branch-free; `cold` is set where the rounding is not decided here)
@@ -503,9 +518,13 @@ SRK_DEV float sine_exact_plain(double pos, bool& cold)  // (branch-free; `cold` 
     const double y = __builtin_fma(b1, z4, b0) * x;        // >= 0 for a pos in [0, 1)
     const float r = (float)y;
     const uint32_t e = __float_as_uint(r) & 0x7f800000u;   // r = 1.m x 2^(E - 127): half an ulp is 2^(E - 151)
-    const double room = (double)__uint_as_float(e - (24u << 23)) - __builtin_fabs(y - (double)r);   // distance of y to the nearer rounding boundary
-    // (an r that is a power of two has the narrower spacing below it: not decided here either)
-    const bool sure = e >= (64u << 23) && (__float_as_uint(r) & 0x007fffffu) != 0u && pos >= 0.0 && pos < 1.0 && room > __builtin_fma(1.0e-13, y, 2.0e-15);
+    // distance of y to the rounding boundary on its side of r: half an ulp — a quarter below an r that is a power of two, where the spacing
+    // halves (r = 1.0 is every phase within 5e-5 of a peak: 1.6e-4 of all samples fell back while those were left undecided, 3e-6 now)
+    const double d = y - (double)r;
+    double half = (double)__uint_as_float(e - (24u << 23));
+    half = (d < 0.0 && (__float_as_uint(r) & 0x007fffffu) == 0u) ? 0.5 * half : half;
+    const double room = half - __builtin_fabs(d);
+    const bool sure = e >= (64u << 23) && pos >= 0.0 && pos < 1.0 && room > __builtin_fma(1.0e-13, y, 2.0e-15);
     cold = cold || !sure;
     return __uint_as_float(__float_as_uint(r) ^ sign);
 }
