@@ -82,6 +82,8 @@ pub mod render_flags {
     pub const NO_SPECIALIZE: u32 = 1 << 4;
     /// the general path through a kernel specialised for the program, whatever the voice count
     pub const SPECIALIZE: u32 = 1 << 5;
+    /// keep the default mode's fast forms where its error bound would make oscillators (or the patch) exact: a render of seconds, not minutes
+    pub const KEEP_DEFAULT: u32 = 1 << 6;
 }
 
 pub const DIST_ID_BYTES: usize = 128;
