@@ -194,7 +194,7 @@ enum {
      * feedback) — the oscillators behind it are evaluated exactly as the reference spells them ("; exact osc 0,3"), and a patch whose
      * VALUES have no bound is rendered in the exact flavour altogether ("approx[exact: ...]").  This flag keeps the default forms in
      * both cases (the f32 PolyBLEP / contracted ladder are still denied module by module where the bound asks for it): faster — config 4:
-     * 7 ms per second of audio against ~11 — and inside the contract for renders of seconds, not minutes ("approx[kept default: ...]"). */
+     * 7 ms per second of audio against 18.5 — and inside the contract for renders of seconds, not minutes ("approx[kept default: ...]"). */
     SRACK_RENDER_KEEP_DEFAULT  = 1u << 6
 };
 
