@@ -43,3 +43,8 @@ for seed in range(lo, hi):
 print(f"seeds {lo}..{hi - 1} noise={noise}: {n} renders, {len(bad)} not bit-identical, {time.time() - t0:.0f} s")
 for b in bad[:40]:
     print("  seed %d flags %d: %.5f of the samples differ" % b)
+if os.environ.get("SOAK_JSON"):  # (tools/soak_par.py merges its workers' results)
+    import json
+    with open(os.environ["SOAK_JSON"], "w") as f:
+        json.dump(dict(first=lo, last=hi, noise=noise, renders=n, bad=len(bad), seconds=time.time() - t0, vt=os.environ.get("SOAK_VT", ""),
+                       special=bool(os.environ.get("FUZZ_SPECIAL")), worst=[[b[0], b[1], b[2], b[2], True] for b in bad]), f)
