@@ -6,8 +6,9 @@
 //   3. gains: per output channel, backward: G(wire) = sum over the inputs that read it of sum over that module's outputs of
 //      g(input -> output) * G(output wire); a fixpoint over the cycles — converging to 1 / (1 - loop gain) or declared unbounded
 //   4. decisions: every approximated form is an epsilon on its wire; forms are denied, largest contribution first, until the sum of
-//      epsilon * G stays below kApproxBudget on every channel; an unbounded gain behind a module the default mode cannot make exact by
-//      itself (an oscillator whose pitch moves, a sine) turns the whole patch exact.
+//      epsilon * G stays below kApproxBudget on every channel; an oscillator behind an unbounded gain whose pitch moves, or whose sine is
+//      heard there, is evaluated exactly as a whole (OSC_EXACT on that op); values without a bound, or an unbounded gain behind the sample
+//      player's pitch (no exact form of its own), turn the whole patch exact.
 //
 // Where the numbers come from.  Epsilons: f32 PolyBLEP / sine — two roundings at values in [1, 2): 2.4e-7.  The contracted ladder —
 // tools/ladder_calib.c emulates both forms on the CPU (filter.rs:58-92 against modules.hip.h vcf_step<true>): over resonance 0 ... 0.89,
@@ -17,8 +18,8 @@
 // filter, from its coefficients (resonance 0.5: 1.1 ... 3.2; 0.89: up to 47 at cutoff 0.2; from ~0.9 the linear ladder does not decay at
 // mid cutoffs: unbounded); the sensitivity to the cutoff is measured at up to 2.7 / cutoff times the port's L1 norm (same tool: 3.0 here).
 // What is NOT bounded here: the default forms' own last-bit differences from the reference's libm (polynomial 2^cv at 3e-16, 1e-12 inside
-// the proved FM loops; the f64 sine at one rounding) — zero-mean, measured over minutes instead (profiles/r05_horizon.json); they only
-// decide anything where a gain is unbounded.
+// the generator's bounded-CV classes; the f64 sine at one rounding) — zero-mean, measured over minutes instead (profiles/r05_horizon.json);
+// they only decide anything where a gain is unbounded: there the oscillator takes the reference's own forms.
 #include "approx.hpp"
 
 #include <algorithm>

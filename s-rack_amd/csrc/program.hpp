@@ -47,7 +47,8 @@ enum : uint32_t {
     OSC_OUT_SINE = 1u << 3,   // which ports anything reads; dead ports are not computed
     OSC_OUT_SQUARE = 1u << 4,
     OSC_OUT_SAW = 1u << 5,
-    OSC_EXACT = 1u << 6,      // f64 PolyBLEP / sin / pow exactly as the reference spells them
+    OSC_EXACT = 1u << 6,      // f64 PolyBLEP / sin / pow exactly as the reference spells them: every oscillator of an exact-flavour render, or — default
+                              // flavour — the single oscillators approx.cpp finds behind an unbounded error gain (a loop through a pitch, a gate ...)
     OSC_CONST_FAST = 1u << 7, // host-proved: no CV, no sync, one live port, PolyBLEP on, every voice's delta < 0.25
                               // => the carried-phase oscillator (modules.hip.h, COsc) may be used
     OSC_CV_AUDIO_RATE = 1u << 8,  // the CV SWEEPS (flatten.cpp `sweeps`: an oscillator, a filter, noise, a sample player upstream): 2^cv by polynomial every sample.
@@ -57,8 +58,8 @@ enum : uint32_t {
     OSC_CV_STEPWISE = 1u << 9,    // host-proved: the CV is a sequencer's note CV (plus constants): constant between steps
     OSC_SINE_LOOSE = 1u << 12,    // host-proved: the sine port's value cannot reach a pitch input (an oscillator's or the sample player's CV), so
                                   // nothing integrates its rounding: default mode may evaluate it in f32 after the exact f64 fold
-    OSC_EXACT_BLEP = 1u << 13,    // host-proved need, default mode only: this oscillator's saw / square can reach a pitch input, where an error is
-                                  // INTEGRATED (or an event input, a filter's cutoff CV, the audio input of a filter with noise on its cutoff: flatten.cpp 2b) — its PolyBLEP is evaluated as in exact mode (f64, true division); everything else about it
+    OSC_EXACT_BLEP = 1u << 13,    // host-derived, default mode only: the f32 PolyBLEP's 2.4e-7 times the gain from this oscillator's saw / square to some output
+                                  // (through a pitch input, an event input, a cutoff CV, a loop ...: approx.cpp) does not fit the error budget — its PolyBLEP is evaluated as in exact mode (f64, true division); everything else about it
                                   // (2^cv, sine, the rest of the patch) stays in the default arithmetic
     OSC_CONST_SMALL = 1u << 11,   // host-proved, whatever the render mode: no CV, no sync, one live port, PolyBLEP on, every voice's delta < 0.25
                                   // (OSC_CONST_FAST = this and not OSC_EXACT)
@@ -76,8 +77,8 @@ enum : uint32_t {
     VCF_OUT_LP = 1u << 3,
     VCF_OUT_BP = 1u << 4,
     VCF_OUT_HP = 1u << 5,
-    VCF_LITERAL = 1u << 6,    // default mode only: an output can reach a pitch / event input or another filter's cutoff, the filter sits on a cycle, or its own cutoff is moved by an
-                              // approximated producer or by noise (flatten.cpp 2b) — the ladder runs the reference's operations one by one (no fma contraction)
+    VCF_LITERAL = 1u << 6,    // default mode only: the contracted ladder's epsilon times the gain from its ports to some output does not fit the error budget, its
+                              // cutoff jumps at audio rate, or it is near self-oscillation (approx.cpp) — the ladder runs the reference's operations one by one (no fma contraction)
     // OP_ADSR
     ADSR_HAS_GATE = 1u << 0,
     // OP_VCA

@@ -715,7 +715,7 @@ def test_pitch_cv_that_holds_and_pitch_cv_that_sweeps(S):
 
 
 def test_cutoff_rules_of_the_flattener(S):
-    """flatten.cpp 2b: an approximated producer (a square) that reaches a filter's cutoff CV gets the exact PolyBLEP and that filter the literal
+    """csrc/approx.cpp through the flattener: an approximated producer (a square) that reaches a filter's cutoff CV gets the exact PolyBLEP and that filter the literal
     ladder (the saw on its audio input keeps the fast form); white noise on a cutoff: literal ladder AND the exact PolyBLEP for the oscillator
     on the audio input; an envelope on the cutoff — P3's sweep — changes nothing."""
     import re

@@ -1,5 +1,5 @@
 """P1 with a saw-LFO vibrato on the audio oscillator's pitch (a tainted value reaches a pitch input, feed-forward): ms per step at scale.
-SRACK_TAINT_GLOBAL=1 gives the pre-round-2 rule (the whole patch in the exact flavour).  usage: python tools/vibrato_bench.py [voices]"""
+(--flags 1 gives what the pre-round-2 rule gave: the whole patch in the exact flavour.)  usage: python tools/vibrato_bench.py [voices]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, srack_pkg
