@@ -267,8 +267,11 @@ struct Analysis {
         case SRACK_MOD_MOOG_FILTER: {
             const double res = std::min(std::max(field(m, SRACK_VCF_RES).hi, 0.0), 1.0);
             o = {1.0, 6.0, in_mag(m, SRACK_VCF_IN_AUDIO) + 3.8 * res + 1.0};
+            // every port keeps the input's edges: band- and highpass by construction, and a lowpass only smooths them at a low cutoff — at 0.9
+            // a square comes out a square (round 5's soak through the specialised kernels, seed 72223: one filter's lowpass, fed from a
+            // chaotic loop, on a second filter's cutoff — 5.3e-5 on that one's contracted highpass)
             const uint32_t a = in_motion(m, SRACK_VCF_IN_AUDIO);
-            mv = {0u, a, a};  // the lowpass smooths what it is fed; band- and highpass keep the input's edges
+            mv = {a, a, a};
             break;
         }
         case SRACK_MOD_ADSR:
