@@ -22,7 +22,7 @@ from tests.fuzz_patches import random_patch  # noqa: E402
 # round 3 (725: a loop through a sync input, 1459: a filter <-> mixer loop with a gain above 1, 1473: a loop through a pitch): 725 and
 # 1473 parted from the oracle in exact mode too, at one of the arguments where the libm's pow is not the correctly rounded 2^e — since
 # round 4 the exact mode evaluates 2^cv with the libm's own algorithm (modules.hip.h, exp2_libm) and they are bit-identical
-@pytest.mark.parametrize("seed,noise", [(s, False) for s in list(range(160)) + [707, 725, 774, 780, 867, 944, 1000, 1157, 1459, 1473, 2691, 4386, 10901, 16340, 28336, 40214, 40913, 66697]] + [(s, True) for s in list(range(40)) + [2127, 2197, 2203, 2360]])
+@pytest.mark.parametrize("seed,noise", [(s, False) for s in list(range(160)) + [707, 725, 774, 780, 867, 944, 1000, 1157, 1459, 1473, 2691, 4386, 10901, 16340, 28336, 40214, 40913, 66697, 72223]] + [(s, True) for s in list(range(40)) + [2127, 2197, 2203, 2360]])
 def test_random_patch_matches_oracle(seed, noise, oracle, monkeypatch):
     S = srack_pkg.load()
     if seed % 2:  # few voices normally run as quarter-filled waves (more waves, same cost); odd seeds force the full,
@@ -73,13 +73,13 @@ KNOWN_CHAOTIC = {
     # through event inputs, amplifying cycles with a filter in them, a loop through a pitch; 2691: a bandpass into a gate; 4386: two mixers
     # amplifying each other; 10901: producers into a cutoff behind a highpass; 16340: a pitch above one cycle per sample; 28336: a square on a
     # cutoff; 40214 / 40913: a ladder in a cycle, an integrator; the noise family's 2127 ... 2360: white noise on a cutoff; 66697: a hard-synced
-    # LFO on a cutoff) — each had a rule of its own in flatten.cpp until round 5 and is now whatever the bound makes of it.
+    # LFO on a cutoff; 72223: a filter's lowpass, fed from a chaotic loop, on a cutoff) — each had a rule of its own in flatten.cpp until round 5 and is now whatever the bound makes of it.
 }
 
 
 def _default_cases():
     cases = []
-    for s, noise in [(s, False) for s in list(range(160)) + [707, 725, 774, 780, 867, 944, 1000, 1157, 1459, 1473, 2691, 4386, 10901, 16340, 28336, 40214, 40913, 66697]] + [(s, True) for s in list(range(40)) + [2127, 2197, 2203, 2360]]:
+    for s, noise in [(s, False) for s in list(range(160)) + [707, 725, 774, 780, 867, 944, 1000, 1157, 1459, 1473, 2691, 4386, 10901, 16340, 28336, 40214, 40913, 66697, 72223]] + [(s, True) for s in list(range(40)) + [2127, 2197, 2203, 2360]]:
         why = KNOWN_CHAOTIC.get((s, noise))
         cases.append(pytest.param(s, noise, marks=pytest.mark.xfail(strict=True, reason=why)) if why else pytest.param(s, noise))
     return cases
@@ -98,7 +98,7 @@ def test_random_patch_default_modes_within_tolerance(seed, noise, oracle, monkey
     ref, _ = o.render_batch(V, T, ov, threads=8)
     r64 = ref.astype(np.float64)
     bad = []
-    for flags in DEFAULT_FLAGS + ((DEFAULT_SPECIAL,) if seed % 3 == 0 else ()):
+    for flags in DEFAULT_FLAGS + ((DEFAULT_SPECIAL,) if seed % 3 == 0 or seed == 72223 else ()):   # (72223: found through the specialised kernels)
         p = S.Patch(48000, B, 2)
         build(p)
         p.configure_voices(V)
