@@ -261,7 +261,9 @@ struct Analysis {
             // the saw (round 5's soak at 200 voices x 6 000 samples, seed 66697: a 22 Hz saw, synced by a filter's highpass, on a second filter's
             // cutoff: 4.5e-5 in the contracted form of that filter, in 8 voices of 200)
             const uint32_t edges = osc_delta_max(m) < 1e-3 && !connected(m, SRACK_OSC_IN_SYNC) ? kJumpRare : kJumpAudio;
-            mv = {connected(m, SRACK_OSC_IN_SYNC) ? (uint32_t)kJumpAudio : 0u, edges, edges};
+            // (the sine of an oscillator above LFO rate has no edges, but it moves by a good part of its range from one sample to the next:
+            // for a cutoff that is the same thing — the calibration's "smooth" cutoffs are envelopes, LFOs and sines up to 1.8 kHz)
+            mv = {edges == kJumpAudio ? (uint32_t)kJumpAudio : 0u, edges, edges};
             break;
         }
         case SRACK_MOD_MOOG_FILTER: {
@@ -270,7 +272,9 @@ struct Analysis {
             // every port keeps the input's edges: band- and highpass by construction, and a lowpass only smooths them at a low cutoff — at 0.9
             // a square comes out a square (round 5's soak through the specialised kernels, seed 72223: one filter's lowpass, fed from a
             // chaotic loop, on a second filter's cutoff — 5.3e-5 on that one's contracted highpass)
-            const uint32_t a = in_motion(m, SRACK_VCF_IN_AUDIO);
+            // ... and a filter whose own cutoff jumps hands that on, input or no input (seed 104123, FUZZ_MORE_OV at 200 voices: a ladder past
+            // self-oscillation with nothing on its audio input and a square on its cutoff, its highpass on the next filter's cutoff: 5.2e-4 there)
+            const uint32_t a = in_motion(m, SRACK_VCF_IN_AUDIO) | (connected(m, SRACK_VCF_IN_CV) ? in_motion(m, SRACK_VCF_IN_CV) : 0u);
             mv = {a, a, a};
             break;
         }

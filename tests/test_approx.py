@@ -189,6 +189,7 @@ def test_producers_into_a_cutoff_pay_by_the_filters_sensitivity(probe):
     r = g.run(probe)
     assert r["exact_blep"][osc] == 1 and r["literal"][a] == 1
     g, (lfo, osc, vcf, out) = chain(OSC, OSC, VCF)
+    g.set_field(lfo, W.OSC_VAL, -7.0)      # 3.4 Hz: an LFO (a sine at audio rate on a cutoff is outside the contracted ladder's calibration: literal)
     g.set_field(vcf, W.VCF_EXP_AMT, 0.01)
     g.set_field(vcf, W.VCF_FREQ, 0.6)
     g.connect(osc, SAW, vcf, 0)
@@ -196,6 +197,8 @@ def test_producers_into_a_cutoff_pay_by_the_filters_sensitivity(probe):
     g.connect(vcf, 0, out, 0)
     r = g.run(probe)
     assert r["sine_loose"][lfo] == 1 and r["literal"][vcf] == 0 and r["bound"] < BUDGET
+    g.lines = [l for l in g.lines if not l.startswith(f"field {lfo} ")]   # the same at 440 Hz
+    assert g.run(probe)["literal"][vcf] == 1
 
 
 def test_a_cutoff_that_jumps(probe):
