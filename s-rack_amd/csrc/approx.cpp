@@ -396,19 +396,20 @@ struct Analysis {
             lo = std::min(lo, 0.9), hi = std::max(hi, 0.0);
             if (lo > hi) std::swap(lo, hi);
             L.motion = has_cv ? in_motion(m, SRACK_VCF_IN_CV) : 0u;
-            // A cutoff that jumps makes the ladder a time-varying system, and the static norms no longer bound it (tools/ladder_calib.c, the
-            // literal ladder's response to a 2.4e-7 disturbance of its input): with a square on the CV the gain stays within 3.5 x the static
-            // one up to resonance 0.8 and is unbounded above (a parametric instability: the margin to self-oscillation shrinks by ~0.1 of
-            // resonance); with white noise on the CV it is unbounded from resonance 0.2 up.
-            const bool edges = (L.motion & kJumpAudio) != 0;
-            if (L.motion & kJumpNoise) L.stable = false;
-            const double res_eff = edges ? std::min(res + 0.1, 1.0) : res;
+            // A cutoff that moves at audio rate makes the ladder a time-varying system, and the static norms no longer bound it.  tools/ladder_calib.c
+            // (`gain`: the literal ladder's response to a 2.4e-7 disturbance of its input): with a square on the CV the response stays within 3.5 x
+            // the static one up to resonance 0.8 for a unit saw on the input and is unbounded above; with white noise on the CV it is unbounded from
+            // resonance 0.2 up.  And round 5's soak with per-voice parameters at 200 voices (seed 105055) has a literal ladder at resonance 0.52
+            // whose cutoff an audio-rate saw moves between 0.44 and the clamp at 0.9, with an input of magnitude 4 driving it into its clamps:
+            // a 4.8e-7 disturbance on the input came out at 6.9e-5 — 145 x, eleven times the static norm times four.  No bound is claimed for
+            // such a filter: unbounded, like one near self-oscillation.
+            if (L.motion & (kJumpAudio | kJumpNoise)) L.stable = false;
             constexpr int kGrid = 12;
             for (int j = 0; j <= kGrid && L.stable; j++) {
                 const double fr = lo + (hi - lo) * (double)j / kGrid;
                 double l1[3];
-                if (!ladder_l1(fr, res_eff, l1) || l1[0] > kLadderL1Max) L.stable = false;
-                for (int p = 0; p < 3; p++) L.l1[p] = std::max(L.l1[p], (edges ? 4.0 : 1.0) * l1[p]);
+                if (!ladder_l1(fr, res, l1) || l1[0] > kLadderL1Max) L.stable = false;
+                for (int p = 0; p < 3; p++) L.l1[p] = std::max(L.l1[p], l1[p]);
                 if (hi == lo) break;
             }
             if (!L.stable) L.l1[0] = L.l1[1] = L.l1[2] = kInf;

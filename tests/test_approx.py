@@ -202,26 +202,28 @@ def test_producers_into_a_cutoff_pay_by_the_filters_sensitivity(probe):
 
 
 def test_a_cutoff_that_jumps(probe):
-    """tools/ladder_calib.c: a square on the cutoff CV takes the contracted ladder out of its band (5e-5) and makes the literal one respond up
-    to 3.5 x its static gain up to resonance 0.8, without bound above; white noise on the CV: without bound from resonance 0.2 (round 4's
-    seeds 28336; 2127 / 2203 / 2360)."""
-    def patch(cv_type, res):
+    """A cutoff that moves at audio rate — a square, a saw, a sine above LFO rate, noise, another filter's output — makes the ladder a
+    time-varying system: tools/ladder_calib.c has the contracted form at 5e-5 under a square and the literal one's response to an input
+    disturbance at 3.5 x its static norm (a unit saw on the input, resonance <= 0.8), unbounded above and under noise; the soak's seed
+    105055 has it at 145 x the disturbance with a louder input.  No bound is claimed: the filter literal, its gains unbounded, everything in
+    front exact (round 4's seeds 28336; 2127 / 2203 / 2360).  An envelope or an LFO on the cutoff (P3's sweep) is calibrated: contracted."""
+    def patch(cv_type, res, lfo=False):
         g, (audio, cv, vcf, out) = chain(OSC, cv_type, VCF)
         g.set_field(vcf, W.VCF_RES, res)
+        if lfo:
+            g.set_field(cv, W.OSC_VAL, -7.0)
         g.connect(audio, SAW, vcf, 0)
         g.connect(cv, SQUARE if cv_type == OSC else 0, vcf, 1)
         g.connect(vcf, 0, out, 0)
         return g, audio, cv, vcf
-    g, audio, cv, vcf = patch(OSC, 0.5)
+    for cv_type in (OSC, NOISE):
+        g, audio, cv, vcf = patch(cv_type, 0.5)
+        r = g.run(probe)
+        assert r["literal"][vcf] == 1 and r["exact_blep"][audio] == 1 and r["saw_fixed"][audio] == 0 and r["gain"][audio][SAW] == float("inf")
+    g, audio, cv, vcf = patch(OSC, 0.5, lfo=True)            # a 3.4 Hz square: rare jumps — twice the still ladder's epsilon
     r = g.run(probe)
-    assert r["literal"][vcf] == 1 and r["exact_blep"][cv] == 1 and r["exact_blep"][audio] == 0     # the audio saw keeps the fast form ...
-    g, audio, cv, vcf = patch(OSC, 0.85)
-    r = g.run(probe)
-    assert r["literal"][vcf] == 1 and r["exact_blep"][audio] == 1 and r["gain"][audio][SAW] == float("inf")   # ... until the margin is gone
-    g, audio, cv, vcf = patch(NOISE, 0.5)
-    r = g.run(probe)
-    assert r["literal"][vcf] == 1 and r["exact_blep"][audio] == 1 and r["saw_fixed"][audio] == 0
-    g, audio, cv, vcf = patch(ADSR, 0.5)                     # an envelope (P3's sweep): jumps now and then — twice the still ladder's epsilon
+    assert r["literal"][vcf] == 0 and r["exact_blep"][audio] == 0 and 3.0e-6 < r["bound"] < BUDGET
+    g, audio, cv, vcf = patch(ADSR, 0.5)                     # an envelope (P3's sweep): the same
     g.connect(audio, SQUARE, cv, 0)
     r = g.run(probe)
     assert r["literal"][vcf] == 0 and r["exact_blep"][audio] == 0 and 3.0e-6 < r["bound"] < BUDGET

@@ -715,9 +715,9 @@ def test_pitch_cv_that_holds_and_pitch_cv_that_sweeps(S):
 
 
 def test_cutoff_rules_of_the_flattener(S):
-    """csrc/approx.cpp through the flattener: an approximated producer (a square) that reaches a filter's cutoff CV gets the exact PolyBLEP and that filter the literal
-    ladder (the saw on its audio input keeps the fast form); white noise on a cutoff: literal ladder AND the exact PolyBLEP for the oscillator
-    on the audio input; an envelope on the cutoff — P3's sweep — changes nothing."""
+    """csrc/approx.cpp through the flattener: a cutoff that moves at audio rate (a square, noise) leaves its filter without a bound — the
+    literal ladder, and the exact PolyBLEP for the square and for the saw on the audio input; an envelope on the cutoff — P3's sweep — changes
+    nothing."""
     import re
     EXACT_BLEP = 1 << 13
     for cv_source in (S.MOD_OSCILLATOR, S.MOD_NOISE, S.MOD_ADSR):
@@ -732,10 +732,8 @@ def test_cutoff_rules_of_the_flattener(S):
         assert ("vcf_run<true>" in src) == (cv_source == S.MOD_ADSR), cv_source
         if cv_source == S.MOD_ADSR:
             assert "fosc_saw" in src and not literal_forms
-        elif cv_source == S.MOD_NOISE:
-            assert "fosc_saw" not in src and len(literal_forms) == 1 and literal_forms[0] & EXACT_BLEP   # the audio saw
         else:
-            assert "fosc_saw" in src and len(literal_forms) == 1 and literal_forms[0] & EXACT_BLEP       # the square on the cutoff; the audio saw stays fast
+            assert "fosc_saw" not in src and literal_forms and all(f & EXACT_BLEP for f in literal_forms)
 
 
 def test_exp2_fast10_coefficients_in_the_header():
