@@ -41,6 +41,12 @@ constexpr double kEpsFixed = 3.2e-12;       // 2^-64 fixed-point phase: kApproxH
 constexpr double kEpsNonlin = 4e-6;         // v_log_f32 / v_exp_f32 power, relative to max(|out|, 1)
 constexpr double kEpsLadder[3] = {1.5e-6, 4.2e-6, 3.6e-6};  // contracted ladder, lowpass / bandpass / highpass (tools/ladder_calib.c)
 constexpr double kLadderRareJumps = 2.0;    // ... with a cutoff that jumps now and then (an envelope's attack, a sequencer's step): same tool, 7e-6 on the bandpass
+constexpr double kLadderDriveMax = 1.75;    // above this input amplitude a ladder is OVERDRIVEN: its stages sit in their clamps and flip within a sample, and the last stage's
+                                            // cubic, b4 - b4^3 / 6 — slope 1 - b4^2 / 2, below -1 past |b4| = 2 — with the stage's own feedback - b4 * f around it is an
+                                            // expanding map: chaos without any resonance.  tools/ladder_calib.c `amp`: the literal ladder's response to a 2.4e-7 disturbance of
+                                            // its input is 10 - 29 x up to an amplitude of 1.75, 1e4 - 1e6 x from 1.9 up at low resonance (round 5's seeds 105055, 123042)
+constexpr double kLadderTameCutoff = 0.35;  // ... but only where the cutoff passes this: below, the stage's coefficient p keeps the last stage's value under the cubic's turning
+                                            // point whatever the drive (same tool, `tame`: <= 23 x at cutoffs <= 0.4 for amplitudes up to 1000; 35 x at 0.42 and 3 700 x at 0.46 for 8 - 16)
 constexpr double kLadderL1Max = 64.0;       // beyond this lowpass L1 norm the ladder is treated as self-oscillating (the calibration stops at 47)
 constexpr double kNonlinSteep = 1e4;        // d|a|^b / da near a = 0 for b < 1: (2.4e-7)^0.5 / 2.4e-7 = 2e3
 constexpr int kSweeps = 400;
@@ -57,6 +63,7 @@ struct Ladder {
     double l1[3] = {0.0, 0.0, 0.0};      // L1 norm of the impulse response audio -> lowpass / bandpass / highpass, worst over the reachable cutoffs
     double cutoff[3] = {0.0, 0.0, 0.0};  // gain cutoff CV -> port
     bool stable = true;
+    bool overdriven = false;             // the audio input can exceed kLadderDriveMax (no contracted form; unbounded where the cutoff passes kLadderTameCutoff)
     uint32_t motion = 0;                 // kJump* of the cutoff CV
 };
 
@@ -256,7 +263,10 @@ struct Analysis {
         };
         switch (mod.type) {
         case SRACK_MOD_OSCILLATOR: {
-            o = {1.0, 2.0, 2.0};
+            // the band-limited saw and square stay within +-1 while the two PolyBLEP windows of a period do not overlap (an increment up to a
+            // quarter cycle per sample: 12 kHz); beyond, twice that
+            const double edge_mag = osc_delta_max(m) <= 0.25 ? 1.0 : 2.0;
+            o = {1.0, edge_mag, edge_mag};
             // below 48 Hz: an LFO's edges — unless something hard-syncs it: the resets come at the sync source's rate, and each is a raw jump of
             // the saw (round 5's soak at 200 voices x 6 000 samples, seed 66697: a 22 Hz saw, synced by a filter's highpass, on a second filter's
             // cutoff: 4.5e-5 in the contracted form of that filter, in 8 voices of 200)
@@ -404,6 +414,8 @@ struct Analysis {
             // a 4.8e-7 disturbance on the input came out at 6.9e-5 — 145 x, eleven times the static norm times four.  No bound is claimed for
             // such a filter: unbounded, like one near self-oscillation.
             if (L.motion & (kJumpAudio | kJumpNoise)) L.stable = false;
+            L.overdriven = in_mag(m, SRACK_VCF_IN_AUDIO) > kLadderDriveMax;
+            if (L.overdriven && hi > kLadderTameCutoff) L.stable = false;
             constexpr int kGrid = 12;
             for (int j = 0; j <= kGrid && L.stable; j++) {
                 const double fr = lo + (hi - lo) * (double)j / kGrid;
@@ -752,7 +764,7 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
             if (saw && !square && !sine && mod.in[SRACK_OSC_IN_CV].src < 0) add(kFixed, m, [&](int c) { return times(kEpsFixed, gw(c, m, SRACK_OSC_OUT_SAW)); });
         } else if (mod.type == SRACK_MOD_MOOG_FILTER) {
             const Ladder& L = A.ladder[(size_t)m];
-            const double j = !L.stable || (L.motion & kJumpAudio) ? kInf : (L.motion & kJumpRare) ? kLadderRareJumps : 1.0;
+            const double j = !L.stable || L.overdriven || (L.motion & kJumpAudio) ? kInf : (L.motion & kJumpRare) ? kLadderRareJumps : 1.0;
             add(kLadder, m, [&](int c) {
                 double v = 0.0;
                 for (int p = 0; p < 3; p++)

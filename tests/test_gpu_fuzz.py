@@ -122,16 +122,18 @@ def test_random_patch_default_modes_within_tolerance(seed, noise, oracle, monkey
     assert not bad, f"seed {seed} noise {noise}: " + " | ".join(bad)
 
 
-@pytest.mark.parametrize("seed", [104123, 105055])
-def test_soak_finds_with_per_voice_parameters(seed, oracle, monkeypatch):
-    """Round 5's soak over patches whose resonances, amounts, envelope times and initial phases are per-voice arrays too (FUZZ_MORE_OV), at the
-    soaks' 200 voices x 6 000 samples: 104123 — an audio-rate sine on a cutoff whose filter feeds another cutoff (5.2e-4 before the motion
-    classes handed a filter's own cutoff's motion on) — and 105055 — an audio-rate saw on the cutoff of a literal ladder that turned a 4.8e-7
-    disturbance of its input into 6.9e-5 (no bound is claimed for such a filter since: everything in front of it exact).  Both are
-    bit-identical to the oracle now in all three default flavours."""
-    monkeypatch.setenv("FUZZ_MORE_OV", "1")
+@pytest.mark.parametrize("seed,noise,more", [(104123, False, True), (105055, False, True), (123042, True, False)])
+def test_soak_finds_at_two_hundred_voices(seed, noise, more, oracle, monkeypatch):
+    """Round 5's later soaks, at their 200 voices x 6 000 samples.  With resonances, amounts, envelope times and initial phases as per-voice arrays
+    too (FUZZ_MORE_OV): 104123 — an audio-rate SINE on a cutoff whose filter feeds another cutoff (5.2e-4 before the motion classes handed a
+    filter's own cutoff's motion on) — and 105055 — a ladder, already literal, behind a mix of magnitude 4 and with an audio-rate saw on its
+    cutoff, that turned a 4.8e-7 disturbance of its input into 6.9e-5.  The noise family: 123042 — a ladder behind a reverb, 1.0e-4.  The last two
+    are the OVERDRIVEN ladder (tools/ladder_calib.c `amp`: chaotic from an input of ~1.9 up where the cutoff is high): no bound is claimed for
+    such a filter, nor for one whose cutoff moves at audio rate — everything in front exact, and all three bit-identical to the oracle."""
+    if more:
+        monkeypatch.setenv("FUZZ_MORE_OV", "1")
     S = srack_pkg.load()
-    B, build, overrides = random_patch(seed, False)
+    B, build, overrides = random_patch(seed, noise)
     V, T = 200, 6000
     o = oracle.OraclePatch(48000, B, 2)
     ids = build(o)

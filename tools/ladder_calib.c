@@ -6,6 +6,9 @@
  *                              and why a cutoff that jumps at audio rate has no contracted form)
  *   gain  <samples> <trials>   the literal ladder's response to a +-2.4e-7 disturbance of its input, same cutoff motions, by resonance bucket
  *                              for the two kinds that jump (the static L1 norms no longer bound it: res + 0.1 and x 4 for edges, unbounded for noise)
+ *   amp   <samples> <trials>   both by the input's AMPLITUDE (the reference clamps the stages, not the input): fine up to 1.75; from 1.9 up the ladder
+ *                              is chaotic at low resonance — 1e4 .. 1e6 x — where the cutoff is high (kLadderDriveMax)
+ *   tame  <samples> <trials>   ... and only there: by cutoff, for inputs far above the clamps (kLadderTameCutoff)
  *   l1    <samples>            L1 norms of the small-signal impulse responses against the measured gain and the sensitivity to the cutoff
  *                              (1.4 / cutoff x L1: approx.cpp uses 1.5)
  * The test suite runs `own` and `gain` at a small size against the constants (tests/test_approx.py). */
@@ -61,13 +64,14 @@ static double blep(double t, double dt) { if (dt == 0) return 0; if (t < dt) { t
 static const char* kNames[] = {"none", "ramp", "sineLFO", "sine700", "saw", "square", "noise", "squareLFO"};
 /* one trial: returns max relative difference per port between ladder A and ladder B.  mode 0: literal vs contracted, same input;
  * mode 1: literal vs literal with the input disturbed by +-2.4e-7 */
+static float g_amp = 1.0f; /* `amp`: the input's amplitude (the reference has no clamp in front of the ladder's first stage) */
 static void trial(int mode, int kind, int N, float res, float fr, float ex, unsigned long long* seed, double m3[3])
 {
     double delta = 440.0 * pow(2.0, rnd(seed) * 6 - 4) / 48000.0, pos = rnd(seed);
     double cd = (kind == 2 ? 3.0 : kind == 7 ? 5.0 : 440.0 * pow(2.0, rnd(seed) * 4 - 2)) / 48000.0, cp = rnd(seed);
     St a, b; memset(&a, 0, sizeof a); a.freq = -1; b = a; m3[0] = m3[1] = m3[2] = 0;
     for (int i = 0; i < N; i++) {
-        float saw = ((float)pos * 2.0f - 1.0f) - (float)blep(pos, delta); pos = fmod(pos + delta, 1.0);
+        float saw = g_amp * (((float)pos * 2.0f - 1.0f) - (float)blep(pos, delta)); pos = fmod(pos + delta, 1.0);
         float cv = 0;
         switch (kind) {
         case 1: cv = (float)fabs(fmod(i / 20000.0, 2.0) - 1.0); break;
@@ -101,6 +105,38 @@ int main(int argc, char** argv)
             }
             printf("own %-9s lp %.3e bp %.3e hp %.3e\n", kNames[kind], worst[0], worst[1], worst[2]);
         }
+    } else if (!strcmp(mode, "amp")) {
+        /* both measurements by the input's amplitude, a still cutoff (up to 0.8) and a ramping one (up to the clamp at 0.9), resonance 0 - 0.89 */
+        const float amps[] = {1, 1.5, 1.75, 1.9, 2.1, 3, 8};
+        for (int ai = 0; ai < 7; ai++)
+            for (int kind = 0; kind < 2; kind++) {
+                double own = 0, gain = 0;
+                g_amp = amps[ai];
+                for (int t = 0; t < trials; t++) {
+                    float res = (float)(rnd(&seed) * 0.89), fr = (float)(0.02 + rnd(&seed) * 0.78), ex = (float)rnd(&seed); double m3[3];
+                    trial(0, kind, N, res, fr, ex, &seed, m3);
+                    for (int k = 0; k < 3; k++) if (m3[k] > own) own = m3[k];
+                    trial(1, kind, N, res, fr, ex, &seed, m3);
+                    for (int k = 0; k < 3; k++) if (m3[k] > gain) gain = m3[k];
+                }
+                printf("amp %5g %-9s own %.3e gain %.3e\n", amps[ai], kNames[kind], own, gain / 2.4e-7);
+            }
+        g_amp = 1.0f;
+    } else if (!strcmp(mode, "tame")) {
+        /* the literal ladder's response to the disturbance by CUTOFF (still), for inputs far above the clamps */
+        const float amps[] = {2.5, 8, 1000}, frs[] = {0.2, 0.3, 0.4, 0.5, 0.6};
+        for (int ai = 0; ai < 3; ai++)
+            for (int fi = 0; fi < 5; fi++) {
+                double gain = 0;
+                g_amp = amps[ai];
+                for (int t = 0; t < trials; t++) {
+                    float res = (float)(rnd(&seed) * 0.89), fr = frs[fi] - 0.05f * (float)rnd(&seed); double m3[3];
+                    trial(1, 0, N, res, fr, 0.0f, &seed, m3);
+                    for (int k = 0; k < 3; k++) if (m3[k] > gain) gain = m3[k];
+                }
+                printf("tame %5g cutoff %.1f gain %.3e\n", amps[ai], frs[fi], gain / 2.4e-7);
+            }
+        g_amp = 1.0f;
     } else if (!strcmp(mode, "gain")) {
         for (int kind = 0; kind < 8; kind++)
             for (int rb = 0; rb < 9; rb++) {
