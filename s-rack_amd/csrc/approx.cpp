@@ -263,9 +263,9 @@ struct Analysis {
         };
         switch (mod.type) {
         case SRACK_MOD_OSCILLATOR: {
-            // the band-limited saw and square stay within +-1 while the two PolyBLEP windows of a period do not overlap (an increment up to a
-            // quarter cycle per sample: 12 kHz); beyond, twice that
-            const double edge_mag = osc_delta_max(m) <= 0.25 ? 1.0 : 2.0;
+            // the square stays within +-1 at any increment, the saw (band-limited or not) up to an increment of one cycle per sample (beyond,
+            // every sample falls into the PolyBLEP window and the correction adds up to 1: 2 pos)
+            const double edge_mag = osc_delta_max(m) <= 1.0 ? 1.0 : 2.0;
             o = {1.0, edge_mag, edge_mag};
             // below 48 Hz: an LFO's edges — unless something hard-syncs it: the resets come at the sync source's rate, and each is a raw jump of
             // the saw (round 5's soak at 200 voices x 6 000 samples, seed 66697: a 22 Hz saw, synced by a filter's highpass, on a second filter's
