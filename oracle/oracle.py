@@ -32,42 +32,46 @@ def build(force=False):
 _lib = None
 
 
+def bind(L):
+    """Argument types of the oracle's C entry points on a loaded library (this one, or a test's own build of srack_oracle.c)."""
+    vp, i32, u32, u64, dbl = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_double
+    fp, ip, dp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.or_patch_new.restype = vp
+    L.or_patch_new.argtypes = [u32, u32, u32]
+    L.or_patch_free.argtypes = [vp]
+    L.or_patch_clone.restype = vp
+    L.or_patch_clone.argtypes = [vp]
+    L.or_add_module.argtypes = [vp, i32]
+    L.or_num_modules.argtypes = [vp]
+    L.or_connect.argtypes = [vp, i32, i32, i32, i32]
+    L.or_disconnect.argtypes = [vp, i32, i32]
+    L.or_set_field.argtypes = [vp, i32, i32, dbl]
+    L.or_get_field.argtypes = [vp, i32, i32, dp]
+    L.or_set_step.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.or_set_wave.argtypes = [vp, i32, fp, u32, C.c_float]
+    L.or_set_output_buffer.argtypes = [vp, i32, i32, fp]
+    L.or_set_noise_seed.restype = None
+    L.or_set_noise_seed.argtypes = [vp, u64, u64]
+    L.or_plan.argtypes = [vp]
+    L.or_plan_list.argtypes = [vp, i32, ip, i32]
+    L.or_get_plan.argtypes = [vp, ip, i32]
+    L.or_get_removed_edges.argtypes = [vp, ip, i32]
+    L.or_module_calc.argtypes = [vp, i32]
+    L.or_execute.argtypes = [vp]
+    L.or_get_output.argtypes = [vp, i32, i32, fp]
+    L.or_render.argtypes = [vp, u32, fp, i32, i32, fp]
+    L.or_render_batch.argtypes = [vp, u32, u32, i32, ip, ip, C.POINTER(dp), fp, dp, i32]
+    L.or_voice_uniform.restype = C.c_float
+    L.or_voice_uniform.argtypes = [u64, u64, u32]
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
-        vp, i32, u32, u64, dbl = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_double
-        fp, ip, dp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)
-        L.or_patch_new.restype = vp
-        L.or_patch_new.argtypes = [u32, u32, u32]
-        L.or_patch_free.argtypes = [vp]
-        L.or_patch_clone.restype = vp
-        L.or_patch_clone.argtypes = [vp]
-        L.or_add_module.argtypes = [vp, i32]
-        L.or_num_modules.argtypes = [vp]
-        L.or_connect.argtypes = [vp, i32, i32, i32, i32]
-        L.or_disconnect.argtypes = [vp, i32, i32]
-        L.or_set_field.argtypes = [vp, i32, i32, dbl]
-        L.or_get_field.argtypes = [vp, i32, i32, dp]
-        L.or_set_step.argtypes = [vp, i32, i32, i32, i32, i32]
-        L.or_set_wave.argtypes = [vp, i32, fp, u32, C.c_float]
-        L.or_set_output_buffer.argtypes = [vp, i32, i32, fp]
-        L.or_set_noise_seed.restype = None
-        L.or_set_noise_seed.argtypes = [vp, u64, u64]
-        L.or_plan.argtypes = [vp]
-        L.or_plan_list.argtypes = [vp, i32, ip, i32]
-        L.or_get_plan.argtypes = [vp, ip, i32]
-        L.or_get_removed_edges.argtypes = [vp, ip, i32]
-        L.or_module_calc.argtypes = [vp, i32]
-        L.or_execute.argtypes = [vp]
-        L.or_get_output.argtypes = [vp, i32, i32, fp]
-        L.or_render.argtypes = [vp, u32, fp, i32, i32, fp]
-        L.or_render_batch.argtypes = [vp, u32, u32, i32, ip, ip, C.POINTER(dp), fp, dp, i32]
-        L.or_voice_uniform.restype = C.c_float
-        L.or_voice_uniform.argtypes = [u64, u64, u32]
-        _lib = L
+        _lib = bind(C.CDLL(_LIB_PATH))
     return _lib
 
 
@@ -78,8 +82,8 @@ def _fp(a):
 class OraclePatch:
     """One module-object graph, as the reference's workspace holds it."""
 
-    def __init__(self, sample_rate=48000, buffer_size=1024, channels=2, _handle=None):
-        self.L = lib()
+    def __init__(self, sample_rate=48000, buffer_size=1024, channels=2, _handle=None, _lib=None):
+        self.L = _lib or lib()
         self.sample_rate, self.buffer_size, self.channels = sample_rate, buffer_size, channels
         self.h = _handle if _handle is not None else self.L.or_patch_new(sample_rate, buffer_size, channels)
 
@@ -89,7 +93,7 @@ class OraclePatch:
             self.h = None
 
     def clone(self):
-        return OraclePatch(self.sample_rate, self.buffer_size, self.channels, _handle=self.L.or_patch_clone(self.h))
+        return type(self)(self.sample_rate, self.buffer_size, self.channels, _handle=self.L.or_patch_clone(self.h), _lib=self.L)
 
     def add_module(self, mtype):
         r = self.L.or_add_module(self.h, mtype)

@@ -135,11 +135,20 @@ typedef struct {
     int p_freeze, p_freeze_ctl;
 } or_freeverb;
 
-typedef struct {
+struct or_patch;
+struct or_module;
+/* A test's replacement for ONE module's calc() (or_set_calc_hook).  NULL — in every user of libsrack_oracle.so — is the reference's calc().
+ * tests/cpp/forms_emu.c, which compiles this file into a library of its own, uses it to put the GPU default mode's cheaper forms (the f32
+ * PolyBLEP, the fma-contracted ladder ...) into single modules of an otherwise untouched tick: a CPU check of csrc/approx.cpp's error bound. */
+typedef void (*or_calc_hook)(struct or_patch* p, struct or_module* m);
+
+typedef struct or_module {
     int type;
     int n_in, n_out;
     or_input in[OR_MAX_IN];
     float* out[OR_MAX_OUT]; /* n_out buffers of B floats; OutputModule keeps its `bufs` here too */
+    or_calc_hook hook;      /* NULL: the reference's calc() */
+    uint32_t hook_word;     /* the hook's own (copied with the module by or_patch_clone) */
     union {
         or_osc osc;
         or_vcf vcf;
@@ -1182,6 +1191,10 @@ void or_set_noise_seed(or_patch* p, uint64_t seed, uint64_t voice)
 
 static void or_calc(or_patch* p, or_module* m)
 {
+    if (m->hook) { /* a test's replacement (see or_calc_hook) */
+        m->hook(p, m);
+        return;
+    }
     switch (m->type) {
     case SRACK_MOD_OUTPUT: or_calc_output(p, m); break;
     case SRACK_MOD_OSCILLATOR: or_calc_osc(p, m); break;
@@ -1197,6 +1210,14 @@ static void or_calc(or_patch* p, or_module* m)
     case SRACK_MOD_GRID_SEQUENCER: or_calc_gridseq(p, m); break;
     case SRACK_MOD_PATTERN_SEQUENCER: or_calc_patseq(p, m); break;
     }
+}
+
+int or_set_calc_hook(or_patch* p, int module, or_calc_hook hook, uint32_t word)
+{
+    if (module < 0 || module >= p->n_modules) return -1;
+    p->modules[module].hook = hook;
+    p->modules[module].hook_word = word;
+    return 0;
 }
 
 /* One module's calc() on its own (the oscillator unit test drives calc() directly). */

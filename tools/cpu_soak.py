@@ -1,0 +1,91 @@
+"""The default mode's error bound soaked on the CPU (no GPU): every fuzz patch rendered twice by the oracle — as the reference computes it,
+and with the cheaper forms csrc/approx.cpp chose for it put into its modules (tests/cpp/forms_emu.c: the GPU's forms restated operation
+for operation) — and the difference held to the contract, |a - b| <= 1e-5 max(|b|, 1).  The emulation is not the GPU bit for bit, but the
+errors it injects are the forms' own at their own places (tests/test_forms_emu.py pins it to the GPU's measured errors), so a structure that
+integrates, thresholds or chaotically amplifies them does so here: round 5's five GPU soak finds all reproduce (with their seeds' decisions
+undone) and pass with them.
+usage: cpu_soak.py <first> <last> [noise] [--vt V,T] [--workers N] [--everything] [--json out.json]
+       environment: FUZZ_MORE_OV, FUZZ_SINE as for the GPU soaks (tests/fuzz_patches.py)
+--everything: every form in every module, whatever the bound says (what the flattener would render without it)."""
+import argparse, json, multiprocessing as mp, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+
+class Both:
+    """The graph API three times over: recorded for the analysis (approx_probe), the plain oracle, the oracle with forms."""
+
+    def __init__(self, sr, B, ch):
+        from oracle import oracle
+        from tests import forms_emu
+        from tests.test_approx import Rec
+        self.rec, self.a, self.b, self.types = Rec(sr, B, ch), oracle.OraclePatch(sr, B, ch), forms_emu.EmuPatch(sr, B, ch), []
+        self.rec.set_noise_seed = lambda *a: None
+
+    def __getattr__(self, name):
+        def call(*args):
+            r = None
+            for o in (self.rec, self.a, self.b):
+                r = getattr(o, name)(*args)
+            if name == "add_module":
+                self.types.append(args[0])
+            return r
+        return call
+
+
+def one(job):
+    seed, noise, V, T, everything = job
+    from tests.fuzz_patches import random_patch
+    probe = os.path.join(ROOT, "tests", "cpp", "approx_probe")
+    B, build, overrides = random_patch(seed, noise)
+    g = Both(48000, B, 2)
+    ids = build(g)
+    ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]
+    for m, f, vals in ov:
+        g.rec.override(m, f, vals)
+    plan = g.rec.run(probe)
+    if plan["exact_patch"] and not everything:
+        return seed, 0.0, 0.0, True, "exact patch", 0
+    forms = g.b.apply_plan(g.types, None if everything else plan, everything)
+    if not forms:
+        return seed, 0.0, 0.0, True, "no forms", 0
+    ref, _ = g.a.render_batch(V, T, ov, threads=1)
+    emu, _ = g.b.render_batch(V, T, ov, threads=1)
+    masks = bool((np.isnan(emu) == np.isnan(ref)).all() and (np.isinf(emu) == np.isinf(ref)).all())
+    ok = np.isfinite(ref) & np.isfinite(emu)
+    r64 = ref.astype(np.float64)
+    err = np.abs(emu.astype(np.float64) - r64) / np.maximum(np.abs(r64), 1.0)
+    err = np.where(ok, err, 0.0)
+    return seed, float(err.max()) if err.size else 0.0, float((err > 1e-5).mean()), masks, "bound %.1e" % plan["bound"], len(forms)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("first", type=int); ap.add_argument("last", type=int); ap.add_argument("noise", nargs="?")
+    ap.add_argument("--vt", default="16,6000"); ap.add_argument("--workers", type=int, default=8); ap.add_argument("--everything", action="store_true")
+    ap.add_argument("--json")
+    a = ap.parse_args()
+    V, T = (int(x) for x in a.vt.split(","))
+    from tests import forms_emu
+    from tests.test_approx import _build, CSRC
+    forms_emu.lib()  # (built once, before the workers start)
+    _build(os.path.join(ROOT, "tests", "cpp", "approx_probe"),
+           [os.path.join(ROOT, "tests", "cpp", "approx_probe.cpp"), os.path.join(CSRC, "graph.cpp"), os.path.join(CSRC, "approx.cpp"), os.path.join(CSRC, "approx.hpp"),
+            os.path.join(CSRC, "graph.hpp"), os.path.join(CSRC, "flatten.hpp"), os.path.join(ROOT, "include", "srack_hip.h")], ["-std=c++17", "-Wall"])
+    t0 = time.time()
+    jobs = [(s, bool(a.noise), V, T, a.everything) for s in range(a.first, a.last)]
+    bad, rendered, worst = [], 0, 0.0
+    with mp.Pool(a.workers) as pool:
+        for seed, e, frac, masks, note, n_forms in pool.imap_unordered(one, jobs, chunksize=4):
+            rendered += n_forms > 0
+            worst = max(worst, e if e == e else 0.0)
+            if e > 1e-5 or not masks:
+                bad.append([seed, e, frac, masks, note])
+                print(f"   seed {seed}: max rel err {e:.2e}, {frac:.5f} of the samples outside, non-finite positions equal {masks}; {note}", flush=True)
+    print(f"cpu soak: seeds {a.first}..{a.last - 1} noise={bool(a.noise)} VT={V},{T} more_ov={bool(os.environ.get('FUZZ_MORE_OV'))} sine={bool(os.environ.get('FUZZ_SINE'))} "
+          f"everything={a.everything}: {rendered} patches with forms rendered (the rest exact or formless), {len(bad)} outside the band, worst inside {worst if not bad else max(worst, 0):.2e}, {time.time() - t0:.0f} s", flush=True)
+    if a.json:
+        json.dump(dict(first=a.first, last=a.last, noise=bool(a.noise), vt=a.vt, more_ov=bool(os.environ.get("FUZZ_MORE_OV")), sine=bool(os.environ.get("FUZZ_SINE")),
+                       everything=a.everything, rendered=rendered, bad=sorted(bad), seconds=time.time() - t0), open(a.json, "w"), indent=1)
