@@ -5,11 +5,11 @@ import srack_pkg
 
 W = srack_pkg.load_workloads()
 
-OSC, VCF, ADSR, VCA, MIX, MATH, GRID, PAT, SMP, NOISE, VERB = 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12
-N_IN = {OSC: 2, VCF: 2, ADSR: 1, VCA: 2, MIX: 4, MATH: 2, GRID: 2, PAT: 2, SMP: 2, NOISE: 0, VERB: 2}
+OSC, VCF, ADSR, VCA, MIX, MATH, GRID, PAT, NONLIN, SMP, NOISE, VERB = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+N_IN = {OSC: 2, VCF: 2, ADSR: 1, VCA: 2, MIX: 4, MATH: 2, GRID: 2, PAT: 2, NONLIN: 2, SMP: 2, NOISE: 0, VERB: 2}
 import os
 # (FUZZ_SINE=1: tools/fuzz_soak.py also draws the oscillators' sine port)
-OUT_PORTS = {OSC: [0, 1, 2] if os.environ.get("FUZZ_SINE") else [1, 2], VCF: [0, 1, 2], ADSR: [0], VCA: [0], MIX: [0], MATH: [0], GRID: [0, 1, 2], PAT: [0, 3, 7, 8], SMP: [0], NOISE: [0], VERB: [0, 1]}
+OUT_PORTS = {OSC: [0, 1, 2] if os.environ.get("FUZZ_SINE") else [1, 2], VCF: [0, 1, 2], ADSR: [0], VCA: [0], MIX: [0], MATH: [0], NONLIN: [0], GRID: [0, 1, 2], PAT: [0, 3, 7, 8], SMP: [0], NOISE: [0], VERB: [0, 1]}
 
 
 def random_patch(seed, noise=False):
@@ -65,6 +65,12 @@ def random_patch(seed, noise=False):
     if not out_conns:
         out_conns = [(out_src[0], OUT_PORTS[types[out_src[0]]][0], 0)]
     out_pos = int(rng.integers(0, n + 1))  # where the OutputModule sits in all_modules: the planner cares
+    if os.environ.get("FUZZ_NONLIN"):  # (tools/cpu_soak.py: half of the MathModules become NonLinearModules — same arity, so the rest of the patch keeps its draw)
+        r3 = np.random.default_rng((seed, 0x9))
+        for m, t in enumerate(types):
+            if t == MATH and r3.random() < 0.5:
+                types[m] = NONLIN
+                fields = [x for x in fields if x[0] != m] + [(m, W.NONLIN_CONSTANT, float(np.float32(r3.choice([0.5, 2.0, 3.0, r3.uniform(0.3, 3.0)]))))]
 
     def build(g):
         ids = []
@@ -98,6 +104,8 @@ def random_patch(seed, noise=False):
                 overrides.append((m, W.VCF_FREQ, lambda V, r=np.random.default_rng(seed * 131 + m): r.uniform(0.03, 0.7, V).astype(np.float32)))
             elif t == MATH:
                 overrides.append((m, W.MATH_CONSTANT, lambda V, r=np.random.default_rng(seed * 131 + m): r.uniform(-1, 1, V).astype(np.float32)))
+            elif t == NONLIN:
+                overrides.append((m, W.NONLIN_CONSTANT, lambda V, r=np.random.default_rng(seed * 131 + m): r.uniform(0.3, 3.0, V).astype(np.float32)))
             elif t == MIX:
                 overrides.append((m, W.MIX_GAIN0 + 1, lambda V, r=np.random.default_rng(seed * 131 + m): r.uniform(0, 1, V).astype(np.float32)))
             elif t == ADSR:
