@@ -223,10 +223,18 @@ def test_a_cutoff_that_jumps(probe):
     g, audio, cv, vcf = patch(OSC, 0.5, lfo=True)            # a 3.4 Hz square: rare jumps — twice the still ladder's epsilon
     r = g.run(probe)
     assert r["literal"][vcf] == 0 and r["exact_blep"][audio] == 0 and 3.0e-6 < r["bound"] < BUDGET
-    g, audio, cv, vcf = patch(ADSR, 0.5)                     # an envelope (P3's sweep): the same
-    g.connect(audio, SQUARE, cv, 0)
+    g, audio, cv, vcf = patch(ADSR, 0.5)                     # an envelope gated by a 3.4 Hz clock (P3's sweep): the same
+    clock = g.add_module(OSC)
+    g.set_field(clock, W.OSC_VAL, -7.0)
+    g.connect(clock, SQUARE, cv, 0)
     r = g.run(probe)
     assert r["literal"][vcf] == 0 and r["exact_blep"][audio] == 0 and 3.0e-6 < r["bound"] < BUDGET
+    # ... but an envelope moves as often as its gate opens: gated by the 440 Hz square (or by noise: tools/cpu_soak.py's seed 277445, the
+    # contracted lowpass at 1.0e-5 where "rare jumps" had said 3e-6) it restarts at audio rate
+    g, audio, cv, vcf = patch(ADSR, 0.5)
+    g.connect(audio, SQUARE, cv, 0)
+    r = g.run(probe)
+    assert r["literal"][vcf] == 1 and r["exact_blep"][audio] == 1
 
 
 def test_a_ladder_near_self_oscillation(probe):

@@ -77,6 +77,6 @@ def test_a_small_soak_of_the_bound(noise, probe):
     worst, rendered = 0.0, 0
     for seed in range(900000, 900120):
         _, e, _, masks, note, n, bound = cpu_soak.one((seed, noise, 16, 3000, False))
-        assert masks and e <= 1e-5 and e <= bound + 1.2e-7, (seed, e, note)
+        assert masks and e <= 1e-5 and e <= bound + 3.6e-7, (seed, e, note)
         worst, rendered = max(worst, e), rendered + (n > 0)
     assert rendered > 30 and worst > 0.0

@@ -81,9 +81,10 @@ if __name__ == "__main__":
         for seed, e, frac, masks, note, n_forms, bound in pool.imap_unordered(one, jobs, chunksize=4):
             rendered += n_forms > 0
             worst = max(worst, e if e == e else 0.0)
-            # the bound's own claim, stronger than the contract: the error stays below the patch's derived bound (plus the output's f32 rounding:
-            # a value rounded the other way is off by an ulp, 1.2e-7 relative to max(|ref|, 1) at most)
-            if n_forms and not a.everything and e > bound + 1.2e-7:
+            # the bound's own claim, stronger than the contract: the error stays below the patch's derived bound — plus three f32 ulps (3.6e-7 relative
+            # to max(|ref|, 1)): the feed-forward arithmetic behind a form (a product, a mixer's sums) rounds the other way here and there once its
+            # operands differ, an ulp per operation, which the bound does not count
+            if n_forms and not a.everything and e > bound + 3.6e-7:
                 above.append([seed, e, bound])
             if e > 1e-5 or not masks:
                 bad.append([seed, e, frac, masks, note])
