@@ -40,6 +40,10 @@ constexpr double kEpsSine = 2.4e-7;         // f32 sine after the exact f64 fold
 constexpr double kEpsFixed = 3.2e-12;       // 2^-64 fixed-point phase: kApproxHorizon steps x 2^-64 = 1.6e-12 of phase, saw slope 2
 constexpr double kEpsNonlin = 4e-6;         // v_log_f32 / v_exp_f32 power, relative to max(|out|, 1)
 constexpr double kEpsLadder[3] = {1.5e-6, 4.2e-6, 3.6e-6};  // contracted ladder, lowpass / bandpass / highpass (tools/ladder_calib.c)
+constexpr double kLadderNoiseInput = 1.5;   // ... with a noise-like signal on the audio input (noise, a sample player, a reverb: a new level every sample excites the resonance all the
+                                            // time, a saw now and then): `noisein`, 2.0 / 5.4 / 1.7e-6 up to resonance 0.6 — and 8.5e-6 / 1.2e-5 / 6.1e-6 from 0.8 up (0.7 with
+                                            // an LFO on the cutoff): no contracted form above kLadderNoiseInputRes (tools/cpu_soak.py, noise family, seeds 235484 ...)
+constexpr double kLadderNoiseInputRes = 0.6;
 constexpr double kLadderRareJumps = 2.0;    // ... with a cutoff that jumps now and then (an envelope's attack, a sequencer's step): same tool, 7e-6 on the bandpass
 constexpr double kLadderDriveMax = 1.75;    // above this input amplitude a ladder is OVERDRIVEN: its stages sit in their clamps and flip within a sample, and the last stage's
                                             // cubic, b4 - b4^3 / 6 — slope 1 - b4^2 / 2, below -1 past |b4| = 2 — with the stage's own feedback - b4 * f around it is an
@@ -63,6 +67,7 @@ struct Ladder {
     double l1[3] = {0.0, 0.0, 0.0};      // L1 norm of the impulse response audio -> lowpass / bandpass / highpass, worst over the reachable cutoffs
     double cutoff[3] = {0.0, 0.0, 0.0};  // gain cutoff CV -> port
     bool stable = true;
+    double own = 1.0;                    // factor on kEpsLadder for the ladder's own rounding (contracted, or literal behind a perturbed input): inf = none claimed
     bool overdriven = false;             // the audio input can exceed kLadderDriveMax (no contracted form; unbounded where the cutoff passes kLadderTameCutoff)
     uint32_t motion = 0;                 // kJump* of the cutoff CV
 };
@@ -423,6 +428,8 @@ struct Analysis {
             if (L.motion & (kJumpAudio | kJumpNoise)) L.stable = false;
             L.overdriven = in_mag(m, SRACK_VCF_IN_AUDIO) > kLadderDriveMax;
             if (L.overdriven && hi > kLadderTameCutoff) L.stable = false;
+            L.own = (L.overdriven || (L.motion & kJumpRare)) ? kLadderRareJumps : 1.0;
+            if (in_motion(m, SRACK_VCF_IN_AUDIO) & kJumpNoise) L.own = res > kLadderNoiseInputRes ? kInf : L.own * kLadderNoiseInput;
             constexpr int kGrid = 12;
             for (int j = 0; j <= kGrid && L.stable; j++) {
                 const double fr = lo + (hi - lo) * (double)j / kGrid;
@@ -771,7 +778,7 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
             if (saw && !square && !sine && mod.in[SRACK_OSC_IN_CV].src < 0) add(kFixed, m, [&](int c) { return times(kEpsFixed, gw(c, m, SRACK_OSC_OUT_SAW)); });
         } else if (mod.type == SRACK_MOD_MOOG_FILTER) {
             const Ladder& L = A.ladder[(size_t)m];
-            const double j = !L.stable || L.overdriven || (L.motion & kJumpAudio) ? kInf : (L.motion & kJumpRare) ? kLadderRareJumps : 1.0;
+            const double j = !L.stable || L.overdriven || (L.motion & kJumpAudio) ? kInf : L.own;
             add(kLadder, m, [&](int c) {
                 double v = 0.0;
                 for (int p = 0; p < 3; p++)
@@ -817,7 +824,7 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
             for (const InputRef& in : g.modules[(size_t)m].in)
                 if (in.src >= 0 && live[(size_t)in.src] && dirty[(size_t)in.src]) dirty_input = true;
             if (!dirty_input || !L.stable) continue;  // (an unstable ladder's gains are unbounded: nothing in front of it is left to dirty it)
-            const double j = (L.overdriven || (L.motion & kJumpRare)) ? kLadderRareJumps : 1.0;
+            const double j = L.own;  // (inf: a resonant ladder behind noise — nothing that perturbs its input may stay)
             for (int c = 0; c < n_ch; c++)
                 if (!G[(size_t)c].empty())
                     for (int p_ = 0; p_ < 3; p_++)

@@ -471,6 +471,33 @@ def test_a_ladder_behind_a_loud_mix(probe):
     assert r["literal"][vcf] == 1 and r["exact_blep"][a] == 0 and r["gain"][mix][0] < 4.0 and r["bound"] < BUDGET
 
 
+def test_noise_on_a_ladders_input(calib, probe):
+    """A saw excites a ladder's resonance now and then, white noise all the time: with noise on the audio input the contracted form's error grows with
+    the resonance — within 1.5 x the saw's figures up to 0.6 (3 x with an LFO square on the cutoff), 8.5e-6 / 1.2e-5 / 6.1e-6 from 0.8 up
+    (tools/cpu_soak.py, noise family: seeds 235484, 227662, 239367 above their own bound).  The bound: a noise-like input (noise, a sample player,
+    a reverb) costs 1.5 x, and above resonance 0.6 such a filter has no contracted form."""
+    out = subprocess.run([calib, "noisein", "30000", "40"], capture_output=True, text=True, timeout=300).stdout
+    rows = {(l.split()[1], float(l.split()[3])): [float(l.split()[k]) for k in (5, 7, 9)] for l in out.splitlines() if l.startswith("noisein")}
+    eps = (1.5e-6, 4.2e-6, 3.6e-6)
+    for (kind, res), e in rows.items():
+        if res <= 0.5:   # (the bucket 0.5 is resonance 0.5 .. 0.6)
+            assert all(x <= (3.0 if kind == "squareLFO" else 1.5) * lim for x, lim in zip(e, eps)), (kind, res, e)
+    assert rows[("none", 0.8)][1] > 8e-6
+
+    def patch(res):
+        g, (noise, vcf, out_) = chain(NOISE, VCF)
+        g.set_field(vcf, W.VCF_RES, res)
+        g.connect(noise, 0, vcf, 0)
+        g.connect(vcf, 0, out_, 0)
+        return g, vcf
+    g, vcf = patch(0.5)
+    r = g.run(probe)
+    assert r["literal"][vcf] == 0 and r["bound"] == pytest.approx(1.5 * 1.5e-6)
+    g, vcf = patch(0.7)
+    r = g.run(probe)
+    assert r["literal"][vcf] == 1 and r["bound"] == 0.0
+
+
 def test_a_synced_lfo_on_a_cutoff_jumps_at_the_sync_sources_rate(probe):
     """Round 5's soak, seed 66697 (200 voices x 6 000 samples): a 22 Hz saw — by its pitch an LFO, whose wraps are rare jumps — hard-synced by a
     filter's highpass and wired to a second filter's cutoff: every sync is a raw jump of the saw, at audio rate, and the second filter's

@@ -6,6 +6,7 @@
  *                              and why a cutoff that jumps at audio rate has no contracted form)
  *   gain  <samples> <trials>   the literal ladder's response to a +-2.4e-7 disturbance of its input, same cutoff motions, by resonance bucket
  *                              for the two kinds that jump (the static L1 norms no longer bound it: res + 0.1 and x 4 for edges, unbounded for noise)
+ *   noisein <samples> <trials> `own` with white noise on the audio input, by resonance (a saw excites a resonance now and then, noise all the time)
  *   amp   <samples> <trials>   both by the input's AMPLITUDE (the reference clamps the stages, not the input): fine up to 1.75; from 1.9 up the ladder
  *                              is chaotic at low resonance — 1e4 .. 1e6 x — where the cutoff is high (kLadderDriveMax)
  *   tame  <samples> <trials>   ... and only there: by cutoff, for inputs far above the clamps (kLadderTameCutoff)
@@ -64,6 +65,7 @@ static double blep(double t, double dt) { if (dt == 0) return 0; if (t < dt) { t
 static const char* kNames[] = {"none", "ramp", "sineLFO", "sine700", "saw", "square", "noise", "squareLFO"};
 /* one trial: returns max relative difference per port between ladder A and ladder B.  mode 0: literal vs contracted, same input;
  * mode 1: literal vs literal with the input disturbed by +-2.4e-7 */
+static int g_noise_in = 0;
 static float g_amp = 1.0f; /* `amp`: the input's amplitude (the reference has no clamp in front of the ladder's first stage) */
 static void trial(int mode, int kind, int N, float res, float fr, float ex, unsigned long long* seed, double m3[3])
 {
@@ -72,6 +74,7 @@ static void trial(int mode, int kind, int N, float res, float fr, float ex, unsi
     St a, b; memset(&a, 0, sizeof a); a.freq = -1; b = a; m3[0] = m3[1] = m3[2] = 0;
     for (int i = 0; i < N; i++) {
         float saw = g_amp * (((float)pos * 2.0f - 1.0f) - (float)blep(pos, delta)); pos = fmod(pos + delta, 1.0);
+        if (g_noise_in) saw = g_amp * (float)(rnd(seed) * 2 - 1); /* `noisein`: white noise on the audio input instead of the saw */
         float cv = 0;
         switch (kind) {
         case 1: cv = (float)fabs(fmod(i / 20000.0, 2.0) - 1.0); break;
@@ -95,7 +98,23 @@ int main(int argc, char** argv)
     const char* mode = argc > 1 ? argv[1] : "own";
     int N = argc > 2 ? atoi(argv[2]) : 100000, trials = argc > 3 ? atoi(argv[3]) : 300;
     unsigned long long seed = 777;
-    if (!strcmp(mode, "own")) {
+    if (!strcmp(mode, "noisein")) {
+        /* `own` with white noise on the audio input, by resonance bucket, for the cutoff motions that have a contracted form */
+        g_noise_in = 1;
+        for (int kind = 0; kind < 8; kind++) {
+            if (kind != 0 && kind != 1 && kind != 2 && kind != 7) continue;
+            for (int rb = 0; rb < 9; rb++) {
+                double worst[3] = {0, 0, 0};
+                for (int t = 0; t < trials; t++) {
+                    float res = (float)(rb * 0.1 + rnd(&seed) * 0.1 * (rb == 8 ? 0.9 : 1.0)), fr = (float)(0.02 + rnd(&seed) * 0.78), ex = (float)rnd(&seed); double m3[3];
+                    trial(0, kind, N, res, fr, ex, &seed, m3);
+                    for (int k = 0; k < 3; k++) if (m3[k] > worst[k]) worst[k] = m3[k];
+                }
+                printf("noisein %-9s res %.1f lp %.3e bp %.3e hp %.3e\n", kNames[kind], rb * 0.1, worst[0], worst[1], worst[2]);
+            }
+        }
+        g_noise_in = 0;
+    } else if (!strcmp(mode, "own")) {
         for (int kind = 0; kind < 8; kind++) {
             double worst[3] = {0, 0, 0};
             for (int t = 0; t < trials; t++) {
