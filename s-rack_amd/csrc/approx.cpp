@@ -281,7 +281,11 @@ struct Analysis {
             const uint32_t edges = osc_delta_max(m) < 1e-3 && !connected(m, SRACK_OSC_IN_SYNC) ? kJumpRare : kJumpAudio;
             // (the sine of an oscillator above LFO rate has no edges, but it moves by a good part of its range from one sample to the next:
             // for a cutoff that is the same thing — the calibration's "smooth" cutoffs are envelopes, LFOs and sines up to 1.8 kHz)
-            mv = {edges == kJumpAudio ? (uint32_t)kJumpAudio : 0u, edges, edges};
+            // ... and RAW jumps at audio rate — a hard sync's resets, the edges of an oscillator without anti-aliasing — excite a filter's resonance
+            // like noise does, not like the band-limited saw the ladder's figures were measured with (tools/cpu_soak.py, seeds 226856 and 405576:
+            // hard-synced saws into contracted ladders at resonance 0.79 / 0.91, 5.2e-6 where the bandpass's figure is 4.2e-6, 1.9e-6 for 1.5e-6)
+            const uint32_t raw = edges == kJumpAudio && (connected(m, SRACK_OSC_IN_SYNC) || field(m, SRACK_OSC_ANTIALIASING).lo == 0.0) ? (uint32_t)kJumpNoise : 0u;
+            mv = {(edges == kJumpAudio ? (uint32_t)kJumpAudio : 0u) | (connected(m, SRACK_OSC_IN_SYNC) ? raw : 0u), edges | raw, edges | raw};
             break;
         }
         case SRACK_MOD_MOOG_FILTER: {

@@ -498,6 +498,25 @@ def test_noise_on_a_ladders_input(calib, probe):
     assert r["literal"][vcf] == 1 and r["bound"] == 0.0
 
 
+def test_raw_jumps_on_a_ladders_input_count_as_noise(probe):
+    """A hard-synced oscillator resets mid-ramp, one without anti-aliasing has raw edges: jumps a band-limited saw does not have, at audio rate.
+    tools/cpu_soak.py (seeds 226856, 405576): such saws into contracted ladders at resonance 0.79 / 0.91 came out at 5.2e-6 / 1.9e-6 against
+    4.2e-6 / 1.5e-6.  They count as a noise-like input: 1.5 x up to resonance 0.6, no contracted form above."""
+    def patch(res, synced=False, aa=True):
+        g, (clock, osc, vcf, out_) = chain(OSC, OSC, VCF)
+        g.set_field(vcf, W.VCF_RES, res)
+        if not aa:
+            g.set_field(osc, W.OSC_ANTIALIASING, 0)
+        if synced:
+            g.connect(clock, SAW, osc, 1)
+        g.connect(osc, SAW, vcf, 0)
+        g.connect(vcf, 0, out_, 0)
+        return g, vcf
+    for res, synced, aa, literal in ((0.8, False, True, 0), (0.8, True, True, 1), (0.8, False, False, 1), (0.5, True, True, 0), (0.5, False, False, 0)):
+        g, vcf = patch(res, synced, aa)
+        assert g.run(probe)["literal"][vcf] == literal, (res, synced, aa)
+
+
 def test_a_synced_lfo_on_a_cutoff_jumps_at_the_sync_sources_rate(probe):
     """Round 5's soak, seed 66697 (200 voices x 6 000 samples): a 22 Hz saw — by its pitch an LFO, whose wraps are rare jumps — hard-synced by a
     filter's highpass and wired to a second filter's cutoff: every sync is a raw jump of the saw, at audio rate, and the second filter's
