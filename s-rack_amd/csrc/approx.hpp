@@ -11,6 +11,12 @@
 // 1 / (1 - loop gain) or diverges.  Where a gain is unbounded every form in front of it is denied — an oscillator whose pitch moves, or whose
 // sine is heard there, is then evaluated exactly as a whole (2^cv by the libm's pow, the reference's sine) —, and a patch whose VALUES have no
 // bound, or with an unbounded gain behind a module without an exact form of its own, is rendered in the exact flavour altogether.
+// Where no bound can be claimed the analysis says so instead of guessing: a ladder whose cutoff moves at audio rate, one driven above 1.75 with
+// a cutoff that can pass 0.35 (the reference's ladder is chaotic there), a resonant one behind noise have unbounded gains — everything in front
+// exact.  A literal ladder behind a perturbed input keeps the contracted one's epsilon as a residual that only cleaning its inputs removes.
+// The constants (the forms' epsilons by input class and resonance, the drive limit, how envelopes, LFOs and sequencers move a cutoff) are
+// MEASURED on a CPU emulation of both ladders (tools/ladder_calib.c; tests/test_approx.py re-runs it), and the whole bound is soaked on the CPU:
+// tools/cpu_soak.py holds every fuzz patch, rendered by the oracle with the chosen forms emulated inside its modules, to its own bound.
 #pragma once
 #include <string>
 #include <vector>
