@@ -28,8 +28,10 @@ per-voice variant (`cfg3_poly`), config 2 (4 096 identical voices), config 4 (P2
 modulator inside its feedback loop exact as a whole (csrc/approx.cpp: a loop through a pitch has no error bound; profiles/r05_horizon.json) — and
 with the fast kernels a host may ask for (`cfg4_fast`: SRACK_RENDER_KEEP_DEFAULT, inside the contract for ~30 s of audio), both again at the app's
 buffer_size 1024 (`cfg4_b1024`, `cfg4_b1024_fast`), and the workloads of scope rows (f)1 and (f)4 (`p3`, `p4`: two output planes each).  They ride on
-the same line: flat scalars `<name>_ms_per_step` / `_frac_hbm` / `_kernel_ms` ... inside `roofline`, full detail under `configs`.  metric / value /
-config / roofline.frac stay the headline's.  `--no-side-configs` skips them.
+the same line as four flat scalars each inside `roofline` (`<name>_ms_per_step` / `_frac_hbm` / `_frac_hbm_kernel` / `_kernel_ms`); each one's
+own full bench line (`configs`) and the long prose go to bench_detail.json beside this file and to stderr, NOT onto the line: the driver's record keeps
+the last 8 KB of stdout, the line is held under 6 KB (shape_line; tests/test_dist.py).  metric / value / config / roofline.frac stay the
+headline's.  `--no-side-configs` skips them.
 
 Prints ONE JSON line (rank 0): metric/value/unit per the driver's contract, plus
   roofline     — achieved = algorithmic bytes of a step / step time (4 B x planes x V x T / t_render, per GPU),
@@ -461,6 +463,92 @@ def arithmetic_note(flags, info=""):
             "`cfg3_exact_*` on this line is the same workload in the reference's own arithmetic")
 
 
+LINE_BUDGET = 6000  # bytes: the driver's record keeps the last 8 KB of stdout — the ONE line has to fit whole (tests/test_dist.py holds it to this)
+SIDE_KEYS = ("ms_per_step", "frac_hbm", "frac_hbm_kernel", "kernel_ms")  # what a side configuration puts on the line; the rest is in bench_detail.json
+
+
+def shape_line(out):
+    """(line, detail): `detail` is everything measured; `line` is what is printed — the contract's keys, `roofline` (the headline's, plus four
+    flat scalars per side configuration), `cpu_baseline` — with the prose stated once and briefly.  Whatever else was measured (`configs`: every
+    side configuration's own full bench line; the long `arithmetic` paragraphs; the traffic's detail) goes to bench_detail.json / stderr.
+    Holds the line to LINE_BUDGET bytes: if it is still longer, optional keys go, least important first, and the line says which."""
+    import copy
+    detail = out
+    line = copy.deepcopy(out)
+    line.pop("configs", None)
+    line.pop("per_rank_ms_per_step", None) if line.get("n_gpus", 1) == 1 else None
+    cfg = line.get("config", {})
+    if len(cfg.get("arithmetic", "")) > 200:
+        cfg["arithmetic"] = cfg["arithmetic_short"] if "arithmetic_short" in cfg else cfg["arithmetic"][:197] + "..."
+    cfg.pop("arithmetic_short", None)
+    detail.get("config", {}).pop("arithmetic_short", None)
+    rf = line.get("roofline", {})
+    td = rf.pop("traffic_detail", None)
+    if td:
+        rf["traffic_source"] = td.get("source")
+    side = set()
+    for k in list(rf):
+        for w, _, _ in SIDE_CONFIGS:
+            if k.startswith(w + "_") and (k[len(w) + 1:] in SIDE_KEYS or k[len(w) + 1:] in ("frac_of_measured_f64_rate", "f64_ops_per_voice_sample")):
+                side.add(k)
+    for k in list(rf):  # side scalars outside SIDE_KEYS stay in the detail only
+        if k not in side and any(k.startswith(w + "_") for w, _, _ in SIDE_CONFIGS) and k != "cfg3_ticked_1024_ms_per_step":
+            del rf[k]
+    for k, v in list(rf.items()):
+        if isinstance(v, float):
+            rf[k] = float("%.6g" % v)
+    cb = line.get("cpu_baseline")
+    if cb:
+        cb.pop("single_thread_sample", None)
+        cb["note"] = "C restatement of the reference tick (oracle/srack_oracle.c); the Rust reference cannot be built here"
+    line["detail"] = "bench_detail.json"
+    dropped = []
+    for path in (("roofline", "definition"), ("config", "program"), ("cpu_baseline", "note"), ("config", "arithmetic"), ("roofline", "note"),
+                 ("host_enqueue_ms_per_step",), ("cpu_baseline", "sample"), ("config", "workload")):
+        if len(json.dumps(line)) <= LINE_BUDGET:
+            break
+        d = line
+        for k in path[:-1]:
+            d = d.get(k, {})
+        if path[-1] in d:
+            if path == ("config", "workload"):
+                d["workload"] = d["workload"][:160]
+            else:
+                del d[path[-1]]
+            dropped.append(".".join(path))
+    if len(json.dumps(line)) > LINE_BUDGET:  # last resort: the side scalars, longest names first (the headline never goes)
+        for k in sorted(side, key=len, reverse=True):
+            if len(json.dumps(line)) <= LINE_BUDGET:
+                break
+            rf.pop(k, None)
+            dropped.append("roofline." + k)
+    if dropped:
+        line["dropped_for_length"] = dropped
+    return line, detail
+
+
+def write_detail(detail):
+    """bench_detail.json beside bench.py (or $SRACK_BENCH_DETAIL), and the same on stderr — never on stdout."""
+    text = json.dumps(detail, indent=1)
+    path = os.environ.get("SRACK_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+    try:
+        with open(path, "w") as f:
+            f.write(text + "\n")
+    except OSError as e:
+        print(f"[bench] could not write {path}: {e}", file=sys.stderr)
+    print("[bench] detail:\n" + text, file=sys.stderr, flush=True)
+
+
+def arithmetic_short(flags, info=""):
+    """arithmetic_note in one sentence (the line carries this; the paragraph is in bench_detail.json and DESIGN.md section 2)"""
+    if "; exact osc " in info and not flags & 1:
+        return "default mode (f32 PolyBLEP, contracted ladder, fixed-point saw phase: within 1e-5), oscillator(s) " + info.split("; exact osc ")[1].split("]")[0] + " exact as a whole; DESIGN.md section 2"
+    if flags & 1 or "approx[exact" in info:
+        return "exact mode: the reference's operations one by one, frames bit-identical to the CPU tick; DESIGN.md section 2"
+    return ("default mode: within the 1e-5 contract, not the reference's operation sequence everywhere (f32 PolyBLEP, ladder with one fma per a*b-c*d, "
+            "2^-64 fixed-point saw phase); cfg3_exact_* is the same workload bit for bit; DESIGN.md section 2")
+
+
 def default_voices(workload):
     return {"cfg3": 262144, "cfg3_poly": 262144, "p3": 262144, "p4": 131072, "cfg2": 4096, "cfg4": 65536, "cfg4_b1024": 65536}[workload]
 
@@ -528,7 +616,7 @@ def run_rank(args, backend_cls=HipBackend):
                             + (" + RCCL reduce of the [2][T] mix (srack_dist_reduce_mix)" if getattr(be, "comm", None) is not None else ""),
                 "name": args.workload, "voices_per_gpu": V, "samples_per_step": T, "buffer_size": getattr(be, "buffer_size", 1024),
                 "render_flags": args.flags, "backend": be.name, "samples_per_call": args.block or T,
-                "arithmetic": arithmetic_note(args.flags, info),
+                "arithmetic": arithmetic_note(args.flags, info), "arithmetic_short": arithmetic_short(args.flags, info),
                 "frames_written": not args.no_frames, "mix_down": not args.no_mix, "program": info,
             },
             "roofline": {
@@ -647,7 +735,9 @@ def main(argv=None, backend_cls=HipBackend, self_cmd=None):
         os.dup2(saved, 1)
         os.close(saved)
     if out is not None:
-        print(json.dumps(out), flush=True)
+        line, detail = shape_line(out)
+        write_detail(detail)
+        print(json.dumps(line), flush=True)
     return 0
 
 

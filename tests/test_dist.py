@@ -102,7 +102,47 @@ def _run_bench_cpu(tmp_path, gpus, extra=(), env_extra=None):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0 only
+    assert len(lines[0]) < 8000, len(lines[0])  # the driver's record keeps the last 8 KB of stdout: the line has to fit whole
     return json.loads(lines[0])
+
+
+def test_bench_line_fits_the_drivers_record():
+    """Round 5's default line was 21.9 KB and the driver's record (last 8 KB of stdout) lost the headline.  bench.shape_line
+    is what stands between everything bench.py measures and the ONE line: fed round 5's own full output (profiles/r05_default_line.json:
+    ten side configurations, the long `arithmetic` paragraphs), and the same with every string doubled, it must stay under 6 KB and keep the
+    contract's keys, `roofline` with its fraction and the side configurations' scalars, and `cpu_baseline`."""
+    import copy
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_default_line.json")))
+    assert len(json.dumps(full)) > 20000
+
+    def double(x):
+        if isinstance(x, dict):
+            return {k: double(v) for k, v in x.items()}
+        return x + " " + x if isinstance(x, str) and len(x) > 40 else x
+    for src in (full, double(full)):
+        line, detail = bench.shape_line(copy.deepcopy(src))
+        text = json.dumps(line)
+        assert len(text) <= bench.LINE_BUDGET < 8000, len(text)
+        back = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+            assert back[k] == src[k], k
+        assert back["config"]["name"] == "cfg3" and "262144 voices" in back["config"]["workload"]
+        rf = back["roofline"]
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+        assert abs(rf["frac"] - src["roofline"]["frac"]) < 1e-5 and abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-5
+        assert rf["traffic"] == float("%.6g" % src["roofline"]["traffic"]) and rf["kernel_ms"] > 0 and rf["frac_kernel"] > 0
+        for w in ("cfg3_exact", "cfg3_poly", "cfg2", "cfg4", "cfg4_fast", "cfg4_b1024", "cfg4_b1024_fast", "p3", "p4"):
+            for key in bench.SIDE_KEYS:
+                assert abs(rf[f"{w}_{key}"] - src["roofline"][f"{w}_{key}"]) <= 1e-5 * abs(src["roofline"][f"{w}_{key}"]), (w, key)
+        cb = back["cpu_baseline"]
+        assert cb["value"] == src["cpu_baseline"]["value"] and cb["cores"] == 256 and cb["kind"] == "port" and cb["sample"]
+        assert "configs" not in back and "configs" in detail  # the side configurations' full lines are in the detail, not on the line
+    # a line that is already short goes through untouched (but for the pointer to the detail)
+    small = {"metric": "m", "value": 1.0, "n_gpus": 2, "per_rank_ms_per_step": [1.0, 2.0], "config": {"workload": "w", "arithmetic": "a"}, "roofline": {"frac": 0.5}}
+    line, _ = bench.shape_line(copy.deepcopy(small))
+    assert line == dict(small, detail="bench_detail.json")
 
 
 def test_bench_self_launches_two_ranks(tmp_path, W, oracle):
