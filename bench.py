@@ -476,7 +476,6 @@ def shape_line(out):
     detail = out
     line = copy.deepcopy(out)
     line.pop("configs", None)
-    line.pop("per_rank_ms_per_step", None) if line.get("n_gpus", 1) == 1 else None
     cfg = line.get("config", {})
     if len(cfg.get("arithmetic", "")) > 200:
         cfg["arithmetic"] = cfg["arithmetic_short"] if "arithmetic_short" in cfg else cfg["arithmetic"][:197] + "..."

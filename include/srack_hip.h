@@ -192,9 +192,12 @@ enum {
      * contract over a ten-minute render (csrc/approx.cpp; srack_render_info: "approx[bound 2.3e-06]").  Where the graph has an unbounded
      * error gain — a loop that amplifies, a ladder near self-oscillation, a loop through a gate or a pitch (BASELINE config 4's FM
      * feedback) — the oscillators behind it are evaluated exactly as the reference spells them ("; exact osc 0,3"), and a patch whose
-     * VALUES have no bound is rendered in the exact flavour altogether ("approx[exact: ...]").  This flag keeps the default forms in
-     * both cases (the f32 PolyBLEP / contracted ladder are still denied module by module where the bound asks for it): faster — config 4:
-     * 7 ms per second of audio against 18.5 — and inside the contract for renders of seconds, not minutes ("approx[kept default: ...]"). */
+     * VALUES have no bound, or with an unbounded gain behind a module without an exact form of its own (the sample player's pitch, a
+     * NonLinear), is rendered in the exact flavour altogether ("approx[exact: ...]").  This flag keeps the default forms where the reason
+     * is an unbounded GAIN (the f32 PolyBLEP / contracted ladder are still denied module by module where the bound asks for it): faster —
+     * config 4: 7 ms per second of audio against 18.5 — and inside the contract for renders of seconds, not minutes ("approx[kept
+     * default: ...]").  It does NOT waive "unbounded values": there the default forms' clamps treat a NaN differently from the
+     * reference's min / max and the render is wrong from the first overflow on — such a patch stays exact. */
     SRACK_RENDER_KEEP_DEFAULT  = 1u << 6
 };
 

@@ -39,6 +39,9 @@ constexpr double kEpsBlep = 2.4e-7;         // f32 PolyBLEP against the f64 one
 constexpr double kEpsSine = 2.4e-7;         // f32 sine after the exact f64 fold
 constexpr double kEpsFixed = 3.2e-12;       // 2^-64 fixed-point phase: kApproxHorizon steps x 2^-64 = 1.6e-12 of phase, saw slope 2
 constexpr double kEpsNonlin = 4e-6;         // v_log_f32 / v_exp_f32 power, relative to max(|out|, 1)
+constexpr double kEpsNonlinPlain = 6e-8;    // the power WITHOUT that form (powf_pos: table-driven f64 log2, polynomial 2^y, one rounding): the host libm's powf is itself
+                                            // within 0.82 ulp, not correctly rounded, so the two part by an f32 ulp now and then (P4: 6.0e-8 in every mode,
+                                            // profiles/r05_horizon.json) — a RESIDUAL no decision removes; only what it reaches decides whether it matters
 constexpr double kEpsLadder[3] = {1.5e-6, 4.2e-6, 3.6e-6};  // contracted ladder, lowpass / bandpass / highpass (tools/ladder_calib.c)
 constexpr double kLadderNoiseInput = 1.5;   // ... with a noise-like signal on the audio input (noise, a sample player, a reverb: a new level every sample excites the resonance all the
                                             // time, a saw now and then): `noisein`, 2.0 / 5.4 / 1.7e-6 up to resonance 0.6 — and 8.5e-6 / 1.2e-5 / 6.1e-6 from 0.8 up (0.7 with
@@ -549,8 +552,10 @@ struct Analysis {
             }
             return s < kBig ? s : kInf;
         };
+        Gains inc = G, inc_prev = G;  // the last two sweeps' increments per wire (zeros)
+        bool changed = false;
         for (int sweep = 0; sweep < kSweeps + 8; sweep++) {
-            bool changed = false;
+            changed = false;
             for (int m : order)
                 for (int p = 0; p < (int)G[(size_t)m].size(); p++) {
                     if (!port_is_live(m, p)) continue;
@@ -558,10 +563,24 @@ struct Analysis {
                     double& cur = G[(size_t)m][(size_t)p];
                     if (v > cur * (1.0 + 1e-3) && sweep >= kSweeps) v = kInf;  // still growing after kSweeps: a cycle with a loop gain of (about) one or more
                     if (v > cur * (1.0 + 1e-7)) changed = true;
+                    inc_prev[(size_t)m][(size_t)p] = inc[(size_t)m][(size_t)p];
+                    inc[(size_t)m][(size_t)p] = v > cur ? v - cur : 0.0;
                     if (v > cur) cur = v;
                 }
             if (!changed) break;
         }
+        // Left with something still creeping up (a loop gain around 0.99: 1e-7 ... 1e-3 per sweep): the rest of the geometric series its last two
+        // increments imply is added, not dropped (the value was a few percent short, silently); increments that do not shrink: unbounded.
+        if (changed)
+            for (int m : order)
+                for (int p = 0; p < (int)G[(size_t)m].size(); p++) {
+                    double& cur = G[(size_t)m][(size_t)p];
+                    const double d = inc[(size_t)m][(size_t)p], d0 = inc_prev[(size_t)m][(size_t)p];
+                    if (d == 0.0 || cur == kInf) continue;
+                    const double rho = d0 > 0.0 ? d / d0 : 1.0;
+                    cur = rho < 1.0 ? cur + d * rho / (1.0 - rho) : kInf;
+                    if (!(cur < kBig)) cur = kInf;
+                }
         return G;
     }
 
@@ -590,11 +609,15 @@ struct Analysis {
             const bool seq = type(r.k) == SRACK_MOD_GRID_SEQUENCER || type(r.k) == SRACK_MOD_PATTERN_SEQUENCER;
             if (is_event_input(r.k, r.i)) {
                 if (same_cycle(m, r.k)) return kInf;
-                if (seq && r.i == SRACK_SEQ_IN_STEP && depth < 4) {
+                if (seq && r.i == SRACK_SEQ_IN_STEP) {
                     const int first = type(r.k) == SRACK_MOD_GRID_SEQUENCER ? (int)SRACK_GRIDSEQ_OUT_GATE : (int)SRACK_PATSEQ_OUT_GATE0;
                     const int last = type(r.k) == SRACK_MOD_GRID_SEQUENCER ? (int)SRACK_GRIDSEQ_OUT_GATE : (int)SRACK_PATSEQ_OUT_GATE0 + 7;
-                    for (int o = first; o <= last; o++)
-                        if (port_is_live(r.k, o)) s += pure_square_gain(G, r.k, o, c, depth + 1);
+                    for (int o = first; o <= last; o++) {
+                        if (!port_is_live(r.k, o)) continue;
+                        // (past four sequencers in a row the hand-on is no longer followed: that gate output counts with its ordinary wire gain —
+                        // its event readers at kEventGain included —, not with 0 as until round 5: ADVICE r05)
+                        s += depth < 4 ? pure_square_gain(G, r.k, o, c, depth + 1) : G[(size_t)r.k][(size_t)o];
+                    }
                 }
                 continue;
             }
@@ -720,6 +743,7 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
         for (size_t p = 0; p < A.mag[(size_t)m].size(); p++)
             if (A.port_is_live(m, (int)p) && A.mag[(size_t)m][p] == kInf) {
                 P.exact_patch = true;
+                P.unbounded_values = true;
                 P.why = "unbounded values at module " + std::to_string(m) + " port " + std::to_string(p);
                 break;
             }
@@ -728,12 +752,14 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
     // An oscillator whose pitch moves (2^cv by polynomial) or whose sine is heard there (the polynomial sine: the reference's own but for 3
     // roundings in a million) is evaluated exactly as a whole — that oscillator: the libm's pow, the reference's sine, f64 PolyBLEP
     // (config 4: the modulator inside its feedback loop; the carrier behind it keeps the default forms).  The sample player's pitch has no
-    // such form: the whole patch goes exact.
+    // such form: the whole patch goes exact.  Nor has a NonLinear: its power is the host libm's powf to within an f32 ulp in every
+    // mode, never bit for bit — the exact flavour is the closest there is (ocml's f64 log2 inside), and it keeps everything AROUND the waveshaper
+    // the reference's own, as round 4 rendered such loops.
     for (int m = 0; m < n_mod; m++) {
         if (!live[(size_t)m]) continue;
         const Module& mod = g.modules[(size_t)m];
         const bool osc = mod.type == SRACK_MOD_OSCILLATOR && (mod.in[SRACK_OSC_IN_CV].src >= 0 || A.port_is_live(m, SRACK_OSC_OUT_SINE));
-        const bool player = mod.type == SRACK_MOD_SAMPLE && mod.in[SRACK_SAMPLE_IN_CV].src >= 0;
+        const bool player = (mod.type == SRACK_MOD_SAMPLE && mod.in[SRACK_SAMPLE_IN_CV].src >= 0) || mod.type == SRACK_MOD_NONLINEAR;
         if (!osc && !player) continue;
         for (size_t p = 0; p < P.gain[(size_t)m].size(); p++)
             if (A.port_is_live(m, (int)p) && P.gain[(size_t)m][p] == kInf) {
@@ -820,6 +846,14 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
             }
         }
         std::vector<double> r((size_t)n_ch, 0.0);
+        for (const Form& f : forms) {  // a NonLinear without the f32 form: the table-driven power's own ulp against the libm's, through whatever reads it (an event input: 1e9)
+            if (f.kind != kNonlin || f.taken) continue;
+            for (int c = 0; c < n_ch; c++)
+                if (!G[(size_t)c].empty()) {
+                    const double v = times(kEpsNonlinPlain * std::max(1.0, A.mag[(size_t)f.module][0]), gw(c, f.module, 0));
+                    r[(size_t)c] += v < kBig ? v : kInf;
+                }
+        }
         for (const Form& f : forms) {
             if (f.kind != kLadder || f.taken) continue;
             const int m = f.module;

@@ -38,6 +38,7 @@ struct ApproxPlan {
     std::vector<char> saw_fixed;     // oscillator: phase in 2^-64 fixed point where the pitch is constant (OSC_FIXED_PHASE)
     bool exact_patch = false;        // the whole patch in the exact flavour (SRACK_RENDER_EXACT_OSC)
     std::string why;                 // what decided exact_patch ("" otherwise), for srack_render_info
+    bool unbounded_values = false;   // ... it was values without a bound (overflow to inf / NaN): not waived by SRACK_RENDER_KEEP_DEFAULT
     // the analysis itself (tests, diagnostics)
     std::vector<std::vector<double>> mag;    // [module][output port]: sup |value| on the wire (inf: unbounded)
     std::vector<std::vector<double>> gain;   // [module][output port]: max over output channels of d(channel) / d(this wire) (inf: unbounded)

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "jit.hpp"
@@ -795,29 +796,133 @@ int srack_device_free(void* d_ptr)
     });
 }
 
-// Device -> host through a PINNED bounce buffer of the library's own, a chunk at a time (DMA into pinned memory, then a CPU copy).  A plain
-// hipMemcpyAsync into the caller's pageable memory is what this was until round 5 — and what that round's soaks caught losing data: with
-// sixteen processes on one device, one read-back in a few thousand came back with a stretch of ZEROS (tens of pages, the same offsets
-// in call after call of one process) where a second read-back of the very same device bytes had the data (tools/fuzz_soak_default.py,
-// SOAK_RETRY=2; notes/r05.md R5.2).  The caller's pages are never handed to the copy engine now.
+// Device -> host through PINNED bounce buffers of the library's own, a chunk at a time (DMA into pinned memory, then a CPU copy).  A plain
+// hipMemcpyAsync into the caller's pageable memory FOLLOWED BY hipStreamSynchronize on the same stream is what this was until round 5 — and
+// what that round's soaks caught losing data: with sixteen processes on one device, one read-back in a few thousand came back with a stretch
+// of ZEROS (tens of pages, the same offsets in call after call of one process) where a second read-back of the very same device bytes had the
+// data (tools/fuzz_soak_default.py, SOAK_RETRY=2; notes/r05.md R5.2).  It was not a copy the host read too early — the synchronize was there,
+// on the copy's own stream, before the call returned (git show 0c84165^:s-rack_amd/csrc/capi.cpp) —: the runtime's staged copy into pageable
+// pages itself dropped them.  The caller's pages are never handed to the copy engine now.
+//   * per DEVICE a small pool of bounce sets (two pinned halves of kBounceBytes, a non-blocking stream, two events), created on demand and
+//     freed when the library is unloaded; no lock is held across a copy (a set is taken out of the pool for the duration);
+//   * the copy of chunk k + 1 runs (DMA) under the CPU's memcpy of chunk k;
+//   * a large read-back is cut into slices that helper threads copy side by side, each through a set of its own: one core's memcpy into
+//     fresh pageable memory (page faults included) is a few GB/s, PCIe is tens.
+// Ordering: everything enqueued on `stream` before the call is waited for first (hipStreamSynchronize), as before.
 namespace {
-std::mutex g_bounce_mutex;
-void* g_bounce = nullptr;
 constexpr size_t kBounceBytes = size_t(8) << 20;
+constexpr size_t kSliceMin = size_t(64) << 20;   // a helper thread is worth it from here
+constexpr int kMaxHelpers = 8;
+struct BounceSet {
+    int device = -1;
+    void* half[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+};
+struct BouncePool {
+    std::mutex m;
+    std::vector<BounceSet*> idle;
+    ~BouncePool()
+    {   // library unload / process exit: the HIP runtime may already be gone — errors are ignored
+        for (BounceSet* b : idle) {
+            for (int k = 0; k < 2; k++) {
+                if (b->half[k]) (void)hipHostFree(b->half[k]);
+                if (b->done[k]) (void)hipEventDestroy(b->done[k]);
+            }
+            if (b->st) (void)hipStreamDestroy(b->st);
+            delete b;
+        }
+    }
+    int take(int device, BounceSet** out)
+    {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i]->device == device) {
+                    *out = idle[i];
+                    idle.erase(idle.begin() + (long)i);
+                    return SRACK_OK;
+                }
+        }
+        BounceSet* b = new BounceSet();
+        b->device = device;
+        *out = b;  // (the caller hands it back whatever happens: a half-built set is completed or freed at unload)
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY_C(hipHostMalloc(&b->half[k], kBounceBytes, hipHostMallocDefault));
+            HIP_TRY_C(hipEventCreateWithFlags(&b->done[k], hipEventDisableTiming));
+        }
+        HIP_TRY_C(hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking));
+        return SRACK_OK;
+    }
+    void give(BounceSet* b)
+    {
+        if (!b) return;
+        std::lock_guard<std::mutex> lock(m);
+        idle.push_back(b);
+    }
+};
+BouncePool g_bounce_pool;
+
+// one slice, through one set: DMA of chunk k + 1 under the memcpy of chunk k
+int bounce_copy(int device, char* dst, const char* src, size_t bytes)
+{
+    HIP_TRY_C(hipSetDevice(device));  // (helper threads start on device 0)
+    BounceSet* b = nullptr;
+    int rc = g_bounce_pool.take(device, &b);
+    auto run = [&]() -> int {
+        if (rc != SRACK_OK) return rc;
+        const size_t n_chunks = (bytes + kBounceBytes - 1) / kBounceBytes;
+        auto len = [&](size_t k) { return std::min(kBounceBytes, bytes - k * kBounceBytes); };
+        auto issue = [&](size_t k) -> int {
+            HIP_TRY_C(hipMemcpyAsync(b->half[k & 1], src + k * kBounceBytes, len(k), hipMemcpyDeviceToHost, b->st));
+            HIP_TRY_C(hipEventRecord(b->done[k & 1], b->st));
+            return SRACK_OK;
+        };
+        int r = issue(0);
+        for (size_t k = 0; k < n_chunks && r == SRACK_OK; k++) {
+            if (k + 1 < n_chunks) r = issue(k + 1);  // (its half was emptied by the memcpy of chunk k - 1)
+            if (r != SRACK_OK) break;
+            HIP_TRY_C(hipEventSynchronize(b->done[k & 1]));
+            std::memcpy(dst + k * kBounceBytes, b->half[k & 1], len(k));
+        }
+        if (r != SRACK_OK) (void)hipStreamSynchronize(b->st);  // nothing of ours in flight when the set goes back
+        return r;
+    };
+    rc = run();
+    g_bounce_pool.give(b);
+    return rc;
+}
 }  // namespace
 int srack_device_to_host(void* h_dst, const void* d_src, size_t bytes, void* stream)
 {
     return guarded([&]() -> int {
         if (bytes == 0) return SRACK_OK;
         if (!h_dst || !d_src) return SRACK_ERR_INVALID;
-        std::lock_guard<std::mutex> lock(g_bounce_mutex);
-        if (!g_bounce) HIP_TRY_C(hipHostMalloc(&g_bounce, kBounceBytes, hipHostMallocDefault));  // (kept for the life of the process)
+        int device = 0;
+        HIP_TRY_C(hipGetDevice(&device));
         HIP_TRY_C(hipStreamSynchronize((hipStream_t)stream));  // what the caller enqueued before the copy
-        for (size_t off = 0; off < bytes; off += kBounceBytes) {
-            const size_t n = std::min(kBounceBytes, bytes - off);
-            HIP_TRY_C(hipMemcpy(g_bounce, (const char*)d_src + off, n, hipMemcpyDeviceToHost));
-            std::memcpy((char*)h_dst + off, g_bounce, n);
-        }
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int helpers = (int)std::min<size_t>({(size_t)kMaxHelpers, (size_t)hw, bytes / kSliceMin});
+        if (helpers <= 1) return bounce_copy(device, (char*)h_dst, (const char*)d_src, bytes);
+        // slices of whole chunks, one helper thread each (the calling thread takes the first)
+        const size_t n_chunks = (bytes + kBounceBytes - 1) / kBounceBytes, per = (n_chunks + (size_t)helpers - 1) / (size_t)helpers * kBounceBytes;
+        std::vector<int> rcs((size_t)helpers, SRACK_OK);
+        std::vector<std::string> errs((size_t)helpers);
+        std::vector<std::thread> threads;
+        auto slice = [&](int i) {
+            const size_t off = (size_t)i * per;
+            if (off >= bytes) return;
+            rcs[(size_t)i] = guarded([&]() { return bounce_copy(device, (char*)h_dst + off, (const char*)d_src + off, std::min(per, bytes - off)); });
+            if (rcs[(size_t)i] != SRACK_OK) errs[(size_t)i] = srack_last_error();  // (thread-local: carried back to the caller's thread below)
+        };
+        for (int i = 1; i < helpers; i++) threads.emplace_back(slice, i);
+        slice(0);
+        for (std::thread& t : threads) t.join();
+        for (int i = 0; i < helpers; i++)
+            if (rcs[(size_t)i] != SRACK_OK) {
+                if (i > 0) set_error(errs[(size_t)i]);
+                return rcs[(size_t)i];
+            }
         return SRACK_OK;
     });
 }

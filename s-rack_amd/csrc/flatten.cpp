@@ -979,7 +979,9 @@ int flatten(Graph& g, uint32_t n_voices, const std::vector<VoiceOverride>& overr
             if (plan.osc_exact[(size_t)m]) oscs += (oscs.empty() ? "" : ",") + std::to_string(m);
         if (render_flags & SRACK_RENDER_EXACT_OSC) {
             // (asked for: nothing to decide)
-        } else if ((render_flags & SRACK_RENDER_KEEP_DEFAULT) && (plan.exact_patch || !oscs.empty())) {
+        } else if ((render_flags & SRACK_RENDER_KEEP_DEFAULT) && (plan.exact_patch || !oscs.empty()) && !plan.unbounded_values) {
+            // (KEEP_DEFAULT waives the unbounded-GAIN cases only: where the VALUES have no bound the default forms' v_med3 clamps send a NaN to -1
+            // where the reference's min / max send it to +1 — wrong from the first overflow on, not "inside the contract for seconds")
             std::fill(A.osc_exact.begin(), A.osc_exact.end(), 0);
             out.approx_note = "kept default: " + (plan.exact_patch ? plan.why : "unbounded gain behind oscillator " + oscs);
         } else if (plan.exact_patch) {

@@ -176,6 +176,8 @@ struct DeviceState {
     hipStream_t ctl_stream = nullptr;      // the control program runs ahead of the voice kernels on its own stream
     hipEvent_t ev_begin = nullptr;         // render start on the caller's stream
     std::vector<hipEvent_t> ev_chunk;      // control chunk k finished
+    hipEvent_t ev_ready = nullptr;         // recorded on the null stream behind the upload's fills; the first render's stream waits for it (ready_pending)
+    bool ready_pending = false;
 };
 
 void device_release(DeviceState* d)
@@ -200,6 +202,7 @@ void device_release(DeviceState* d)
     for (auto e : d->pool) (void)hipEventDestroy(e);
     for (auto e : d->ev_chunk) (void)hipEventDestroy(e);
     if (d->ev_begin) (void)hipEventDestroy(d->ev_begin);
+    if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
     if (d->ctl_stream) (void)hipStreamDestroy(d->ctl_stream);
     delete d;
 }
@@ -442,10 +445,15 @@ static int upload_program(PatchHandle& h)
     h.dev->ctl.resize(h.prog.ctl.size());
     for (size_t s = 0; s < h.prog.ctl.size() && rc == SRACK_OK; s++) rc = upload_one(h.prog.ctl[s], h.dev->ctl[s]);
     // The fills above (hipMemset of rings and reverb lines) are asynchronous on the null stream, and what reads them first may run on the
-    // caller's stream or on the control pipeline's non-blocking one: set-up ends with the device at rest.  (Round 5's soaks, sixteen processes
-    // on one device: one render in ~2 500 came out with a stretch of samples wrong in every voice and right on the spot when repeated —
-    // e.g. the first 3.5 laps of a feedback ring, as if the ring had not been zero yet; never seen from a process that had the device to itself.)
-    if (rc == SRACK_OK) HIP_TRY(hipDeviceSynchronize());
+    // caller's stream or on the control pipeline's non-blocking one.  Ordered by an EVENT — recorded here behind the fills, waited for by the
+    // first render's stream (Segment::run; the control and mix streams start behind events of that stream) — not by putting the whole device
+    // to rest: a host that edits one patch's parameters while its other patches render on other streams re-flattens without stalling them
+    // (until round 6 this was a hipDeviceSynchronize).
+    if (rc == SRACK_OK) {
+        HIP_TRY(hipEventCreateWithFlags(&h.dev->ev_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(h.dev->ev_ready, nullptr));
+        h.dev->ready_pending = true;
+    }
     if (rc == SRACK_OK && h.dev_old) {
         rc = transplant(h);
         device_release(h.dev_old);
@@ -1320,6 +1328,10 @@ static int render_segment(PatchHandle& h, uint32_t T_total, uint32_t t_seg, uint
     if (!h.dev) {
         const int rc = upload_program(h);
         if (rc != SRACK_OK) return rc;
+    }
+    if (h.dev->ready_pending) {  // the upload's fills (null stream) before anything of this render
+        HIP_TRY(hipStreamWaitEvent(st, h.dev->ev_ready, 0));
+        h.dev->ready_pending = false;
     }
     return Segment(h, T_total, t_seg, T, d_frames, d_mix, flags, st).run();
 }

@@ -139,6 +139,32 @@ def test_event_inputs_and_the_square_that_arrives_unchanged(probe):
     g.connect(seq, W.GRIDSEQ_OUT_GATE, env, 0)
     g.connect(env, 0, out, 0)
     assert g.run(probe)["exact_blep"][lfo] == 0
+    # ... through as many sequencers in a row as anyone wires, the last one's gate also HEARD (a VCA): past the fourth the hand-on is no longer
+    # followed and that gate output counts with its ordinary gain — until round 5 it counted 0, readers and all
+    g, ids = chain(OSC, *([GRID] * 6), ADSR, VCA)
+    lfo, seqs, env, vca, out = ids[0], ids[1:7], ids[7], ids[8], ids[9]
+    for q in seqs:
+        g.set_step(q, 0, 0, W.STEP_ON, 3)
+    g.connect(lfo, SQUARE, seqs[0], 0)
+    for a_, b_ in zip(seqs, seqs[1:]):
+        g.connect(a_, W.GRIDSEQ_OUT_GATE, b_, 0)
+    g.connect(seqs[-1], W.GRIDSEQ_OUT_GATE, env, 0)
+    g.connect(seqs[-1], W.GRIDSEQ_OUT_GATE, vca, 0)
+    g.connect(env, 0, vca, 1)
+    g.connect(vca, 0, out, 0)
+    assert g.run(probe)["exact_blep"][lfo] == 1
+    g, ids = chain(OSC, *([GRID] * 3), ADSR, VCA)   # three in a row: followed to the end — the gate costs nothing, the VCA hears 2.4e-7
+    lfo, seqs, env, vca, out = ids[0], ids[1:4], ids[4], ids[5], ids[6]
+    for q in seqs:
+        g.set_step(q, 0, 0, W.STEP_ON, 3)
+    g.connect(lfo, SQUARE, seqs[0], 0)
+    for a_, b_ in zip(seqs, seqs[1:]):
+        g.connect(a_, W.GRIDSEQ_OUT_GATE, b_, 0)
+    g.connect(seqs[-1], W.GRIDSEQ_OUT_GATE, env, 0)
+    g.connect(seqs[-1], W.GRIDSEQ_OUT_GATE, vca, 0)
+    g.connect(env, 0, vca, 1)
+    g.connect(vca, 0, out, 0)
+    assert g.run(probe)["exact_blep"][lfo] == 0
     # ... after arithmetic it is a value like any other (round 4's seed 2691: a bandpass into a gate): exact PolyBLEP
     g, (lfo, gain, env, out) = chain(OSC, MATH, ADSR)
     g.set_field(gain, W.MATH_OPERATION, W.MATH_MULTIPLY)
@@ -288,6 +314,13 @@ def test_cycles_converge_to_their_geometric_series_or_diverge(probe):
     g, osc, a = loop(0.96)      # 25: the f32 PolyBLEP's 2.4e-7 becomes 6e-6
     r = g.run(probe)
     assert r["gain"][osc][SAW] == pytest.approx(25.0, rel=2e-2) and r["exact_blep"][osc] == 1
+    g, osc, a = loop(0.99)      # 100: the fixpoint stops sweeping at ~400 with 1.6 % to go — the geometric tail is added, not dropped
+    r = g.run(probe)
+    assert r["gain"][osc][SAW] == pytest.approx(100.0, rel=2e-3)
+    g, osc, a = loop(0.995)     # 200: 13 % to go after 400 sweeps (from 0.997 on a sweep still adds more than 1e-3: declared unbounded)
+    r = g.run(probe)
+    assert r["gain"][osc][SAW] == pytest.approx(200.0, rel=1e-2)
+    assert loop(0.997)[0].run(probe)["gain"][osc][SAW] == float("inf")
     g, osc, a = loop(1.0)       # round 4's seed 40913: gain exactly one — an integrator: the gain AND the values have no bound
     r = g.run(probe)
     assert r["gain"][osc][SAW] == float("inf") and r["exact_blep"][osc] == 1 and r["exact_patch"] and "unbounded values" in r["why"]
@@ -367,6 +400,32 @@ def test_a_shaper_with_an_exponent_below_one_is_steep_at_zero(probe):
     g, osc, shaper = patch(2.0)
     r = g.run(probe)
     assert r["gain"][osc][SAW] == pytest.approx(2.0) and r["exact_blep"][osc] == 0 and r["saw_fixed"][osc] == 1   # b |a|^(b-1) at |a| = 1
+
+
+def test_a_shaper_behind_an_unbounded_gain_turns_the_patch_exact(probe):
+    """NonLinear's power is the libm's powf to within an f32 ulp in EVERY mode, never bit for bit (powf_pos: table-driven log2, polynomial
+    2^y) — so inside a loop through a pitch, where only identical bits follow the reference, denying its f32 form is not enough and nothing about
+    it counts as 0: the whole patch goes exact (as the sample player's pitch does), which is how round 4 rendered such loops.  And where the form is
+    merely denied the plain power's own 6e-8 stays in the sums as a residual, through whatever gain the wire has."""
+    g, (osc, shaper, gain, out) = chain(OSC, NONLIN, MATH)
+    g.set_field(gain, W.MATH_OPERATION, W.MATH_MULTIPLY)
+    g.set_field(gain, W.MATH_CONSTANT, 0.3)
+    g.connect(osc, SINE, shaper, 0)
+    g.connect(shaper, 0, gain, 0)
+    g.connect(gain, 0, osc, 0)          # osc.sine -> |.|^b -> x 0.3 -> osc.cv: a loop through a pitch
+    g.connect(osc, SINE, out, 0)
+    r = g.run(probe)
+    assert r["gain"][shaper][0] == float("inf") and r["exact_patch"] and "unbounded gain behind module %d" % shaper in r["why"]
+    # a shaper whose f32 form is denied by a steep reader (another shaper with an exponent below one): the plain power's residual is in the bound
+    g, (osc, first, second, out) = chain(OSC, NONLIN, NONLIN)
+    g.set_field(first, W.NONLIN_CONSTANT, 2.0)
+    g.set_field(second, W.NONLIN_CONSTANT, 0.5)
+    g.connect(osc, SAW, first, 0)
+    g.connect(first, 0, second, 0)
+    g.connect(second, 0, out, 0)
+    r = g.run(probe)
+    assert not r["exact_patch"] and r["nonlin_loose"][first] == 0 and r["gain"][first][0] == pytest.approx(1e4)
+    assert r["bound"] > 1e-5 and r["bound"] == pytest.approx(6e-8 * max(1.0, r["mag"][first][0]) * 1e4 + (4e-6 if r["nonlin_loose"][second] else 6e-8) * max(1.0, r["mag"][second][0]), rel=1e-3)
 
 
 # ---- the budget is shared ----------------------------------------------------------------------------------------------------------------------

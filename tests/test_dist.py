@@ -140,7 +140,7 @@ def test_bench_line_fits_the_drivers_record():
         assert cb["value"] == src["cpu_baseline"]["value"] and cb["cores"] == 256 and cb["kind"] == "port" and cb["sample"]
         assert "configs" not in back and "configs" in detail  # the side configurations' full lines are in the detail, not on the line
     # a line that is already short goes through untouched (but for the pointer to the detail)
-    small = {"metric": "m", "value": 1.0, "n_gpus": 2, "per_rank_ms_per_step": [1.0, 2.0], "config": {"workload": "w", "arithmetic": "a"}, "roofline": {"frac": 0.5}}
+    small = {"metric": "m", "value": 1.0, "n_gpus": 1, "per_rank_ms_per_step": [1.0], "config": {"workload": "w", "arithmetic": "a"}, "roofline": {"frac": 0.5}}
     line, _ = bench.shape_line(copy.deepcopy(small))
     assert line == dict(small, detail="bench_detail.json")
 

@@ -153,6 +153,45 @@ def test_soak_finds_at_two_hundred_voices(seed, noise, more, oracle, monkeypatch
         assert "approx[bound" in p.info() and "exact osc" in p.info(), p.info()
 
 
+@pytest.mark.parametrize("seed,noise,env", [(251484, False, ("FUZZ_MORE_OV",)), (277445, True, ("FUZZ_MORE_OV",)), (235484, True, ()), (227662, True, ()), (239367, True, ()),
+                                            (226856, True, ()), (405576, False, ("FUZZ_NONLIN",))])
+def test_cpu_soak_finds_on_the_gpu(seed, noise, env, oracle, monkeypatch):
+    """The patches round 5's CPU soak (tools/cpu_soak.py on tests/cpp/forms_emu.c — an EMULATION of the kernels' forms) found above their own
+    derived bound, here through the kernels themselves, at the soak's 200 voices x 6 000 samples and its draw (notes/r05.md R5.8: 251484 a
+    literal ladder behind an f32 square; 277445 noise on an envelope's gate, the envelope on a cutoff: 9.98e-6 with every form taken; 235484 /
+    227662 / 239367 noise on a contracted ladder's input: 7.0 - 7.7e-6; 226856 / 405576 hard-synced saws — raw jumps at audio rate — into
+    contracted ladders, the second from the NonLinear family).  Each is held to the CONTRACT and to its OWN bound as srack_render_info states
+    it, plus three f32 ulps (the feed-forward roundings behind a form, which the bound does not count)."""
+    for e in env:
+        monkeypatch.setenv(e, "1")
+    S = srack_pkg.load()
+    B, build, overrides = random_patch(seed, noise)
+    V, T = 200, 6000
+    o = oracle.OraclePatch(48000, B, 2)
+    ids = build(o)
+    ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]
+    ref, _ = o.render_batch(V, T, ov, threads=8)
+    r64 = ref.astype(np.float64)
+    assert np.isfinite(r64).all() and np.abs(r64).max() > 0.01
+    for flags in DEFAULT_FLAGS + (DEFAULT_SPECIAL,):
+        p = S.Patch(48000, B, 2)
+        build(p)
+        p.configure_voices(V)
+        for m, f, vals in ov:
+            p.set_voice_field(m, f, vals)
+        if flags & 32:
+            try:
+                p.kernel_source(flags)
+            except S.SrackError as e:
+                assert e.code == S.ERR_UNSUPPORTED
+                continue
+        fr = p.render_channels(T, flags).astype(np.float64)
+        info = p.info()
+        err = float((np.abs(fr - r64) / np.maximum(np.abs(r64), 1.0)).max())
+        bound = 0.0 if "approx[exact" in info else float(info.split("approx[bound ")[1].split(";")[0].split("]")[0])
+        assert err <= 1e-5 and err <= bound * 1.05 + 3.6e-7, f"seed {seed} flags {flags}: {err:.2e} against its bound {bound:.1e}; {info}"
+
+
 @pytest.mark.parametrize("seed", [30111, 31051, 7, 23])
 def test_random_patch_default_modes_over_a_whole_second(seed, oracle):
     """The default contract over 48 000 samples (the other cases render 1 300 - 2 300): what grows with time.  30111: a held pitch CV's
