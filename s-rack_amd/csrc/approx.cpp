@@ -10,7 +10,7 @@
 //      heard there, is evaluated exactly as a whole (OSC_EXACT on that op); values without a bound, or an unbounded gain behind the sample
 //      player's pitch (no exact form of its own), turn the whole patch exact.
 //
-// Where the numbers come from.  Epsilons: f32 PolyBLEP / sine — two roundings at values in [1, 2): 2.4e-7.  The contracted ladder —
+// Where the numbers come from.  Epsilons: the f32 sine — two roundings at values in [1, 2): 2.4e-7; the f32 PolyBLEP — measured on the kernels' forms: 3.2e-7 (kEpsBlep).  The contracted ladder —
 // tools/ladder_calib.c emulates both forms on the CPU (filter.rs:58-92 against modules.hip.h vcf_step<true>): over resonance 0 ... 0.89,
 // cutoff 0.02 ... 0.9, saw inputs and still / ramped / sine-swept cutoffs the difference stays below 1.3e-6 (lowpass), 3.9e-6 (bandpass),
 // 3.3e-6 (highpass) whatever the L1 norm (the roundings are not aligned with the impulse response); a cutoff that JUMPS at audio rate (a
@@ -35,9 +35,15 @@ constexpr double kBig = 1e200;              // a gain or magnitude beyond this c
 constexpr double kEventGain = 1e9;          // an event input (`value > 0.0` decides when something happens: a gate, a sync, a step): an error e moves an
                                             // edge by a sample wherever |value| < e at a crossing, and a moved edge is an error of O(1) — the "gain" is
                                             // 1 / (the |value| a crossing may be trusted at): forms with e > 5e-15 are denied in front of an event
-constexpr double kEpsBlep = 2.4e-7;         // f32 PolyBLEP against the f64 one
+constexpr double kEpsBlep = 3.2e-7;         // f32 PolyBLEP against the f64 one, MEASURED on the kernels' own forms (tools/blep_calib.py, 2 048 pitches x 1 s, through tests/cpp/
+                                            // forms_emu.c, which tools/emu_vs_gpu.py holds to the kernels bit for bit): osc_step's 1.2e-7, the carried-phase saw 2.42e-7, the
+                                            // fixed-point saw 3.15e-7 on top of its window term (kEpsFixedWindow) — with 1 / dt rounded once (modules.hip.h, inv_dt_f32)
 constexpr double kEpsSine = 2.4e-7;         // f32 sine after the exact f64 fold
-constexpr double kEpsFixed = 3.2e-12;       // 2^-64 fixed-point phase: kApproxHorizon steps x 2^-64 = 1.6e-12 of phase, saw slope 2
+constexpr double kEpsFixed = 3.2e-12;       // 2^-64 fixed-point phase: kApproxHorizon steps x 2^-64 = 1.6e-12 of phase, saw slope 2 ...
+constexpr double kEpsFixedWindow = 0x1p-31; // ... PLUS, inside the two PolyBLEP windows, t = pos / dt taken from the phase's UPPER 32 bits (modules.hip.h, fosc_saw: c32 = f32(hi)):
+                                            // pos is below dt there, so the truncation to 2^-32 is an error of 2^-32 / dt in t and of up to twice that in -(1 - t)^2 —
+                                            // nothing at 440 Hz (5e-8), 1.0e-6 at 17 Hz (round 6, tools/emu_vs_gpu.py: seed 900146 rendered 1.02e-6 where the bound said
+                                            // 2.4e-7), 2.5e-5 for a 0.9 Hz LFO: the form's epsilon is this over the SMALLEST increment any voice has
 constexpr double kEpsNonlin = 4e-6;         // v_log_f32 / v_exp_f32 power, relative to max(|out|, 1)
 constexpr double kEpsNonlinPlain = 6e-8;    // the power WITHOUT that form (powf_pos: table-driven f64 log2, polynomial 2^y, one rounding): the host libm's powf is itself
                                             // within 0.82 ulp, not correctly rounded, so the two part by an f32 ulp now and then (P4: 6.0e-8 in every mode,
@@ -805,7 +811,11 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
                     return v;
                 });
             if (sine) add(kSine, m, [&](int c) { return times(kEpsSine, gw(c, m, SRACK_OSC_OUT_SINE)); });
-            if (saw && !square && !sine && mod.in[SRACK_OSC_IN_CV].src < 0) add(kFixed, m, [&](int c) { return times(kEpsFixed, gw(c, m, SRACK_OSC_OUT_SAW)); });
+            if (saw && !square && !sine && mod.in[SRACK_OSC_IN_CV].src < 0) {
+                const double dt_min = 440.0 * std::exp2(A.field(m, SRACK_OSC_VAL).lo) / A.sr;  // (no CV: the pitch is val alone, per voice)
+                const double eps = dt_min > 0.0 ? kEpsFixed + kEpsFixedWindow / dt_min : kInf;
+                add(kFixed, m, [&](int c) { return times(eps, gw(c, m, SRACK_OSC_OUT_SAW)); });
+            }
         } else if (mod.type == SRACK_MOD_MOOG_FILTER) {
             const Ladder& L = A.ladder[(size_t)m];
             const double j = !L.stable || L.overdriven || (L.motion & kJumpAudio) ? kInf : L.own;
@@ -891,6 +901,9 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
                 if (f.taken && f.at[(size_t)worst_c] > 0.0 && (!top || f.at[(size_t)worst_c] > top->at[(size_t)worst_c])) top = &f;
             if (!top) break;
             top->taken = false;
+            if (top->kind == kBlep)  // (the kernels' fixed-point saw IS the f32 PolyBLEP form: without that one there is no fixed-point phase to pay for)
+                for (Form& f : forms)
+                    if (f.kind == kFixed && f.module == top->module) f.taken = false;
         }
         // the residuals of what is taken NOW (they only shrink as forms are denied): consistent, or once more with them in the sums
         std::vector<double> now = residuals();

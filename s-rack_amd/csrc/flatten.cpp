@@ -730,10 +730,11 @@ int Builder::build()
 void Builder::match_fused(bool has_rings)
 {
     // (the fused kernels take the exact flavour as ONE template parameter: a program in which single oscillators are exact — approx.cpp's
-    // answer to an unbounded gain — is the general path's)
+    // answer to an unbounded gain — is the general path's, but for the one mixed shape that has a kernel of its own: fm_pair_x below)
+    bool mixed = false;
     if (!(render_flags & SRACK_RENDER_EXACT_OSC))
         for (const DevOp& op : out.ops)
-            if (op.kind == OP_OSC && (op.flags & OSC_EXACT)) return;
+            if (op.kind == OP_OSC && (op.flags & OSC_EXACT)) mixed = true;
     if (has_rings) {
         // 2-operator FM with a one-sample feedback edge (patch P2 at buffer_size 1):
         //   DELAY_RD -> MATH_FB -> OSC_M -> DELAY_WR ; OSC_M -> MATH_IDX -> OSC_C -> OUT ; only sine ports, no sync
@@ -753,11 +754,16 @@ void Builder::match_fused(bool has_rings)
             o[1].in_slot[0] == o[0].out_slot[0] && o[2].in_slot[0] == o[1].out_slot[0] && o[3].in_slot[0] == o[2].out_slot[0] &&
             o[4].in_slot[0] == o[2].out_slot[0] && o[5].in_slot[0] == o[4].out_slot[0] && o[6].in_slot[0] == o[5].out_slot[0] && o[0].aux == o[3].aux)
         {
-            out.fused = FUSED_FM_PAIR;
-            out.fused_variant = far ? 1 : 0;  // 1: ring in HBM
+            if (!mixed) {
+                out.fused = FUSED_FM_PAIR;
+                out.fused_variant = far ? 1 : 0;  // 1: ring in HBM
+            } else if (far && (o[2].flags & OSC_EXACT) && !(o[5].flags & (OSC_EXACT | OSC_EXACT_BLEP)) && (o[5].flags & OSC_SINE_LOOSE)) {
+                out.fm_pair_x = true;  // the modulator exact as a whole, the carrier — its sine only heard — in its default forms (`fused` stays FUSED_NONE)
+            }
         }
         return;
     }
+    if (mixed) return;
     if (is_ctl) return;  // the voice-chain shapes below are per-voice programs
     int n_kind[kOpKinds] = {0};
     for (const DevOp& op : out.ops) n_kind[op.kind]++;

@@ -144,11 +144,11 @@ __global__ __launch_bounds__(64) void render_voice_chain(KernelArgs a, ChainRole
     ka.sr = oa.sample_rate;
     ka.val = 0.0;
     ka.delta = oa.delta_row >= 0 ? make_f64(row(oa.delta_row), row(oa.delta_row + 1)) : oa.delta;
-    ka.inv_dt = 1.0f / (float)ka.delta;
+    ka.inv_dt = inv_dt_f32(ka.delta);
     kl.sr = ol.sample_rate;
     kl.val = 0.0;
     kl.delta = ol.delta_row >= 0 ? make_f64(row(ol.delta_row), row(ol.delta_row + 1)) : ol.delta;
-    kl.inv_dt = 1.0f / (float)kl.delta;
+    kl.inv_dt = inv_dt_f32(kl.delta);
 
     VcfRegs sv;
     {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64) void render_voice_chain_track(KernelArgs a, Cha
     ka.sr = oa.sample_rate;
     ka.val = 0.0;
     ka.delta = oa.delta_row >= 0 ? make_f64(row(oa.delta_row), row(oa.delta_row + 1)) : oa.delta;
-    ka.inv_dt = 1.0f / (float)ka.delta;
+    ka.inv_dt = inv_dt_f32(ka.delta);
 
     VcfRegs sv;
     const int s0 = ov.state_row;
@@ -1414,6 +1414,339 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (s == 0) {
             auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
             put(om.state_row + OSC_S_POS_LO, f64_lo(pos_m));
+            put(om.state_row + OSC_S_POS_HI, f64_hi(pos_m));
+            put(om.state_row + OSC_S_SYNC_LAST, 0u);
+            put(ocr.state_row + OSC_S_POS_LO, f64_lo(pos_c));
+            put(ocr.state_row + OSC_S_POS_HI, f64_hi(pos_c));
+            put(ocr.state_row + OSC_S_SYNC_LAST, 0u);
+        }
+    }
+}
+
+// ---- the same, with the MODULATOR EXACT: time lanes for everything but two instructions (round 6) -----------------------------------------
+// Default mode renders config 4 with the modulator exact as a whole (csrc/approx.cpp: its feedback loop runs through a pitch, where only the
+// reference's own bits follow the reference for longer than seconds) — 2^cv by the host libm's pow operation for operation, the reference's
+// sine —, and until round 6 that program was the general path's: one lane per voice, 48 000 samples in a row, one wave per SIMD, the ring
+// through HBM both ways (22.2 ms per step, 3.0 x the algorithmic bytes).  But with a delay of B >= 256 samples the modulator's pitch CV of a
+// whole chunk is in the ring when the chunk starts, exactly as for the kernel above; what an EXACT oscillator may not do is add its
+// increments in another order.  So only that stays serial:
+//     pos[t + 1] = (pos[t] + delta[t]) % 1.0            oscillator.rs:152-153 — one v_add_f64 and one v_fract_f64 per voice-sample,
+// the reference's operations in the reference's order, and everything around it is evaluated across TIME lanes, each value by the
+// reference's own expression: delta[t] = 440 * 2^(f64(cv[t]) + f64(val)) / sr (oscillator.rs:43-48,132: exp2_libm, div_rn) before the scan,
+// sine[t] = (pos[t] * PI * 2).sin() as f32 (oscillator.rs:133: sine_exact) after it.  Bit-identical to osc_step's exact flavour, hence to
+// the CPU tick.
+//   * A workgroup of 512 threads owns 32 voices for the launch, lane (g, s) = voice g, time slice s of 16; a chunk is 64 samples, slice s
+//     holds samples [4 s, 4 s + 4).  The ring ([B][32] f32, 128 KB at the app's 1024) lives in LDS for the whole launch: HBM sees the frames.
+//   * The scan runs in the first 32 lanes of wave 0, through one [64][32] f64 buffer in LDS (increments in, phases out, in place), while
+//     all eight waves do the rest — a three-stage pipeline over chunks, three barriers per chunk:
+//         iteration k:   phases of chunk k -> registers | barrier | increments of chunk k + 1 -> buffer | barrier |
+//                        scan(k + 1)  ||  carrier frames of chunk k - 1, sines of chunk k (-> ring, carrier increments), increments of chunk k + 2 -> registers | barrier
+//   * The carrier behind the loop keeps the default forms of the kernel above (bounded-CV classes, prefix sum of its increments, f32
+//     sine): nothing feeds it back.  Its slice totals cross between the waves one iteration late, on the pipeline's own barriers.
+//   * A workgroup whose carrier cannot be proved tame (gains of hundreds of octaves, a phase outside [0, 1)) renders sample by sample
+//     through osc_step, one lane per voice, like the kernel above; increments that are not finite send the scan through fmod1.
+constexpr int kXPer = 4, kXChunk = kBlkSlices * kXPer;  // 64 samples per chunk
+__host__ __device__ inline size_t fm_block_x_lds_bytes(uint32_t B) { return sizeof(float) * B * kBlkVoices + sizeof(double) * kXChunk * kBlkVoices + sizeof(double) * 2 * 8 * kBlkVoices + sizeof(uint64_t) * 256 + 16; }
+struct LibmTabLds {
+    const uint64_t* t;
+    SRK_DEV uint64_t operator()(uint32_t i) const { return t[i]; }
+};
+
+template <int kOut>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void render_fm_pair_block_x(KernelArgs a, ChainRoles r)
+{
+    using namespace dev;
+    extern __shared__ __attribute__((aligned(16))) float blk_lds[];
+    const uint32_t B = (uint32_t)a.prog.buffer_size, V = a.V;
+    float* const ring_l = blk_lds;                                                   // [B][32]
+    double* const buf = (double*)(blk_lds + (size_t)B * kBlkVoices);                 // [64][32]: a chunk's modulator increments, then its phases
+    double* const sums = buf + kXChunk * kBlkVoices;                                  // [2][8][32]: the carrier's slice totals, per chunk parity, per wave, per voice
+    uint64_t* const tab = (uint64_t*)(sums + 2 * 8 * kBlkVoices);                     // the libm's 2^(k/128) table
+    uint32_t* const flag = (uint32_t*)(tab + 256);                                    // [0]: some modulator increment is not an ordinary number
+    const int tid = (int)threadIdx.x, g = tid & 31, s = tid >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave holds slices 2 w and 2 w + 1 of all 32 voices
+    const bool odd = (s & 1) != 0;
+    const uint32_t voice0 = (blockIdx.x - a.block0) * (uint32_t)kBlkVoices;
+    const uint32_t n_act = min((uint32_t)kBlkVoices, V - voice0);
+    const bool active = (uint32_t)g < n_act;
+    const uint32_t voice = voice0 + (uint32_t)g, vc = active ? voice : voice0 + n_act - 1u;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+
+    const DevOp& ofb = a.ops[r.adsr];    // roles as in render_fm_pair_ring
+    const DevOp& om = a.ops[r.osc_l];
+    const DevOp& oix = a.ops[r.vca];
+    const DevOp& ocr = a.ops[r.osc_a];
+    const int plane = a.ops[r.out].aux;
+    float* const ring = a.rings + (size_t)r.track * B * V;
+
+    constexpr uint32_t fo = OSC_HAS_CV | OSC_CV_AUDIO_RATE | OSC_AA | OSC_OUT_SINE;
+    constexpr uint32_t fo_mod = fo | OSC_EXACT, fo_carrier = fo | OSC_SINE_LOOSE;
+    OscConst km, kc;
+    double pos_m = make_f64(row(om.state_row + OSC_S_POS_LO), row(om.state_row + OSC_S_POS_HI));  // (scan lanes: the phase at the start of the next chunk to scan)
+    double pos_c = make_f64(row(ocr.state_row + OSC_S_POS_LO), row(ocr.state_row + OSC_S_POS_HI));
+    km.sr = om.sample_rate;
+    km.val = (double)parv(om, OSC_P_VAL);
+    km.delta = 0.0;
+    km.inv_dt = 0.0f;
+    kc = km;
+    kc.sr = ocr.sample_rate;
+    kc.val = (double)parv(ocr, OSC_P_VAL);
+    kc.scale = (440.0 / kc.sr) * exp2(kc.val);
+    const float c_fb = parv(ofb, MATH_P_CONST), c_ix = parv(oix, MATH_P_CONST);
+    BlkConsts K;
+    blk_consts_load(K);
+    const LibmTabLds libm{tab};
+
+    if (tid == 0) flag[0] = 0u;
+    for (int k = tid; k < 256; k += kBlkVoices * kBlkSlices) tab[k] = kLibmExpTab[k];
+    for (uint32_t p = (uint32_t)s; p < B; p += (uint32_t)kBlkSlices) ring_l[p * kBlkVoices + (uint32_t)g] = ring[(size_t)p * V + vc];
+    __syncthreads();
+    // every wave holds all 32 voices (two slices of each): its ballots speak for the workgroup
+    const OscFacts cf = fm_osc_facts(c_ix, kc, pos_c);
+    const int car_class = fm_gain_class(c_ix);
+    const double biggest = kc.scale * exp2((double)__builtin_fabsf(c_ix));  // (a prefix sum adds a chunk's increments before it wraps: see the kernel above)
+    const bool sane = cf.tame && __builtin_amdgcn_ballot_w64(!(biggest <= 1048576.0)) == 0;
+    if (!(pos_m >= 0.0 && pos_m < 1.0)) atomicOr(flag, 1u);  // (only a host can store such a phase: the scan then wraps with fmod1)
+    uint32_t p0 = (uint32_t)(a.n0 % B);
+    const uint32_t i0 = (uint32_t)s * (uint32_t)kXPer;  // this lane's first sample of a chunk
+    float* const frame_base = a.frames ? a.frames + (size_t)plane * a.plane_stride + voice0 : nullptr;
+    float* const mp = a.mixpart ? a.mixpart + ((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride : nullptr;
+    const bool frames = kOut == 0 ? frame_base != nullptr : (kOut & 1) != 0;
+    const bool mix = kOut == 0 ? mp != nullptr : (kOut & 2) != 0;
+
+    auto run = [&](auto fc_c) {
+        constexpr uint32_t FC = decltype(fc_c)::value;
+        const uint32_t n_chunks = (a.T + (uint32_t)kXChunk - 1u) / (uint32_t)kXChunk;
+        // the ring's word for this lane's sample j of a chunk whose first sample of this slice sits at ring position `at` (below B; B >= 4)
+        auto ring_at = [&](uint32_t at, int j) {
+            const uint32_t p = at + (uint32_t)j;
+            return (p >= B ? p - B : p) * (uint32_t)kBlkVoices + (uint32_t)g;
+        };
+        auto ring_step = [&](uint32_t at) {  // ... one chunk on (B >= 256 > 64)
+            const uint32_t p = at + (uint32_t)kXChunk;
+            return p >= B ? p - B : p;
+        };
+        auto live = [&](uint32_t chunk, int j) { return chunk * (uint32_t)kXChunk + i0 + (uint32_t)j < a.T; };
+        // the modulator's increments of a chunk, from what the ring holds: 440 * 2^(f64(cv) + f64(val)) / sr (oscillator.rs:43-48,132)
+        auto increments = [&](uint32_t chunk, uint32_t at, double (&d)[kXPer]) {
+            float fed[kXPer];
+#pragma unroll
+            for (int j = 0; j < kXPer; j++) fed[j] = ring_l[ring_at(at, j)];
+            bool cold = false;
+            double e[kXPer];
+#pragma unroll
+            for (int j = 0; j < kXPer; j++) {
+                e[j] = (double)(fed[j] * c_fb) + km.val;
+                d[j] = div_rn_plain(440.0 * exp2_libm_plain_t(e[j], cold, libm), km.sr, cold);
+            }
+            if (__builtin_amdgcn_ballot_w64(cold) != 0) {
+                if (cold) {
+#pragma unroll
+                    for (int j = 0; j < kXPer; j++) d[j] = osc_delta_exact_cold(e[j], km.sr);  // (the reference's expression itself: the same value wherever the plain form had decided)
+                }
+            }
+            bool ordinary = true;
+#pragma unroll
+            for (int j = 0; j < kXPer; j++) {
+                ordinary = ordinary && d[j] >= 0.0 && d[j] < 4503599627370496.0;
+                d[j] = live(chunk, j) ? d[j] : 0.0;  // (past the launch's last sample: the phase stands still)
+            }
+            if (!ordinary) atomicOr(flag, 1u);
+        };
+        // the scan: chunk's increments in `buf` -> its phases, in place; lanes 0 .. 31 of wave 0, one voice each
+        auto scan = [&]() {
+            if (tid >= kBlkVoices) return;
+            double p = pos_m;
+            double* const col = buf + g;
+            if (flag[0] == 0u) {
+#pragma unroll 1
+                for (int t0 = 0; t0 < kXChunk; t0 += 16) {
+                    double d[16];
+#pragma unroll
+                    for (int t = 0; t < 16; t++) d[t] = col[(t0 + t) * kBlkVoices];
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        col[(t0 + t) * kBlkVoices] = p;
+                        p = __builtin_amdgcn_fract(p + d[t]);   // pos += delta; pos %= 1.0 — exact for ordinary increments and a phase in [0, 1)
+                    }
+                }
+            } else {
+                for (int t = 0; t < kXChunk; t++) {
+                    const double d = col[t * kBlkVoices];
+                    col[t * kBlkVoices] = p;
+                    p = fmod1(p + d);
+                }
+            }
+            pos_m = p;
+        };
+        // where a lane's slice starts (carrier): the phase at the chunk's first sample + the totals of the slices below it
+        auto slice_totals = [&](int parity, double mine) {
+            const double pair = mine + __shfl_xor(mine, 32);
+            if (!odd) sums[(parity * 8 + w) * kBlkVoices + g] = pair;
+            return pair;
+        };
+        auto slice_base = [&](int parity, double mine, double pair, double start, double& base, double& total) {
+            base = start;
+            total = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < 8; w2++) {
+                const double v = sums[(parity * 8 + w2) * kBlkVoices + g];
+                total += v;
+                if (w2 < w) base += v;
+            }
+            if (odd) base += pair - mine;
+        };
+        // frames and mix partial of a chunk whose carrier phases are known
+        auto emit = [&](uint32_t chunk, const double (&pre)[kXPer], double base) {
+            const uint32_t t0 = chunk * (uint32_t)kXChunk;
+            float out[kXPer];
+#pragma unroll
+            for (int j = 0; j < kXPer; j++) out[j] = blk_sine_loose(__builtin_amdgcn_fract(base + pre[j]));
+            if (frames && active) {
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(frame_base + (size_t)(t0 + (uint32_t)w * 2u * (uint32_t)kXPer) * V, 0, 0x7fffffff, 0x00020000);
+                const uint32_t voff = ((uint32_t)g + (odd ? (uint32_t)kXPer * V : 0u)) * 4u;
+#pragma unroll
+                for (int j = 0; j < kXPer; j++)
+                    if (live(chunk, j)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[j]), rsrc, (int)voff, (int)((uint32_t)j * V * 4u), SRK_FRAME_AUX);
+            }
+            if (mix) {
+                // sum over the 32 voices of each of this slice's 4 samples: 4 -> 2 -> 1 values per lane while lanes pair up (g ^ 1, g ^ 2), then
+                // plain butterflies over the remaining voice bits: lane g ends with sample (g & 3) of its slice
+                float v[kXPer];
+#pragma unroll
+                for (int j = 0; j < kXPer; j++) v[j] = active ? out[j] : 0.0f;
+                {
+                    const bool up = (g & 1) != 0;
+                    const float s0 = up ? v[0] : v[2], s1 = up ? v[1] : v[3], k0 = up ? v[2] : v[0], k1 = up ? v[3] : v[1];
+                    v[0] = k0 + row_xchg<1>(s0);
+                    v[1] = k1 + row_xchg<1>(s1);
+                }
+                {
+                    const bool up = (g & 2) != 0;
+                    const float send = up ? v[0] : v[1], keep_ = up ? v[1] : v[0];
+                    v[0] = keep_ + row_xchg<2>(send);
+                }
+                float sum = v[0];
+                sum += __shfl_xor(sum, 4);
+                sum += __shfl_xor(sum, 8);
+                sum += __shfl_xor(sum, 16);
+                const int mine_j = ((g & 1) ? 2 : 0) + ((g & 2) ? 1 : 0);  // which of the slice's samples this lane ended up with
+                if (g < 4 && t0 + i0 + (uint32_t)mine_j < a.T) mp[t0 + i0 + (uint32_t)mine_j] = sum;
+            }
+        };
+
+        // ---- prologue: increments of chunks 0 and 1, phases of chunk 0 ----
+        double dM[kXPer];
+        uint32_t at_k = (p0 + i0) % B;                     // ring position of this slice's first sample of chunk k ...
+        uint32_t at_inc = at_k;                            // ... and of the chunk whose increments are computed next
+        increments(0u, at_inc, dM);
+        at_inc = ring_step(at_inc);
+#pragma unroll
+        for (int j = 0; j < kXPer; j++) buf[(i0 + (uint32_t)j) * kBlkVoices + (uint32_t)g] = dM[j];
+        __syncthreads();
+        scan();
+        if (n_chunks > 1u) increments(1u, at_inc, dM);
+        at_inc = ring_step(at_inc);
+        __syncthreads();
+        double preC[kXPer] = {0.0, 0.0, 0.0, 0.0}, pairC = 0.0, mineC = 0.0;  // the carrier's local prefix / totals of the chunk whose frames are still to come
+        for (uint32_t k = 0; k < n_chunks; k++) {
+            double pM[kXPer];
+#pragma unroll
+            for (int j = 0; j < kXPer; j++) pM[j] = buf[(i0 + (uint32_t)j) * kBlkVoices + (uint32_t)g];
+            __syncthreads();
+            if (k + 1u < n_chunks) {
+#pragma unroll
+                for (int j = 0; j < kXPer; j++) buf[(i0 + (uint32_t)j) * kBlkVoices + (uint32_t)g] = dM[j];
+            }
+            __syncthreads();
+            if (k + 1u < n_chunks) scan();
+            if (k > 0u) {  // the carrier's frames of chunk k - 1 (its slice totals crossed on the barriers above)
+                double base, total;
+                slice_base((int)((k - 1u) & 1u), mineC, pairC, pos_c, base, total);
+                emit(k - 1u, preC, base);
+                pos_c = __builtin_amdgcn_fract(pos_c + total);
+            }
+            {   // sines of chunk k -> ring; the carrier's increments, their local prefix and slice totals
+                float sine[kXPer];
+                bool cold = false;
+#pragma unroll
+                for (int j = 0; j < kXPer; j++) sine[j] = sine_exact_plain(pM[j], cold);  // (pos * PI * 2).sin() as f32, oscillator.rs:133
+                if (__builtin_amdgcn_ballot_w64(cold) != 0) {
+                    if (cold) {
+#pragma unroll
+                        for (int j = 0; j < kXPer; j++) {
+                            double unused = 0.0;
+                            osc_exact_cold(0.0, 1.0, pM[j], false, unused, sine[j]);  // (the reference's expression itself: the same f32 wherever the plain form had decided)
+                        }
+                    }
+                }
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < kXPer; j++) {
+                    double d = fm_increment<FC>(K, kc, sine[j] * c_ix);
+                    const bool lv = live(k, j);
+                    if (lv) ring_l[ring_at(at_k, j)] = sine[j];
+                    d = lv ? d : 0.0;
+                    preC[j] = acc;
+                    acc += d;
+                }
+                mineC = acc;
+                pairC = slice_totals((int)(k & 1u), acc);
+            }
+            at_k = ring_step(at_k);
+            if (k + 2u < n_chunks) increments(k + 2u, at_inc, dM);
+            at_inc = ring_step(at_inc);
+            __syncthreads();
+        }
+        {   // the last chunk's frames
+            double base, total;
+            slice_base((int)((n_chunks - 1u) & 1u), mineC, pairC, pos_c, base, total);
+            emit(n_chunks - 1u, preC, base);
+            pos_c = __builtin_amdgcn_fract(pos_c + total);
+        }
+    };
+    if (a.T == 0u) {
+        // nothing to render: the ring goes back as it came
+    } else if (sane) {
+        using std::integral_constant;
+        constexpr uint32_t P = OSC_PHASE_TAME | OSC_VAL_FOLDED;
+        if (car_class == 2)
+            run(integral_constant<uint32_t, fo_carrier | P | OSC_CV_SMALL>{});
+        else if (car_class == 1)
+            run(integral_constant<uint32_t, fo_carrier | P | OSC_CV_QUAD>{});
+        else
+            run(integral_constant<uint32_t, fo_carrier | P>{});
+    } else if (s == 0) {  // the recurrence, sample by sample, one lane per voice
+        OscRegs sm, sc;
+        sm.pos = pos_m;
+        sc.pos = pos_c;
+        sm.sync_last = sc.sync_last = false;
+        float sq = 0.0f, sw = 0.0f;
+        for (uint32_t t = 0; t < a.T; t++) {
+            const uint32_t at = p0 * (uint32_t)kBlkVoices + (uint32_t)g;
+            float sine_m = 0.0f, out = 0.0f;
+            osc_step(fo_mod, sm, km, ring_l[at] * c_fb, 0.0f, sine_m, sq, sw);
+            ring_l[at] = sine_m;
+            osc_step(fo_carrier, sc, kc, sine_m * c_ix, 0.0f, out, sq, sw);
+            if (frames && active) frame_base[(size_t)t * V + (uint32_t)g] = out;
+            if (mix) {
+                float v = active ? out : 0.0f;
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+                if (g == 0) mp[t] = v;
+            }
+            p0 = p0 + 1u == B ? 0u : p0 + 1u;
+        }
+        pos_m = sm.pos;
+        pos_c = sc.pos;
+    }
+    __syncthreads();  // the last chunk's ring writes
+    if (active) {
+        for (uint32_t p = (uint32_t)s; p < B; p += (uint32_t)kBlkSlices) ring[(size_t)p * V + voice] = ring_l[p * kBlkVoices + (uint32_t)g];
+        if (s == 0) {
+            auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+            put(om.state_row + OSC_S_POS_LO, f64_lo(pos_m));   // (slice 0 = the scan lanes)
             put(om.state_row + OSC_S_POS_HI, f64_hi(pos_m));
             put(om.state_row + OSC_S_SYNC_LAST, 0u);
             put(ocr.state_row + OSC_S_POS_LO, f64_lo(pos_c));

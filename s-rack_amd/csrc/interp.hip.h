@@ -141,7 +141,7 @@ SRK_DEV OscSetup osc_setup(const Ctx& c, COp& op)
     u.k.sr = op.sample_rate;
     u.k.val = (double)par(c, op, OSC_P_VAL);
     u.k.delta = op.delta_row >= 0 ? make_f64(ROW(op.delta_row), ROW(op.delta_row + 1)) : op.delta;
-    u.k.inv_dt = 1.0f / (float)u.k.delta;
+    u.k.inv_dt = inv_dt_f32(u.k.delta);
     return u;
 }
 SRK_DEV void osc_store(const Ctx& c, COp& op, double pos, bool sync_last)

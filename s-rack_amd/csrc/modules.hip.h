@@ -88,6 +88,12 @@ struct OscConst {    // per-voice constants, set up once per kernel (or tile)
     double scale = 0.0;  // 440 / sr * 2^val, only where a kernel passes OSC_VAL_FOLDED
 };
 
+// 1 / f32(dt) for the f32 PolyBLEP of a CONSTANT pitch, rounded ONCE: the f64 quotient, then one conversion (set-up time: once per voice and
+// launch).  `1.0f / (float)delta` rounds twice, and the carried-phase forms (cosc_saw, fosc_saw: t' + 1 = next phase / dt) square the quotient —
+// measured on the GPU in round 6 (tools/emu_vs_gpu.py): a raw constant-pitch saw or square was up to 1.0e-6 off the reference where the
+// error bound (csrc/approx.cpp, kEpsBlep) had counted 2.4e-7.
+SRK_DEV float inv_dt_f32(double delta) { return (float)(1.0 / delta); }
+
 // 2^x in f64 for the CV path of the default mode: x = n + f, |f| <= 1/2, a degree-8 polynomial for 2^f (Chebyshev
 // interpolant: max relative error 1.1e-12 on the interval), scaled by 2^n with ldexp.  The phase increment needs ~1e-10
 // relative accuracy to keep the accumulated phase error of a 1 s render below 1e-7 cycles; this leaves two orders of
@@ -351,8 +357,10 @@ SRK_DEV void libm_tab_fill(int lane)
 __device__ __attribute__((noinline)) double pow2_cold(double e) { return pow(2.0, e); }
 __device__ __attribute__((noinline)) double fmod1_cold(double x) { return fmod(x, 1.0); }
 
-// (the arithmetic of the plain range, branch-free; `cold` is set where the argument is outside it and the value returned is not pow's)
-SRK_DEV double exp2_libm_plain(double e, bool& cold)
+// (the arithmetic of the plain range, branch-free; `cold` is set where the argument is outside it and the value returned is not pow's;
+// `tab(i)`: word i of the table above, from wherever the caller keeps it)
+template <class Tab>
+SRK_DEV double exp2_libm_plain_t(double e, bool& cold, const Tab& tab)
 {
     constexpr double lhi = 0x1.62e42fefa39efp-1, llo = 0x1.abc9e3b398000p-56;  // log(2.0) as glibc's log_inline returns it
     const double ehi = e * lhi;
@@ -365,8 +373,8 @@ SRK_DEV double exp2_libm_plain(double e, bool& cold)
     double r = __builtin_fma(kd, -0x1.cf79abc9e3b3ap-47, __builtin_fma(kd, -0x1.62e42fefa0000p-8, ehi));
     r = elo + r;
     const uint32_t idx = 2u * ((uint32_t)ki & 127u);
-    const double tail = __longlong_as_double((long long)SRK_LIBM_TAB(idx));
-    const uint64_t sbits = SRK_LIBM_TAB(idx + 1u) + (ki << 45);
+    const double tail = __longlong_as_double((long long)tab(idx));
+    const uint64_t sbits = tab(idx + 1u) + (ki << 45);
     const double r2 = r * r;
     const double a = __builtin_fma(r, 0x1.555555555543cp-3, 0x1.ffffffffffdbdp-2);
     const double b = r + tail;
@@ -376,6 +384,10 @@ SRK_DEV double exp2_libm_plain(double e, bool& cold)
     const double scale = __longlong_as_double((long long)sbits);
     return __builtin_fma(tmp, scale, scale);
 }
+struct LibmTabDefault {
+    SRK_DEV uint64_t operator()(uint32_t i) const { return SRK_LIBM_TAB(i); }
+};
+SRK_DEV double exp2_libm_plain(double e, bool& cold) { return exp2_libm_plain_t(e, cold, LibmTabDefault{}); }
 // (what pow does outside the plain range)
 SRK_DEV double exp2_libm_special(double e)
 {
@@ -617,6 +629,9 @@ __device__ __attribute__((noinline)) void osc_exact_cold(double e, double sr, do
     sine = (float)sin(pos * 3.14159265358979323846 * 2.0);
 }
 
+// (the increment alone, for a kernel that evaluates increments and sines of different samples side by side: render_fm_pair_block_x)
+__device__ __attribute__((noinline)) double osc_delta_exact_cold(double e, double sr) { return 440.0 * exp2_libm(e) / sr; }
+
 SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, float sync, float& sine, float& square, float& saw)
 {
     if (flags & OSC_HAS_SYNC) {
@@ -763,7 +778,7 @@ SRK_DEV void cosc_init(COsc& o, double pos, double delta)
 {
     o.pos = pos;
     o.delta = delta;
-    o.inv_dt = 1.0f / (float)delta;
+    o.inv_dt = inv_dt_f32(delta);
     o.p32 = (float)pos;
     o.ta = o.p32 * o.inv_dt;
     // margin 2^-20 over every f64 rounding in the reference's compares; g = 0.25 makes the three
@@ -1036,7 +1051,7 @@ SRK_DEV void fosc_init(FOsc& o, uint32_t lo, uint32_t hi, uint32_t dlo, uint32_t
     o.dlo = dlo;
     o.dhi = dhi;
     const double delta = __builtin_fma((double)dhi, 0x1p-32, (double)dlo * 0x1p-64);  // exact: 64 bits fit after the fma's single rounding to 53
-    o.inv_s = (1.0f / (float)delta) * 0x1p-32f;
+    o.inv_s = inv_dt_f32(delta) * 0x1p-32f;
     o.c32 = (float)hi;
     o.ta = o.c32 * o.inv_s;
     o.first = hi < dhi || (hi == dhi && lo < dlo);

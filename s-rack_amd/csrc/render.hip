@@ -630,6 +630,35 @@ static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_
         hipLaunchKernelGGL(render_interp<false>, dim3(ka.n_waves), dim3(64), lds, st, ka);
 }
 
+// ... and with the modulator exact as a whole (default mode's answer to the loop through its pitch, csrc/approx.cpp): render_fm_pair_block_x —
+// unless the host asked for a specialised kernel or the general path by name
+static bool fm_block_x_shape(const FlatProgram& P, uint32_t flags, uint32_t n_samples)
+{
+    return P.fm_pair_x && n_samples >= knobs().fm_block_min && knobs().fm_block && P.hdr.buffer_size >= 256 && P.hdr.buffer_size <= 1024 &&
+           !(flags & (SRACK_RENDER_EXACT_OSC | SRACK_RENDER_NO_FUSION | SRACK_RENDER_SPECIALIZE));
+}
+
+static int launch_fm_block_x(int out_mode, const KernelArgs& ka, const ChainRoles& roles, hipStream_t st)
+{
+    const size_t lds = fm_block_x_lds_bytes((uint32_t)ka.prog.buffer_size);
+    const dim3 grid(ka.n_waves), block(kBlkVoices * kBlkSlices);
+#define SRK_BLK(O)                                                                                                              \
+    do {                                                                                                                        \
+        HIP_TRY(hipFuncSetAttribute((const void*)render_fm_pair_block_x<O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((render_fm_pair_block_x<O>), grid, block, lds, st, ka, roles);                                       \
+    } while (0)
+    if (out_mode == 3)
+        SRK_BLK(3);
+    else if (out_mode == 1)
+        SRK_BLK(1);
+    else if (out_mode == 2)
+        SRK_BLK(2);
+    else
+        SRK_BLK(0);
+#undef SRK_BLK
+    return SRACK_OK;
+}
+
 // The general path: a kernel specialised for the program (jit.cpp), or the tile interpreter.  Specialising costs a compilation
 // (~1 s) the first time a program structure is seen, so by default it is reserved for renders wide enough to repay it.
 constexpr uint32_t kSpecializeMinVoices = 4096;
@@ -654,13 +683,13 @@ static bool specializable_shape(const FlatProgram& P, uint32_t flags)
 
 static uint32_t lanes_per_wave(uint32_t V);
 
-static int resolve_specialized(PatchHandle& h, uint32_t flags, int out_mode, const JitKernel** out, bool* with_ctl)
+static int resolve_specialized(PatchHandle& h, uint32_t flags, uint32_t n_samples, int out_mode, const JitKernel** out, bool* with_ctl)
 {
     *out = nullptr;
     *with_ctl = false;
     const FlatProgram& P = h.prog.voice;
     DeviceState* d = h.dev;
-    if (!specializable_shape(P, flags) || (flags & SRACK_RENDER_NO_SPECIALIZE) || P.ops.empty()) return SRACK_OK;
+    if (!specializable_shape(P, flags) || (flags & SRACK_RENDER_NO_SPECIALIZE) || P.ops.empty() || fm_block_x_shape(P, flags, n_samples)) return SRACK_OK;
     const bool forced = (flags & SRACK_RENDER_SPECIALIZE) != 0;
     if (!forced && (P.n_voices < kSpecializeMinVoices || d->jit_failed || !jit_supported(P))) return SRACK_OK;
     // the control program's units ride along in the same launches whenever the generator covers them all
@@ -743,6 +772,7 @@ struct Segment {
     // costs the same for 16 lanes as for 64, so this only pays while SIMDs would otherwise sit idle (VALU-bound
     // kernels: up to one wave per SIMD) or while waves are latency-bound (FM pair, interpreter: up to four).
     const bool fm_block;  // 32 voices per workgroup, whatever the voice count
+    const bool fm_block_x;  // ... the same with the modulator exact (render_fm_pair_block_x)
     const uint32_t lanes, n_waves;
     // plan
     bool has_ctl = false, co_ctl = false, special_ctl = false, tick = false;
@@ -762,8 +792,8 @@ struct Segment {
     Segment(PatchHandle& h_, uint32_t T_total_, uint32_t t_seg_, uint32_t T_, float* d_frames_, float* d_mix_, uint32_t flags_, hipStream_t st_)
         : h(h_), P(h_.prog.voice), d(h_.dev), tk(h_.dev->tick), V(h_.prog.voice.n_voices), C((uint32_t)h_.prog.voice.hdr.n_channels), T_total(T_total_),
           t_seg(t_seg_), T(T_), flags(flags_), d_frames(d_frames_ ? d_frames_ + (size_t)t_seg_ * h_.prog.voice.n_voices : nullptr),
-          d_mix(d_mix_ ? d_mix_ + t_seg_ : nullptr), st(st_), fm_block(fm_block_shape(h_.prog.voice, flags_, T_)),
-          lanes(fm_block ? (uint32_t)kBlkVoices : lanes_per_wave(h_.prog.voice.n_voices)), n_waves((h_.prog.voice.n_voices + lanes - 1) / lanes)
+          d_mix(d_mix_ ? d_mix_ + t_seg_ : nullptr), st(st_), fm_block(fm_block_shape(h_.prog.voice, flags_, T_)), fm_block_x(fm_block_x_shape(h_.prog.voice, flags_, T_)),
+          lanes((fm_block || fm_block_x) ? (uint32_t)kBlkVoices : lanes_per_wave(h_.prog.voice.n_voices)), n_waves((h_.prog.voice.n_voices + lanes - 1) / lanes)
     {
     }
 
@@ -935,7 +965,7 @@ struct Segment {
         co_ctl = has_ctl && P.fused == FUSED_VOICE_CHAIN_TRACK && n_stages == 1 && h.prog.ctl[0].fused == FUSED_CTL_GATE_ENV && h.prog.n_tracks == 1;
         {
             const int om = (d_frames ? 1 : 0) | (d_mix ? 2 : 0);
-            if ((rc = resolve_specialized(h, flags, om ? om : 4, &special, &special_ctl)) != SRACK_OK) return rc;
+            if ((rc = resolve_specialized(h, flags, T, om ? om : 4, &special, &special_ctl)) != SRACK_OK) return rc;
         }
         // chunk schedule: short first chunks (only control chunk 0 is exposed), doubling up to kChunkMax
         // With a control pipeline of depth L the first voice chunk waits for L + 1 control launches: those stay short.
@@ -976,7 +1006,7 @@ struct Segment {
             const bool fm_z1 = P.fused == FUSED_FM_PAIR && P.fused_variant == 0 && !(flags & (SRACK_RENDER_NO_FUSION | SRACK_RENDER_EXACT_OSC));
             const bool lone_waves = special && P.hdr.n_rings == 0 && n_waves <= 1024 && !(flags & SRACK_RENDER_EXACT_OSC);
             // (the time-parallel FM pair keeps its ring in LDS for a launch and moves it to and from HBM at the ends: one launch per segment)
-            const uint32_t len = fm_block ? knobs().fm_block_chunk : (fm_z1 || lone_waves) ? std::min(kChunkMax, 2048u) : kChunkMax;
+            const uint32_t len = (fm_block || fm_block_x) ? knobs().fm_block_chunk : (fm_z1 || lone_waves) ? std::min(kChunkMax, 2048u) : kChunkMax;
             for (uint32_t t_off = 0; t_off < T; t_off += len) chunks.emplace_back(t_off, std::min(len, T - t_off));
         }
         n_chunks = (uint32_t)chunks.size();
@@ -1148,7 +1178,7 @@ struct Segment {
             d->kernel_name = "render_voice_chain_seq";
         }
         if (special) d->kernel_name = "render_specialized";
-        fm_pair = P.fused == FUSED_FM_PAIR;
+        fm_pair = P.fused == FUSED_FM_PAIR || fm_block_x;
         if (fm_pair) {  // op order fixed by the matcher: DELAY_RD, MATH_FB, OSC_M, DELAY_WR, MATH_IDX, OSC_C, OUT
             roles.adsr = 1;
             roles.osc_l = 2;
@@ -1156,7 +1186,7 @@ struct Segment {
             roles.osc_a = 5;
             roles.out = 6;
             roles.track = P.ops[0].aux;  // the ring's state row
-            if (!special) d->kernel_name = fm_block ? "render_fm_pair_block" : P.fused_variant == 1 ? "render_fm_pair_ring" : "render_fm_pair";
+            if (!special) d->kernel_name = fm_block_x ? "render_fm_pair_block_x" : fm_block ? "render_fm_pair_block" : P.fused_variant == 1 ? "render_fm_pair_ring" : "render_fm_pair";
         }
     }
 
@@ -1233,6 +1263,8 @@ struct Segment {
             } else if (seq_chain) {
                 const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
                 launch_seq(seq_port, out_mode, ka, seq, dim3(n_waves), st);
+            } else if (fm_pair && fm_block_x) {
+                if ((rc = launch_fm_block_x((ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0), ka, roles, st)) != SRACK_OK) return rc;
             } else if (fm_pair && fm_block) {
                 if ((rc = launch_fm_block((ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0), ka, roles, st)) != SRACK_OK) return rc;
             } else if (fm_pair) {
@@ -1370,7 +1402,8 @@ int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t f
     DeviceState* d = h.dev;
     const FlatProgram& P = h.prog.voice;
     const uint32_t T = std::min(n_samples, 65536u);  // one segment
-    const uint32_t lanes = fm_block_shape(P, h.prog.effective_flags, T) ? (uint32_t)kBlkVoices : lanes_per_wave(P.n_voices), n_waves = (P.n_voices + lanes - 1) / lanes;
+    const uint32_t eff = h.prog.effective_flags | (flags & kLaunchPolicyFlags);
+    const uint32_t lanes = (fm_block_shape(P, eff, T) || fm_block_x_shape(P, eff, T)) ? (uint32_t)kBlkVoices : lanes_per_wave(P.n_voices), n_waves = (P.n_voices + lanes - 1) / lanes;
     if (want_mix && P.hdr.n_planes > 0) {
         if ((rc = grow(d->d_mixpart, d->mixpart_bytes, sizeof(float) * (size_t)P.hdr.n_planes * n_waves * T)) != SRACK_OK) return rc;
         if ((rc = grow(d->d_mixgroup, d->mixgroup_bytes, sizeof(float) * (size_t)P.hdr.n_planes * kMixSplit * T)) != SRACK_OK) return rc;
@@ -1378,7 +1411,7 @@ int device_reserve(PatchHandle& h, uint32_t n_samples, bool want_mix, uint32_t f
     if (h.prog.n_tracks > 0 && (rc = grow(d->d_tracks, d->tracks_bytes, sizeof(float) * (size_t)h.prog.n_tracks * T)) != SRACK_OK) return rc;
     const JitKernel* special = nullptr;  // compile now what the first render would otherwise compile (frames + mix, or frames only)
     bool special_ctl = false;
-    if ((rc = resolve_specialized(h, h.prog.effective_flags | (flags & kLaunchPolicyFlags), want_mix ? 3 : 1, &special, &special_ctl)) != SRACK_OK) return rc;
+    if ((rc = resolve_specialized(h, h.prog.effective_flags | (flags & kLaunchPolicyFlags), T, want_mix ? 3 : 1, &special, &special_ctl)) != SRACK_OK) return rc;
     return SRACK_OK;
 }
 

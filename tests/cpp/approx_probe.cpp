@@ -59,6 +59,9 @@ int main()
     flags("nonlin_loose", P.nonlin_loose);
     flags("saw_fixed", P.saw_fixed);
     flags("live", live);
+    o << "\"port_live\": [";
+    for (size_t i = 0; i < port_live.size(); i++) o << (i ? ", " : "") << port_live[i];
+    o << "], ";
     o << "\"exact_patch\": " << (P.exact_patch ? "true" : "false") << ", \"why\": \"" << P.why << "\", \"bound\": ";
     num(o, P.bound);
     for (int which = 0; which < 2; which++) {

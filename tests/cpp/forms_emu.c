@@ -6,7 +6,14 @@
  * by a soak on the GPU.  This file lets the same soak run on the CPU: it compiles oracle/srack_oracle.c into a library of its own and
  * replaces the calc() of single modules (or_set_calc_hook) by the oracle's calc() with the form in question, restated from
  * csrc/modules.hip.h operation for operation:
- *     oscillator  EMU_OSC_F32_BLEP    osc_step's default saw / square: poly_blep_sel in f32 on the f32 phase, square_sign_safe
+ *     oscillator  EMU_OSC_F32_BLEP    osc_step's default saw / square: poly_blep_sel in f32 on the f32 phase, square_sign_safe; with
+ *                 EMU_OSC_ONE_PORT    (exactly one port is read: flatten.cpp's OSC_CONST_FAST) and a constant pitch below a quarter cycle per sample,
+ *                                     no sync: the CARRIED-phase forms every kernel renders such an oscillator with — cosc_saw (the second
+ *                                     window as (next phase / dt)^2), cosc_square (poly_blep_fast) — round 6: tools/emu_vs_gpu.py found the
+ *                                     kernels at 1.0e-6 where this file, restating osc_step only, had 1.2e-7
+ *                 EMU_OSC_FIXED       ... and that saw with its phase in 2^-64 fixed point (fosc_saw): f32(pos) and t = pos / dt from the phase's UPPER 32
+ *                                     bits — which is where the 1.0e-6 came from (a 17 Hz saw: 2^-32 / dt = 6.4e-7 in t).  The fixed-point accumulator
+ *                                     itself (2^-64 per step) is not restated: the upper word is taken from the oracle's f64 phase
  *                 EMU_OSC_SINE_LOOSE  sine_loose: the exact fold, a degree-9 polynomial in f32
  *                 EMU_OSC_SINE_FAST   sine_fast: the fold, a degree-13 polynomial in f64, one rounding (differs from the libm's sine by an
  *                                     f32 ulp about once in 3e5 samples)
@@ -21,7 +28,7 @@
  * Build: gcc -O2 -std=c11 -fPIC -ffp-contract=off -fno-fast-math -shared (tests/forms_emu.py). */
 #include "../../oracle/srack_oracle.c"
 
-enum { EMU_OSC_F32_BLEP = 1u, EMU_OSC_SINE_LOOSE = 2u, EMU_OSC_SINE_FAST = 4u, EMU_VCF_CONTRACTED = 1u, EMU_NONLIN_LOOSE = 1u };
+enum { EMU_OSC_F32_BLEP = 1u, EMU_OSC_SINE_LOOSE = 2u, EMU_OSC_SINE_FAST = 4u, EMU_OSC_ONE_PORT = 8u, EMU_OSC_FIXED = 16u, EMU_VCF_CONTRACTED = 1u, EMU_NONLIN_LOOSE = 1u };
 
 /* ---- oscillator (modules.hip.h: sine_fold, sine_fast, sine_loose, poly_blep_sel, square_sign_safe, osc_step) ------------------------- */
 static double emu_sine_fold(double pos, uint32_t* sign)
@@ -90,8 +97,57 @@ static void emu_calc_osc(or_patch* p, or_module* m)
         double delta = hz / (double)o->sample_rate;
         const double pos = o->pos;
         sine[i] = (forms & EMU_OSC_SINE_LOOSE) ? emu_sine_loose(pos) : (forms & EMU_OSC_SINE_FAST) ? emu_sine_fast(pos) : (float)sin(pos * PI * 2.0);
-        if (forms & EMU_OSC_F32_BLEP) {
-            const float inv_dt = 1.0f / (float)delta;
+        if ((forms & EMU_OSC_F32_BLEP) && (forms & EMU_OSC_ONE_PORT) && (forms & EMU_OSC_FIXED) && !cv && !sync_in && o->antialiasing && delta < 0.25) {
+            /* fosc_saw (modules.hip.h) */
+            const float inv_s = (float)(1.0 / delta) * 0x1p-32f;
+            const uint32_t hi = (uint32_t)floor(ldexp(pos, 32));
+            double w = pos + delta;
+            const int wrapped = w >= 1.0;
+            w = w - floor(w);
+            const uint32_t nhi = (uint32_t)floor(ldexp(w, 32));
+            const float c32 = (float)hi, cn = (float)nhi;
+            float s_ = fmaf(c32, 0x1p-31f, -1.0f);
+            if (pos < delta) {
+                float u = 1.0f - c32 * inv_s;
+                u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+                s_ = fmaf(u, u, s_);
+            }
+            if (wrapped) {
+                const float tn = cn * inv_s;
+                s_ = fmaf(-tn, tn, s_);
+            }
+            saw[i] = s_;
+            square[i] = 0.0f;   /* (not read: one port) */
+        } else if ((forms & EMU_OSC_F32_BLEP) && (forms & EMU_OSC_ONE_PORT) && !cv && !sync_in && o->antialiasing && delta < 0.25) {
+            /* cosc_saw / cosc_square (modules.hip.h): functions of (pos, delta) alone — the carried terms are f32(pos) and f32(pos) * inv_dt */
+            const float inv_dt = (float)(1.0 / delta);              /* inv_dt_f32: one rounding */
+            const float p32 = (float)pos;
+            const float ta = p32 * inv_dt;
+            double w = pos + delta;
+            const int wrapped = w >= 1.0;
+            w = w - floor(w);
+            const float tn = (float)w * inv_dt;
+            const float base = fmaf(p32, 2.0f, -1.0f);
+            float u = 1.0f - ta;
+            u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);          /* v_med3(1 - ta, 0, 1); ta is never a NaN here (delta > 0, finite) */
+            const float s1 = fmaf(u, u, base);
+            const float s2 = fmaf(-tn, tn, s1);
+            saw[i] = wrapped ? s2 : s1;
+            {   /* poly_blep_fast twice, square_sign_safe */
+                const float tb = (float)(pos - 1.0) * inv_dt;
+                const float fa = fmaf(ta, 2.0f - ta, -1.0f), fb = fmaf(tb, tb + 2.0f, 1.0f);
+                const float blep0 = ta < 1.0f ? fa : (tb > -1.0f ? fb : 0.0f);
+                double p2 = pos + 0.5;
+                p2 = p2 >= 1.0 ? p2 - 1.0 : p2;
+                const float ta2 = (float)p2 * inv_dt, tb2 = (float)(p2 - 1.0) * inv_dt;
+                const float fa2 = fmaf(ta2, 2.0f - ta2, -1.0f), fb2 = fmaf(tb2, tb2 + 2.0f, 1.0f);
+                const float blep1 = ta2 < 1.0f ? fa2 : (tb2 > -1.0f ? fb2 : 0.0f);
+                float sq = (pos < 0.5 ? -1.0f : 1.0f) - (blep0 - blep1);
+                if (fabsf(sq) < 2.0e-6f) sq = (pos < 0.5 ? -1.0f : 1.0f) - (float)(or_poly_blep(pos, delta) - or_poly_blep(fmod(pos + 0.5, 1.0), delta));
+                square[i] = sq;
+            }
+        } else if (forms & EMU_OSC_F32_BLEP) {
+            const float inv_dt = cv ? 1.0f / (float)delta : (float)(1.0 / delta);   /* osc_step: per sample where the pitch moves; inv_dt_f32 once where it does not */
             const float p32 = (float)pos;
             const double upper = 1.0 - delta;
             float blep0 = 0.0f, blep1 = 0.0f;

@@ -12,7 +12,7 @@ from oracle import oracle
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SRC = os.path.join(ROOT, "tests", "cpp", "forms_emu.c")
 _LIB = os.path.join(ROOT, "tests", "cpp", "libforms_emu.so")
-OSC_F32_BLEP, OSC_SINE_LOOSE, OSC_SINE_FAST, VCF_CONTRACTED, NONLIN_LOOSE = 1, 2, 4, 1, 1
+OSC_F32_BLEP, OSC_SINE_LOOSE, OSC_SINE_FAST, OSC_ONE_PORT, OSC_FIXED, VCF_CONTRACTED, NONLIN_LOOSE = 1, 2, 4, 8, 16, 1, 1
 _lib = None
 
 
@@ -39,18 +39,22 @@ class EmuPatch(oracle.OraclePatch):
         if self.L.emu_set_forms(self.h, module, forms) < 0:
             raise ValueError(f"emu_set_forms({module}, {forms}) failed")
 
-    def apply_plan(self, types, plan=None, everything=False):
-        """types: module types in creation order; plan: approx_probe's result.  -> the forms set, {module: word}"""
+    def apply_plan(self, types, plan=None, everything=False, per_voice=None):
+        """types: module types in creation order; plan: approx_probe's result; per_voice: the modules with per-voice overrides, or None for
+        "every module is evaluated per voice" (render flag 4) — a constant-pitch oscillator WITHOUT one is voice-invariant, hoisted into
+        the control program, and keeps its f64 phase there (flatten.cpp: OSC_FIXED_PHASE is a voice program's).  -> the forms set, {module: word}"""
         out = {}
         for m, t in enumerate(types):
             if plan is not None and (not plan["live"][m] or plan["exact_patch"]):
                 continue
             w = 0
             if t == oracle.MOD_OSCILLATOR:
+                one_port = plan is not None and bin(plan["port_live"][m]).count("1") == 1   # (flatten.cpp's OSC_CONST_FAST: the carried-phase forms)
                 if everything:
-                    w = OSC_F32_BLEP | OSC_SINE_LOOSE
+                    w = OSC_F32_BLEP | OSC_SINE_LOOSE | (OSC_ONE_PORT if one_port else 0)
                 elif not plan["osc_exact"][m]:
-                    w = (0 if plan["exact_blep"][m] else OSC_F32_BLEP) | (OSC_SINE_LOOSE if plan["sine_loose"][m] else OSC_SINE_FAST)
+                    fixed = plan["saw_fixed"][m] and one_port and (per_voice is None or m in per_voice)
+                    w = (0 if plan["exact_blep"][m] else OSC_F32_BLEP | (OSC_ONE_PORT if one_port else 0) | (OSC_FIXED if fixed else 0)) | (OSC_SINE_LOOSE if plan["sine_loose"][m] else OSC_SINE_FAST)
             elif t == oracle.MOD_MOOG_FILTER:
                 w = VCF_CONTRACTED if everything or not plan["literal"][m] else 0
             elif t == oracle.MOD_NONLINEAR:

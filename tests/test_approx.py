@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W = srack_pkg.load_workloads()
 CSRC = os.path.join(ROOT, "s-rack_amd", "csrc")
 BUDGET, HORIZON, EVENT = 5e-6, 2.88e7, 1e9   # approx.hpp / approx.cpp
+EPS_BLEP = 3.2e-7                             # approx.cpp kEpsBlep (tools/blep_calib.py)
 
 
 def _build(binary, sources, extra=()):
@@ -85,7 +86,8 @@ def test_straight_chain_takes_every_form_and_says_its_bound(probe):
     assert r["exact_blep"][osc] == 0 and r["literal"][vcf] == 0 and r["saw_fixed"][osc] == 1 and not r["exact_patch"]
     l1 = r["gain"][osc][SAW]                       # the lowpass's L1 norm at the default cutoff 0.2 / resonance 0.5 (tools/ladder_calib.c l1: 1.54)
     assert 1.5 < l1 < 1.6
-    assert r["bound"] == pytest.approx(1.5e-6 + 2.4e-7 * l1 + 3.2e-12 * l1, rel=1e-6) and r["bound"] < BUDGET
+    dt = 440.0 / 48000.0                             # the fixed-point phase's window term: 2^-31 over the smallest increment (5.1e-8 at 440 Hz)
+    assert r["bound"] == pytest.approx(1.5e-6 + EPS_BLEP * l1 + (3.2e-12 + 2.0 ** -31 / dt) * l1, rel=1e-6) and r["bound"] < BUDGET
     assert g.run(probe, exact=True)["saw_fixed"][osc] == 0   # exact mode: no form on offer at all
 
 
@@ -153,7 +155,7 @@ def test_event_inputs_and_the_square_that_arrives_unchanged(probe):
     g.connect(env, 0, vca, 1)
     g.connect(vca, 0, out, 0)
     assert g.run(probe)["exact_blep"][lfo] == 1
-    g, ids = chain(OSC, *([GRID] * 3), ADSR, VCA)   # three in a row: followed to the end — the gate costs nothing, the VCA hears 2.4e-7
+    g, ids = chain(OSC, *([GRID] * 3), ADSR, VCA)   # three in a row: followed to the end — the gate costs nothing, the VCA hears 3.2e-7
     lfo, seqs, env, vca, out = ids[0], ids[1:4], ids[4], ids[5], ids[6]
     for q in seqs:
         g.set_step(q, 0, 0, W.STEP_ON, 3)
@@ -180,6 +182,22 @@ def test_event_inputs_and_the_square_that_arrives_unchanged(probe):
     g.connect(slave, SAW, out, 0)
     r = g.run(probe)
     assert r["exact_blep"][osc] == 1 and r["literal"][vcf] == 1 and r["exact_blep"][slave] == 0 and r["saw_fixed"][osc] == 0
+
+
+def test_a_fixed_point_phase_is_for_audio_pitches(probe):
+    """fosc_saw takes t = pos / dt inside the PolyBLEP windows from the phase's upper 32 bits: an error of up to 2^-31 / dt — 5e-8 at 440 Hz, 1.0e-6
+    at 17 Hz (what the GPU rendered for the fuzzer's seed 900146 in round 6, against a bound that said 2.4e-7), 2.6e-5 for a 0.86 Hz LFO.  The
+    form's epsilon is that over the smallest increment any voice has; an LFO keeps its f64 phase."""
+    for val, per_voice, fixed in ((0.0, None, 1), (-9.0, None, 0), (0.0, [0.0, -2.0, -9.0], 0), (-3.0, None, 1)):
+        g, (osc, out) = chain(OSC)
+        g.set_field(osc, W.OSC_VAL, val)
+        if per_voice is not None:
+            g.override(osc, W.OSC_VAL, per_voice)
+        g.connect(osc, SAW, out, 0)
+        r = g.run(probe)
+        lowest = min(per_voice) if per_voice is not None else val
+        assert r["saw_fixed"][osc] == fixed and r["exact_blep"][osc] == 0, (val, per_voice, r["bound"])
+        assert r["bound"] == pytest.approx(EPS_BLEP + (3.2e-12 + 2.0 ** -31 / (440.0 * 2.0 ** lowest / 48000.0) if fixed else 0.0), rel=1e-6)
 
 
 def test_a_fixed_point_phase_is_denied_in_front_of_an_event_but_not_of_a_vca(probe):
@@ -279,7 +297,9 @@ def test_a_ladder_near_self_oscillation(probe):
         return g, osc, vcf
     g, osc, vcf = patch(0.85)
     r = g.run(probe)
-    assert r["literal"][vcf] == 0 and 10.0 < r["gain"][osc][SAW] < 12.0 and r["exact_blep"][osc] == 0
+    assert r["literal"][vcf] == 0 and 10.0 < r["gain"][osc][SAW] < 12.0
+    assert r["exact_blep"][osc] == 1     # (11 x the f32 PolyBLEP's 3.2e-7 + the contracted ladder's 1.5e-6 is just over the budget; at 0.8 — L1 = 7 — both fit)
+    assert patch(0.8)[0].run(probe)["exact_blep"][osc] == 0
     g, osc, vcf = patch(0.95)
     r = g.run(probe)
     assert r["literal"][vcf] == 1 and r["exact_blep"][osc] == 1 and r["gain"][osc][SAW] == float("inf") and not r["exact_patch"]
@@ -310,8 +330,8 @@ def test_cycles_converge_to_their_geometric_series_or_diverge(probe):
         return g, osc, a
     g, osc, a = loop(0.5)
     r = g.run(probe)
-    assert r["gain"][osc][SAW] == pytest.approx(2.0, rel=1e-4) and r["exact_blep"][osc] == 0 and r["bound"] == pytest.approx(2 * (2.4e-7 + 3.2e-12), rel=1e-3)
-    g, osc, a = loop(0.96)      # 25: the f32 PolyBLEP's 2.4e-7 becomes 6e-6
+    assert r["gain"][osc][SAW] == pytest.approx(2.0, rel=1e-4) and r["exact_blep"][osc] == 0 and r["bound"] == pytest.approx(2 * (EPS_BLEP + 3.2e-12 + 2.0 ** -31 / (440.0 / 48000.0)), rel=1e-3)
+    g, osc, a = loop(0.96)      # 25: the f32 PolyBLEP's 3.2e-7 becomes 8e-6
     r = g.run(probe)
     assert r["gain"][osc][SAW] == pytest.approx(25.0, rel=2e-2) and r["exact_blep"][osc] == 1
     g, osc, a = loop(0.99)      # 100: the fixpoint stops sweeping at ~400 with 1.6 % to go — the geometric tail is added, not dropped

@@ -305,7 +305,62 @@ def test_fm_feedback_gain_above_one_takes_the_exact_flavour(S, oracle, B):
     q.set_voice_field(ids["mul_idx"], S.MATH_CONSTANT, i2)
     q.render_channels(4096, S.RENDER_KEEP_DEFAULT)   # (round 5: config 4's own draw goes exact by default as well — any loop through a pitch; its fast kernels on request)
     assert ("render_fm_pair_block" in q.info()) if B == 1024 else ("render_fm_pair" in q.info() or "render_specialized" in q.info())
-    assert "render_fm_pair" not in p.info() and "; exact osc 0]" in p.info(), p.info()   # the general path, the modulator exact as a whole
+    # the modulator exact as a whole: the general path, or — from round 6, where the delay allows time lanes — the pair's kernel for exactly that program
+    assert ("kernel=render_fm_pair_block_x" in p.info() if B == 1024 else "render_fm_pair" not in p.info()) and "; exact osc 0]" in p.info(), p.info()
+
+
+@pytest.mark.parametrize("B,T", [(256, 9216), (1000, 9000), (1024, 9216), (1024, 8191), (640, 4097)])
+def test_fm_pair_with_the_modulator_exact_across_time_lanes(S, oracle, B, T):
+    """render_fm_pair_block_x (round 6): config 4's program as default mode renders it — the modulator exact as a whole, the carrier in its default
+    forms — with a delay of 256 ... 1024 samples: increments (the libm's 2^cv, the correctly rounded quotient) and sines across time lanes, only
+    `pos = (pos + delta) % 1.0` serial (oscillator.rs:152-153).  70 voices (two full workgroups of 32 and a ragged one), ring lengths that are and
+    are not multiples of the 64-sample chunk, render lengths that are and are not.  The frames against the oracle (the carrier's f32 sine on a phase
+    that is the reference's to 1e-12: 5e-7), the MODULATOR's phase after the render bit for bit, a second call continuing the first, and a voice
+    whose feedback gain overflows 2^cv (NaNs where the reference has them: the scan's fmod1 path)."""
+    V = 70
+    beta, index = S.p2_voice_params(V)
+    beta, index = beta.copy(), index.copy()
+    wild = 41
+    beta[wild] = 3.0e4   # 2^(30000 sin) overflows: the increment is inf, the phase NaN from there on — in that voice only
+    over = lambda ids: [(ids["mul_fb"], S.MATH_CONSTANT, beta), (ids["mul_idx"], S.MATH_CONSTANT, index)]
+    o = oracle.OraclePatch(48000, B, 2)
+    ids = S.build_p2(o)
+    ref, _ = o.render_batch(V, 2 * T, over(ids), threads=8)
+    p = S.Patch(48000, B, 2)
+    S.build_p2(p)
+    p.configure_voices(V)
+    for m, f, v in over(ids):
+        p.set_voice_field(m, f, v)
+    a = p.render_channels(T, 0)
+    assert "kernel=render_fm_pair_block_x" in p.info() and "; exact osc 0]" in p.info(), p.info()
+    if T % B == 0:   # the oracle ticks block by block: its modules hold the state after whole blocks
+        pos = p.get_voice_field(ids["osc_m"], S.OSC_POS)
+        for v in (0, 31, 32, 63, 64, 69, wild):
+            q = oracle.OraclePatch(48000, B, 2)
+            S.build_p2(q)
+            q.set_field(ids["mul_fb"], S.MATH_CONSTANT, float(beta[v]))
+            q.set_field(ids["mul_idx"], S.MATH_CONSTANT, float(index[v]))
+            q.render(T)
+            want = q.get_field(ids["osc_m"], S.OSC_POS)
+            assert np.float64(pos[v]).view(np.uint64) == np.float64(want).view(np.uint64) or (np.isnan(pos[v]) and np.isnan(want)), (v, pos[v], want)
+    b = p.render_channels(T, 0)
+    out = np.concatenate([a[0], b[0]])
+    assert np.isnan(ref[0][:, wild]).any() and not np.isnan(np.delete(ref[0], wild, axis=1)).any()
+    np.testing.assert_array_equal(np.isnan(out), np.isnan(ref[0]))
+    ok = ~np.isnan(ref[0])
+    err = np.where(ok, np.abs(out.astype(np.float64) - ref[0]) / np.maximum(np.abs(ref[0]), 1.0), 0.0)
+    assert err.max() < 5e-7, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert np.abs(out[ok]).max() > 0.9
+    # the general path (flags 2: no fusion) renders the same program — the same exact modulator, the carrier through osc_step: within the carrier's 4e-7
+    g2 = S.Patch(48000, B, 2)
+    S.build_p2(g2)
+    g2.configure_voices(V)
+    for m, f, v in over(ids):
+        g2.set_voice_field(m, f, v)
+    c = g2.render_channels(T, 2)
+    assert "render_fm_pair_block_x" not in g2.info()
+    fin = ~np.isnan(c[0])
+    assert np.abs(c[0][fin].astype(np.float64) - a[0][fin]).max() < 8e-7
 
 
 def _envelope_fm(g, S):
@@ -773,7 +828,7 @@ def test_cfg3_poly_modes(S, oracle, flags, V, T):
 
 # (since round 3 the kernels bench.py times for this patch: buffer_size 1 — the kernel specialised at run time, whose generator derives
 # the bounded pitch CVs render_fm_pair proves by hand; buffer_size 1024 — the time-parallel pair with its ring in LDS)
-@pytest.mark.parametrize("B,flags,kernel", [(1, 64, "render_specialized"), (1024, 64, "render_fm_pair_block"), (1, 0, "render_specialized"), (1024, 0, "render_specialized")])
+@pytest.mark.parametrize("B,flags,kernel", [(1, 64, "render_specialized"), (1024, 64, "render_fm_pair_block"), (1, 0, "render_specialized"), (1024, 0, "render_fm_pair_block_x")])
 def test_cfg4_exactly_as_benchmarked(S, oracle, B, flags, kernel):
     """BASELINE config 4 at full size, the workload `bench.py --workload cfg4` (and cfg4_b1024) times: 65 536 voices x 48 000
     samples of the 2-operator FM patch with its feedback edge, per-voice feedback / index (12.6 GB of frames, kept on the device) —

@@ -48,7 +48,7 @@ def one(job):
     plan = g.rec.run(probe)
     if plan["exact_patch"] and not everything:
         return seed, 0.0, 0.0, True, "exact patch", 0, 0.0
-    forms = g.b.apply_plan(g.types, None if everything else plan, everything)
+    forms = g.b.apply_plan(g.types, None if everything else plan, everything, per_voice={m for m, _, _ in ov})
     if not forms:
         return seed, 0.0, 0.0, True, "no forms", 0, 0.0
     ref, _ = g.a.render_batch(V, T, ov, threads=1)

@@ -22,7 +22,7 @@ def compare(seed, noise, V, T, flags_list, S, probe):
     plan = g.rec.run(probe)
     if plan["exact_patch"]:
         return None
-    forms = g.b.apply_plan(g.types, plan)
+    forms = g.b.apply_plan(g.types, plan, per_voice={m for m, _, _ in ov})
     if not forms:
         return None
     ref, _ = g.a.render_batch(V, T, ov, threads=8)
@@ -71,6 +71,8 @@ if __name__ == "__main__":
         rows = compare(seed, bool(a.noise), V, T, [int(x) for x in a.flags.split(",")], S, probe)
         for r in rows or []:
             out.append(r)
-            print("seed %d flags %2d forms %d: bit-equal %.5f  |gpu-emu| %.2e  gpu err %.2e  emu err %.2e  bound %.1e" % (r["seed"], r["flags"], r["forms"], r["bit_equal"], r["gpu_minus_emu"], r["gpu_err"], r["emu_err"], r["bound"]), flush=True)
+            print("seed %d flags %2d forms %d: bit-equal %.5f  |gpu-emu| %.2e  gpu err %.2e  emu err %.2e  bound %.1e" % (r["seed"], r["flags"], r["forms"], r["bit_equal"], r["gpu_minus_emu"], r["gpu_err"], r["emu_err"], r["bound"])
+                  + ("   " + r["info"] if os.environ.get("EMU_INFO") or r["gpu_err"] > r["bound"] * 1.05 + 3.6e-7 else ""), flush=True)
     if a.json:
+        os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
         json.dump(out, open(a.json, "w"), indent=1)
