@@ -1451,6 +1451,74 @@ struct LibmTabLds {
     const uint64_t* t;
     SRK_DEV uint64_t operator()(uint32_t i) const { return t[i]; }
 };
+// The exact forms' constants as REGISTERS (as BlkConsts above: an f64 VOP3 cannot take a 64-bit literal, and with four evaluations in flight the
+// compiler rematerialised every one at every use — 95 of the chunk loop's 544 vector instructions were moves).  The operations below are
+// dev::exp2_libm_plain_t's and dev::sine_exact_plain's own (modules.hip.h), operation for operation: same values, same roundings.
+struct XConsts {
+    double lhi, llo, inv_ln2n, shift, nln2hi, nln2lo, c2, c3, c4, c5, k440;  // 2^e as the host libm's pow
+    double q[7], quarter, rel, abs_;                                          // the sine's polynomial, its fold, the decision's interval
+};
+SRK_DEV void x_consts_load(XConsts& X)
+{
+    X.lhi = 0x1.62e42fefa39efp-1, X.llo = 0x1.abc9e3b398000p-56, X.inv_ln2n = 0x1.71547652b82fep+7, X.shift = 0x1.8p52;
+    X.nln2hi = -0x1.62e42fefa0000p-8, X.nln2lo = -0x1.cf79abc9e3b3ap-47;
+    X.c2 = 0x1.ffffffffffdbdp-2, X.c3 = 0x1.555555555543cp-3, X.c4 = 0x1.55555cf172b91p-5, X.c5 = 0x1.1111167a4d017p-7, X.k440 = 440.0;
+    const double q[7] = {6.283185307179272, -41.34170223990684, 81.60524914955879, -76.70584757807868, 42.05813586028645, -15.081496425342264, 3.6659216216293173};
+#pragma unroll
+    for (int i = 0; i < 7; i++) X.q[i] = q[i];
+    X.quarter = 0.25, X.rel = 1.0e-13, X.abs_ = 2.0e-15;
+    double* const all = &X.lhi;
+    static_assert(sizeof(XConsts) == 21 * sizeof(double), "XConsts is 21 doubles in a row");
+#pragma unroll
+    for (int i = 0; i < 21; i++) asm volatile("" : "+v"(all[i]));
+}
+template <class Tab>
+SRK_DEV double x_exp2_libm_plain(const XConsts& X, double e, bool& cold, const Tab& tab)  // == dev::exp2_libm_plain_t(e, cold, tab)
+{
+    const double ehi = e * X.lhi;
+    const double elo = __builtin_fma(e, X.llo, __builtin_fma(X.lhi, e, -ehi));
+    const uint32_t abstop = ((uint32_t)__double2hiint(ehi) >> 20) & 0x7ffu;
+    cold = cold || !(abstop - 0x3c9u <= 0x3eu);
+    const double kds = __builtin_fma(ehi, X.inv_ln2n, X.shift);
+    const uint64_t ki = (uint64_t)__double_as_longlong(kds);
+    const double kd = kds - X.shift;
+    double r = __builtin_fma(kd, X.nln2lo, __builtin_fma(kd, X.nln2hi, ehi));
+    r = elo + r;
+    const uint32_t idx = 2u * ((uint32_t)ki & 127u);
+    const double tail = __longlong_as_double((long long)tab(idx));
+    const uint64_t sbits = tab(idx + 1u) + (ki << 45);
+    const double r2 = r * r;
+    const double a = __builtin_fma(r, X.c3, X.c2);
+    const double b = r + tail;
+    const double c = __builtin_fma(r, X.c5, X.c4);
+    double tmp = __builtin_fma(a, r2, b);
+    tmp = __builtin_fma(c, r2 * r2, tmp);
+    const double scale = __longlong_as_double((long long)sbits);
+    return __builtin_fma(tmp, scale, scale);
+}
+template <bool kRange>
+SRK_DEV float x_sine_exact_plain(const XConsts& X, double pos, bool& cold)  // == dev::sine_exact_plain<kRange>(pos, cold)
+{
+    const double qn = 0.5 - pos;
+    const uint32_t sign = (uint32_t)__double2hiint(qn) & 0x80000000u;
+    const double t = __builtin_fabs(qn) - X.quarter;
+    const double x = X.quarter - __builtin_fabs(t);
+    const double z = x * x;
+    const double a01 = __builtin_fma(X.q[1], z, X.q[0]);
+    const double a23 = __builtin_fma(X.q[3], z, X.q[2]);
+    const double a45 = __builtin_fma(X.q[5], z, X.q[4]);
+    const double z2 = z * z;
+    const double b0 = __builtin_fma(a23, z2, a01);
+    const double b1 = __builtin_fma(X.q[6], z2, a45);
+    const double z4 = z2 * z2;
+    const double y = __builtin_fma(b1, z4, b0) * x;
+    const double d = __builtin_fma(X.rel, y, X.abs_);
+    const float r = (float)(y - d), r2 = (float)(y + d);
+    bool sure = __float_as_uint(r) == __float_as_uint(r2);
+    if (kRange) sure = sure && pos >= 0.0 && pos < 1.0;
+    cold = cold || !sure;
+    return __uint_as_float(__float_as_uint(r) ^ sign);
+}
 
 template <int kOut>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void render_fm_pair_block_x(KernelArgs a, ChainRoles r)
@@ -1462,7 +1530,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     double* const buf = (double*)(blk_lds + (size_t)B * kBlkVoices);                 // [64][32]: a chunk's modulator increments, then its phases
     double* const sums = buf + kXChunk * kBlkVoices;                                  // [2][8][32]: the carrier's slice totals, per chunk parity, per wave, per voice
     uint64_t* const tab = (uint64_t*)(sums + 2 * 8 * kBlkVoices);                     // the libm's 2^(k/128) table
-    uint32_t* const flag = (uint32_t*)(tab + 256);                                    // [0]: some modulator increment is not an ordinary number
+    uint32_t* const flag = (uint32_t*)(tab + 256);                                    // [0]: some modulator increment is not an ordinary number; [1]: the ring came with a value above 1
     const int tid = (int)threadIdx.x, g = tid & 31, s = tid >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave holds slices 2 w and 2 w + 1 of all 32 voices
     const bool odd = (s & 1) != 0;
@@ -1496,17 +1564,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float c_fb = parv(ofb, MATH_P_CONST), c_ix = parv(oix, MATH_P_CONST);
     BlkConsts K;
     blk_consts_load(K);
+    XConsts X;
+    x_consts_load(X);
     const LibmTabLds libm{tab};
 
-    if (tid == 0) flag[0] = 0u;
+    if (tid == 0) flag[0] = flag[1] = 0u;
     for (int k = tid; k < 256; k += kBlkVoices * kBlkSlices) tab[k] = kLibmExpTab[k];
-    for (uint32_t p = (uint32_t)s; p < B; p += (uint32_t)kBlkSlices) ring_l[p * kBlkVoices + (uint32_t)g] = ring[(size_t)p * V + vc];
+    __syncthreads();
+    bool unit = true;  // the ring: HBM -> LDS, looking at every value on the way (the host's may be anything; a sine is at most 1)
+    for (uint32_t p = (uint32_t)s; p < B; p += (uint32_t)kBlkSlices) {
+        const float x = ring[(size_t)p * V + vc];
+        ring_l[p * kBlkVoices + (uint32_t)g] = x;
+        unit = unit && __builtin_fabsf(x) <= 1.0f;
+    }
+    if (!unit) atomicOr(flag + 1, 1u);
     __syncthreads();
     // every wave holds all 32 voices (two slices of each): its ballots speak for the workgroup
     const OscFacts cf = fm_osc_facts(c_ix, kc, pos_c);
     const int car_class = fm_gain_class(c_ix);
     const double biggest = kc.scale * exp2((double)__builtin_fabsf(c_ix));  // (a prefix sum adds a chunk's increments before it wraps: see the kernel above)
     const bool sane = cf.tame && __builtin_amdgcn_ballot_w64(!(biggest <= 1048576.0)) == 0;
+    // What the modulator's arithmetic may skip once it is PROVED for the launch: |cv| <= |gain| (the ring holds sines: looked at above) and
+    // |gain| + |val| <= 800 put every exponent within pow's plain range on the large side and every increment, 440 * 2^e / sr, within the
+    // normal range and below 2^52 — no test of the quotient, no look at the increments, a phase that stays in [0, 1): the wrap is the one
+    // instruction, the sine needs no range check.  (The SMALL side of pow's plain range — |e ln 2| < 2^-54, e = 0 among them: a silent ring —
+    // is an argument's own business and stays tested per sample.)
+    const bool mod_ok = (double)__builtin_fabsf(c_fb) + __builtin_fabs(km.val) <= 800.0 && km.sr >= 1.0 && km.sr <= 65535.0 && pos_m >= 0.0 && pos_m < 1.0;
+    const bool proved = flag[1] == 0u && __builtin_amdgcn_ballot_w64(!mod_ok) == 0;
     if (!(pos_m >= 0.0 && pos_m < 1.0)) atomicOr(flag, 1u);  // (only a host can store such a phase: the scan then wraps with fmod1)
     uint32_t p0 = (uint32_t)(a.n0 % B);
     const uint32_t i0 = (uint32_t)s * (uint32_t)kXPer;  // this lane's first sample of a chunk
@@ -1514,12 +1598,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* const mp = a.mixpart ? a.mixpart + ((size_t)plane * a.n_waves + (blockIdx.x - a.block0)) * a.t_stride : nullptr;
     const bool frames = kOut == 0 ? frame_base != nullptr : (kOut & 1) != 0;
     const bool mix = kOut == 0 ? mp != nullptr : (kOut & 2) != 0;
+    const double inv_sr = 1.0 / km.sr;
 
-    auto run = [&](auto fc_c) {
+    // kFast: the modulator proved (above), every chunk whole (the launch's length a multiple of 64), no slice wraps inside the ring (its length
+    // and position multiples of 4) and all 32 voices real — no masks, no selects, ring addresses as instruction offsets
+    auto run = [&](auto fc_c, auto fast_c) {
         constexpr uint32_t FC = decltype(fc_c)::value;
+        constexpr bool kFast = decltype(fast_c)::value;
         const uint32_t n_chunks = (a.T + (uint32_t)kXChunk - 1u) / (uint32_t)kXChunk;
         // the ring's word for this lane's sample j of a chunk whose first sample of this slice sits at ring position `at` (below B; B >= 4)
         auto ring_at = [&](uint32_t at, int j) {
+            if (kFast) return (at + (uint32_t)j) * (uint32_t)kBlkVoices + (uint32_t)g;
             const uint32_t p = at + (uint32_t)j;
             return (p >= B ? p - B : p) * (uint32_t)kBlkVoices + (uint32_t)g;
         };
@@ -1527,7 +1616,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const uint32_t p = at + (uint32_t)kXChunk;
             return p >= B ? p - B : p;
         };
-        auto live = [&](uint32_t chunk, int j) { return chunk * (uint32_t)kXChunk + i0 + (uint32_t)j < a.T; };
+        auto live = [&](uint32_t chunk, int j) { return kFast || chunk * (uint32_t)kXChunk + i0 + (uint32_t)j < a.T; };
         // the modulator's increments of a chunk, from what the ring holds: 440 * 2^(f64(cv) + f64(val)) / sr (oscillator.rs:43-48,132)
         auto increments = [&](uint32_t chunk, uint32_t at, double (&d)[kXPer]) {
             float fed[kXPer];
@@ -1538,7 +1627,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int j = 0; j < kXPer; j++) {
                 e[j] = (double)(fed[j] * c_fb) + km.val;
-                d[j] = div_rn_plain(440.0 * exp2_libm_plain_t(e[j], cold, libm), km.sr, cold);
+                const double pw = X.k440 * x_exp2_libm_plain(X, e[j], cold, libm);
+                d[j] = kFast ? div_rn_proved(pw, km.sr, inv_sr) : div_rn_plain(pw, km.sr, cold);
             }
             if (__builtin_amdgcn_ballot_w64(cold) != 0) {
                 if (cold) {
@@ -1546,20 +1636,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int j = 0; j < kXPer; j++) d[j] = osc_delta_exact_cold(e[j], km.sr);  // (the reference's expression itself: the same value wherever the plain form had decided)
                 }
             }
-            bool ordinary = true;
+            if (!kFast) {
+                bool ordinary = true;
 #pragma unroll
-            for (int j = 0; j < kXPer; j++) {
-                ordinary = ordinary && d[j] >= 0.0 && d[j] < 4503599627370496.0;
-                d[j] = live(chunk, j) ? d[j] : 0.0;  // (past the launch's last sample: the phase stands still)
+                for (int j = 0; j < kXPer; j++) {
+                    ordinary = ordinary && d[j] >= 0.0 && d[j] < 4503599627370496.0;
+                    d[j] = live(chunk, j) ? d[j] : 0.0;  // (past the launch's last sample: the phase stands still)
+                }
+                if (!ordinary) atomicOr(flag, 1u);
             }
-            if (!ordinary) atomicOr(flag, 1u);
         };
         // the scan: chunk's increments in `buf` -> its phases, in place; lanes 0 .. 31 of wave 0, one voice each
         auto scan = [&]() {
             if (tid >= kBlkVoices) return;
             double p = pos_m;
             double* const col = buf + g;
-            if (flag[0] == 0u) {
+            if (kFast || flag[0] == 0u) {
 #pragma unroll 1
                 for (int t0 = 0; t0 < kXChunk; t0 += 16) {
                     double d[16];
@@ -1587,13 +1679,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             return pair;
         };
         auto slice_base = [&](int parity, double mine, double pair, double start, double& base, double& total) {
+            // (the waves below this one: a wave-uniform count.  A product with a scalar 0 / 1 — one fma per wave where an addition behind a
+            // select costs three instructions, two scalar-count loops more still (measured: 13.7 / 14.5 / 14.6 ms per step) — unless a total is
+            // a NaN: a voice whose modulator has overflowed hands them on, and they must not reach the slices BEFORE them: then the selects)
             base = start;
             total = 0.0;
 #pragma unroll
             for (int w2 = 0; w2 < 8; w2++) {
                 const double v = sums[(parity * 8 + w2) * kBlkVoices + g];
                 total += v;
-                if (w2 < w) base += v;
+                base = __builtin_fma(v, w2 < w ? 1.0 : 0.0, base);
+            }
+            if (__builtin_amdgcn_ballot_w64(total != total) != 0) {
+                base = start;
+#pragma unroll
+                for (int w2 = 0; w2 < 8; w2++) {
+                    const double v = sums[(parity * 8 + w2) * kBlkVoices + g];
+                    base = w2 < w ? base + v : base;
+                }
             }
             if (odd) base += pair - mine;
         };
@@ -1603,7 +1706,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float out[kXPer];
 #pragma unroll
             for (int j = 0; j < kXPer; j++) out[j] = blk_sine_loose(__builtin_amdgcn_fract(base + pre[j]));
-            if (frames && active) {
+            if (frames && (kFast || active)) {
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(frame_base + (size_t)(t0 + (uint32_t)w * 2u * (uint32_t)kXPer) * V, 0, 0x7fffffff, 0x00020000);
                 const uint32_t voff = ((uint32_t)g + (odd ? (uint32_t)kXPer * V : 0u)) * 4u;
 #pragma unroll
@@ -1615,7 +1718,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // plain butterflies over the remaining voice bits: lane g ends with sample (g & 3) of its slice
                 float v[kXPer];
 #pragma unroll
-                for (int j = 0; j < kXPer; j++) v[j] = active ? out[j] : 0.0f;
+                for (int j = 0; j < kXPer; j++) v[j] = (kFast || active) ? out[j] : 0.0f;
                 {
                     const bool up = (g & 1) != 0;
                     const float s0 = up ? v[0] : v[2], s1 = up ? v[1] : v[3], k0 = up ? v[2] : v[0], k1 = up ? v[3] : v[1];
@@ -1632,7 +1735,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 sum += __shfl_xor(sum, 8);
                 sum += __shfl_xor(sum, 16);
                 const int mine_j = ((g & 1) ? 2 : 0) + ((g & 2) ? 1 : 0);  // which of the slice's samples this lane ended up with
-                if (g < 4 && t0 + i0 + (uint32_t)mine_j < a.T) mp[t0 + i0 + (uint32_t)mine_j] = sum;
+                if (g < 4 && (kFast || t0 + i0 + (uint32_t)mine_j < a.T)) mp[t0 + i0 + (uint32_t)mine_j] = sum;
             }
         };
 
@@ -1671,7 +1774,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float sine[kXPer];
                 bool cold = false;
 #pragma unroll
-                for (int j = 0; j < kXPer; j++) sine[j] = sine_exact_plain(pM[j], cold);  // (pos * PI * 2).sin() as f32, oscillator.rs:133
+                for (int j = 0; j < kXPer; j++) sine[j] = x_sine_exact_plain<!kFast>(X, pM[j], cold);  // (pos * PI * 2).sin() as f32, oscillator.rs:133
                 if (__builtin_amdgcn_ballot_w64(cold) != 0) {
                     if (cold) {
 #pragma unroll
@@ -1687,7 +1790,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     double d = fm_increment<FC>(K, kc, sine[j] * c_ix);
                     const bool lv = live(k, j);
                     if (lv) ring_l[ring_at(at_k, j)] = sine[j];
-                    d = lv ? d : 0.0;
+                    if (!kFast) d = lv ? d : 0.0;
                     preC[j] = acc;
                     acc += d;
                 }
@@ -1706,17 +1809,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             pos_c = __builtin_amdgcn_fract(pos_c + total);
         }
     };
+    const bool fast = proved && (a.T % (uint32_t)kXChunk) == 0u && (B % (uint32_t)kXPer) == 0u && (p0 % (uint32_t)kXPer) == 0u && n_act == (uint32_t)kBlkVoices;
     if (a.T == 0u) {
         // nothing to render: the ring goes back as it came
     } else if (sane) {
         using std::integral_constant;
+        using std::true_type;
+        using std::false_type;
         constexpr uint32_t P = OSC_PHASE_TAME | OSC_VAL_FOLDED;
+        // (the fast copy for the class config 4's draw takes — index 0.5 ... 1.5: (2^(cv/4))^4 —; the general one for every class)
         if (car_class == 2)
-            run(integral_constant<uint32_t, fo_carrier | P | OSC_CV_SMALL>{});
+            run(integral_constant<uint32_t, fo_carrier | P | OSC_CV_SMALL>{}, false_type{});
+        else if (car_class == 1 && fast)
+            run(integral_constant<uint32_t, fo_carrier | P | OSC_CV_QUAD>{}, true_type{});
         else if (car_class == 1)
-            run(integral_constant<uint32_t, fo_carrier | P | OSC_CV_QUAD>{});
+            run(integral_constant<uint32_t, fo_carrier | P | OSC_CV_QUAD>{}, false_type{});
         else
-            run(integral_constant<uint32_t, fo_carrier | P>{});
+            run(integral_constant<uint32_t, fo_carrier | P>{}, false_type{});
     } else if (s == 0) {  // the recurrence, sample by sample, one lane per voice
         OscRegs sm, sc;
         sm.pos = pos_m;

@@ -511,10 +511,11 @@ SRK_DEV float sine_fast(double pos)
 // The reference's own sine, `(pos * PI * 2.0).sin() as f32` (oscillator.rs:133), bit for bit — through the polynomial wherever that is decidable.
 // The polynomial's value y is within 8e-14 y of sin(2 pi pos) (tests/test_oracle.py evaluates it against mpmath); the reference's f64 sine is
 // within 1.6e-15 + 1.2e-16 y of it (one rounding of pos * PI, the libm's sub-ulp error).  Both round to the SAME f32 unless y lies within the
-// sum of those of a rounding boundary: that is tested here (y minus its f32 rounding, against half an ulp of that f32), and only the lanes
+// sum of those of a rounding boundary: that is tested here (the two ends of that interval, converted), and only the lanes
 // that fail — 3 in a million, the neighbourhoods of the sine's zeros, where the reference's value is its argument's rounding error —
 // evaluate the reference's expression itself (ocml's sin, as the exact flavour did for every sample until round 5: 27.5 -> ms per step on
 // config 4).  A phase outside [0, 1) — only a host can store one — takes that way too.
+template <bool kRange = true>
 SRK_DEV float sine_exact_plain(double pos, bool& cold)  // (branch-free; `cold` is set where the rounding is not decided here)
 {
     uint32_t sign;
@@ -528,15 +529,15 @@ SRK_DEV float sine_exact_plain(double pos, bool& cold)  // (branch-free; `cold` 
     const double b1 = __builtin_fma(3.6659216216293173, z2, a45);
     const double z4 = z2 * z2;
     const double y = __builtin_fma(b1, z4, b0) * x;        // >= 0 for a pos in [0, 1)
-    const float r = (float)y;
-    const uint32_t e = __float_as_uint(r) & 0x7f800000u;   // r = 1.m x 2^(E - 127): half an ulp is 2^(E - 151)
-    // distance of y to the rounding boundary on its side of r: half an ulp — a quarter below an r that is a power of two, where the spacing
-    // halves (r = 1.0 is every phase within 5e-5 of a peak: 1.6e-4 of all samples fell back while those were left undecided, 3e-6 now)
-    const double d = y - (double)r;
-    double half = (double)__uint_as_float(e - (24u << 23));
-    half = (d < 0.0 && (__float_as_uint(r) & 0x007fffffu) == 0u) ? 0.5 * half : half;
-    const double room = half - __builtin_fabs(d);
-    const bool sure = e >= (64u << 23) && pos >= 0.0 && pos < 1.0 && room > __builtin_fma(1.0e-13, y, 2.0e-15);
+    // Every value within d = 1e-13 y + 2e-15 of y — the polynomial's 8e-14 y, the reference's 1.6e-15 + 1.2e-16 y — rounds to the same f32 iff the
+    // two ends of that interval do (rounding is monotone): two conversions and a compare, where round 5 measured y's distance to the rounding
+    // boundary on its side (a conversion back, the half-ulp's exponent, its halving below a power of two, three compares: twice the
+    // instructions).  tools/sine_check.c restates this on the CPU: 4.8e8 phases against glibc — uniform, around the quarter points, dyadic —, no
+    // decided value differs; 3.4e-6 of uniformly distributed phases stay undecided (the zeros' neighbourhoods, where y - d < 0 <= y + d, among them).
+    const double d = __builtin_fma(1.0e-13, y, 2.0e-15);
+    const float r = (float)(y - d), r2 = (float)(y + d);
+    bool sure = __float_as_uint(r) == __float_as_uint(r2);
+    if (kRange) sure = sure && pos >= 0.0 && pos < 1.0;    // (a phase outside [0, 1) — only a host can store one — or a NaN: the reference's expression; kRange == false: the caller has proved it)
     cold = cold || !sure;
     return __uint_as_float(__float_as_uint(r) ^ sign);
 }
@@ -610,6 +611,13 @@ SRK_DEV double div_rn_plain(double a, double b, bool& cold)  // (branch-free; `c
     const double q = a * y;
     const double r = __builtin_fma(-q, b, a);
     cold = cold || !(__builtin_fabs(q) > 0x1p-900 && __builtin_fabs(q) < 0x1p900);
+    return __builtin_fma(r, y, q);
+}
+// (the same where the caller has proved the quotient's range — a sample rate of 1 ... 65 535 under 440 * 2^e with |e| <= 800 — and holds y = RN(1 / b))
+SRK_DEV double div_rn_proved(double a, double b, double y)
+{
+    const double q = a * y;
+    const double r = __builtin_fma(-q, b, a);
     return __builtin_fma(r, y, q);
 }
 SRK_DEV double div_rn(double a, double b)
