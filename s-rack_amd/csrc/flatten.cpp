@@ -757,8 +757,8 @@ void Builder::match_fused(bool has_rings)
             if (!mixed) {
                 out.fused = FUSED_FM_PAIR;
                 out.fused_variant = far ? 1 : 0;  // 1: ring in HBM
-            } else if (far && (o[2].flags & OSC_EXACT) && !(o[5].flags & (OSC_EXACT | OSC_EXACT_BLEP)) && (o[5].flags & OSC_SINE_LOOSE)) {
-                out.fm_pair_x = true;  // the modulator exact as a whole, the carrier — its sine only heard — in its default forms (`fused` stays FUSED_NONE)
+            } else if ((o[2].flags & OSC_EXACT) && !(o[5].flags & (OSC_EXACT | OSC_EXACT_BLEP)) && (o[5].flags & OSC_SINE_LOOSE)) {
+                out.fm_pair_x = far ? 1 : 2;  // the modulator exact as a whole, the carrier — its sine only heard — in its default forms (`fused` stays FUSED_NONE)
             }
         }
         return;

@@ -48,8 +48,9 @@ struct FlatProgram {
     std::vector<int> op_of_module;    // module index -> op index, -1 if the module cannot reach the output
     int fused = FUSED_NONE;
     int fused_variant = 0;            // kernel-specific (which oscillator port / filter port the chain uses)
-    bool fm_pair_x = false;           // the FM pair's shape with the ring in HBM, the MODULATOR exact as a whole and the carrier in its default forms (csrc/approx.cpp's
-                                      // answer to config 4's loop): render_fm_pair_block_x renders it where the delay allows (render.hip), the general path elsewhere
+    int fm_pair_x = 0;                // the FM pair's shape with the MODULATOR exact as a whole and the carrier in its default forms (csrc/approx.cpp's answer to config 4's
+                                      // loop) — 1: the ring in HBM (render_fm_pair_block_x where the delay allows, render.hip; the general path elsewhere), 2: buffer_size 1
+                                      // (render_fm_pair_x)
     uint32_t n_voices = 0;
     uint32_t render_flags = 0;
     std::string description;

@@ -1865,6 +1865,170 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---- the z^-1 FM pair with the MODULATOR EXACT (config 4 as default mode renders it; round 6) -----------------------------------------------------
+// buffer_size 1: the fed-back sine is last sample's, in a register, and nothing can be evaluated across time — the modulator of sample t + 1 needs
+// the sine of sample t.  Until round 6 this program was the general path's (a kernel specialised at run time: 18.5 ms per step, 16.4 with the
+// cheaper sine decision).  Written by hand, on TWO waves per 64 voices like render_fm_pair_split: wave 0 of the workgroup runs the modulators (the
+// recurrence), wave 1 their carriers, frames and mix; the sines cross through a double-buffered LDS tile, one barrier per 32 samples.  65 536
+// voices are then 2048 waves — two per SIMD, each with half the work — and one wave's instructions fill the gaps the other's dependent chains
+// leave (a lone wave per SIMD issued 54 % of the time: 14.1 ms per step on one wave against this kernel's two).  Per modulator sample two chains
+// that do not wait for each other — the increment from the fed-back sine (the libm's 2^e, the correctly rounded quotient), the sine from the
+// phase —, the exact forms' constants in registers, the libm's table in LDS, ONE test per sample for "some lane could not decide", and what a wave
+// can prove once per launch (|gain| + |val| <= 800, a fed-back value of at most 1: no test of the quotient's range, a phase that stays in [0, 1)).
+// The modulator's arithmetic is osc_step's exact flavour operation for operation (x_exp2_libm_plain, div_rn_proved / div_rn_plain,
+// x_sine_exact_plain, v_fract / fmod1): bit-identical to it and to the CPU tick; the carrier's is render_fm_pair's default loop.
+// Reference: oscillator.rs:43-48,124-153, math.rs:152.
+template <int kOut>
+__global__ __launch_bounds__(128) void render_fm_pair_x(KernelArgs a, ChainRoles r)
+{
+    using namespace dev;
+    using std::integral_constant;
+    __shared__ __attribute__((aligned(16))) float mix_tile[kMixTile];
+    __shared__ float sines[2][kMixRows * 64];
+    __shared__ uint64_t tab[256];
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool carrier = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;
+    const WaveMap wm = wave_map(a, lane);
+    const uint32_t voice = wm.voice, vc = wm.vc, V = a.V;
+    const bool active = wm.active;
+    auto row = [&](int rr) { return a.table[(size_t)rr * V + vc]; };
+    auto parv = [&](const DevOp& op, int k) { return op.par_row[k] >= 0 ? __uint_as_float(row(op.par_row[k])) : op.par_val[k]; };
+    auto put = [&](int rr, uint32_t v) { a.table[(size_t)rr * V + voice] = v; };
+    const DevOp& oscop = a.ops[carrier ? r.osc_a : r.osc_l];   // this wave's oscillator (roles as in render_fm_pair)
+    const DevOp& mulop = a.ops[carrier ? r.vca : r.adsr];      // the Multiply in front of its CV: x index / x feedback gain
+    const int plane = a.ops[r.out].aux;
+    const int ring_row = r.track;
+
+    for (int k = (int)threadIdx.x; k < 256; k += 128) tab[k] = kLibmExpTab[k];
+    constexpr uint32_t fo = OSC_HAS_CV | OSC_CV_AUDIO_RATE | OSC_AA | OSC_OUT_SINE;
+    constexpr uint32_t fo_mod = fo | OSC_EXACT, fo_carrier = fo | OSC_SINE_LOOSE;
+    OscRegs s;
+    OscConst k;
+    s.pos = make_f64(row(oscop.state_row + OSC_S_POS_LO), row(oscop.state_row + OSC_S_POS_HI));
+    s.sync_last = false;
+    k.sr = oscop.sample_rate;
+    k.val = (double)parv(oscop, OSC_P_VAL);
+    k.delta = 0.0;
+    k.inv_dt = 0.0f;
+    k.scale = (440.0 / k.sr) * exp2(k.val);  // (the carrier's proved loops)
+    const float gain = parv(mulop, MATH_P_CONST);
+    float fed = __uint_as_float(row(ring_row));  // (modulator wave) OSC_M.sine of the previous tick
+    Emit em = make_emit(a, plane, lane);         // (carrier wave)
+    float sq = 0.0f, sw = 0.0f;
+    XConsts X;
+    x_consts_load(X);
+    const LibmTabLds libm{tab};
+    const double inv_sr = 1.0 / k.sr;
+    OscFacts facts = fm_osc_facts(gain, k, s.pos);  // (carrier wave: its class; re-proved once a tile has left it)
+    int car_class = fm_gain_class(gain);
+    // (modulator wave) what the exact forms may skip once it is proved for the launch — see render_fm_pair_block_x
+    const bool mod_ok = (double)__builtin_fabsf(gain) + __builtin_fabs(k.val) <= 800.0 && k.sr >= 1.0 && k.sr <= 65535.0 && s.pos >= 0.0 && s.pos < 1.0 && __builtin_fabsf(fed) <= 1.0f;
+    const bool mod_proved = __builtin_amdgcn_ballot_w64(!mod_ok) == 0;
+    __syncthreads();  // the table
+
+    const uint32_t n_tiles = (a.T + (uint32_t)kMixRows - 1u) / (uint32_t)kMixRows;
+    for (uint32_t kt = 0; kt <= n_tiles; kt++) {
+        if (!carrier) {
+            if (kt < n_tiles) {
+                const uint32_t t0 = kt * (uint32_t)kMixRows;
+                const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+                float* const dst = sines[kt & 1u] + lane;
+                if (mod_proved && n == kMixRows) {
+                    // A tile of 32 samples SPECULATIVELY: osc_step's exact flavour (merged form) with its tests proved away and its one remaining
+                    // question — "could some lane not decide?" (a sine within 1e-13 of an f32 rounding boundary, an exponent below pow's plain range:
+                    // 3.4e-6 of the samples) — asked ONCE, after the tile.  Asked per sample it is a wave-uniform branch between every two samples of a
+                    // recurrence that runs at one or two waves per SIMD: 14.5 ms per step against 9.2 without the question (tools/gpu_r6.sh ab).  A tile
+                    // with an undecided sample (0.7 % of them) is rendered again from its first sample through osc_step itself — every value the
+                    // reference's, the decided ones the same bits as before.
+                    const double pos0 = s.pos;
+                    const float fed0 = fed;
+                    bool cold = false;
+#pragma unroll SRK_FM_UNROLL
+                    for (int i = 0; i < kMixRows; i++) {
+                        const double e = (double)(fed * gain) + k.val;
+                        const double delta = div_rn_proved(X.k440 * x_exp2_libm_plain(X, e, cold, libm), k.sr, inv_sr);
+                        const float sn = x_sine_exact_plain<false>(X, s.pos, cold);
+                        s.pos = __builtin_amdgcn_fract(s.pos + delta);
+                        fed = sn;
+                        dst[i * 64] = sn;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(cold) != 0) {
+                        s.pos = pos0;
+                        fed = fed0;
+                        for (int i = 0; i < kMixRows; i++) {
+                            float sine = 0.0f;
+                            osc_step(fo_mod, s, k, fed * gain, 0.0f, sine, sq, sw);
+                            fed = sine;
+                            dst[i * 64] = sine;
+                        }
+                    }
+                } else {  // a ragged last tile, a modulator that is not proved: osc_step itself (the same values)
+                    for (int i = 0; i < n; i++) {
+                        float sine = 0.0f;
+                        osc_step(fo_mod, s, k, fed * gain, 0.0f, sine, sq, sw);
+                        fed = sine;
+                        dst[i * 64] = sine;
+                    }
+                }
+            }
+        } else if (kt > 0) {
+            const uint32_t t0 = (kt - 1u) * (uint32_t)kMixRows;
+            const int n = (int)min((uint32_t)kMixRows, a.T - t0);
+            const float* const src = sines[(kt - 1u) & 1u] + lane;
+            float in[kMixRows];
+#pragma unroll
+            for (int i = 0; i < kMixRows; i++) in[i] = src[i * 64];  // (rows past a short last tile: stale, unused)
+            bool proved = false;
+            if (facts.tame) {  // a sine from a phase outside [0, 1), or a NaN, is not bounded by 1: look (a ragged last tile takes the same arithmetic as a whole one)
+                float m = 0.0f;
+#pragma unroll
+                for (int i = 0; i < kMixRows; i++) m = __builtin_fmaxf(m, i < n ? __builtin_fabsf(in[i]) : 0.0f);
+                proved = __builtin_amdgcn_ballot_w64(!(m <= 1.0f)) == 0;
+            }
+            auto tile = [&](auto flags_c) {
+                constexpr uint32_t F = decltype(flags_c)::value;
+                if (n == kMixRows) {
+#pragma unroll SRK_FM_UNROLL
+                    for (int i = 0; i < kMixRows; i++) {
+                        float out = 0.0f;
+                        osc_step(F, s, k, in[i] * gain, 0.0f, out, sq, sw);
+                        emit_put<kOut>(em, mix_tile, out, i, V);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kMixRows; i++)
+                        if (i < n) {
+                            float out = 0.0f;
+                            osc_step(F, s, k, in[i] * gain, 0.0f, out, sq, sw);
+                            emit_put<kOut>(em, mix_tile, out, i, V);
+                        }
+                }
+            };
+            constexpr uint32_t P = OSC_PHASE_TAME | OSC_VAL_FOLDED;
+            if (proved && car_class == 2)
+                tile(integral_constant<uint32_t, fo_carrier | P | OSC_CV_SMALL>{});
+            else if (proved && car_class == 1)
+                tile(integral_constant<uint32_t, fo_carrier | P | OSC_CV_QUAD>{});
+            else if (proved)
+                tile(integral_constant<uint32_t, fo_carrier | P>{});
+            else
+                tile(integral_constant<uint32_t, fo_carrier>{});
+            if (!proved) {  // the literal forms may have left [0, 1)
+                facts = fm_osc_facts(gain, k, s.pos);
+                car_class = fm_gain_class(gain);
+            }
+            emit_flush<kOut, false>(em, mix_tile, t0, n, V);
+        }
+        __syncthreads();  // tile kt is complete and visible; the carrier is done with the buffer tile kt + 1 will overwrite
+    }
+    if (active) {
+        put(oscop.state_row + OSC_S_POS_LO, f64_lo(s.pos));
+        put(oscop.state_row + OSC_S_POS_HI, f64_hi(s.pos));
+        put(oscop.state_row + OSC_S_SYNC_LAST, 0u);
+        if (!carrier) put(ring_row, __float_as_uint(fed));
+    }
+}
+
 // ---- mix-down, passes 2 and 3: mix[c][i] = sum over waves of mixpart[plane(c)][w][i] ---------------------------
 // Deterministic (fixed order, no atomics).  Pass 2 splits the waves into kMixSplit groups so that enough loads
 // are in flight to stream the partials at HBM rate: block (x, y) sums group y for 256 consecutive samples into

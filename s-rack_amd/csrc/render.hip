@@ -634,8 +634,25 @@ static void launch_interp(const FlatProgram& P, const KernelArgs& ka, hipStream_
 // unless the host asked for a specialised kernel or the general path by name
 static bool fm_block_x_shape(const FlatProgram& P, uint32_t flags, uint32_t n_samples)
 {
-    return P.fm_pair_x && n_samples >= knobs().fm_block_min && knobs().fm_block && P.hdr.buffer_size >= 256 && P.hdr.buffer_size <= 1024 &&
+    return P.fm_pair_x == 1 && n_samples >= knobs().fm_block_min && knobs().fm_block && P.hdr.buffer_size >= 256 && P.hdr.buffer_size <= 1024 &&
            !(flags & (SRACK_RENDER_EXACT_OSC | SRACK_RENDER_NO_FUSION | SRACK_RENDER_SPECIALIZE));
+}
+
+// ... and at buffer_size 1 (the fed-back sine in a register): render_fm_pair_x
+static bool fm_x_z1_shape(const FlatProgram& P, uint32_t flags)
+{
+    return P.fm_pair_x == 2 && !(flags & (SRACK_RENDER_EXACT_OSC | SRACK_RENDER_NO_FUSION | SRACK_RENDER_SPECIALIZE));
+}
+static void launch_fm_pair_x(int out_mode, const KernelArgs& ka, const ChainRoles& roles, dim3 grid, hipStream_t st)
+{
+    if (out_mode == 3)
+        hipLaunchKernelGGL((render_fm_pair_x<3>), grid, dim3(128), 0, st, ka, roles);
+    else if (out_mode == 1)
+        hipLaunchKernelGGL((render_fm_pair_x<1>), grid, dim3(128), 0, st, ka, roles);
+    else if (out_mode == 2)
+        hipLaunchKernelGGL((render_fm_pair_x<2>), grid, dim3(128), 0, st, ka, roles);
+    else
+        hipLaunchKernelGGL((render_fm_pair_x<0>), grid, dim3(128), 0, st, ka, roles);
 }
 
 static int launch_fm_block_x(int out_mode, const KernelArgs& ka, const ChainRoles& roles, hipStream_t st)
@@ -689,7 +706,7 @@ static int resolve_specialized(PatchHandle& h, uint32_t flags, uint32_t n_sample
     *with_ctl = false;
     const FlatProgram& P = h.prog.voice;
     DeviceState* d = h.dev;
-    if (!specializable_shape(P, flags) || (flags & SRACK_RENDER_NO_SPECIALIZE) || P.ops.empty() || fm_block_x_shape(P, flags, n_samples)) return SRACK_OK;
+    if (!specializable_shape(P, flags) || (flags & SRACK_RENDER_NO_SPECIALIZE) || P.ops.empty() || fm_block_x_shape(P, flags, n_samples) || fm_x_z1_shape(P, flags)) return SRACK_OK;
     const bool forced = (flags & SRACK_RENDER_SPECIALIZE) != 0;
     if (!forced && (P.n_voices < kSpecializeMinVoices || d->jit_failed || !jit_supported(P))) return SRACK_OK;
     // the control program's units ride along in the same launches whenever the generator covers them all
@@ -773,6 +790,7 @@ struct Segment {
     // kernels: up to one wave per SIMD) or while waves are latency-bound (FM pair, interpreter: up to four).
     const bool fm_block;  // 32 voices per workgroup, whatever the voice count
     const bool fm_block_x;  // ... the same with the modulator exact (render_fm_pair_block_x)
+    const bool fm_x_z1;     // the z^-1 pair with the modulator exact (render_fm_pair_x)
     const uint32_t lanes, n_waves;
     // plan
     bool has_ctl = false, co_ctl = false, special_ctl = false, tick = false;
@@ -792,7 +810,7 @@ struct Segment {
     Segment(PatchHandle& h_, uint32_t T_total_, uint32_t t_seg_, uint32_t T_, float* d_frames_, float* d_mix_, uint32_t flags_, hipStream_t st_)
         : h(h_), P(h_.prog.voice), d(h_.dev), tk(h_.dev->tick), V(h_.prog.voice.n_voices), C((uint32_t)h_.prog.voice.hdr.n_channels), T_total(T_total_),
           t_seg(t_seg_), T(T_), flags(flags_), d_frames(d_frames_ ? d_frames_ + (size_t)t_seg_ * h_.prog.voice.n_voices : nullptr),
-          d_mix(d_mix_ ? d_mix_ + t_seg_ : nullptr), st(st_), fm_block(fm_block_shape(h_.prog.voice, flags_, T_)), fm_block_x(fm_block_x_shape(h_.prog.voice, flags_, T_)),
+          d_mix(d_mix_ ? d_mix_ + t_seg_ : nullptr), st(st_), fm_block(fm_block_shape(h_.prog.voice, flags_, T_)), fm_block_x(fm_block_x_shape(h_.prog.voice, flags_, T_)), fm_x_z1(fm_x_z1_shape(h_.prog.voice, flags_)),
           lanes((fm_block || fm_block_x) ? (uint32_t)kBlkVoices : lanes_per_wave(h_.prog.voice.n_voices)), n_waves((h_.prog.voice.n_voices + lanes - 1) / lanes)
     {
     }
@@ -1003,7 +1021,7 @@ struct Segment {
             // step, 4096 7.39, 1536 7.31, 1024 7.43, 8192 7.85 (tools/ab_env.sh, one box); its ring variant and the flagship are flat from 3072 to 6144.
             // A specialised kernel without rings in HBM at one wave per SIMD or fewer is in the same position (config 4 through the general
             // path: 7.36 - 7.46 ms per step at 4096, 7.26 - 7.28 at 2048, two rounds on one box).
-            const bool fm_z1 = P.fused == FUSED_FM_PAIR && P.fused_variant == 0 && !(flags & (SRACK_RENDER_NO_FUSION | SRACK_RENDER_EXACT_OSC));
+            const bool fm_z1 = fm_x_z1 || (P.fused == FUSED_FM_PAIR && P.fused_variant == 0 && !(flags & (SRACK_RENDER_NO_FUSION | SRACK_RENDER_EXACT_OSC)));
             const bool lone_waves = special && P.hdr.n_rings == 0 && n_waves <= 1024 && !(flags & SRACK_RENDER_EXACT_OSC);
             // (the time-parallel FM pair keeps its ring in LDS for a launch and moves it to and from HBM at the ends: one launch per segment)
             const uint32_t len = (fm_block || fm_block_x) ? knobs().fm_block_chunk : (fm_z1 || lone_waves) ? std::min(kChunkMax, 2048u) : kChunkMax;
@@ -1178,7 +1196,7 @@ struct Segment {
             d->kernel_name = "render_voice_chain_seq";
         }
         if (special) d->kernel_name = "render_specialized";
-        fm_pair = P.fused == FUSED_FM_PAIR || fm_block_x;
+        fm_pair = P.fused == FUSED_FM_PAIR || fm_block_x || fm_x_z1;
         if (fm_pair) {  // op order fixed by the matcher: DELAY_RD, MATH_FB, OSC_M, DELAY_WR, MATH_IDX, OSC_C, OUT
             roles.adsr = 1;
             roles.osc_l = 2;
@@ -1186,7 +1204,7 @@ struct Segment {
             roles.osc_a = 5;
             roles.out = 6;
             roles.track = P.ops[0].aux;  // the ring's state row
-            if (!special) d->kernel_name = fm_block_x ? "render_fm_pair_block_x" : fm_block ? "render_fm_pair_block" : P.fused_variant == 1 ? "render_fm_pair_ring" : "render_fm_pair";
+            if (!special) d->kernel_name = fm_x_z1 ? "render_fm_pair_x" : fm_block_x ? "render_fm_pair_block_x" : fm_block ? "render_fm_pair_block" : P.fused_variant == 1 ? "render_fm_pair_ring" : "render_fm_pair";
         }
     }
 
@@ -1263,6 +1281,8 @@ struct Segment {
             } else if (seq_chain) {
                 const int out_mode = (ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0);
                 launch_seq(seq_port, out_mode, ka, seq, dim3(n_waves), st);
+            } else if (fm_pair && fm_x_z1) {
+                launch_fm_pair_x((ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0), ka, roles, dim3(n_waves), st);
             } else if (fm_pair && fm_block_x) {
                 if ((rc = launch_fm_block_x((ka.frames ? 1 : 0) | (ka.mixpart ? 2 : 0), ka, roles, st)) != SRACK_OK) return rc;
             } else if (fm_pair && fm_block) {

@@ -306,17 +306,18 @@ def test_fm_feedback_gain_above_one_takes_the_exact_flavour(S, oracle, B):
     q.render_channels(4096, S.RENDER_KEEP_DEFAULT)   # (round 5: config 4's own draw goes exact by default as well — any loop through a pitch; its fast kernels on request)
     assert ("render_fm_pair_block" in q.info()) if B == 1024 else ("render_fm_pair" in q.info() or "render_specialized" in q.info())
     # the modulator exact as a whole: the general path, or — from round 6, where the delay allows time lanes — the pair's kernel for exactly that program
-    assert ("kernel=render_fm_pair_block_x" in p.info() if B == 1024 else "render_fm_pair" not in p.info()) and "; exact osc 0]" in p.info(), p.info()
+    assert ("kernel=render_fm_pair_block_x" if B == 1024 else "kernel=render_fm_pair_x") in p.info() and "; exact osc 0]" in p.info(), p.info()
 
 
-@pytest.mark.parametrize("B,T", [(256, 9216), (1000, 9000), (1024, 9216), (1024, 8191), (640, 4097)])
+@pytest.mark.parametrize("B,T", [(256, 9216), (1000, 9000), (1024, 9216), (1024, 8191), (640, 4097), (1, 4096), (1, 2501)])
 def test_fm_pair_with_the_modulator_exact_across_time_lanes(S, oracle, B, T):
     """render_fm_pair_block_x (round 6): config 4's program as default mode renders it — the modulator exact as a whole, the carrier in its default
     forms — with a delay of 256 ... 1024 samples: increments (the libm's 2^cv, the correctly rounded quotient) and sines across time lanes, only
     `pos = (pos + delta) % 1.0` serial (oscillator.rs:152-153).  70 voices (two full workgroups of 32 and a ragged one), ring lengths that are and
     are not multiples of the 64-sample chunk, render lengths that are and are not.  The frames against the oracle (the carrier's f32 sine on a phase
     that is the reference's to 1e-12: 5e-7), the MODULATOR's phase after the render bit for bit, a second call continuing the first, and a voice
-    whose feedback gain overflows 2^cv (NaNs where the reference has them: the scan's fmod1 path)."""
+    whose feedback gain overflows 2^cv (NaNs where the reference has them: the scan's fmod1 path).  buffer_size 1: render_fm_pair_x, the same program
+    with the fed-back sine in a register — nothing across time there, the same exact forms per sample."""
     V = 70
     beta, index = S.p2_voice_params(V)
     beta, index = beta.copy(), index.copy()
@@ -332,7 +333,7 @@ def test_fm_pair_with_the_modulator_exact_across_time_lanes(S, oracle, B, T):
     for m, f, v in over(ids):
         p.set_voice_field(m, f, v)
     a = p.render_channels(T, 0)
-    assert "kernel=render_fm_pair_block_x" in p.info() and "; exact osc 0]" in p.info(), p.info()
+    assert ("kernel=render_fm_pair_x" if B == 1 else "kernel=render_fm_pair_block_x") in p.info() and "; exact osc 0]" in p.info(), p.info()
     if T % B == 0:   # the oracle ticks block by block: its modules hold the state after whole blocks
         pos = p.get_voice_field(ids["osc_m"], S.OSC_POS)
         for v in (0, 31, 32, 63, 64, 69, wild):
@@ -358,7 +359,7 @@ def test_fm_pair_with_the_modulator_exact_across_time_lanes(S, oracle, B, T):
     for m, f, v in over(ids):
         g2.set_voice_field(m, f, v)
     c = g2.render_channels(T, 2)
-    assert "render_fm_pair_block_x" not in g2.info()
+    assert "render_fm_pair_block_x" not in g2.info() and "render_fm_pair_x" not in g2.info()
     fin = ~np.isnan(c[0])
     assert np.abs(c[0][fin].astype(np.float64) - a[0][fin]).max() < 8e-7
 
@@ -828,7 +829,7 @@ def test_cfg3_poly_modes(S, oracle, flags, V, T):
 
 # (since round 3 the kernels bench.py times for this patch: buffer_size 1 — the kernel specialised at run time, whose generator derives
 # the bounded pitch CVs render_fm_pair proves by hand; buffer_size 1024 — the time-parallel pair with its ring in LDS)
-@pytest.mark.parametrize("B,flags,kernel", [(1, 64, "render_specialized"), (1024, 64, "render_fm_pair_block"), (1, 0, "render_specialized"), (1024, 0, "render_fm_pair_block_x")])
+@pytest.mark.parametrize("B,flags,kernel", [(1, 64, "render_specialized"), (1024, 64, "render_fm_pair_block"), (1, 0, "render_fm_pair_x"), (1024, 0, "render_fm_pair_block_x")])
 def test_cfg4_exactly_as_benchmarked(S, oracle, B, flags, kernel):
     """BASELINE config 4 at full size, the workload `bench.py --workload cfg4` (and cfg4_b1024) times: 65 536 voices x 48 000
     samples of the 2-operator FM patch with its feedback edge, per-voice feedback / index (12.6 GB of frames, kept on the device) —
