@@ -882,10 +882,10 @@ struct COscQuiet {
     uint32_t hQspanq;
 };
 
-SRK_DEV void cosc_quiet_init(const COsc& o, COscQuiet& q)
+SRK_DEV void cosc_quiet_init(const COsc& o, COscQuiet& q, int len = kQuietGroup)  // len: samples per group (a group that is not quiet is halved: 8, 4, 2, 1)
 {
     const double g = __builtin_fmin(o.delta * (1.0 + 9.5367431640625e-07) + 1e-300, 0.25);  // cosc_init's window half-width
-    const double w = g + (double)kQuietGroup * o.delta * (1.0 + 9.5367431640625e-07);        // ... plus the phase the group's samples cover
+    const double w = g + (double)len * o.delta * (1.0 + 9.5367431640625e-07);                // ... plus the phase the group's samples cover
     if (w < 0.24) {
         q.hBq = __double2hiint(1.0 - w);
         q.hQ0q = __double2hiint(0.5 - w);
@@ -903,13 +903,6 @@ SRK_DEV bool cosc_square_quiet(const COsc& o, const COscQuiet& q)
 {
     const int h = __double2hiint(o.pos);
     return !(h <= o.hA || h >= q.hBq || (uint32_t)(h - q.hQ0q) <= q.hQspanq);
-}
-// ... and for ONE sample (a group that is not quiet as a whole is walked sample by sample: the event-free form for every sample no lane
-// has an event in — cosc_square's own `near` test —, the per-sample form for the others)
-SRK_DEV bool cosc_square_calm(const COsc& o)
-{
-    const int h = __double2hiint(o.pos);
-    return !(h <= o.hA || h >= o.hB || (uint32_t)(h - o.hQ0) <= o.hQspan);
 }
 SRK_DEV float cosc_square_level(const COsc& o) { return __double2hiint(o.pos) < 0x3fe00000 ? -1.0f : 1.0f; }
 // (a quiet group ends below 1 - g: `pos %= 1.0` is the identity on every one of its sums, the wrap instruction is not needed)
@@ -1535,7 +1528,7 @@ SRK_DEV float adsr_seg_step(AdsrRegs& s, const AdsrConst& c, AdsrSeg& g, float g
     } else {
         s.phase = ph;
         g.last = m_high;
-        const float u = g.k0 + g.k1 * ph;
+        const float u = __builtin_fmaf(g.k1, ph, g.k0);  // (k1 = +-1: the product is exact, the one rounding is the sum's — k0 + k1 * ph bit for bit)
         out = g.c0 + g.c1 * u;
     }
     g.held = out;
@@ -1545,21 +1538,13 @@ SRK_DEV float adsr_seg_step(AdsrRegs& s, const AdsrConst& c, AdsrSeg& g, float g
 // Quiet groups (see cosc_quiet_init): no lane leaves its segment during the next kQuietGroup samples, given that its gate holds the value
 // `gate` for all of them (a group-constant gate: a quiet square oscillator's level).  Wave-uniform part: the gate's level or edge ends no
 // lane's segment — adsr_seg_step's own mask, evaluated once; a constant gate has its only possible edge at the group's first sample.
-// Per-lane part: the phase stays below 1 — each of the group's rounded additions adds at most inc + 2^-24 (an infinite or NaN increment
+// Per-lane part: the phase stays below 1 — each of the group's `len` rounded additions adds at most inc + 2^-24 (an infinite or NaN increment
 // says no).  `m_high` returns the gate's level mask: what adsr_seg_step would leave in g.last after every one of the group's samples.
-SRK_DEV bool adsr_seg_quiet(const AdsrRegs& s, const AdsrSeg& g, float gate, uint64_t& m_high)
+SRK_DEV bool adsr_seg_quiet(const AdsrRegs& s, const AdsrSeg& g, float gate, uint64_t& m_high, int len = kQuietGroup)
 {
     m_high = __builtin_amdgcn_ballot_w64(gate > 0.0f);
     const uint64_t m_leave = (m_high & g.on_high) | (~m_high & g.on_low) | (m_high & ~g.last & g.on_edge);
-    return m_leave == 0 && s.phase + (float)kQuietGroup * g.inc <= 0.9999f;
-}
-// the same question for ONE sample: adsr_seg_step's own test (m_leave == 0, i.e. no lane's phase reaches 1 and no gate level or edge ends
-// a segment), asked ahead of the sample for a gate that is known before the envelope's turn
-SRK_DEV bool adsr_seg_calm(const AdsrRegs& s, const AdsrSeg& g, float gate, uint64_t& m_high)
-{
-    m_high = __builtin_amdgcn_ballot_w64(gate > 0.0f);
-    const uint64_t m_leave = (m_high & g.on_high) | (~m_high & g.on_low) | (m_high & ~g.last & g.on_edge);
-    return m_leave == 0 && !(s.phase + g.inc >= 1.0f);
+    return m_leave == 0 && s.phase + (float)len * g.inc <= 0.9999f;
 }
 // The VCA behind such an envelope asks `cv > 0.0` every sample (vca.rs:132).  Within a quiet group the answer is one per lane: the
 // segment's output c0 + c1 u is monotonic in u, u moves one way, and with c0, c1 >= 0 it is positive from the first sample on if c0 > 0
@@ -1585,7 +1570,7 @@ SRK_DEV float vca_step_decided(bool open_lane, float audio, float cv)
 SRK_DEV float adsr_seg_quiet_step(AdsrRegs& s, AdsrSeg& g)
 {
     s.phase = s.phase + g.inc;
-    const float u = g.k0 + g.k1 * s.phase;
+    const float u = __builtin_fmaf(g.k1, s.phase, g.k0);  // (= k0 + k1 * phase bit for bit: k1 = +-1)
     const float out = g.c0 + g.c1 * u;
     g.held = out;
     return out;
@@ -1617,7 +1602,7 @@ SRK_DEV float adsr_seg_tile(AdsrRegs& s, const AdsrConst& c, AdsrSeg& g, float g
             float ph = s.phase, out = g.held;
             for (int k = 0; k < run; k++) {
                 ph = ph + g.inc;
-                const float u = g.k0 + g.k1 * ph;
+                const float u = __builtin_fmaf(g.k1, ph, g.k0);  // (k1 = +-1: the product is exact, the one rounding is the sum's — k0 + k1 * ph bit for bit)
                 out = g.c0 + g.c1 * u;
                 keep = lane == i + k ? out : keep;
             }
