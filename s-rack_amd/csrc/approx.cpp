@@ -45,9 +45,9 @@ constexpr double kEpsFixedWindow = 0x1p-31; // ... PLUS, inside the two PolyBLEP
                                             // nothing at 440 Hz (5e-8), 1.0e-6 at 17 Hz (round 6, tools/emu_vs_gpu.py: seed 900146 rendered 1.02e-6 where the bound said
                                             // 2.4e-7), 2.5e-5 for a 0.9 Hz LFO: the form's epsilon is this over the SMALLEST increment any voice has
 constexpr double kEpsNonlin = 4e-6;         // v_log_f32 / v_exp_f32 power, relative to max(|out|, 1)
-constexpr double kEpsNonlinPlain = 6e-8;    // the power WITHOUT that form (powf_pos: table-driven f64 log2, polynomial 2^y, one rounding): the host libm's powf is itself
-                                            // within 0.82 ulp, not correctly rounded, so the two part by an f32 ulp now and then (P4: 6.0e-8 in every mode,
-                                            // profiles/r05_horizon.json) — a RESIDUAL no decision removes; only what it reaches decides whether it matters
+                                            // (the power WITHOUT that form is the host libm's powf operation for operation since round 6 — modules.hip.h,
+                                            // powf_libm_plain — and costs nothing here; until then it was an f32 ulp away now and then, which ADVICE r05
+                                            // found counted as 0 behind unbounded gains)
 constexpr double kEpsLadder[3] = {1.5e-6, 4.2e-6, 3.6e-6};  // contracted ladder, lowpass / bandpass / highpass (tools/ladder_calib.c)
 constexpr double kLadderNoiseInput = 1.5;   // ... with a noise-like signal on the audio input (noise, a sample player, a reverb: a new level every sample excites the resonance all the
                                             // time, a saw now and then): `noisein`, 2.0 / 5.4 / 1.7e-6 up to resonance 0.6 — and 8.5e-6 / 1.2e-5 / 6.1e-6 from 0.8 up (0.7 with
@@ -758,14 +758,12 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
     // An oscillator whose pitch moves (2^cv by polynomial) or whose sine is heard there (the polynomial sine: the reference's own but for 3
     // roundings in a million) is evaluated exactly as a whole — that oscillator: the libm's pow, the reference's sine, f64 PolyBLEP
     // (config 4: the modulator inside its feedback loop; the carrier behind it keeps the default forms).  The sample player's pitch has no
-    // such form: the whole patch goes exact.  Nor has a NonLinear: its power is the host libm's powf to within an f32 ulp in every
-    // mode, never bit for bit — the exact flavour is the closest there is (ocml's f64 log2 inside), and it keeps everything AROUND the waveshaper
-    // the reference's own, as round 4 rendered such loops.
+    // such form: the whole patch goes exact.  (A NonLinear does: denied its f32 form, its power is the host libm's own — modules.hip.h, powf_libm_plain.)
     for (int m = 0; m < n_mod; m++) {
         if (!live[(size_t)m]) continue;
         const Module& mod = g.modules[(size_t)m];
         const bool osc = mod.type == SRACK_MOD_OSCILLATOR && (mod.in[SRACK_OSC_IN_CV].src >= 0 || A.port_is_live(m, SRACK_OSC_OUT_SINE));
-        const bool player = (mod.type == SRACK_MOD_SAMPLE && mod.in[SRACK_SAMPLE_IN_CV].src >= 0) || mod.type == SRACK_MOD_NONLINEAR;
+        const bool player = mod.type == SRACK_MOD_SAMPLE && mod.in[SRACK_SAMPLE_IN_CV].src >= 0;
         if (!osc && !player) continue;
         for (size_t p = 0; p < P.gain[(size_t)m].size(); p++)
             if (A.port_is_live(m, (int)p) && P.gain[(size_t)m][p] == kInf) {
@@ -856,14 +854,6 @@ ApproxPlan plan_approximations(const Graph& g, const std::vector<char>& live, co
             }
         }
         std::vector<double> r((size_t)n_ch, 0.0);
-        for (const Form& f : forms) {  // a NonLinear without the f32 form: the table-driven power's own ulp against the libm's, through whatever reads it (an event input: 1e9)
-            if (f.kind != kNonlin || f.taken) continue;
-            for (int c = 0; c < n_ch; c++)
-                if (!G[(size_t)c].empty()) {
-                    const double v = times(kEpsNonlinPlain * std::max(1.0, A.mag[(size_t)f.module][0]), gw(c, f.module, 0));
-                    r[(size_t)c] += v < kBig ? v : kInf;
-                }
-        }
         for (const Form& f : forms) {
             if (f.kind != kLadder || f.taken) continue;
             const int m = f.module;

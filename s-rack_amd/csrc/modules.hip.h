@@ -1681,48 +1681,28 @@ SRK_DEV float noise_sample(uint64_t key, uint64_t n)
 // ---------------------------------------------------------------------------------------------
 // NonLinearModule — math.rs:203-205: `if a > 0.0 { a.powf(b) } else { -(-a).powf(b) }`
 // ---------------------------------------------------------------------------------------------
-// f32 powf(x, b) for the common case (x finite > 0, b finite, result a normal float) as 2^(b*log2 x) in f64:
-// the f64 error (~1e-13 relative) is far below half an f32 ulp, so the result is the correctly rounded power
-// except within ~1e-13 of a rounding boundary — as close to libm's powf (itself within ~2^-34 of exact before
-// its final rounding) as any implementation other than libm's own tables gets.  Everything else (zeros,
-// infinities, NaNs, over/underflow) goes to ocml's powf, which implements the C99 special cases libm does.
-// log2 of a normal positive f32, in f64, absolute error < 1e-15 + the table's rounding (default mode; the exact mode keeps ocml's
-// log2, whose double-double arithmetic costs four times as much): x = 2^e * m, the mantissa's top five bits pick c = 1 + (i + 1/2) / 32
-// with 1 / c and log2(c) from a table, z = m / c - 1 is at most 1 / 64 in size (one fma: m has 24 bits), and
-// log2(1 + z) = z * (a1 + a2 z + ... + a7 z^6) — the Taylor series, whose next term is 6e-16 there — by Estrin's scheme.
-__device__ const uint64_t kLog2Tab[32][2] = {  // {bits(1 / c_i), bits(log2 c_i)}
-    {0x3fef81f81f81f820, 0x3f96e79685c2d22a},
-    {0x3fee9131abf0b767, 0x3fb0eb389fa29f9b},
-    {0x3fedae6076b981db, 0x3fbbc84240adabba},
-    {0x3fecd85689039b0b, 0x3fc32ae9e278ae1a},
-    {0x3fec0e070381c0e0, 0x3fc84c2bd02f03b3},
-    {0x3feb4e81b4e81b4f, 0x3fcd49ee4c325970},
-    {0x3fea98ef606a63be, 0x3fd11307dad30b76},
-    {0x3fe9ec8e951033d9, 0x3fd37124cea4cded},
-    {0x3fe948b0fcd6e9e0, 0x3fd5c01a39fbd688},
-    {0x3fe8acb90f6bf3aa, 0x3fd800a563161c54},
-    {0x3fe8181818181818, 0x3fda33760a7f6051},
-    {0x3fe78a4c8178a4c8, 0x3fdc592fad295b56},
-    {0x3fe702e05c0b8170, 0x3fde726aa1e754d2},
-    {0x3fe6816816816817, 0x3fe03fda8b97997f},
-    {0x3fe6058160581606, 0x3fe140c9faa1e544},
-    {0x3fe58ed2308158ed, 0x3fe23c41d42727c8},
-    {0x3fe51d07eae2f815, 0x3fe3327c6ab49ca7},
-    {0x3fe4afd6a052bf5b, 0x3fe423b07e986aa9},
-    {0x3fe446f86562d9fb, 0x3fe510118708a8f9},
-    {0x3fe3e22cbce4a902, 0x3fe5f7cff41e09af},
-    {0x3fe3813813813814, 0x3fe6db196a76194a},
-    {0x3fe323e34a2b10bf, 0x3fe7ba18f93502e4},
-    {0x3fe2c9fb4d812ca0, 0x3fe894f74b06ef8b},
-    {0x3fe27350b8812735, 0x3fe96bdad2acb5f6},
-    {0x3fe21fb78121fb78, 0x3fea3ee7f38e181f},
-    {0x3fe1cf06ada2811d, 0x3feb0e4126bcc86c},
-    {0x3fe1811811811812, 0x3febda071cc67e6e},
-    {0x3fe135c81135c811, 0x3feca258dca93316},
-    {0x3fe0ecf56be69c90, 0x3fed6753e032ea0f},
-    {0x3fe0a6810a6810a7, 0x3fee29142e0e0140},
-    {0x3fe0624dd2f1a9fc, 0x3feee7b471b3a950},
-    {0x3fe0204081020408, 0x3fefa34e1177c233},
+// `a.powf(b)` is the HOST libm's powf (Rust's f32::powf), and glibc's powf (2.27 and later: Szabolcs Nagy's algorithm, sysdeps/ieee754/flt-32/
+// e_powf.c) is within 0.82 ulp of the true power: NOT the correctly rounded float.  Until round 6 the kernels evaluated 2^(b log2 x) in f64 with
+// tables of their own and rounded once — the correctly rounded power but for one argument in 1e13, and therefore an f32 ulp away from the
+// reference wherever the libm is (P4: 6.0e-8 in every render mode; a waveshaper inside a feedback loop: a different render — the fuzzer's seed
+// 405576, 1.97 off).  This is the algorithm itself, operation for operation as the x86-64 FMA build of glibc 2.35 executes it (disassembled: which
+// products are contracted into fused multiply-adds is the compiler's choice, and part of the result):
+//     log2 x:  x = 2^k z, z in [0x1.66p-1, 0x1.66p0) (OFF = 0x3f330000), the top four bits of z's offset mantissa pick c with 1 / c and log2 c from
+//              its 16-entry table, r = fma(z, 1 / c, -1), y0 = log2 c + k,
+//              log2 x = fma(fma(r, A0, A1), r^4, fma(r^2, fma(r, A2, A3), fma(r, A4, y0)))
+//     2^(y log2 x):  kd = ylogx + 0x1.8p52 / 32 - the same, r = ylogx - kd, 2^(k / 32) from pow2f_libm's table,
+//              fma(fma(r, C0, C1), r^2, fma(r, C2, 1)) * 2^(k / 32), ONE rounding to f32 (subnormal results round there)
+// with its overflow (ylogx > 0x1.fffffffd1d571p+6) and underflow (ylogx <= -150) answers and its normalisation of a subnormal x.  The table is the
+// host libm's own (tools/powf_tables.py reads it out of libm.so.6); tests/libm_powf.py transliterates this function with exact fused multiply-adds
+// and tests/test_oracle.py holds it to the host's powf.  Zero, infinite and NaN arguments (and a negative x: no caller has one) go to ocml's powf,
+// which answers them as C99 Annex F prescribes.
+__device__ const uint64_t kPowfLog2Tab[16][2] = {  // glibc's __powf_log2_data.tab: {bits(1 / c_i), bits(log2 c_i)}
+    {0x3ff661ec79f8f3be, 0xbfdefec65b963019}, {0x3ff571ed4aaf883d, 0xbfdb0b6832d4fca4}, {0x3ff49539f0f010b0, 0xbfd7418b0a1fb77b},
+    {0x3ff3c995b0b80385, 0xbfd39de91a6dcf7b}, {0x3ff30d190c8864a5, 0xbfd01d9bf3f2b631}, {0x3ff25e227b0b8ea0, 0xbfc97c1d1b3b7af0},
+    {0x3ff1bb4a4a1a343f, 0xbfc2f9e393af3c9f}, {0x3ff12358f08ae5ba, 0xbfb960cbbf788d5c}, {0x3ff0953f419900a7, 0xbfaa6f9db6475fce},
+    {0x3ff0000000000000, 0x0000000000000000}, {0x3fee608cfd9a47ac, 0x3fb338ca9f24f53d}, {0x3feca4b31f026aa0, 0x3fc476a9543891ba},
+    {0x3feb2036576afce6, 0x3fce840b4ac4e4d2}, {0x3fe9c2d163a1aa2d, 0x3fd40645f0c6651c}, {0x3fe886e6037841ed, 0x3fd88e9c2c1b9ff8},
+    {0x3fe767dcf5534862, 0x3fdce0a44eb17bcc},
 };
 // (pow2f_libm's table, below: tab[i] = bits(2^(i/32)) - (i << 47))
 __device__ const uint64_t kExp2fTab[32] = {
@@ -1741,45 +1721,68 @@ __device__ const uint64_t kExp2fTab[32] = {
 typedef __attribute__((address_space(3))) const uint64_t LdsTab;
 struct GlobalTables {
     SRK_DEV uint64_t exp2f(uint32_t i) const { return kExp2fTab[i]; }
-    SRK_DEV uint64_t log2_inv_c(uint32_t i) const { return kLog2Tab[i][0]; }
-    SRK_DEV uint64_t log2_c(uint32_t i) const { return kLog2Tab[i][1]; }
+    SRK_DEV uint64_t log2_inv_c(uint32_t i) const { return kPowfLog2Tab[i][0]; }
+    SRK_DEV uint64_t log2_c(uint32_t i) const { return kPowfLog2Tab[i][1]; }
 };
 struct LdsTables {
     LdsTab* exp2f_tab;  // [32]
-    LdsTab* log2_tab;   // [32][2]
+    LdsTab* log2_tab;   // [16][2]
     SRK_DEV uint64_t exp2f(uint32_t i) const { return exp2f_tab[i]; }
     SRK_DEV uint64_t log2_inv_c(uint32_t i) const { return log2_tab[2u * i]; }
     SRK_DEV uint64_t log2_c(uint32_t i) const { return log2_tab[2u * i + 1u]; }
 };
 
+// (branch-free; `cold` is set where an argument is zero, infinite or a NaN — or x negative — and the value returned is not powf's)
 template <class Tab = GlobalTables>
-SRK_DEV double log2_pos_f32(float x, const Tab tab = Tab{})
+SRK_DEV float powf_libm_plain(float x, float y, bool& cold, const Tab tab = Tab{})
 {
-    const uint32_t bits = __float_as_uint(x);
-    const int e = (int)(bits >> 23) - 127;
-    const uint32_t i = (bits >> 18) & 31u;
-    const double m = (double)__uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
-    const double inv_c = __longlong_as_double((long long)tab.log2_inv_c(i)), log_c = __longlong_as_double((long long)tab.log2_c(i));
-    const double z = __builtin_fma(m, inv_c, -1.0);
-    const double z2 = z * z, z4 = z2 * z2;
-    const double p01 = __builtin_fma(-0.7213475204444817, z, 1.4426950408889634);
-    const double p23 = __builtin_fma(-0.36067376022224085, z, 0.4808983469629878);
-    const double p45 = __builtin_fma(-0.2404491734814939, z, 0.28853900817779266);
-    const double q0 = __builtin_fma(p23, z2, p01);
-    const double q1 = __builtin_fma(0.2060992915555662, z2, p45);
-    const double p = __builtin_fma(q1, z4, q0);
-    return __builtin_fma(z, p, (double)e + log_c);
+    uint32_t ix = __float_as_uint(x);
+    const uint32_t iy = __float_as_uint(y);
+    cold = cold || !(ix - 1u < 0x7f7fffffu) || !(2u * iy - 1u < 2u * 0x7f800000u - 1u);   // plain: 0 < x < inf, y finite and not zero
+    // a subnormal x: normalise (`ix = asuint(x * 0x1p23f) & 0x7fffffff; ix -= 23 << 23`)
+    const uint32_t in = (__float_as_uint(x * 0x1p23f) & 0x7fffffffu) - (23u << 23);
+    ix = ix < 0x00800000u ? in : ix;
+    // log2_inline
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> 19) & 15u;
+    const uint32_t top = tmp & 0xff800000u;
+    const int k = (int)top >> 23;   // arithmetic shift
+    const double invc = __longlong_as_double((long long)tab.log2_inv_c(i)), logc = __longlong_as_double((long long)tab.log2_c(i));
+    const double z = (double)__uint_as_float(ix - top);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    const double yy = __builtin_fma(r, 0x1.27616c9496e0bp-2, -0x1.71969a075c67ap-2);
+    const double p = __builtin_fma(r, 0x1.ec70a6ca7baddp-2, -0x1.7154748bef6c8p-1);
+    const double r4 = r2 * r2;
+    double q = __builtin_fma(r, 0x1.71547652ab82bp+0, y0);
+    q = __builtin_fma(r2, p, q);
+    const double logx = __builtin_fma(yy, r4, q);
+    const double ylogx = (double)y * logx;   // (cannot overflow: y is single precision)
+    // exp2_inline (sign_bias 0)
+    const double shift = 0x1.8p+52 / 32.0;
+    double kd = ylogx + shift;
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= shift;
+    const double re = ylogx - kd;
+    const uint64_t t = tab.exp2f((uint32_t)ki & 31u) + (ki << 47);
+    const double sc = __longlong_as_double((long long)t);
+    const double zz = __builtin_fma(re, 0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3);
+    const double re2 = re * re;
+    double v = __builtin_fma(re, 0x1.62e42ff0c52d6p-1, 1.0);
+    v = __builtin_fma(zz, re2, v);
+    float out = (float)(v * sc);              // subnormal results round here, as in the libm
+    out = ylogx <= -150.0 ? 0.0f : out;       // __math_uflowf
+    out = ylogx > 0x1.fffffffd1d571p+6 ? __builtin_inff() : out;   // __math_oflowf
+    return out;
 }
-
 template <class Tab = GlobalTables>
-SRK_DEV float powf_pos(float x, float b, bool exact, const Tab tab = Tab{})
+SRK_DEV float powf_pos(float x, float b, bool /* exact: every flavour but NONLIN_LOOSE is the libm's own since round 6 */, const Tab tab = Tab{})
 {
-    // (a subnormal x goes to ocml's powf below, like every other special case)
-    const double y = (double)b * (exact ? ::log2((double)x) : log2_pos_f32(x >= 0x1p-126f ? x : 1.0f, tab));
-    const bool fast = x >= 0x1p-126f && x < __builtin_inff() && __builtin_fabs(y) < 126.0;  // NaN x / b / y: false
-    float r = (float)exp2_fast(fast ? y : 0.0);
-    if (__builtin_amdgcn_ballot_w64(!fast)) {
-        if (!fast) r = ::powf(x, b);
+    bool cold = false;
+    float r = powf_libm_plain(x, b, cold, tab);
+    if (__builtin_amdgcn_ballot_w64(cold)) {
+        if (cold) r = ::powf(x, b);
     }
     return r;
 }

@@ -160,7 +160,9 @@ def test_cpu_soak_finds_on_the_gpu(seed, noise, env, oracle, monkeypatch):
     derived bound, here through the kernels themselves, at the soak's 200 voices x 6 000 samples and its draw (notes/r05.md R5.8: 251484 a
     literal ladder behind an f32 square; 277445 noise on an envelope's gate, the envelope on a cutoff: 9.98e-6 with every form taken; 235484 /
     227662 / 239367 noise on a contracted ladder's input: 7.0 - 7.7e-6; 226856 / 405576 hard-synced saws — raw jumps at audio rate — into
-    contracted ladders, the second from the NonLinear family).  Each is held to the CONTRACT and to its OWN bound as srack_render_info states
+    contracted ladders, the second from the NonLinear family — a waveshaper inside a loop of unbounded gain, which the emulation rendered with the
+    host's powf and the kernels, until round 6, with a power of their own an f32 ulp away now and then: 1.97 on the GPU; since the port of the libm's
+    powf, modules.hip.h powf_libm_plain, the same render).  Each is held to the CONTRACT and to its OWN bound as srack_render_info states
     it, plus three f32 ulps (the feed-forward roundings behind a form, which the bound does not count)."""
     for e in env:
         monkeypatch.setenv(e, "1")

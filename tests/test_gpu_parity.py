@@ -1161,8 +1161,8 @@ def test_p4_sample_nonlinear_vs_oracle(S, oracle, flags):
     assert p.planes() == (2, [0, 1])
     fr, mix = p.render(T, flags=flags)
     np.testing.assert_array_equal(bits(fr[1]), bits(ref[1]))   # the raw sample player: wave values, bit for bit
-    assert_close(fr[0], ref[0])                                # the waveshaper: powf within the f32 contract
-    assert (bits(fr[0]) == bits(ref[0])).mean() > 0.99         # ... and almost always the very same float
+    np.testing.assert_array_equal(bits(fr[0]), bits(ref[0]))   # the waveshaper: the host libm's powf, operation for operation (round 6: powf_libm_plain;
+                                                               # until then a correctly rounded power of the kernels' own, an f32 ulp off now and then)
     scale = np.abs(ref.astype(np.float64)).sum(axis=2)
     assert (np.abs(mix - ref_mix) <= 2e-5 * np.maximum(scale, 1.0)).all()
     assert np.abs(fr[1]).max() > 0.3 and len(np.unique(fr[1][:, 0])) > 100
@@ -1349,9 +1349,8 @@ def test_nonlinear_edge_cases_on_gpu(S, oracle, flags):
     np.testing.assert_array_equal(np.isnan(fr), np.isnan(ref))
     if flags & 1:
         np.testing.assert_array_equal(fr[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)])   # +-inf where libm overflows
-        g64, r64 = fr[fin].astype(np.float64), ref[fin].astype(np.float64)
-        assert (np.abs(g64 - r64) <= 1e-5 * np.maximum(np.abs(r64), 1e-30)).all()              # purely relative: powf spans 1e-38..1e38
-        assert (np.signbit(fr[fin]) == np.signbit(ref[fin])).all()
+        # powf spans 1e-38 .. 1e38 here, lands on subnormals and on zero: the libm's own bits everywhere (round 6)
+        np.testing.assert_array_equal(bits(fr[fin]), bits(ref[fin]))
         return
     if flags & 32:
         assert "kernel=render_specialized" in p.info() and "powf_pos_loose" not in p.info()

@@ -668,3 +668,37 @@ def test_exp2_libm_transliteration_is_the_hosts_pow():
                            rng.uniform(-700, 700, 3000), rng.uniform(-1, 1, 1000) * 2.0 ** rng.integers(-80, 0, 1000), [0.0, -0.0, 1.0, -1.0, 0.5, 1e-300]])
     differ = [float(e) for e in args if L.exp2_libm(float(e), tab) != math.pow(2.0, float(e))]
     assert not differ, differ[:5]
+
+
+# ---- a.powf(b) of NonLinearModule: the host libm's powf, operation for operation -------------------------------------------------------------
+def test_powf_libm_transliteration_is_the_hosts_powf():
+    """`powf_libm_plain` (modules.hip.h, round 6) ports glibc's powf — the x86-64 FMA build — so that a waveshaper's samples are the reference's
+    to the last bit, misroundings included (powf is a 0.82-ulp function).  Here: the same operations in Python with exact fused multiply-adds and the
+    DEVICE HEADER's tables, against the powf of the libm this host runs (the one the oracle calls): waveshaper-like arguments, the whole range of
+    x (subnormals among them) with exponents of either sign, results that overflow, underflow and land on subnormals."""
+    import ctypes
+    import ctypes.util
+    import platform
+    import struct
+    from tests import libm_powf as L
+    if platform.machine() != "x86_64" or platform.libc_ver()[0] != "glibc":
+        pytest.skip("the port follows glibc's x86-64 FMA build of powf")
+    if "fma" not in open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split():
+        pytest.skip("a host without FMA runs glibc's other build of powf")
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.powf.restype = ctypes.c_float
+    libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    log2_tab, exp2f_tab = L.header_tables()
+    assert log2_tab[9] == (0x3FF0000000000000, 0) and exp2f_tab[0] == 0x3FF0000000000000
+    rng = np.random.default_rng(11)
+    n = 6000
+    xs = np.concatenate([rng.uniform(0, 2, n), 10.0 ** rng.uniform(-38, 38, n), rng.uniform(0, 1e-39, n // 4), np.abs(rng.normal(size=n)), [1.0, 2.0, 0.5, 1e-45, 3.4e38]]).astype(np.float32)
+    ys = np.concatenate([rng.uniform(0.3, 3, n), rng.uniform(-4, 4, n), rng.uniform(-2, 2, n // 4), rng.choice([0.5, 2.0, 3.0, 0.75, 1.0, -1.0, 100.0, -100.0], n), [1.0, 0.5, 2.0, 1.0, 1.5]]).astype(np.float32)
+    differ = []
+    for x, y in zip(xs, ys):
+        if not (x > 0 and np.isfinite(x)) or y == 0:
+            continue
+        got, want = L.powf_libm(float(x), float(y), log2_tab, exp2f_tab), float(libm.powf(float(x), float(y)))
+        if struct.pack("<f", got) != struct.pack("<f", want):
+            differ.append((float(x).hex(), float(y), got, want))
+    assert not differ, differ[:5]
