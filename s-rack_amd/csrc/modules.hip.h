@@ -1776,13 +1776,15 @@ SRK_DEV float powf_libm_plain(float x, float y, bool& cold, const Tab tab = Tab{
     out = ylogx > 0x1.fffffffd1d571p+6 ? __builtin_inff() : out;   // __math_oflowf
     return out;
 }
+// (ocml's powf behind the cold branch, out of line: inlined, its few hundred instructions sat in every sample's straight-line code)
+__device__ __attribute__((noinline)) float powf_cold(float x, float b) { return ::powf(x, b); }
 template <class Tab = GlobalTables>
 SRK_DEV float powf_pos(float x, float b, bool /* exact: every flavour but NONLIN_LOOSE is the libm's own since round 6 */, const Tab tab = Tab{})
 {
     bool cold = false;
     float r = powf_libm_plain(x, b, cold, tab);
     if (__builtin_amdgcn_ballot_w64(cold)) {
-        if (cold) r = ::powf(x, b);
+        if (cold) r = powf_cold(x, b);
     }
     return r;
 }
@@ -1824,9 +1826,8 @@ SRK_DEV float nonlin_step(uint32_t flags, float in1, float in2, float constant, 
 template <class Tab = GlobalTables>
 SRK_DEV float pow2f_libm(float y, const Tab tab = Tab{})
 {
-    if (y != y) return y + 2.0f;                  // NaN
-    if (y >= 128.0f) return __builtin_inff();     // f64(y) > 0x1.fffffffd1d571p+6: overflow (covers +inf)
-    if (y <= -150.0f) return 0.0f;                // underflow (covers -inf)
+    // (branch-free since round 6: the three special answers are selected at the end — as early returns they were three exec-mask branches per
+    // sample of the sample player's position recurrence; the arithmetic in between has no traps, whatever it makes of a NaN or 1e30)
     const double xd = (double)y;
     const double shift = 0x1.8p+52 / 32.0;
     double kd = xd + shift;                       // round to a multiple of 1/32
@@ -1840,7 +1841,10 @@ SRK_DEV float pow2f_libm(float y, const Tab tab = Tab{})
     double p = 0x1.62e42ff0c52d6p-1 * r + 1.0;
     p = z * r2 + p;
     p = p * s;
-    return (float)p;                              // subnormal results round here, as in libm
+    float out = (float)p;                         // subnormal results round here, as in libm
+    out = y <= -150.0f ? 0.0f : out;              // underflow (covers -inf)
+    out = y >= 128.0f ? __builtin_inff() : out;   // f64(y) > 0x1.fffffffd1d571p+6: overflow (covers +inf)
+    return y != y ? y + 2.0f : out;               // NaN
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1901,7 +1905,11 @@ SRK_DEV uint32_t sample_advance(uint32_t flags, SmpRegs& s, float ratio, uint32_
         s.playing = false;
         idx = 0u;
     }
-    if (s.playing) s.pos += (flags & SMP_HAS_CV) ? ratio * pow2f_libm(cv, tab) : ratio * 1.0f;
+    // (the step is computed in every lane and selected: behind `if (playing)` it was an exec-mask branch around 2^cv in every sample of the
+    // position's recurrence — for a player that is playing nearly always)
+    const float step = (flags & SMP_HAS_CV) ? ratio * pow2f_libm(cv, tab) : ratio * 1.0f;
+    const float next = s.pos + step;
+    s.pos = s.playing ? next : s.pos;
     return idx;
 }
 
