@@ -41,7 +41,7 @@ bool jit_ctl_supported(const FlatPair& pair, std::string* why = nullptr);
 // The HIP source of the kernel for the pair's voice program with the given output mode (1 frames, 2 mix, 3 both, 4 neither);
 // with_ctl: the control program's units ride along as blocks [0, block0) of every launch (KernelArgs::ctl_slots).
 // waves: > 0 asks the compiler for a register budget that lets so many waves share a SIMD (amdgpu_waves_per_eu): see jit_get.
-int jit_source(const FlatPair& pair, int out_mode, bool with_ctl, std::string& src, int waves = 0);
+int jit_source(const FlatPair& pair, int out_mode, bool with_ctl, std::string& src, int waves = 0, int want_waves = 0);  // want_waves: waves per SIMD the render has for the kernel (what LDS it may spend)
 // Generate + compile for the current device's architecture (gfx950 when the process has no device); nothing is loaded.
 int jit_compile_only(const FlatPair& pair, int out_mode, bool with_ctl);
 // Generate, fetch the code object (memory -> disk -> hiprtc; jit.cpp "the kernel cache") and load it on the current device.

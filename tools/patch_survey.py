@@ -14,7 +14,8 @@ V = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 T = int(sys.argv[4]) if len(sys.argv) > 4 else 24000
 FLAGS = [int(x) for x in os.environ.get("SURVEY_FLAGS", "0").split(",")]   # e.g. SURVEY_FLAGS=0,4: with and without uniform hoisting
 rows = []
-for seed in range(lo, hi):
+SEEDS = [int(x) for x in os.environ["SURVEY_SEEDS"].split(",")] if os.environ.get("SURVEY_SEEDS") else range(lo, hi)   # (a list instead of the range: A/B runs)
+for seed in SEEDS:
     B, build, overrides = random_patch(seed)
     p = S.Patch(48000, B, 2)
     ids = build(p)
