@@ -1618,22 +1618,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         auto live = [&](uint32_t chunk, int j) { return kFast || chunk * (uint32_t)kXChunk + i0 + (uint32_t)j < a.T; };
         // the modulator's increments of a chunk, from what the ring holds: 440 * 2^(f64(cv) + f64(val)) / sr (oscillator.rs:43-48,132)
-        auto increments = [&](uint32_t chunk, uint32_t at, double (&d)[kXPer]) {
+        // (`redo`: the lanes whose plain forms could not decide — the reference's expression itself, the same value wherever they had.  The
+        // question "could some lane not decide" is asked ONCE per iteration, after its arithmetic, for increments and sines together: a branch
+        // in the middle fences the iteration's two halves off from each other — 13.7 against 12.7 ms per step without any question)
+        auto increments = [&](uint32_t chunk, uint32_t at, double (&d)[kXPer], bool& cold, bool redo) {
             float fed[kXPer];
 #pragma unroll
             for (int j = 0; j < kXPer; j++) fed[j] = ring_l[ring_at(at, j)];
-            bool cold = false;
             double e[kXPer];
 #pragma unroll
             for (int j = 0; j < kXPer; j++) {
                 e[j] = (double)(fed[j] * c_fb) + km.val;
-                const double pw = X.k440 * x_exp2_libm_plain(X, e[j], cold, libm);
-                d[j] = kFast ? div_rn_proved(pw, km.sr, inv_sr) : div_rn_plain(pw, km.sr, cold);
-            }
-            if (__builtin_amdgcn_ballot_w64(cold) != 0) {
-                if (cold) {
-#pragma unroll
-                    for (int j = 0; j < kXPer; j++) d[j] = osc_delta_exact_cold(e[j], km.sr);  // (the reference's expression itself: the same value wherever the plain form had decided)
+                if (redo) {
+                    d[j] = osc_delta_exact_cold(e[j], km.sr);
+                } else {
+                    const double pw = X.k440 * x_exp2_libm_plain(X, e[j], cold, libm);
+                    d[j] = kFast ? div_rn_proved(pw, km.sr, inv_sr) : div_rn_plain(pw, km.sr, cold);
                 }
             }
             if (!kFast) {
@@ -1743,13 +1743,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         double dM[kXPer];
         uint32_t at_k = (p0 + i0) % B;                     // ring position of this slice's first sample of chunk k ...
         uint32_t at_inc = at_k;                            // ... and of the chunk whose increments are computed next
-        increments(0u, at_inc, dM);
+        {
+            bool cold = false;
+            increments(0u, at_inc, dM, cold, false);
+            if (__builtin_amdgcn_ballot_w64(cold) != 0) increments(0u, at_inc, dM, cold, true);
+        }
         at_inc = ring_step(at_inc);
 #pragma unroll
         for (int j = 0; j < kXPer; j++) buf[(i0 + (uint32_t)j) * kBlkVoices + (uint32_t)g] = dM[j];
         __syncthreads();
         scan();
-        if (n_chunks > 1u) increments(1u, at_inc, dM);
+        if (n_chunks > 1u) {
+            bool cold = false;
+            increments(1u, at_inc, dM, cold, false);
+            if (__builtin_amdgcn_ballot_w64(cold) != 0) increments(1u, at_inc, dM, cold, true);
+        }
         at_inc = ring_step(at_inc);
         __syncthreads();
         double preC[kXPer] = {0.0, 0.0, 0.0, 0.0}, pairC = 0.0, mineC = 0.0;  // the carrier's local prefix / totals of the chunk whose frames are still to come
@@ -1770,18 +1778,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 emit(k - 1u, preC, base);
                 pos_c = __builtin_amdgcn_fract(pos_c + total);
             }
-            {   // sines of chunk k -> ring; the carrier's increments, their local prefix and slice totals
+            // sines of chunk k -> ring; the carrier's increments, their local prefix and slice totals; the modulator's increments of chunk k + 2
+            auto second_half = [&](bool& cold, bool redo) {
                 float sine[kXPer];
-                bool cold = false;
 #pragma unroll
-                for (int j = 0; j < kXPer; j++) sine[j] = x_sine_exact_plain<!kFast>(X, pM[j], cold);  // (pos * PI * 2).sin() as f32, oscillator.rs:133
-                if (__builtin_amdgcn_ballot_w64(cold) != 0) {
-                    if (cold) {
-#pragma unroll
-                        for (int j = 0; j < kXPer; j++) {
-                            double unused = 0.0;
-                            osc_exact_cold(0.0, 1.0, pM[j], false, unused, sine[j]);  // (the reference's expression itself: the same f32 wherever the plain form had decided)
-                        }
+                for (int j = 0; j < kXPer; j++) {
+                    if (redo) {
+                        double unused = 0.0;
+                        osc_exact_cold(0.0, 1.0, pM[j], false, unused, sine[j]);
+                    } else {
+                        sine[j] = x_sine_exact_plain<!kFast>(X, pM[j], cold);  // (pos * PI * 2).sin() as f32, oscillator.rs:133
                     }
                 }
                 double acc = 0.0;
@@ -1796,9 +1802,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 mineC = acc;
                 pairC = slice_totals((int)(k & 1u), acc);
-            }
+                if (k + 2u < n_chunks) increments(k + 2u, at_inc, dM, cold, redo);
+            };
+            bool cold = false;
+            second_half(cold, false);
+#ifndef SRK_X_NOCOLD
+            if (__builtin_amdgcn_ballot_w64(cold) != 0) second_half(cold, true);  // (3.4e-6 of the samples: this wave's part of the iteration again, every value the reference's own)
+#endif
             at_k = ring_step(at_k);
-            if (k + 2u < n_chunks) increments(k + 2u, at_inc, dM);
             at_inc = ring_step(at_inc);
             __syncthreads();
         }
@@ -1878,6 +1889,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // The modulator's arithmetic is osc_step's exact flavour operation for operation (x_exp2_libm_plain, div_rn_proved / div_rn_plain,
 // x_sine_exact_plain, v_fract / fmod1): bit-identical to it and to the CPU tick; the carrier's is render_fm_pair's default loop.
 // Reference: oscillator.rs:43-48,124-153, math.rs:152.
+// (a tile with an undecided sample, again through osc_step itself — out of line: inlined, its cold arms' calls sat in the kernel's hot
+// function, and their register conventions with them)
+__device__ __attribute__((noinline)) void fm_x_tile_again(double pos0, float fed0, double sr, double val, float gain, float* dst, double& pos_out, float& fed_out)
+{
+    using namespace dev;
+    OscRegs s;
+    s.pos = pos0;
+    s.sync_last = false;
+    OscConst k;
+    k.sr = sr;
+    k.val = val;
+    k.delta = 0.0;
+    k.inv_dt = 0.0f;
+    float fed = fed0, sq = 0.0f, sw = 0.0f;
+    for (int i = 0; i < kMixRows; i++) {
+        float sine = 0.0f;
+        osc_step(OSC_HAS_CV | OSC_CV_AUDIO_RATE | OSC_AA | OSC_OUT_SINE | OSC_EXACT, s, k, fed * gain, 0.0f, sine, sq, sw);
+        fed = sine;
+        dst[i * 64] = sine;
+    }
+    pos_out = s.pos;
+    fed_out = fed;
+}
+
 template <int kOut>
 __global__ __launch_bounds__(128) void render_fm_pair_x(KernelArgs a, ChainRoles r)
 {
@@ -1952,16 +1987,7 @@ __global__ __launch_bounds__(128) void render_fm_pair_x(KernelArgs a, ChainRoles
                         fed = sn;
                         dst[i * 64] = sn;
                     }
-                    if (__builtin_amdgcn_ballot_w64(cold) != 0) {
-                        s.pos = pos0;
-                        fed = fed0;
-                        for (int i = 0; i < kMixRows; i++) {
-                            float sine = 0.0f;
-                            osc_step(fo_mod, s, k, fed * gain, 0.0f, sine, sq, sw);
-                            fed = sine;
-                            dst[i * 64] = sine;
-                        }
-                    }
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(cold) != 0, 0)) fm_x_tile_again(pos0, fed0, k.sr, k.val, gain, dst, s.pos, fed);
                 } else {  // a ragged last tile, a modulator that is not proved: osc_step itself (the same values)
                     for (int i = 0; i < n; i++) {
                         float sine = 0.0f;
