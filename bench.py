@@ -76,7 +76,14 @@ FM_PAIR_F64_OPS = {"render_fm_pair": 48, "render_fm_pair_ring": 48,
                    # the time-parallel pair (buffer_size 256 ... 1024): 809 f64-rate instructions per 16 samples and lane in the copy config 4's draw
                    # takes (tools/disasm.sh ... render_fm_pair_block: 538 between the two barriers of a chunk, 271 after) — the same polynomials, two
                    # additions and a fract per phase instead of one and one, the slice scan, less the carrier sine's f64 fold
-                   "render_fm_pair_block": 50.6}
+                   "render_fm_pair_block": 50.6,
+                   # round 6, config 4 as default mode renders it (the modulator exact as a whole): the z^-1 pair on two waves per 64 voices — 336 f64-rate
+                   # instructions per 8 samples in the modulator wave's speculative tile (the libm's 2^e: 18, the correctly rounded quotient: 4, the
+                   # sine, its fold and the two-conversion decision: 18, the phase: 2), 176 in the carrier wave's loop for config 4's class ((2^(cv/4))^4) ...
+                   "render_fm_pair_x": 64,
+                   # ... and across time lanes at the app's block size: 62 per voice-sample in the chunk loop's fast copy (tools/disasm.sh) + the scan's
+                   # add and fract on a half-filled wave (4 lane-slots per voice-sample)
+                   "render_fm_pair_block_x": 66}
 F64_LANE_OPS_MEASURED = 33.3e12
 
 WORKLOADS = ("cfg3", "cfg3_poly", "cfg2", "cfg4", "cfg4_b1024", "p3", "p4")
@@ -403,7 +410,7 @@ def side_config(args, workload, flags=0):
                "frac_hbm": bytes_per_step / step_s / 1e9 / HBM_PEAK_GBS, "kernel": kname, "kernel_ms": kernel_ms, "launches_per_step": launches,
                "frac_hbm_kernel": (bytes_per_step / launches / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms > 0 else 0.0, "program": info}
         # (the ISA counts are those of the fast kernels' loops: KEEP_DEFAULT; the exact flavour runs the libm's pow and ocml's sin)
-        ops = FM_PAIR_F64_OPS.get(kname) if (flags & KEEP_DEFAULT) and (workload == "cfg4" or kname != "render_specialized") else None
+        ops = FM_PAIR_F64_OPS.get(kname) if (kname in ("render_fm_pair_x", "render_fm_pair_block_x") or ((flags & KEEP_DEFAULT) and (workload == "cfg4" or kname != "render_specialized"))) else None
         if ops:
             out.update({"f64_ops_per_voice_sample": ops, "frac_valu_f64": ops * V * T / step_s / F64_LANE_OPS_PEAK,
                         "frac_of_measured_f64_rate": ops * V * T / step_s / F64_LANE_OPS_MEASURED})
@@ -629,7 +636,7 @@ def run_rank(args, backend_cls=HipBackend):
                 "traffic": None,
             },
         }
-        if args.workload in ("cfg4", "cfg4_b1024") and (args.flags & KEEP_DEFAULT) and FM_PAIR_F64_OPS.get(kname) and not (kname == "render_specialized" and args.workload != "cfg4"):
+        if args.workload in ("cfg4", "cfg4_b1024") and ((args.flags & KEEP_DEFAULT) or kname in ("render_fm_pair_x", "render_fm_pair_block_x")) and FM_PAIR_F64_OPS.get(kname) and not (kname == "render_specialized" and args.workload != "cfg4"):
             ops = FM_PAIR_F64_OPS[kname]
             lane_ops = ops * V * T / step_s
             out["roofline"].update({
@@ -681,6 +688,7 @@ def run_rank(args, backend_cls=HipBackend):
                 if "frac_valu_f64" in c:
                     rf[w + "_frac_valu_f64"] = c["frac_valu_f64"]
                     rf[w + "_f64_ops_per_voice_sample"] = c["f64_ops_per_voice_sample"]
+                    rf[w + "_frac_of_measured_f64_rate"] = c["frac_of_measured_f64_rate"]
         if world == 1 and not args.no_cpu and args.workload not in ("p3", "p4") and be.name == "hip":
             out["cpu_baseline"] = cpu_baseline(be.S, args.workload)
     be.close()

@@ -47,7 +47,9 @@ except Exception as e:
 PY
         done; done
         cp /tmp/keep.so s-rack_amd/libsrack_hip.so ;;
-    prof) tag=$2; args=$3; shift 3; bash profiles/run_profile.sh $tag "$args" > $OUT/prof_$tag.log 2>&1; tail -25 $OUT/prof_$tag.log ;;
+    prof) tag=$2; args=$3; shift 3; bash profiles/run_profile.sh $tag "$args" > $OUT/prof_$tag.log 2>&1; tail -4 $OUT/prof_$tag.log
+          mkdir -p $OUT/profiles; cp profiles/${tag}_* $OUT/profiles/ 2>/dev/null; rm -rf gpurun_out/prof_$tag/*/  # (the condensed files travel back; the raw databases do not)
+          ;;
     *) echo "unknown pass $1"; shift ;;
   esac
 done
