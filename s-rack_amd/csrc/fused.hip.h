@@ -1673,12 +1673,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             pos_m = p;
         };
         // where a lane's slice starts (carrier): the phase at the chunk's first sample + the totals of the slices below it
+        // (returns the OTHER slice of this wave's pair: the odd slice starts behind the even one's total — taken as it is, not as pair - mine: a
+        // voice whose modulator has just overflowed has a NaN in ITS slice's total, and the samples before it must not inherit it)
         auto slice_totals = [&](int parity, double mine) {
-            const double pair = mine + __shfl_xor(mine, 32);
-            if (!odd) sums[(parity * 8 + w) * kBlkVoices + g] = pair;
-            return pair;
+            const double other = __shfl_xor(mine, 32);
+            if (!odd) sums[(parity * 8 + w) * kBlkVoices + g] = mine + other;
+            return other;
         };
-        auto slice_base = [&](int parity, double mine, double pair, double start, double& base, double& total) {
+        auto slice_base = [&](int parity, double mine, double other, double start, double& base, double& total) {
             // (the waves below this one: a wave-uniform count.  A product with a scalar 0 / 1 — one fma per wave where an addition behind a
             // select costs three instructions, two scalar-count loops more still (measured: 13.7 / 14.5 / 14.6 ms per step) — unless a total is
             // a NaN: a voice whose modulator has overflowed hands them on, and they must not reach the slices BEFORE them: then the selects)
@@ -1698,7 +1700,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     base = w2 < w ? base + v : base;
                 }
             }
-            if (odd) base += pair - mine;
+            (void)mine;
+            if (odd) base += other;
         };
         // frames and mix partial of a chunk whose carrier phases are known
         auto emit = [&](uint32_t chunk, const double (&pre)[kXPer], double base) {

@@ -364,6 +364,21 @@ def test_fm_pair_with_the_modulator_exact_across_time_lanes(S, oracle, B, T):
     assert np.abs(c[0][fin].astype(np.float64) - a[0][fin]).max() < 8e-7
 
 
+@pytest.mark.parametrize("seed", [78, 87] + list(range(0, 24)))
+def test_fm_x_soak_seeds(S, oracle, seed):
+    """tools/fm_x_soak.py's draw — random sample rates, ring lengths (any), voice counts, render lengths, a second call, per-voice gains / indices /
+    pitches / initial phases, now and then a voice whose 2^cv overflows or a carrier outside every bounded class — through round 6's FM kernels.
+    Seeds 78 and 87 are its finds: the odd slice of a wave's pair started behind `pair - mine`, and a voice whose modulator had just overflowed
+    (a NaN in its own slice's total) turned the two or three samples BEFORE the overflow into NaNs too."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fm_x_soak
+    k, nan_ok, err, state_bad, info = fm_x_soak.one(seed, S, oracle)
+    assert k in ("render_fm_pair_x", "render_fm_pair_block_x"), info
+    assert nan_ok and err <= 1e-5 and state_bad == 0, (nan_ok, err, state_bad, info)
+
+
 def _envelope_fm(g, S):
     """FM with an envelope on the index: gate LFO -> ADSR -> VCA.cv, modulator sine -> VCA.audio -> x index -> carrier pitch."""
     lfo, env, om, vca, idx, oc, out = (g.add_module(t) for t in (S.MOD_OSCILLATOR, S.MOD_ADSR, S.MOD_OSCILLATOR, S.MOD_VCA, S.MOD_MATH, S.MOD_OSCILLATOR, S.MOD_OUTPUT))
