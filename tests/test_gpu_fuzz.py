@@ -58,6 +58,40 @@ def test_random_patch_matches_oracle(seed, noise, oracle, monkeypatch):
         assert same.all(), f"seed {seed} flags {flags}: {1 - same.mean():.5f} of the samples differ; {p.info()}"
 
 
+@pytest.mark.parametrize("seed", list(range(2000, 2030)))
+def test_random_patch_with_waveshapers_matches_oracle(seed, oracle, monkeypatch):
+    """The NonLinear family (FUZZ_NONLIN: half the MathModules become sign-preserving waveshapers, exponents 0.3 ... 3 per voice) in the exact modes, bit
+    for bit — possible since round 6, when `a.powf(b)` became the host libm's powf operation for operation (modules.hip.h, powf_libm_plain); until then
+    the fuzzer's exact-mode family had no waveshaper because the power was an f32 ulp off now and then.  (tools/fuzz_soak.py with FUZZ_NONLIN=1: 2 100
+    renders past these seeds, 300 of them through the specialised kernels, 0 not bit-identical.)"""
+    monkeypatch.setenv("FUZZ_NONLIN", "1")
+    S = srack_pkg.load()
+    if seed % 2:
+        monkeypatch.setenv("SRACK_WANT_WAVES", "1")
+    B, build, overrides = random_patch(seed, False)
+    V, T = (67, 1300) if B < 1024 else (131, 2300)
+    o = oracle.OraclePatch(48000, B, 2)
+    ids = build(o)
+    ov = [(ids[m], f, fn(V)) for m, f, fn in overrides]
+    ref, _ = o.render_batch(V, T, ov, threads=8)
+    for flags in (1, 3, 5) + ((35,) if seed % 3 == 0 else ()):
+        p = S.Patch(48000, B, 2)
+        build(p)
+        p.configure_voices(V)
+        for m, f, vals in ov:
+            p.set_voice_field(m, f, vals)
+        assert p.plan() == o.plan()
+        if flags & 32:
+            try:
+                p.kernel_source(flags)
+            except S.SrackError as e:
+                assert e.code == S.ERR_UNSUPPORTED
+                continue
+        fr = p.render_channels(T, flags)
+        same = (fr.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(fr) & np.isnan(ref))
+        assert same.all(), f"seed {seed} flags {flags}: {1 - same.mean():.5f} of the samples differ; {p.info()}"
+
+
 # ---- the DEFAULT (approximating) render modes — what bench.py times — over the same patches ----------------------------------------
 # Contract: |gpu - ref| <= 1e-5 * max(|ref|, 1) per sample, NaN / inf at the oracle's positions (BASELINE.json north_star; SURVEY 7 gives
 # the denominator).  Default arithmetic is 1e-7-accurate, not bit-identical: the f32 PolyBLEP, the fma-contracted ladder, the polynomial
