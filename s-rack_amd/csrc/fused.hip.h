@@ -1648,6 +1648,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         // the scan: chunk's increments in `buf` -> its phases, in place; lanes 0 .. 31 of wave 0, one voice each
         auto scan = [&]() {
+#ifdef SRK_X_NOSCAN
+            return;  // (timing experiment only)
+#endif
             if (tid >= kBlkVoices) return;
             double p = pos_m;
             double* const col = buf + g;

@@ -34,6 +34,40 @@ def assert_close(gpu, ref, tol=TOL):
     return err.max()
 
 
+def read_plane(S, d_ptr, T, V, pick, rows=512, workers=6):
+    """One plane of frames [T][V] on the device, read back a slice of rows at a time: the sampled voices `pick`, and per row the f64 sum and
+    the f64 sum of magnitudes over ALL voices (what the mix is held against).  The copies on this thread, the sums on a few others (numpy
+    lets go of the interpreter lock while it sums): 50 GB take seconds."""
+    import ctypes as C
+    import queue
+    from concurrent.futures import ThreadPoolExecutor
+    got = np.empty((T, len(pick)), dtype=np.float32)
+    own, scale = np.empty(T), np.empty(T)
+    free = queue.Queue()
+    for _ in range(workers + 1):
+        free.put((np.empty((rows, V), dtype=np.float32), np.empty((rows, V), dtype=np.float32)))
+
+    def sums(pair, t0, n):
+        buf, tmp = pair
+        got[t0:t0 + n] = buf[:n, pick]
+        own[t0:t0 + n] = buf[:n].sum(axis=1, dtype=np.float64)
+        np.abs(buf[:n], out=tmp[:n])
+        scale[t0:t0 + n] = tmp[:n].sum(axis=1, dtype=np.float64)
+        free.put(pair)
+
+    with ThreadPoolExecutor(workers) as pool:
+        jobs = []
+        for t0 in range(0, T, rows):
+            n = min(rows, T - t0)
+            pair = free.get()
+            assert S.lib.srack_device_to_host(pair[0].ctypes.data_as(C.c_void_p), C.c_void_p(d_ptr + t0 * V * 4), n * V * 4, None) == 0
+            assert S.lib.srack_device_sync(None) == 0
+            jobs.append(pool.submit(sums, pair, t0, n))
+        for j in jobs:
+            j.result()
+    return got, own, scale
+
+
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
@@ -731,17 +765,7 @@ def test_cfg3_exactly_as_benchmarked(S, oracle):
         assert S.lib.srack_device_sync(None) == 0
         assert "kernel=render_voice_chain_track" in p.info()
         pick = np.unique(np.concatenate([np.arange(0, V, 4099), [0, 63, 64, V - 65, V - 64, V - 1]]))
-        got = np.empty((T, len(pick)), dtype=np.float32)
-        own, scale = np.empty(T), np.empty(T)
-        rows = 256
-        buf = np.empty((rows, V), dtype=np.float32)
-        for t0 in range(0, T, rows):
-            n = min(rows, T - t0)
-            assert S.lib.srack_device_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + t0 * V * 4), n * V * 4, None) == 0
-            assert S.lib.srack_device_sync(None) == 0
-            got[t0:t0 + n] = buf[:n, pick]
-            own[t0:t0 + n] = buf[:n].sum(axis=1, dtype=np.float64)
-            scale[t0:t0 + n] = np.abs(buf[:n]).sum(axis=1, dtype=np.float64)
+        got, own, scale = read_plane(S, d_fr.value, T, V, pick)
         mix = np.empty((2, T), dtype=np.float32)
         assert S.lib.srack_device_to_host(mix.ctypes.data_as(C.c_void_p), d_mx, mix.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
     finally:
@@ -775,17 +799,7 @@ def test_cfg3_poly_exactly_as_benchmarked(S, oracle):
         assert S.lib.srack_device_sync(None) == 0
         assert "kernel=render_specialized" in p.info() and "ctl[" not in p.info(), p.info()   # nothing hoisted: no control program
         pick = np.unique(np.concatenate([np.arange(0, V, 2731), [0, 63, 64, V - 65, V - 64, V - 1]]))
-        got = np.empty((T, len(pick)), dtype=np.float32)
-        own, scale = np.empty(T), np.empty(T)
-        rows = 256
-        buf = np.empty((rows, V), dtype=np.float32)
-        for t0 in range(0, T, rows):
-            n = min(rows, T - t0)
-            assert S.lib.srack_device_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + t0 * V * 4), n * V * 4, None) == 0
-            assert S.lib.srack_device_sync(None) == 0
-            got[t0:t0 + n] = buf[:n, pick]
-            own[t0:t0 + n] = buf[:n].sum(axis=1, dtype=np.float64)
-            scale[t0:t0 + n] = np.abs(buf[:n]).sum(axis=1, dtype=np.float64)
+        got, own, scale = read_plane(S, d_fr.value, T, V, pick)
         mix = np.empty((2, T), dtype=np.float32)
         assert S.lib.srack_device_to_host(mix.ctypes.data_as(C.c_void_p), d_mx, mix.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
     finally:
@@ -866,17 +880,7 @@ def test_cfg4_exactly_as_benchmarked(S, oracle, B, flags, kernel):
         assert S.lib.srack_device_sync(None) == 0
         assert "kernel=" + kernel in p.info() and ("approx[kept default" if flags else "; exact osc 0]") in p.info(), p.info()
         pick = np.unique(np.concatenate([np.arange(0, V, 2113), [0, 63, 64, V - 65, V - 64, V - 1]]))
-        got = np.empty((T, len(pick)), dtype=np.float32)
-        own, scale = np.empty(T), np.empty(T)
-        rows = 1024
-        buf = np.empty((rows, V), dtype=np.float32)
-        for t0 in range(0, T, rows):
-            n = min(rows, T - t0)
-            assert S.lib.srack_device_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + t0 * V * 4), n * V * 4, None) == 0
-            assert S.lib.srack_device_sync(None) == 0
-            got[t0:t0 + n] = buf[:n, pick]
-            own[t0:t0 + n] = buf[:n].sum(axis=1, dtype=np.float64)
-            scale[t0:t0 + n] = np.abs(buf[:n]).sum(axis=1, dtype=np.float64)
+        got, own, scale = read_plane(S, d_fr.value, T, V, pick)
         mix = np.empty((2, T), dtype=np.float32)
         assert S.lib.srack_device_to_host(mix.ctypes.data_as(C.c_void_p), d_mx, mix.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
     finally:
@@ -1041,16 +1045,8 @@ def test_p3_exactly_as_benchmarked(S, oracle):
         assert "kernel=render_specialized" in p.info() and p.info().count("ctl[") == 5
         pick = np.unique(np.concatenate([np.arange(0, V, 8209), [0, 63, 64, V - 65, V - 64, V - 1]]))
         got = np.empty((2, T, len(pick)), dtype=np.float32)
-        own, scale = np.empty(T), np.empty(T)
-        rows = 1024
-        buf = np.empty((rows, V), dtype=np.float32)
-        for t0 in range(0, T, rows):   # plane 0 in full (50 GB over PCIe), plane 1 (every voice the same gate) at the sampled voices
-            n = min(rows, T - t0)
-            assert S.lib.srack_device_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + t0 * V * 4), n * V * 4, None) == 0
-            assert S.lib.srack_device_sync(None) == 0
-            got[0, t0:t0 + n] = buf[:n, pick]
-            own[t0:t0 + n] = buf[:n].sum(axis=1, dtype=np.float64)
-            scale[t0:t0 + n] = np.abs(buf[:n]).sum(axis=1, dtype=np.float64)
+        # plane 0 in full (50 GB over PCIe), plane 1 (every voice the same gate) at the sampled voices
+        got[0], own, scale = read_plane(S, d_fr.value, T, V, pick)
         row = np.empty(V, dtype=np.float32)
         for t in range(0, T, 997):   # plane 1: whole rows at a stride (every voice must carry the same gate)
             assert S.lib.srack_device_to_host(row.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + ((T + t) * V) * 4), V * 4, None) == 0
@@ -1224,16 +1220,8 @@ def test_p4_exactly_as_benchmarked(S, oracle):
         pick = np.unique(np.concatenate([np.arange(0, V, 4099), [0, 63, 64, V - 65, V - 64, V - 1]]))
         got = np.empty((2, T, len(pick)), dtype=np.float32)
         own, scale = np.empty((2, T)), np.empty((2, T))
-        rows = 1024
-        buf = np.empty((rows, V), dtype=np.float32)
         for plane in range(2):
-            for t0 in range(0, T, rows):
-                n = min(rows, T - t0)
-                assert S.lib.srack_device_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + (plane * T + t0) * V * 4), n * V * 4, None) == 0
-                assert S.lib.srack_device_sync(None) == 0
-                got[plane, t0:t0 + n] = buf[:n, pick]
-                own[plane, t0:t0 + n] = buf[:n].sum(axis=1, dtype=np.float64)
-                scale[plane, t0:t0 + n] = np.abs(buf[:n]).sum(axis=1, dtype=np.float64)
+            got[plane], own[plane], scale[plane] = read_plane(S, d_fr.value + plane * T * V * 4, T, V, pick)
         mix = np.empty((2, T), dtype=np.float32)
         assert S.lib.srack_device_to_host(mix.ctypes.data_as(C.c_void_p), d_mx, mix.nbytes, None) == 0 and S.lib.srack_device_sync(None) == 0
     finally:
