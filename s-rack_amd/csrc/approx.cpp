@@ -17,8 +17,9 @@
 // square, noise on the CV) breaks that: 5e-5 and worse — such a filter has no contracted form.  Gains: the L1 norms are computed here, per
 // filter, from its coefficients (resonance 0.5: 1.1 ... 3.2; 0.89: up to 47 at cutoff 0.2; from ~0.9 the linear ladder does not decay at
 // mid cutoffs: unbounded); the sensitivity to the cutoff is measured at up to 2.7 / cutoff times the port's L1 norm (same tool: 3.0 here).
-// What is NOT bounded here: the default forms' own last-bit differences from the reference's libm (polynomial 2^cv at 3e-16, 1e-12 inside
-// the generator's bounded-CV classes; the f64 sine at one rounding) — zero-mean, measured over minutes instead (profiles/r05_horizon.json);
+// What is NOT bounded here: the default forms' own last-bit differences from the reference's libm (polynomial 2^cv at 3e-16, 2e-14 inside
+// the proved bounded-CV classes — 1e-10 cycles of phase per minute; the degree-8 series they had through round 5 left 1.2e-8 and showed on the
+// minute's curve —; the f64 sine at one rounding), measured over minutes instead (profiles/r06_horizon.json);
 // they only decide anything where a gain is unbounded: there the oscillator takes the reference's own forms.
 #include "approx.hpp"
 

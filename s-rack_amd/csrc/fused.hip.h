@@ -1099,17 +1099,21 @@ SRK_DEV size_t fm_block_lds_bytes(uint32_t B) { return sizeof(float) * B * kBlkV
 // compiler rematerialised every coefficient at every use (s_mov + v_mov: a fifth of the chunk's instructions).  Loaded once per launch and
 // made opaque, they stay where they are; the operations are exp2_fast's and sine_fast's own (modules.hip.h), bit for bit.
 struct BlkConsts {
-    double e[9];  // 2^f, degree 8
-    double q[7];  // sin(2 pi x) / x in x^2, degree 6
+    double e[10];  // 2^f: degree 8 (e[9] unused) or, loaded with kSeries9, degree 9 (exp2_fast9's coefficients)
+    double q[7];   // sin(2 pi x) / x in x^2, degree 6
 };
+template <bool kSeries9 = false>
 SRK_DEV void blk_consts_load(BlkConsts& K)
 {
-    const double e[9] = {1.0000000000000004, 0.6931471805459332, 0.24022650695814518, 0.055504109412108156, 0.009618129159053034,
-                         0.0013333450563173552, 0.00015403456082633648, 1.5310080611926545e-05, 1.3255179556479267e-06};
+    const double e8[10] = {1.0000000000000004, 0.6931471805459332, 0.24022650695814518, 0.055504109412108156, 0.009618129159053034,
+                           0.0013333450563173552, 0.00015403456082633648, 1.5310080611926545e-05, 1.3255179556479267e-06, 0.0};
+    const double e9[10] = {0x1.000000000003dp+0, 0x1.62e42fefa39f7p-1, 0x1.ebfbdff8149f2p-3, 0x1.c6b08d7044119p-5, 0x1.3b2ab72b175eep-7,
+                           0x1.5d87fe908f88ap-10, 0x1.43088e257f341p-13, 0x1.ffcb76789860fp-17, 0x1.63ef969a64d3cp-20, 0x1.b6571de2f2351p-24};
     const double q[7] = {6.283185307179272, -41.34170223990684, 81.60524914955879, -76.70584757807868, 42.05813586028645, -15.081496425342264, 3.6659216216293173};
+    K.e[9] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-        K.e[i] = e[i];
+    for (int i = 0; i < (kSeries9 ? 10 : 9); i++) {
+        K.e[i] = kSeries9 ? e9[i] : e8[i];
         asm volatile("" : "+v"(K.e[i]));
     }
 #pragma unroll
@@ -1132,6 +1136,24 @@ SRK_DEV double blk_exp2(const BlkConsts& K, double x)  // == dev::exp2_fast<kRed
     const double b0 = __builtin_fma(a23, f2, a01);
     const double b1 = __builtin_fma(a67, f2, a45);
     const double b2 = __builtin_fma(K.e[8], f4, b1);
+    const double p = __builtin_fma(b2, f4, b0);
+    return kReduce ? __builtin_ldexp(p, (int)n) : p;
+}
+template <bool kReduce>
+SRK_DEV double blk_exp2_9(const BlkConsts& K, double x)  // == dev::exp2_fast9<kReduce>(x); K loaded with kSeries9
+{
+    const double n = kReduce ? __builtin_rint(x) : 0.0;
+    const double f = kReduce ? x - n : x;
+    const double f2 = f * f;
+    const double a01 = __builtin_fma(K.e[1], f, K.e[0]);
+    const double a23 = __builtin_fma(K.e[3], f, K.e[2]);
+    const double a45 = __builtin_fma(K.e[5], f, K.e[4]);
+    const double a67 = __builtin_fma(K.e[7], f, K.e[6]);
+    const double a89 = __builtin_fma(K.e[9], f, K.e[8]);
+    const double f4 = f2 * f2;
+    const double b0 = __builtin_fma(a23, f2, a01);
+    const double b1 = __builtin_fma(a67, f2, a45);
+    const double b2 = __builtin_fma(a89, f4, b1);
     const double p = __builtin_fma(b2, f4, b0);
     return kReduce ? __builtin_ldexp(p, (int)n) : p;
 }
@@ -1170,12 +1192,15 @@ SRK_DEV double fm_increment(const BlkConsts& K, const dev::OscConst& c, float cv
 {
     static_assert((kFlags & OSC_VAL_FOLDED) != 0, "the time-parallel pair runs proved loops only");
     double p;
+    constexpr bool d9 = (kFlags & OSC_CV_SERIES9) != 0;  // (the degree-9 series: K loaded with kSeries9)
     if (kFlags & OSC_CV_QUAD) {
-        p = blk_exp2<false>(K, (double)(cv * 0.25f));
+        p = d9 ? blk_exp2_9<false>(K, (double)(cv * 0.25f)) : blk_exp2<false>(K, (double)(cv * 0.25f));
         p = p * p;
         p = p * p;
+    } else if (kFlags & OSC_CV_SMALL) {
+        p = d9 ? blk_exp2_9<false>(K, (double)cv) : blk_exp2<false>(K, (double)cv);
     } else {
-        p = (kFlags & OSC_CV_SMALL) ? blk_exp2<false>(K, (double)cv) : blk_exp2<true>(K, (double)cv);
+        p = d9 ? blk_exp2_9<true>(K, (double)cv) : blk_exp2<true>(K, (double)cv);
     }
     return c.scale * p;
 }
@@ -1563,7 +1588,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     kc.scale = (440.0 / kc.sr) * exp2(kc.val);
     const float c_fb = parv(ofb, MATH_P_CONST), c_ix = parv(oix, MATH_P_CONST);
     BlkConsts K;
-    blk_consts_load(K);
+    blk_consts_load<true>(K);  // (the carrier's 2^cv at degree 9: OSC_CV_SERIES9)
     XConsts X;
     x_consts_load(X);
     const LibmTabLds libm{tab};
@@ -1833,7 +1858,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         using std::integral_constant;
         using std::true_type;
         using std::false_type;
-        constexpr uint32_t P = OSC_PHASE_TAME | OSC_VAL_FOLDED;
+        constexpr uint32_t P = OSC_PHASE_TAME | OSC_VAL_FOLDED | OSC_CV_SERIES9;
         // (the fast copy for the class config 4's draw takes — index 0.5 ... 1.5: (2^(cv/4))^4 —; the general one for every class)
         if (car_class == 2)
             run(integral_constant<uint32_t, fo_carrier | P | OSC_CV_SMALL>{}, false_type{});
@@ -2036,7 +2061,7 @@ __global__ __launch_bounds__(128) void render_fm_pair_x(KernelArgs a, ChainRoles
                         }
                 }
             };
-            constexpr uint32_t P = OSC_PHASE_TAME | OSC_VAL_FOLDED;
+            constexpr uint32_t P = OSC_PHASE_TAME | OSC_VAL_FOLDED | OSC_CV_SERIES9;
             if (proved && car_class == 2)
                 tile(integral_constant<uint32_t, fo_carrier | P | OSC_CV_SMALL>{});
             else if (proved && car_class == 1)

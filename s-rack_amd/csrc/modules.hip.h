@@ -151,6 +151,31 @@ SRK_DEV double exp2_fast10(double x)
     return kReduce ? __builtin_ldexp(p, (int)n) : p;
 }
 
+// Between the two, degree 9 (tools/exp2_coeffs.py 9: 1.9e-14; 9 fma + 2 mul, depth 4 like degree 8) — for the PROVED classes (OSC_CV_SERIES9:
+// render_fm_pair_x / render_fm_pair_block_x's carriers, the specialised kernels' bounded-CV oscillators).  Their CVs are sines through gains
+// and do sweep, but a sine does not average a smooth error away: the degree-8 error, weighted by 2^cv, leaves 1.3e-13 relative — 1.2e-8 cycles
+// of phase per minute at config 4's carrier, and the time-parallel kernel's error crept from 2.4e-7 to 3.6e-7 over a minute
+// (profiles/r06_horizon.json; the same sum on the CPU: -1.2e-8 / +1.2e-8 / -1.0e-8 cycles for index 0.5 / 1 / 1.5).  Degree 9 leaves 1e-10
+// cycles per minute for one instruction more (degree 10: 3e-12 for three: config 4 at buffer_size 1024 13.75 -> 14.35 ms, measured).
+template <bool kReduce = true>
+SRK_DEV double exp2_fast9(double x)
+{
+    const double n = kReduce ? __builtin_rint(x) : 0.0;
+    const double f = kReduce ? x - n : x;
+    const double f2 = f * f;
+    const double a01 = __builtin_fma(0x1.62e42fefa39f7p-1, f, 0x1.000000000003dp+0);
+    const double a23 = __builtin_fma(0x1.c6b08d7044119p-5, f, 0x1.ebfbdff8149f2p-3);
+    const double a45 = __builtin_fma(0x1.5d87fe908f88ap-10, f, 0x1.3b2ab72b175eep-7);
+    const double a67 = __builtin_fma(0x1.ffcb76789860fp-17, f, 0x1.43088e257f341p-13);
+    const double a89 = __builtin_fma(0x1.b6571de2f2351p-24, f, 0x1.63ef969a64d3cp-20);
+    const double f4 = f2 * f2;
+    const double b0 = __builtin_fma(a23, f2, a01);
+    const double b1 = __builtin_fma(a67, f2, a45);
+    const double b2 = __builtin_fma(a89, f4, b1);
+    const double p = __builtin_fma(b2, f4, b0);
+    return kReduce ? __builtin_ldexp(p, (int)n) : p;
+}
+
 // 2^e, correctly rounded (exact render mode).  The reference evaluates `2.0_f64.powf(e)` with the host's libm, whose pow is
 // within 0.52 ulp of the true value, i.e. the correctly rounded double except for a fraction of a percent of the arguments.
 // ocml's pow / exp2 are ~1 ulp functions: 19 % of their results differ from the host's in the last bit (tools/powcheck.hip),
@@ -671,12 +696,15 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
         if ((flags & OSC_CV_AUDIO_RATE) || __builtin_amdgcn_ballot_w64(cv != s.seen_cv) != 0) {
             if (!(flags & OSC_EXACT) && (flags & OSC_VAL_FOLDED)) {  // (a kernel that proved a bound on |cv|: see the flags)
                 double p;
+                const bool d9 = (flags & OSC_CV_SERIES9) != 0;
                 if (flags & OSC_CV_QUAD) {
-                    p = exp2_fast<false>((double)(cv * 0.25f));
+                    p = d9 ? exp2_fast9<false>((double)(cv * 0.25f)) : exp2_fast<false>((double)(cv * 0.25f));
                     p = p * p;
                     p = p * p;
+                } else if (flags & OSC_CV_SMALL) {
+                    p = d9 ? exp2_fast9<false>((double)cv) : exp2_fast<false>((double)cv);
                 } else {
-                    p = (flags & OSC_CV_SMALL) ? exp2_fast<false>((double)cv) : exp2_fast<true>((double)cv);
+                    p = d9 ? exp2_fast9<true>((double)cv) : exp2_fast<true>((double)cv);
                 }
                 s.seen_delta = c.scale * p;
             } else {
@@ -759,7 +787,7 @@ struct UC {
 };
 constexpr uint32_t fm_class_flags(uint32_t cls)
 {
-    return cls == 0u ? 0u : (OSC_PHASE_TAME | OSC_VAL_FOLDED | (cls == 3u ? OSC_CV_SMALL : cls == 2u ? OSC_CV_QUAD : 0u));
+    return cls == 0u ? 0u : (OSC_PHASE_TAME | OSC_VAL_FOLDED | OSC_CV_SERIES9 | (cls == 3u ? OSC_CV_SMALL : cls == 2u ? OSC_CV_QUAD : 0u));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -71,6 +71,10 @@ enum : uint32_t {
                                   // 2^val 2^cv: one rounding more than the sum's, 1e-16 against the polynomial's 1e-12), so the bound is on |cv| alone
     OSC_CV_QUAD = 1u << 17,       // with OSC_VAL_FOLDED, |cv| <= 2: 2^cv = (2^(cv / 4))^4 — cv / 4 is exact in f32 and needs no range reduction; two
                                   // squarings instead of v_rndne, subtract, v_cvt_i32 and v_ldexp (the relative error is four times the polynomial's)
+    OSC_CV_SERIES9 = 1u << 18,    // with OSC_VAL_FOLDED: the polynomial 2^f is the degree-9 interpolant (1.9e-14; exp2_fast9) instead of the degree-8 one (1.1e-12):
+                                  // the degree-8 error is a smooth function of the CV, and a sine through a gain does not average it away — 1.3e-13 relative
+                                  // stays, 1.2e-8 cycles of phase per minute at config 4's carrier (profiles/r06_horizon.json).  Every proved class carries it
+                                  // except inside the fast FM kernels a host asks for by name (SRACK_RENDER_KEEP_DEFAULT), whose modulators drift by more
     // OP_VCF
     VCF_HAS_AUDIO = 1u << 0,
     VCF_HAS_CV = 1u << 1,

@@ -759,6 +759,40 @@ def test_exp2_fast10_coefficients_in_the_header():
     assert worst < 6e-16, float(worst)
 
 
+def test_exp2_fast9_coefficients_in_the_header():
+    """The degree-9 form the proved classes take (exp2_fast9, OSC_CV_SERIES9), the same way: 2e-14 over |f| <= 1/2 — and what it is there for:
+    the error of 2^cv = (2^(cv / 4))^4 summed over a minute of a sine through config 4's index, weighted by the increment — the phase the
+    carrier drifts by — is below 5e-10 cycles (degree 8: 1.2e-8; profiles/r06_horizon.json saw that one as 1.2e-7 on the output)."""
+    import re
+    mp = pytest.importorskip("mpmath")
+    text = open(os.path.join(ROOT, "s-rack_amd", "csrc", "modules.hip.h")).read()
+    body = text[text.index("SRK_DEV double exp2_fast9(double x)"):]
+    body = body[:body.index("return kReduce")]
+    hx = [float.fromhex(h) for h in re.findall(r"0x1\.[0-9a-f]+p[+-]\d+", body)]
+    assert len(hx) == 10   # c1, c0, c3, c2, c5, c4, c7, c6, c9, c8 in the order the fmas name them
+    c1, c0, c3, c2, c5, c4, c7, c6, c9, c8 = hx
+
+    def series(f):
+        f2 = f * f
+        a01, a23, a45, a67, a89 = c1 * f + c0, c3 * f + c2, c5 * f + c4, c7 * f + c6, c9 * f + c8
+        f4 = f2 * f2
+        b0, b1 = a23 * f2 + a01, a67 * f2 + a45
+        return (a89 * f4 + b1) * f4 + b0
+
+    f = np.linspace(-0.5, 0.5, 4001)
+    mp.mp.dps = 40
+    worst = max(abs(mp.mpf(float(pi)) / mp.power(2, mp.mpf(float(fi))) - 1) for pi, fi in zip(series(f), f))
+    assert worst < 2e-14, float(worst)
+    t = np.arange(2_880_000)
+    for index in (0.5, 1.0, 1.5):
+        cv = np.sin(2 * np.pi * 0.0123 * t + 0.3).astype(np.float32) * np.float32(index)
+        p = series((cv * np.float32(0.25)).astype(np.float64))
+        p = p * p
+        p = p * p
+        drift = float(((440.0 / 48000.0) * (p.astype(np.longdouble) - np.exp2(cv.astype(np.longdouble)))).sum())
+        assert abs(drift) < 5e-10, (index, drift)
+
+
 def test_cycle_rules_of_the_flattener(S):
     """approx.cpp, the cycles: an Add <-> Subtract pair is an integrator — neither its gain nor its VALUES have a bound: the exact flavour; the
     same pair with a ladder in it (whose lowpass is clamped: bounded values, unbounded gain): the saw that feeds it gets the exact PolyBLEP (its

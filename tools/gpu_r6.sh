@@ -32,7 +32,8 @@ while [ $# -gt 0 ]; do
     tests) shift; ( time timeout 1500 python -m pytest tests -m gpu -q -x ${1:-} ) > $OUT/pytest.log 2>&1; grep -E "passed|failed|error|^real" $OUT/pytest.log | tail -4; shift ;;
     line) shift; ( time python bench.py --steps 20 --warmup 5 ) > $OUT/default_line.json 2> $OUT/default_line.err; grep -E "^real" $OUT/default_line.err; digest $OUT/default_line.json; cp bench_detail.json $OUT/default_detail.json 2>/dev/null ;;
     bench) name=$2; args=$3; shift 3; timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu --no-side-configs $args > $OUT/$name.json 2> $OUT/$name.err; echo "$name rc=$?"; digest $OUT/$name.json ;;
-    ab) args=$2; shift 2; libs="$@"; set --
+    ab) args=$2; shift 2; libs=""
+        while [ $# -gt 0 ] && [[ "$1" == *.so ]]; do libs="$libs $1"; shift; done
         cp s-rack_amd/libsrack_hip.so /tmp/keep.so
         for round in 1 2 3; do for lib in $libs; do
           cp $lib s-rack_amd/libsrack_hip.so

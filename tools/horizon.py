@@ -67,6 +67,7 @@ def main():
             print(f"{name:11s} flags {flags:2d} {row['kernel'][:40]:40s} worst {row['worst']:.2e}  at 0 / 25 / 50 / 75 / 100 % of {seconds} s: "
                   + " ".join(f"{x:.2e}" for x in q) + f"  ({row['wall_s']:.0f} s)", flush=True)
     if out_path:
+        os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
         with open(out_path, "w") as f:
             json.dump(dict(what="max |gpu - oracle| / max(|oracle|, 1) per second of a render carried across one-second calls (tools/horizon.py)",
                            sample_rate=SR, rows=rows), f, indent=1)
