@@ -79,11 +79,12 @@ FM_PAIR_F64_OPS = {"render_fm_pair": 48, "render_fm_pair_ring": 48,
                    "render_fm_pair_block": 50.6,
                    # round 6, config 4 as default mode renders it (the modulator exact as a whole): the z^-1 pair on two waves per 64 voices — 336 f64-rate
                    # instructions per 8 samples in the modulator wave's speculative tile (the libm's 2^e: 18, the correctly rounded quotient: 4, the
-                   # sine, its fold and the two-conversion decision: 18, the phase: 2), 176 in the carrier wave's loop for config 4's class ((2^(cv/4))^4) ...
-                   "render_fm_pair_x": 64,
+                   # sine, its fold and the two-conversion decision: 18, the phase: 2), 176 + 8 in the carrier wave's loop for config 4's class ((2^(cv/4))^4; the
+                   # 8: its series at degree 9 since the minute's curve, notes/r06.md R6.12) ...
+                   "render_fm_pair_x": 65,
                    # ... and across time lanes at the app's block size: 62 per voice-sample in the chunk loop's fast copy (tools/disasm.sh) + the scan's
-                   # add and fract on a half-filled wave (4 lane-slots per voice-sample)
-                   "render_fm_pair_block_x": 66}
+                   # add and fract on a half-filled wave (4 lane-slots per voice-sample) + 1 (the carrier's series at degree 9)
+                   "render_fm_pair_block_x": 67}
 F64_LANE_OPS_MEASURED = 33.3e12
 
 WORKLOADS = ("cfg3", "cfg3_poly", "cfg2", "cfg4", "cfg4_b1024", "p3", "p4")
