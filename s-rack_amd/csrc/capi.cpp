@@ -824,14 +824,7 @@ struct BouncePool {
     std::vector<BounceSet*> idle;
     ~BouncePool()
     {   // library unload / process exit: the HIP runtime may already be gone — errors are ignored
-        for (BounceSet* b : idle) {
-            for (int k = 0; k < 2; k++) {
-                if (b->half[k]) (void)hipHostFree(b->half[k]);
-                if (b->done[k]) (void)hipEventDestroy(b->done[k]);
-            }
-            if (b->st) (void)hipStreamDestroy(b->st);
-            delete b;
-        }
+        for (BounceSet* b : idle) drop(b);
     }
     int take(int device, BounceSet** out)
     {
@@ -846,13 +839,30 @@ struct BouncePool {
         }
         BounceSet* b = new BounceSet();
         b->device = device;
-        *out = b;  // (the caller hands it back whatever happens: a half-built set is completed or freed at unload)
-        for (int k = 0; k < 2; k++) {
-            HIP_TRY_C(hipHostMalloc(&b->half[k], kBounceBytes, hipHostMallocDefault));
-            HIP_TRY_C(hipEventCreateWithFlags(&b->done[k], hipEventDisableTiming));
+        auto build = [&]() -> int {
+            for (int k = 0; k < 2; k++) {
+                HIP_TRY_C(hipHostMalloc(&b->half[k], kBounceBytes, hipHostMallocDefault));
+                HIP_TRY_C(hipEventCreateWithFlags(&b->done[k], hipEventDisableTiming));
+            }
+            HIP_TRY_C(hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking));
+            return SRACK_OK;
+        };
+        const int rc = build();
+        if (rc != SRACK_OK) {  // a half-built set never reaches the pool (the error text stays the failing call's)
+            drop(b);
+            return rc;
         }
-        HIP_TRY_C(hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking));
+        *out = b;
         return SRACK_OK;
+    }
+    static void drop(BounceSet* b)
+    {
+        for (int k = 0; k < 2; k++) {
+            if (b->half[k]) (void)hipHostFree(b->half[k]);
+            if (b->done[k]) (void)hipEventDestroy(b->done[k]);
+        }
+        if (b->st) (void)hipStreamDestroy(b->st);
+        delete b;
     }
     void give(BounceSet* b)
     {
@@ -915,8 +925,13 @@ int srack_device_to_host(void* h_dst, const void* d_src, size_t bytes, void* str
             rcs[(size_t)i] = guarded([&]() { return bounce_copy(device, (char*)h_dst + off, (const char*)d_src + off, std::min(per, bytes - off)); });
             if (rcs[(size_t)i] != SRACK_OK) errs[(size_t)i] = srack_last_error();  // (thread-local: carried back to the caller's thread below)
         };
-        for (int i = 1; i < helpers; i++) threads.emplace_back(slice, i);
+        int started = 1;  // (slice 0 is the caller's)
+        try {
+            for (; started < helpers; started++) threads.emplace_back(slice, started);
+        } catch (const std::exception&) {  // no more threads to be had: the slices without one are copied here, after the caller's own
+        }
         slice(0);
+        for (int i = started; i < helpers; i++) slice(i);
         for (std::thread& t : threads) t.join();
         for (int i = 0; i < helpers; i++)
             if (rcs[(size_t)i] != SRACK_OK) {
