@@ -2210,3 +2210,43 @@ def test_exact_mode_frames_do_not_depend_on_the_sharding(S, B):
     small = shard(16384, 8192)
     np.testing.assert_array_equal(bits(small), bits(big[:, 16384:24576]))
     assert np.abs(small).max() > 0.5
+
+
+def test_read_backs_from_several_host_threads_at_once(S):
+    """`srack_device_to_host` holds no lock across a copy since round 6 (a pool of bounce sets per device, helper threads for large copies):
+    six host threads read overlapping windows of one rendered plane at the same time — sizes on both sides of the 8 MB bounce chunk and of
+    the 64 MB helper-thread threshold — and every one of them gets the bytes a single-threaded read-back gets."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    V, T = 65536, 1280   # 320 MB of frames
+    det, cut = S.p1_voice_params(V)
+    p = S.Patch(48000, 1024, 2)
+    ids = S.build_p1(p, adsr="finite", lfo_val=0.0)   # (a gate that opens within the first milliseconds)
+    p.configure_voices(V)
+    p.set_voice_field(ids["osc_a"], S.OSC_VAL, det)
+    p.set_voice_field(ids["vcf"], S.VCF_FREQ, cut)
+    d_fr = C.c_void_p()
+    assert S.lib.srack_device_alloc(C.byref(d_fr), T * V * 4) == 0
+    try:
+        p.render_raw(T, d_fr, None, 0, None)
+        assert S.lib.srack_device_sync(None) == 0
+        whole = np.empty(T * V, dtype=np.float32)
+        assert S.lib.srack_device_to_host(whole.ctypes.data_as(C.c_void_p), d_fr, whole.nbytes, None) == 0
+        assert np.abs(whole).max() > 1e-3 and (whole != 0).mean() > 0.5
+        windows = [(0, 1 << 20), (3 << 20, 9 << 20), (1 << 20, 70 << 20), (5, 4099), (11 << 20, 80 << 20), (0, T * V * 4), (64 << 20, 200 << 20), (17, 33 << 20)]   # (byte offset, bytes)
+        windows = [(off // 4 * 4, n // 4 * 4) for off, n in windows]
+
+        def read(w):
+            off, n = w
+            out = np.empty(n // 4, dtype=np.float32)
+            rc = S.lib.srack_device_to_host(out.ctypes.data_as(C.c_void_p), C.c_void_p(d_fr.value + off), n, None)
+            return rc, out
+
+        for _ in range(2):
+            with ThreadPoolExecutor(6) as pool:
+                got = list(pool.map(read, windows))
+            for (off, n), (rc, out) in zip(windows, got):
+                assert rc == 0
+                np.testing.assert_array_equal(out, whole[off // 4:(off + n) // 4])
+    finally:
+        S.lib.srack_device_free(d_fr)
