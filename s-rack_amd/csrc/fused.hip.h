@@ -1796,7 +1796,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             double pM[kXPer];
 #pragma unroll
             for (int j = 0; j < kXPer; j++) pM[j] = buf[(i0 + (uint32_t)j) * kBlkVoices + (uint32_t)g];
-            __syncthreads();
+            // (no barrier here: a lane overwrites exactly the entries it has just read; the scan, which reads everybody's, is behind the next one)
             if (k + 1u < n_chunks) {
 #pragma unroll
                 for (int j = 0; j < kXPer; j++) buf[(i0 + (uint32_t)j) * kBlkVoices + (uint32_t)g] = dM[j];
