@@ -1463,8 +1463,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   * A workgroup of 512 threads owns 32 voices for the launch, lane (g, s) = voice g, time slice s of 16; a chunk is 64 samples, slice s
 //     holds samples [4 s, 4 s + 4).  The ring ([B][32] f32, 128 KB at the app's 1024) lives in LDS for the whole launch: HBM sees the frames.
 //   * The scan runs in the first 32 lanes of wave 0, through one [64][32] f64 buffer in LDS (increments in, phases out, in place), while
-//     all eight waves do the rest — a three-stage pipeline over chunks, three barriers per chunk:
-//         iteration k:   phases of chunk k -> registers | barrier | increments of chunk k + 1 -> buffer | barrier |
+//     all eight waves do the rest — a three-stage pipeline over chunks, two barriers per chunk:
+//         iteration k:   phases of chunk k -> registers, increments of chunk k + 1 -> buffer (a lane overwrites what it has just read) | barrier |
 //                        scan(k + 1)  ||  carrier frames of chunk k - 1, sines of chunk k (-> ring, carrier increments), increments of chunk k + 2 -> registers | barrier
 //   * The carrier behind the loop keeps the default forms of the kernel above (bounded-CV classes, prefix sum of its increments, f32
 //     sine): nothing feeds it back.  Its slice totals cross between the waves one iteration late, on the pipeline's own barriers.
