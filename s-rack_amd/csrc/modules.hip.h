@@ -176,6 +176,9 @@ SRK_DEV double exp2_fast9(double x)
     return kReduce ? __builtin_ldexp(p, (int)n) : p;
 }
 
+// (SRK_OSC_NOCOLD, below: a TIMING experiment only — tools/ab_survey_opts.sh passes it to the kernel generator's compiles through SRACK_JIT_OPTS.
+// It leaves the out-of-line repairs of the exact forms out — the results then differ from the reference's in a few samples per million — to
+// measure what the per-sample "could some lane not decide" branches cost the general path: notes/r06.md R6.17.)
 // 2^e, correctly rounded (exact render mode).  The reference evaluates `2.0_f64.powf(e)` with the host's libm, whose pow is
 // within 0.52 ulp of the true value, i.e. the correctly rounded double except for a fraction of a percent of the arguments.
 // ocml's pow / exp2 are ~1 ulp functions: 19 % of their results differ from the host's in the last bit (tools/powcheck.hip),
@@ -428,9 +431,11 @@ SRK_DEV double exp2_libm(double e)
 {
     bool cold = false;
     double y = exp2_libm_plain(e, cold);
+#ifndef SRK_OSC_NOCOLD
     if (__builtin_amdgcn_ballot_w64(cold) != 0) {
         if (cold) y = exp2_libm_special(e);
     }
+#endif
     return y;
 }
 
@@ -570,9 +575,11 @@ SRK_DEV float sine_exact(double pos)
 {
     bool cold = false;
     float r = sine_exact_plain(pos, cold);
+#ifndef SRK_OSC_NOCOLD
     if (__builtin_amdgcn_ballot_w64(cold) != 0) {
         if (cold) r = (float)sin(pos * 3.14159265358979323846 * 2.0);
     }
+#endif
     return r;
 }
 
@@ -649,9 +656,11 @@ SRK_DEV double div_rn(double a, double b)
 {
     bool cold = false;
     double out = div_rn_plain(a, b, cold);
+#ifndef SRK_OSC_NOCOLD
     if (__builtin_amdgcn_ballot_w64(cold) != 0) {
         if (cold) out = a / b;
     }
+#endif
     return out;
 }
 // An exact oscillator's sample where one of the branch-free forms could not decide (a 2^e outside pow's plain range, an increment outside
@@ -685,9 +694,11 @@ SRK_DEV void osc_step(uint32_t flags, OscRegs& s, const OscConst& c, float cv, f
         delta = div_rn_plain(440.0 * exp2_libm_plain(e, cold), c.sr, cold);
         float sn = 0.0f;
         if (flags & OSC_OUT_SINE) sn = sine_exact_plain(pos, cold);
+#ifndef SRK_OSC_NOCOLD
         if (__builtin_amdgcn_ballot_w64(cold) != 0) {
             if (cold) osc_exact_cold(e, c.sr, pos, true, delta, sn);
         }
+#endif
         if (flags & OSC_OUT_SINE) sine = sn;
         s.seen_delta = delta;
         s.seen_cv = cv;
